@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X DDP hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): DDP iterations/s (whole node), batch = 4096 cart-pole instances (nx=4, nu=1, T=100,
+fp64) per GPU.  One STEP = one batched `solve()` through the C-ABI that executes exactly --iters-per-solve
+DDP iterations (DDPSolver::procOnce, DDPSolver.hpp:143-340: linearise + regularised backward pass + line-search
+forward pass) on every instance, with termination disabled (k_rel_norm_thre = 0, cost_update_thre = -inf) and
+inputs already resident in HBM.  --iters-per-solve defaults to 8: the pre-convergence regime in which an
+iteration is nominal (1 backward + ~1 forward pass; after convergence the reference algorithm thrashes its
+line search).  value = n_gpus * K * iters / t, t = max over ranks of the wall time
+between two barrier + device-synchronise brackets.  Weak scaling: every rank owns its own 4096 instances; the
+only collective is ONE all_gather of the final trajectories (RCCL over xGMI) at the end of the timed job.
+
+The JSON line also carries
+  roofline     HBM-roofline accounting of the solve kernel: algorithmic bytes (SURVEY.md §8 d formula with the
+               measured backward / forward pass counts) / HIP-event kernel time measured on the launch stream;
+  cpu_baseline the CPU oracle ("port" of the reference's Eigen path, oracle/) timed on this host's cores on a
+               bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--iters-per-solve", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+def cpu_baseline(wl, iters_per_solve: int, target_seconds: float):
+    """Time the CPU oracle (kind "port") on a bounded sample of the same workload, all host cores."""
+    import oracle
+    cores = os.cpu_count() or 1
+    build_dir = tempfile.mkdtemp(prefix="oracle_native_")
+    cfg = oracle.default_config(max_iter=iters_per_solve, horizon_steps=wl.T, k_rel_norm_thre=0.0,
+                                cost_update_thre=-np.inf)
+
+    def run(nb, threads):
+        r = oracle.solve_batch(wl.model, cfg, wl.x0[:nb], wl.u_init[:nb], t0=wl.t0[:nb], n_threads=threads,
+                               want_gains=False, native=True, native_dir=build_dir)
+        return r.total_iters, r.seconds
+
+    probe = min(wl.B, 8 * cores)
+    it, sec = run(probe, cores)
+    rate = it / max(sec, 1e-9)  # instance-iterations / s
+    nb = int(min(wl.B, max(probe, rate * target_seconds / iters_per_solve)))
+    it, sec = run(nb, cores)
+    it1, sec1 = run(min(nb, max(8, nb // cores)), 1)
+    return {
+        "value": (it / sec) / wl.B,  # batch(4096)-iterations / s
+        "unit": "DDP iterations/s (batch=%d)" % wl.B,
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d of %d instances x %d iterations, %d threads, %.1f s; oracle/ built -O3 -march=native"
+                  % (nb, wl.B, iters_per_solve, cores, sec),
+        "instance_iterations_per_s": it / sec,
+        "instance_iterations_per_s_1core": it1 / sec1,
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch  # device memory for the inputs + torch.distributed (RCCL); imported before the HIP library
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import nmpc_amd
+    from nmpc_amd import _capi, workloads
+
+    # per-rank shard: rank r owns instances [r*B, (r+1)*B) of the global splitmix64 stream
+    wl = workloads.cartpole_batch(B=args.batch, T=args.horizon, seed=args.seed + 7919 * rank)
+    solver = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B, device=local_rank)
+    cfg = solver.config()
+    cfg.print_level = 0
+    cfg.horizon_steps = wl.T
+    cfg.max_iter = args.iters_per_solve
+    cfg.k_rel_norm_thre = 0.0
+    cfg.cost_update_thre = -np.inf
+    cfg.trace_level = 1
+
+    d_x0 = torch.from_numpy(wl.x0).to(dev)
+    d_u0 = torch.from_numpy(wl.u_init).to(dev)
+    d_t0 = torch.from_numpy(wl.t0).to(dev)
+    n_x = wl.B * (wl.T + 1) * wl.n
+    n_u = wl.B * wl.T * max(wl.m, 1)
+    d_res = torch.empty(n_x + n_u, dtype=torch.float64, device=dev)  # packed [X | U] send buffer
+    d_all = torch.empty(world * (n_x + n_u), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        solver.solveDevice(d_t0.data_ptr(), d_x0.data_ptr(), d_u0.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    solver.synchronize()
+    solver.timingStats(reset=True)
+
+    barrier()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    solver.synchronize()
+    t_solve = time.perf_counter()
+    # the one collective of the job: gather the final trajectories of every shard
+    solver.getDevice(_capi.FIELD_X, d_res.data_ptr(), n_x * 8)
+    solver.getDevice(_capi.FIELD_U, d_res.data_ptr() + n_x * 8, n_u * 8)
+    solver.synchronize()
+    if world > 1:
+        dist.all_gather_into_tensor(d_all, d_res)
+    barrier()
+    t_end = time.perf_counter()
+
+    elapsed = torch.tensor([t_end - t_begin, t_end - t_solve], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed, gather_s = float(elapsed[0]), float(elapsed[1])
+
+    n_solves, total_ms, kernel_ms = solver.timingStats()
+    tr = solver.trace()  # (B, max_iter+1, 12) of the last solve
+    iters = solver.iters()
+    rows = tr[:, 1:, :]
+    executed = rows[:, :, 0] > 0
+    n_it = int(executed.sum())
+    n_bw = float(rows[:, :, _capi.TRACE_COLUMNS.index("n_backward")][executed].sum()) / max(n_it, 1)
+    n_fw = float(rows[:, :, _capi.TRACE_COLUMNS.index("n_forward")][executed].sum()) / max(n_it, 1)
+    inst_it_per_solve = float(iters.sum())
+    status = solver.status()
+
+    if rank == 0:
+        words = workloads.algorithmic_words_per_instance_iteration(wl.n, wl.m, wl.T, n_bw, n_fw)
+        fused = workloads.fused_words_per_instance_iteration(wl.n, wl.m, wl.T, n_bw, n_fw)
+        k_ms = kernel_ms / max(n_solves, 1)
+        bytes_per_launch = words * 8.0 * inst_it_per_solve
+        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        value = world * args.steps * (inst_it_per_solve / wl.B) / elapsed
+        out = {
+            "metric": "DDP iterations/s (whole node), batch=4096, T=100",
+            "value": value,
+            "unit": "DDP iterations/s (one iteration = procOnce over a batch of %d instances per GPU)" % wl.B,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2 batched cart-pole swing-up: nx=4, nu=1, T=%d, batch=%d per GPU, fp64, "
+                            "x0~U([-1,1]x[-pi,pi]x[-1,1]x[-1,1]) splitmix64 seed %d, u_init=0, unconstrained, "
+                            "default DDPSolver::Configuration except termination disabled"
+                            % (wl.T, wl.B, args.seed),
+                "iterations_per_step": args.iters_per_solve,
+                "instance_iterations_per_step": inst_it_per_solve,
+                "backward_passes_per_iteration": n_bw,
+                "forward_passes_per_iteration": n_fw,
+                "status_counts": {str(k): int(v) for k, v in zip(*np.unique(status, return_counts=True))},
+                "lane_mapping": "one lane per instance, 64 instances per wavefront",
+                "final_gather_ms": 1e3 * gather_s,
+            },
+            "instance_iterations_per_s": value * wl.B,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "ddp_solve_tpi_kernel<DDPProblemCartPole>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms_avg": k_ms,
+                "launches_timed": int(n_solves),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "algorithmic_bytes_per_instance_iteration": words * 8.0,
+                "fused_lower_bound_bytes_per_instance_iteration": fused * 8.0,
+            },
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl, args.iters_per_solve, args.cpu_seconds)
+            except Exception as e:  # the GPU number stands on its own; say why the baseline is missing
+                out["cpu_baseline"] = {"value": None, "unit": "DDP iterations/s", "cores": os.cpu_count(),
+                                       "kind": "port", "sample": "failed: %r" % (e,)}
+        traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tf = json.load(open(traffic_file))
+                if tf.get("batch") == wl.B and tf.get("iterations_per_step") == args.iters_per_solve:
+                    out["roofline"]["traffic"] = tf.get("hbm_bytes_per_launch")
+                    out["roofline"]["traffic_source"] = tf.get("source")
+            except Exception:
+                pass
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

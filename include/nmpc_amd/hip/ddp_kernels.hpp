@@ -1,0 +1,1329 @@
+// gfx950 device code of the batched DDP solver: one persistent kernel runs the whole optimisation loop of
+// nmpc_ddp::DDPSolver::solve (/root/reference/nmpc_ddp/include/nmpc_ddp/DDPSolver.hpp:26-141) for every
+// instance of the batch; there is no host round trip per iteration and no inter-workgroup communication
+// (instances are independent, DDPSolver.h:329-374).
+//
+// LANE MAPPING "TPI" (this file): one LANE per problem instance, 64 instances per wavefront, one wavefront per
+// workgroup.  The per-instance recursion state (Vx, Vxx, Q blocks, gains) lives in VGPRs, so nothing has to be
+// exchanged between lanes and every VALU instruction does 64 instances' worth of work; all batched arrays are
+// laid out instance-minor ([...][Bp]) so that a wave's access to one scalar field of 64 neighbouring instances is
+// one contiguous 512-byte segment.  Dynamics / cost derivatives are evaluated on the fly inside the backward
+// sweep (never materialised in HBM): per instance-iteration the kernel moves T*(3n + 5m + 2mn + 1) words instead
+// of the reference's materialised T*(2D + ...).
+//
+// Arithmetic follows the reference statement by statement (cited inline); products are accumulated in ascending
+// index order; hipcc contracts a*b+c into FMA, so results differ from an x86 build in the last bits (tolerances
+// in tests/).  Discrete decisions (alpha index, retries, BoxQP sets, iteration counts, status) are taken by the
+// same comparisons as the reference.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <nmpc_amd/DDPProblem.hpp>
+#include <nmpc_hip_ddp.h>
+
+#define NMPC_D __device__ __forceinline__
+
+namespace nmpc_amd
+{
+namespace hip
+{
+constexpr int kMaxInputDim = 16; //!< capacity of the constant input-limit arrays passed by value
+constexpr int kLanesPerBlock = 64; //!< one wavefront per workgroup
+
+/** Device pointers of one solver handle.  Bp = batch rounded up to a multiple of 64; every array is
+    instance-minor: element (..., b) of a field sits at [...]*Bp + b. */
+struct DeviceBuffers
+{
+  int B; //!< number of valid instances
+  int Bp; //!< padded batch (leading stride of every array)
+  int T; //!< horizon_steps
+  int trace_rows; //!< allocated trace rows (max_iter+1 if trace_level >= 1, else 1)
+  const double * t0; //!< [Bp]
+  const double * x0; //!< [N][Bp]
+  double * X; //!< [2][T+1][N][Bp]   current / candidate state sequences (x_list)
+  double * U; //!< [2][T][MM][Bp]    current / candidate input sequences (u_list); U[0] holds u_init on entry
+  double * cost; //!< [2][T+1][Bp]   current / candidate cost sequences (cost_list)
+  double * kff; //!< [T][MM][Bp]       k_list_
+  double * Kfb; //!< [T][N*MM][Bp]     K_list_ (element a + c*MM of the m x N gain)
+  double * trace; //!< [trace_rows][NMPC_HIP_NTRACE][Bp]
+  double * trace_last; //!< [NMPC_HIP_NTRACE][Bp]
+  double * dV; //!< [2][Bp]
+  int * status; //!< [Bp]
+  int * iters; //!< [Bp]
+  int * sel; //!< [Bp]  which half of X/U/cost holds control_data_ after the solve
+  int * qp_ret; //!< [T][Bp]  (constrained solves only)
+  unsigned * qp_free; //!< [T][Bp]
+  int * input_dim; //!< [T][Bp]
+  double lim_lo[kMaxInputDim]; //!< input lower limits (constant in time)
+  double lim_hi[kMaxInputDim]; //!< input upper limits
+};
+
+namespace detail
+{
+/** Unroll factor for the small dense loops: full unrolling keeps the per-instance blocks in VGPRs for the
+    small problems; large problems (n >= 9) loop instead (their blocks then live in scratch; the LDS-staged
+    wave-per-instance mapping for those shapes is the planned replacement). */
+template<int N, int MM>
+struct Unroll
+{
+  static constexpr bool kFull = (N * N * (N + MM) <= 160);
+  static constexpr int kFactor = kFull ? 64 : 1;
+};
+} // namespace detail
+
+/** One DDP problem instance, executed by one lane. */
+template<class Problem>
+struct InstanceSolver
+{
+  static constexpr int N = Problem::kStateDim;
+  static constexpr int M = Problem::kInputDimMax;
+  static constexpr int MM = (M > 0) ? M : 1;
+  static constexpr bool kDyn = Problem::kDynamicInput;
+  static constexpr int kU = detail::Unroll<N, MM>::kFactor;
+  static_assert(M <= kMaxInputDim, "input dimension capacity exceeded");
+
+  using StateDimVector = typename Problem::StateDimVector;
+  using InputDimVector = typename Problem::InputDimVector;
+  using StateStateDimMatrix = typename Problem::StateStateDimMatrix;
+  using InputInputDimMatrix = typename Problem::InputInputDimMatrix;
+  using StateInputDimMatrix = typename Problem::StateInputDimMatrix;
+
+  const Problem & problem;
+  const nmpc_hip_ddp_config & cfg;
+  const DeviceBuffers & buf;
+  const int b; //!< instance index = global lane index
+  const int T;
+  const size_t Bp;
+
+  double current_t;
+  double lambda;
+  double dlambda;
+  double dV0, dV1;
+  double k_rel_norm;
+  double J_cur; //!< control_data_.cost_list.sum()
+  double J_cand; //!< candidate_control_data_.cost_list.sum()
+  int sel; //!< half of X/U/cost that is control_data_; 1-sel is candidate_control_data_
+
+  NMPC_D InstanceSolver(const Problem & p, const nmpc_hip_ddp_config & c, const DeviceBuffers & bf, int lane)
+  : problem(p), cfg(c), buf(bf), b(lane), T(bf.T), Bp(static_cast<size_t>(bf.Bp))
+  {
+  }
+
+  // ---- addressing (instance-minor) ----
+  NMPC_D double * xPtr(int s, int i) const
+  {
+    return buf.X + ((static_cast<size_t>(s) * (T + 1) + i) * N) * Bp + b;
+  }
+  NMPC_D double * uPtr(int s, int i) const
+  {
+    return buf.U + ((static_cast<size_t>(s) * T + i) * MM) * Bp + b;
+  }
+  NMPC_D double * costPtr(int s, int i) const
+  {
+    return buf.cost + (static_cast<size_t>(s) * (T + 1) + i) * Bp + b;
+  }
+  NMPC_D double * kPtr(int i) const
+  {
+    return buf.kff + (static_cast<size_t>(i) * MM) * Bp + b;
+  }
+  NMPC_D double * KPtr(int i) const
+  {
+    return buf.Kfb + (static_cast<size_t>(i) * (N * MM)) * Bp + b;
+  }
+
+  NMPC_D int inputDimAt(double t) const
+  {
+    if constexpr(kDyn)
+    {
+      return problem.inputDim(t);
+    }
+    else
+    {
+      return M;
+    }
+  }
+
+  NMPC_D void loadX(const double * p, StateDimVector & x) const
+  {
+#pragma unroll
+    for(int j = 0; j < N; j++)
+    {
+      x[j] = p[j * Bp];
+    }
+  }
+  NMPC_D void storeX(double * p, const StateDimVector & x) const
+  {
+#pragma unroll
+    for(int j = 0; j < N; j++)
+    {
+      p[j * Bp] = x[j];
+    }
+  }
+  NMPC_D void loadU(const double * p, InputDimVector & u, int m) const
+  {
+    u.resize(m);
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      u[a] = (a < m) ? p[a * Bp] : 0.0;
+    }
+  }
+  NMPC_D void storeU(double * p, const InputDimVector & u, int m) const
+  {
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      p[a * Bp] = (a < m) ? u[a] : 0.0;
+    }
+  }
+
+  // -------------------------------------------------------------------------------------------------
+  // initial rollout    DDPSolver.hpp:83-95
+  // -------------------------------------------------------------------------------------------------
+  NMPC_D void initialRollout()
+  {
+    StateDimVector x;
+    loadX(buf.x0 + b, x);
+    storeX(xPtr(sel, 0), x);
+    double J = 0;
+    for(int i = 0; i < T; i++)
+    {
+      const double t = current_t + i * problem.dt();
+      const int m = inputDimAt(t);
+      buf.input_dim[static_cast<size_t>(i) * Bp + b] = m;
+      InputDimVector u;
+      loadU(uPtr(sel, i), u, m);
+      storeU(uPtr(sel, i), u, m); // zero the padding beyond inputDim(t)
+      const StateDimVector xn = problem.stateEq(t, x, u);
+      const double c = problem.runningCost(t, x, u);
+      *costPtr(sel, i) = c;
+      J += c;
+      storeX(xPtr(sel, i + 1), xn);
+      x = xn;
+    }
+    const double terminal_t = current_t + T * problem.dt();
+    const double cT = problem.terminalCost(terminal_t, x);
+    *costPtr(sel, T) = cT;
+    J += cT;
+    J_cur = J;
+  }
+
+  // -------------------------------------------------------------------------------------------------
+  // dense helpers on per-lane arrays (column-major)
+  // -------------------------------------------------------------------------------------------------
+  /** Unblocked lower Cholesky in place, leading dimension LD; fails (returns false) iff a pivot is <= 0
+      (a NaN pivot passes), as Eigen::LLT does (DDPSolver.hpp:500-508, BoxQP.h:229-238). */
+  template<int LD>
+  NMPC_D static bool lltInPlace(double * A, int n)
+  {
+    bool ok = true;
+#pragma unroll kU
+    for(int k = 0; k < LD; k++)
+    {
+      if(k < n && ok)
+      {
+        double x = A[k + k * LD];
+#pragma unroll kU
+        for(int j = 0; j < LD; j++)
+        {
+          if(j < k)
+          {
+            x -= A[k + j * LD] * A[k + j * LD];
+          }
+        }
+        if(x <= 0)
+        {
+          ok = false;
+        }
+        else
+        {
+          x = sqrt(x);
+          A[k + k * LD] = x;
+#pragma unroll kU
+          for(int i = 0; i < LD; i++)
+          {
+            if(i > k && i < n)
+            {
+              double s = A[i + k * LD];
+#pragma unroll kU
+              for(int j = 0; j < LD; j++)
+              {
+                if(j < k)
+                {
+                  s -= A[i + j * LD] * A[k + j * LD];
+                }
+              }
+              A[i + k * LD] = s / x;
+            }
+          }
+        }
+      }
+    }
+    return ok;
+  }
+
+  /** Solve L L^T x = rhs in place for one right-hand side with element stride RS. */
+  template<int LD, int RS>
+  NMPC_D static void lltSolveInPlace(const double * L, int n, double * rhs)
+  {
+#pragma unroll kU
+    for(int i = 0; i < LD; i++)
+    {
+      if(i < n)
+      {
+        double s = rhs[i * RS];
+#pragma unroll kU
+        for(int j = 0; j < LD; j++)
+        {
+          if(j < i)
+          {
+            s -= L[i + j * LD] * rhs[j * RS];
+          }
+        }
+        rhs[i * RS] = s / L[i + i * LD];
+      }
+    }
+#pragma unroll kU
+    for(int ii = 0; ii < LD; ii++)
+    {
+      const int i = LD - 1 - ii;
+      if(i < n)
+      {
+        double s = rhs[i * RS];
+#pragma unroll kU
+        for(int j = 0; j < LD; j++)
+        {
+          if(j > i && j < n)
+          {
+            s -= L[j + i * LD] * rhs[j * RS];
+          }
+        }
+        rhs[i * RS] = s / L[i + i * LD];
+      }
+    }
+  }
+
+  // -------------------------------------------------------------------------------------------------
+  // BoxQP::solve    BoxQP.h:141-347   (H, llt: leading dimension MM)
+  // -------------------------------------------------------------------------------------------------
+  struct QPOut
+  {
+    double x[MM];
+    double llt_free[MM * MM]; //!< lower factor of H[free, free], leading dimension MM
+    int free_idx[MM];
+    int n_free;
+    int retval;
+  };
+
+  NMPC_D static double qpObjective(int m, const double * H, const double * g, const double * x)
+  {
+    double xg = 0;
+#pragma unroll kU
+    for(int i = 0; i < MM; i++)
+    {
+      if(i < m)
+      {
+        xg += x[i] * g[i];
+      }
+    }
+    double xHx = 0;
+#pragma unroll kU
+    for(int i = 0; i < MM; i++)
+    {
+      if(i < m)
+      {
+        double hx = 0;
+#pragma unroll kU
+        for(int j = 0; j < MM; j++)
+        {
+          if(j < m)
+          {
+            hx += H[i + j * MM] * x[j];
+          }
+        }
+        xHx += x[i] * hx;
+      }
+    }
+    return xg + 0.5 * xHx;
+  }
+
+  NMPC_D void boxQP(int m,
+                    const double * H,
+                    const double * g,
+                    const double * lower,
+                    const double * upper,
+                    const double * initial_x,
+                    QPOut & out) const
+  {
+    double * x = out.x;
+#pragma unroll kU
+    for(int i = 0; i < MM; i++)
+    {
+      x[i] = (i < m) ? fmax(fmin(initial_x[i], upper[i]), lower[i]) : 0.0; // BoxQP.h:148
+    }
+    double obj = qpObjective(m, H, g, x);
+    double old_obj = obj;
+    out.retval = 0;
+    out.n_free = 0;
+    double grad[MM];
+    unsigned clamped = 0, old_clamped = 0;
+    double search_dir[MM], x_cand[MM], rhs[MM];
+    for(int iter = 1;; iter++)
+    {
+      // relative improvement    BoxQP.h:176-181
+      if(iter > 1 && (old_obj - obj) < cfg.qp_rel_improve_thre * fabs(old_obj))
+      {
+        out.retval = 4;
+        break;
+      }
+      old_obj = obj;
+
+      // gradient    BoxQP.h:184
+#pragma unroll kU
+      for(int i = 0; i < MM; i++)
+      {
+        if(i < m)
+        {
+          double hx = 0;
+#pragma unroll kU
+          for(int j = 0; j < MM; j++)
+          {
+            if(j < m)
+            {
+              hx += H[i + j * MM] * x[j];
+            }
+          }
+          grad[i] = g[i] + hx;
+        }
+      }
+
+      // clamped / free sets (exact == compare)    BoxQP.h:187-213
+      old_clamped = clamped;
+      clamped = 0;
+      int nf = 0;
+#pragma unroll kU
+      for(int i = 0; i < MM; i++)
+      {
+        if(i < m)
+        {
+          const bool c = (x[i] == lower[i] && grad[i] > 0) || (x[i] == upper[i] && grad[i] < 0);
+          if(c)
+          {
+            clamped |= (1u << i);
+          }
+          else
+          {
+            out.free_idx[nf] = i;
+            nf++;
+          }
+        }
+      }
+      out.n_free = nf;
+      if(nf == 0)
+      {
+        out.retval = 6;
+        break;
+      }
+
+      // factorise the free block iff the clamped set changed    BoxQP.h:216-241
+      if(iter == 1 || clamped != old_clamped)
+      {
+        for(int i = 0; i < nf; i++)
+        {
+          for(int j = 0; j < nf; j++)
+          {
+            out.llt_free[i + j * MM] = H[out.free_idx[i] + out.free_idx[j] * MM];
+          }
+        }
+        if(!lltInPlace<MM>(out.llt_free, nf))
+        {
+          out.retval = -1;
+          break;
+        }
+      }
+
+      // free gradient norm    BoxQP.h:244-253
+      double grad_norm = 0;
+      for(int i = 0; i < nf; i++)
+      {
+        grad_norm += grad[out.free_idx[i]] * grad[out.free_idx[i]];
+      }
+      if(grad_norm < cfg.qp_grad_thre * cfg.qp_grad_thre)
+      {
+        out.retval = 5;
+        break;
+      }
+
+      // Newton direction on the free dimensions    BoxQP.h:256-279
+      for(int i = 0; i < nf; i++)
+      {
+        double s = 0;
+#pragma unroll kU
+        for(int j = 0; j < MM; j++)
+        {
+          if(j < m && ((clamped >> j) & 1u))
+          {
+            s += H[out.free_idx[i] + j * MM] * x[j];
+          }
+        }
+        rhs[i] = g[out.free_idx[i]] + s;
+      }
+      lltSolveInPlace<MM, 1>(out.llt_free, nf, rhs);
+#pragma unroll kU
+      for(int i = 0; i < MM; i++)
+      {
+        search_dir[i] = 0;
+      }
+      for(int i = 0; i < nf; i++)
+      {
+        search_dir[out.free_idx[i]] = -1 * rhs[i] - x[out.free_idx[i]];
+      }
+
+      // descent check    BoxQP.h:282-291
+      double sdg = 0;
+#pragma unroll kU
+      for(int i = 0; i < MM; i++)
+      {
+        if(i < m)
+        {
+          sdg += search_dir[i] * grad[i];
+        }
+      }
+      if(sdg > 1e-10)
+      {
+        out.retval = -2;
+        break;
+      }
+
+      // Armijo line search with projection    BoxQP.h:294-309
+      double step = 1;
+#pragma unroll kU
+      for(int i = 0; i < MM; i++)
+      {
+        x_cand[i] = (i < m) ? fmax(fmin(x[i] + step * search_dir[i], upper[i]), lower[i]) : 0.0;
+      }
+      double obj_cand = qpObjective(m, H, g, x_cand);
+      while((obj_cand - old_obj) / (step * sdg) < cfg.qp_armijo_param)
+      {
+        step = step * cfg.qp_step_factor;
+#pragma unroll kU
+        for(int i = 0; i < MM; i++)
+        {
+          x_cand[i] = (i < m) ? fmax(fmin(x[i] + step * search_dir[i], upper[i]), lower[i]) : 0.0;
+        }
+        obj_cand = qpObjective(m, H, g, x_cand);
+        if(step < cfg.qp_min_step)
+        {
+          out.retval = 2; // leaves only the inner loop (BoxQP.h:304-308)
+          break;
+        }
+      }
+
+      // accept    BoxQP.h:328-329
+#pragma unroll kU
+      for(int i = 0; i < MM; i++)
+      {
+        x[i] = x_cand[i];
+      }
+      obj = obj_cand;
+      if(iter == cfg.qp_max_iter)
+      {
+        out.retval = 1; // BoxQP.h:332-336
+        break;
+      }
+    }
+  }
+
+  // -------------------------------------------------------------------------------------------------
+  // backward pass    DDPSolver.hpp:342-534, with the linearisation of :160-180 evaluated on the fly
+  // -------------------------------------------------------------------------------------------------
+  NMPC_D bool backwardPass()
+  {
+    double Vx[N], Vxx[N * N];
+    {
+      // calcTerminalCostDeriv at x[T]    :179-180, :346-347
+      StateDimVector xT, vx;
+      StateStateDimMatrix vxx;
+      loadX(xPtr(sel, T), xT);
+      problem.calcTerminalCostDeriv(current_t + T * problem.dt(), xT, vx, vxx);
+#pragma unroll kU
+      for(int j = 0; j < N; j++)
+      {
+        Vx[j] = vx[j];
+      }
+#pragma unroll kU
+      for(int e = 0; e < N * N; e++)
+      {
+        Vxx[e] = vxx.data()[e];
+      }
+    }
+    dV0 = 0;
+    dV1 = 0;
+    k_rel_norm = 0;
+    bool ok = true;
+    double k_next[MM]; // k_list_[i+1] (BoxQP warm start)
+    int m_next = -1;
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      k_next[a] = 0;
+    }
+
+    for(int i = T - 1; i >= 0 && ok; i--)
+    {
+      const double t = current_t + i * problem.dt();
+      const int m = inputDimAt(t);
+
+      // ---- Step 1 of procOnce for this timestep: derivatives at (x_i, u_i)    :160-178
+      StateDimVector x;
+      InputDimVector u;
+      loadX(xPtr(sel, i), x);
+      loadU(uPtr(sel, i), u, m);
+      StateStateDimMatrix Fx, Lxx;
+      StateInputDimMatrix Fu, Lxu;
+      StateDimVector Lx;
+      InputDimVector Lu;
+      InputInputDimMatrix Luu;
+      Fu.resize(N, m);
+      Lxu.resize(N, m);
+      Lu.resize(m);
+      Luu.resize(m, m);
+      problem.calcStateEqDeriv(t, x, u, Fx, Fu);
+      problem.calcRunningCostDeriv(t, x, u, Lx, Lu, Lxx, Luu, Lxu);
+
+      // ---- Q terms    :386-408  (products left to right through a temporary)
+      double Qu[MM], Qx[N], Qux[MM * N], Quu[MM * MM], Qxx[N * N];
+      double FuT_V[MM * N]; // Fu^T Vxx   (m x N, ld MM)
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        if(a < m)
+        {
+          double s = 0;
+#pragma unroll kU
+          for(int r = 0; r < N; r++)
+          {
+            s += Fu(r, a) * Vx[r];
+          }
+          Qu[a] = Lu[a] + s;
+        }
+      }
+#pragma unroll kU
+      for(int a = 0; a < N; a++)
+      {
+        double s = 0;
+#pragma unroll kU
+        for(int r = 0; r < N; r++)
+        {
+          s += Fx(r, a) * Vx[r];
+        }
+        Qx[a] = Lx[a] + s;
+      }
+#pragma unroll kU
+      for(int c = 0; c < N; c++)
+      {
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
+          {
+            double s = 0;
+#pragma unroll kU
+            for(int r = 0; r < N; r++)
+            {
+              s += Fu(r, a) * Vxx[r + c * N];
+            }
+            FuT_V[a + c * MM] = s;
+          }
+        }
+      }
+#pragma unroll kU
+      for(int c = 0; c < N; c++)
+      {
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
+          {
+            double s = 0;
+#pragma unroll kU
+            for(int r = 0; r < N; r++)
+            {
+              s += FuT_V[a + r * MM] * Fx(r, c);
+            }
+            Qux[a + c * MM] = Lxu(c, a) + s;
+          }
+        }
+      }
+#pragma unroll kU
+      for(int bb = 0; bb < MM; bb++)
+      {
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m && bb < m)
+          {
+            double s = 0;
+#pragma unroll kU
+            for(int r = 0; r < N; r++)
+            {
+              s += FuT_V[a + r * MM] * Fu(r, bb);
+            }
+            Quu[a + bb * MM] = Luu(a, bb) + s;
+          }
+        }
+      }
+      {
+        double FxT_V[N * N]; // Fx^T Vxx
+#pragma unroll kU
+        for(int c = 0; c < N; c++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < N; a++)
+          {
+            double s = 0;
+#pragma unroll kU
+            for(int r = 0; r < N; r++)
+            {
+              s += Fx(r, a) * Vxx[r + c * N];
+            }
+            FxT_V[a + c * N] = s;
+          }
+        }
+#pragma unroll kU
+        for(int c = 0; c < N; c++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < N; a++)
+          {
+            double s = 0;
+#pragma unroll kU
+            for(int r = 0; r < N; r++)
+            {
+              s += FxT_V[a + r * N] * Fx(r, c);
+            }
+            Qxx[a + c * N] = Lxx(a, c) + s;
+          }
+        }
+      }
+
+      // ---- regularisation    :421-441
+      double Qux_reg[MM * N], Quu_F[MM * MM];
+      if(cfg.reg_type == 2)
+      {
+        // Vxx_reg = Vxx + lambda I: Fu^T Vxx_reg = Fu^T Vxx with lambda * Fu^T added entrywise before the sum
+        // is NOT what the reference does; recompute the products from Vxx_reg as written there.
+#pragma unroll kU
+        for(int c = 0; c < N; c++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            if(a < m)
+            {
+              double s = 0;
+#pragma unroll kU
+              for(int r = 0; r < N; r++)
+              {
+                const double v = (r == c) ? (Vxx[r + c * N] + lambda) : Vxx[r + c * N];
+                s += Fu(r, a) * v;
+              }
+              FuT_V[a + c * MM] = s;
+            }
+          }
+        }
+#pragma unroll kU
+        for(int c = 0; c < N; c++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            if(a < m)
+            {
+              double s = 0;
+#pragma unroll kU
+              for(int r = 0; r < N; r++)
+              {
+                s += FuT_V[a + r * MM] * Fx(r, c);
+              }
+              Qux_reg[a + c * MM] = Lxu(c, a) + s;
+            }
+          }
+        }
+#pragma unroll kU
+        for(int bb = 0; bb < MM; bb++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            if(a < m && bb < m)
+            {
+              double s = 0;
+#pragma unroll kU
+              for(int r = 0; r < N; r++)
+              {
+                s += FuT_V[a + r * MM] * Fu(r, bb);
+              }
+              Quu_F[a + bb * MM] = Luu(a, bb) + s;
+            }
+          }
+        }
+      }
+      else
+      {
+        // reg_type 1: Vxx_reg == Vxx, so Qux_reg and the product part of Quu_F are the very same
+        // floating-point expressions as Qux / Quu (:427,:433 vs :390,:399); then Quu_F.diagonal() += lambda (:438-441)
+#pragma unroll kU
+        for(int e = 0; e < MM * N; e++)
+        {
+          Qux_reg[e] = Qux[e];
+        }
+#pragma unroll kU
+        for(int bb = 0; bb < MM; bb++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            Quu_F[a + bb * MM] = (a == bb && cfg.reg_type == 1) ? (Quu[a + bb * MM] + lambda) : Quu[a + bb * MM];
+          }
+        }
+      }
+
+      // ---- gains    :448-517
+      double k[MM], K[MM * N];
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        k[a] = 0;
+      }
+#pragma unroll kU
+      for(int e = 0; e < MM * N; e++)
+      {
+        K[e] = 0;
+      }
+      if(m > 0)
+      {
+        if(cfg.with_input_constraint)
+        {
+          double initial_k[MM], lo[MM], up[MM];
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            // warm start from k_list_[i+1] when its size matches    :452-467
+            initial_k[a] = (i != T - 1 && m_next == m) ? k_next[a] : 0.0;
+            lo[a] = buf.lim_lo[a] - u[a]; // :470-472
+            up[a] = buf.lim_hi[a] - u[a];
+          }
+          QPOut qp;
+          boxQP(m, Quu_F, Qu, lo, up, initial_k, qp);
+          unsigned free_mask = 0;
+          for(int j = 0; j < qp.n_free; j++)
+          {
+            free_mask |= (1u << qp.free_idx[j]);
+          }
+          buf.qp_ret[static_cast<size_t>(i) * Bp + b] = qp.retval;
+          buf.qp_free[static_cast<size_t>(i) * Bp + b] = free_mask;
+          if(qp.retval < 0)
+          {
+            ok = false; // :473-480
+          }
+          else
+          {
+#pragma unroll kU
+            for(int a = 0; a < MM; a++)
+            {
+              k[a] = qp.x[a];
+            }
+            // K rows in free_idxs_ = -llt_free.solve(Qux_reg[free, :]), clamped rows 0    :482-496
+            if(qp.n_free > 0)
+            {
+              for(int c = 0; c < N; c++)
+              {
+                double col[MM];
+                for(int j = 0; j < qp.n_free; j++)
+                {
+                  col[j] = Qux_reg[qp.free_idx[j] + c * MM];
+                }
+                lltSolveInPlace<MM, 1>(qp.llt_free, qp.n_free, col);
+                for(int j = 0; j < qp.n_free; j++)
+                {
+                  K[qp.free_idx[j] + c * MM] = -1 * col[j];
+                }
+              }
+            }
+          }
+        }
+        else
+        {
+          // LLT(Quu_F); k = -solve(Qu); K = -solve(Qux_reg)    :500-510
+          double L[MM * MM];
+#pragma unroll kU
+          for(int e = 0; e < MM * MM; e++)
+          {
+            L[e] = Quu_F[e];
+          }
+          if(!lltInPlace<MM>(L, m))
+          {
+            ok = false;
+          }
+          else
+          {
+#pragma unroll kU
+            for(int a = 0; a < MM; a++)
+            {
+              k[a] = Qu[a];
+            }
+            lltSolveInPlace<MM, 1>(L, m, k);
+#pragma unroll kU
+            for(int a = 0; a < MM; a++)
+            {
+              k[a] = -1 * k[a];
+            }
+#pragma unroll kU
+            for(int c = 0; c < N; c++)
+            {
+#pragma unroll kU
+              for(int a = 0; a < MM; a++)
+              {
+                K[a + c * MM] = Qux_reg[a + c * MM];
+              }
+              lltSolveInPlace<MM, 1>(L, m, &K[c * MM]);
+#pragma unroll kU
+              for(int a = 0; a < MM; a++)
+              {
+                K[a + c * MM] = -1 * K[a + c * MM];
+              }
+            }
+          }
+        }
+      }
+      if(!ok)
+      {
+        break;
+      }
+
+      // ---- cost-to-go update with the UNregularised Quu / Qux    :522-526
+      {
+        double kQu = 0, kQuuk = 0;
+        double Quu_k[MM];
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
+          {
+            kQu += k[a] * Qu[a];
+            double s = 0;
+#pragma unroll kU
+            for(int bb = 0; bb < MM; bb++)
+            {
+              if(bb < m)
+              {
+                s += Quu[a + bb * MM] * k[bb];
+              }
+            }
+            Quu_k[a] = s;
+          }
+        }
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
+          {
+            kQuuk += k[a] * Quu_k[a];
+          }
+        }
+        dV0 += kQu;
+        dV1 += 0.5 * kQuuk;
+      }
+      double KtQuu[N * MM]; // K^T Quu   (N x m, ld N)
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+#pragma unroll kU
+        for(int r = 0; r < N; r++)
+        {
+          double s = 0;
+#pragma unroll kU
+          for(int p = 0; p < MM; p++)
+          {
+            if(p < m && a < m)
+            {
+              s += K[p + r * MM] * Quu[p + a * MM];
+            }
+          }
+          KtQuu[r + a * N] = s;
+        }
+      }
+      double Vxx_new[N * N];
+#pragma unroll kU
+      for(int r = 0; r < N; r++)
+      {
+        double s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
+          {
+            s1 += KtQuu[r + a * N] * k[a];
+            s2 += K[a + r * MM] * Qu[a];
+            s3 += Qux[a + r * MM] * k[a];
+          }
+        }
+        Vx[r] = ((Qx[r] + s1) + s2) + s3;
+      }
+#pragma unroll kU
+      for(int c = 0; c < N; c++)
+      {
+#pragma unroll kU
+        for(int r = 0; r < N; r++)
+        {
+          double s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            if(a < m)
+            {
+              s1 += KtQuu[r + a * N] * K[a + c * MM];
+              s2 += K[a + r * MM] * Qux[a + c * MM];
+              s3 += Qux[a + r * MM] * K[a + c * MM];
+            }
+          }
+          Vxx_new[r + c * N] = ((Qxx[r + c * N] + s1) + s2) + s3;
+        }
+      }
+#pragma unroll kU
+      for(int c = 0; c < N; c++)
+      {
+#pragma unroll kU
+        for(int r = 0; r < N; r++)
+        {
+          Vxx[r + c * N] = 0.5 * (Vxx_new[r + c * N] + Vxx_new[c + r * N]);
+        }
+      }
+
+      // ---- save gains    :529-530, and the running max of |k_i| / (|u_i| + 1)    :217-221
+      {
+        double * kp = kPtr(i);
+        double * Kp = KPtr(i);
+        double kn = 0, un = 0;
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          kp[a * Bp] = k[a];
+          k_next[a] = k[a];
+          if(a < m)
+          {
+            kn += k[a] * k[a];
+            un += u[a] * u[a];
+          }
+        }
+#pragma unroll kU
+        for(int e = 0; e < MM * N; e++)
+        {
+          Kp[e * Bp] = K[e];
+        }
+        m_next = m;
+        k_rel_norm = fmax(k_rel_norm, sqrt(kn) / (sqrt(un) + 1.0));
+      }
+    }
+    return ok;
+  }
+
+  // -------------------------------------------------------------------------------------------------
+  // forward pass    DDPSolver.hpp:536-560
+  // -------------------------------------------------------------------------------------------------
+  NMPC_D void forwardPass(double alpha)
+  {
+    const int cs = 1 - sel;
+    StateDimVector xc;
+    loadX(xPtr(sel, 0), xc);
+    storeX(xPtr(cs, 0), xc);
+    double J = 0;
+    for(int i = 0; i < T; i++)
+    {
+      const double t = current_t + i * problem.dt();
+      const int m = inputDimAt(t);
+      StateDimVector x;
+      InputDimVector u, uc;
+      loadX(xPtr(sel, i), x);
+      loadU(uPtr(sel, i), u, m);
+      uc.resize(m);
+      const double * kp = kPtr(i);
+      const double * Kp = KPtr(i);
+      // u' = u + alpha k + K (x' - x)    :545-546
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        if(a < m)
+        {
+          double s = 0;
+#pragma unroll kU
+          for(int c = 0; c < N; c++)
+          {
+            s += Kp[(a + c * MM) * Bp] * (xc[c] - x[c]);
+          }
+          uc[a] = (u[a] + alpha * kp[a * Bp]) + s;
+        }
+        else
+        {
+          uc[a] = 0;
+        }
+      }
+      storeU(uPtr(cs, i), uc, m);
+      const StateDimVector xn = problem.stateEq(t, xc, uc);
+      const double c = problem.runningCost(t, xc, uc);
+      *costPtr(cs, i) = c;
+      J += c;
+      storeX(xPtr(cs, i + 1), xn);
+      xc = xn;
+    }
+    const double cT = problem.terminalCost(current_t + T * problem.dt(), xc);
+    *costPtr(cs, T) = cT;
+    J += cT;
+    J_cand = J;
+  }
+
+  // -------------------------------------------------------------------------------------------------
+  // solve = setup + optimisation loop    DDPSolver.hpp:26-141, procOnce :143-340
+  // -------------------------------------------------------------------------------------------------
+  NMPC_D void writeTraceRow(int row, const double * tr) const
+  {
+    if(buf.trace_rows > 1 && row < buf.trace_rows)
+    {
+      double * p = buf.trace + (static_cast<size_t>(row) * NMPC_HIP_NTRACE) * Bp + b;
+#pragma unroll
+      for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+      {
+        p[f * Bp] = tr[f];
+      }
+    }
+  }
+
+  NMPC_D void solve()
+  {
+    current_t = buf.t0 ? buf.t0[b] : 0.0;
+    lambda = cfg.initial_lambda; // :37
+    dlambda = cfg.initial_dlambda; // :38
+    sel = 0;
+    dV0 = dV1 = 0;
+    k_rel_norm = 0;
+    J_cand = 0;
+    initialRollout();
+
+    double tr[NMPC_HIP_NTRACE];
+#pragma unroll
+    for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+    {
+      tr[f] = 0;
+    }
+    // trace[0]    :98-104
+    tr[NMPC_HIP_TRACE_COST] = J_cur;
+    tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
+    tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
+    tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
+    writeTraceRow(0, tr);
+
+    int retval = 0;
+    int iter = 0;
+    for(iter = 1; iter <= cfg.max_iter; iter++)
+    {
+#pragma unroll
+      for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+      {
+        tr[f] = 0;
+      }
+      tr[NMPC_HIP_TRACE_ITER] = iter;
+      tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
+      retval = 0;
+
+      // Step 2 (with Step 1 fused in): backward pass with regularisation retries    :188-214
+      int n_backward = 1;
+      bool bw_failed = false;
+      while(!backwardPass())
+      {
+        dlambda = fmax(dlambda * cfg.lambda_factor, cfg.lambda_factor);
+        lambda = fmax(lambda * dlambda, cfg.lambda_min);
+        if(lambda > cfg.lambda_max)
+        {
+          bw_failed = true;
+          break;
+        }
+        n_backward++;
+      }
+      tr[NMPC_HIP_TRACE_N_BACKWARD] = n_backward;
+      if(bw_failed)
+      {
+        retval = -1; // :196-204
+      }
+      else
+      {
+        tr[NMPC_HIP_TRACE_K_REL_NORM] = k_rel_norm;
+        if(k_rel_norm < cfg.k_rel_norm_thre && lambda < cfg.lambda_thre)
+        {
+          retval = 1; // :223-231
+        }
+        else
+        {
+          // Step 3: backtracking line search    :234-274
+          bool forward_pass_success = false;
+          double alpha = 0, cost_update_actual = 0, cost_update_expected = 0, cost_update_ratio = 0;
+          int ai = 0;
+          for(ai = 0; ai < cfg.n_alpha; ai++)
+          {
+            alpha = cfg.alpha_list[ai];
+            forwardPass(alpha);
+            cost_update_actual = J_cur - J_cand;
+            cost_update_expected = -1 * alpha * (dV0 + alpha * dV1);
+            cost_update_ratio = cost_update_actual / cost_update_expected;
+            if(cost_update_expected < 0)
+            {
+              cost_update_ratio = (cost_update_actual >= 0 ? 1 : -1); // :251-259
+            }
+            if(cost_update_ratio > cfg.cost_update_ratio_thre)
+            {
+              forward_pass_success = true;
+              break;
+            }
+          }
+          tr[NMPC_HIP_TRACE_ALPHA] = alpha;
+          tr[NMPC_HIP_TRACE_COST_UPDATE_ACTUAL] = cost_update_actual;
+          tr[NMPC_HIP_TRACE_COST_UPDATE_EXPECTED] = cost_update_expected;
+          tr[NMPC_HIP_TRACE_COST_UPDATE_RATIO] = cost_update_ratio;
+          tr[NMPC_HIP_TRACE_ALPHA_IDX] = forward_pass_success ? ai : cfg.n_alpha - 1;
+          tr[NMPC_HIP_TRACE_N_FORWARD] = forward_pass_success ? ai + 1 : cfg.n_alpha;
+
+          // Step 4: accept (swap halves instead of copying, :285-287) or reject    :280-333
+          if(forward_pass_success)
+          {
+            sel = 1 - sel;
+            J_cur = J_cand;
+            if(cost_update_actual < cfg.cost_update_thre)
+            {
+              retval = 1;
+            }
+            dlambda = fmin(dlambda / cfg.lambda_factor, 1 / cfg.lambda_factor);
+            if(lambda >= cfg.lambda_min)
+            {
+              lambda *= dlambda;
+            }
+            else
+            {
+              lambda = 0;
+            }
+          }
+          else
+          {
+            dlambda = fmax(dlambda * cfg.lambda_factor, cfg.lambda_factor);
+            lambda = fmax(lambda * dlambda, cfg.lambda_min);
+            if(lambda > cfg.lambda_max)
+            {
+              retval = -1;
+            }
+          }
+          tr[NMPC_HIP_TRACE_COST] = J_cur; // :335-337
+          tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
+          tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
+        }
+      }
+      writeTraceRow(iter, tr);
+      if(retval != 0)
+      {
+        break;
+      }
+    }
+
+    // results that do not live in the big arrays
+#pragma unroll
+    for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+    {
+      buf.trace_last[static_cast<size_t>(f) * Bp + b] = tr[f];
+    }
+    buf.status[b] = retval;
+    buf.iters[b] = static_cast<int>(tr[NMPC_HIP_TRACE_ITER]);
+    buf.sel[b] = sel;
+    buf.dV[b] = dV0;
+    buf.dV[Bp + b] = dV1;
+  }
+};
+
+/** The solve kernel: grid = Bp / 64 workgroups of one wavefront, lane = instance. */
+template<class Problem>
+__global__ __launch_bounds__(kLanesPerBlock) void ddp_solve_tpi_kernel(const Problem problem,
+                                                                        const nmpc_hip_ddp_config cfg,
+                                                                        const DeviceBuffers buf)
+{
+  const int b = blockIdx.x * kLanesPerBlock + threadIdx.x;
+  if(b >= buf.B)
+  {
+    return;
+  }
+  InstanceSolver<Problem> solver(problem, cfg, buf, b);
+  solver.solve();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// layout kernels: reference layouts ([B][rows]) <-> instance-minor device layout ([rows][Bp])
+// ---------------------------------------------------------------------------------------------------------
+/** in [B][R] (row-major) -> out [R][Bp].  32x32 tiles through LDS so both sides are coalesced. */
+template<class T>
+__global__ __launch_bounds__(256) void batch_major_to_minor_kernel(const T * __restrict__ in,
+                                                                    T * __restrict__ out,
+                                                                    int B,
+                                                                    int R,
+                                                                    int Bp)
+{
+  __shared__ T tile[32][33];
+  const int r0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+  for(int k = ty; k < 32; k += 8)
+  {
+    const int bb = b0 + k, r = r0 + tx;
+    tile[k][tx] = (bb < B && r < R) ? in[static_cast<size_t>(bb) * R + r] : T(0);
+  }
+  __syncthreads();
+  for(int k = ty; k < 32; k += 8)
+  {
+    const int r = r0 + k, bb = b0 + tx;
+    if(r < R && bb < Bp)
+    {
+      out[static_cast<size_t>(r) * Bp + bb] = tile[tx][k];
+    }
+  }
+}
+
+/** in: two halves [2][R][Bp] selected per instance by sel[b] (or a single half when sel == nullptr)
+    -> out [B][R] (row-major). */
+template<class T>
+__global__ __launch_bounds__(256) void batch_minor_to_major_kernel(const T * __restrict__ in,
+                                                                    T * __restrict__ out,
+                                                                    const int * __restrict__ sel,
+                                                                    int B,
+                                                                    int R,
+                                                                    int Bp)
+{
+  __shared__ T tile[32][33];
+  const int r0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t half = static_cast<size_t>(R) * Bp;
+  {
+    const int bb = b0 + tx;
+    const int s = (sel != nullptr && bb < B) ? sel[bb] : 0;
+    for(int k = ty; k < 32; k += 8)
+    {
+      const int r = r0 + k;
+      tile[k][tx] = (bb < B && r < R) ? in[s * half + static_cast<size_t>(r) * Bp + bb] : T(0);
+    }
+  }
+  __syncthreads();
+  for(int k = ty; k < 32; k += 8)
+  {
+    const int bb = b0 + k, r = r0 + tx;
+    if(bb < B && r < R)
+    {
+      out[static_cast<size_t>(bb) * R + r] = tile[tx][k];
+    }
+  }
+}
+} // namespace hip
+} // namespace nmpc_amd

@@ -1,0 +1,117 @@
+// Registry that connects a problem TYPE (a functor class derived from nmpc_amd::DDPProblem, compiled into
+// gfx950 code together with the solver kernel) to the NAME the C-ABI of include/nmpc_hip_ddp.h uses.
+//
+// A user model is added without touching the library: write the problem header, then in one .hip file
+//     #include <nmpc_amd/hip/model_registry.hpp>
+//     #include "MyProblem.hpp"
+//     NMPC_AMD_REGISTER_PROBLEM(MyProblem);          // needs: static constexpr const char * kName
+// compile it with hipcc --offload-arch=gfx950 and link (or dlopen) it next to libnmpc_hip_ddp.so.
+#pragma once
+
+#include <cstring>
+#include <new>
+#include <type_traits>
+
+#include <nmpc_amd/hip/ddp_kernels.hpp>
+
+namespace nmpc_amd
+{
+namespace hip
+{
+/** Type-erased operations of one registered problem type. */
+struct ModelOps
+{
+  const char * name;
+  int state_dim;
+  int input_dim_max;
+  int dynamic_input;
+  size_t param_bytes;
+  //! placement-constructs a default problem object into out
+  void (*default_params)(void * out);
+  //! launches the solve kernel; params points to a host copy of the problem object
+  hipError_t (*launch_solve)(const void * params,
+                             const nmpc_hip_ddp_config & cfg,
+                             const DeviceBuffers & buf,
+                             hipStream_t stream);
+  //! host-side inputDim(t0 + i dt) for i < T (validation of initial_u_list, DDPSolver.hpp:46-58)
+  void (*input_dims)(const void * params, double t0, int T, int * out);
+  //! dt() of the problem object
+  double (*dt)(const void * params);
+};
+
+template<class Problem>
+struct ModelOpsFor
+{
+  static void defaultParams(void * out)
+  {
+    new(out) Problem();
+  }
+  static hipError_t launchSolve(const void * params,
+                                const nmpc_hip_ddp_config & cfg,
+                                const DeviceBuffers & buf,
+                                hipStream_t stream)
+  {
+    Problem problem;
+    std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
+    const int grid = buf.Bp / kLanesPerBlock;
+    hipLaunchKernelGGL(ddp_solve_tpi_kernel<Problem>, dim3(grid), dim3(kLanesPerBlock), 0, stream, problem, cfg, buf);
+    return hipGetLastError();
+  }
+  static void inputDims(const void * params, double t0, int T, int * out)
+  {
+    Problem problem;
+    std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
+    for(int i = 0; i < T; i++)
+    {
+      if constexpr(Problem::kDynamicInput)
+      {
+        out[i] = problem.inputDim(t0 + i * problem.dt());
+      }
+      else
+      {
+        out[i] = Problem::kInputDimMax;
+      }
+    }
+  }
+  static double dt(const void * params)
+  {
+    Problem problem;
+    std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
+    return problem.dt();
+  }
+  static ModelOps make()
+  {
+    static_assert(std::is_trivially_copyable<Problem>::value,
+                  "a DDP problem must be trivially copyable (no std::function / heap members): it is passed to "
+                  "the GPU by value");
+    static_assert(std::is_default_constructible<Problem>::value, "a DDP problem must be default constructible");
+    ModelOps ops;
+    ops.name = Problem::kName;
+    ops.state_dim = Problem::kStateDim;
+    ops.input_dim_max = Problem::kInputDimMax;
+    ops.dynamic_input = Problem::kDynamicInput ? 1 : 0;
+    ops.param_bytes = sizeof(Problem);
+    ops.default_params = &defaultParams;
+    ops.launch_solve = &launchSolve;
+    ops.input_dims = &inputDims;
+    ops.dt = &dt;
+    return ops;
+  }
+};
+} // namespace hip
+} // namespace nmpc_amd
+
+extern "C" int nmpc_hip_ddp_register_model(const nmpc_amd::hip::ModelOps * ops);
+
+#define NMPC_AMD_REGISTER_PROBLEM(ProblemType)                                                        \
+  namespace                                                                                           \
+  {                                                                                                   \
+  struct ProblemType##Registrar                                                                       \
+  {                                                                                                   \
+    ProblemType##Registrar()                                                                          \
+    {                                                                                                 \
+      static const nmpc_amd::hip::ModelOps ops = nmpc_amd::hip::ModelOpsFor<ProblemType>::make();     \
+      nmpc_hip_ddp_register_model(&ops);                                                              \
+    }                                                                                                 \
+  } g_##ProblemType##_registrar;                                                                      \
+  }

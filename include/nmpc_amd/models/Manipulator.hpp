@@ -1,0 +1,185 @@
+// 7-DoF joint-space manipulator problem (n = 14, m = 7) for the MI355X DDP solver — BASELINE.json config 5.
+// The reference has no manipulator model; this synthetic chain is defined by this project
+// so that Fx and Fu are dense and state dependent:
+//   state x = [q(7), qd(7)], input u = joint torques
+//   r_j   = u_j - damping qd_j - grav_j sin(q_0 + ... + q_j)          (torque left after damping and gravity)
+//   qdd_i = sum_j W_ij(q) r_j,  W_ij = w_diag [i == j] + w_off cos(q_i - q_j)   (configuration-dependent coupling)
+//   explicit Euler: q+ = q + dt qd, qd+ = qd + dt qdd
+#pragma once
+
+#include <nmpc_amd/DDPProblem.hpp>
+
+namespace nmpc_amd
+{
+class DDPProblemManipulator : public DDPProblem<14, 7>
+{
+public:
+  static constexpr const char * kName = "manipulator";
+  static constexpr int kJoints = 7;
+
+  NMPC_HD explicit DDPProblemManipulator(double dt = 0.01) : DDPProblem(dt) {}
+
+  NMPC_HD double gravityGain(int j) const
+  {
+    return grav_scale_ * static_cast<double>(kJoints - j) / kJoints;
+  }
+  NMPC_HD double refAngle(int j) const
+  {
+    return (j % 2 == 1) ? -q_ref_scale_ : q_ref_scale_;
+  }
+  NMPC_HD double coupling(const StateDimVector & x, int i, int j) const
+  {
+    return (i == j ? w_diag_ : 0.0) + w_off_ * cos(x[i] - x[j]);
+  }
+
+  /** Net joint torques r and cumulative angles. */
+  NMPC_HD void netTorque(const StateDimVector & x, const InputDimVector & u, double * r, double * cum_angle) const
+  {
+    double angle = 0;
+    for(int j = 0; j < kJoints; j++)
+    {
+      angle += x[j];
+      cum_angle[j] = angle;
+      r[j] = (u[j] - damping_ * x[kJoints + j]) - gravityGain(j) * sin(angle);
+    }
+  }
+
+  NMPC_HD StateDimVector stateEq(double, // t
+                                 const StateDimVector & x,
+                                 const InputDimVector & u) const
+  {
+    double r[kJoints], cum_angle[kJoints];
+    netTorque(x, u, r, cum_angle);
+    StateDimVector x_next;
+    for(int i = 0; i < kJoints; i++)
+    {
+      double acc = 0;
+      for(int j = 0; j < kJoints; j++)
+      {
+        acc += coupling(x, i, j) * r[j];
+      }
+      x_next[i] = x[i] + dt_ * x[kJoints + i];
+      x_next[kJoints + i] = x[kJoints + i] + dt_ * acc;
+    }
+    return x_next;
+  }
+
+  NMPC_HD double runningCost(double, const StateDimVector & x, const InputDimVector & u) const
+  {
+    double cost_x = 0;
+    for(int j = 0; j < kJoints; j++)
+    {
+      const double e = x[j] - refAngle(j);
+      cost_x += wq_ * (e * e);
+    }
+    for(int j = 0; j < kJoints; j++)
+    {
+      cost_x += wv_ * (x[kJoints + j] * x[kJoints + j]);
+    }
+    return 0.5 * cost_x + 0.5 * wu_ * u.squaredNorm();
+  }
+
+  NMPC_HD double terminalCost(double, const StateDimVector & x) const
+  {
+    double cost_x = 0;
+    for(int j = 0; j < kJoints; j++)
+    {
+      const double e = x[j] - refAngle(j);
+      cost_x += (wt_scale_ * wq_) * (e * e);
+    }
+    for(int j = 0; j < kJoints; j++)
+    {
+      cost_x += (wt_scale_ * wv_) * (x[kJoints + j] * x[kJoints + j]);
+    }
+    return 0.5 * cost_x;
+  }
+
+  NMPC_HD void calcStateEqDeriv(double, // t
+                                const StateDimVector & x,
+                                const InputDimVector & u,
+                                StateStateDimMatrix & state_eq_deriv_x,
+                                StateInputDimMatrix & state_eq_deriv_u) const
+  {
+    double r[kJoints], cum_angle[kJoints];
+    netTorque(x, u, r, cum_angle);
+
+    state_eq_deriv_x.setIdentity();
+    state_eq_deriv_u.setZero();
+    for(int i = 0; i < kJoints; i++)
+    {
+      state_eq_deriv_x(i, kJoints + i) = dt_;
+
+      // sum_j sin(q_i - q_j) r_j : derivative of row i of W w.r.t. its own angle
+      double own = 0;
+      for(int j = 0; j < kJoints; j++)
+      {
+        own += sin(x[i] - x[j]) * r[j];
+      }
+      for(int l = 0; l < kJoints; l++)
+      {
+        double d_coupling = w_off_ * sin(x[i] - x[l]) * r[l];
+        if(l == i)
+        {
+          d_coupling += -w_off_ * own;
+        }
+        // gravity torque of joint j depends on q_l for every l <= j
+        double d_gravity = 0;
+        for(int j = l; j < kJoints; j++)
+        {
+          d_gravity += coupling(x, i, j) * (gravityGain(j) * cos(cum_angle[j]));
+        }
+        state_eq_deriv_x(kJoints + i, l) += dt_ * (d_coupling - d_gravity);
+        state_eq_deriv_x(kJoints + i, kJoints + l) += dt_ * (-coupling(x, i, l) * damping_);
+        state_eq_deriv_u(kJoints + i, l) = dt_ * coupling(x, i, l);
+      }
+    }
+  }
+
+  NMPC_HD void calcRunningCostDeriv(double, // t
+                                    const StateDimVector & x,
+                                    const InputDimVector & u,
+                                    StateDimVector & running_cost_deriv_x,
+                                    InputDimVector & running_cost_deriv_u,
+                                    StateStateDimMatrix & running_cost_deriv_xx,
+                                    InputInputDimMatrix & running_cost_deriv_uu,
+                                    StateInputDimMatrix & running_cost_deriv_xu) const
+  {
+    running_cost_deriv_xx.setZero();
+    running_cost_deriv_uu.setZero();
+    for(int j = 0; j < kJoints; j++)
+    {
+      running_cost_deriv_x[j] = wq_ * (x[j] - refAngle(j));
+      running_cost_deriv_x[kJoints + j] = wv_ * x[kJoints + j];
+      running_cost_deriv_xx(j, j) = wq_;
+      running_cost_deriv_xx(kJoints + j, kJoints + j) = wv_;
+      running_cost_deriv_u[j] = wu_ * u[j];
+      running_cost_deriv_uu(j, j) = wu_;
+    }
+    running_cost_deriv_xu.setZero();
+  }
+
+  NMPC_HD void calcTerminalCostDeriv(double, // t
+                                     const StateDimVector & x,
+                                     StateDimVector & terminal_cost_deriv_x,
+                                     StateStateDimMatrix & terminal_cost_deriv_xx) const
+  {
+    terminal_cost_deriv_xx.setZero();
+    for(int j = 0; j < kJoints; j++)
+    {
+      terminal_cost_deriv_x[j] = (wt_scale_ * wq_) * (x[j] - refAngle(j));
+      terminal_cost_deriv_x[kJoints + j] = (wt_scale_ * wv_) * x[kJoints + j];
+      terminal_cost_deriv_xx(j, j) = wt_scale_ * wq_;
+      terminal_cost_deriv_xx(kJoints + j, kJoints + j) = wt_scale_ * wv_;
+    }
+  }
+
+public:
+  double w_diag_ = 2.0;
+  double w_off_ = 0.15;
+  double damping_ = 0.5;
+  double grav_scale_ = 4.0;
+  double wq_ = 1.0, wv_ = 0.05, wu_ = 0.002;
+  double wt_scale_ = 20.0;
+  double q_ref_scale_ = 0.3;
+};
+} // namespace nmpc_amd

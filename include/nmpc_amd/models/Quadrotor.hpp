@@ -1,0 +1,218 @@
+// Quadrotor problem (n = 12, m = 4) for the MI355X DDP solver — BASELINE.json config 4.
+// The reference has no quadrotor model; this one is defined by this project:
+//   state  x = [position(3), roll-pitch-yaw(3), world velocity(3), body rates(3)]
+//   input  u = thrust of the four rotors (plus configuration, rotor i on the +x, +y, -x, -y arm)
+//   rigid-body dynamics with ZYX Euler kinematics, explicit Euler step; quadratic costs around hover.
+#pragma once
+
+#include <nmpc_amd/DDPProblem.hpp>
+
+namespace nmpc_amd
+{
+class DDPProblemQuadrotor : public DDPProblem<12, 4>
+{
+public:
+  static constexpr const char * kName = "quadrotor";
+  static constexpr double g_ = 9.80665; // [m/s^2]
+
+  NMPC_HD explicit DDPProblemQuadrotor(double dt = 0.02) : DDPProblem(dt) {}
+
+  NMPC_HD double hoverThrust() const
+  {
+    return mass_ * g_ / 4;
+  }
+
+  NMPC_HD double stateWeight(int i) const
+  {
+    return i < 3 ? w_pos_ : (i < 6 ? w_rpy_ : (i < 9 ? w_vel_ : w_omega_));
+  }
+
+  NMPC_HD double stateError(const StateDimVector & x, int i) const
+  {
+    return i < 3 ? x[i] - ref_pos_[i] : x[i];
+  }
+
+  /** Trigonometry of the attitude shared by the dynamics and its Jacobian. */
+  struct Trig
+  {
+    double sr, cr, sp, cp, sy, cy, tp;
+    NMPC_HD explicit Trig(const StateDimVector & x)
+    : sr(sin(x[3])), cr(cos(x[3])), sp(sin(x[4])), cp(cos(x[4])), sy(sin(x[5])), cy(cos(x[5])), tp(sp / cp)
+    {
+    }
+  };
+
+  NMPC_HD StateDimVector stateEq(double, // t
+                                 const StateDimVector & x,
+                                 const InputDimVector & u) const
+  {
+    const Trig g(x);
+    const double p = x[9], q = x[10], r = x[11];
+    const double thrust = ((u[0] + u[1]) + u[2]) + u[3];
+    // body z axis expressed in the world frame
+    const double bz[3] = {g.cr * g.sp * g.cy + g.sr * g.sy, g.cr * g.sp * g.sy - g.sr * g.cy, g.cr * g.cp};
+    const double torque[3] = {arm_ * (u[1] - u[3]), arm_ * (u[2] - u[0]), yaw_coef_ * (((u[0] - u[1]) + u[2]) - u[3])};
+
+    double x_dot[12];
+    x_dot[0] = x[6];
+    x_dot[1] = x[7];
+    x_dot[2] = x[8];
+    x_dot[3] = p + g.sr * g.tp * q + g.cr * g.tp * r;
+    x_dot[4] = g.cr * q - g.sr * r;
+    x_dot[5] = (g.sr * q + g.cr * r) / g.cp;
+    x_dot[6] = thrust / mass_ * bz[0];
+    x_dot[7] = thrust / mass_ * bz[1];
+    x_dot[8] = thrust / mass_ * bz[2] - g_;
+    x_dot[9] = (torque[0] - (inertia_[2] - inertia_[1]) * q * r) / inertia_[0];
+    x_dot[10] = (torque[1] - (inertia_[0] - inertia_[2]) * p * r) / inertia_[1];
+    x_dot[11] = (torque[2] - (inertia_[1] - inertia_[0]) * p * q) / inertia_[2];
+
+    StateDimVector x_next;
+    for(int i = 0; i < 12; i++)
+    {
+      x_next[i] = x[i] + dt_ * x_dot[i];
+    }
+    return x_next;
+  }
+
+  NMPC_HD double runningCost(double, const StateDimVector & x, const InputDimVector & u) const
+  {
+    double cost_x = 0;
+    for(int i = 0; i < 12; i++)
+    {
+      const double e = stateError(x, i);
+      cost_x += stateWeight(i) * (e * e);
+    }
+    double cost_u = 0;
+    for(int i = 0; i < 4; i++)
+    {
+      const double e = u[i] - hoverThrust();
+      cost_u += e * e;
+    }
+    return 0.5 * cost_x + 0.5 * w_u_ * cost_u;
+  }
+
+  NMPC_HD double terminalCost(double, const StateDimVector & x) const
+  {
+    double cost_x = 0;
+    for(int i = 0; i < 12; i++)
+    {
+      const double e = stateError(x, i);
+      cost_x += (wt_scale_ * stateWeight(i)) * (e * e);
+    }
+    return 0.5 * cost_x;
+  }
+
+  NMPC_HD void calcStateEqDeriv(double, // t
+                                const StateDimVector & x,
+                                const InputDimVector & u,
+                                StateStateDimMatrix & state_eq_deriv_x,
+                                StateInputDimMatrix & state_eq_deriv_u) const
+  {
+    const Trig g(x);
+    const double p = x[9], q = x[10], r = x[11];
+    const double thrust = ((u[0] + u[1]) + u[2]) + u[3];
+    const double acc = thrust / mass_;
+    const double cp2 = g.cp * g.cp;
+
+    StateStateDimMatrix & A = state_eq_deriv_x; // filled with d(x_dot)/dx, then scaled
+    A.setZero();
+    A(0, 6) = 1;
+    A(1, 7) = 1;
+    A(2, 8) = 1;
+    // Euler-angle kinematics
+    A(3, 3) = g.cr * g.tp * q - g.sr * g.tp * r;
+    A(3, 4) = (g.sr * q + g.cr * r) / cp2;
+    A(3, 9) = 1;
+    A(3, 10) = g.sr * g.tp;
+    A(3, 11) = g.cr * g.tp;
+    A(4, 3) = -g.sr * q - g.cr * r;
+    A(4, 10) = g.cr;
+    A(4, 11) = -g.sr;
+    A(5, 3) = (g.cr * q - g.sr * r) / g.cp;
+    A(5, 4) = (g.sr * q + g.cr * r) * g.sp / cp2;
+    A(5, 10) = g.sr / g.cp;
+    A(5, 11) = g.cr / g.cp;
+    // thrust direction w.r.t. roll, pitch, yaw
+    A(6, 3) = acc * (-g.sr * g.sp * g.cy + g.cr * g.sy);
+    A(7, 3) = acc * (-g.sr * g.sp * g.sy - g.cr * g.cy);
+    A(8, 3) = acc * (-g.sr * g.cp);
+    A(6, 4) = acc * (g.cr * g.cp * g.cy);
+    A(7, 4) = acc * (g.cr * g.cp * g.sy);
+    A(8, 4) = acc * (-g.cr * g.sp);
+    A(6, 5) = acc * (-g.cr * g.sp * g.sy + g.sr * g.cy);
+    A(7, 5) = acc * (g.cr * g.sp * g.cy + g.sr * g.sy);
+    // gyroscopic coupling
+    A(9, 10) = -(inertia_[2] - inertia_[1]) * r / inertia_[0];
+    A(9, 11) = -(inertia_[2] - inertia_[1]) * q / inertia_[0];
+    A(10, 9) = -(inertia_[0] - inertia_[2]) * r / inertia_[1];
+    A(10, 11) = -(inertia_[0] - inertia_[2]) * p / inertia_[1];
+    A(11, 9) = -(inertia_[1] - inertia_[0]) * q / inertia_[2];
+    A(11, 10) = -(inertia_[1] - inertia_[0]) * p / inertia_[2];
+    A *= dt_;
+    A.addToDiagonal(1.0);
+
+    const double bz[3] = {g.cr * g.sp * g.cy + g.sr * g.sy, g.cr * g.sp * g.sy - g.sr * g.cy, g.cr * g.cp};
+    StateInputDimMatrix & Bm = state_eq_deriv_u;
+    Bm.setZero();
+    for(int i = 0; i < 4; i++)
+    {
+      Bm(6, i) = dt_ * (bz[0] / mass_);
+      Bm(7, i) = dt_ * (bz[1] / mass_);
+      Bm(8, i) = dt_ * (bz[2] / mass_);
+      Bm(11, i) = dt_ * ((i % 2 == 0 ? yaw_coef_ : -yaw_coef_) / inertia_[2]);
+    }
+    Bm(9, 1) = dt_ * (arm_ / inertia_[0]);
+    Bm(9, 3) = dt_ * (-arm_ / inertia_[0]);
+    Bm(10, 2) = dt_ * (arm_ / inertia_[1]);
+    Bm(10, 0) = dt_ * (-arm_ / inertia_[1]);
+  }
+
+  NMPC_HD void calcRunningCostDeriv(double, // t
+                                    const StateDimVector & x,
+                                    const InputDimVector & u,
+                                    StateDimVector & running_cost_deriv_x,
+                                    InputDimVector & running_cost_deriv_u,
+                                    StateStateDimMatrix & running_cost_deriv_xx,
+                                    InputInputDimMatrix & running_cost_deriv_uu,
+                                    StateInputDimMatrix & running_cost_deriv_xu) const
+  {
+    running_cost_deriv_xx.setZero();
+    for(int i = 0; i < 12; i++)
+    {
+      running_cost_deriv_x[i] = stateWeight(i) * stateError(x, i);
+      running_cost_deriv_xx(i, i) = stateWeight(i);
+    }
+    running_cost_deriv_uu.setZero();
+    for(int i = 0; i < 4; i++)
+    {
+      running_cost_deriv_u[i] = w_u_ * (u[i] - hoverThrust());
+      running_cost_deriv_uu(i, i) = w_u_;
+    }
+    running_cost_deriv_xu.setZero();
+  }
+
+  NMPC_HD void calcTerminalCostDeriv(double, // t
+                                     const StateDimVector & x,
+                                     StateDimVector & terminal_cost_deriv_x,
+                                     StateStateDimMatrix & terminal_cost_deriv_xx) const
+  {
+    terminal_cost_deriv_xx.setZero();
+    for(int i = 0; i < 12; i++)
+    {
+      terminal_cost_deriv_x[i] = (wt_scale_ * stateWeight(i)) * stateError(x, i);
+      terminal_cost_deriv_xx(i, i) = wt_scale_ * stateWeight(i);
+    }
+  }
+
+public:
+  double mass_ = 1.0; // [kg]
+  double inertia_[3] = {0.01, 0.01, 0.02}; // [kg m^2]
+  double arm_ = 0.2; // [m]
+  double yaw_coef_ = 0.05; // rotor drag torque per unit thrust [m]
+  double w_pos_ = 1.0, w_rpy_ = 0.5, w_vel_ = 0.1, w_omega_ = 0.05;
+  double w_u_ = 0.01;
+  double wt_scale_ = 10.0; // terminal weight = wt_scale * running weight
+  double ref_pos_[3] = {0.0, 0.0, 1.0}; // [m]
+};
+} // namespace nmpc_amd

@@ -1,0 +1,194 @@
+/* C-ABI of the MI355X-native batched DDP solver (libnmpc_hip_ddp.so).
+ *
+ * This is the drop-in boundary for the hot path of the reference's nmpc_ddp::DDPSolver
+ * (/root/reference/nmpc_ddp/include/nmpc_ddp/DDPSolver.h:255-308): a whole batch of independent
+ * `solve()` calls crosses it at once and the entire optimisation loop (DDPSolver.hpp:115-123 -> procOnce
+ * :143-340 -> backwardPass :342-534 / forwardPass :536-560, BoxQP.h:141-347) runs on the GPU.
+ * The reference has no FFI layer of its own (it is a header-only C++ template library); each entry point
+ * below cites the reference member it replaces.  Plain pointers and sizes only; no C++ or torch types.
+ * Every function returns an int: 0 (NMPC_HIP_OK) or a negative nmpc_hip_status; nothing throws across
+ * this boundary.  The host-side C++ mirror (include/nmpc_amd/DDPSolverBatch.hpp) turns the codes back into
+ * the exception types the reference throws.
+ *
+ * Layouts (row-major in the order written; MM = max(input_dim_max, 1); doubles unless noted):
+ *   x0      [B][N]                current_x of each instance                (DDPSolver.h:275)
+ *   t0      [B]                   current_t of each instance (NULL = all 0) (DDPSolver.h:275)
+ *   u_init  [B][T][MM]            initial_u_list, entries >= inputDim(t) ignored
+ *   X       [B][T+1][N]           controlData().x_list                      (DDPSolver.h:116)
+ *   U       [B][T][MM]            controlData().u_list                      (DDPSolver.h:119)
+ *   COST    [B][T+1]              controlData().cost_list                   (DDPSolver.h:122)
+ *   KFF     [B][T][MM]            k_list_                                   (DDPSolver.h:359)
+ *   KFB     [B][T][N][MM]         K_list_; per step the m x N gain, column-major with leading dim MM,
+ *                                 i.e. the memory image of Eigen's K_list_[t] when m == MM (DDPSolver.h:362)
+ *   TRACE   [B][max_iter+1][NMPC_HIP_NTRACE]  traceDataList()               (DDPSolver.h:179-216,294)
+ *   STATUS  [B] int               1 converged (solve() returned true), 0 max_iter exhausted, -1 failure
+ *                                 (the retval of the last procOnce, DDPSolver.h:311-315, DDPSolver.hpp:140)
+ *   ITERS   [B] int               traceDataList().back().iter
+ */
+#ifndef NMPC_HIP_DDP_H
+#define NMPC_HIP_DDP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+#define NMPC_HIP_MAX_ALPHA 32
+#define NMPC_HIP_NTRACE 12
+
+  typedef enum
+  {
+    NMPC_HIP_OK = 0,
+    NMPC_HIP_ERR_INVALID_ARGUMENT = -1, /* std::invalid_argument in the reference (DDPSolver.hpp:41-45) */
+    NMPC_HIP_ERR_RUNTIME = -2, /* std::runtime_error in the reference (DDPSolver.hpp:46-58,391-414) */
+    NMPC_HIP_ERR_UNKNOWN_MODEL = -3,
+    NMPC_HIP_ERR_HIP = -4, /* a HIP runtime call failed; see nmpc_hip_ddp_last_error() */
+    NMPC_HIP_ERR_NO_DEVICE = -5, /* no gfx950 device / HIP runtime unavailable: there is NO CPU fallback */
+    NMPC_HIP_ERR_NOT_SOLVED = -6
+  } nmpc_hip_status;
+
+  /** DDPSolver::Configuration (DDPSolver.h:47-110) as a POD, plus BoxQP::Configuration (BoxQP.h:33-55).
+      print_level is host-side only and lives in the C++/Python mirrors. */
+  typedef struct
+  {
+    int with_input_constraint; /* DDPSolver.h:70 */
+    int max_iter; /* :73 */
+    int horizon_steps; /* :76 (fixed at create(); set_config rejects a different value) */
+    int reg_type; /* :79 */
+    double initial_lambda; /* :82 */
+    double initial_dlambda; /* :85 */
+    double lambda_factor; /* :88 */
+    double lambda_min; /* :91 */
+    double lambda_max; /* :94 */
+    double k_rel_norm_thre; /* :97 */
+    double lambda_thre; /* :100 */
+    double cost_update_ratio_thre; /* :106 */
+    double cost_update_thre; /* :109 */
+    int n_alpha; /* alpha_list.size() (:103) */
+    double alpha_list[NMPC_HIP_MAX_ALPHA];
+    int use_state_eq_second_derivative; /* :67; non-zero is rejected with NMPC_HIP_ERR_RUNTIME (DDPSolver.hpp:391-414) */
+    int qp_max_iter; /* BoxQP.h:39 */
+    double qp_grad_thre; /* BoxQP.h:42 */
+    double qp_rel_improve_thre; /* BoxQP.h:45 */
+    double qp_step_factor; /* BoxQP.h:48 */
+    double qp_min_step; /* BoxQP.h:51 */
+    double qp_armijo_param; /* BoxQP.h:54 */
+    int trace_level; /* 0: keep only the last trace row per instance; 1: full per-iteration trace */
+  } nmpc_hip_ddp_config;
+
+  /** Trace columns (TraceData, DDPSolver.h:179-216).  The three duration_* fields of the reference are
+      per-instance CPU timers with no batched equivalent; their slots carry the discrete decisions the
+      parity tests compare instead (alpha index, number of backward passes, number of forward passes). */
+  typedef enum
+  {
+    NMPC_HIP_TRACE_ITER = 0,
+    NMPC_HIP_TRACE_COST = 1,
+    NMPC_HIP_TRACE_LAMBDA = 2,
+    NMPC_HIP_TRACE_DLAMBDA = 3,
+    NMPC_HIP_TRACE_ALPHA = 4,
+    NMPC_HIP_TRACE_K_REL_NORM = 5,
+    NMPC_HIP_TRACE_COST_UPDATE_ACTUAL = 6,
+    NMPC_HIP_TRACE_COST_UPDATE_EXPECTED = 7,
+    NMPC_HIP_TRACE_COST_UPDATE_RATIO = 8,
+    NMPC_HIP_TRACE_ALPHA_IDX = 9,
+    NMPC_HIP_TRACE_N_BACKWARD = 10,
+    NMPC_HIP_TRACE_N_FORWARD = 11
+  } nmpc_hip_trace_col;
+
+  typedef enum
+  {
+    NMPC_HIP_FIELD_X = 0,
+    NMPC_HIP_FIELD_U = 1,
+    NMPC_HIP_FIELD_COST = 2,
+    NMPC_HIP_FIELD_KFF = 3,
+    NMPC_HIP_FIELD_KFB = 4,
+    NMPC_HIP_FIELD_TRACE = 5,
+    NMPC_HIP_FIELD_STATUS = 6, /* int */
+    NMPC_HIP_FIELD_ITERS = 7, /* int */
+    NMPC_HIP_FIELD_TRACE_LAST = 8, /* [B][NMPC_HIP_NTRACE]: last trace row of each instance */
+    NMPC_HIP_FIELD_DV = 9, /* [B][2]: dV_ of the last backward pass (DDPSolver.h:374) */
+    NMPC_HIP_FIELD_QP_RETVAL = 10, /* int [B][T]: BoxQP retval_ of the last backward pass (BoxQP.h:372) */
+    NMPC_HIP_FIELD_QP_FREE_MASK = 11, /* unsigned [B][T]: bit i set <=> i in free_idxs_ (BoxQP.h:389) */
+    NMPC_HIP_FIELD_INPUT_DIM = 12 /* int [B][T]: problem->inputDim(t0 + i dt) */
+  } nmpc_hip_field;
+
+  typedef struct nmpc_hip_ddp_solver * nmpc_hip_ddp_handle;
+
+  /** Fill cfg with the reference defaults (DDPSolver::Configuration::Configuration, DDPSolver.h:50-60). */
+  int nmpc_hip_ddp_default_config(nmpc_hip_ddp_config * cfg);
+
+  /** Number of registered problem types, and their names / dimensions.
+      Replaces the compile-time template arguments DDPSolver<StateDim, InputDim> (DDPSolver.h:23-25). */
+  int nmpc_hip_ddp_model_count(void);
+  int nmpc_hip_ddp_model_name(int index, const char ** name);
+  int nmpc_hip_ddp_model_info(const char * model, int * state_dim, int * input_dim_max, int * dynamic_input,
+                              size_t * param_bytes);
+  /** Copy the default-constructed problem object (a trivially-copyable blob of param_bytes) to out. */
+  int nmpc_hip_ddp_model_default_params(const char * model, void * out, size_t bytes);
+
+  /** DDPSolver::DDPSolver(problem) (DDPSolver.hpp:20-24) for a batch of `batch` instances with horizon
+      `horizon_steps` on HIP device `device`.  All device buffers are allocated here and live until destroy,
+      so consecutive solves (MPC warm start, DDPSolver.hpp:74-78) reuse them. */
+  int nmpc_hip_ddp_create(const char * model, int horizon_steps, int batch, int device, nmpc_hip_ddp_handle * out);
+  int nmpc_hip_ddp_destroy(nmpc_hip_ddp_handle h);
+
+  /** DDPSolver::config() (DDPSolver.h:258-267). */
+  int nmpc_hip_ddp_set_config(nmpc_hip_ddp_handle h, const nmpc_hip_ddp_config * cfg);
+  int nmpc_hip_ddp_get_config(nmpc_hip_ddp_handle h, nmpc_hip_ddp_config * cfg);
+
+  /** The problem object the solver co-owns (DDPSolver.h:332): overwrite it with a caller-built blob. */
+  int nmpc_hip_ddp_set_model_params(nmpc_hip_ddp_handle h, const void * params, size_t bytes);
+
+  /** problem->inputDim(t0 + i * dt) for i < horizon_steps, evaluated on the host from the handle's problem object:
+      what DDPSolver::solve validates initial_u_list against (DDPSolver.hpp:46-58).  out has room for T ints. */
+  int nmpc_hip_ddp_input_dims(nmpc_hip_ddp_handle h, double t0, int * out);
+
+  /** DDPSolver::setInputLimitsFunc (DDPSolver.h:282-285) for limits that are constant in time, the only form
+      the reference's callers use (TestDDPCartPole.cpp:379-386, TestDDPVerticalMotion.cpp:262-270):
+      lower[MM], upper[MM]; entries >= inputDim(t) are ignored. */
+  int nmpc_hip_ddp_set_input_limits(nmpc_hip_ddp_handle h, const double * lower, const double * upper);
+
+  /** DDPSolver::solve (DDPSolver.h:275, DDPSolver.hpp:26-141) for the whole batch, HOST pointers:
+      H2D copy, device solve, synchronise.  Results stay on the device until nmpc_hip_ddp_get. */
+  int nmpc_hip_ddp_solve(nmpc_hip_ddp_handle h, const double * t0, const double * x0, const double * u_init);
+
+  /** Same with DEVICE pointers (reference layouts above, resident in HBM), asynchronous on `stream`
+      (a hipStream_t, NULL = the solver's own stream).  Nothing is copied over PCIe. */
+  int nmpc_hip_ddp_solve_device(nmpc_hip_ddp_handle h,
+                                const double * d_t0,
+                                const double * d_x0,
+                                const double * d_u_init,
+                                void * stream);
+  int nmpc_hip_ddp_synchronize(nmpc_hip_ddp_handle h);
+
+  /** controlData() / traceDataList() and friends (DDPSolver.h:288-297): copy one result field to HOST memory
+      in the reference layout.  bytes must equal the field size. */
+  int nmpc_hip_ddp_get(nmpc_hip_ddp_handle h, int field, void * out, size_t bytes);
+  /** Same into DEVICE memory (e.g. the send buffer of the final RCCL gather), asynchronous on `stream`. */
+  int nmpc_hip_ddp_get_device(nmpc_hip_ddp_handle h, int field, void * d_out, size_t bytes, void * stream);
+  int nmpc_hip_ddp_field_bytes(nmpc_hip_ddp_handle h, int field, size_t * bytes);
+
+  /** computationDuration() (DDPSolver.h:300-303): HIP-event time of the last device solve [ms]
+      (ingest + solve kernel), and of the solve kernel alone. */
+  int nmpc_hip_ddp_last_solve_ms(nmpc_hip_ddp_handle h, float * total_ms, float * kernel_ms);
+
+  /** Accumulated HIP-event times over every device solve since create / the last reset: number of solves and
+      the sums of (ingest + kernel) and of the solve kernel alone [ms].  Events are recorded on the launch stream
+      and harvested lazily, so a sequence of asynchronous solves is timed without host synchronisation in
+      between (bench.py's roofline leg). */
+  int nmpc_hip_ddp_timing_stats(nmpc_hip_ddp_handle h,
+                                int reset,
+                                long long * n_solves,
+                                double * total_ms_sum,
+                                double * kernel_ms_sum);
+
+  /** Text of the last error raised on this thread (HIP error string or argument description). */
+  const char * nmpc_hip_ddp_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NMPC_HIP_DDP_H */

@@ -1,0 +1,80 @@
+"""Build libnmpc_hip_ddp.so (gfx950 code objects + C-ABI) in-tree with hipcc.
+
+`python -m nmpc_amd.build` or `nmpc_amd.build.build()`; hipcc cross-compiles without a GPU.  The library is
+written to nmpc_amd/lib/ so that it travels with the source tree (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "nmpc_amd", "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB_DIR = os.path.join(ROOT, "nmpc_amd", "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libnmpc_hip_ddp.so")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+SOURCES = ("capi.hip", "builtin_models.hip", "builder_models.hip")
+ARCH = "gfx950"
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X path cannot be built (there is no CPU fallback)")
+
+
+def _headers():
+    out = []
+    for base, _, files in os.walk(INCLUDE):
+        out += [os.path.join(base, f) for f in files]
+    return out
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cc = hipcc()
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}"]
+    objs = []
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if (not force) and os.path.exists(obj) and all(
+                os.path.getmtime(obj) > os.path.getmtime(d) for d in [src] + _headers()):
+            continue
+        cmd = [cc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

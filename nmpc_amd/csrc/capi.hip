@@ -1,0 +1,943 @@
+// C-ABI of libnmpc_hip_ddp.so (declared in include/nmpc_hip_ddp.h): solver handles, device-buffer ownership,
+// layout conversion at the boundary and the launch of the persistent solve kernel.  No CPU fallback exists: if
+// the HIP runtime or a gfx950 device is missing every entry point that needs the GPU fails loudly.
+#include <nmpc_hip_ddp.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <nmpc_amd/hip/model_registry.hpp>
+
+using nmpc_amd::hip::DeviceBuffers;
+using nmpc_amd::hip::ModelOps;
+
+namespace
+{
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string & msg)
+{
+  g_last_error = msg;
+  return code;
+}
+
+#define NMPC_HIP_TRY(expr)                                                                                     \
+  do                                                                                                           \
+  {                                                                                                            \
+    hipError_t e_ = (expr);                                                                                    \
+    if(e_ != hipSuccess)                                                                                       \
+    {                                                                                                          \
+      return fail(NMPC_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    }                                                                                                          \
+  } while(0)
+
+std::vector<const ModelOps *> & registry()
+{
+  static std::vector<const ModelOps *> r;
+  return r;
+}
+
+const ModelOps * findModel(const char * name)
+{
+  if(!name)
+  {
+    return nullptr;
+  }
+  for(const ModelOps * m : registry())
+  {
+    if(std::strcmp(m->name, name) == 0)
+    {
+      return m;
+    }
+  }
+  return nullptr;
+}
+} // namespace
+
+struct nmpc_hip_ddp_solver
+{
+  const ModelOps * ops = nullptr;
+  int device = 0;
+  int B = 0, Bp = 0, T = 0, N = 0, M = 0, MM = 1;
+  nmpc_hip_ddp_config cfg;
+  std::vector<unsigned char> params;
+  double lim_lo[nmpc_amd::hip::kMaxInputDim];
+  double lim_hi[nmpc_amd::hip::kMaxInputDim];
+  bool has_limits = false;
+  bool solved = false;
+  hipStream_t stream = nullptr;
+  // ring of HIP-event triples {begin, kernel start, end}: one per solve, harvested lazily so that timing a
+  // sequence of asynchronous solves never inserts a host synchronisation between them
+  static constexpr int kEvPool = 128;
+  hipEvent_t ev_begin[kEvPool] = {}, ev_kernel[kEvPool] = {}, ev_end[kEvPool] = {};
+  bool ev_pending[kEvPool] = {};
+  long long n_solves = 0; // solves recorded since create / last reset
+  long long n_harvested = 0;
+  double sum_total_ms = 0, sum_kernel_ms = 0;
+  float last_total_ms = 0, last_kernel_ms = 0;
+  hipStream_t last_stream = nullptr;
+
+  // device memory
+  double * d_t0 = nullptr;
+  double * d_x0 = nullptr;
+  double * d_X = nullptr;
+  double * d_U = nullptr;
+  double * d_cost = nullptr;
+  double * d_kff = nullptr;
+  double * d_Kfb = nullptr;
+  double * d_trace = nullptr;
+  double * d_trace_last = nullptr;
+  double * d_dV = nullptr;
+  int * d_status = nullptr;
+  int * d_iters = nullptr;
+  int * d_sel = nullptr;
+  int * d_qp_ret = nullptr;
+  unsigned * d_qp_free = nullptr;
+  int * d_input_dim = nullptr;
+  int trace_rows = 0;
+  // staging in the reference layouts
+  void * d_stage_in = nullptr; // x0 / u_init / t0 as handed over by the host entry point
+  size_t stage_in_bytes = 0;
+  void * d_stage_out = nullptr; // one result field in the reference layout
+  size_t stage_out_bytes = 0;
+};
+
+namespace
+{
+template<class T>
+int devAlloc(T ** p, size_t count)
+{
+  NMPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+  NMPC_HIP_TRY(hipMemset(*p, 0, count * sizeof(T)));
+  return NMPC_HIP_OK;
+}
+
+int ensureStage(void ** p, size_t * have, size_t need)
+{
+  if(*have >= need)
+  {
+    return NMPC_HIP_OK;
+  }
+  if(*p)
+  {
+    NMPC_HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+  }
+  NMPC_HIP_TRY(hipMalloc(p, need));
+  *have = need;
+  return NMPC_HIP_OK;
+}
+
+int allocTrace(nmpc_hip_ddp_solver * s)
+{
+  const int rows = (s->cfg.trace_level >= 1) ? s->cfg.max_iter + 1 : 1;
+  if(rows == s->trace_rows && s->d_trace)
+  {
+    return NMPC_HIP_OK;
+  }
+  if(s->d_trace)
+  {
+    NMPC_HIP_TRY(hipDeviceSynchronize()); // a solve in flight may still write the old trace buffer
+    NMPC_HIP_TRY(hipFree(s->d_trace));
+    s->d_trace = nullptr;
+  }
+  s->trace_rows = rows;
+  return devAlloc(&s->d_trace, static_cast<size_t>(rows) * NMPC_HIP_NTRACE * s->Bp);
+}
+
+DeviceBuffers makeBuffers(const nmpc_hip_ddp_solver * s)
+{
+  DeviceBuffers b;
+  b.B = s->B;
+  b.Bp = s->Bp;
+  b.T = s->T;
+  b.trace_rows = s->trace_rows;
+  b.t0 = s->d_t0;
+  b.x0 = s->d_x0;
+  b.X = s->d_X;
+  b.U = s->d_U;
+  b.cost = s->d_cost;
+  b.kff = s->d_kff;
+  b.Kfb = s->d_Kfb;
+  b.trace = s->d_trace;
+  b.trace_last = s->d_trace_last;
+  b.dV = s->d_dV;
+  b.status = s->d_status;
+  b.iters = s->d_iters;
+  b.sel = s->d_sel;
+  b.qp_ret = s->d_qp_ret;
+  b.qp_free = s->d_qp_free;
+  b.input_dim = s->d_input_dim;
+  for(int i = 0; i < nmpc_amd::hip::kMaxInputDim; i++)
+  {
+    b.lim_lo[i] = s->lim_lo[i];
+    b.lim_hi[i] = s->lim_hi[i];
+  }
+  return b;
+}
+
+template<class T>
+hipError_t toMinor(const T * in, T * out, int B, int R, int Bp, hipStream_t st)
+{
+  dim3 grid((R + 31) / 32, (Bp + 31) / 32);
+  hipLaunchKernelGGL(nmpc_amd::hip::batch_major_to_minor_kernel<T>, grid, dim3(256), 0, st, in, out, B, R, Bp);
+  return hipGetLastError();
+}
+
+template<class T>
+hipError_t toMajor(const T * in, T * out, const int * sel, int B, int R, int Bp, hipStream_t st)
+{
+  dim3 grid((R + 31) / 32, (B + 31) / 32);
+  hipLaunchKernelGGL(nmpc_amd::hip::batch_minor_to_major_kernel<T>, grid, dim3(256), 0, st, in, out, sel, B, R, Bp);
+  return hipGetLastError();
+}
+
+struct FieldInfo
+{
+  size_t rows; // elements per instance
+  size_t elem; // bytes per element
+};
+
+int fieldInfo(const nmpc_hip_ddp_solver * s, int field, FieldInfo * fi)
+{
+  const size_t T = s->T, N = s->N, MM = s->MM;
+  switch(field)
+  {
+    case NMPC_HIP_FIELD_X:
+      *fi = {(T + 1) * N, sizeof(double)};
+      return NMPC_HIP_OK;
+    case NMPC_HIP_FIELD_U:
+      *fi = {T * MM, sizeof(double)};
+      return NMPC_HIP_OK;
+    case NMPC_HIP_FIELD_COST:
+      *fi = {T + 1, sizeof(double)};
+      return NMPC_HIP_OK;
+    case NMPC_HIP_FIELD_KFF:
+      *fi = {T * MM, sizeof(double)};
+      return NMPC_HIP_OK;
+    case NMPC_HIP_FIELD_KFB:
+      *fi = {T * N * MM, sizeof(double)};
+      return NMPC_HIP_OK;
+    case NMPC_HIP_FIELD_TRACE:
+      *fi = {static_cast<size_t>(s->cfg.max_iter + 1) * NMPC_HIP_NTRACE, sizeof(double)};
+      return NMPC_HIP_OK;
+    case NMPC_HIP_FIELD_STATUS:
+    case NMPC_HIP_FIELD_ITERS:
+      *fi = {1, sizeof(int)};
+      return NMPC_HIP_OK;
+    case NMPC_HIP_FIELD_TRACE_LAST:
+      *fi = {NMPC_HIP_NTRACE, sizeof(double)};
+      return NMPC_HIP_OK;
+    case NMPC_HIP_FIELD_DV:
+      *fi = {2, sizeof(double)};
+      return NMPC_HIP_OK;
+    case NMPC_HIP_FIELD_QP_RETVAL:
+    case NMPC_HIP_FIELD_INPUT_DIM:
+      *fi = {T, sizeof(int)};
+      return NMPC_HIP_OK;
+    case NMPC_HIP_FIELD_QP_FREE_MASK:
+      *fi = {T, sizeof(unsigned)};
+      return NMPC_HIP_OK;
+    default:
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "unknown field " + std::to_string(field));
+  }
+}
+
+/** Convert one field from the device layout into the reference layout at d_out (device memory). */
+int packField(nmpc_hip_ddp_solver * s, int field, void * d_out, hipStream_t st)
+{
+  const int B = s->B, Bp = s->Bp;
+  FieldInfo fi;
+  int rc = fieldInfo(s, field, &fi);
+  if(rc != NMPC_HIP_OK)
+  {
+    return rc;
+  }
+  const int R = static_cast<int>(fi.rows);
+  double * dout = static_cast<double *>(d_out);
+  int * iout = static_cast<int *>(d_out);
+  switch(field)
+  {
+    case NMPC_HIP_FIELD_X:
+      NMPC_HIP_TRY(toMajor<double>(s->d_X, dout, s->d_sel, B, R, Bp, st));
+      break;
+    case NMPC_HIP_FIELD_U:
+      NMPC_HIP_TRY(toMajor<double>(s->d_U, dout, s->d_sel, B, R, Bp, st));
+      break;
+    case NMPC_HIP_FIELD_COST:
+      NMPC_HIP_TRY(toMajor<double>(s->d_cost, dout, s->d_sel, B, R, Bp, st));
+      break;
+    case NMPC_HIP_FIELD_KFF:
+      NMPC_HIP_TRY(toMajor<double>(s->d_kff, dout, nullptr, B, R, Bp, st));
+      break;
+    case NMPC_HIP_FIELD_KFB:
+      NMPC_HIP_TRY(toMajor<double>(s->d_Kfb, dout, nullptr, B, R, Bp, st));
+      break;
+    case NMPC_HIP_FIELD_TRACE:
+      if(s->trace_rows != s->cfg.max_iter + 1)
+      {
+        return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "full trace was not recorded: set trace_level = 1 before solve");
+      }
+      NMPC_HIP_TRY(toMajor<double>(s->d_trace, dout, nullptr, B, R, Bp, st));
+      break;
+    case NMPC_HIP_FIELD_TRACE_LAST:
+      NMPC_HIP_TRY(toMajor<double>(s->d_trace_last, dout, nullptr, B, R, Bp, st));
+      break;
+    case NMPC_HIP_FIELD_DV:
+      NMPC_HIP_TRY(toMajor<double>(s->d_dV, dout, nullptr, B, R, Bp, st));
+      break;
+    case NMPC_HIP_FIELD_STATUS:
+      NMPC_HIP_TRY(hipMemcpyAsync(iout, s->d_status, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+      break;
+    case NMPC_HIP_FIELD_ITERS:
+      NMPC_HIP_TRY(hipMemcpyAsync(iout, s->d_iters, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+      break;
+    case NMPC_HIP_FIELD_QP_RETVAL:
+      NMPC_HIP_TRY(toMajor<int>(s->d_qp_ret, iout, nullptr, B, R, Bp, st));
+      break;
+    case NMPC_HIP_FIELD_INPUT_DIM:
+      NMPC_HIP_TRY(toMajor<int>(s->d_input_dim, iout, nullptr, B, R, Bp, st));
+      break;
+    case NMPC_HIP_FIELD_QP_FREE_MASK:
+      NMPC_HIP_TRY(toMajor<unsigned>(s->d_qp_free, static_cast<unsigned *>(d_out), nullptr, B, R, Bp, st));
+      break;
+    default:
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "unknown field");
+  }
+  return NMPC_HIP_OK;
+}
+
+/** Wait for the event triple in `slot` and fold its elapsed times into the running sums. */
+int harvestSlot(nmpc_hip_ddp_solver * s, int slot)
+{
+  if(!s->ev_pending[slot])
+  {
+    return NMPC_HIP_OK;
+  }
+  NMPC_HIP_TRY(hipEventSynchronize(s->ev_end[slot]));
+  float tot = 0, ker = 0;
+  NMPC_HIP_TRY(hipEventElapsedTime(&tot, s->ev_begin[slot], s->ev_end[slot]));
+  NMPC_HIP_TRY(hipEventElapsedTime(&ker, s->ev_kernel[slot], s->ev_end[slot]));
+  s->sum_total_ms += tot;
+  s->sum_kernel_ms += ker;
+  s->last_total_ms = tot;
+  s->last_kernel_ms = ker;
+  s->n_harvested++;
+  s->ev_pending[slot] = false;
+  return NMPC_HIP_OK;
+}
+
+int harvestAll(nmpc_hip_ddp_solver * s)
+{
+  // oldest first so that last_* end up describing the most recent solve
+  for(int k = 0; k < nmpc_hip_ddp_solver::kEvPool; k++)
+  {
+    const int slot = static_cast<int>((s->n_solves + k) % nmpc_hip_ddp_solver::kEvPool);
+    int rc = harvestSlot(s, slot);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+  }
+  return NMPC_HIP_OK;
+}
+
+int checkConfig(const nmpc_hip_ddp_solver * s, const nmpc_hip_ddp_config * c)
+{
+  if(c->horizon_steps != s->T)
+  {
+    return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "horizon_steps is fixed at create(): " + std::to_string(s->T) + " but "
+                                                   + std::to_string(c->horizon_steps) + ".");
+  }
+  if(c->use_state_eq_second_derivative)
+  {
+    // the reference throws here as well (DDPSolver.hpp:391-414)
+    return fail(NMPC_HIP_ERR_RUNTIME, "Vector-tensor product is not implemented yet.");
+  }
+  if(c->n_alpha < 1 || c->n_alpha > NMPC_HIP_MAX_ALPHA)
+  {
+    return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "alpha_list size must be in [1, 32]");
+  }
+  if(c->max_iter < 0)
+  {
+    return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "max_iter must be non-negative");
+  }
+  if(c->reg_type != 1 && c->reg_type != 2 && c->reg_type != 0)
+  {
+    return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "reg_type must be 1 or 2");
+  }
+  return NMPC_HIP_OK;
+}
+} // namespace
+
+extern "C"
+{
+  int nmpc_hip_ddp_register_model(const ModelOps * ops)
+  {
+    if(!ops || !ops->name)
+    {
+      return NMPC_HIP_ERR_INVALID_ARGUMENT;
+    }
+    if(findModel(ops->name))
+    {
+      return NMPC_HIP_OK; // already known (same translation unit loaded twice)
+    }
+    registry().push_back(ops);
+    return NMPC_HIP_OK;
+  }
+
+  const char * nmpc_hip_ddp_last_error(void)
+  {
+    return g_last_error.c_str();
+  }
+
+  int nmpc_hip_ddp_default_config(nmpc_hip_ddp_config * c)
+  {
+    if(!c)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "cfg is NULL");
+    }
+    std::memset(c, 0, sizeof(*c));
+    c->with_input_constraint = 0;
+    c->max_iter = 500;
+    c->horizon_steps = 100;
+    c->reg_type = 1;
+    c->initial_lambda = 1e-4;
+    c->initial_dlambda = 1.0;
+    c->lambda_factor = 1.6;
+    c->lambda_min = 1e-6;
+    c->lambda_max = 1e10;
+    c->k_rel_norm_thre = 1e-4;
+    c->lambda_thre = 1e-5;
+    c->cost_update_ratio_thre = 0;
+    c->cost_update_thre = 1e-7;
+    // alpha_list = 10^linspace(0, -3, 11)    (DDPSolver.h:50-60)
+    c->n_alpha = 11;
+    const double low = 0, high = -3;
+    const double step = (high - low) / (c->n_alpha - 1);
+    for(int i = 0; i < c->n_alpha; i++)
+    {
+      const double e = (i == c->n_alpha - 1) ? high : (low + i * step);
+      c->alpha_list[i] = std::pow(10, e);
+    }
+    c->use_state_eq_second_derivative = 0;
+    c->qp_max_iter = 500;
+    c->qp_grad_thre = 1e-8;
+    c->qp_rel_improve_thre = 1e-8;
+    c->qp_step_factor = 0.6;
+    c->qp_min_step = 1e-22;
+    c->qp_armijo_param = 0.1;
+    c->trace_level = 1;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_model_count(void)
+  {
+    return static_cast<int>(registry().size());
+  }
+
+  int nmpc_hip_ddp_model_name(int index, const char ** name)
+  {
+    if(index < 0 || index >= static_cast<int>(registry().size()) || !name)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "model index out of range");
+    }
+    *name = registry()[index]->name;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_model_info(const char * model,
+                              int * state_dim,
+                              int * input_dim_max,
+                              int * dynamic_input,
+                              size_t * param_bytes)
+  {
+    const ModelOps * m = findModel(model);
+    if(!m)
+    {
+      return fail(NMPC_HIP_ERR_UNKNOWN_MODEL, std::string("unknown model: ") + (model ? model : "(null)"));
+    }
+    if(state_dim)
+    {
+      *state_dim = m->state_dim;
+    }
+    if(input_dim_max)
+    {
+      *input_dim_max = m->input_dim_max;
+    }
+    if(dynamic_input)
+    {
+      *dynamic_input = m->dynamic_input;
+    }
+    if(param_bytes)
+    {
+      *param_bytes = m->param_bytes;
+    }
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_model_default_params(const char * model, void * out, size_t bytes)
+  {
+    const ModelOps * m = findModel(model);
+    if(!m)
+    {
+      return fail(NMPC_HIP_ERR_UNKNOWN_MODEL, std::string("unknown model: ") + (model ? model : "(null)"));
+    }
+    if(!out || bytes != m->param_bytes)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "params size should be " + std::to_string(m->param_bytes) + " but "
+                                                     + std::to_string(bytes) + ".");
+    }
+    m->default_params(out);
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_create(const char * model, int horizon_steps, int batch, int device, nmpc_hip_ddp_handle * out)
+  {
+    if(!out)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "out handle is NULL");
+    }
+    *out = nullptr;
+    const ModelOps * m = findModel(model);
+    if(!m)
+    {
+      return fail(NMPC_HIP_ERR_UNKNOWN_MODEL, std::string("unknown model: ") + (model ? model : "(null)"));
+    }
+    if(horizon_steps < 1 || batch < 1)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "horizon_steps and batch must be positive");
+    }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if(e != hipSuccess || n_dev < 1)
+    {
+      return fail(NMPC_HIP_ERR_NO_DEVICE, std::string("no HIP device available (") + hipGetErrorString(e)
+                                              + "); this library has no CPU fallback");
+    }
+    if(device < 0 || device >= n_dev)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "device index out of range");
+    }
+    NMPC_HIP_TRY(hipSetDevice(device));
+
+    nmpc_hip_ddp_solver * s = new nmpc_hip_ddp_solver();
+    s->ops = m;
+    s->device = device;
+    s->B = batch;
+    s->Bp = ((batch + 63) / 64) * 64;
+    s->T = horizon_steps;
+    s->N = m->state_dim;
+    s->M = m->input_dim_max;
+    s->MM = m->input_dim_max > 0 ? m->input_dim_max : 1;
+    nmpc_hip_ddp_default_config(&s->cfg);
+    s->cfg.horizon_steps = horizon_steps;
+    s->params.resize(m->param_bytes);
+    m->default_params(s->params.data());
+    for(int i = 0; i < nmpc_amd::hip::kMaxInputDim; i++)
+    {
+      s->lim_lo[i] = -INFINITY;
+      s->lim_hi[i] = INFINITY;
+    }
+
+    const size_t Bp = s->Bp, T = s->T, N = s->N, MM = s->MM;
+    int rc = NMPC_HIP_OK;
+    auto chk = [&](int r)
+    {
+      if(rc == NMPC_HIP_OK)
+      {
+        rc = r;
+      }
+    };
+    chk(devAlloc(&s->d_t0, Bp));
+    chk(devAlloc(&s->d_x0, N * Bp));
+    chk(devAlloc(&s->d_X, 2 * (T + 1) * N * Bp));
+    chk(devAlloc(&s->d_U, 2 * T * MM * Bp));
+    chk(devAlloc(&s->d_cost, 2 * (T + 1) * Bp));
+    chk(devAlloc(&s->d_kff, T * MM * Bp));
+    chk(devAlloc(&s->d_Kfb, T * N * MM * Bp));
+    chk(devAlloc(&s->d_trace_last, static_cast<size_t>(NMPC_HIP_NTRACE) * Bp));
+    chk(devAlloc(&s->d_dV, 2 * Bp));
+    chk(devAlloc(&s->d_status, Bp));
+    chk(devAlloc(&s->d_iters, Bp));
+    chk(devAlloc(&s->d_sel, Bp));
+    chk(devAlloc(&s->d_qp_ret, T * Bp));
+    chk(devAlloc(&s->d_qp_free, T * Bp));
+    chk(devAlloc(&s->d_input_dim, T * Bp));
+    if(rc == NMPC_HIP_OK)
+    {
+      rc = allocTrace(s);
+    }
+    if(rc == NMPC_HIP_OK && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
+    {
+      rc = fail(NMPC_HIP_ERR_HIP, "hipStreamCreate failed");
+    }
+    for(int i = 0; i < nmpc_hip_ddp_solver::kEvPool && rc == NMPC_HIP_OK; i++)
+    {
+      if(hipEventCreate(&s->ev_begin[i]) != hipSuccess || hipEventCreate(&s->ev_kernel[i]) != hipSuccess
+         || hipEventCreate(&s->ev_end[i]) != hipSuccess)
+      {
+        rc = fail(NMPC_HIP_ERR_HIP, "hipEventCreate failed");
+      }
+    }
+    if(rc != NMPC_HIP_OK)
+    {
+      std::string keep = g_last_error;
+      nmpc_hip_ddp_destroy(s);
+      g_last_error = keep;
+      return rc;
+    }
+    *out = s;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_destroy(nmpc_hip_ddp_handle s)
+  {
+    if(!s)
+    {
+      return NMPC_HIP_OK;
+    }
+    (void)hipSetDevice(s->device);
+    if(s->stream)
+    {
+      (void)hipStreamSynchronize(s->stream);
+    }
+    void * ptrs[] = {s->d_t0,     s->d_x0,     s->d_X,   s->d_U,      s->d_cost,    s->d_kff,       s->d_Kfb,
+                     s->d_trace,  s->d_trace_last, s->d_dV, s->d_status, s->d_iters, s->d_sel,     s->d_qp_ret,
+                     s->d_qp_free, s->d_input_dim, s->d_stage_in, s->d_stage_out};
+    for(void * p : ptrs)
+    {
+      if(p)
+      {
+        (void)hipFree(p);
+      }
+    }
+    for(int i = 0; i < nmpc_hip_ddp_solver::kEvPool; i++)
+    {
+      if(s->ev_begin[i])
+      {
+        (void)hipEventDestroy(s->ev_begin[i]);
+      }
+      if(s->ev_kernel[i])
+      {
+        (void)hipEventDestroy(s->ev_kernel[i]);
+      }
+      if(s->ev_end[i])
+      {
+        (void)hipEventDestroy(s->ev_end[i]);
+      }
+    }
+    if(s->stream)
+    {
+      (void)hipStreamDestroy(s->stream);
+    }
+    delete s;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_set_config(nmpc_hip_ddp_handle s, const nmpc_hip_ddp_config * cfg)
+  {
+    if(!s || !cfg)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or cfg");
+    }
+    int rc = checkConfig(s, cfg);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    s->cfg = *cfg; // kernels capture the configuration by value at launch, so no synchronisation is needed
+    return allocTrace(s); // (re)allocates, after a device synchronise, only when the trace size changes
+  }
+
+  int nmpc_hip_ddp_get_config(nmpc_hip_ddp_handle s, nmpc_hip_ddp_config * cfg)
+  {
+    if(!s || !cfg)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or cfg");
+    }
+    *cfg = s->cfg;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_set_model_params(nmpc_hip_ddp_handle s, const void * params, size_t bytes)
+  {
+    if(!s || !params)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or params");
+    }
+    if(bytes != s->ops->param_bytes)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "params size should be " + std::to_string(s->ops->param_bytes)
+                                                     + " but " + std::to_string(bytes) + ".");
+    }
+    std::memcpy(s->params.data(), params, bytes);
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_input_dims(nmpc_hip_ddp_handle s, double t0, int * out)
+  {
+    if(!s || !out)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output");
+    }
+    s->ops->input_dims(s->params.data(), t0, s->T, out);
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_set_input_limits(nmpc_hip_ddp_handle s, const double * lower, const double * upper)
+  {
+    if(!s || !lower || !upper)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or limits");
+    }
+    for(int i = 0; i < s->MM; i++)
+    {
+      s->lim_lo[i] = lower[i];
+      s->lim_hi[i] = upper[i];
+    }
+    s->has_limits = true;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_solve_device(nmpc_hip_ddp_handle s,
+                                const double * d_t0,
+                                const double * d_x0,
+                                const double * d_u_init,
+                                void * stream)
+  {
+    if(!s || !d_x0 || !d_u_init)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle, x0 or u_init");
+    }
+    if(s->cfg.with_input_constraint && !s->has_limits)
+    {
+      return fail(NMPC_HIP_ERR_RUNTIME, "with_input_constraint is set but no input limits were given "
+                                        "(setInputLimitsFunc, DDPSolver.h:282-285)");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
+    s->last_stream = st;
+    const int slot = static_cast<int>(s->n_solves % nmpc_hip_ddp_solver::kEvPool);
+    {
+      int hrc = harvestSlot(s, slot); // only blocks when 128 solves are in flight
+      if(hrc != NMPC_HIP_OK)
+      {
+        return hrc;
+      }
+    }
+    NMPC_HIP_TRY(hipEventRecord(s->ev_begin[slot], st));
+    // ingest: reference layouts -> instance-minor device layout
+    if(d_t0)
+    {
+      NMPC_HIP_TRY(hipMemcpyAsync(s->d_t0, d_t0, sizeof(double) * s->B, hipMemcpyDeviceToDevice, st));
+    }
+    else
+    {
+      NMPC_HIP_TRY(hipMemsetAsync(s->d_t0, 0, sizeof(double) * s->Bp, st));
+    }
+    NMPC_HIP_TRY(toMinor<double>(d_x0, s->d_x0, s->B, s->N, s->Bp, st));
+    NMPC_HIP_TRY(toMinor<double>(d_u_init, s->d_U, s->B, s->T * s->MM, s->Bp, st));
+    NMPC_HIP_TRY(hipEventRecord(s->ev_kernel[slot], st));
+    const DeviceBuffers buf = makeBuffers(s);
+    NMPC_HIP_TRY(s->ops->launch_solve(s->params.data(), s->cfg, buf, st));
+    NMPC_HIP_TRY(hipEventRecord(s->ev_end[slot], st));
+    s->ev_pending[slot] = true;
+    s->n_solves++;
+    s->solved = true;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_synchronize(nmpc_hip_ddp_handle s)
+  {
+    if(!s)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    NMPC_HIP_TRY(hipStreamSynchronize(s->last_stream ? s->last_stream : s->stream));
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_solve(nmpc_hip_ddp_handle s, const double * t0, const double * x0, const double * u_init)
+  {
+    if(!s || !x0 || !u_init)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle, x0 or u_init");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    const size_t nx = static_cast<size_t>(s->B) * s->N;
+    const size_t nu = static_cast<size_t>(s->B) * s->T * s->MM;
+    const size_t nt = static_cast<size_t>(s->B);
+    int rc = ensureStage(&s->d_stage_in, &s->stage_in_bytes, (nx + nu + nt) * sizeof(double));
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    double * dx = static_cast<double *>(s->d_stage_in);
+    double * du = dx + nx;
+    double * dt = du + nu;
+    NMPC_HIP_TRY(hipMemcpyAsync(dx, x0, nx * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    NMPC_HIP_TRY(hipMemcpyAsync(du, u_init, nu * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    if(t0)
+    {
+      NMPC_HIP_TRY(hipMemcpyAsync(dt, t0, nt * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    }
+    rc = nmpc_hip_ddp_solve_device(s, t0 ? dt : nullptr, dx, du, nullptr);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    NMPC_HIP_TRY(hipStreamSynchronize(s->stream));
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_field_bytes(nmpc_hip_ddp_handle s, int field, size_t * bytes)
+  {
+    if(!s || !bytes)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or bytes");
+    }
+    FieldInfo fi;
+    int rc = fieldInfo(s, field, &fi);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    *bytes = fi.rows * fi.elem * static_cast<size_t>(s->B);
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_get_device(nmpc_hip_ddp_handle s, int field, void * d_out, size_t bytes, void * stream)
+  {
+    if(!s || !d_out)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output");
+    }
+    if(!s->solved)
+    {
+      return fail(NMPC_HIP_ERR_NOT_SOLVED, "solve() has not been called");
+    }
+    size_t need = 0;
+    int rc = nmpc_hip_ddp_field_bytes(s, field, &need);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    if(bytes != need)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT,
+                  "field size should be " + std::to_string(need) + " but " + std::to_string(bytes) + ".");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : (s->last_stream ? s->last_stream : s->stream);
+    return packField(s, field, d_out, st);
+  }
+
+  int nmpc_hip_ddp_get(nmpc_hip_ddp_handle s, int field, void * out, size_t bytes)
+  {
+    if(!s || !out)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output");
+    }
+    if(!s->solved)
+    {
+      return fail(NMPC_HIP_ERR_NOT_SOLVED, "solve() has not been called");
+    }
+    size_t need = 0;
+    int rc = nmpc_hip_ddp_field_bytes(s, field, &need);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    if(bytes != need)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT,
+                  "field size should be " + std::to_string(need) + " but " + std::to_string(bytes) + ".");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = s->last_stream ? s->last_stream : s->stream;
+    rc = ensureStage(&s->d_stage_out, &s->stage_out_bytes, need);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    rc = packField(s, field, s->d_stage_out, st);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    NMPC_HIP_TRY(hipMemcpyAsync(out, s->d_stage_out, need, hipMemcpyDeviceToHost, st));
+    NMPC_HIP_TRY(hipStreamSynchronize(st));
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_last_solve_ms(nmpc_hip_ddp_handle s, float * total_ms, float * kernel_ms)
+  {
+    if(!s)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle");
+    }
+    if(!s->solved)
+    {
+      return fail(NMPC_HIP_ERR_NOT_SOLVED, "solve() has not been called");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    int rc = harvestAll(s);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    if(total_ms)
+    {
+      *total_ms = s->last_total_ms;
+    }
+    if(kernel_ms)
+    {
+      *kernel_ms = s->last_kernel_ms;
+    }
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_timing_stats(nmpc_hip_ddp_handle s,
+                                int reset,
+                                long long * n_solves,
+                                double * total_ms_sum,
+                                double * kernel_ms_sum)
+  {
+    if(!s)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    int rc = harvestAll(s);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    if(n_solves)
+    {
+      *n_solves = s->n_harvested;
+    }
+    if(total_ms_sum)
+    {
+      *total_ms_sum = s->sum_total_ms;
+    }
+    if(kernel_ms_sum)
+    {
+      *kernel_ms_sum = s->sum_kernel_ms;
+    }
+    if(reset)
+    {
+      s->n_harvested = 0;
+      s->sum_total_ms = 0;
+      s->sum_kernel_ms = 0;
+    }
+    return NMPC_HIP_OK;
+  }
+} // extern "C"

@@ -1,0 +1,332 @@
+"""Python mirror of the reference's nmpc_ddp::DDPSolver interface for a BATCH of problem instances.
+
+Same member names, argument meaning and error behaviour as
+/root/reference/nmpc_ddp/include/nmpc_ddp/DDPSolver.h:255-308 (`config()`, `solve()`, `setInputLimitsFunc()`,
+`controlData()`, `traceDataList()`, `computationDuration()`, `dumpTraceDataList()`), with a leading batch
+axis.  Everything numeric happens in libnmpc_hip_ddp.so through the C-ABI (include/nmpc_hip_ddp.h); this file
+only marshals arrays and re-raises status codes as the exception types the reference throws.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+from .models import _Problem
+
+
+class Configuration:
+    """DDPSolver::Configuration (DDPSolver.h:47-110).  Defaults come from the library
+    (nmpc_hip_ddp_default_config), not from Python."""
+
+    _PLAIN = ("with_input_constraint", "max_iter", "horizon_steps", "reg_type", "initial_lambda",
+              "initial_dlambda", "lambda_factor", "lambda_min", "lambda_max", "k_rel_norm_thre", "lambda_thre",
+              "cost_update_ratio_thre", "cost_update_thre", "use_state_eq_second_derivative", "qp_max_iter",
+              "qp_grad_thre", "qp_rel_improve_thre", "qp_step_factor", "qp_min_step", "qp_armijo_param",
+              "trace_level")
+
+    def __init__(self):
+        c = _capi.Config()
+        _capi.check(_capi.load().nmpc_hip_ddp_default_config(C.byref(c)))
+        self.print_level = 1  # host-side only (DDPSolver.h:62-63)
+        for k in self._PLAIN:
+            v = getattr(c, k)
+            setattr(self, k, bool(v) if k in ("with_input_constraint", "use_state_eq_second_derivative") else v)
+        self.alpha_list = np.array(c.alpha_list[: c.n_alpha], dtype=np.float64)
+
+    def to_c(self) -> _capi.Config:
+        c = _capi.Config()
+        for k in self._PLAIN:
+            setattr(c, k, int(getattr(self, k)) if isinstance(getattr(c, k), int) else float(getattr(self, k)))
+        a = np.asarray(self.alpha_list, dtype=np.float64).ravel()
+        if a.size > _capi.MAX_ALPHA:
+            raise ValueError(f"alpha_list supports at most {_capi.MAX_ALPHA} entries")
+        c.n_alpha = a.size
+        for i, v in enumerate(a):
+            c.alpha_list[i] = v
+        return c
+
+
+@dataclass
+class ControlData:
+    """DDPSolver::ControlData (DDPSolver.h:113-123) of one instance."""
+    x_list: np.ndarray  # (T+1, n)
+    u_list: List[np.ndarray]  # T vectors of size inputDim(t)
+    cost_list: np.ndarray  # (T+1,)
+
+
+@dataclass
+class TraceData:
+    """DDPSolver::TraceData (DDPSolver.h:179-216).  duration_* have no per-instance meaning on the GPU and are
+    0; alpha_idx / n_backward / n_forward are the discrete decisions of the iteration."""
+    iter: int = 0
+    cost: float = 0.0
+    lambda_: float = 0.0
+    dlambda: float = 0.0
+    alpha: float = 0.0
+    k_rel_norm: float = 0.0
+    cost_update_actual: float = 0.0
+    cost_update_expected: float = 0.0
+    cost_update_ratio: float = 0.0
+    duration_derivative: float = 0.0
+    duration_backward: float = 0.0
+    duration_forward: float = 0.0
+    alpha_idx: int = -1
+    n_backward: int = 0
+    n_forward: int = 0
+
+
+@dataclass
+class ComputationDuration:
+    """DDPSolver::ComputationDuration (DDPSolver.h:219-247) for the whole batch [msec]: `solve` is the HIP-event
+    time of ingest + solve kernel, `opt` the solve kernel alone, `setup` their difference.  The per-phase
+    splits of the reference are not separable inside the fused kernel; profiles/ holds rocprofv3 data."""
+    solve: float = 0.0
+    setup: float = 0.0
+    opt: float = 0.0
+
+
+class DDPSolverBatch:
+    """Batched DDP solver on one MI355X.
+
+    problem: a nmpc_amd.models problem handle (the reference passes std::shared_ptr<DDPProblem>, DDPSolver.h:255)
+    batch_size: number of independent instances solved per `solve()` call
+    """
+
+    def __init__(self, problem: _Problem, batch_size: int, device: int = 0):
+        self._L = _capi.load()
+        self.problem = problem
+        self.batch_size = int(batch_size)
+        self.device = int(device)
+        self.n, self.m_max, self.dynamic_input, _ = problem.dims()
+        self.mm = max(self.m_max, 1)
+        self._config = Configuration()
+        self._h = C.c_void_p()
+        self._h_T = None
+        self._limits = None
+        self._cache = {}
+
+    # ---- DDPSolver::config()  (DDPSolver.h:258-267) ----
+    def config(self) -> Configuration:
+        return self._config
+
+    # ---- DDPSolver::setInputLimitsFunc  (DDPSolver.h:282-285) ----
+    def setInputLimitsFunc(self, input_limits_func) -> None:
+        """input_limits_func(t) -> (lower, upper).  Only time-constant limits are supported on the device (the
+        only form the reference's callers use); the function is sampled once at t = 0."""
+        lo, up = input_limits_func(0.0)
+        self.setInputLimits(lo, up)
+
+    def setInputLimits(self, lower, upper) -> None:
+        lo = np.full(self.mm, -np.inf)
+        up = np.full(self.mm, np.inf)
+        lower = np.asarray(lower, dtype=np.float64).ravel()
+        upper = np.asarray(upper, dtype=np.float64).ravel()
+        lo[: lower.size] = lower
+        up[: upper.size] = upper
+        if lower.size == 1 and self.mm > 1:  # scalar limits apply to every input
+            lo[:] = lower[0]
+            up[:] = upper[0]
+        self._limits = (lo, up)
+
+    # ---- handle management ----
+    def _ensure_handle(self):
+        T = int(self._config.horizon_steps)
+        if self._h and self._h_T == T:
+            return
+        self.close()
+        _capi.check(self._L.nmpc_hip_ddp_create(self.problem.name.encode(), T, self.batch_size, self.device,
+                                                C.byref(self._h)))
+        self._h_T = T
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nmpc_hip_ddp_destroy(self._h)
+            self._h = C.c_void_p()
+            self._h_T = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _push_state(self):
+        self._ensure_handle()
+        _capi.check(self._L.nmpc_hip_ddp_set_model_params(self._h, C.byref(self.problem.blob),
+                                                          C.sizeof(self.problem.blob)))
+        c = self._config.to_c()
+        _capi.check(self._L.nmpc_hip_ddp_set_config(self._h, C.byref(c)))
+        if self._limits is not None:
+            lo, up = self._limits
+            _capi.check(self._L.nmpc_hip_ddp_set_input_limits(
+                self._h, lo.ctypes.data_as(C.POINTER(C.c_double)), up.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def inputDims(self, t0: float) -> np.ndarray:
+        """problem->inputDim(t0 + i dt) for every step of the horizon."""
+        self._push_state()
+        out = np.zeros(self._h_T, dtype=np.int32)
+        _capi.check(self._L.nmpc_hip_ddp_input_dims(self._h, float(t0), out.ctypes.data_as(C.POINTER(C.c_int))))
+        return out
+
+    def _pack_u(self, initial_u_list, current_t) -> np.ndarray:
+        """Accept either a padded array (B, T, MM) or nested sequences [b][i] -> vector of size inputDim(t).
+        Size checks reproduce DDPSolver.hpp:41-58."""
+        B, T, MM = self.batch_size, int(self._config.horizon_steps), self.mm
+        if isinstance(initial_u_list, np.ndarray) and initial_u_list.dtype != object:
+            u = np.asarray(initial_u_list, dtype=np.float64)
+            if u.ndim == 2 and MM == 1:
+                u = u[:, :, None]
+            if u.ndim != 3 or u.shape[0] != B:
+                raise ValueError(f"initial_u_list batch should be {B} but {u.shape[0] if u.ndim else 0}.")
+            if u.shape[1] != T:
+                raise ValueError(f"initial_u_list length should be {T} but {u.shape[1]}.")
+            if u.shape[2] != MM:
+                raise RuntimeError(f"initial_u dimension should be {MM} but {u.shape[2]}.")
+            return np.ascontiguousarray(u)
+        if len(initial_u_list) != B:
+            raise ValueError(f"initial_u_list batch should be {B} but {len(initial_u_list)}.")
+        u = np.zeros((B, T, MM))
+        for b, ul in enumerate(initial_u_list):
+            if len(ul) != T:
+                raise ValueError(f"initial_u_list length should be {T} but {len(ul)}.")
+            dims = self.inputDims(current_t[b]) if self.dynamic_input else None
+            for i, ui in enumerate(ul):
+                ui = np.asarray(ui, dtype=np.float64).ravel()
+                want = int(dims[i]) if dims is not None else self.m_max
+                if ui.size != want:
+                    raise RuntimeError(f"initial_u dimension should be {want} but {ui.size}. i: {i}, "
+                                       f"time: {current_t[b] + i * self.problem.dt()}")
+                u[b, i, : ui.size] = ui
+        return u
+
+    # ---- DDPSolver::solve  (DDPSolver.h:275, DDPSolver.hpp:26-141) ----
+    def solve(self, current_t, current_x, initial_u_list) -> np.ndarray:
+        """current_t: scalar or (B,), current_x: (B, n), initial_u_list: (B, T, MM) padded or nested lists.
+        Returns a bool array: True where the reference's solve() would return true (retval == 1)."""
+        B = self.batch_size
+        t0 = np.broadcast_to(np.asarray(current_t, dtype=np.float64), (B,)).copy()
+        x0 = np.ascontiguousarray(np.asarray(current_x, dtype=np.float64).reshape(B, self.n))
+        self._push_state()
+        u = self._pack_u(initial_u_list, t0)
+        dp = C.POINTER(C.c_double)
+        _capi.check(self._L.nmpc_hip_ddp_solve(self._h, t0.ctypes.data_as(dp), x0.ctypes.data_as(dp),
+                                               u.ctypes.data_as(dp)))
+        self._cache = {}
+        status = self.status()
+        if self._config.print_level >= 1:
+            n_fail = int((status < 0).sum())
+            if n_fail:
+                print(f"[DDP] Failure due to large lambda in {n_fail} of {B} instances.")
+        return status == 1
+
+    def solveDevice(self, d_t0: Optional[int], d_x0: int, d_u_init: int, stream: Optional[int] = None) -> None:
+        """Asynchronous solve from DEVICE pointers (integers, e.g. torch.Tensor.data_ptr()) in the reference
+        layouts; nothing crosses PCIe.  Call synchronize() before reading results."""
+        self._push_state()
+        _capi.check(self._L.nmpc_hip_ddp_solve_device(self._h, C.c_void_p(d_t0 or 0), C.c_void_p(d_x0),
+                                                      C.c_void_p(d_u_init), C.c_void_p(stream or 0)))
+        self._cache = {}
+
+    def synchronize(self) -> None:
+        _capi.check(self._L.nmpc_hip_ddp_synchronize(self._h))
+
+    # ---- results ----
+    def _field(self, field: int, dtype, shape) -> np.ndarray:
+        if field in self._cache:
+            return self._cache[field]
+        out = np.zeros(shape, dtype=dtype)
+        _capi.check(self._L.nmpc_hip_ddp_get(self._h, field, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        self._cache[field] = out
+        return out
+
+    def getDevice(self, field: int, d_out: int, nbytes: int, stream: Optional[int] = None) -> None:
+        """Pack one result field (reference layout) into DEVICE memory, e.g. an RCCL send buffer."""
+        _capi.check(self._L.nmpc_hip_ddp_get_device(self._h, field, C.c_void_p(d_out), nbytes,
+                                                    C.c_void_p(stream or 0)))
+
+    def X(self) -> np.ndarray:
+        return self._field(_capi.FIELD_X, np.float64, (self.batch_size, self._h_T + 1, self.n))
+
+    def U(self) -> np.ndarray:
+        return self._field(_capi.FIELD_U, np.float64, (self.batch_size, self._h_T, self.mm))
+
+    def cost(self) -> np.ndarray:
+        return self._field(_capi.FIELD_COST, np.float64, (self.batch_size, self._h_T + 1))
+
+    def kff(self) -> np.ndarray:
+        return self._field(_capi.FIELD_KFF, np.float64, (self.batch_size, self._h_T, self.mm))
+
+    def Kfb(self) -> np.ndarray:
+        """(B, T, MM, n): Kfb()[b, t] is the m x n feedback gain of step t."""
+        raw = self._field(_capi.FIELD_KFB, np.float64, (self.batch_size, self._h_T, self.n, self.mm))
+        return raw.transpose(0, 1, 3, 2)
+
+    def status(self) -> np.ndarray:
+        return self._field(_capi.FIELD_STATUS, np.int32, (self.batch_size,))
+
+    def iters(self) -> np.ndarray:
+        return self._field(_capi.FIELD_ITERS, np.int32, (self.batch_size,))
+
+    def trace(self) -> np.ndarray:
+        """(B, max_iter+1, 12); rows beyond iters[b] are zero.  Needs config().trace_level >= 1."""
+        return self._field(_capi.FIELD_TRACE, np.float64,
+                           (self.batch_size, int(self._config.max_iter) + 1, _capi.NTRACE))
+
+    def traceLast(self) -> np.ndarray:
+        return self._field(_capi.FIELD_TRACE_LAST, np.float64, (self.batch_size, _capi.NTRACE))
+
+    def dV(self) -> np.ndarray:
+        return self._field(_capi.FIELD_DV, np.float64, (self.batch_size, 2))
+
+    def qpRetval(self) -> np.ndarray:
+        return self._field(_capi.FIELD_QP_RETVAL, np.int32, (self.batch_size, self._h_T))
+
+    def qpFreeMask(self) -> np.ndarray:
+        return self._field(_capi.FIELD_QP_FREE_MASK, np.uint32, (self.batch_size, self._h_T))
+
+    def inputDimList(self) -> np.ndarray:
+        return self._field(_capi.FIELD_INPUT_DIM, np.int32, (self.batch_size, self._h_T))
+
+    # ---- DDPSolver::controlData()  (DDPSolver.h:288-291) ----
+    def controlData(self, b: int) -> ControlData:
+        dims = self.inputDimList()[b]
+        U = self.U()[b]
+        return ControlData(self.X()[b], [U[i, : dims[i]].copy() for i in range(self._h_T)], self.cost()[b])
+
+    # ---- DDPSolver::traceDataList()  (DDPSolver.h:294-297) ----
+    def traceDataList(self, b: int) -> List[TraceData]:
+        tr = self.trace()[b]
+        n = int(self.iters()[b]) + 1
+        out = []
+        for r in tr[:n]:
+            out.append(TraceData(iter=int(r[0]), cost=r[1], lambda_=r[2], dlambda=r[3], alpha=r[4], k_rel_norm=r[5],
+                                 cost_update_actual=r[6], cost_update_expected=r[7], cost_update_ratio=r[8],
+                                 alpha_idx=int(r[9]), n_backward=int(r[10]), n_forward=int(r[11])))
+        return out
+
+    # ---- DDPSolver::computationDuration()  (DDPSolver.h:300-303) ----
+    def computationDuration(self) -> ComputationDuration:
+        tot, ker = C.c_float(), C.c_float()
+        _capi.check(self._L.nmpc_hip_ddp_last_solve_ms(self._h, C.byref(tot), C.byref(ker)))
+        return ComputationDuration(solve=tot.value, setup=tot.value - ker.value, opt=ker.value)
+
+    def timingStats(self, reset: bool = False):
+        """(number of device solves, sum of ingest+kernel ms, sum of solve-kernel ms) since the last reset."""
+        n, tot, ker = C.c_longlong(), C.c_double(), C.c_double()
+        _capi.check(self._L.nmpc_hip_ddp_timing_stats(self._h, 1 if reset else 0, C.byref(n), C.byref(tot),
+                                                      C.byref(ker)))
+        return n.value, tot.value, ker.value
+
+    # ---- DDPSolver::dumpTraceDataList  (DDPSolver.hpp:562-598): same 12 columns, same separator ----
+    def dumpTraceDataList(self, b: int, file_path: str) -> None:
+        with open(file_path, "w") as f:
+            f.write("iter cost lambda dlambda alpha k_rel_norm cost_update_actual cost_update_expected "
+                    "cost_update_ratio duration_derivative duration_backward duration_forward\n")
+            for t in self.traceDataList(b):
+                f.write(f"{t.iter} {t.cost:g} {t.lambda_:g} {t.dlambda:g} {t.alpha:g} {t.k_rel_norm:g} "
+                        f"{t.cost_update_actual:g} {t.cost_update_expected:g} {t.cost_update_ratio:g} "
+                        f"{t.duration_derivative:g} {t.duration_backward:g} {t.duration_forward:g}\n")

@@ -72,8 +72,10 @@ struct Unroll
 };
 } // namespace detail
 
-/** One DDP problem instance, executed by one lane. */
-template<class Problem>
+/** One DDP problem instance, executed by one lane.
+    \tparam kConstrained compile-time value of Configuration::with_input_constraint (DDPSolver.h:70): the
+    unconstrained kernel carries no BoxQP code or registers */
+template<class Problem, bool kConstrained>
 struct InstanceSolver
 {
   static constexpr int N = Problem::kStateDim;
@@ -111,25 +113,53 @@ struct InstanceSolver
   }
 
   // ---- addressing (instance-minor) ----
-  NMPC_D double * xPtr(int s, int i) const
+  // Every access is  UNIFORM row pointer (SGPR pair, advanced by scalar code)  +  per-lane 32-bit byte offset
+  // (one VGPR), the form the global_load/store "saddr + voffset" encoding takes directly: no 64-bit vector
+  // address arithmetic per access.  The lane offset also selects the current / candidate half.
+  NMPC_D static double ld(const double * row, unsigned lane_off)
   {
-    return buf.X + ((static_cast<size_t>(s) * (T + 1) + i) * N) * Bp + b;
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(row) + lane_off);
   }
-  NMPC_D double * uPtr(int s, int i) const
+  NMPC_D static void st(double * row, unsigned lane_off, double v)
   {
-    return buf.U + ((static_cast<size_t>(s) * T + i) * MM) * Bp + b;
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(row) + lane_off) = v;
   }
-  NMPC_D double * costPtr(int s, int i) const
+  NMPC_D double * xRow(int i) const
   {
-    return buf.cost + (static_cast<size_t>(s) * (T + 1) + i) * Bp + b;
+    return buf.X + (static_cast<size_t>(i) * N) * Bp;
   }
-  NMPC_D double * kPtr(int i) const
+  NMPC_D double * uRow(int i) const
   {
-    return buf.kff + (static_cast<size_t>(i) * MM) * Bp + b;
+    return buf.U + (static_cast<size_t>(i) * MM) * Bp;
   }
-  NMPC_D double * KPtr(int i) const
+  NMPC_D double * costRow(int i) const
   {
-    return buf.Kfb + (static_cast<size_t>(i) * (N * MM)) * Bp + b;
+    return buf.cost + static_cast<size_t>(i) * Bp;
+  }
+  NMPC_D double * kRow(int i) const
+  {
+    return buf.kff + (static_cast<size_t>(i) * MM) * Bp;
+  }
+  NMPC_D double * KRow(int i) const
+  {
+    return buf.Kfb + (static_cast<size_t>(i) * (N * MM)) * Bp;
+  }
+  //! per-lane byte offsets of half s (0 / 1) of X, U, cost; offB addresses single-copy arrays
+  NMPC_D unsigned offX(int s) const
+  {
+    return (static_cast<unsigned>(s) * static_cast<unsigned>((T + 1) * N) * static_cast<unsigned>(Bp) + b) * 8u;
+  }
+  NMPC_D unsigned offU(int s) const
+  {
+    return (static_cast<unsigned>(s) * static_cast<unsigned>(T * MM) * static_cast<unsigned>(Bp) + b) * 8u;
+  }
+  NMPC_D unsigned offC(int s) const
+  {
+    return (static_cast<unsigned>(s) * static_cast<unsigned>(T + 1) * static_cast<unsigned>(Bp) + b) * 8u;
+  }
+  NMPC_D unsigned offB() const
+  {
+    return static_cast<unsigned>(b) * 8u;
   }
 
   NMPC_D int inputDimAt(double t) const
@@ -144,37 +174,37 @@ struct InstanceSolver
     }
   }
 
-  NMPC_D void loadX(const double * p, StateDimVector & x) const
+  NMPC_D void loadX(const double * row, unsigned off, StateDimVector & x) const
   {
 #pragma unroll
     for(int j = 0; j < N; j++)
     {
-      x[j] = p[j * Bp];
+      x[j] = ld(row + j * Bp, off);
     }
   }
-  NMPC_D void storeX(double * p, const StateDimVector & x) const
+  NMPC_D void storeX(double * row, unsigned off, const StateDimVector & x) const
   {
 #pragma unroll
     for(int j = 0; j < N; j++)
     {
-      p[j * Bp] = x[j];
+      st(row + j * Bp, off, x[j]);
     }
   }
-  NMPC_D void loadU(const double * p, InputDimVector & u, int m) const
+  NMPC_D void loadU(const double * row, unsigned off, InputDimVector & u, int m) const
   {
     u.resize(m);
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
-      u[a] = (a < m) ? p[a * Bp] : 0.0;
+      u[a] = (a < m) ? ld(row + a * Bp, off) : 0.0;
     }
   }
-  NMPC_D void storeU(double * p, const InputDimVector & u, int m) const
+  NMPC_D void storeU(double * row, unsigned off, const InputDimVector & u, int m) const
   {
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
-      p[a * Bp] = (a < m) ? u[a] : 0.0;
+      st(row + a * Bp, off, (a < m) ? u[a] : 0.0);
     }
   }
 
@@ -183,9 +213,10 @@ struct InstanceSolver
   // -------------------------------------------------------------------------------------------------
   NMPC_D void initialRollout()
   {
+    const unsigned ox = offX(sel), ou = offU(sel), oc = offC(sel);
     StateDimVector x;
-    loadX(buf.x0 + b, x);
-    storeX(xPtr(sel, 0), x);
+    loadX(buf.x0, offB(), x);
+    storeX(xRow(0), ox, x);
     double J = 0;
     for(int i = 0; i < T; i++)
     {
@@ -193,18 +224,18 @@ struct InstanceSolver
       const int m = inputDimAt(t);
       buf.input_dim[static_cast<size_t>(i) * Bp + b] = m;
       InputDimVector u;
-      loadU(uPtr(sel, i), u, m);
-      storeU(uPtr(sel, i), u, m); // zero the padding beyond inputDim(t)
+      loadU(uRow(i), ou, u, m);
+      storeU(uRow(i), ou, u, m); // zero the padding beyond inputDim(t)
       const StateDimVector xn = problem.stateEq(t, x, u);
       const double c = problem.runningCost(t, x, u);
-      *costPtr(sel, i) = c;
+      st(costRow(i), oc, c);
       J += c;
-      storeX(xPtr(sel, i + 1), xn);
+      storeX(xRow(i + 1), ox, xn);
       x = xn;
     }
     const double terminal_t = current_t + T * problem.dt();
     const double cT = problem.terminalCost(terminal_t, x);
-    *costPtr(sel, T) = cT;
+    st(costRow(T), oc, cT);
     J += cT;
     J_cur = J;
   }
@@ -212,10 +243,54 @@ struct InstanceSolver
   // -------------------------------------------------------------------------------------------------
   // dense helpers on per-lane arrays (column-major)
   // -------------------------------------------------------------------------------------------------
-  /** Unblocked lower Cholesky in place, leading dimension LD; fails (returns false) iff a pivot is <= 0
-      (a NaN pivot passes), as Eigen::LLT does (DDPSolver.hpp:500-508, BoxQP.h:229-238). */
+  /** s += a * b, skipping factors that the COMPILER knows to be structurally 0 or 1.
+      After the problem functor is inlined and the loops are unrolled, the entries a model writes as literal
+      0 / 1 (state_eq_deriv_x.setZero(), identity diagonals, diagonal cost Hessians) are compile-time
+      constants; __builtin_constant_p folds after inlining, so those terms cost no instruction while entries
+      that are run-time values take the ordinary FMA path with no branch.  Dropping x + 0*y is exact for finite
+      y (it differs from the reference only where that would have produced NaN from 0*Inf). */
+  NMPC_D static void macc(double & s, double a, double b)
+  {
+    if((__builtin_constant_p(a) && a == 0.0) || (__builtin_constant_p(b) && b == 0.0))
+    {
+      return;
+    }
+    const bool a_one = __builtin_constant_p(a) && a == 1.0;
+    const bool b_one = __builtin_constant_p(b) && b == 1.0;
+    const double p = a_one ? b : (b_one ? a : a * b);
+    if(__builtin_constant_p(s) && s == 0.0)
+    {
+      s = p;
+    }
+    else
+    {
+      s += p;
+    }
+  }
+
+  /** l + s, skipping a structurally-zero l. */
+  NMPC_D static double addc(double l, double s)
+  {
+    if(__builtin_constant_p(l) && l == 0.0)
+    {
+      return s;
+    }
+    if(__builtin_constant_p(s) && s == 0.0)
+    {
+      return l;
+    }
+    return l + s;
+  }
+
+  /** In-place factorisation A = L D L^T of the leading n x n block (leading dimension LD): on exit the strict
+      lower part holds the unit-lower L and inv_d[k] = 1 / d_k.
+      d_k is the same quantity as the squared Cholesky pivot of Eigen::LLT (A_kk minus the already eliminated
+      part), so the failure test "pivot <= 0" (NaN passes) selects the same matrices as the reference's
+      LLT::info() == NumericalIssue (DDPSolver.hpp:500-508, BoxQP.h:229-238) up to rounding of the pivot.
+      One reciprocal per pivot replaces LLT's sqrt + 2 divisions per right-hand-side entry: on gfx950 an fp64
+      divide costs ~10 FMAs and a sqrt ~13 (profiles/ubench_r01.txt). */
   template<int LD>
-  NMPC_D static bool lltInPlace(double * A, int n)
+  NMPC_D static bool ldltInPlace(double * A, double * inv_d, int n)
   {
     bool ok = true;
 #pragma unroll kU
@@ -223,23 +298,24 @@ struct InstanceSolver
     {
       if(k < n && ok)
       {
-        double x = A[k + k * LD];
+        double d = A[k + k * LD];
 #pragma unroll kU
         for(int j = 0; j < LD; j++)
         {
           if(j < k)
           {
-            x -= A[k + j * LD] * A[k + j * LD];
+            d -= (A[k + j * LD] * A[k + j * LD]) * A[j + j * LD];
           }
         }
-        if(x <= 0)
+        if(d <= 0)
         {
           ok = false;
         }
         else
         {
-          x = sqrt(x);
-          A[k + k * LD] = x;
+          A[k + k * LD] = d;
+          const double r = 1.0 / d;
+          inv_d[k] = r;
 #pragma unroll kU
           for(int i = 0; i < LD; i++)
           {
@@ -251,10 +327,10 @@ struct InstanceSolver
               {
                 if(j < k)
                 {
-                  s -= A[i + j * LD] * A[k + j * LD];
+                  s -= (A[i + j * LD] * A[k + j * LD]) * A[j + j * LD];
                 }
               }
-              A[i + k * LD] = s / x;
+              A[i + k * LD] = s * r;
             }
           }
         }
@@ -263,9 +339,9 @@ struct InstanceSolver
     return ok;
   }
 
-  /** Solve L L^T x = rhs in place for one right-hand side with element stride RS. */
+  /** Solve (L D L^T) x = rhs in place for one right-hand side with element stride RS. */
   template<int LD, int RS>
-  NMPC_D static void lltSolveInPlace(const double * L, int n, double * rhs)
+  NMPC_D static void ldltSolveInPlace(const double * A, const double * inv_d, int n, double * rhs)
   {
 #pragma unroll kU
     for(int i = 0; i < LD; i++)
@@ -278,10 +354,10 @@ struct InstanceSolver
         {
           if(j < i)
           {
-            s -= L[i + j * LD] * rhs[j * RS];
+            s -= A[i + j * LD] * rhs[j * RS];
           }
         }
-        rhs[i * RS] = s / L[i + i * LD];
+        rhs[i * RS] = s;
       }
     }
 #pragma unroll kU
@@ -290,27 +366,28 @@ struct InstanceSolver
       const int i = LD - 1 - ii;
       if(i < n)
       {
-        double s = rhs[i * RS];
+        double s = rhs[i * RS] * inv_d[i];
 #pragma unroll kU
         for(int j = 0; j < LD; j++)
         {
           if(j > i && j < n)
           {
-            s -= L[j + i * LD] * rhs[j * RS];
+            s -= A[j + i * LD] * rhs[j * RS];
           }
         }
-        rhs[i * RS] = s / L[i + i * LD];
+        rhs[i * RS] = s;
       }
     }
   }
 
   // -------------------------------------------------------------------------------------------------
-  // BoxQP::solve    BoxQP.h:141-347   (H, llt: leading dimension MM)
+  // BoxQP::solve    BoxQP.h:141-347   (H, factor: leading dimension MM)
   // -------------------------------------------------------------------------------------------------
   struct QPOut
   {
     double x[MM];
-    double llt_free[MM * MM]; //!< lower factor of H[free, free], leading dimension MM
+    double fac[MM * MM]; //!< L D L^T factor of H[free, free], leading dimension MM (llt_free_, BoxQP.h:386)
+    double inv_d[MM];
     int free_idx[MM];
     int n_free;
     int retval;
@@ -433,10 +510,10 @@ struct InstanceSolver
         {
           for(int j = 0; j < nf; j++)
           {
-            out.llt_free[i + j * MM] = H[out.free_idx[i] + out.free_idx[j] * MM];
+            out.fac[i + j * MM] = H[out.free_idx[i] + out.free_idx[j] * MM];
           }
         }
-        if(!lltInPlace<MM>(out.llt_free, nf))
+        if(!ldltInPlace<MM>(out.fac, out.inv_d, nf))
         {
           out.retval = -1;
           break;
@@ -469,7 +546,7 @@ struct InstanceSolver
         }
         rhs[i] = g[out.free_idx[i]] + s;
       }
-      lltSolveInPlace<MM, 1>(out.llt_free, nf, rhs);
+      ldltSolveInPlace<MM, 1>(out.fac, out.inv_d, nf, rhs);
 #pragma unroll kU
       for(int i = 0; i < MM; i++)
       {
@@ -545,7 +622,7 @@ struct InstanceSolver
       // calcTerminalCostDeriv at x[T]    :179-180, :346-347
       StateDimVector xT, vx;
       StateStateDimMatrix vxx;
-      loadX(xPtr(sel, T), xT);
+      loadX(xRow(T), offX(sel), xT);
       problem.calcTerminalCostDeriv(current_t + T * problem.dt(), xT, vx, vxx);
 #pragma unroll kU
       for(int j = 0; j < N; j++)
@@ -570,16 +647,27 @@ struct InstanceSolver
       k_next[a] = 0;
     }
 
+    // software prefetch: (x, u) of step i-1 are requested while step i is being processed
+    StateDimVector x_pref;
+    InputDimVector u_pref;
+    const unsigned ox = offX(sel), ou = offU(sel), ob = offB();
+    loadX(xRow(T - 1), ox, x_pref);
+    loadU(uRow(T - 1), ou, u_pref, MM);
+
     for(int i = T - 1; i >= 0 && ok; i--)
     {
       const double t = current_t + i * problem.dt();
       const int m = inputDimAt(t);
 
       // ---- Step 1 of procOnce for this timestep: derivatives at (x_i, u_i)    :160-178
-      StateDimVector x;
-      InputDimVector u;
-      loadX(xPtr(sel, i), x);
-      loadU(uPtr(sel, i), u, m);
+      StateDimVector x = x_pref;
+      InputDimVector u = u_pref;
+      u.resize(m);
+      if(i > 0)
+      {
+        loadX(xRow(i - 1), ox, x_pref);
+        loadU(uRow(i - 1), ou, u_pref, MM);
+      }
       StateStateDimMatrix Fx, Lxx;
       StateInputDimMatrix Fu, Lxu;
       StateDimVector Lx;
@@ -604,9 +692,9 @@ struct InstanceSolver
 #pragma unroll kU
           for(int r = 0; r < N; r++)
           {
-            s += Fu(r, a) * Vx[r];
+            macc(s, Fu(r, a), Vx[r]);
           }
-          Qu[a] = Lu[a] + s;
+          Qu[a] = addc(Lu[a], s);
         }
       }
 #pragma unroll kU
@@ -616,9 +704,9 @@ struct InstanceSolver
 #pragma unroll kU
         for(int r = 0; r < N; r++)
         {
-          s += Fx(r, a) * Vx[r];
+          macc(s, Fx(r, a), Vx[r]);
         }
-        Qx[a] = Lx[a] + s;
+        Qx[a] = addc(Lx[a], s);
       }
 #pragma unroll kU
       for(int c = 0; c < N; c++)
@@ -632,7 +720,7 @@ struct InstanceSolver
 #pragma unroll kU
             for(int r = 0; r < N; r++)
             {
-              s += Fu(r, a) * Vxx[r + c * N];
+              macc(s, Fu(r, a), Vxx[r + c * N]);
             }
             FuT_V[a + c * MM] = s;
           }
@@ -650,9 +738,9 @@ struct InstanceSolver
 #pragma unroll kU
             for(int r = 0; r < N; r++)
             {
-              s += FuT_V[a + r * MM] * Fx(r, c);
+              macc(s, FuT_V[a + r * MM], Fx(r, c));
             }
-            Qux[a + c * MM] = Lxu(c, a) + s;
+            Qux[a + c * MM] = addc(Lxu(c, a), s);
           }
         }
       }
@@ -668,9 +756,9 @@ struct InstanceSolver
 #pragma unroll kU
             for(int r = 0; r < N; r++)
             {
-              s += FuT_V[a + r * MM] * Fu(r, bb);
+              macc(s, FuT_V[a + r * MM], Fu(r, bb));
             }
-            Quu[a + bb * MM] = Luu(a, bb) + s;
+            Quu[a + bb * MM] = addc(Luu(a, bb), s);
           }
         }
       }
@@ -686,7 +774,7 @@ struct InstanceSolver
 #pragma unroll kU
             for(int r = 0; r < N; r++)
             {
-              s += Fx(r, a) * Vxx[r + c * N];
+              macc(s, Fx(r, a), Vxx[r + c * N]);
             }
             FxT_V[a + c * N] = s;
           }
@@ -701,9 +789,9 @@ struct InstanceSolver
 #pragma unroll kU
             for(int r = 0; r < N; r++)
             {
-              s += FxT_V[a + r * N] * Fx(r, c);
+              macc(s, FxT_V[a + r * N], Fx(r, c));
             }
-            Qxx[a + c * N] = Lxx(a, c) + s;
+            Qxx[a + c * N] = addc(Lxx(a, c), s);
           }
         }
       }
@@ -712,8 +800,7 @@ struct InstanceSolver
       double Qux_reg[MM * N], Quu_F[MM * MM];
       if(cfg.reg_type == 2)
       {
-        // Vxx_reg = Vxx + lambda I: Fu^T Vxx_reg = Fu^T Vxx with lambda * Fu^T added entrywise before the sum
-        // is NOT what the reference does; recompute the products from Vxx_reg as written there.
+        // Vxx_reg = Vxx + lambda I: recompute the products from Vxx_reg as the reference writes them
 #pragma unroll kU
         for(int c = 0; c < N; c++)
         {
@@ -727,7 +814,7 @@ struct InstanceSolver
               for(int r = 0; r < N; r++)
               {
                 const double v = (r == c) ? (Vxx[r + c * N] + lambda) : Vxx[r + c * N];
-                s += Fu(r, a) * v;
+                macc(s, Fu(r, a), v);
               }
               FuT_V[a + c * MM] = s;
             }
@@ -745,9 +832,9 @@ struct InstanceSolver
 #pragma unroll kU
               for(int r = 0; r < N; r++)
               {
-                s += FuT_V[a + r * MM] * Fx(r, c);
+                macc(s, FuT_V[a + r * MM], Fx(r, c));
               }
-              Qux_reg[a + c * MM] = Lxu(c, a) + s;
+              Qux_reg[a + c * MM] = addc(Lxu(c, a), s);
             }
           }
         }
@@ -763,9 +850,9 @@ struct InstanceSolver
 #pragma unroll kU
               for(int r = 0; r < N; r++)
               {
-                s += FuT_V[a + r * MM] * Fu(r, bb);
+                macc(s, FuT_V[a + r * MM], Fu(r, bb));
               }
-              Quu_F[a + bb * MM] = Luu(a, bb) + s;
+              Quu_F[a + bb * MM] = addc(Luu(a, bb), s);
             }
           }
         }
@@ -804,7 +891,7 @@ struct InstanceSolver
       }
       if(m > 0)
       {
-        if(cfg.with_input_constraint)
+        if constexpr(kConstrained)
         {
           double initial_k[MM], lo[MM], up[MM];
 #pragma unroll kU
@@ -845,7 +932,7 @@ struct InstanceSolver
                 {
                   col[j] = Qux_reg[qp.free_idx[j] + c * MM];
                 }
-                lltSolveInPlace<MM, 1>(qp.llt_free, qp.n_free, col);
+                ldltSolveInPlace<MM, 1>(qp.fac, qp.inv_d, qp.n_free, col);
                 for(int j = 0; j < qp.n_free; j++)
                 {
                   K[qp.free_idx[j] + c * MM] = -1 * col[j];
@@ -856,14 +943,14 @@ struct InstanceSolver
         }
         else
         {
-          // LLT(Quu_F); k = -solve(Qu); K = -solve(Qux_reg)    :500-510
-          double L[MM * MM];
+          // LLT(Quu_F); k = -solve(Qu); K = -solve(Qux_reg)    :500-510  (as L D L^T, see ldltInPlace)
+          double fac[MM * MM], inv_d[MM];
 #pragma unroll kU
           for(int e = 0; e < MM * MM; e++)
           {
-            L[e] = Quu_F[e];
+            fac[e] = Quu_F[e];
           }
-          if(!lltInPlace<MM>(L, m))
+          if(!ldltInPlace<MM>(fac, inv_d, m))
           {
             ok = false;
           }
@@ -874,7 +961,7 @@ struct InstanceSolver
             {
               k[a] = Qu[a];
             }
-            lltSolveInPlace<MM, 1>(L, m, k);
+            ldltSolveInPlace<MM, 1>(fac, inv_d, m, k);
 #pragma unroll kU
             for(int a = 0; a < MM; a++)
             {
@@ -888,7 +975,7 @@ struct InstanceSolver
               {
                 K[a + c * MM] = Qux_reg[a + c * MM];
               }
-              lltSolveInPlace<MM, 1>(L, m, &K[c * MM]);
+              ldltSolveInPlace<MM, 1>(fac, inv_d, m, &K[c * MM]);
 #pragma unroll kU
               for(int a = 0; a < MM; a++)
               {
@@ -912,14 +999,14 @@ struct InstanceSolver
         {
           if(a < m)
           {
-            kQu += k[a] * Qu[a];
+            macc(kQu, k[a], Qu[a]);
             double s = 0;
 #pragma unroll kU
             for(int bb = 0; bb < MM; bb++)
             {
               if(bb < m)
               {
-                s += Quu[a + bb * MM] * k[bb];
+                macc(s, Quu[a + bb * MM], k[bb]);
               }
             }
             Quu_k[a] = s;
@@ -930,7 +1017,7 @@ struct InstanceSolver
         {
           if(a < m)
           {
-            kQuuk += k[a] * Quu_k[a];
+            macc(kQuuk, k[a], Quu_k[a]);
           }
         }
         dV0 += kQu;
@@ -949,7 +1036,7 @@ struct InstanceSolver
           {
             if(p < m && a < m)
             {
-              s += K[p + r * MM] * Quu[p + a * MM];
+              macc(s, K[p + r * MM], Quu[p + a * MM]);
             }
           }
           KtQuu[r + a * N] = s;
@@ -965,9 +1052,9 @@ struct InstanceSolver
         {
           if(a < m)
           {
-            s1 += KtQuu[r + a * N] * k[a];
-            s2 += K[a + r * MM] * Qu[a];
-            s3 += Qux[a + r * MM] * k[a];
+            macc(s1, KtQuu[r + a * N], k[a]);
+            macc(s2, K[a + r * MM], Qu[a]);
+            macc(s3, Qux[a + r * MM], k[a]);
           }
         }
         Vx[r] = ((Qx[r] + s1) + s2) + s3;
@@ -984,9 +1071,9 @@ struct InstanceSolver
           {
             if(a < m)
             {
-              s1 += KtQuu[r + a * N] * K[a + c * MM];
-              s2 += K[a + r * MM] * Qux[a + c * MM];
-              s3 += Qux[a + r * MM] * K[a + c * MM];
+              macc(s1, KtQuu[r + a * N], K[a + c * MM]);
+              macc(s2, K[a + r * MM], Qux[a + c * MM]);
+              macc(s3, Qux[a + r * MM], K[a + c * MM]);
             }
           }
           Vxx_new[r + c * N] = ((Qxx[r + c * N] + s1) + s2) + s3;
@@ -1004,13 +1091,13 @@ struct InstanceSolver
 
       // ---- save gains    :529-530, and the running max of |k_i| / (|u_i| + 1)    :217-221
       {
-        double * kp = kPtr(i);
-        double * Kp = KPtr(i);
+        double * kp = kRow(i);
+        double * Kp = KRow(i);
         double kn = 0, un = 0;
 #pragma unroll kU
         for(int a = 0; a < MM; a++)
         {
-          kp[a * Bp] = k[a];
+          st(kp + a * Bp, ob, k[a]);
           k_next[a] = k[a];
           if(a < m)
           {
@@ -1021,10 +1108,13 @@ struct InstanceSolver
 #pragma unroll kU
         for(int e = 0; e < MM * N; e++)
         {
-          Kp[e * Bp] = K[e];
+          st(Kp + e * Bp, ob, K[e]);
         }
         m_next = m;
-        k_rel_norm = fmax(k_rel_norm, sqrt(kn) / (sqrt(un) + 1.0));
+        // for m == 1 the two norms are |k| and |u| exactly (sqrt(x*x) == |x| up to under/overflow)
+        const double knorm = (M == 1) ? fabs(k[0]) : sqrt(kn);
+        const double unorm = (M == 1) ? fabs(u[0]) : sqrt(un);
+        k_rel_norm = fmax(k_rel_norm, knorm / (unorm + 1.0));
       }
     }
     return ok;
@@ -1035,22 +1125,64 @@ struct InstanceSolver
   // -------------------------------------------------------------------------------------------------
   NMPC_D void forwardPass(double alpha)
   {
-    const int cs = 1 - sel;
+    const unsigned ox = offX(sel), ou = offU(sel), ob = offB();
+    const unsigned cx = offX(1 - sel), cu = offU(1 - sel), cc = offC(1 - sel);
     StateDimVector xc;
-    loadX(xPtr(sel, 0), xc);
-    storeX(xPtr(cs, 0), xc);
+    loadX(xRow(0), ox, xc);
+    storeX(xRow(0), cx, xc);
     double J = 0;
+
+    // software prefetch: the nominal trajectory and gains of step i+1 are requested while step i is evaluated
+    StateDimVector x_pref;
+    InputDimVector u_pref;
+    double k_pref[MM], K_pref[MM * N];
+    x_pref = xc;
+    loadU(uRow(0), ou, u_pref, MM);
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      k_pref[a] = ld(kRow(0) + a * Bp, ob);
+    }
+#pragma unroll kU
+    for(int e = 0; e < MM * N; e++)
+    {
+      K_pref[e] = ld(KRow(0) + e * Bp, ob);
+    }
+
     for(int i = 0; i < T; i++)
     {
       const double t = current_t + i * problem.dt();
       const int m = inputDimAt(t);
-      StateDimVector x;
-      InputDimVector u, uc;
-      loadX(xPtr(sel, i), x);
-      loadU(uPtr(sel, i), u, m);
+      const StateDimVector x = x_pref;
+      InputDimVector u = u_pref, uc;
+      u.resize(m);
       uc.resize(m);
-      const double * kp = kPtr(i);
-      const double * Kp = KPtr(i);
+      double kk[MM], KK[MM * N];
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        kk[a] = k_pref[a];
+      }
+#pragma unroll kU
+      for(int e = 0; e < MM * N; e++)
+      {
+        KK[e] = K_pref[e];
+      }
+      if(i + 1 < T)
+      {
+        loadX(xRow(i + 1), ox, x_pref);
+        loadU(uRow(i + 1), ou, u_pref, MM);
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          k_pref[a] = ld(kRow(i + 1) + a * Bp, ob);
+        }
+#pragma unroll kU
+        for(int e = 0; e < MM * N; e++)
+        {
+          K_pref[e] = ld(KRow(i + 1) + e * Bp, ob);
+        }
+      }
       // u' = u + alpha k + K (x' - x)    :545-546
 #pragma unroll kU
       for(int a = 0; a < MM; a++)
@@ -1061,25 +1193,25 @@ struct InstanceSolver
 #pragma unroll kU
           for(int c = 0; c < N; c++)
           {
-            s += Kp[(a + c * MM) * Bp] * (xc[c] - x[c]);
+            s += KK[a + c * MM] * (xc[c] - x[c]);
           }
-          uc[a] = (u[a] + alpha * kp[a * Bp]) + s;
+          uc[a] = (u[a] + alpha * kk[a]) + s;
         }
         else
         {
           uc[a] = 0;
         }
       }
-      storeU(uPtr(cs, i), uc, m);
+      storeU(uRow(i), cu, uc, m);
       const StateDimVector xn = problem.stateEq(t, xc, uc);
       const double c = problem.runningCost(t, xc, uc);
-      *costPtr(cs, i) = c;
+      st(costRow(i), cc, c);
       J += c;
-      storeX(xPtr(cs, i + 1), xn);
+      storeX(xRow(i + 1), cx, xn);
       xc = xn;
     }
     const double cT = problem.terminalCost(current_t + T * problem.dt(), xc);
-    *costPtr(cs, T) = cT;
+    st(costRow(T), cc, cT);
     J += cT;
     J_cand = J;
   }
@@ -1248,7 +1380,7 @@ struct InstanceSolver
 };
 
 /** The solve kernel: grid = Bp / 64 workgroups of one wavefront, lane = instance. */
-template<class Problem>
+template<class Problem, bool kConstrained>
 __global__ __launch_bounds__(kLanesPerBlock) void ddp_solve_tpi_kernel(const Problem problem,
                                                                         const nmpc_hip_ddp_config cfg,
                                                                         const DeviceBuffers buf)
@@ -1258,7 +1390,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void ddp_solve_tpi_kernel(const Pro
   {
     return;
   }
-  InstanceSolver<Problem> solver(problem, cfg, buf, b);
+  InstanceSolver<Problem, kConstrained> solver(problem, cfg, buf, b);
   solver.solve();
 }
 

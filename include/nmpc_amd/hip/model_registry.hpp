@@ -54,7 +54,16 @@ struct ModelOpsFor
     Problem problem;
     std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
     const int grid = buf.Bp / kLanesPerBlock;
-    hipLaunchKernelGGL(ddp_solve_tpi_kernel<Problem>, dim3(grid), dim3(kLanesPerBlock), 0, stream, problem, cfg, buf);
+    if(cfg.with_input_constraint)
+    {
+      hipLaunchKernelGGL((ddp_solve_tpi_kernel<Problem, true>), dim3(grid), dim3(kLanesPerBlock), 0, stream, problem, cfg,
+                         buf);
+    }
+    else
+    {
+      hipLaunchKernelGGL((ddp_solve_tpi_kernel<Problem, false>), dim3(grid), dim3(kLanesPerBlock), 0, stream, problem,
+                         cfg, buf);
+    }
     return hipGetLastError();
   }
   static void inputDims(const void * params, double t0, int T, int * out)

@@ -18,6 +18,13 @@
 
 namespace nmpc_amd
 {
+/** sin and cos of the same angle in one call (one argument reduction instead of two: on gfx950 an fp64 sin or
+    cos costs ~320 cycles per wavefront and the fused sincos ~340, profiles/ubench_r01.txt). */
+NMPC_HD void sincos(double x, double & s, double & c)
+{
+  ::sincos(x, &s, &c);
+}
+
 //! Marker for a run-time input dimension (the reference's Eigen::Dynamic).
 constexpr int Dynamic = -1;
 

@@ -5,11 +5,13 @@
 //
 // LANE MAPPING "TPI" (this file): one LANE per problem instance, 64 instances per wavefront, one wavefront per
 // workgroup.  The per-instance recursion state (Vx, Vxx, Q blocks, gains) lives in VGPRs, so nothing has to be
-// exchanged between lanes and every VALU instruction does 64 instances' worth of work; all batched arrays are
-// laid out instance-minor ([...][Bp]) so that a wave's access to one scalar field of 64 neighbouring instances is
-// one contiguous 512-byte segment.  Dynamics / cost derivatives are evaluated on the fly inside the backward
-// sweep (never materialised in HBM): per instance-iteration the kernel moves T*(3n + 5m + 2mn + 1) words instead
-// of the reference's materialised T*(2D + ...).
+// exchanged between lanes and every VALU instruction does 64 instances' worth of work.  Measured on MI355X
+// (profiles/ubench_r01.txt): a wave64 fp64 FMA issues in 4 cycles whether 1 or 64 lanes are active, so a
+// wavefront-per-instance mapping of an n = 4 problem would spend the same issue cycles on 1/64 of the work.
+// All batched arrays are tile-major [tile][half][row][64] (see InstanceSolver addressing), so a wave's access to
+// one row is one contiguous 512-byte segment and every stride is an immediate.  Dynamics / cost derivatives are
+// evaluated on the fly inside the backward sweep (never materialised in HBM): per instance-iteration the kernel
+// moves T*(3n + 5m + 2mn + 1) words instead of the reference's materialised T*(2D + ...).
 //
 // Arithmetic follows the reference statement by statement (cited inline); products are accumulated in ascending
 // index order; hipcc contracts a*b+c into FMA, so results differ from an x86 build in the last bits (tolerances
@@ -31,30 +33,32 @@ namespace hip
 constexpr int kMaxInputDim = 16; //!< capacity of the constant input-limit arrays passed by value
 constexpr int kLanesPerBlock = 64; //!< one wavefront per workgroup
 
-/** Device pointers of one solver handle.  Bp = batch rounded up to a multiple of 64; every array is
-    instance-minor: element (..., b) of a field sits at [...]*Bp + b. */
+/** Device pointers of one solver handle.  Bp = batch rounded up to a multiple of 64 = 64 * number of tiles.
+    Every array is tile-major: element (half s, row r) of instance b sits at
+        ((b / 64) * halves + s) * rows * 64  +  r * 64  +  b % 64
+    with the per-array `rows` / `halves` listed below ("[tile]" = that leading index). */
 struct DeviceBuffers
 {
   int B; //!< number of valid instances
-  int Bp; //!< padded batch (leading stride of every array)
+  int Bp; //!< padded batch
   int T; //!< horizon_steps
   int trace_rows; //!< allocated trace rows (max_iter+1 if trace_level >= 1, else 1)
-  const double * t0; //!< [Bp]
-  const double * x0; //!< [N][Bp]
-  double * X; //!< [2][T+1][N][Bp]   current / candidate state sequences (x_list)
-  double * U; //!< [2][T][MM][Bp]    current / candidate input sequences (u_list); U[0] holds u_init on entry
-  double * cost; //!< [2][T+1][Bp]   current / candidate cost sequences (cost_list)
-  double * kff; //!< [T][MM][Bp]       k_list_
-  double * Kfb; //!< [T][N*MM][Bp]     K_list_ (element a + c*MM of the m x N gain)
-  double * trace; //!< [trace_rows][NMPC_HIP_NTRACE][Bp]
-  double * trace_last; //!< [NMPC_HIP_NTRACE][Bp]
-  double * dV; //!< [2][Bp]
-  int * status; //!< [Bp]
-  int * iters; //!< [Bp]
-  int * sel; //!< [Bp]  which half of X/U/cost holds control_data_ after the solve
-  int * qp_ret; //!< [T][Bp]  (constrained solves only)
-  unsigned * qp_free; //!< [T][Bp]
-  int * input_dim; //!< [T][Bp]
+  const double * t0; //!< [tile][1][64]
+  const double * x0; //!< [tile][N][64]
+  double * X; //!< [tile][2][(T+1)*N][64]   current / candidate state sequences (x_list), row = i*N + j
+  double * U; //!< [tile][2][T*MM][64]      current / candidate input sequences (u_list); half 0 = u_init on entry
+  double * cost; //!< [tile][2][T+1][64]    current / candidate cost sequences (cost_list)
+  double * kff; //!< [tile][T*MM][64]         k_list_
+  double * Kfb; //!< [tile][T*N*MM][64]       K_list_, row = i*N*MM + (a + c*MM) of the m x N gain
+  double * trace; //!< [tile][trace_rows*NMPC_HIP_NTRACE][64]
+  double * trace_last; //!< [tile][NMPC_HIP_NTRACE][64]
+  double * dV; //!< [tile][2][64]
+  int * status; //!< [tile][1][64]
+  int * iters; //!< [tile][1][64]
+  int * sel; //!< [tile][1][64]  which half of X/U/cost holds control_data_ after the solve
+  int * qp_ret; //!< [tile][T][64]  (constrained solves only)
+  unsigned * qp_free; //!< [tile][T][64]
+  int * input_dim; //!< [tile][T][64]
   double lim_lo[kMaxInputDim]; //!< input lower limits (constant in time)
   double lim_hi[kMaxInputDim]; //!< input upper limits
 };
@@ -96,7 +100,15 @@ struct InstanceSolver
   const DeviceBuffers & buf;
   const int b; //!< instance index = global lane index
   const int T;
-  const size_t Bp;
+  const unsigned tile; //!< wavefront tile = b / 64
+  const unsigned lane; //!< b % 64
+  // this tile's slice of every big array (wave-uniform, computed once)
+  double * Xt;
+  double * Ut;
+  double * Ct;
+  double * kt;
+  double * Kt;
+  static constexpr size_t LW = kLanesPerBlock; //!< row stride of every array: the 64 instances of one tile
 
   double current_t;
   double lambda;
@@ -107,15 +119,30 @@ struct InstanceSolver
   double J_cand; //!< candidate_control_data_.cost_list.sum()
   int sel; //!< half of X/U/cost that is control_data_; 1-sel is candidate_control_data_
 
-  NMPC_D InstanceSolver(const Problem & p, const nmpc_hip_ddp_config & c, const DeviceBuffers & bf, int lane)
-  : problem(p), cfg(c), buf(bf), b(lane), T(bf.T), Bp(static_cast<size_t>(bf.Bp))
+  NMPC_D InstanceSolver(const Problem & p, const nmpc_hip_ddp_config & c, const DeviceBuffers & bf, int global_lane)
+  : problem(p), cfg(c), buf(bf), b(global_lane), T(bf.T), tile(static_cast<unsigned>(global_lane) / kLanesPerBlock),
+    lane(static_cast<unsigned>(global_lane) % kLanesPerBlock)
   {
+    Xt = tileBase(bf.X, rowsX(), 2);
+    Ut = tileBase(bf.U, rowsU(), 2);
+    Ct = tileBase(bf.cost, static_cast<size_t>(T + 1), 2);
+    kt = tileBase(bf.kff, rowsU());
+    Kt = tileBase(bf.Kfb, rowsU() * N);
   }
 
-  // ---- addressing (instance-minor) ----
-  // Every access is  UNIFORM row pointer (SGPR pair, advanced by scalar code)  +  per-lane 32-bit byte offset
-  // (one VGPR), the form the global_load/store "saddr + voffset" encoding takes directly: no 64-bit vector
-  // address arithmetic per access.  The lane offset also selects the current / candidate half.
+  // ---- addressing: tile-major ("AoSoA-64") ----
+  // Every batched array is laid out [tile][half][row][64]: the 64 instances of one wavefront are the fastest
+  // index, so (a) a wave's access to one row is one contiguous 512-byte segment, (b) ALL data of one wave is
+  // one contiguous block (few TLB entries, no 32 KB strides between the fields of one timestep), and (c) every
+  // stride is a compile-time constant: an access is  UNIFORM row pointer (SGPR pair, bumped once per timestep
+  // by scalar code)  +  per-lane 32-bit byte offset (one VGPR, also selects the current / candidate half)  +
+  // immediate (j * 512), the "saddr + voffset + imm" form of global_load/store — no vector address arithmetic.
+  //! base of this wavefront's tile in an array with `rows` rows per instance and `halves` copies
+  template<class Tp>
+  NMPC_D Tp * tileBase(Tp * array, size_t rows, int halves = 1) const
+  {
+    return array + static_cast<size_t>(__builtin_amdgcn_readfirstlane(tile)) * (rows * halves * LW);
+  }
   NMPC_D static double ld(const double * row, unsigned lane_off)
   {
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(row) + lane_off);
@@ -124,42 +151,56 @@ struct InstanceSolver
   {
     *reinterpret_cast<double *>(reinterpret_cast<char *>(row) + lane_off) = v;
   }
+  NMPC_D size_t rowsX() const
+  {
+    return static_cast<size_t>(T + 1) * N;
+  }
+  NMPC_D size_t rowsU() const
+  {
+    return static_cast<size_t>(T) * MM;
+  }
   NMPC_D double * xRow(int i) const
   {
-    return buf.X + (static_cast<size_t>(i) * N) * Bp;
+    return Xt + (static_cast<size_t>(i) * N) * LW;
   }
   NMPC_D double * uRow(int i) const
   {
-    return buf.U + (static_cast<size_t>(i) * MM) * Bp;
+    return Ut + (static_cast<size_t>(i) * MM) * LW;
   }
   NMPC_D double * costRow(int i) const
   {
-    return buf.cost + static_cast<size_t>(i) * Bp;
+    return Ct + static_cast<size_t>(i) * LW;
   }
   NMPC_D double * kRow(int i) const
   {
-    return buf.kff + (static_cast<size_t>(i) * MM) * Bp;
+    return kt + (static_cast<size_t>(i) * MM) * LW;
   }
   NMPC_D double * KRow(int i) const
   {
-    return buf.Kfb + (static_cast<size_t>(i) * (N * MM)) * Bp;
+    return Kt + (static_cast<size_t>(i) * (N * MM)) * LW;
   }
   //! per-lane byte offsets of half s (0 / 1) of X, U, cost; offB addresses single-copy arrays
   NMPC_D unsigned offX(int s) const
   {
-    return (static_cast<unsigned>(s) * static_cast<unsigned>((T + 1) * N) * static_cast<unsigned>(Bp) + b) * 8u;
+    return (static_cast<unsigned>(s) * static_cast<unsigned>(rowsX() * LW) + lane) * 8u;
   }
   NMPC_D unsigned offU(int s) const
   {
-    return (static_cast<unsigned>(s) * static_cast<unsigned>(T * MM) * static_cast<unsigned>(Bp) + b) * 8u;
+    return (static_cast<unsigned>(s) * static_cast<unsigned>(rowsU() * LW) + lane) * 8u;
   }
   NMPC_D unsigned offC(int s) const
   {
-    return (static_cast<unsigned>(s) * static_cast<unsigned>(T + 1) * static_cast<unsigned>(Bp) + b) * 8u;
+    return (static_cast<unsigned>(s) * static_cast<unsigned>((T + 1) * LW) + lane) * 8u;
   }
   NMPC_D unsigned offB() const
   {
-    return static_cast<unsigned>(b) * 8u;
+    return lane * 8u;
+  }
+  //! address of per-instance element `row` of a single-copy [tile][rows][64] array of any type
+  template<class Tp>
+  NMPC_D Tp & elem(Tp * array, size_t rows, size_t row) const
+  {
+    return tileBase(array, rows)[row * LW + lane];
   }
 
   NMPC_D int inputDimAt(double t) const
@@ -179,7 +220,7 @@ struct InstanceSolver
 #pragma unroll
     for(int j = 0; j < N; j++)
     {
-      x[j] = ld(row + j * Bp, off);
+      x[j] = ld(row + j * LW, off);
     }
   }
   NMPC_D void storeX(double * row, unsigned off, const StateDimVector & x) const
@@ -187,7 +228,7 @@ struct InstanceSolver
 #pragma unroll
     for(int j = 0; j < N; j++)
     {
-      st(row + j * Bp, off, x[j]);
+      st(row + j * LW, off, x[j]);
     }
   }
   NMPC_D void loadU(const double * row, unsigned off, InputDimVector & u, int m) const
@@ -196,7 +237,7 @@ struct InstanceSolver
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
-      u[a] = (a < m) ? ld(row + a * Bp, off) : 0.0;
+      u[a] = (a < m) ? ld(row + a * LW, off) : 0.0;
     }
   }
   NMPC_D void storeU(double * row, unsigned off, const InputDimVector & u, int m) const
@@ -204,7 +245,7 @@ struct InstanceSolver
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
-      st(row + a * Bp, off, (a < m) ? u[a] : 0.0);
+      st(row + a * LW, off, (a < m) ? u[a] : 0.0);
     }
   }
 
@@ -215,14 +256,14 @@ struct InstanceSolver
   {
     const unsigned ox = offX(sel), ou = offU(sel), oc = offC(sel);
     StateDimVector x;
-    loadX(buf.x0, offB(), x);
+    loadX(tileBase(buf.x0, N), offB(), x);
     storeX(xRow(0), ox, x);
     double J = 0;
     for(int i = 0; i < T; i++)
     {
       const double t = current_t + i * problem.dt();
       const int m = inputDimAt(t);
-      buf.input_dim[static_cast<size_t>(i) * Bp + b] = m;
+      elem(buf.input_dim, T, i) = m;
       InputDimVector u;
       loadU(uRow(i), ou, u, m);
       storeU(uRow(i), ou, u, m); // zero the padding beyond inputDim(t)
@@ -909,8 +950,8 @@ struct InstanceSolver
           {
             free_mask |= (1u << qp.free_idx[j]);
           }
-          buf.qp_ret[static_cast<size_t>(i) * Bp + b] = qp.retval;
-          buf.qp_free[static_cast<size_t>(i) * Bp + b] = free_mask;
+          elem(buf.qp_ret, T, i) = qp.retval;
+          elem(buf.qp_free, T, i) = free_mask;
           if(qp.retval < 0)
           {
             ok = false; // :473-480
@@ -1097,7 +1138,7 @@ struct InstanceSolver
 #pragma unroll kU
         for(int a = 0; a < MM; a++)
         {
-          st(kp + a * Bp, ob, k[a]);
+          st(kp + a * LW, ob, k[a]);
           k_next[a] = k[a];
           if(a < m)
           {
@@ -1108,7 +1149,7 @@ struct InstanceSolver
 #pragma unroll kU
         for(int e = 0; e < MM * N; e++)
         {
-          st(Kp + e * Bp, ob, K[e]);
+          st(Kp + e * LW, ob, K[e]);
         }
         m_next = m;
         // for m == 1 the two norms are |k| and |u| exactly (sqrt(x*x) == |x| up to under/overflow)
@@ -1141,12 +1182,12 @@ struct InstanceSolver
 #pragma unroll kU
     for(int a = 0; a < MM; a++)
     {
-      k_pref[a] = ld(kRow(0) + a * Bp, ob);
+      k_pref[a] = ld(kRow(0) + a * LW, ob);
     }
 #pragma unroll kU
     for(int e = 0; e < MM * N; e++)
     {
-      K_pref[e] = ld(KRow(0) + e * Bp, ob);
+      K_pref[e] = ld(KRow(0) + e * LW, ob);
     }
 
     for(int i = 0; i < T; i++)
@@ -1175,12 +1216,12 @@ struct InstanceSolver
 #pragma unroll kU
         for(int a = 0; a < MM; a++)
         {
-          k_pref[a] = ld(kRow(i + 1) + a * Bp, ob);
+          k_pref[a] = ld(kRow(i + 1) + a * LW, ob);
         }
 #pragma unroll kU
         for(int e = 0; e < MM * N; e++)
         {
-          K_pref[e] = ld(KRow(i + 1) + e * Bp, ob);
+          K_pref[e] = ld(KRow(i + 1) + e * LW, ob);
         }
       }
       // u' = u + alpha k + K (x' - x)    :545-546
@@ -1223,11 +1264,12 @@ struct InstanceSolver
   {
     if(buf.trace_rows > 1 && row < buf.trace_rows)
     {
-      double * p = buf.trace + (static_cast<size_t>(row) * NMPC_HIP_NTRACE) * Bp + b;
+      double * p = tileBase(buf.trace, static_cast<size_t>(buf.trace_rows) * NMPC_HIP_NTRACE)
+                   + (static_cast<size_t>(row) * NMPC_HIP_NTRACE) * LW;
 #pragma unroll
       for(int f = 0; f < NMPC_HIP_NTRACE; f++)
       {
-        p[f * Bp] = tr[f];
+        st(p + f * LW, offB(), tr[f]);
       }
     }
   }
@@ -1369,13 +1411,13 @@ struct InstanceSolver
 #pragma unroll
     for(int f = 0; f < NMPC_HIP_NTRACE; f++)
     {
-      buf.trace_last[static_cast<size_t>(f) * Bp + b] = tr[f];
+      elem(buf.trace_last, NMPC_HIP_NTRACE, f) = tr[f];
     }
     buf.status[b] = retval;
     buf.iters[b] = static_cast<int>(tr[NMPC_HIP_TRACE_ITER]);
     buf.sel[b] = sel;
-    buf.dV[b] = dV0;
-    buf.dV[Bp + b] = dV1;
+    elem(buf.dV, 2, 0) = dV0;
+    elem(buf.dV, 2, 1) = dV1;
   }
 };
 
@@ -1395,65 +1437,68 @@ __global__ __launch_bounds__(kLanesPerBlock) void ddp_solve_tpi_kernel(const Pro
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// layout kernels: reference layouts ([B][rows]) <-> instance-minor device layout ([rows][Bp])
+// layout kernels: reference layouts ([B][R], row-major) <-> tile-major device layout ([tile][halves][R][64])
+// One workgroup moves a 64-instance x 64-row block through LDS so that both the global read and the global
+// write are contiguous 512-byte segments per wavefront.
 // ---------------------------------------------------------------------------------------------------------
-/** in [B][R] (row-major) -> out [R][Bp].  32x32 tiles through LDS so both sides are coalesced. */
+/** in [B][R] -> out [tile][halves][R][64], written into half `half`. */
 template<class T>
-__global__ __launch_bounds__(256) void batch_major_to_minor_kernel(const T * __restrict__ in,
-                                                                    T * __restrict__ out,
-                                                                    int B,
-                                                                    int R,
-                                                                    int Bp)
+__global__ __launch_bounds__(256) void batch_major_to_tile_kernel(const T * __restrict__ in,
+                                                                   T * __restrict__ out,
+                                                                   int B,
+                                                                   int R,
+                                                                   int halves,
+                                                                   int half)
 {
-  __shared__ T tile[32][33];
-  const int r0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
-  for(int k = ty; k < 32; k += 8)
+  __shared__ T blk[64][65];
+  const int r0 = blockIdx.x * 64, tile = blockIdx.y;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 64 x 4
+  for(int k = ty; k < 64; k += 4)
   {
-    const int bb = b0 + k, r = r0 + tx;
-    tile[k][tx] = (bb < B && r < R) ? in[static_cast<size_t>(bb) * R + r] : T(0);
+    const int bb = tile * 64 + k, r = r0 + tx;
+    blk[k][tx] = (bb < B && r < R) ? in[static_cast<size_t>(bb) * R + r] : T(0);
   }
   __syncthreads();
-  for(int k = ty; k < 32; k += 8)
+  T * o = out + (static_cast<size_t>(tile) * halves + half) * R * 64;
+  for(int k = ty; k < 64; k += 4)
   {
-    const int r = r0 + k, bb = b0 + tx;
-    if(r < R && bb < Bp)
+    const int r = r0 + k;
+    if(r < R)
     {
-      out[static_cast<size_t>(r) * Bp + bb] = tile[tx][k];
+      o[static_cast<size_t>(r) * 64 + tx] = blk[tx][k];
     }
   }
 }
 
-/** in: two halves [2][R][Bp] selected per instance by sel[b] (or a single half when sel == nullptr)
-    -> out [B][R] (row-major). */
+/** in [tile][halves][R][64], half selected per instance by sel (sel == nullptr: half 0) -> out [B][R]. */
 template<class T>
-__global__ __launch_bounds__(256) void batch_minor_to_major_kernel(const T * __restrict__ in,
-                                                                    T * __restrict__ out,
-                                                                    const int * __restrict__ sel,
-                                                                    int B,
-                                                                    int R,
-                                                                    int Bp)
+__global__ __launch_bounds__(256) void tile_to_batch_major_kernel(const T * __restrict__ in,
+                                                                   T * __restrict__ out,
+                                                                   const int * __restrict__ sel,
+                                                                   int B,
+                                                                   int R,
+                                                                   int halves)
 {
-  __shared__ T tile[32][33];
-  const int r0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const size_t half = static_cast<size_t>(R) * Bp;
+  __shared__ T blk[64][65];
+  const int r0 = blockIdx.x * 64, tile = blockIdx.y;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   {
-    const int bb = b0 + tx;
+    const int bb = tile * 64 + tx;
     const int s = (sel != nullptr && bb < B) ? sel[bb] : 0;
-    for(int k = ty; k < 32; k += 8)
+    const T * src = in + (static_cast<size_t>(tile) * halves + s) * R * 64;
+    for(int k = ty; k < 64; k += 4)
     {
       const int r = r0 + k;
-      tile[k][tx] = (bb < B && r < R) ? in[s * half + static_cast<size_t>(r) * Bp + bb] : T(0);
+      blk[k][tx] = (r < R) ? src[static_cast<size_t>(r) * 64 + tx] : T(0);
     }
   }
   __syncthreads();
-  for(int k = ty; k < 32; k += 8)
+  for(int k = ty; k < 64; k += 4)
   {
-    const int bb = b0 + k, r = r0 + tx;
+    const int bb = tile * 64 + k, r = r0 + tx;
     if(bb < B && r < R)
     {
-      out[static_cast<size_t>(bb) * R + r] = tile[tx][k];
+      out[static_cast<size_t>(bb) * R + r] = blk[tx][k];
     }
   }
 }

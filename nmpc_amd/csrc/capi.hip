@@ -181,18 +181,18 @@ DeviceBuffers makeBuffers(const nmpc_hip_ddp_solver * s)
 }
 
 template<class T>
-hipError_t toMinor(const T * in, T * out, int B, int R, int Bp, hipStream_t st)
+hipError_t toTile(const T * in, T * out, int B, int R, int Bp, int halves, int half, hipStream_t st)
 {
-  dim3 grid((R + 31) / 32, (Bp + 31) / 32);
-  hipLaunchKernelGGL(nmpc_amd::hip::batch_major_to_minor_kernel<T>, grid, dim3(256), 0, st, in, out, B, R, Bp);
+  dim3 grid((R + 63) / 64, Bp / 64);
+  hipLaunchKernelGGL(nmpc_amd::hip::batch_major_to_tile_kernel<T>, grid, dim3(256), 0, st, in, out, B, R, halves, half);
   return hipGetLastError();
 }
 
 template<class T>
-hipError_t toMajor(const T * in, T * out, const int * sel, int B, int R, int Bp, hipStream_t st)
+hipError_t toMajor(const T * in, T * out, const int * sel, int B, int R, int Bp, int halves, hipStream_t st)
 {
-  dim3 grid((R + 31) / 32, (B + 31) / 32);
-  hipLaunchKernelGGL(nmpc_amd::hip::batch_minor_to_major_kernel<T>, grid, dim3(256), 0, st, in, out, sel, B, R, Bp);
+  dim3 grid((R + 63) / 64, Bp / 64);
+  hipLaunchKernelGGL(nmpc_amd::hip::tile_to_batch_major_kernel<T>, grid, dim3(256), 0, st, in, out, sel, B, R, halves);
   return hipGetLastError();
 }
 
@@ -263,32 +263,32 @@ int packField(nmpc_hip_ddp_solver * s, int field, void * d_out, hipStream_t st)
   switch(field)
   {
     case NMPC_HIP_FIELD_X:
-      NMPC_HIP_TRY(toMajor<double>(s->d_X, dout, s->d_sel, B, R, Bp, st));
+      NMPC_HIP_TRY(toMajor<double>(s->d_X, dout, s->d_sel, B, R, Bp, 2, st));
       break;
     case NMPC_HIP_FIELD_U:
-      NMPC_HIP_TRY(toMajor<double>(s->d_U, dout, s->d_sel, B, R, Bp, st));
+      NMPC_HIP_TRY(toMajor<double>(s->d_U, dout, s->d_sel, B, R, Bp, 2, st));
       break;
     case NMPC_HIP_FIELD_COST:
-      NMPC_HIP_TRY(toMajor<double>(s->d_cost, dout, s->d_sel, B, R, Bp, st));
+      NMPC_HIP_TRY(toMajor<double>(s->d_cost, dout, s->d_sel, B, R, Bp, 2, st));
       break;
     case NMPC_HIP_FIELD_KFF:
-      NMPC_HIP_TRY(toMajor<double>(s->d_kff, dout, nullptr, B, R, Bp, st));
+      NMPC_HIP_TRY(toMajor<double>(s->d_kff, dout, nullptr, B, R, Bp, 1, st));
       break;
     case NMPC_HIP_FIELD_KFB:
-      NMPC_HIP_TRY(toMajor<double>(s->d_Kfb, dout, nullptr, B, R, Bp, st));
+      NMPC_HIP_TRY(toMajor<double>(s->d_Kfb, dout, nullptr, B, R, Bp, 1, st));
       break;
     case NMPC_HIP_FIELD_TRACE:
       if(s->trace_rows != s->cfg.max_iter + 1)
       {
         return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "full trace was not recorded: set trace_level = 1 before solve");
       }
-      NMPC_HIP_TRY(toMajor<double>(s->d_trace, dout, nullptr, B, R, Bp, st));
+      NMPC_HIP_TRY(toMajor<double>(s->d_trace, dout, nullptr, B, R, Bp, 1, st));
       break;
     case NMPC_HIP_FIELD_TRACE_LAST:
-      NMPC_HIP_TRY(toMajor<double>(s->d_trace_last, dout, nullptr, B, R, Bp, st));
+      NMPC_HIP_TRY(toMajor<double>(s->d_trace_last, dout, nullptr, B, R, Bp, 1, st));
       break;
     case NMPC_HIP_FIELD_DV:
-      NMPC_HIP_TRY(toMajor<double>(s->d_dV, dout, nullptr, B, R, Bp, st));
+      NMPC_HIP_TRY(toMajor<double>(s->d_dV, dout, nullptr, B, R, Bp, 1, st));
       break;
     case NMPC_HIP_FIELD_STATUS:
       NMPC_HIP_TRY(hipMemcpyAsync(iout, s->d_status, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
@@ -297,13 +297,13 @@ int packField(nmpc_hip_ddp_solver * s, int field, void * d_out, hipStream_t st)
       NMPC_HIP_TRY(hipMemcpyAsync(iout, s->d_iters, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
       break;
     case NMPC_HIP_FIELD_QP_RETVAL:
-      NMPC_HIP_TRY(toMajor<int>(s->d_qp_ret, iout, nullptr, B, R, Bp, st));
+      NMPC_HIP_TRY(toMajor<int>(s->d_qp_ret, iout, nullptr, B, R, Bp, 1, st));
       break;
     case NMPC_HIP_FIELD_INPUT_DIM:
-      NMPC_HIP_TRY(toMajor<int>(s->d_input_dim, iout, nullptr, B, R, Bp, st));
+      NMPC_HIP_TRY(toMajor<int>(s->d_input_dim, iout, nullptr, B, R, Bp, 1, st));
       break;
     case NMPC_HIP_FIELD_QP_FREE_MASK:
-      NMPC_HIP_TRY(toMajor<unsigned>(s->d_qp_free, static_cast<unsigned *>(d_out), nullptr, B, R, Bp, st));
+      NMPC_HIP_TRY(toMajor<unsigned>(s->d_qp_free, static_cast<unsigned *>(d_out), nullptr, B, R, Bp, 1, st));
       break;
     default:
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "unknown field");
@@ -741,8 +741,8 @@ extern "C"
     {
       NMPC_HIP_TRY(hipMemsetAsync(s->d_t0, 0, sizeof(double) * s->Bp, st));
     }
-    NMPC_HIP_TRY(toMinor<double>(d_x0, s->d_x0, s->B, s->N, s->Bp, st));
-    NMPC_HIP_TRY(toMinor<double>(d_u_init, s->d_U, s->B, s->T * s->MM, s->Bp, st));
+    NMPC_HIP_TRY(toTile<double>(d_x0, s->d_x0, s->B, s->N, s->Bp, 1, 0, st));
+    NMPC_HIP_TRY(toTile<double>(d_u_init, s->d_U, s->B, s->T * s->MM, s->Bp, 2, 0, st));
     NMPC_HIP_TRY(hipEventRecord(s->ev_kernel[slot], st));
     const DeviceBuffers buf = makeBuffers(s);
     NMPC_HIP_TRY(s->ops->launch_solve(s->params.data(), s->cfg, buf, st));

@@ -1,0 +1,89 @@
+"""Golden vectors (tests/golden/ddp_golden.npz, made by tests/golden/make_golden.py).
+
+  * not gpu: the CPU oracle built on THIS host reproduces the committed vectors (so the checker that runs on the
+    GPU box is the checker that was pinned in the build container);
+  * gpu: the HIP path, called through the C-ABI, reproduces them: indices bit-exact, values within the fp64
+    tolerances of SURVEY.md §8 c.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ddp_golden.npz")
+D = np.load(GOLDEN)
+NAMES = [str(n) for n in D["__names__"]]
+
+# tolerances (fp64): |dX|, |dU|, |dk|, |dK| <= 1e-9 (1 + |ref|); total cost relative <= 1e-10
+TOL_STATE = 1e-9
+TOL_COST = 1e-10
+INT_COLS = (0, 9, 10, 11)  # iter, alpha_idx, n_backward, n_forward
+
+
+def case(name):
+    g = {k.split("/", 1)[1]: D[k] for k in D.files if k.startswith(name + "/")}
+    kw = {str(k): (int(v) if float(v).is_integer() and str(k) not in ("initial_lambda",) else float(v))
+          for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    return g, kw
+
+
+def assert_close(name, got, want, tol):
+    err = np.abs(got - want) / (1.0 + np.abs(want))
+    assert err.max() <= tol, f"{name}: max scaled error {err.max():.3e} > {tol}"
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_reproduces_golden(name):
+    g, kw = case(name)
+    cfg = oracle.default_config(**kw)
+    lo, up = (g["lower"], g["upper"]) if "lower" in g else (None, None)
+    r = oracle.solve(str(g["model"]), cfg, g["x0"], g["u_init"], t0=float(g["t0"]), lower=lo, upper=up)
+    assert r.status == int(g["status"])
+    assert r.trace.shape == g["trace"].shape
+    np.testing.assert_array_equal(r.trace[:, INT_COLS], g["trace"][:, INT_COLS])
+    np.testing.assert_array_equal(r.qp_retval, g["qp_retval"])
+    np.testing.assert_array_equal(r.qp_free_mask, g["qp_free_mask"])
+    for k in ("X", "U", "cost", "k", "K"):
+        assert_close(f"{name}/{k}", getattr(r, k), g[k], 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_reproduces_golden(name):
+    import nmpc_amd
+
+    g, kw = case(name)
+    model = str(g["model"])
+    T = kw["horizon_steps"]
+    solver = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(model), 1)
+    c = solver.config()
+    c.print_level = 0
+    for k, v in kw.items():
+        setattr(c, k, bool(v) if k == "with_input_constraint" else v)
+    if "lower" in g:
+        solver.setInputLimits(g["lower"], g["upper"])
+    mm = max(solver.m_max, 1)
+    ok = solver.solve(float(g["t0"]), g["x0"][None, :], g["u_init"].reshape(1, T, mm))
+    status = int(g["status"])
+    assert int(solver.status()[0]) == status
+    assert bool(ok[0]) == (status == 1)
+    n_rows = g["trace"].shape[0]
+    assert int(solver.iters()[0]) == int(g["trace"][-1, 0])
+    tr = solver.trace()[0, :n_rows]
+    np.testing.assert_array_equal(tr[:, INT_COLS], g["trace"][:, INT_COLS])  # discrete decisions: bit exact
+    np.testing.assert_array_equal(solver.inputDimList()[0], g["m_list"])
+    if kw.get("with_input_constraint", 0) and status >= 0:
+        np.testing.assert_array_equal(solver.qpRetval()[0], g["qp_retval"])
+        np.testing.assert_array_equal(solver.qpFreeMask()[0], g["qp_free_mask"])
+    assert_close(f"{name}/X", solver.X()[0], g["X"], TOL_STATE)
+    assert_close(f"{name}/U", solver.U()[0], g["U"], TOL_STATE)
+    if status >= 0:
+        assert_close(f"{name}/k", solver.kff()[0], g["k"], TOL_STATE)
+        assert_close(f"{name}/K", solver.Kfb()[0], g["K"], TOL_STATE)
+    # per-iteration total cost, lambda schedule
+    want = g["trace"]
+    for col in (1, 2, 3, 4):
+        np.testing.assert_allclose(tr[:, col], want[:, col], rtol=TOL_COST, atol=1e-300)
+    assert abs(solver.cost()[0].sum() - g["cost"].sum()) <= TOL_COST * abs(g["cost"].sum())

@@ -1,0 +1,329 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI, libnmpc_hip_ddp.so) against the CPU oracle on the
+same seeded inputs, plus size-independent properties at BASELINE.json's full sizes and the edge cases the
+reference handles (variable / zero input dimension, box constraints, failures, tiny and ragged batches).
+
+Bar (SURVEY.md §8 c): discrete decisions — status, iteration count, alpha index / backward retries / forward
+trials per iteration, BoxQP retval and free set per timestep, input dimensions — BIT-EXACT; fp64 values
+|dX|, |dU|, |dk|, |dK| <= 1e-9 (1 + |ref|), total cost relative <= 1e-10.
+"""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+TOL_COST = 1e-10
+INT_COLS = (0, 9, 10, 11)
+
+
+def make_solver(wl, **cfg):
+    import nmpc_amd
+
+    prob = nmpc_amd.make_problem(wl.model)
+    s = nmpc_amd.DDPSolverBatch(prob, wl.B)
+    c = s.config()
+    c.print_level = 0
+    c.horizon_steps = wl.T
+    for k, v in cfg.items():
+        setattr(c, k, v)
+    if wl.limits is not None:
+        s.setInputLimits(*wl.limits)
+    return s
+
+
+def oracle_batch(wl, **cfg):
+    ocfg = oracle.default_config(horizon_steps=wl.T, **{k: (int(v) if isinstance(v, bool) else v) for k, v in cfg.items()})
+    lo, up = wl.limits if wl.limits is not None else (None, None)
+    return oracle.solve_batch(wl.model, ocfg, wl.x0, wl.u_init, t0=wl.t0, lower=lo, upper=up, n_threads=8,
+                              want_alpha_hist=True)
+
+
+def scaled_err(got, want):
+    return float((np.abs(got - want) / (1.0 + np.abs(want))).max())
+
+
+def check_against_oracle(wl, s, ref, check_gains=True):
+    np.testing.assert_array_equal(s.status(), ref.status)
+    np.testing.assert_array_equal(s.iters(), ref.iters)
+    # per-iteration alpha index history
+    tr = s.trace()
+    gpu_hist = np.full_like(ref.alpha_idx_hist, -2)
+    for b in range(wl.B):
+        n = int(ref.iters[b])
+        gpu_hist[b, :n] = tr[b, 1:n + 1, 9].astype(np.int32)
+    np.testing.assert_array_equal(gpu_hist, ref.alpha_idx_hist)
+    np.testing.assert_array_equal(s.traceLast()[:, INT_COLS], ref.trace_last[:, INT_COLS])
+    assert scaled_err(s.X(), ref.X) <= TOL
+    assert scaled_err(s.U(), ref.U) <= TOL
+    ok = ref.status >= 0
+    if check_gains and ok.any():
+        assert scaled_err(s.kff()[ok], ref.k[ok]) <= TOL
+        assert scaled_err(s.Kfb()[ok], ref.K[ok]) <= TOL
+    Jg, Jr = s.cost().sum(axis=1), ref.cost.sum(axis=1)
+    assert np.all(np.abs(Jg - Jr) <= TOL_COST * np.abs(Jr) + 1e-300)
+
+
+# ---------------------------------------------------------------------------------------------------
+# oracle parity on every model
+# ---------------------------------------------------------------------------------------------------
+def test_cartpole_batch_converged():
+    """BASELINE config 2 at a size the oracle finishes in seconds: 320 instances (5 tiles), solve to convergence."""
+    from nmpc_amd import workloads
+    wl = workloads.cartpole_batch(B=320, T=100, seed=1234)
+    s = make_solver(wl)
+    ok = s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_batch(wl)
+    assert ok.all() and (ref.status == 1).all()
+    check_against_oracle(wl, s, ref)
+
+
+def test_cartpole_single_reference_start():
+    """BASELINE config 1: x0 = (0, pi, 0, 0): 17 iterations at T = 100."""
+    from nmpc_amd import workloads
+    wl = workloads.cartpole_single()
+    s = make_solver(wl)
+    assert s.solve(wl.t0, wl.x0, wl.u_init)[0]
+    assert int(s.iters()[0]) == 17
+    check_against_oracle(wl, s, oracle_batch(wl))
+
+
+def test_cartpole_box_constrained():
+    """+-15 N box (TestDDPCartPole.cpp:379-386): BoxQP retval and free set of every timestep must match."""
+    from nmpc_amd import workloads
+    wl = workloads.cartpole_batch(B=192, T=100, seed=99, constrained=True)
+    s = make_solver(wl, with_input_constraint=True)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_batch(wl, with_input_constraint=True)
+    assert set(np.unique(ref.status)) >= {1}
+    check_against_oracle(wl, s, ref)
+    # per-timestep BoxQP decisions of the last backward pass, instance by instance
+    ocfg = oracle.default_config(horizon_steps=wl.T, with_input_constraint=1)
+    qret, qfree = s.qpRetval(), s.qpFreeMask()
+    n_clamped = 0
+    for b in range(0, wl.B, 7):
+        r = oracle.solve(wl.model, ocfg, wl.x0[b], wl.u_init[b], lower=wl.limits[0], upper=wl.limits[1])
+        if r.status < 0:
+            continue
+        np.testing.assert_array_equal(qret[b], r.qp_retval)
+        np.testing.assert_array_equal(qfree[b], r.qp_free_mask)
+        n_clamped += int((r.qp_free_mask == 0).sum())
+    assert n_clamped > 0, "the sample never hit the bounds: the constrained branch was not exercised"
+
+
+def test_bipedal_time_varying_dynamics():
+    """BASELINE config 3 (TestDDPBipedal, LTV): per-instance start times across the omega^2 transient, T = 300."""
+    from nmpc_amd import workloads
+    wl = workloads.bipedal_batch(B=128, T=300, seed=1234)
+    s = make_solver(wl)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    check_against_oracle(wl, s, oracle_batch(wl))
+
+
+@pytest.mark.parametrize("constrained", [False, True])
+def test_vertical_motion_variable_input_dimension(constrained):
+    """Input dimension 1 / 2 / 0 along the horizon (TestDDPVerticalMotion.cpp:58-75), with and without [0, 30]."""
+    from nmpc_amd import workloads
+    wl = workloads.vertical_batch(B=128, T=300, seed=1234, constrained=constrained)
+    s = make_solver(wl, initial_lambda=1e-6, with_input_constraint=constrained, max_iter=60)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_batch(wl, initial_lambda=1e-6, with_input_constraint=constrained, max_iter=60)
+    dims = s.inputDimList()
+    assert set(np.unique(dims)) == {0, 1, 2}
+    for b in range(0, wl.B, 16):
+        np.testing.assert_array_equal(dims[b], oracle.input_dims(wl.model, None, wl.t0[b], wl.T))
+    check_against_oracle(wl, s, ref)
+    # entries beyond inputDim(t) are zero
+    U = s.U()
+    assert np.all(U[dims == 0] == 0.0) and np.all(U[:, :, 1][dims < 2] == 0.0)
+
+
+def test_centroidal_large_input_dimension():
+    """nu in {16, 0} (TestDDPCentroidalMotion.cpp:64-68), n = 9: the largest blocks in the reference tree."""
+    from nmpc_amd import workloads
+    wl = workloads.centroidal_batch(B=64, T=100, seed=1234)
+    s = make_solver(wl, max_iter=4)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    check_against_oracle(wl, s, oracle_batch(wl, max_iter=4))
+    assert set(np.unique(s.inputDimList())) == {0, 16}
+
+
+def test_quadrotor_and_manipulator():
+    """Builder-defined models of BASELINE configs 4 and 5 (fp64), parity vs the oracle's own statement."""
+    from nmpc_amd import workloads
+    for wl, it in ((workloads.quadrotor_batch(B=64, T=50, seed=1234), 12),
+                   (workloads.manipulator_batch(B=64, T=30, seed=1234), 8)):
+        s = make_solver(wl, max_iter=it)
+        s.solve(wl.t0, wl.x0, wl.u_init)
+        check_against_oracle(wl, s, oracle_batch(wl, max_iter=it))
+
+
+def test_reg_type_2_and_custom_alpha_list():
+    from nmpc_amd import workloads
+    wl = workloads.cartpole_batch(B=64, T=60, seed=3)
+    alphas = np.array([1.0, 0.3, 0.1, 0.03])
+    s = make_solver(wl, reg_type=2, alpha_list=alphas, max_iter=30)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    check_against_oracle(wl, s, oracle_batch(wl, reg_type=2, alpha_list=alphas, max_iter=30))
+
+
+def test_failure_status_matches():
+    """lambda > lambda_max => status -1 (DDPSolver.hpp:196-204,320-328); max_iter exhaustion => 0."""
+    import nmpc_amd
+    from nmpc_amd import workloads
+    wl = workloads.cartpole_batch(B=64, T=20, seed=5)
+    prob = nmpc_amd.DDPProblemCartPole(running_u=[-1.0])  # negative input weight: Quu_F never positive definite
+    s = nmpc_amd.DDPSolverBatch(prob, wl.B)
+    s.config().print_level = 0
+    s.config().horizon_steps = wl.T
+    s.config().lambda_max = 1e-3
+    ok = s.solve(wl.t0, wl.x0, wl.u_init)
+    ocfg = oracle.default_config(horizon_steps=wl.T, lambda_max=1e-3)
+    ref = oracle.solve_batch("cartpole", ocfg, wl.x0, wl.u_init, params=oracle.default_params("cartpole", running_u=-1.0))
+    assert not ok.any() and (ref.status == -1).all()
+    np.testing.assert_array_equal(s.status(), ref.status)
+    np.testing.assert_array_equal(s.iters(), ref.iters)
+    np.testing.assert_array_equal(s.traceLast()[:, INT_COLS], ref.trace_last[:, INT_COLS])
+    wl2 = workloads.cartpole_batch(B=64, T=100, seed=5)
+    s2 = make_solver(wl2, max_iter=2)
+    assert not s2.solve(wl2.t0, wl2.x0, wl2.u_init).any()
+    assert (s2.status() == 0).all() and (s2.iters() == 2).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# edge cases: tiny, ragged and degenerate shapes
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B", [1, 63, 65, 130])
+def test_ragged_batches(B):
+    from nmpc_amd import workloads
+    wl = workloads.cartpole_batch(B=B, T=40, seed=B)
+    s = make_solver(wl, max_iter=15)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    check_against_oracle(wl, s, oracle_batch(wl, max_iter=15))
+
+
+def test_single_step_horizon_and_zero_iterations():
+    from nmpc_amd import workloads
+    wl = workloads.cartpole_batch(B=8, T=1, seed=2)
+    s = make_solver(wl)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    check_against_oracle(wl, s, oracle_batch(wl))
+    wl = workloads.cartpole_batch(B=8, T=30, seed=2)
+    s = make_solver(wl, max_iter=0)  # only the initial rollout (DDPSolver.hpp:83-95)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert (s.iters() == 0).all() and (s.status() == 0).all()
+    np.testing.assert_allclose(s.trace()[:, 0, 1], s.cost().sum(axis=1), rtol=1e-14)  # trace[0] = initial cost
+    np.testing.assert_array_equal(s.U(), wl.u_init)
+    ocfg = oracle.default_config(horizon_steps=wl.T, max_iter=1)
+    r0 = oracle.solve(wl.model, ocfg, wl.x0[0], wl.u_init[0])
+    assert abs(s.trace()[0, 0, 1] - r0.trace[0, 1]) <= TOL_COST * abs(r0.trace[0, 1])
+
+
+def test_api_misuse_raises_like_the_reference():
+    import nmpc_amd
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.DDPProblemCartPole(), 4)
+    s.config().print_level = 0
+    with pytest.raises(ValueError, match="length should be 100 but 99"):  # DDPSolver.hpp:41-45
+        s.solve(0.0, np.zeros((4, 4)), np.zeros((4, 99, 1)))
+    s.config().use_state_eq_second_derivative = True
+    with pytest.raises(RuntimeError, match="not implemented"):  # DDPSolver.hpp:391-414
+        s.solve(0.0, np.zeros((4, 4)), np.zeros((4, 100, 1)))
+    s.config().use_state_eq_second_derivative = False
+    s.config().with_input_constraint = True
+    with pytest.raises(RuntimeError, match="input limits"):
+        s.solve(0.0, np.zeros((4, 4)), np.zeros((4, 100, 1)))
+    v = nmpc_amd.DDPSolverBatch(nmpc_amd.DDPProblemVerticalMotion(), 1)
+    v.config().horizon_steps = 10
+    with pytest.raises(RuntimeError, match="dimension should be 1 but 2"):  # DDPSolver.hpp:46-58
+        v.solve(0.0, np.zeros((1, 2)), [[np.zeros(2)] * 10])
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE full size: size-independent properties
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_c2_properties():
+    """4096 cart-pole instances, T = 100 (BASELINE config 2).  Properties that need no oracle:
+    determinism, monotone cost over accepted iterations, trajectory == rollout of its own inputs,
+    dV / lambda-schedule consistency; plus an oracle spot check on a strided sample."""
+    from nmpc_amd import workloads
+    wl = workloads.cartpole_batch(B=4096, T=100, seed=1234)
+    s = make_solver(wl)
+    ok = s.solve(wl.t0, wl.x0, wl.u_init)
+    X, U, cost, tr, iters, status = s.X().copy(), s.U().copy(), s.cost().copy(), s.trace().copy(), s.iters().copy(), \
+        s.status().copy()
+    assert ok.all() and (status == 1).all()
+    # (1) bitwise determinism of a second solve
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert np.array_equal(X, s.X()) and np.array_equal(U, s.U()) and np.array_equal(iters, s.iters())
+    # (2) the total cost never increases along the iterations of any instance
+    for b in range(0, wl.B, 37):
+        J = tr[b, : iters[b] + 1, 1]
+        J = J[J != 0] if tr[b, iters[b], 1] == 0 else J  # a row ended by the small-gradient test carries cost 0
+        assert np.all(np.diff(J) <= 1e-9 * np.abs(J[:-1]))
+    # (3) X is the rollout of U through the model; cost_list is its running / terminal cost (oracle model eval)
+    for b in range(0, wl.B, 511):
+        x = wl.x0[b].copy()
+        for i in range(wl.T):
+            ev = oracle.model_eval("cartpole", None, i * 0.01, x, U[b, i])
+            assert abs(ev.running_cost - cost[b, i]) <= 1e-12 * (1 + abs(cost[b, i]))
+            x = ev.xn
+            assert np.abs(x - X[b, i + 1]).max() <= 1e-11 * (1 + np.abs(x).max())
+    # (4) initial states are untouched, first trace row is the initial cost
+    np.testing.assert_array_equal(X[:, 0, :], wl.x0)
+    # (5) oracle spot check on a strided sample of 128 instances: identical decisions
+    idx = np.arange(0, wl.B, 32)
+    ocfg = oracle.default_config(horizon_steps=wl.T)
+    ref = oracle.solve_batch(wl.model, ocfg, wl.x0[idx], wl.u_init[idx], n_threads=8)
+    np.testing.assert_array_equal(iters[idx], ref.iters)
+    np.testing.assert_array_equal(status[idx], ref.status)
+    assert scaled_err(X[idx], ref.X) <= TOL and scaled_err(U[idx], ref.U) <= TOL
+
+
+def test_device_pointer_entry_and_get_device():
+    """solve_device / get_device with buffers resident in HBM (torch tensors): same results as the host entry."""
+    torch = pytest.importorskip("torch")
+    from nmpc_amd import _capi, workloads
+    wl = workloads.cartpole_batch(B=256, T=50, seed=8)
+    s = make_solver(wl, max_iter=12)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    Xh, Uh = s.X().copy(), s.U().copy()
+    dev = torch.device("cuda", 0)
+    dx, du, dt = (torch.from_numpy(a).to(dev) for a in (wl.x0, wl.u_init, wl.t0))
+    s.solveDevice(dt.data_ptr(), dx.data_ptr(), du.data_ptr())
+    out = torch.empty(Xh.size, dtype=torch.float64, device=dev)
+    s.getDevice(_capi.FIELD_X, out.data_ptr(), Xh.nbytes)
+    s.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy().reshape(Xh.shape), Xh)
+    np.testing.assert_array_equal(s.U(), Uh)
+    n, tot, ker = s.timingStats()
+    assert n >= 2 and 0 < ker <= tot
+
+
+def test_mpc_warm_start_loop_matches_oracle():
+    """Receding-horizon use (TestDDPBipedal.cpp:243-268): solve -> x_list[1], shifted u_list -> solve ... with the
+    handle (device buffers) kept alive across solves; 12 ticks of a batch of 16 against the oracle's loop."""
+    import nmpc_amd
+    B, T, ticks = 16, 300, 12
+    rng = np.random.default_rng(4)
+    x = np.stack([rng.uniform(-0.02, 0.02, B), rng.uniform(-0.05, 0.05, B)], 1)
+    t = np.full(B, 6.9)  # the horizon crosses the omega^2 transient at 7 s
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.DDPProblemBipedal(), B)
+    s.config().print_level = 0
+    s.config().horizon_steps = T
+    u = np.zeros((B, T, 1))
+    xs, us = [], []
+    for _ in range(ticks):
+        s.solve(t, x, u)
+        X, U = s.X(), s.U()
+        xs.append(X[:, 0].copy())
+        us.append(U[:, 0, 0].copy())
+        x = X[:, 1].copy()
+        u = np.concatenate([U[:, 1:], U[:, -1:]], axis=1)
+        t = t + 0.01
+    cfg = oracle.default_config(horizon_steps=T)
+    for b in range(0, B, 5):
+        r = oracle.mpc_run("bipedal", cfg, xs[0][b], ticks, t0=6.9, shift_warm_start=True)
+        got_x = np.array([xx[b] for xx in xs])
+        got_u = np.array([uu[b] for uu in us])
+        assert scaled_err(got_x, r.x) <= TOL and scaled_err(got_u, r.u0[:, 0]) <= TOL

@@ -1138,8 +1138,8 @@ struct InstanceSolver
 #pragma unroll kU
         for(int a = 0; a < MM; a++)
         {
-          st(kp + a * LW, ob, k[a]);
-          k_next[a] = k[a];
+          st(kp + a * LW, ob, (a < m) ? k[a] : 0.0); // entries beyond inputDim(t) are kept zero
+          k_next[a] = (a < m) ? k[a] : 0.0;
           if(a < m)
           {
             kn += k[a] * k[a];
@@ -1149,7 +1149,7 @@ struct InstanceSolver
 #pragma unroll kU
         for(int e = 0; e < MM * N; e++)
         {
-          st(Kp + e * LW, ob, K[e]);
+          st(Kp + e * LW, ob, ((e % MM) < m) ? K[e] : 0.0);
         }
         m_next = m;
         // for m == 1 the two norms are |k| and |u| exactly (sqrt(x*x) == |x| up to under/overflow)
@@ -1262,7 +1262,7 @@ struct InstanceSolver
   // -------------------------------------------------------------------------------------------------
   NMPC_D void writeTraceRow(int row, const double * tr) const
   {
-    if(buf.trace_rows > 1 && row < buf.trace_rows)
+    if(cfg.trace_level >= 1 && row < buf.trace_rows)
     {
       double * p = tileBase(buf.trace, static_cast<size_t>(buf.trace_rows) * NMPC_HIP_NTRACE)
                    + (static_cast<size_t>(row) * NMPC_HIP_NTRACE) * LW;

@@ -44,25 +44,45 @@ def scaled_err(got, want):
     return float((np.abs(got - want) / (1.0 + np.abs(want))).max())
 
 
-def check_against_oracle(wl, s, ref, check_gains=True):
-    np.testing.assert_array_equal(s.status(), ref.status)
-    np.testing.assert_array_equal(s.iters(), ref.iters)
+def decision_stable_mask(wl, ref, **cfg):
+    """Instances whose discrete decisions the ORACLE ITSELF keeps under 1e-15 .. 1e-13 relative perturbations of
+    x0.  The reference algorithm is not decision-stable everywhere: e.g. the box-constrained vertical-motion
+    problem has two identical actuators (a degenerate QP), and a 1e-15 perturbation of the inputs flips BoxQP
+    terminations and iteration counts of ~4 % of the instances in the Eigen-path restatement itself.  Bit-exact
+    index parity is only meaningful on the stable set (cf. the margin filter of SURVEY.md §8 c)."""
+    rng = np.random.default_rng(12345)
+    stable = np.ones(wl.B, bool)
+    ocfg = oracle.default_config(horizon_steps=wl.T, **{k: (int(v) if isinstance(v, bool) else v) for k, v in cfg.items()})
+    lo, up = wl.limits if wl.limits is not None else (None, None)
+    for eps in (1e-15, 2e-15, 5e-15, 1e-14, 2e-14, 5e-14, 1e-13, 2e-13, 5e-13, 1e-12, 3e-12, 1e-11):
+        x0p = wl.x0 * (1 + eps * rng.uniform(-1, 1, wl.x0.shape)) + 1e-300
+        r = oracle.solve_batch(wl.model, ocfg, x0p, wl.u_init, t0=wl.t0, lower=lo, upper=up, n_threads=8,
+                               want_alpha_hist=True)
+        stable &= (r.iters == ref.iters) & (r.status == ref.status) & (r.alpha_idx_hist == ref.alpha_idx_hist).all(axis=1)
+        stable &= np.abs(r.U - ref.U).reshape(wl.B, -1).max(axis=1) <= 1e-7 * (1 + np.abs(ref.U).reshape(wl.B, -1).max(axis=1))
+    return stable
+
+
+def check_against_oracle(wl, s, ref, check_gains=True, mask=None):
+    mk = np.ones(wl.B, bool) if mask is None else mask
+    np.testing.assert_array_equal(s.status()[mk], ref.status[mk])
+    np.testing.assert_array_equal(s.iters()[mk], ref.iters[mk])
     # per-iteration alpha index history
     tr = s.trace()
     gpu_hist = np.full_like(ref.alpha_idx_hist, -2)
     for b in range(wl.B):
-        n = int(ref.iters[b])
+        n = min(int(ref.iters[b]), int(s.iters()[b]))
         gpu_hist[b, :n] = tr[b, 1:n + 1, 9].astype(np.int32)
-    np.testing.assert_array_equal(gpu_hist, ref.alpha_idx_hist)
-    np.testing.assert_array_equal(s.traceLast()[:, INT_COLS], ref.trace_last[:, INT_COLS])
-    assert scaled_err(s.X(), ref.X) <= TOL
-    assert scaled_err(s.U(), ref.U) <= TOL
-    ok = ref.status >= 0
+    np.testing.assert_array_equal(gpu_hist[mk], ref.alpha_idx_hist[mk])
+    np.testing.assert_array_equal(s.traceLast()[mk][:, INT_COLS], ref.trace_last[mk][:, INT_COLS])
+    assert scaled_err(s.X()[mk], ref.X[mk]) <= TOL
+    assert scaled_err(s.U()[mk], ref.U[mk]) <= TOL
+    ok = (ref.status >= 0) & mk
     if check_gains and ok.any():
         assert scaled_err(s.kff()[ok], ref.k[ok]) <= TOL
         assert scaled_err(s.Kfb()[ok], ref.K[ok]) <= TOL
     Jg, Jr = s.cost().sum(axis=1), ref.cost.sum(axis=1)
-    assert np.all(np.abs(Jg - Jr) <= TOL_COST * np.abs(Jr) + 1e-300)
+    assert np.all((np.abs(Jg - Jr) <= TOL_COST * np.abs(Jr) + 1e-300)[mk])
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -133,7 +153,17 @@ def test_vertical_motion_variable_input_dimension(constrained):
     assert set(np.unique(dims)) == {0, 1, 2}
     for b in range(0, wl.B, 16):
         np.testing.assert_array_equal(dims[b], oracle.input_dims(wl.model, None, wl.t0[b], wl.T))
-    check_against_oracle(wl, s, ref)
+    # two identical actuators make the constrained QP degenerate: compare on the oracle's decision-stable set
+    mask = decision_stable_mask(wl, ref, initial_lambda=1e-6, with_input_constraint=constrained, max_iter=60)
+    assert mask.mean() > 0.75
+    if not constrained:
+        assert mask.all()
+    check_against_oracle(wl, s, ref, mask=mask)
+    # every converged instance, stable or not: same optimum to 1e-3 relative.  (Inputs may leave the box: like
+    # the reference, the forward pass does not clamp u, DDPSolver.hpp:548 "todo"; callers clamp u[0].)
+    Jg, Jr = s.cost().sum(axis=1), ref.cost.sum(axis=1)
+    both = (s.status() == 1) & (ref.status == 1)
+    assert np.all(np.abs(Jg - Jr)[both] <= 1e-3 * np.abs(Jr)[both])
     # entries beyond inputDim(t) are zero
     U = s.U()
     assert np.all(U[dims == 0] == 0.0) and np.all(U[:, :, 1][dims < 2] == 0.0)
@@ -252,7 +282,7 @@ def test_full_size_c2_properties():
     ok = s.solve(wl.t0, wl.x0, wl.u_init)
     X, U, cost, tr, iters, status = s.X().copy(), s.U().copy(), s.cost().copy(), s.trace().copy(), s.iters().copy(), \
         s.status().copy()
-    assert ok.all() and (status == 1).all()
+    assert np.array_equal(ok, status == 1) and (status >= 0).all() and (status == 1).mean() > 0.99
     # (1) bitwise determinism of a second solve
     s.solve(wl.t0, wl.x0, wl.u_init)
     assert np.array_equal(X, s.X()) and np.array_equal(U, s.U()) and np.array_equal(iters, s.iters())
@@ -271,13 +301,13 @@ def test_full_size_c2_properties():
             assert np.abs(x - X[b, i + 1]).max() <= 1e-11 * (1 + np.abs(x).max())
     # (4) initial states are untouched, first trace row is the initial cost
     np.testing.assert_array_equal(X[:, 0, :], wl.x0)
-    # (5) oracle spot check on a strided sample of 128 instances: identical decisions
-    idx = np.arange(0, wl.B, 32)
+    # (5) the whole batch against the oracle: identical decisions for all 4096 instances (a handful exhaust
+    #     max_iter = 500 in the reference algorithm too: status 0)
     ocfg = oracle.default_config(horizon_steps=wl.T)
-    ref = oracle.solve_batch(wl.model, ocfg, wl.x0[idx], wl.u_init[idx], n_threads=8)
-    np.testing.assert_array_equal(iters[idx], ref.iters)
-    np.testing.assert_array_equal(status[idx], ref.status)
-    assert scaled_err(X[idx], ref.X) <= TOL and scaled_err(U[idx], ref.U) <= TOL
+    ref = oracle.solve_batch(wl.model, ocfg, wl.x0, wl.u_init, n_threads=16, want_gains=False)
+    np.testing.assert_array_equal(iters, ref.iters)
+    np.testing.assert_array_equal(status, ref.status)
+    assert scaled_err(X, ref.X) <= TOL and scaled_err(U, ref.U) <= TOL
 
 
 def test_device_pointer_entry_and_get_device():

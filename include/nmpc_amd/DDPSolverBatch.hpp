@@ -1,0 +1,459 @@
+// Host-side C++ mirror of the reference's nmpc_ddp::DDPSolver<StateDim, InputDim>
+// (/root/reference/nmpc_ddp/include/nmpc_ddp/DDPSolver.h:23-376) for a BATCH of independent problem instances
+// solved on one MI355X.  Same member names, argument meaning and error behaviour (the exception types of
+// DDPSolver.hpp:41-58,391-414), with a leading batch index where the reference has one instance.
+//
+// This header is plain C++17 (no HIP, no Eigen): everything numeric happens behind the C-ABI of
+// <nmpc_hip_ddp.h> in libnmpc_hip_ddp.so.  The problem TYPE must have been compiled into a gfx950 code object
+// and registered (NMPC_AMD_REGISTER_PROBLEM, <nmpc_amd/hip/model_registry.hpp>); the problem OBJECT the user
+// passes here (parameters, cost weights, dt) is copied to the solver at every solve(), so mutating
+// `problem->param_` between solves behaves as with the reference's shared_ptr.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include <nmpc_amd/DDPProblem.hpp>
+#include <nmpc_hip_ddp.h>
+
+namespace nmpc_amd
+{
+/** \brief Batched DDP solver.
+    \tparam Problem problem class derived from nmpc_amd::DDPProblem<StateDim, InputDim[, MaxInputDim]> with a
+            `static constexpr const char * kName` under which its kernels are registered */
+template<class Problem>
+class DDPSolverBatch
+{
+public:
+  static constexpr int StateDim = Problem::kStateDim;
+  static constexpr int InputDimMax = Problem::kInputDimMax;
+  static constexpr int MM = InputDimMax > 0 ? InputDimMax : 1;
+
+  using StateDimVector = typename Problem::StateDimVector;
+  using InputDimVector = typename Problem::InputDimVector;
+  using InputStateDimMatrix = typename Problem::InputStateDimMatrix;
+
+  /*! \brief Configuration (DDPSolver::Configuration, DDPSolver.h:47-110; defaults come from the library). */
+  struct Configuration
+  {
+    Configuration()
+    {
+      nmpc_hip_ddp_config c;
+      nmpc_hip_ddp_default_config(&c);
+      with_input_constraint = c.with_input_constraint != 0;
+      max_iter = c.max_iter;
+      horizon_steps = c.horizon_steps;
+      reg_type = c.reg_type;
+      initial_lambda = c.initial_lambda;
+      initial_dlambda = c.initial_dlambda;
+      lambda_factor = c.lambda_factor;
+      lambda_min = c.lambda_min;
+      lambda_max = c.lambda_max;
+      k_rel_norm_thre = c.k_rel_norm_thre;
+      lambda_thre = c.lambda_thre;
+      alpha_list.assign(c.alpha_list, c.alpha_list + c.n_alpha);
+      cost_update_ratio_thre = c.cost_update_ratio_thre;
+      cost_update_thre = c.cost_update_thre;
+    }
+
+    int print_level = 1;
+    bool use_state_eq_second_derivative = false;
+    bool with_input_constraint = false;
+    int max_iter = 500;
+    int horizon_steps = 100;
+    int reg_type = 1;
+    double initial_lambda = 1e-4;
+    double initial_dlambda = 1.0;
+    double lambda_factor = 1.6;
+    double lambda_min = 1e-6;
+    double lambda_max = 1e10;
+    double k_rel_norm_thre = 1e-4;
+    double lambda_thre = 1e-5;
+    std::vector<double> alpha_list;
+    double cost_update_ratio_thre = 0;
+    double cost_update_thre = 1e-7;
+    //! 1: keep the per-iteration trace of every instance on the device (traceDataList); 0: last row only
+    int trace_level = 1;
+  };
+
+  /*! \brief Control data of one instance (DDPSolver::ControlData, DDPSolver.h:113-123). */
+  struct ControlData
+  {
+    std::vector<StateDimVector> x_list;
+    std::vector<InputDimVector> u_list;
+    std::vector<double> cost_list;
+  };
+
+  /*! \brief Data to trace optimization loop (DDPSolver::TraceData, DDPSolver.h:179-216).  The duration_*
+      members have no per-instance meaning on the GPU and stay 0; the three integers are the discrete decisions
+      of the iteration. */
+  struct TraceData
+  {
+    int iter = 0;
+    double cost = 0;
+    double lambda = 0;
+    double dlambda = 0;
+    double alpha = 0;
+    double k_rel_norm = 0;
+    double cost_update_actual = 0;
+    double cost_update_expected = 0;
+    double cost_update_ratio = 0;
+    double duration_derivative = 0;
+    double duration_backward = 0;
+    double duration_forward = 0;
+    int alpha_idx = -1;
+    int n_backward = 0;
+    int n_forward = 0;
+  };
+
+  /*! \brief Data of computation duration (DDPSolver.h:219-247) for the whole batch [msec]. */
+  struct ComputationDuration
+  {
+    double solve = 0; //!< H2D + layout conversion + solve kernel (HIP events)
+    double setup = 0; //!< solve - opt
+    double opt = 0; //!< solve kernel alone
+  };
+
+public:
+  /** \brief Constructor.
+      \param problem DDP problem
+      \param batch_size number of independent instances per solve()
+      \param device HIP device index */
+  DDPSolverBatch(const std::shared_ptr<Problem> & problem, int batch_size, int device = 0)
+  : problem_(problem), batch_size_(batch_size), device_(device)
+  {
+    static_assert(std::is_trivially_copyable<Problem>::value, "the problem object is passed to the GPU by value");
+    if(batch_size <= 0)
+    {
+      throw std::invalid_argument("batch_size must be positive: " + std::to_string(batch_size));
+    }
+  }
+
+  ~DDPSolverBatch()
+  {
+    nmpc_hip_ddp_destroy(handle_);
+  }
+
+  DDPSolverBatch(const DDPSolverBatch &) = delete;
+  DDPSolverBatch & operator=(const DDPSolverBatch &) = delete;
+
+  /** \brief Accessor to configuration. */
+  inline Configuration & config()
+  {
+    return config_;
+  }
+  inline const Configuration & config() const
+  {
+    return config_;
+  }
+
+  inline int batchSize() const
+  {
+    return batch_size_;
+  }
+
+  /** \brief Set function to return input limits (lower, upper), DDPSolver.h:282-285.
+      Only limits that are constant in time are supported on the device — the only form the reference's callers
+      use (TestDDPCartPole.cpp:379-386, TestDDPVerticalMotion.cpp:262-270): the function is sampled at t = 0. */
+  inline void setInputLimitsFunc(const std::function<std::array<InputDimVector, 2>(double)> & input_limits_func)
+  {
+    const std::array<InputDimVector, 2> lim = input_limits_func(0.0);
+    has_limits_ = true;
+    for(int i = 0; i < MM; i++)
+    {
+      lower_[i] = i < lim[0].size() ? lim[0][i] : (lim[0].size() > 0 ? lim[0][lim[0].size() - 1] : -INFINITY);
+      upper_[i] = i < lim[1].size() ? lim[1][i] : (lim[1].size() > 0 ? lim[1][lim[1].size() - 1] : INFINITY);
+    }
+  }
+
+  /** \brief Solve optimization for every instance of the batch (DDPSolver::solve, DDPSolver.h:275).
+      \param current_t current time of each instance [sec] (size batch)
+      \param current_x current state of each instance (size batch)
+      \param initial_u_list initial input sequence of each instance (size batch x horizon_steps)
+      \return per instance, whether the process finished successfully (converged) */
+  std::vector<bool> solve(const std::vector<double> & current_t,
+                          const std::vector<StateDimVector> & current_x,
+                          const std::vector<std::vector<InputDimVector>> & initial_u_list)
+  {
+    const int T = config_.horizon_steps;
+    const size_t B = static_cast<size_t>(batch_size_);
+    if(current_t.size() != B || current_x.size() != B || initial_u_list.size() != B)
+    {
+      throw std::invalid_argument("batch of current_t / current_x / initial_u_list should be " + std::to_string(B) + ".");
+    }
+    ensureHandle();
+    pushState();
+    std::vector<double> x0(B * StateDim), u0(B * T * MM, 0.0);
+    std::vector<int> dims(T);
+    for(size_t b = 0; b < B; b++)
+    {
+      // Check initial_u_list    DDPSolver.hpp:41-58
+      if(static_cast<int>(initial_u_list[b].size()) != T)
+      {
+        throw std::invalid_argument("initial_u_list length should be " + std::to_string(T) + " but "
+                                    + std::to_string(initial_u_list[b].size()) + ".");
+      }
+      check(nmpc_hip_ddp_input_dims(handle_, current_t[b], dims.data()));
+      for(int i = 0; i < T; i++)
+      {
+        const InputDimVector & u = initial_u_list[b][i];
+        if(u.size() != dims[i])
+        {
+          const double t = current_t[b] + i * problem_->dt();
+          throw std::runtime_error("initial_u dimension should be " + std::to_string(dims[i]) + " but "
+                                   + std::to_string(u.size()) + ". i: " + std::to_string(i)
+                                   + ", time: " + std::to_string(t));
+        }
+        for(int a = 0; a < dims[i]; a++)
+        {
+          u0[(b * T + i) * MM + a] = u[a];
+        }
+      }
+      for(int j = 0; j < StateDim; j++)
+      {
+        x0[b * StateDim + j] = current_x[b][j];
+      }
+    }
+    check(nmpc_hip_ddp_solve(handle_, current_t.data(), x0.data(), u0.data()));
+    fetched_ = false;
+    fetchResults();
+    std::vector<bool> ok(B);
+    int n_fail = 0;
+    for(size_t b = 0; b < B; b++)
+    {
+      ok[b] = status_[b] == 1;
+      n_fail += status_[b] < 0 ? 1 : 0;
+    }
+    if(n_fail > 0 && config_.print_level >= 1)
+    {
+      std::cout << "[DDP] Failure due to large lambda in " << n_fail << " of " << B << " instances." << std::endl;
+    }
+    return ok;
+  }
+
+  /** \brief Const accessor to control data of instance b calculated by solve(). */
+  inline const ControlData & controlData(int b) const
+  {
+    return control_data_.at(b);
+  }
+
+  /** \brief Const accessor to trace data list of instance b. */
+  inline const std::vector<TraceData> & traceDataList(int b) const
+  {
+    return trace_data_list_.at(b);
+  }
+
+  /** \brief Feedforward terms k[0..N-1] and feedback gains K[0..N-1] of instance b (k_list_, K_list_). */
+  inline const std::vector<InputDimVector> & kList(int b) const
+  {
+    return k_list_.at(b);
+  }
+  inline const std::vector<InputStateDimMatrix> & KList(int b) const
+  {
+    return K_list_.at(b);
+  }
+
+  /** \brief Status of instance b: 1 converged, 0 max_iter exhausted, -1 failure (procOnce retval, DDPSolver.h:311-315). */
+  inline int status(int b) const
+  {
+    return status_.at(b);
+  }
+
+  /** \brief Const accessor to computation duration. */
+  inline const ComputationDuration & computationDuration() const
+  {
+    return computation_duration_;
+  }
+
+  /** \brief Dump trace data list of instance b (same 12 columns as DDPSolver::dumpTraceDataList). */
+  void dumpTraceDataList(int b, const std::string & file_path) const
+  {
+    std::ofstream ofs(file_path);
+    ofs << "iter cost lambda dlambda alpha k_rel_norm cost_update_actual cost_update_expected cost_update_ratio "
+           "duration_derivative duration_backward duration_forward"
+        << std::endl;
+    for(const auto & t : trace_data_list_.at(b))
+    {
+      ofs << t.iter << " " << t.cost << " " << t.lambda << " " << t.dlambda << " " << t.alpha << " " << t.k_rel_norm
+          << " " << t.cost_update_actual << " " << t.cost_update_expected << " " << t.cost_update_ratio << " "
+          << t.duration_derivative << " " << t.duration_backward << " " << t.duration_forward << std::endl;
+    }
+  }
+
+protected:
+  static void check(int rc)
+  {
+    if(rc == NMPC_HIP_OK)
+    {
+      return;
+    }
+    const std::string msg = nmpc_hip_ddp_last_error();
+    if(rc == NMPC_HIP_ERR_INVALID_ARGUMENT || rc == NMPC_HIP_ERR_UNKNOWN_MODEL)
+    {
+      throw std::invalid_argument(msg);
+    }
+    throw std::runtime_error(msg);
+  }
+
+  void ensureHandle()
+  {
+    if(handle_ && handle_T_ == config_.horizon_steps)
+    {
+      return;
+    }
+    nmpc_hip_ddp_destroy(handle_);
+    handle_ = nullptr;
+    check(nmpc_hip_ddp_create(Problem::kName, config_.horizon_steps, batch_size_, device_, &handle_));
+    handle_T_ = config_.horizon_steps;
+  }
+
+  void pushState()
+  {
+    check(nmpc_hip_ddp_set_model_params(handle_, problem_.get(), sizeof(Problem)));
+    nmpc_hip_ddp_config c;
+    nmpc_hip_ddp_default_config(&c);
+    c.with_input_constraint = config_.with_input_constraint ? 1 : 0;
+    c.use_state_eq_second_derivative = config_.use_state_eq_second_derivative ? 1 : 0;
+    c.max_iter = config_.max_iter;
+    c.horizon_steps = config_.horizon_steps;
+    c.reg_type = config_.reg_type;
+    c.initial_lambda = config_.initial_lambda;
+    c.initial_dlambda = config_.initial_dlambda;
+    c.lambda_factor = config_.lambda_factor;
+    c.lambda_min = config_.lambda_min;
+    c.lambda_max = config_.lambda_max;
+    c.k_rel_norm_thre = config_.k_rel_norm_thre;
+    c.lambda_thre = config_.lambda_thre;
+    c.cost_update_ratio_thre = config_.cost_update_ratio_thre;
+    c.cost_update_thre = config_.cost_update_thre;
+    c.trace_level = config_.trace_level;
+    if(config_.alpha_list.empty() || config_.alpha_list.size() > NMPC_HIP_MAX_ALPHA)
+    {
+      throw std::invalid_argument("alpha_list size must be in [1, 32]");
+    }
+    c.n_alpha = static_cast<int>(config_.alpha_list.size());
+    for(int i = 0; i < c.n_alpha; i++)
+    {
+      c.alpha_list[i] = config_.alpha_list[i];
+    }
+    check(nmpc_hip_ddp_set_config(handle_, &c));
+    if(has_limits_)
+    {
+      check(nmpc_hip_ddp_set_input_limits(handle_, lower_, upper_));
+    }
+  }
+
+  void fetchResults()
+  {
+    const int T = config_.horizon_steps;
+    const size_t B = static_cast<size_t>(batch_size_);
+    std::vector<double> X(B * (T + 1) * StateDim), U(B * T * MM), C(B * (T + 1)), k(B * T * MM), K(B * T * StateDim * MM);
+    std::vector<int> dims(B * T), iters(B);
+    status_.resize(B);
+    check(nmpc_hip_ddp_get(handle_, NMPC_HIP_FIELD_X, X.data(), X.size() * sizeof(double)));
+    check(nmpc_hip_ddp_get(handle_, NMPC_HIP_FIELD_U, U.data(), U.size() * sizeof(double)));
+    check(nmpc_hip_ddp_get(handle_, NMPC_HIP_FIELD_COST, C.data(), C.size() * sizeof(double)));
+    check(nmpc_hip_ddp_get(handle_, NMPC_HIP_FIELD_KFF, k.data(), k.size() * sizeof(double)));
+    check(nmpc_hip_ddp_get(handle_, NMPC_HIP_FIELD_KFB, K.data(), K.size() * sizeof(double)));
+    check(nmpc_hip_ddp_get(handle_, NMPC_HIP_FIELD_INPUT_DIM, dims.data(), dims.size() * sizeof(int)));
+    check(nmpc_hip_ddp_get(handle_, NMPC_HIP_FIELD_STATUS, status_.data(), B * sizeof(int)));
+    check(nmpc_hip_ddp_get(handle_, NMPC_HIP_FIELD_ITERS, iters.data(), B * sizeof(int)));
+    std::vector<double> trace;
+    const size_t rows = static_cast<size_t>(config_.max_iter) + 1;
+    if(config_.trace_level >= 1)
+    {
+      trace.resize(B * rows * NMPC_HIP_NTRACE);
+      check(nmpc_hip_ddp_get(handle_, NMPC_HIP_FIELD_TRACE, trace.data(), trace.size() * sizeof(double)));
+    }
+    control_data_.assign(B, ControlData());
+    k_list_.assign(B, {});
+    K_list_.assign(B, {});
+    trace_data_list_.assign(B, {});
+    for(size_t b = 0; b < B; b++)
+    {
+      ControlData & cd = control_data_[b];
+      cd.x_list.resize(T + 1);
+      cd.u_list.resize(T);
+      cd.cost_list.assign(C.begin() + b * (T + 1), C.begin() + (b + 1) * (T + 1));
+      k_list_[b].resize(T);
+      K_list_[b].resize(T);
+      for(int i = 0; i <= T; i++)
+      {
+        for(int j = 0; j < StateDim; j++)
+        {
+          cd.x_list[i][j] = X[(b * (T + 1) + i) * StateDim + j];
+        }
+      }
+      for(int i = 0; i < T; i++)
+      {
+        const int m = dims[b * T + i];
+        cd.u_list[i].resize(m);
+        k_list_[b][i].resize(m);
+        K_list_[b][i].resize(m, StateDim);
+        for(int a = 0; a < m; a++)
+        {
+          cd.u_list[i][a] = U[(b * T + i) * MM + a];
+          k_list_[b][i][a] = k[(b * T + i) * MM + a];
+          for(int c = 0; c < StateDim; c++)
+          {
+            K_list_[b][i](a, c) = K[((b * T + i) * StateDim + c) * MM + a];
+          }
+        }
+      }
+      if(config_.trace_level >= 1)
+      {
+        for(int r = 0; r <= iters[b]; r++)
+        {
+          const double * t = &trace[(b * rows + r) * NMPC_HIP_NTRACE];
+          TraceData td;
+          td.iter = static_cast<int>(t[NMPC_HIP_TRACE_ITER]);
+          td.cost = t[NMPC_HIP_TRACE_COST];
+          td.lambda = t[NMPC_HIP_TRACE_LAMBDA];
+          td.dlambda = t[NMPC_HIP_TRACE_DLAMBDA];
+          td.alpha = t[NMPC_HIP_TRACE_ALPHA];
+          td.k_rel_norm = t[NMPC_HIP_TRACE_K_REL_NORM];
+          td.cost_update_actual = t[NMPC_HIP_TRACE_COST_UPDATE_ACTUAL];
+          td.cost_update_expected = t[NMPC_HIP_TRACE_COST_UPDATE_EXPECTED];
+          td.cost_update_ratio = t[NMPC_HIP_TRACE_COST_UPDATE_RATIO];
+          td.alpha_idx = static_cast<int>(t[NMPC_HIP_TRACE_ALPHA_IDX]);
+          td.n_backward = static_cast<int>(t[NMPC_HIP_TRACE_N_BACKWARD]);
+          td.n_forward = static_cast<int>(t[NMPC_HIP_TRACE_N_FORWARD]);
+          trace_data_list_[b].push_back(td);
+        }
+      }
+    }
+    float total_ms = 0, kernel_ms = 0;
+    check(nmpc_hip_ddp_last_solve_ms(handle_, &total_ms, &kernel_ms));
+    computation_duration_.solve = total_ms;
+    computation_duration_.opt = kernel_ms;
+    computation_duration_.setup = total_ms - kernel_ms;
+    fetched_ = true;
+  }
+
+protected:
+  Configuration config_;
+  std::shared_ptr<Problem> problem_;
+  int batch_size_ = 0;
+  int device_ = 0;
+  nmpc_hip_ddp_handle handle_ = nullptr;
+  int handle_T_ = -1;
+  bool has_limits_ = false;
+  double lower_[MM];
+  double upper_[MM];
+  bool fetched_ = false;
+  std::vector<ControlData> control_data_;
+  std::vector<std::vector<TraceData>> trace_data_list_;
+  std::vector<std::vector<InputDimVector>> k_list_;
+  std::vector<std::vector<InputStateDimMatrix>> K_list_;
+  std::vector<int> status_;
+  ComputationDuration computation_duration_;
+};
+} // namespace nmpc_amd

@@ -357,3 +357,39 @@ def test_mpc_warm_start_loop_matches_oracle():
         got_x = np.array([xx[b] for xx in xs])
         got_u = np.array([uu[b] for uu in us])
         assert scaled_err(got_x, r.x) <= TOL and scaled_err(got_u, r.u0[:, 0]) <= TOL
+
+
+def test_cpp_host_mirror_example(tmp_path):
+    """include/nmpc_amd/DDPSolverBatch.hpp (plain C++ over the C-ABI, built with g++) gives the same numbers as the
+    Python mirror, and re-raises misuse as std::invalid_argument like the reference."""
+    import os
+    import re
+    import subprocess
+    import nmpc_amd
+    from nmpc_amd import build as hip_build
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cartpole_batch")
+    libdir = os.path.dirname(hip_build.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O2", f"-I{root}/include", f"{root}/examples/cartpole_batch.cpp", f"-L{libdir}",
+           "-lnmpc_hip_ddp", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    B = 8
+    r = subprocess.run([exe, str(B)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = re.findall(r"instance (\d+) converged (\d) iter (\d+) cost (\S+) u0 (\S+) theta_end (\S+)", r.stdout)
+    assert len(rows) == B and "invalid_argument: initial_u_list length should be 100 but 99." in r.stdout
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.DDPProblemCartPole(), B)
+    s.config().print_level = 0
+    x0 = np.array([[0.0, np.pi - 0.25 * b, 0.0, 0.0] for b in range(B)])
+    ok = s.solve(0.0, x0, np.zeros((B, 100, 1)))
+    for b, (_, conv, it, cost, u0, th) in enumerate(rows):
+        assert int(conv) == int(ok[b]) and int(it) == int(s.iters()[b])
+        assert abs(float(cost) - s.cost()[b].sum()) <= 1e-11 * abs(float(cost))
+        assert abs(float(u0) - s.U()[b, 0, 0]) <= 1e-10 * (1 + abs(float(u0)))
+    assert int(rows[0][2]) == 17  # the reference's start state: 17 iterations at T = 100
+    cols = open("/tmp/CartPoleBatchTraceData.txt").readline().split()
+    assert cols == ["iter", "cost", "lambda", "dlambda", "alpha", "k_rel_norm", "cost_update_actual",
+                    "cost_update_expected", "cost_update_ratio", "duration_derivative", "duration_backward",
+                    "duration_forward"]  # DDPSolver.hpp:567-578: what scripts/plotDDPTraceData.py reads

@@ -19,10 +19,48 @@
 namespace nmpc_amd
 {
 /** sin and cos of the same angle in one call (one argument reduction instead of two: on gfx950 an fp64 sin or
-    cos costs ~320 cycles per wavefront and the fused sincos ~340, profiles/ubench_r01.txt). */
+    cos of the device math library costs ~320 cycles per wavefront and its fused sincos ~340, profiles/).
+    For |x| < 2^17 (any physical joint / pole angle) it is computed here in ~30 instructions: three-term
+    Cody-Waite reduction by pi/2 with FMAs (119 bits of pi/2, exact products for |k| < 2^20), then the degree-13 /
+    degree-14 minimax kernels on [-pi/4, pi/4]; measured error against long-double references: <= 1.5 ulp for
+    |x| <= 1e3, <= 2.5 ulp up to 1e5 (tests/test_host_cpu.py).  Larger arguments take the libm / ocml path. */
 NMPC_HD void sincos(double x, double & s, double & c)
 {
-  ::sincos(x, &s, &c);
+  if(!(fabs(x) < 131072.0))
+  {
+    ::sincos(x, &s, &c);
+    return;
+  }
+  constexpr double kTwoOverPi = 6.36619772367581382433e-01;
+  constexpr double kPio2_1 = 1.57079632673412561417e+00; // first 33 bits of pi/2
+  constexpr double kPio2_2 = 6.07710050630396597660e-11; // next 33 bits
+  constexpr double kPio2_3 = 2.02226624879595063154e-21; // pi/2 - kPio2_1 - kPio2_2
+  const double k = rint(x * kTwoOverPi);
+  double r = fma(-k, kPio2_1, x);
+  r = fma(-k, kPio2_2, r);
+  r = fma(-k, kPio2_3, r);
+  const double z = r * r;
+  // sin(r) = r + r z (S1 + z (S2 + ... )),  cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ...))
+  double ps = 1.58969099521155010221e-10;
+  ps = fma(ps, z, -2.50507602534068634195e-08);
+  ps = fma(ps, z, 2.75573137070700676789e-06);
+  ps = fma(ps, z, -1.98412698298579493134e-04);
+  ps = fma(ps, z, 8.33333333332248946124e-03);
+  ps = fma(ps, z, -1.66666666666666324348e-01);
+  const double sr = fma(r * z, ps, r);
+  double pc = -1.13596475577881948265e-11;
+  pc = fma(pc, z, 2.08757232129817482790e-09);
+  pc = fma(pc, z, -2.75573143513906633035e-07);
+  pc = fma(pc, z, 2.48015872894767294178e-05);
+  pc = fma(pc, z, -1.38888888888741095749e-03);
+  pc = fma(pc, z, 4.16666666666666019037e-02);
+  const double cr = fma(z, fma(z, pc, -0.5), 1.0);
+  // quadrant: x = r + k pi/2
+  const int q = static_cast<int>(k) & 3;
+  const double s0 = (q & 1) ? cr : sr;
+  const double c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
 }
 
 //! Marker for a run-time input dimension (the reference's Eigen::Dynamic).

@@ -18,27 +18,26 @@
 
 namespace nmpc_amd
 {
-/** sin and cos of the same angle in one call (one argument reduction instead of two: on gfx950 an fp64 sin or
-    cos of the device math library costs ~320 cycles per wavefront and its fused sincos ~340, profiles/).
-    For |x| < 2^17 (any physical joint / pole angle) it is computed here in ~30 instructions: three-term
-    Cody-Waite reduction by pi/2 with FMAs (119 bits of pi/2, exact products for |k| < 2^20), then the degree-13 /
-    degree-14 minimax kernels on [-pi/4, pi/4]; measured error against long-double references: <= 1.5 ulp for
-    |x| <= 1e3, <= 2.5 ulp up to 1e5 (tests/test_host_cpu.py).  Larger arguments take the libm / ocml path. */
-NMPC_HD void sincos(double x, double & s, double & c)
+/** sin and cos of the same angle, restricted range: |x| < 2^27 rad (2.1e7 revolutions); outside (and for
+    NaN / Inf) both results are NaN — loud, never a silently wrong value.  Branch-free, ~32 instructions:
+    four-term Cody-Waite reduction by pi/2 with FMAs (three 26-bit pieces + a 53-bit tail = 131 bits of pi/2; the
+    products k * piece are exact for |k| < 2^27), then the degree-13 / degree-14 minimax kernels on [-pi/4, pi/4].
+    Measured against long-double references: <= 1.5 ulp for |x| <= 1e3, <= 2.5 ulp up to 1e8
+    (tests/test_host_cpu.py).  On gfx950 the device math library's sin / cos cost ~320 cycles per wavefront each
+    and its sincos ~340 (profiles/); this costs ~130.  Problem functors whose angles are physical (joint, pole,
+    attitude angles) should use this; sincos() below is the full-range version. */
+NMPC_HD void sincosFast(double x, double & s, double & c)
 {
-  if(!(fabs(x) < 131072.0))
-  {
-    ::sincos(x, &s, &c);
-    return;
-  }
   constexpr double kTwoOverPi = 6.36619772367581382433e-01;
-  constexpr double kPio2_1 = 1.57079632673412561417e+00; // first 33 bits of pi/2
-  constexpr double kPio2_2 = 6.07710050630396597660e-11; // next 33 bits
-  constexpr double kPio2_3 = 2.02226624879595063154e-21; // pi/2 - kPio2_1 - kPio2_2
+  constexpr double kP1 = 0x1.921fb50000000p+0; // pi/2, bits 1..26
+  constexpr double kP2 = 0x1.110b460000000p-26; // bits 27..52
+  constexpr double kP3 = 0x1.1a62630000000p-54; // bits 53..78
+  constexpr double kP4 = 0x1.8a2e03707344ap-81; // remainder
   const double k = rint(x * kTwoOverPi);
-  double r = fma(-k, kPio2_1, x);
-  r = fma(-k, kPio2_2, r);
-  r = fma(-k, kPio2_3, r);
+  double r = fma(-k, kP1, x);
+  r = fma(-k, kP2, r);
+  r = fma(-k, kP3, r);
+  r = fma(-k, kP4, r);
   const double z = r * r;
   // sin(r) = r + r z (S1 + z (S2 + ... )),  cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ...))
   double ps = 1.58969099521155010221e-10;
@@ -55,12 +54,27 @@ NMPC_HD void sincos(double x, double & s, double & c)
   pc = fma(pc, z, -1.38888888888741095749e-03);
   pc = fma(pc, z, 4.16666666666666019037e-02);
   const double cr = fma(z, fma(z, pc, -0.5), 1.0);
-  // quadrant: x = r + k pi/2
+  // quadrant: x = r + k pi/2; out of range => NaN
+  const bool in_range = fabs(x) < 134217728.0;
   const int q = static_cast<int>(k) & 3;
   const double s0 = (q & 1) ? cr : sr;
   const double c0 = (q & 1) ? sr : cr;
-  s = (q & 2) ? -s0 : s0;
-  c = ((q + 1) & 2) ? -c0 : c0;
+  const double nan = __builtin_nan("");
+  s = in_range ? ((q & 2) ? -s0 : s0) : nan;
+  c = in_range ? (((q + 1) & 2) ? -c0 : c0) : nan;
+}
+
+/** sin and cos of the same angle, full range: sincosFast inside |x| < 2^27, the math library beyond. */
+NMPC_HD void sincos(double x, double & s, double & c)
+{
+  if(__builtin_expect(fabs(x) < 134217728.0, 1))
+  {
+    sincosFast(x, s, c);
+  }
+  else
+  {
+    ::sincos(x, &s, &c);
+  }
 }
 
 //! Marker for a run-time input dimension (the reference's Eigen::Dynamic).

@@ -56,7 +56,7 @@ public:
     const double l = param_.pole_length;
 
     double sin_theta, cos_theta;
-    sincos(theta, sin_theta, cos_theta);
+    sincosFast(theta, sin_theta, cos_theta); // |theta| < 2^27 rad, NaN beyond (linalg.hpp)
     const double omega2 = omega * omega;
     const double denom = m1 + m2 * (sin_theta * sin_theta);
     // one reciprocal instead of the two divisions of the textbook form (an fp64 divide costs ~10 FMAs on gfx950)
@@ -110,7 +110,7 @@ public:
     const double l = param_.pole_length;
 
     double sin_theta, cos_theta;
-    sincos(theta, sin_theta, cos_theta);
+    sincosFast(theta, sin_theta, cos_theta); // |theta| < 2^27 rad, NaN beyond (linalg.hpp)
     const double omega2 = omega * omega;
     const double sin2 = sin_theta * sin_theta;
     const double denom = m1 + m2 * sin2;

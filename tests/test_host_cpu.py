@@ -220,3 +220,14 @@ def test_two_rank_gather_equals_unsharded_solve(tmp_path):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("ok") >= 2  # both ranks passed their in-process asserts (stdout may interleave)
+
+
+def test_sincos_fast_accuracy(tmp_path):
+    """nmpc_amd::sincosFast (the ~32-instruction sin/cos the cart-pole functor inlines on the GPU) against
+    long-double references on the host: <= 1.6 ulp for |x| <= 1e3, <= 2.6 ulp up to 1e8, NaN outside 2^27."""
+    exe = str(tmp_path / "test_sincos")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", f"-I{ROOT}/include",
+                        os.path.join(ROOT, "tests", "cpp", "test_sincos.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SINCOS_OK" in r.stdout, r.stdout

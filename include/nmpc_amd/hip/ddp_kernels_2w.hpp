@@ -1,0 +1,1190 @@
+// gfx950 device code of the batched DDP solver, LANE MAPPING "TPI-2W": one lane per problem instance as in
+// ddp_kernels.hpp, but TWO wavefronts per 64 instances in one workgroup, specialised by role and coupled through
+// LDS records (one s_barrier per timestep):
+//
+//   master wave   owns the per-instance solver state and executes only what is on the sequential dependency
+//                 chain: the Riccati recursion (backward) and u' -> x' (forward);
+//   helper wave   backward: evaluates the problem's derivatives at (x_i, u_i) ONE TIMESTEP AHEAD of the master
+//                           (they do not depend on the recursion) and stages them in an LDS record;
+//                 forward : fetches the nominal (x, u, k, K) of the next timestep from HBM into LDS for the master,
+//                           and takes the master's (x', u') to evaluate runningCost / terminalCost, accumulate the
+//                           candidate cost and do all HBM stores.
+//
+// Why (profiles/r01_*): the single-wave kernel is bound by the issue rate of its one wavefront (~4 cycles per
+// instruction, one wave per SIMD, 64 of 1024 SIMDs busy at B = 4096); HBM is idle.  About 45 % of the backward
+// instruction stream (sin/cos, the divide, the Jacobian arithmetic, loads, address math) is off the dependency chain
+// and moves to the helper, as do the cost evaluation and all memory traffic of the forward pass.
+//
+// Structural sparsity survives the hand-off: the master evaluates the problem functor on DUMMY run-time inputs and
+// replaces every entry that is not a compile-time constant by the value from the LDS record; the dummy arithmetic
+// (sin/cos, divides) is then dead code and is eliminated, while entries the model writes as literal 0 / 1 remain
+// constants for macc().  The helper writes every entry, so the two sides cannot disagree about the record layout.
+#pragma once
+
+#include <nmpc_amd/hip/ddp_kernels.hpp>
+
+namespace nmpc_amd
+{
+namespace hip
+{
+template<class Problem, bool kConstrained>
+struct PairSolver : InstanceSolver<Problem, kConstrained>
+{
+  using Base = InstanceSolver<Problem, kConstrained>;
+  using Base::b;
+  using Base::buf;
+  using Base::cfg;
+  using Base::current_t;
+  using Base::dlambda;
+  using Base::dV0;
+  using Base::dV1;
+  using Base::J_cand;
+  using Base::J_cur;
+  using Base::k_rel_norm;
+  using Base::lambda;
+  using Base::lane;
+  using Base::problem;
+  using Base::sel;
+  using Base::T;
+  static constexpr int N = Base::N;
+  static constexpr int M = Base::M;
+  static constexpr int MM = Base::MM;
+  static constexpr int kU = Base::kU;
+  static constexpr size_t LW = Base::LW;
+  using typename Base::InputDimVector;
+  using typename Base::InputInputDimMatrix;
+  using typename Base::QPOut;
+  using typename Base::StateDimVector;
+  using typename Base::StateInputDimMatrix;
+  using typename Base::StateStateDimMatrix;
+
+  // ---- LDS record layouts (doubles per lane) ----
+  // backward record (helper -> master): derivatives of timestep i and u_i
+  static constexpr int oFx = 0;
+  static constexpr int oFu = oFx + N * N;
+  static constexpr int oLx = oFu + N * MM;
+  static constexpr int oLu = oLx + N;
+  static constexpr int oLxx = oLu + MM;
+  static constexpr int oLuu = oLxx + N * N;
+  static constexpr int oLxu = oLuu + MM * MM;
+  static constexpr int oU = oLxu + N * MM;
+  static constexpr int kBwdRec = oU + MM;
+  // forward records: "in" (helper -> master): nominal x_i, u_i, k_i, K_i; "out" (master -> helper): x'_i, u'_i
+  static constexpr int oXn = 0;
+  static constexpr int oUn = oXn + N;
+  static constexpr int oKff = oUn + MM;
+  static constexpr int oKfb = oKff + MM;
+  static constexpr int oXc = oKfb + MM * N;
+  static constexpr int oUc = oXc + N;
+  static constexpr int kFwdRec = oUc + MM;
+  static constexpr int kRec = kBwdRec > kFwdRec ? kBwdRec : kFwdRec;
+  //! LDS doubles per workgroup: two record slots + per-lane mailboxes (flags, J_cand)
+  static constexpr int kLdsDoubles = (2 * kRec + 2) * static_cast<int>(LW);
+  static constexpr size_t kLdsBytes = static_cast<size_t>(kLdsDoubles) * sizeof(double);
+  static constexpr bool kFits = kLdsBytes <= 64 * 1024;
+
+  double * lds; //!< workgroup LDS base
+
+  NMPC_D PairSolver(const Problem & p,
+                    const nmpc_hip_ddp_config & c,
+                    const DeviceBuffers & bf,
+                    int global_lane,
+                    double * lds_base)
+  : Base(p, c, bf, global_lane), lds(lds_base)
+  {
+  }
+
+  NMPC_D double & rec(int slot, int idx) const
+  {
+    return lds[(static_cast<size_t>(slot) * kRec + idx) * LW + lane];
+  }
+  NMPC_D double & mailFlags() const
+  {
+    return lds[(2 * static_cast<size_t>(kRec)) * LW + lane];
+  }
+  NMPC_D double & mailCost() const
+  {
+    return lds[(2 * static_cast<size_t>(kRec) + 1) * LW + lane];
+  }
+  /** Workgroup barrier for the LDS hand-off.  Only LDS traffic has to be complete (lgkmcnt); __syncthreads() would
+      also wait for vmcnt(0), i.e. drain the helper's HBM prefetches and the stores of every timestep. */
+  NMPC_D static void wgBarrier()
+  {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
+  // ===================================================================================================
+  // backward pass
+  // ===================================================================================================
+  /** Helper: derivatives of timestep i at (x, u) = (x_i, u_i) of the current trajectory -> record slot. */
+  NMPC_D void produceDerivatives(int i, int slot, const StateDimVector & x, const InputDimVector & u_all) const
+  {
+    const double t = current_t + i * problem.dt();
+    const int m = Base::inputDimAt(t);
+    InputDimVector u = u_all;
+    u.resize(m);
+    StateStateDimMatrix Fx, Lxx;
+    StateInputDimMatrix Fu, Lxu;
+    StateDimVector Lx;
+    InputDimVector Lu;
+    InputInputDimMatrix Luu;
+    Fu.resize(N, m);
+    Lxu.resize(N, m);
+    Lu.resize(m);
+    Luu.resize(m, m);
+    problem.calcStateEqDeriv(t, x, u, Fx, Fu);
+    problem.calcRunningCostDeriv(t, x, u, Lx, Lu, Lxx, Luu, Lxu);
+#pragma unroll kU
+    for(int e = 0; e < N * N; e++)
+    {
+      rec(slot, oFx + e) = Fx.data()[e];
+      rec(slot, oLxx + e) = Lxx.data()[e];
+    }
+#pragma unroll kU
+    for(int e = 0; e < N * MM; e++)
+    {
+      rec(slot, oFu + e) = Fu.data()[e];
+      rec(slot, oLxu + e) = Lxu.data()[e];
+    }
+#pragma unroll kU
+    for(int e = 0; e < N; e++)
+    {
+      rec(slot, oLx + e) = Lx[e];
+    }
+#pragma unroll kU
+    for(int e = 0; e < MM; e++)
+    {
+      rec(slot, oLu + e) = Lu[e];
+      rec(slot, oU + e) = u[e];
+    }
+#pragma unroll kU
+    for(int e = 0; e < MM * MM; e++)
+    {
+      rec(slot, oLuu + e) = Luu.data()[e];
+    }
+  }
+
+  NMPC_D void backwardHelper(int sel_h) const
+  {
+    // barrier k separates "record of step T-1-k written" from "record of step T-1-k read".
+    // (x, u) of step i-1 are requested from HBM while the derivatives of step i are evaluated.
+    const unsigned ox = Base::offX(sel_h), ou = Base::offU(sel_h);
+    StateDimVector x_pref;
+    InputDimVector u_pref;
+    Base::loadX(Base::xRow(T - 1), ox, x_pref);
+    Base::loadU(Base::uRow(T - 1), ou, u_pref, MM);
+    for(int i = T - 1; i >= 0; i--)
+    {
+      const StateDimVector x = x_pref;
+      const InputDimVector u = u_pref;
+      if(i > 0)
+      {
+        Base::loadX(Base::xRow(i - 1), ox, x_pref);
+        Base::loadU(Base::uRow(i - 1), ou, u_pref, MM);
+      }
+      produceDerivatives(i, i & 1, x, u);
+      wgBarrier();
+    }
+    wgBarrier(); // closes the pass: the master's last record reads are done
+  }
+
+  /** Fill v from the record unless the compiler knows it as a structural constant. */
+  NMPC_D void fromRecord(double & v, int slot, int idx) const
+  {
+    if(!__builtin_constant_p(v))
+    {
+      v = rec(slot, idx);
+    }
+  }
+
+  /** Master: the Riccati recursion of DDPSolver::backwardPass (DDPSolver.hpp:342-534) over the staged records.
+      `need` masks the lanes this pass is run for; returns the per-lane success flag. */
+  NMPC_D bool backwardMaster(bool need)
+  {
+    double Vx[N], Vxx[N * N];
+    {
+      StateDimVector xT, vx;
+      StateStateDimMatrix vxx;
+      Base::loadX(Base::xRow(T), Base::offX(sel), xT);
+      problem.calcTerminalCostDeriv(current_t + T * problem.dt(), xT, vx, vxx);
+#pragma unroll kU
+      for(int j = 0; j < N; j++)
+      {
+        Vx[j] = vx[j];
+      }
+#pragma unroll kU
+      for(int e = 0; e < N * N; e++)
+      {
+        Vxx[e] = vxx.data()[e];
+      }
+    }
+    double dV0_l = 0, dV1_l = 0, krn = 0;
+    bool ok = true;
+    double k_next[MM];
+    int m_next = -1;
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      k_next[a] = 0;
+    }
+    const unsigned ob = Base::offB();
+
+    for(int i = T - 1; i >= 0; i--)
+    {
+      wgBarrier(); // record of step i is complete
+      const int slot = i & 1;
+      const double t = current_t + i * problem.dt();
+      const int m = Base::inputDimAt(t);
+
+      // structure of the derivatives from a dummy evaluation; values from the record (file header)
+      StateDimVector xd;
+      InputDimVector u;
+      u.resize(m);
+#pragma unroll kU
+      for(int j = 0; j < N; j++)
+      {
+        xd[j] = rec(slot, oLx + j);
+      }
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        u[a] = rec(slot, oU + a);
+      }
+      StateStateDimMatrix Fx, Lxx;
+      StateInputDimMatrix Fu, Lxu;
+      StateDimVector Lx;
+      InputDimVector Lu;
+      InputInputDimMatrix Luu;
+      Fu.resize(N, m);
+      Lxu.resize(N, m);
+      Lu.resize(m);
+      Luu.resize(m, m);
+      problem.calcStateEqDeriv(t, xd, u, Fx, Fu);
+      problem.calcRunningCostDeriv(t, xd, u, Lx, Lu, Lxx, Luu, Lxu);
+#pragma unroll kU
+      for(int e = 0; e < N * N; e++)
+      {
+        fromRecord(Fx.data()[e], slot, oFx + e);
+        fromRecord(Lxx.data()[e], slot, oLxx + e);
+      }
+#pragma unroll kU
+      for(int e = 0; e < N * MM; e++)
+      {
+        fromRecord(Fu.data()[e], slot, oFu + e);
+        fromRecord(Lxu.data()[e], slot, oLxu + e);
+      }
+#pragma unroll kU
+      for(int e = 0; e < N; e++)
+      {
+        fromRecord(Lx[e], slot, oLx + e);
+      }
+#pragma unroll kU
+      for(int e = 0; e < MM; e++)
+      {
+        fromRecord(Lu[e], slot, oLu + e);
+      }
+#pragma unroll kU
+      for(int e = 0; e < MM * MM; e++)
+      {
+        fromRecord(Luu.data()[e], slot, oLuu + e);
+      }
+
+      // ---- Q terms    DDPSolver.hpp:386-408
+      double Qu[MM], Qx[N], Qux[MM * N], Quu[MM * MM], Qxx[N * N];
+      double FuT_V[MM * N];
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        if(a < m)
+        {
+          double s = 0;
+#pragma unroll kU
+          for(int r = 0; r < N; r++)
+          {
+            Base::macc(s, Fu(r, a), Vx[r]);
+          }
+          Qu[a] = Base::addc(Lu[a], s);
+        }
+      }
+#pragma unroll kU
+      for(int a = 0; a < N; a++)
+      {
+        double s = 0;
+#pragma unroll kU
+        for(int r = 0; r < N; r++)
+        {
+          Base::macc(s, Fx(r, a), Vx[r]);
+        }
+        Qx[a] = Base::addc(Lx[a], s);
+      }
+#pragma unroll kU
+      for(int c = 0; c < N; c++)
+      {
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
+          {
+            double s = 0;
+#pragma unroll kU
+            for(int r = 0; r < N; r++)
+            {
+              Base::macc(s, Fu(r, a), Vxx[r + c * N]);
+            }
+            FuT_V[a + c * MM] = s;
+          }
+        }
+      }
+#pragma unroll kU
+      for(int c = 0; c < N; c++)
+      {
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
+          {
+            double s = 0;
+#pragma unroll kU
+            for(int r = 0; r < N; r++)
+            {
+              Base::macc(s, FuT_V[a + r * MM], Fx(r, c));
+            }
+            Qux[a + c * MM] = Base::addc(Lxu(c, a), s);
+          }
+        }
+      }
+#pragma unroll kU
+      for(int bb = 0; bb < MM; bb++)
+      {
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m && bb < m)
+          {
+            double s = 0;
+#pragma unroll kU
+            for(int r = 0; r < N; r++)
+            {
+              Base::macc(s, FuT_V[a + r * MM], Fu(r, bb));
+            }
+            Quu[a + bb * MM] = Base::addc(Luu(a, bb), s);
+          }
+        }
+      }
+      {
+        double FxT_V[N * N];
+#pragma unroll kU
+        for(int c = 0; c < N; c++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < N; a++)
+          {
+            double s = 0;
+#pragma unroll kU
+            for(int r = 0; r < N; r++)
+            {
+              Base::macc(s, Fx(r, a), Vxx[r + c * N]);
+            }
+            FxT_V[a + c * N] = s;
+          }
+        }
+#pragma unroll kU
+        for(int c = 0; c < N; c++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < N; a++)
+          {
+            double s = 0;
+#pragma unroll kU
+            for(int r = 0; r < N; r++)
+            {
+              Base::macc(s, FxT_V[a + r * N], Fx(r, c));
+            }
+            Qxx[a + c * N] = Base::addc(Lxx(a, c), s);
+          }
+        }
+      }
+
+      // ---- regularisation    :421-441
+      double Qux_reg[MM * N], Quu_F[MM * MM];
+      if(cfg.reg_type == 2)
+      {
+#pragma unroll kU
+        for(int c = 0; c < N; c++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            if(a < m)
+            {
+              double s = 0;
+#pragma unroll kU
+              for(int r = 0; r < N; r++)
+              {
+                const double v = (r == c) ? (Vxx[r + c * N] + lambda) : Vxx[r + c * N];
+                Base::macc(s, Fu(r, a), v);
+              }
+              FuT_V[a + c * MM] = s;
+            }
+          }
+        }
+#pragma unroll kU
+        for(int c = 0; c < N; c++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            if(a < m)
+            {
+              double s = 0;
+#pragma unroll kU
+              for(int r = 0; r < N; r++)
+              {
+                Base::macc(s, FuT_V[a + r * MM], Fx(r, c));
+              }
+              Qux_reg[a + c * MM] = Base::addc(Lxu(c, a), s);
+            }
+          }
+        }
+#pragma unroll kU
+        for(int bb = 0; bb < MM; bb++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            if(a < m && bb < m)
+            {
+              double s = 0;
+#pragma unroll kU
+              for(int r = 0; r < N; r++)
+              {
+                Base::macc(s, FuT_V[a + r * MM], Fu(r, bb));
+              }
+              Quu_F[a + bb * MM] = Base::addc(Luu(a, bb), s);
+            }
+          }
+        }
+      }
+      else
+      {
+#pragma unroll kU
+        for(int e = 0; e < MM * N; e++)
+        {
+          Qux_reg[e] = Qux[e];
+        }
+#pragma unroll kU
+        for(int bb = 0; bb < MM; bb++)
+        {
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            Quu_F[a + bb * MM] = (a == bb && cfg.reg_type == 1) ? (Quu[a + bb * MM] + lambda) : Quu[a + bb * MM];
+          }
+        }
+      }
+
+      // ---- gains    :448-517
+      double k[MM], K[MM * N];
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        k[a] = 0;
+      }
+#pragma unroll kU
+      for(int e = 0; e < MM * N; e++)
+      {
+        K[e] = 0;
+      }
+      bool step_ok = true;
+      if(m > 0)
+      {
+        if constexpr(kConstrained)
+        {
+          double initial_k[MM], lo[MM], up[MM];
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            initial_k[a] = (i != T - 1 && m_next == m) ? k_next[a] : 0.0;
+            lo[a] = buf.lim_lo[a] - u[a];
+            up[a] = buf.lim_hi[a] - u[a];
+          }
+          QPOut qp;
+          Base::boxQP(m, Quu_F, Qu, lo, up, initial_k, qp);
+          unsigned free_mask = 0;
+          for(int j = 0; j < qp.n_free; j++)
+          {
+            free_mask |= (1u << qp.free_idx[j]);
+          }
+          if(need && ok)
+          {
+            Base::elem(buf.qp_ret, T, i) = qp.retval;
+            Base::elem(buf.qp_free, T, i) = free_mask;
+          }
+          if(qp.retval < 0)
+          {
+            step_ok = false;
+          }
+          else
+          {
+#pragma unroll kU
+            for(int a = 0; a < MM; a++)
+            {
+              k[a] = qp.x[a];
+            }
+            if(qp.n_free > 0)
+            {
+              for(int c = 0; c < N; c++)
+              {
+                double col[MM];
+                for(int j = 0; j < qp.n_free; j++)
+                {
+                  col[j] = Qux_reg[qp.free_idx[j] + c * MM];
+                }
+                Base::template ldltSolveInPlace<MM, 1>(qp.fac, qp.inv_d, qp.n_free, col);
+                for(int j = 0; j < qp.n_free; j++)
+                {
+                  K[qp.free_idx[j] + c * MM] = -1 * col[j];
+                }
+              }
+            }
+          }
+        }
+        else
+        {
+          double fac[MM * MM], inv_d[MM];
+#pragma unroll kU
+          for(int e = 0; e < MM * MM; e++)
+          {
+            fac[e] = Quu_F[e];
+          }
+          if(!Base::template ldltInPlace<MM>(fac, inv_d, m))
+          {
+            step_ok = false;
+          }
+          else
+          {
+#pragma unroll kU
+            for(int a = 0; a < MM; a++)
+            {
+              k[a] = Qu[a];
+            }
+            Base::template ldltSolveInPlace<MM, 1>(fac, inv_d, m, k);
+#pragma unroll kU
+            for(int a = 0; a < MM; a++)
+            {
+              k[a] = -1 * k[a];
+            }
+#pragma unroll kU
+            for(int c = 0; c < N; c++)
+            {
+#pragma unroll kU
+              for(int a = 0; a < MM; a++)
+              {
+                K[a + c * MM] = Qux_reg[a + c * MM];
+              }
+              Base::template ldltSolveInPlace<MM, 1>(fac, inv_d, m, &K[c * MM]);
+#pragma unroll kU
+              for(int a = 0; a < MM; a++)
+              {
+                K[a + c * MM] = -1 * K[a + c * MM];
+              }
+            }
+          }
+        }
+      }
+      // a lane whose factorisation failed stops updating its state (the reference returns false here, :473-480,
+      // :501-508); the wave keeps running the remaining timesteps for the other lanes
+      const bool live = need && ok && step_ok;
+      ok = ok && step_ok;
+
+      // ---- cost-to-go update    :522-526
+      {
+        double kQu = 0, kQuuk = 0;
+        double Quu_k[MM];
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
+          {
+            Base::macc(kQu, k[a], Qu[a]);
+            double s = 0;
+#pragma unroll kU
+            for(int bb = 0; bb < MM; bb++)
+            {
+              if(bb < m)
+              {
+                Base::macc(s, Quu[a + bb * MM], k[bb]);
+              }
+            }
+            Quu_k[a] = s;
+          }
+        }
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
+          {
+            Base::macc(kQuuk, k[a], Quu_k[a]);
+          }
+        }
+        if(live)
+        {
+          dV0_l += kQu;
+          dV1_l += 0.5 * kQuuk;
+        }
+      }
+      double KtQuu[N * MM];
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+#pragma unroll kU
+        for(int r = 0; r < N; r++)
+        {
+          double s = 0;
+#pragma unroll kU
+          for(int p = 0; p < MM; p++)
+          {
+            if(p < m && a < m)
+            {
+              Base::macc(s, K[p + r * MM], Quu[p + a * MM]);
+            }
+          }
+          KtQuu[r + a * N] = s;
+        }
+      }
+      double Vxx_new[N * N];
+#pragma unroll kU
+      for(int r = 0; r < N; r++)
+      {
+        double s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
+          {
+            Base::macc(s1, KtQuu[r + a * N], k[a]);
+            Base::macc(s2, K[a + r * MM], Qu[a]);
+            Base::macc(s3, Qux[a + r * MM], k[a]);
+          }
+        }
+        const double v = ((Qx[r] + s1) + s2) + s3;
+        Vx[r] = live ? v : Vx[r];
+      }
+#pragma unroll kU
+      for(int c = 0; c < N; c++)
+      {
+#pragma unroll kU
+        for(int r = 0; r < N; r++)
+        {
+          double s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll kU
+          for(int a = 0; a < MM; a++)
+          {
+            if(a < m)
+            {
+              Base::macc(s1, KtQuu[r + a * N], K[a + c * MM]);
+              Base::macc(s2, K[a + r * MM], Qux[a + c * MM]);
+              Base::macc(s3, Qux[a + r * MM], K[a + c * MM]);
+            }
+          }
+          Vxx_new[r + c * N] = ((Qxx[r + c * N] + s1) + s2) + s3;
+        }
+      }
+#pragma unroll kU
+      for(int c = 0; c < N; c++)
+      {
+#pragma unroll kU
+        for(int r = 0; r < N; r++)
+        {
+          const double v = 0.5 * (Vxx_new[r + c * N] + Vxx_new[c + r * N]);
+          Vxx[r + c * N] = live ? v : Vxx[r + c * N];
+        }
+      }
+
+      // ---- save gains    :529-530, running max of |k_i| / (|u_i| + 1)    :217-221
+      if(live)
+      {
+        double * kp = Base::kRow(i);
+        double * Kp = Base::KRow(i);
+        double kn = 0, un = 0;
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          Base::st(kp + a * LW, ob, (a < m) ? k[a] : 0.0);
+          k_next[a] = (a < m) ? k[a] : 0.0;
+          if(a < m)
+          {
+            kn += k[a] * k[a];
+            un += u[a] * u[a];
+          }
+        }
+#pragma unroll kU
+        for(int e = 0; e < MM * N; e++)
+        {
+          Base::st(Kp + e * LW, ob, ((e % MM) < m) ? K[e] : 0.0);
+        }
+        m_next = m;
+        const double knorm = (M == 1) ? fabs(k[0]) : sqrt(kn);
+        const double unorm = (M == 1) ? fabs(u[0]) : sqrt(un);
+        krn = fmax(krn, knorm / (unorm + 1.0));
+      }
+    }
+    wgBarrier(); // closes the pass
+    if(need)
+    {
+      dV0 = dV0_l;
+      dV1 = dV1_l;
+      k_rel_norm = krn;
+    }
+    return ok;
+  }
+
+  // ===================================================================================================
+  // forward pass    DDPSolver.hpp:536-560
+  // ===================================================================================================
+  /** Nominal (x_i, u_i, k_i, K_i) of one timestep held in registers between its HBM load and its LDS store. */
+  struct Nominal
+  {
+    double x[N], u[MM], k[MM], K[MM * N];
+  };
+  NMPC_D void loadNominal(int i, int sel_h, Nominal & n) const
+  {
+    const unsigned ox = Base::offX(sel_h), ou = Base::offU(sel_h), ob = Base::offB();
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      n.x[j] = Base::ld(Base::xRow(i) + j * LW, ox);
+    }
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      n.u[a] = Base::ld(Base::uRow(i) + a * LW, ou);
+      n.k[a] = Base::ld(Base::kRow(i) + a * LW, ob);
+    }
+#pragma unroll kU
+    for(int e = 0; e < MM * N; e++)
+    {
+      n.K[e] = Base::ld(Base::KRow(i) + e * LW, ob);
+    }
+  }
+  NMPC_D void stageNominal(int slot, const Nominal & n) const
+  {
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      rec(slot, oXn + j) = n.x[j];
+    }
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      rec(slot, oUn + a) = n.u[a];
+      rec(slot, oKff + a) = n.k[a];
+    }
+#pragma unroll kU
+    for(int e = 0; e < MM * N; e++)
+    {
+      rec(slot, oKfb + e) = n.K[e];
+    }
+  }
+
+  /** Helper side of one forward pass: stages nominal data one step ahead (requested from HBM two steps ahead),
+      evaluates the cost of the step the master has just finished, stores the candidate trajectory, returns the
+      candidate total cost through LDS. */
+  NMPC_D void forwardHelper(int sel_h) const
+  {
+    const int cs = 1 - sel_h;
+    const unsigned cx = Base::offX(cs), cu = Base::offU(cs), cc = Base::offC(cs);
+    Nominal nom;
+    loadNominal(0, sel_h, nom);
+    stageNominal(0, nom);
+    if(T > 1)
+    {
+      loadNominal(1, sel_h, nom);
+    }
+    wgBarrier(); // barrier S: slot 0 "in" ready
+    double J = 0;
+    for(int i = 0; i < T; i++)
+    {
+      if(i + 1 < T)
+      {
+        stageNominal((i + 1) & 1, nom); // loaded during the previous iteration
+        if(i + 2 < T)
+        {
+          loadNominal(i + 2, sel_h, nom);
+        }
+      }
+      if(i > 0)
+      {
+        J += consumeStep(i - 1, cx, cu, cc);
+      }
+      wgBarrier(); // barrier i: master wrote "out" of step i, helper wrote "in" of step i+1
+    }
+    J += consumeStep(T - 1, cx, cu, cc);
+    // terminal state x'_T is in the "out" part of slot T & 1 (written by the master before its last barrier)
+    wgBarrier(); // barrier E: x'_T available
+    {
+      StateDimVector xT;
+#pragma unroll kU
+      for(int j = 0; j < N; j++)
+      {
+        xT[j] = rec(T & 1, oXc + j);
+      }
+      Base::storeX(Base::xRow(T), cx, xT);
+      const double cT = problem.terminalCost(current_t + T * problem.dt(), xT);
+      Base::st(Base::costRow(T), cc, cT);
+      J += cT;
+    }
+    mailCost() = J;
+    wgBarrier(); // barrier F: candidate cost published
+  }
+
+  /** Helper: cost + stores of step i from the "out" record the master wrote. */
+  NMPC_D double consumeStep(int i, unsigned cx, unsigned cu, unsigned cc) const
+  {
+    const int slot = i & 1;
+    const double t = current_t + i * problem.dt();
+    const int m = Base::inputDimAt(t);
+    StateDimVector x;
+    InputDimVector u;
+    u.resize(m);
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      x[j] = rec(slot, oXc + j);
+    }
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      u[a] = rec(slot, oUc + a);
+    }
+    Base::storeX(Base::xRow(i), cx, x);
+    Base::storeU(Base::uRow(i), cu, u, m);
+    const double c = problem.runningCost(t, x, u);
+    Base::st(Base::costRow(i), cc, c);
+    return c;
+  }
+
+  /** Master side: u' = u + alpha k + K (x' - x), x'' = stateEq(x', u').  All memory traffic goes through LDS. */
+  NMPC_D void forwardMaster(double alpha)
+  {
+    StateDimVector xc;
+    wgBarrier(); // barrier S
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      xc[j] = rec(0, oXn + j); // x'_0 = x_0
+    }
+    for(int i = 0; i < T; i++)
+    {
+      const int slot = i & 1;
+      const double t = current_t + i * problem.dt();
+      const int m = Base::inputDimAt(t);
+      InputDimVector uc;
+      uc.resize(m);
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        if(a < m)
+        {
+          double s = 0;
+#pragma unroll kU
+          for(int c = 0; c < N; c++)
+          {
+            s += rec(slot, oKfb + a + c * MM) * (xc[c] - rec(slot, oXn + c));
+          }
+          uc[a] = (rec(slot, oUn + a) + alpha * rec(slot, oKff + a)) + s;
+        }
+        else
+        {
+          uc[a] = 0;
+        }
+      }
+#pragma unroll kU
+      for(int j = 0; j < N; j++)
+      {
+        rec(slot, oXc + j) = xc[j];
+      }
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        rec(slot, oUc + a) = uc[a];
+      }
+      xc = problem.stateEq(t, xc, uc);
+      wgBarrier(); // barrier i
+    }
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      rec(T & 1, oXc + j) = xc[j];
+    }
+    wgBarrier(); // barrier E
+    wgBarrier(); // barrier F
+    J_cand = mailCost();
+  }
+
+  // ===================================================================================================
+  // pass protocol: the master posts {command, per-lane sel} and both waves enter the pass
+  // ===================================================================================================
+  enum Command
+  {
+    kCmdExit = 0,
+    kCmdBackward = 1,
+    kCmdForward = 2
+  };
+
+  NMPC_D void post(int cmd) const
+  {
+    // flags word per lane: command in the integer part (uniform over the wave), sel in the fraction
+    mailFlags() = static_cast<double>(cmd * 2 + sel);
+    // barrier P: command visible.  Pass boundaries use the full barrier (vmcnt(0) too): what one wave stored to HBM
+    // in the previous pass (gains k, K; the candidate trajectory) is loaded by the other wave in the next one.
+    __syncthreads();
+  }
+
+  NMPC_D void helperLoop() const
+  {
+    for(;;)
+    {
+      __syncthreads(); // barrier P (full: see post())
+      const int word = static_cast<int>(mailFlags());
+      const int cmd = __builtin_amdgcn_readfirstlane(word >> 1);
+      const int sel_h = word & 1;
+      if(cmd == kCmdExit)
+      {
+        return;
+      }
+      if(cmd == kCmdBackward)
+      {
+        backwardHelper(sel_h);
+      }
+      else
+      {
+        forwardHelper(sel_h);
+      }
+    }
+  }
+
+  // ===================================================================================================
+  // master: solve = setup + optimisation loop (DDPSolver.hpp:26-141, procOnce :143-340), written with wave-uniform
+  // pass invocations (every lane of the wave enters every pass; `need_*` masks select whose state it updates)
+  // ===================================================================================================
+  NMPC_D void solveMaster(bool valid)
+  {
+    current_t = buf.t0 ? Base::tileBase(buf.t0, 1)[lane] : 0.0;
+    lambda = cfg.initial_lambda;
+    dlambda = cfg.initial_dlambda;
+    sel = 0;
+    dV0 = dV1 = 0;
+    k_rel_norm = 0;
+    J_cand = 0;
+    Base::initialRollout();
+
+    double tr[NMPC_HIP_NTRACE];
+#pragma unroll
+    for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+    {
+      tr[f] = 0;
+    }
+    tr[NMPC_HIP_TRACE_COST] = J_cur;
+    tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
+    tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
+    tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
+    if(valid)
+    {
+      Base::writeTraceRow(0, tr);
+    }
+
+    int retval = 0;
+    bool active = valid; // this lane still iterates
+    for(int iter = 1; iter <= cfg.max_iter; iter++)
+    {
+      if(!__any(active))
+      {
+        break;
+      }
+      if(active)
+      {
+#pragma unroll
+        for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+        {
+          tr[f] = 0;
+        }
+        tr[NMPC_HIP_TRACE_ITER] = iter;
+        tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
+        retval = 0;
+      }
+
+      // ---- Step 2 (+ Step 1 in the helper): backward pass with regularisation retries    :188-214
+      bool need_bw = active;
+      bool bw_ok = false;
+      int n_backward = 0;
+      while(__any(need_bw))
+      {
+        post(kCmdBackward);
+        const bool ok = backwardMaster(need_bw);
+        if(need_bw)
+        {
+          n_backward++;
+          if(ok)
+          {
+            bw_ok = true;
+            need_bw = false;
+          }
+          else
+          {
+            dlambda = fmax(dlambda * cfg.lambda_factor, cfg.lambda_factor);
+            lambda = fmax(lambda * dlambda, cfg.lambda_min);
+            if(lambda > cfg.lambda_max)
+            {
+              need_bw = false; // failure    :196-204
+            }
+          }
+        }
+      }
+
+      bool need_fw = false;
+      if(active)
+      {
+        tr[NMPC_HIP_TRACE_N_BACKWARD] = n_backward;
+        if(!bw_ok)
+        {
+          retval = -1;
+        }
+        else
+        {
+          tr[NMPC_HIP_TRACE_K_REL_NORM] = k_rel_norm;
+          if(k_rel_norm < cfg.k_rel_norm_thre && lambda < cfg.lambda_thre)
+          {
+            retval = 1; // :223-231
+          }
+          else
+          {
+            need_fw = true;
+          }
+        }
+      }
+
+      // ---- Step 3: backtracking line search    :234-274   (all searching lanes are at the same alpha index)
+      const bool searched = need_fw;
+      bool forward_pass_success = false;
+      double alpha = 0, cost_update_actual = 0, cost_update_expected = 0, cost_update_ratio = 0;
+      int ai_used = 0;
+      for(int ai = 0; ai < cfg.n_alpha; ai++)
+      {
+        if(!__any(need_fw))
+        {
+          break;
+        }
+        const double a_try = cfg.alpha_list[ai];
+        post(kCmdForward);
+        forwardMaster(a_try);
+        if(need_fw)
+        {
+          alpha = a_try;
+          ai_used = ai;
+          cost_update_actual = J_cur - J_cand;
+          cost_update_expected = -1 * alpha * (dV0 + alpha * dV1);
+          cost_update_ratio = cost_update_actual / cost_update_expected;
+          if(cost_update_expected < 0)
+          {
+            cost_update_ratio = (cost_update_actual >= 0 ? 1 : -1); // :251-259
+          }
+          if(cost_update_ratio > cfg.cost_update_ratio_thre)
+          {
+            forward_pass_success = true;
+            need_fw = false;
+            // accept immediately: later trials of other lanes write their candidate into THEIR candidate half
+            sel = 1 - sel;
+            J_cur = J_cand;
+          }
+        }
+      }
+
+      if(searched)
+      {
+        tr[NMPC_HIP_TRACE_ALPHA] = alpha;
+        tr[NMPC_HIP_TRACE_COST_UPDATE_ACTUAL] = cost_update_actual;
+        tr[NMPC_HIP_TRACE_COST_UPDATE_EXPECTED] = cost_update_expected;
+        tr[NMPC_HIP_TRACE_COST_UPDATE_RATIO] = cost_update_ratio;
+        tr[NMPC_HIP_TRACE_ALPHA_IDX] = ai_used;
+        tr[NMPC_HIP_TRACE_N_FORWARD] = ai_used + 1;
+        // ---- Step 4: accept / reject and the lambda schedule    :280-333
+        if(forward_pass_success)
+        {
+          if(cost_update_actual < cfg.cost_update_thre)
+          {
+            retval = 1;
+          }
+          dlambda = fmin(dlambda / cfg.lambda_factor, 1 / cfg.lambda_factor);
+          if(lambda >= cfg.lambda_min)
+          {
+            lambda *= dlambda;
+          }
+          else
+          {
+            lambda = 0;
+          }
+        }
+        else
+        {
+          dlambda = fmax(dlambda * cfg.lambda_factor, cfg.lambda_factor);
+          lambda = fmax(lambda * dlambda, cfg.lambda_min);
+          if(lambda > cfg.lambda_max)
+          {
+            retval = -1;
+          }
+        }
+        tr[NMPC_HIP_TRACE_COST] = J_cur;
+        tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
+        tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
+      }
+      if(active)
+      {
+        Base::writeTraceRow(iter, tr);
+        if(retval != 0)
+        {
+          active = false;
+        }
+      }
+    }
+    post(kCmdExit);
+
+    if(valid)
+    {
+#pragma unroll
+      for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+      {
+        Base::elem(buf.trace_last, NMPC_HIP_NTRACE, f) = tr[f];
+      }
+      buf.status[b] = retval;
+      buf.iters[b] = static_cast<int>(tr[NMPC_HIP_TRACE_ITER]);
+      buf.sel[b] = sel;
+      Base::elem(buf.dV, 2, 0) = dV0;
+      Base::elem(buf.dV, 2, 1) = dV1;
+    }
+  }
+};
+
+/** The 2-wave solve kernel: grid = Bp / 64 workgroups of 128 threads; wave 0 = master, wave 1 = helper. */
+template<class Problem, bool kConstrained>
+__global__ __launch_bounds__(2 * kLanesPerBlock) void ddp_solve_tpi2w_kernel(const Problem problem,
+                                                                              const nmpc_hip_ddp_config cfg,
+                                                                              const DeviceBuffers buf)
+{
+  using Solver = PairSolver<Problem, kConstrained>;
+  extern __shared__ __attribute__((aligned(16))) double lds_2w[];
+  const int wave = threadIdx.x / kLanesPerBlock;
+  const int b = blockIdx.x * kLanesPerBlock + (threadIdx.x % kLanesPerBlock);
+  Solver solver(problem, cfg, buf, b, lds_2w);
+  if(wave == 0)
+  {
+    solver.solveMaster(b < buf.B);
+  }
+  else
+  {
+    solver.current_t = buf.t0 ? solver.tileBase(buf.t0, 1)[solver.lane] : 0.0;
+    solver.helperLoop();
+  }
+}
+} // namespace hip
+} // namespace nmpc_amd

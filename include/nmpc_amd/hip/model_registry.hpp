@@ -8,11 +8,13 @@
 // compile it with hipcc --offload-arch=gfx950 and link (or dlopen) it next to libnmpc_hip_ddp.so.
 #pragma once
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <type_traits>
 
 #include <nmpc_amd/hip/ddp_kernels.hpp>
+#include <nmpc_amd/hip/ddp_kernels_2w.hpp>
 
 namespace nmpc_amd
 {
@@ -54,7 +56,30 @@ struct ModelOpsFor
     Problem problem;
     std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
     const int grid = buf.Bp / kLanesPerBlock;
-    if(cfg.with_input_constraint)
+    // Lane mapping: the 2-wave (master + helper, LDS-staged) kernel whenever its records fit in LDS, else the
+    // single-wave kernel.  NMPC_HIP_DDP_KERNEL=1w forces the single-wave kernel (A/B measurements, tests).
+    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
+    constexpr bool fits_2w = PairSolver<Problem, false>::kFits;
+    const bool use_2w = fits_2w && !(force && std::strcmp(force, "1w") == 0);
+    if(use_2w)
+    {
+      if constexpr(PairSolver<Problem, false>::kFits)
+      {
+        using Pair = PairSolver<Problem, false>; // record layout does not depend on kConstrained
+        constexpr size_t lds_bytes = Pair::kLdsBytes;
+        if(cfg.with_input_constraint)
+        {
+          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, true>), dim3(grid), dim3(2 * kLanesPerBlock), lds_bytes,
+                             stream, problem, cfg, buf);
+        }
+        else
+        {
+          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, false>), dim3(grid), dim3(2 * kLanesPerBlock), lds_bytes,
+                             stream, problem, cfg, buf);
+        }
+      }
+    }
+    else if(cfg.with_input_constraint)
     {
       hipLaunchKernelGGL((ddp_solve_tpi_kernel<Problem, true>), dim3(grid), dim3(kLanesPerBlock), 0, stream, problem, cfg,
                          buf);

@@ -233,12 +233,19 @@ public:
     }
     return *this;
   }
+  /** Scaling leaves STRUCTURAL zeros (entries the compiler knows to be literal 0, e.g. after setZero()) untouched
+      instead of turning them into the run-time value 0 * s, which IEEE arithmetic does not allow the compiler to
+      fold.  This keeps the reference's idiom `m.setZero(); m(i,j) = ...; m *= dt_; m.diagonal() += 1`
+      (TestDDPCartPole.cpp:136-153) sparse for the solver kernels (ddp_kernels.hpp, macc()); exact for finite s. */
   NMPC_HD Matrix & operator*=(Scalar s)
   {
 #pragma unroll
     for(int i = 0; i < kCapacity; i++)
     {
-      d_[i] *= s;
+      if(!(__builtin_constant_p(d_[i]) && d_[i] == Scalar(0)))
+      {
+        d_[i] *= s;
+      }
     }
     return *this;
   }

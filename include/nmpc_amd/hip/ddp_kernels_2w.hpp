@@ -668,7 +668,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
           }
         }
         const double v = ((Qx[r] + s1) + s2) + s3;
-        Vx[r] = live ? v : Vx[r];
+        Vx[r] = v; // pass-local: lanes that are not live never commit anything derived from it
       }
 #pragma unroll kU
       for(int c = 0; c < N; c++)
@@ -697,7 +697,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
         for(int r = 0; r < N; r++)
         {
           const double v = 0.5 * (Vxx_new[r + c * N] + Vxx_new[c + r * N]);
-          Vxx[r + c * N] = live ? v : Vxx[r + c * N];
+          Vxx[r + c * N] = v;
         }
       }
 

@@ -67,6 +67,20 @@ struct ModelOpsFor
       {
         using Pair = PairSolver<Problem, false>; // record layout does not depend on kConstrained
         constexpr size_t lds_bytes = Pair::kLdsBytes;
+        if constexpr(lds_bytes > 64 * 1024)
+        {
+          static const hipError_t attr_rc = []() {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ddp_solve_tpi2w_kernel<Problem, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+            hipError_t f = hipFuncSetAttribute(reinterpret_cast<const void *>(&ddp_solve_tpi2w_kernel<Problem, false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+            return e != hipSuccess ? e : f;
+          }();
+          if(attr_rc != hipSuccess)
+          {
+            return attr_rc;
+          }
+        }
         if(cfg.with_input_constraint)
         {
           hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, true>), dim3(grid), dim3(2 * kLanesPerBlock), lds_bytes,

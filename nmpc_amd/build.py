@@ -48,6 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     cc = hipcc()
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}"]
+    flags += os.environ.get("NMPC_AMD_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DNMPC_AMD_PROFILE_2W
     objs = []
     procs = []
     for s in SOURCES:

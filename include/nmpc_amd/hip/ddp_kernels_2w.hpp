@@ -6,9 +6,14 @@
 //                 chain: the Riccati recursion (backward) and u' -> x' (forward);
 //   helper wave   backward: evaluates the problem's derivatives at (x_i, u_i) ONE TIMESTEP AHEAD of the master
 //                           (they do not depend on the recursion) and stages them in an LDS record;
-//                 forward : fetches the nominal (x, u, k, K) of the next timestep from HBM into LDS for the master,
-//                           and takes the master's (x', u') to evaluate runningCost / terminalCost, accumulate the
-//                           candidate cost and do all HBM stores.
+//                 forward : takes the master's (x', u') to evaluate runningCost / terminalCost, accumulate the
+//                           candidate cost and do all HBM stores (the master prefetches the nominal x, u, k, K itself,
+//                           two timesteps ahead).
+//
+// Every wave has only ONE kind of global memory operation in flight in any pass (backward: helper loads, master
+// stores; forward: master loads, helper stores).  gfx9 counts loads and stores in one vmcnt and they may complete out
+// of order with respect to each other, so a wave with both kinds pending can only wait for "everything"
+// (s_waitcnt vmcnt(0)) — which exposes the full latency of prefetches issued after a store.
 //
 // Why (profiles/r01_*): the single-wave kernel is bound by the issue rate of its one wavefront (~4 cycles per
 // instruction, one wave per SIMD, 64 of 1024 SIMDs busy at B = 4096); HBM is idle.  About 45 % of the backward
@@ -69,12 +74,8 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   static constexpr int oLxu = oLuu + MM * MM;
   static constexpr int oU = oLxu + N * MM;
   static constexpr int kBwdRec = oU + MM;
-  // forward records: "in" (helper -> master): nominal x_i, u_i, k_i, K_i; "out" (master -> helper): x'_i, u'_i
-  static constexpr int oXn = 0;
-  static constexpr int oUn = oXn + N;
-  static constexpr int oKff = oUn + MM;
-  static constexpr int oKfb = oKff + MM;
-  static constexpr int oXc = oKfb + MM * N;
+  // forward record (master -> helper): candidate x'_i, u'_i
+  static constexpr int oXc = 0;
   static constexpr int oUc = oXc + N;
   static constexpr int kFwdRec = oUc + MM;
   static constexpr int kRec = kBwdRec > kFwdRec ? kBwdRec : kFwdRec;
@@ -742,7 +743,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   // ===================================================================================================
   // forward pass    DDPSolver.hpp:536-560
   // ===================================================================================================
-  /** Nominal (x_i, u_i, k_i, K_i) of one timestep held in registers between its HBM load and its LDS store. */
+  /** Nominal (x_i, u_i, k_i, K_i) of one timestep, in registers from its HBM load (two timesteps early) to its use. */
   struct Nominal
   {
     double x[N], u[MM], k[MM], K[MM * N];
@@ -767,60 +768,21 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       n.K[e] = Base::ld(Base::KRow(i) + e * LW, ob);
     }
   }
-  NMPC_D void stageNominal(int slot, const Nominal & n) const
-  {
-#pragma unroll kU
-    for(int j = 0; j < N; j++)
-    {
-      rec(slot, oXn + j) = n.x[j];
-    }
-#pragma unroll kU
-    for(int a = 0; a < MM; a++)
-    {
-      rec(slot, oUn + a) = n.u[a];
-      rec(slot, oKff + a) = n.k[a];
-    }
-#pragma unroll kU
-    for(int e = 0; e < MM * N; e++)
-    {
-      rec(slot, oKfb + e) = n.K[e];
-    }
-  }
-
-  /** Helper side of one forward pass: stages nominal data one step ahead (requested from HBM two steps ahead),
-      evaluates the cost of the step the master has just finished, stores the candidate trajectory, returns the
-      candidate total cost through LDS. */
+  /** Helper side of one forward pass: evaluates the cost of the step the master has just finished, stores the
+      candidate trajectory (the helper issues ONLY stores during this pass, the master ONLY loads: a wave with both
+      kinds in flight has to drain them all at every wait), returns the candidate total cost through
+      LDS. */
   NMPC_D void forwardHelper(int sel_h) const
   {
     const int cs = 1 - sel_h;
     const unsigned cx = Base::offX(cs), cu = Base::offU(cs), cc = Base::offC(cs);
-    Nominal nom;
-    loadNominal(0, sel_h, nom);
-    stageNominal(0, nom);
-    if(T > 1)
-    {
-      loadNominal(1, sel_h, nom);
-    }
-    wgBarrier(); // barrier S: slot 0 "in" ready
     double J = 0;
     for(int i = 0; i < T; i++)
     {
-      if(i + 1 < T)
-      {
-        stageNominal((i + 1) & 1, nom); // loaded during the previous iteration
-        if(i + 2 < T)
-        {
-          loadNominal(i + 2, sel_h, nom);
-        }
-      }
-      if(i > 0)
-      {
-        J += consumeStep(i - 1, cx, cu, cc);
-      }
-      wgBarrier(); // barrier i: master wrote "out" of step i, helper wrote "in" of step i+1
+      wgBarrier(); // barrier i: the master wrote "out" of step i
+      J += consumeStep(i, cx, cu, cc);
     }
-    J += consumeStep(T - 1, cx, cu, cc);
-    // terminal state x'_T is in the "out" part of slot T & 1 (written by the master before its last barrier)
+    // terminal state x'_T is in the "out" part of slot T & 1 (written by the master after barrier T-1)
     wgBarrier(); // barrier E: x'_T available
     {
       StateDimVector xT;
@@ -864,53 +826,71 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     return c;
   }
 
-  /** Master side: u' = u + alpha k + K (x' - x), x'' = stateEq(x', u').  All memory traffic goes through LDS. */
-  NMPC_D void forwardMaster(double alpha)
+  /** Master side: u' = u + alpha k + K (x' - x), x'' = stateEq(x', u').  The nominal (x, u, k, K) of timestep i + 2
+      is requested from HBM while timestep i is computed (two register sets, loop unrolled by two so that neither is
+      ever copied); the candidate (x', u') goes to the helper through LDS. */
+  NMPC_D void forwardStep(int i, double alpha, Nominal & nom, StateDimVector & xc) const
   {
-    StateDimVector xc;
-    wgBarrier(); // barrier S
+    const int slot = i & 1;
+    const double t = current_t + i * problem.dt();
+    const int m = Base::inputDimAt(t);
+    InputDimVector uc;
+    uc.resize(m);
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      if(a < m)
+      {
+        double s = 0;
+#pragma unroll kU
+        for(int c = 0; c < N; c++)
+        {
+          s += nom.K[a + c * MM] * (xc[c] - nom.x[c]);
+        }
+        uc[a] = (nom.u[a] + alpha * nom.k[a]) + s;
+      }
+      else
+      {
+        uc[a] = 0;
+      }
+    }
+    // unconditional (the last two requests re-read timestep T-1 and are never used): with a branch around the loads
+    // the compiler cannot count the requests in flight and falls back to waiting for all of them at every timestep
+    loadNominal(i + 2 < T ? i + 2 : T - 1, sel, nom);
 #pragma unroll kU
     for(int j = 0; j < N; j++)
     {
-      xc[j] = rec(0, oXn + j); // x'_0 = x_0
+      rec(slot, oXc + j) = xc[j];
     }
-    for(int i = 0; i < T; i++)
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
     {
-      const int slot = i & 1;
-      const double t = current_t + i * problem.dt();
-      const int m = Base::inputDimAt(t);
-      InputDimVector uc;
-      uc.resize(m);
+      rec(slot, oUc + a) = uc[a];
+    }
+    xc = problem.stateEq(t, xc, uc);
+    wgBarrier(); // barrier i
+  }
+
+  NMPC_D void forwardMaster(double alpha)
+  {
+    Nominal nA, nB;
+    loadNominal(0, sel, nA);
+    loadNominal(T > 1 ? 1 : 0, sel, nB);
+    StateDimVector xc;
 #pragma unroll kU
-      for(int a = 0; a < MM; a++)
-      {
-        if(a < m)
-        {
-          double s = 0;
-#pragma unroll kU
-          for(int c = 0; c < N; c++)
-          {
-            s += rec(slot, oKfb + a + c * MM) * (xc[c] - rec(slot, oXn + c));
-          }
-          uc[a] = (rec(slot, oUn + a) + alpha * rec(slot, oKff + a)) + s;
-        }
-        else
-        {
-          uc[a] = 0;
-        }
-      }
-#pragma unroll kU
-      for(int j = 0; j < N; j++)
-      {
-        rec(slot, oXc + j) = xc[j];
-      }
-#pragma unroll kU
-      for(int a = 0; a < MM; a++)
-      {
-        rec(slot, oUc + a) = uc[a];
-      }
-      xc = problem.stateEq(t, xc, uc);
-      wgBarrier(); // barrier i
+    for(int j = 0; j < N; j++)
+    {
+      xc[j] = nA.x[j]; // x'_0 = x_0
+    }
+    int i = 0;
+    for(; i + 1 < T; i += 2)
+    {
+      forwardStep(i, alpha, nA, xc);
+      forwardStep(i + 1, alpha, nB, xc);
+    }
+    if(i < T)
+    {
+      forwardStep(i, alpha, nA, xc);
     }
 #pragma unroll kU
     for(int j = 0; j < N; j++)

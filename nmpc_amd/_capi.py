@@ -86,9 +86,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
-    if _build.needs_build():
-        path = _build.build()
+    path = os.environ.get("NMPC_HIP_DDP_LIB")  # developer override: A/B-time two builds on the same GPU box
+    if not path:
+        path = _build.LIB_PATH
+        if _build.needs_build():
+            path = _build.build()
     if not os.path.exists(path):
         raise RuntimeError("libnmpc_hip_ddp.so is missing and could not be built; there is no CPU fallback")
     L = C.CDLL(path)

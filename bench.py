@@ -198,13 +198,13 @@ def main():
                 "backward_passes_per_iteration": n_bw,
                 "forward_passes_per_iteration": n_fw,
                 "status_counts": {str(k): int(v) for k, v in zip(*np.unique(status, return_counts=True))},
-                "lane_mapping": "one lane per instance, 64 instances per wavefront",
+                "lane_mapping": "one lane per instance, 64 instances per workgroup (%s)" % solver.kernelName(),
                 "final_gather_ms": 1e3 * gather_s,
             },
             "instance_iterations_per_s": value * wl.B,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ddp_solve_tpi_kernel<DDPProblemCartPole>",
+                "kernel": solver.kernelName() + "<DDPProblemCartPole, false>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

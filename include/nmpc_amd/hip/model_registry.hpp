@@ -39,6 +39,8 @@ struct ModelOps
   void (*input_dims)(const void * params, double t0, int T, int * out);
   //! dt() of the problem object
   double (*dt)(const void * params);
+  //! name of the kernel launch_solve launches (lane mapping, see launchSolve)
+  const char * (*kernel_name)();
 };
 
 template<class Problem>
@@ -48,6 +50,17 @@ struct ModelOpsFor
   {
     new(out) Problem();
   }
+  /** Lane mapping: the 2-wave (master + helper, LDS-staged) kernel whenever its records fit in LDS, else the
+      single-wave kernel.  NMPC_HIP_DDP_KERNEL=1w forces the single-wave kernel (A/B measurements, tests). */
+  static bool useTwoWave()
+  {
+    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
+    return PairSolver<Problem, false>::kFits && !(force && std::strcmp(force, "1w") == 0);
+  }
+  static const char * kernelName()
+  {
+    return useTwoWave() ? "ddp_solve_tpi2w_kernel" : "ddp_solve_tpi_kernel";
+  }
   static hipError_t launchSolve(const void * params,
                                 const nmpc_hip_ddp_config & cfg,
                                 const DeviceBuffers & buf,
@@ -56,12 +69,7 @@ struct ModelOpsFor
     Problem problem;
     std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
     const int grid = buf.Bp / kLanesPerBlock;
-    // Lane mapping: the 2-wave (master + helper, LDS-staged) kernel whenever its records fit in LDS, else the
-    // single-wave kernel.  NMPC_HIP_DDP_KERNEL=1w forces the single-wave kernel (A/B measurements, tests).
-    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
-    constexpr bool fits_2w = PairSolver<Problem, false>::kFits;
-    const bool use_2w = fits_2w && !(force && std::strcmp(force, "1w") == 0);
-    if(use_2w)
+    if(useTwoWave())
     {
       if constexpr(PairSolver<Problem, false>::kFits)
       {
@@ -143,6 +151,7 @@ struct ModelOpsFor
     ops.launch_solve = &launchSolve;
     ops.input_dims = &inputDims;
     ops.dt = &dt;
+    ops.kernel_name = &kernelName;
     return ops;
   }
 };

@@ -184,6 +184,12 @@ extern "C"
                                 double * total_ms_sum,
                                 double * kernel_ms_sum);
 
+  /** Name of the gfx950 kernel the next solve of this handle launches (as rocprofv3 --kernel-trace lists it, without
+      template arguments): "ddp_solve_tpi2w_kernel" (master + helper wavefront per 64 instances, LDS-staged; chosen
+      when the model's LDS records fit) or "ddp_solve_tpi_kernel" (one wavefront per 64 instances; also forced by the
+      environment variable NMPC_HIP_DDP_KERNEL=1w).  No reference counterpart: diagnostics for profiles / bench.py. */
+  int nmpc_hip_ddp_kernel_name(nmpc_hip_ddp_handle h, const char ** name);
+
   /** Text of the last error raised on this thread (HIP error string or argument description). */
   const char * nmpc_hip_ddp_last_error(void);
 

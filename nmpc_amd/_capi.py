@@ -73,7 +73,7 @@ EXPORTS = (
     "nmpc_hip_ddp_set_model_params", "nmpc_hip_ddp_input_dims", "nmpc_hip_ddp_set_input_limits", "nmpc_hip_ddp_solve",
     "nmpc_hip_ddp_solve_device", "nmpc_hip_ddp_synchronize", "nmpc_hip_ddp_get", "nmpc_hip_ddp_get_device",
     "nmpc_hip_ddp_field_bytes", "nmpc_hip_ddp_last_solve_ms", "nmpc_hip_ddp_timing_stats",
-    "nmpc_hip_ddp_last_error",
+    "nmpc_hip_ddp_kernel_name", "nmpc_hip_ddp_last_error",
 )
 
 
@@ -114,6 +114,7 @@ def load():
     L.nmpc_hip_ddp_get_device.argtypes = [vp, C.c_int, vp, C.c_size_t, vp]
     L.nmpc_hip_ddp_field_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
     L.nmpc_hip_ddp_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.nmpc_hip_ddp_kernel_name.argtypes = [vp, C.POINTER(C.c_char_p)]
     L.nmpc_hip_ddp_timing_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), dp, dp]
     L.nmpc_hip_ddp_last_error.argtypes = []
     L.nmpc_hip_ddp_last_error.restype = C.c_char_p

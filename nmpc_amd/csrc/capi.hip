@@ -904,6 +904,16 @@ extern "C"
     return NMPC_HIP_OK;
   }
 
+  int nmpc_hip_ddp_kernel_name(nmpc_hip_ddp_handle s, const char ** name)
+  {
+    if(!s || !name)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output pointer");
+    }
+    *name = s->ops->kernel_name();
+    return NMPC_HIP_OK;
+  }
+
   int nmpc_hip_ddp_timing_stats(nmpc_hip_ddp_handle s,
                                 int reset,
                                 long long * n_solves,

@@ -314,6 +314,12 @@ class DDPSolverBatch:
         _capi.check(self._L.nmpc_hip_ddp_last_solve_ms(self._h, C.byref(tot), C.byref(ker)))
         return ComputationDuration(solve=tot.value, setup=tot.value - ker.value, opt=ker.value)
 
+    def kernelName(self) -> str:
+        """gfx950 kernel the next solve launches (lane mapping), as rocprofv3 lists it."""
+        name = C.c_char_p()
+        _capi.check(self._L.nmpc_hip_ddp_kernel_name(self._h, C.byref(name)))
+        return name.value.decode()
+
     def timingStats(self, reset: bool = False):
         """(number of device solves, sum of ingest+kernel ms, sum of solve-kernel ms) since the last reset."""
         n, tot, ker = C.c_longlong(), C.c_double(), C.c_double()

@@ -43,7 +43,7 @@ bench = json.loads(bench_line)
 json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
 hbm_bytes = (pm["FETCH_SIZE"] * fetch_scale + pm["WRITE_SIZE"] * write_scale) * 1024.0
 with open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w") as f:
-    f.write(f"kernel: ddp_solve_tpi_kernel (bench.py --steps 10 --warmup 2, batch 4096, 8 iterations per launch)\n")
+    f.write(f"kernel: {bench['roofline']['kernel']} (bench.py --steps 10 --warmup 2, batch 4096, 8 iterations per launch)\n")
     f.write("per-launch means; SQ_* cycle counters are in quad-cycles (x4 = shader cycles), summed over the 64 waves\n")
     for k in sorted(pm):
         f.write(f"  {k:28s} n={cnt[k]:3d} mean={pm[k]:18.1f}\n")

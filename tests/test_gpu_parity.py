@@ -393,3 +393,30 @@ def test_cpp_host_mirror_example(tmp_path):
     assert cols == ["iter", "cost", "lambda", "dlambda", "alpha", "k_rel_norm", "cost_update_actual",
                     "cost_update_expected", "cost_update_ratio", "duration_derivative", "duration_backward",
                     "duration_forward"]  # DDPSolver.hpp:567-578: what scripts/plotDDPTraceData.py reads
+
+
+@pytest.mark.parametrize("model", ["cartpole", "bipedal", "vertical"])
+def test_two_wave_and_single_wave_kernels_agree(model, monkeypatch):
+    """Both lane mappings (ddp_kernels_2w.hpp: master + helper wave through LDS; ddp_kernels.hpp: one wave) run the
+    same algorithm: identical discrete decisions, values equal up to FMA-contraction differences."""
+    from nmpc_amd import workloads
+
+    wl = {"cartpole": lambda: workloads.cartpole_batch(B=200, T=60, seed=11, constrained=True),
+          "bipedal": lambda: workloads.bipedal_batch(B=130, T=40, seed=12),
+          "vertical": lambda: workloads.vertical_batch(B=96, T=80, seed=13, constrained=False)}[model]()
+    cfg = dict(with_input_constraint=wl.limits is not None, max_iter=30)
+    if model == "vertical":
+        cfg["initial_lambda"] = 1e-6
+    out = {}
+    for kernel in ("2w", "1w"):
+        monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", kernel)
+        s = make_solver(wl, **cfg)
+        s.solve(wl.t0, wl.x0, wl.u_init)
+        out[kernel] = dict(status=s.status(), iters=s.iters(), X=s.X(), U=s.U(), cost=s.cost(), kff=s.kff(),
+                           Kfb=s.Kfb(), trace=s.trace(), qp=s.qpRetval(), free=s.qpFreeMask())
+    a, b = out["2w"], out["1w"]
+    for key in ("status", "iters", "qp", "free"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(a["trace"][..., INT_COLS], b["trace"][..., INT_COLS])
+    for key in ("X", "U", "cost", "kff", "Kfb"):
+        assert scaled_err(a[key], b[key]) <= TOL, key

@@ -1120,13 +1120,17 @@ struct InstanceSolver
           Vxx_new[r + c * N] = ((Qxx[r + c * N] + s1) + s2) + s3;
         }
       }
+      // Vxx = 0.5 (Vxx + Vxx^T)    DDPSolver.hpp:527.  IEEE addition commutes, so entries (r, c) and (c, r) of the
+      // reference's result are the same bits: each off-diagonal pair is computed once.
 #pragma unroll kU
       for(int c = 0; c < N; c++)
       {
 #pragma unroll kU
-        for(int r = 0; r < N; r++)
+        for(int r = 0; r <= c; r++)
         {
-          Vxx[r + c * N] = 0.5 * (Vxx_new[r + c * N] + Vxx_new[c + r * N]);
+          const double v = 0.5 * (Vxx_new[r + c * N] + Vxx_new[c + r * N]);
+          Vxx[r + c * N] = v;
+          Vxx[c + r * N] = v;
         }
       }
 

@@ -109,10 +109,49 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   }
   /** Workgroup barrier for the LDS hand-off.  Only LDS traffic has to be complete (lgkmcnt); __syncthreads() would
       also wait for vmcnt(0), i.e. drain the helper's HBM prefetches and the stores of every timestep. */
+#ifdef NMPC_AMD_PROFILE_2W
+  // Profiling build (NMPC_AMD_EXTRA_HIPCC_FLAGS=-DNMPC_AMD_PROFILE_2W python -m nmpc_amd.build --force, then
+  // scripts/profile_2w.py): shader cycles per pass kind and the share spent waiting in the per-timestep barriers,
+  // per role; written over qp_free of instances 0 (master) / 1 (helper) of tile 0.  Never enabled in product builds.
+  mutable unsigned long long prof_wait = 0, prof_t0 = 0;
+  mutable unsigned long long prof_acc[4] = {0, 0, 0, 0}; // [2 * pass_kind + 0] = total, [+ 1] = barrier wait
+  NMPC_D void wgBarrier() const
+  {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    prof_wait += __builtin_readcyclecounter() - t0;
+  }
+  NMPC_D void profBegin() const
+  {
+    prof_wait = 0;
+    prof_t0 = __builtin_readcyclecounter();
+  }
+  NMPC_D void profEnd(int kind) const
+  {
+    prof_acc[2 * kind] += __builtin_readcyclecounter() - prof_t0;
+    prof_acc[2 * kind + 1] += prof_wait;
+  }
+  NMPC_D void profFlush(int instance) const
+  {
+    if(blockIdx.x == 0 && lane == 0)
+    {
+      for(int r = 0; r < 4; r++)
+      {
+        buf.qp_free[static_cast<size_t>(r) * LW + instance] = static_cast<unsigned>(prof_acc[r] >> 4);
+      }
+      // HW_REG_HW_ID (id 4): [3:0] wave slot, [5:4] SIMD, [11:8] CU, [15:13] SE -> which SIMD each role runs on
+      buf.qp_free[static_cast<size_t>(4) * LW + instance] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+    }
+  }
+#else
   NMPC_D static void wgBarrier()
   {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+  NMPC_D void profBegin() const {}
+  NMPC_D void profEnd(int) const {}
+  NMPC_D void profFlush(int) const {}
+#endif
 
   // ===================================================================================================
   // backward pass
@@ -165,26 +204,77 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     }
   }
 
+  /** (x_i, u_i) in registers from its HBM request (kBwdAhead timesteps early) to its use. */
+  struct Point
+  {
+    StateDimVector x;
+    InputDimVector u;
+  };
+  static constexpr int kBwdAhead = 4;
+  NMPC_D void loadPoint(int i, unsigned ox, unsigned ou, Point & p) const
+  {
+    Base::loadX(Base::xRow(i), ox, p.x);
+    Base::loadU(Base::uRow(i), ou, p.u, MM);
+  }
+  /** Scheduling fence for one value: everything computed from v is issued after this point (volatile asm statements
+      keep their order, so also after the preceding wgBarrier()).  Without it the compiler hoists the arithmetic of
+      several unrolled timesteps in front of the first barrier: one long timestep and three short ones per four, and
+      since the waves meet at a barrier every timestep, the long one sets the pace. */
+  NMPC_D static void pin(double & v)
+  {
+    asm volatile("" : "+v"(v));
+  }
+  NMPC_D void backwardHelperStep(int i, unsigned ox, unsigned ou, Point & p) const
+  {
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      pin(p.x[j]);
+    }
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      pin(p.u[a]);
+    }
+    produceDerivatives(i, i & 1, p.x, p.u);
+    // unconditional (the last requests re-read timestep 0 and are never used), so that the compiler can count the
+    // requests in flight instead of waiting for all of them
+    loadPoint(i >= kBwdAhead ? i - kBwdAhead : 0, ox, ou, p);
+    wgBarrier();
+  }
+
   NMPC_D void backwardHelper(int sel_h) const
   {
     // barrier k separates "record of step T-1-k written" from "record of step T-1-k read".
-    // (x, u) of step i-1 are requested from HBM while the derivatives of step i are evaluated.
+    // (x, u) of step i - kBwdAhead are requested while the derivatives of step i are evaluated: a request takes
+    // 500 .. 2000 cycles (L2 / MALL / HBM), a timestep ~900.  Ring of kBwdAhead register sets, loop unrolled by the
+    // same number so that no set is ever copied.
+    static_assert(kBwdAhead == 4, "backwardHelper is written for a ring of four register sets");
     const unsigned ox = Base::offX(sel_h), ou = Base::offU(sel_h);
-    StateDimVector x_pref;
-    InputDimVector u_pref;
-    Base::loadX(Base::xRow(T - 1), ox, x_pref);
-    Base::loadU(Base::uRow(T - 1), ou, u_pref, MM);
-    for(int i = T - 1; i >= 0; i--)
+    Point p0, p1, p2, p3;
+    loadPoint(T - 1, ox, ou, p0);
+    loadPoint(T > 1 ? T - 2 : 0, ox, ou, p1);
+    loadPoint(T > 2 ? T - 3 : 0, ox, ou, p2);
+    loadPoint(T > 3 ? T - 4 : 0, ox, ou, p3);
+    int i = T - 1;
+    for(; i >= 3; i -= 4)
     {
-      const StateDimVector x = x_pref;
-      const InputDimVector u = u_pref;
-      if(i > 0)
-      {
-        Base::loadX(Base::xRow(i - 1), ox, x_pref);
-        Base::loadU(Base::uRow(i - 1), ou, u_pref, MM);
-      }
-      produceDerivatives(i, i & 1, x, u);
-      wgBarrier();
+      backwardHelperStep(i, ox, ou, p0);
+      backwardHelperStep(i - 1, ox, ou, p1);
+      backwardHelperStep(i - 2, ox, ou, p2);
+      backwardHelperStep(i - 3, ox, ou, p3);
+    }
+    if(i >= 0)
+    {
+      backwardHelperStep(i, ox, ou, p0);
+    }
+    if(i >= 1)
+    {
+      backwardHelperStep(i - 1, ox, ou, p1);
+    }
+    if(i >= 2)
+    {
+      backwardHelperStep(i - 2, ox, ou, p2);
     }
     wgBarrier(); // closes the pass: the master's last record reads are done
   }
@@ -691,14 +781,17 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
           Vxx_new[r + c * N] = ((Qxx[r + c * N] + s1) + s2) + s3;
         }
       }
+      // Vxx = 0.5 (Vxx + Vxx^T)    DDPSolver.hpp:527.  IEEE addition commutes, so entries (r, c) and (c, r) of the
+      // reference's result are the same bits: each off-diagonal pair is computed once.
 #pragma unroll kU
       for(int c = 0; c < N; c++)
       {
 #pragma unroll kU
-        for(int r = 0; r < N; r++)
+        for(int r = 0; r <= c; r++)
         {
           const double v = 0.5 * (Vxx_new[r + c * N] + Vxx_new[c + r * N]);
           Vxx[r + c * N] = v;
+          Vxx[c + r * N] = v;
         }
       }
 
@@ -826,14 +919,31 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     return c;
   }
 
-  /** Master side: u' = u + alpha k + K (x' - x), x'' = stateEq(x', u').  The nominal (x, u, k, K) of timestep i + 2
-      is requested from HBM while timestep i is computed (two register sets, loop unrolled by two so that neither is
-      ever copied); the candidate (x', u') goes to the helper through LDS. */
+  /** Master side: u' = u + alpha k + K (x' - x), x'' = stateEq(x', u').  The nominal (x, u, k, K) of timestep
+      i + kFwdAhead is requested while timestep i is computed: a request takes 500 .. 1500 cycles (L2 / MALL / HBM), a
+      timestep ~500.  The candidate (x', u') goes to the helper through LDS. */
+  static constexpr int kFwdAhead = 4;
   NMPC_D void forwardStep(int i, double alpha, Nominal & nom, StateDimVector & xc) const
   {
     const int slot = i & 1;
     const double t = current_t + i * problem.dt();
     const int m = Base::inputDimAt(t);
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      pin(nom.x[j]); // keep the arithmetic of this timestep behind the previous barrier, see pin()
+    }
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      pin(nom.u[a]);
+      pin(nom.k[a]);
+    }
+#pragma unroll kU
+    for(int e = 0; e < MM * N; e++)
+    {
+      pin(nom.K[e]);
+    }
     InputDimVector uc;
     uc.resize(m);
 #pragma unroll kU
@@ -856,7 +966,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     }
     // unconditional (the last two requests re-read timestep T-1 and are never used): with a branch around the loads
     // the compiler cannot count the requests in flight and falls back to waiting for all of them at every timestep
-    loadNominal(i + 2 < T ? i + 2 : T - 1, sel, nom);
+    loadNominal(i + kFwdAhead < T ? i + kFwdAhead : T - 1, sel, nom);
 #pragma unroll kU
     for(int j = 0; j < N; j++)
     {
@@ -873,24 +983,39 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 
   NMPC_D void forwardMaster(double alpha)
   {
-    Nominal nA, nB;
-    loadNominal(0, sel, nA);
-    loadNominal(T > 1 ? 1 : 0, sel, nB);
+    // kFwdAhead register sets form a ring: set r holds timestep i with i % kFwdAhead == r, the loop is unrolled by
+    // kFwdAhead so that every set keeps its registers (no copies) and the compiler can count the requests in flight
+    Nominal n0, n1, n2, n3;
+    static_assert(kFwdAhead == 4, "forwardMaster is written for a ring of four register sets");
+    loadNominal(0, sel, n0);
+    loadNominal(T > 1 ? 1 : T - 1, sel, n1);
+    loadNominal(T > 2 ? 2 : T - 1, sel, n2);
+    loadNominal(T > 3 ? 3 : T - 1, sel, n3);
     StateDimVector xc;
 #pragma unroll kU
     for(int j = 0; j < N; j++)
     {
-      xc[j] = nA.x[j]; // x'_0 = x_0
+      xc[j] = n0.x[j]; // x'_0 = x_0
     }
     int i = 0;
-    for(; i + 1 < T; i += 2)
+    for(; i + 3 < T; i += 4)
     {
-      forwardStep(i, alpha, nA, xc);
-      forwardStep(i + 1, alpha, nB, xc);
+      forwardStep(i, alpha, n0, xc);
+      forwardStep(i + 1, alpha, n1, xc);
+      forwardStep(i + 2, alpha, n2, xc);
+      forwardStep(i + 3, alpha, n3, xc);
     }
     if(i < T)
     {
-      forwardStep(i, alpha, nA, xc);
+      forwardStep(i, alpha, n0, xc);
+    }
+    if(i + 1 < T)
+    {
+      forwardStep(i + 1, alpha, n1, xc);
+    }
+    if(i + 2 < T)
+    {
+      forwardStep(i + 2, alpha, n2, xc);
     }
 #pragma unroll kU
     for(int j = 0; j < N; j++)
@@ -931,15 +1056,19 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       const int sel_h = word & 1;
       if(cmd == kCmdExit)
       {
+        profFlush(1);
         return;
       }
+      profBegin();
       if(cmd == kCmdBackward)
       {
         backwardHelper(sel_h);
+        profEnd(0);
       }
       else
       {
         forwardHelper(sel_h);
+        profEnd(1);
       }
     }
   }
@@ -1001,7 +1130,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       while(__any(need_bw))
       {
         post(kCmdBackward);
+        profBegin();
         const bool ok = backwardMaster(need_bw);
+        profEnd(0);
         if(need_bw)
         {
           n_backward++;
@@ -1057,7 +1188,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
         }
         const double a_try = cfg.alpha_list[ai];
         post(kCmdForward);
+        profBegin();
         forwardMaster(a_try);
+        profEnd(1);
         if(need_fw)
         {
           alpha = a_try;
@@ -1128,6 +1261,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       }
     }
     post(kCmdExit);
+    profFlush(0);
 
     if(valid)
     {

@@ -13,3 +13,5 @@ print("kernel ms", s.computationDuration().opt)
 for role, inst in (("master", 0), ("helper", 1)):
     bt, bw, ft, fw = q[inst, 0], q[inst, 1], q[inst, 2], q[inst, 3]
     print(f"{role}: backward total {bt:.0f} cyc, barrier wait {bw:.0f} ({bw / max(bt, 1):.2%}) | forward total {ft:.0f}, wait {fw:.0f} ({fw / max(ft, 1):.2%})")
+    hw = int(s.qpFreeMask()[inst, 4])
+    print(f"   HW_ID wave slot {hw & 15}, SIMD {(hw >> 4) & 3}, CU {(hw >> 8) & 15}, SE {(hw >> 13) & 7}")

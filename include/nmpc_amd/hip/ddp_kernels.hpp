@@ -355,7 +355,7 @@ struct InstanceSolver
         else
         {
           A[k + k * LD] = d;
-          const double r = 1.0 / d;
+          const double r = recipFast(d); // d > 0 here
           inv_d[k] = r;
 #pragma unroll kU
           for(int i = 0; i < LD; i++)
@@ -1159,7 +1159,7 @@ struct InstanceSolver
         // for m == 1 the two norms are |k| and |u| exactly (sqrt(x*x) == |x| up to under/overflow)
         const double knorm = (M == 1) ? fabs(k[0]) : sqrt(kn);
         const double unorm = (M == 1) ? fabs(u[0]) : sqrt(un);
-        k_rel_norm = fmax(k_rel_norm, knorm / (unorm + 1.0));
+        k_rel_norm = fmax(k_rel_norm, knorm * recipFast(unorm + 1.0));
       }
     }
     return ok;

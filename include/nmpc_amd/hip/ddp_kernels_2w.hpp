@@ -820,7 +820,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
         m_next = m;
         const double knorm = (M == 1) ? fabs(k[0]) : sqrt(kn);
         const double unorm = (M == 1) ? fabs(u[0]) : sqrt(un);
-        krn = fmax(krn, knorm / (unorm + 1.0));
+        krn = fmax(krn, knorm * recipFast(unorm + 1.0));
       }
     }
     wgBarrier(); // closes the pass

@@ -60,7 +60,7 @@ public:
     const double omega2 = omega * omega;
     const double denom = m1 + m2 * (sin_theta * sin_theta);
     // one reciprocal instead of the two divisions of the textbook form (an fp64 divide costs ~10 FMAs on gfx950)
-    const double inv_denom = 1 / denom;
+    const double inv_denom = recipFast(denom); // denom >= cart mass > 0
     const double inv_l = 1 / l;
 
     StateDimVector x_next;
@@ -114,7 +114,7 @@ public:
     const double omega2 = omega * omega;
     const double sin2 = sin_theta * sin_theta;
     const double denom = m1 + m2 * sin2;
-    const double inv_denom = 1 / denom;
+    const double inv_denom = recipFast(denom); // denom >= cart mass > 0
     const double inv_denom_sq = inv_denom * inv_denom;
     const double inv_l = 1 / l;
     // numerators of the two accelerations and d(denom)/d(theta)

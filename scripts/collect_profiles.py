@@ -4,7 +4,9 @@
   profiles/<tag>_kernel_stats.csv        rocprofv3 --kernel-trace --stats of `python bench.py --steps 10 --warmup 2`
   profiles/<tag>_pmc_summary.txt         per-launch means of the PMC passes (each set collected in its own run)
   profiles/<tag>_counter_calibration.txt FETCH_SIZE / WRITE_SIZE on a known 1 GiB read / write at 8 B per lane
-  profiles/<tag>_ubench.txt              per-instruction prices (clock, fp64 FMA / div / sqrt / sin / sincos)
+  profiles/<tag>_ubench.txt              per-instruction prices (clock, fp64 FMA / div / sqrt / sin / sincos; FMA latency
+                                         vs issue interval for a lone wavefront; recipFast accuracy)
+  profiles/<tag>_roles.txt               master / helper cycles and barrier-wait shares (profiling build of the 2-wave kernel)
   profiles/<tag>_bench.json              the bench line of the same session (unprofiled run)
   profiles/hbm_traffic.json              corrected HBM bytes per launch, read by bench.py for roofline.traffic
 """
@@ -16,6 +18,8 @@ dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "ubench_clock.txt"), os.path.join(dst, f"{tag}_ubench.txt"))
+if os.path.exists(os.path.join(src, "roles.txt")):  # per-role cycle counters of the -DNMPC_AMD_PROFILE_2W build
+    shutil.copy(os.path.join(src, "roles.txt"), os.path.join(dst, f"{tag}_roles.txt"))
 
 def means(pattern_file, kernel_pat):
     out = collections.defaultdict(list)

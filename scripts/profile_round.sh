@@ -18,4 +18,7 @@ rocprofv3 --pmc WRITE_SIZE TCC_HIT TCC_MISS --output-format csv -d $OUT -o pmcE 
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o calF -- ./scripts/ubench_hbm_counters > $OUT/calF.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o calW -- ./scripts/ubench_hbm_counters > $OUT/calW.log 2>&1
 ./scripts/ubench_clock > $OUT/ubench_clock.txt 2>&1
+./scripts/ubench_latency >> $OUT/ubench_clock.txt 2>&1
+./scripts/ubench_recip >> $OUT/ubench_clock.txt 2>&1
+if [ -f nmpc_amd/lib/alt/prof.so ]; then NMPC_HIP_DDP_LIB=$PWD/nmpc_amd/lib/alt/prof.so python scripts/profile_2w.py > $OUT/roles.txt 2>&1; fi
 ls $OUT

@@ -183,45 +183,9 @@ public:
                           const std::vector<StateDimVector> & current_x,
                           const std::vector<std::vector<InputDimVector>> & initial_u_list)
   {
-    const int T = config_.horizon_steps;
     const size_t B = static_cast<size_t>(batch_size_);
-    if(current_t.size() != B || current_x.size() != B || initial_u_list.size() != B)
-    {
-      throw std::invalid_argument("batch of current_t / current_x / initial_u_list should be " + std::to_string(B) + ".");
-    }
-    ensureHandle();
-    pushState();
-    std::vector<double> x0(B * StateDim), u0(B * T * MM, 0.0);
-    std::vector<int> dims(T);
-    for(size_t b = 0; b < B; b++)
-    {
-      // Check initial_u_list    DDPSolver.hpp:41-58
-      if(static_cast<int>(initial_u_list[b].size()) != T)
-      {
-        throw std::invalid_argument("initial_u_list length should be " + std::to_string(T) + " but "
-                                    + std::to_string(initial_u_list[b].size()) + ".");
-      }
-      check(nmpc_hip_ddp_input_dims(handle_, current_t[b], dims.data()));
-      for(int i = 0; i < T; i++)
-      {
-        const InputDimVector & u = initial_u_list[b][i];
-        if(u.size() != dims[i])
-        {
-          const double t = current_t[b] + i * problem_->dt();
-          throw std::runtime_error("initial_u dimension should be " + std::to_string(dims[i]) + " but "
-                                   + std::to_string(u.size()) + ". i: " + std::to_string(i)
-                                   + ", time: " + std::to_string(t));
-        }
-        for(int a = 0; a < dims[i]; a++)
-        {
-          u0[(b * T + i) * MM + a] = u[a];
-        }
-      }
-      for(int j = 0; j < StateDim; j++)
-      {
-        x0[b * StateDim + j] = current_x[b][j];
-      }
-    }
+    std::vector<double> x0, u0;
+    packInputs(current_t, current_x, initial_u_list, x0, u0);
     check(nmpc_hip_ddp_solve(handle_, current_t.data(), x0.data(), u0.data()));
     fetched_ = false;
     fetchResults();
@@ -237,6 +201,65 @@ public:
       std::cout << "[DDP] Failure due to large lambda in " << n_fail << " of " << B << " instances." << std::endl;
     }
     return ok;
+  }
+
+  /*! \brief Per-tick log of mpcRun(): the columns the reference's closed-loop tests dump (TestDDPBipedal.cpp:251-262). */
+  struct MpcLog
+  {
+    int n_ticks = 0;
+    std::vector<double> t; //!< [batch][n_ticks]
+    std::vector<double> x; //!< [batch][n_ticks][StateDim] state handed to the solve of the tick
+    std::vector<double> u0; //!< [batch][n_ticks][MM] first input of the solution (clamped in the plant pattern)
+    std::vector<int> iters, status, m0; //!< [batch][n_ticks]
+    std::vector<double> x_final; //!< [batch][StateDim] state after the last advance
+    std::vector<double> t_final; //!< [batch]
+  };
+
+  /** \brief The reference's receding-horizon caller loops, batched and device-resident (nmpc_hip_ddp_mpc_run):
+      n_ticks times { solve; advance (t, x, u_list) on the device }.
+      \param shift_warm_start true: the loop of TestDDPBipedal.cpp:243-268 (next x = x_list[1], u_list shifted);
+                               false: the plant loop of TestDDPCartPole.cpp:323-346,388-403 (u_list[0], clamped to the
+                               input limits if clamp_u0, drives sim_substeps steps of stateEq(t, x, u, sim_dt))
+      \param max_iter_after_first if > 0, config().max_iter of every solve after the first one
+      Afterwards controlData(b) etc. hold the results of the last solve. */
+  MpcLog mpcRun(const std::vector<double> & current_t,
+                const std::vector<StateDimVector> & current_x,
+                const std::vector<std::vector<InputDimVector>> & initial_u_list,
+                int n_ticks,
+                bool shift_warm_start = true,
+                int max_iter_after_first = 0,
+                int sim_substeps = 0,
+                double sim_dt = 0.0,
+                bool clamp_u0 = true)
+  {
+    const size_t B = static_cast<size_t>(batch_size_);
+    std::vector<double> x0, u0;
+    packInputs(current_t, current_x, initial_u_list, x0, u0);
+    nmpc_hip_ddp_mpc_options opt;
+    check(nmpc_hip_ddp_mpc_default_options(&opt));
+    opt.n_ticks = n_ticks;
+    opt.shift_warm_start = shift_warm_start ? 1 : 0;
+    opt.max_iter_after_first = max_iter_after_first;
+    opt.sim_substeps = sim_substeps;
+    opt.sim_dt = sim_dt;
+    opt.clamp_u0 = clamp_u0 ? 1 : 0;
+    MpcLog log;
+    log.n_ticks = n_ticks;
+    const size_t nt = n_ticks > 0 ? static_cast<size_t>(n_ticks) : 0;
+    log.t.resize(B * nt);
+    log.x.resize(B * nt * StateDim);
+    log.u0.resize(B * nt * MM);
+    log.iters.resize(B * nt);
+    log.status.resize(B * nt);
+    log.m0.resize(B * nt);
+    log.x_final.resize(B * StateDim);
+    log.t_final.resize(B);
+    check(nmpc_hip_ddp_mpc_run(handle_, current_t.data(), x0.data(), u0.data(), &opt, log.t.data(), log.x.data(),
+                               log.u0.data(), log.iters.data(), log.status.data(), log.m0.data(), log.x_final.data(),
+                               log.t_final.data()));
+    fetched_ = false;
+    fetchResults();
+    return log;
   }
 
   /** \brief Const accessor to control data of instance b calculated by solve(). */
@@ -436,6 +459,56 @@ protected:
     computation_duration_.opt = kernel_ms;
     computation_duration_.setup = total_ms - kernel_ms;
     fetched_ = true;
+  }
+
+protected:
+  /** Validate (DDPSolver.hpp:41-58) and pack current_x / initial_u_list into the C-ABI's padded arrays. */
+  void packInputs(const std::vector<double> & current_t,
+                  const std::vector<StateDimVector> & current_x,
+                  const std::vector<std::vector<InputDimVector>> & initial_u_list,
+                  std::vector<double> & x0,
+                  std::vector<double> & u0)
+  {
+    const int T = config_.horizon_steps;
+    const size_t B = static_cast<size_t>(batch_size_);
+    if(current_t.size() != B || current_x.size() != B || initial_u_list.size() != B)
+    {
+      throw std::invalid_argument("batch of current_t / current_x / initial_u_list should be " + std::to_string(B) + ".");
+    }
+    ensureHandle();
+    pushState();
+    x0.assign(B * StateDim, 0.0);
+    u0.assign(B * T * MM, 0.0);
+    std::vector<int> dims(T);
+    for(size_t b = 0; b < B; b++)
+    {
+      // Check initial_u_list    DDPSolver.hpp:41-58
+      if(static_cast<int>(initial_u_list[b].size()) != T)
+      {
+        throw std::invalid_argument("initial_u_list length should be " + std::to_string(T) + " but "
+                                    + std::to_string(initial_u_list[b].size()) + ".");
+      }
+      check(nmpc_hip_ddp_input_dims(handle_, current_t[b], dims.data()));
+      for(int i = 0; i < T; i++)
+      {
+        const InputDimVector & u = initial_u_list[b][i];
+        if(u.size() != dims[i])
+        {
+          const double t = current_t[b] + i * problem_->dt();
+          throw std::runtime_error("initial_u dimension should be " + std::to_string(dims[i]) + " but "
+                                   + std::to_string(u.size()) + ". i: " + std::to_string(i)
+                                   + ", time: " + std::to_string(t));
+        }
+        for(int a = 0; a < dims[i]; a++)
+        {
+          u0[(b * T + i) * MM + a] = u[a];
+        }
+      }
+      for(int j = 0; j < StateDim; j++)
+      {
+        x0[b * StateDim + j] = current_x[b][j];
+      }
+    }
   }
 
 protected:

@@ -15,6 +15,7 @@
 
 #include <nmpc_amd/hip/ddp_kernels.hpp>
 #include <nmpc_amd/hip/ddp_kernels_2w.hpp>
+#include <nmpc_amd/hip/mpc_kernels.hpp>
 
 namespace nmpc_amd
 {
@@ -41,6 +42,13 @@ struct ModelOps
   double (*dt)(const void * params);
   //! name of the kernel launch_solve launches (lane mapping, see launchSolve)
   const char * (*kernel_name)();
+  //! launches the receding-horizon advance step (mpc_kernels.hpp) between two solves
+  hipError_t (*launch_mpc_advance)(const void * params,
+                                   const DeviceBuffers & buf,
+                                   const MpcAdvanceArgs & args,
+                                   hipStream_t stream);
+  //! 1 if the problem has the plant step stateEq(t, x, u, dt) the plant pattern integrates with
+  int has_plant_step;
 };
 
 template<class Problem>
@@ -113,6 +121,17 @@ struct ModelOpsFor
     }
     return hipGetLastError();
   }
+  static hipError_t launchMpcAdvance(const void * params,
+                                     const DeviceBuffers & buf,
+                                     const MpcAdvanceArgs & args,
+                                     hipStream_t stream)
+  {
+    Problem problem;
+    std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
+    hipLaunchKernelGGL((mpc_advance_kernel<Problem>), dim3(buf.Bp / kLanesPerBlock), dim3(kLanesPerBlock), 0, stream,
+                       problem, buf, args);
+    return hipGetLastError();
+  }
   static void inputDims(const void * params, double t0, int T, int * out)
   {
     Problem problem;
@@ -152,6 +171,8 @@ struct ModelOpsFor
     ops.input_dims = &inputDims;
     ops.dt = &dt;
     ops.kernel_name = &kernelName;
+    ops.launch_mpc_advance = &launchMpcAdvance;
+    ops.has_plant_step = HasPlantStep<Problem>::value ? 1 : 0;
     return ops;
   }
 };

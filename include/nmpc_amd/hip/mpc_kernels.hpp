@@ -1,0 +1,192 @@
+// gfx950 device code of the receding-horizon (MPC) driver: what the reference's callers do BETWEEN two solve() calls,
+// executed on the device so that thousands of closed-loop rollouts advance without a host round trip.
+//
+// The reference has two caller patterns:
+//   shift pattern   TestDDPBipedal.cpp:243-268, TestDDPVerticalMotion.cpp:290-326, TestDDPCentroidalMotion.cpp:307-347
+//                   current_x = controlData().x_list[1]; current_u_list = controlData().u_list with the first entry
+//                   erased and the last one repeated (or a zero vector of the terminal dimension when the input
+//                   dimension changes at the end of the horizon); current_t += dt
+//   plant pattern   TestDDPCartPole.cpp:323-346,388-403
+//                   current_u = controlData().u_list[0] clamped to the input limits; the plant is integrated with
+//                   ddp_problem->stateEq(t, x, u, sim_dt) (the problem's 4-argument overload) for several sim steps;
+//                   initial_u_list = controlData().u_list (not shifted)
+// One lane per instance, same tile-major arrays as the solver kernels (ddp_kernels.hpp); the kernel rewrites the solver's
+// own input buffers (t0, x0, half 0 of U), so the next solve is launched without any ingest.
+#pragma once
+
+#include <type_traits>
+#include <utility>
+
+#include <nmpc_amd/hip/ddp_kernels.hpp>
+
+namespace nmpc_amd
+{
+namespace hip
+{
+/** Arguments of one advance step (tick).  Log pointers are batch-major device arrays [B][n_ticks][...] or nullptr. */
+struct MpcAdvanceArgs
+{
+  int tick;
+  int n_ticks;
+  int shift_warm_start; //!< 1: shift pattern, 0: plant pattern
+  int sim_substeps; //!< plant pattern: number of stateEq(t, x, u, sim_dt) steps per tick
+  double sim_dt;
+  int clamp_u0; //!< plant pattern: clamp u[0] to the handle's input limits first
+  double * t0; //!< [Bp]            solver input: start time of the next solve
+  double * x0; //!< [tile][N][64]   solver input: initial state of the next solve
+  double * t_log; //!< [B][n_ticks]
+  double * x_log; //!< [B][n_ticks][N]    state handed to the solve of this tick
+  double * u0_log; //!< [B][n_ticks][MM]  first input of the solution (clamped in the plant pattern)
+  int * iter_log; //!< [B][n_ticks]
+  int * status_log; //!< [B][n_ticks]
+  int * m0_log; //!< [B][n_ticks]         input dimension of the first timestep
+};
+
+/** Does the problem offer the plant step stateEq(t, x, u, dt) (TestDDPCartPole.cpp:63-98 has it)? */
+template<class Problem, class = void>
+struct HasPlantStep : std::false_type
+{
+};
+template<class Problem>
+struct HasPlantStep<Problem,
+                    std::void_t<decltype(std::declval<const Problem &>().stateEq(
+                        0.0,
+                        std::declval<const typename Problem::StateDimVector &>(),
+                        std::declval<const typename Problem::InputDimVector &>(),
+                        0.0))>> : std::true_type
+{
+};
+
+template<class Problem>
+__global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Problem problem,
+                                                                     const DeviceBuffers buf,
+                                                                     const MpcAdvanceArgs args)
+{
+  constexpr int N = Problem::kStateDim;
+  constexpr int M = Problem::kInputDimMax;
+  constexpr int MM = (M > 0) ? M : 1;
+  constexpr size_t LW = kLanesPerBlock;
+  const int b = blockIdx.x * kLanesPerBlock + threadIdx.x;
+  if(b >= buf.B)
+  {
+    return;
+  }
+  const size_t tile = static_cast<size_t>(b) / LW, lane = static_cast<size_t>(b) % LW;
+  const int T = buf.T;
+  const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;
+  const int sel = buf.sel[b];
+  const double * Xs = buf.X + ((tile * 2 + sel) * rows_x) * LW + lane; // control_data_.x_list, row r at Xs[r * 64]
+  const double * Us = buf.U + ((tile * 2 + sel) * rows_u) * LW + lane; // control_data_.u_list
+  double * U0 = buf.U + ((tile * 2 + 0) * rows_u) * LW + lane; // initial_u_list of the next solve
+  double * x0 = args.x0 + (tile * N) * LW + lane;
+  const double t = args.t0[b];
+  const int m0 = buf.input_dim[(tile * T + 0) * LW + lane];
+  const size_t log_at = static_cast<size_t>(b) * args.n_ticks + args.tick;
+
+  typename Problem::StateDimVector x;
+  typename Problem::InputDimVector u0;
+  u0.resize(m0);
+  for(int j = 0; j < N; j++)
+  {
+    x[j] = Xs[static_cast<size_t>(j) * LW];
+  }
+  for(int a = 0; a < MM; a++)
+  {
+    u0[a] = (a < m0) ? Us[static_cast<size_t>(a) * LW] : 0.0;
+  }
+  if(!args.shift_warm_start && args.clamp_u0)
+  {
+    for(int a = 0; a < MM; a++)
+    {
+      if(a < m0)
+      {
+        u0[a] = fmin(fmax(u0[a], buf.lim_lo[a]), buf.lim_hi[a]); // cwiseMax(lower).cwiseMin(upper), :394
+      }
+    }
+  }
+  if(args.t_log)
+  {
+    args.t_log[log_at] = t;
+  }
+  if(args.x_log)
+  {
+    for(int j = 0; j < N; j++)
+    {
+      args.x_log[log_at * N + j] = x[j];
+    }
+  }
+  if(args.u0_log)
+  {
+    for(int a = 0; a < MM; a++)
+    {
+      args.u0_log[log_at * MM + a] = u0[a];
+    }
+  }
+  if(args.iter_log)
+  {
+    args.iter_log[log_at] = buf.iters[b];
+  }
+  if(args.status_log)
+  {
+    args.status_log[log_at] = buf.status[b];
+  }
+  if(args.m0_log)
+  {
+    args.m0_log[log_at] = m0;
+  }
+
+  double t_next = t;
+  if(args.shift_warm_start)
+  {
+    for(int j = 0; j < N; j++)
+    {
+      x0[static_cast<size_t>(j) * LW] = Xs[static_cast<size_t>(N + j) * LW]; // x_list[1]
+    }
+    // erase(begin()); push_back(back()) — or a zero vector when the terminal input dimension differs.  When sel == 0
+    // source and destination are the same column: row i + 1 is read before row i is written, ascending i.
+    for(int i = 0; i + 1 < T; i++)
+    {
+      for(int a = 0; a < MM; a++)
+      {
+        U0[(static_cast<size_t>(i) * MM + a) * LW] = Us[(static_cast<size_t>(i + 1) * MM + a) * LW];
+      }
+    }
+    int last_m = MM, term_m = MM;
+    if constexpr(Problem::kDynamicInput)
+    {
+      last_m = buf.input_dim[(tile * T + (T - 1)) * LW + lane];
+      term_m = problem.inputDim(t + T * problem.dt());
+    }
+    for(int a = 0; a < MM; a++)
+    {
+      const double keep = Us[(static_cast<size_t>(T - 1) * MM + a) * LW];
+      U0[(static_cast<size_t>(T - 1) * MM + a) * LW] = (last_m == term_m) ? keep : 0.0;
+    }
+    t_next = t + problem.dt();
+  }
+  else
+  {
+    if constexpr(HasPlantStep<Problem>::value)
+    {
+      for(int s = 0; s < args.sim_substeps; s++)
+      {
+        x = problem.stateEq(t_next, x, u0, args.sim_dt);
+        t_next += args.sim_dt;
+      }
+    }
+    for(int j = 0; j < N; j++)
+    {
+      x0[static_cast<size_t>(j) * LW] = x[j];
+    }
+    if(sel != 0)
+    {
+      for(size_t r = 0; r < rows_u; r++)
+      {
+        U0[r * LW] = Us[r * LW];
+      }
+    }
+  }
+  args.t0[b] = t_next;
+}
+} // namespace hip
+} // namespace nmpc_amd

@@ -184,6 +184,49 @@ extern "C"
                                 double * total_ms_sum,
                                 double * kernel_ms_sum);
 
+  /** Options of the device-resident receding-horizon loop nmpc_hip_ddp_mpc_run. */
+  typedef struct nmpc_hip_ddp_mpc_options
+  {
+    int n_ticks; /**< number of solve -> advance rounds */
+    /** 1: "shift" caller pattern (TestDDPBipedal.cpp:243-268, TestDDPVerticalMotion.cpp:290-326,
+        TestDDPCentroidalMotion.cpp:307-347): next x = x_list[1], u_list shifted by one with the last entry repeated
+        (zeros when the input dimension changes at the end of the horizon), t += dt.
+        0: "plant" caller pattern (TestDDPCartPole.cpp:323-346,388-403): u_list[0] (clamped to the input limits if
+        clamp_u0) drives sim_substeps steps of the problem's stateEq(t, x, u, sim_dt), u_list is reused unshifted. */
+    int shift_warm_start;
+    /** > 0: config().max_iter for every solve after the first one (capped at the handle's config().max_iter, which
+        sized the trace buffers) */
+    int max_iter_after_first;
+    int sim_substeps;
+    double sim_dt;
+    int clamp_u0;
+  } nmpc_hip_ddp_mpc_options;
+
+  /** shift pattern, one tick, no max_iter change. */
+  int nmpc_hip_ddp_mpc_default_options(nmpc_hip_ddp_mpc_options * opt);
+
+  /** The reference's receding-horizon caller loops, batched and device-resident: n_ticks times { solve; log; advance
+      (t, x, u_list) on the device } without a host round trip in between.  Inputs as nmpc_hip_ddp_solve (HOST
+      pointers).  Every log pointer is a HOST array or NULL:
+        t_log[B][n_ticks], x_log[B][n_ticks][n] (state handed to the solve of that tick), u0_log[B][n_ticks][MM]
+        (first input of the solution; clamped in the plant pattern), iter_log / status_log / m0_log[B][n_ticks]
+        (iterations, status, input dimension of the first timestep), x_final[B][n], t_final[B] (after the last advance).
+      Afterwards the handle holds the results of the LAST solve (nmpc_hip_ddp_get).  config().max_iter is restored.
+      The plant pattern needs a problem type with the 4-argument stateEq (else NMPC_HIP_ERR_INVALID_ARGUMENT). */
+  int nmpc_hip_ddp_mpc_run(nmpc_hip_ddp_handle h,
+                           const double * t0,
+                           const double * x0,
+                           const double * u_init,
+                           const nmpc_hip_ddp_mpc_options * opt,
+                           double * t_log,
+                           double * x_log,
+                           double * u0_log,
+                           int * iter_log,
+                           int * status_log,
+                           int * m0_log,
+                           double * x_final,
+                           double * t_final);
+
   /** Name of the gfx950 kernel the next solve of this handle launches (as rocprofv3 --kernel-trace lists it, without
       template arguments): "ddp_solve_tpi2w_kernel" (master + helper wavefront per 64 instances, LDS-staged; chosen
       when the model's LDS records fit) or "ddp_solve_tpi_kernel" (one wavefront per 64 instances; also forced by the

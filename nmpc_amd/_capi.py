@@ -63,6 +63,19 @@ class Config(C.Structure):
     ]
 
 
+class MpcOptions(C.Structure):
+    """nmpc_hip_ddp_mpc_options (include/nmpc_hip_ddp.h)."""
+
+    _fields_ = [
+        ("n_ticks", C.c_int),
+        ("shift_warm_start", C.c_int),
+        ("max_iter_after_first", C.c_int),
+        ("sim_substeps", C.c_int),
+        ("sim_dt", C.c_double),
+        ("clamp_u0", C.c_int),
+    ]
+
+
 _lib = None
 
 # every symbol include/nmpc_hip_ddp.h declares
@@ -73,7 +86,8 @@ EXPORTS = (
     "nmpc_hip_ddp_set_model_params", "nmpc_hip_ddp_input_dims", "nmpc_hip_ddp_set_input_limits", "nmpc_hip_ddp_solve",
     "nmpc_hip_ddp_solve_device", "nmpc_hip_ddp_synchronize", "nmpc_hip_ddp_get", "nmpc_hip_ddp_get_device",
     "nmpc_hip_ddp_field_bytes", "nmpc_hip_ddp_last_solve_ms", "nmpc_hip_ddp_timing_stats",
-    "nmpc_hip_ddp_kernel_name", "nmpc_hip_ddp_last_error",
+    "nmpc_hip_ddp_kernel_name", "nmpc_hip_ddp_mpc_default_options", "nmpc_hip_ddp_mpc_run",
+    "nmpc_hip_ddp_last_error",
 )
 
 
@@ -115,6 +129,8 @@ def load():
     L.nmpc_hip_ddp_field_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
     L.nmpc_hip_ddp_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.nmpc_hip_ddp_kernel_name.argtypes = [vp, C.POINTER(C.c_char_p)]
+    L.nmpc_hip_ddp_mpc_default_options.argtypes = [C.POINTER(MpcOptions)]
+    L.nmpc_hip_ddp_mpc_run.argtypes = [vp, dp, dp, dp, C.POINTER(MpcOptions), dp, dp, dp, ip, ip, ip, dp, dp]
     L.nmpc_hip_ddp_timing_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), dp, dp]
     L.nmpc_hip_ddp_last_error.argtypes = []
     L.nmpc_hip_ddp_last_error.restype = C.c_char_p

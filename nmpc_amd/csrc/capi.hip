@@ -3,6 +3,7 @@
 // the HIP runtime or a gfx950 device is missing every entry point that needs the GPU fails loudly.
 #include <nmpc_hip_ddp.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -374,6 +375,53 @@ int checkConfig(const nmpc_hip_ddp_solver * s, const nmpc_hip_ddp_config * c)
 }
 } // namespace
 
+namespace
+{
+/** One solve on stream st, bracketed by the HIP-event triple of the timing ring.  ingest: convert the reference-layout
+    device arrays into the solver's tile-major input buffers first (false: they are already in place, as after
+    mpc_advance_kernel). */
+int launchRecorded(nmpc_hip_ddp_solver * s,
+                   hipStream_t st,
+                   const double * d_t0,
+                   const double * d_x0,
+                   const double * d_u_init,
+                   bool ingest)
+{
+  s->last_stream = st;
+  const int slot = static_cast<int>(s->n_solves % nmpc_hip_ddp_solver::kEvPool);
+  {
+    int hrc = harvestSlot(s, slot); // only blocks when 128 solves are in flight
+    if(hrc != NMPC_HIP_OK)
+    {
+      return hrc;
+    }
+  }
+  NMPC_HIP_TRY(hipEventRecord(s->ev_begin[slot], st));
+  if(ingest)
+  {
+    // reference layouts -> instance-minor device layout
+    if(d_t0)
+    {
+      NMPC_HIP_TRY(hipMemcpyAsync(s->d_t0, d_t0, sizeof(double) * s->B, hipMemcpyDeviceToDevice, st));
+    }
+    else
+    {
+      NMPC_HIP_TRY(hipMemsetAsync(s->d_t0, 0, sizeof(double) * s->Bp, st));
+    }
+    NMPC_HIP_TRY(toTile<double>(d_x0, s->d_x0, s->B, s->N, s->Bp, 1, 0, st));
+    NMPC_HIP_TRY(toTile<double>(d_u_init, s->d_U, s->B, s->T * s->MM, s->Bp, 2, 0, st));
+  }
+  NMPC_HIP_TRY(hipEventRecord(s->ev_kernel[slot], st));
+  const DeviceBuffers buf = makeBuffers(s);
+  NMPC_HIP_TRY(s->ops->launch_solve(s->params.data(), s->cfg, buf, st));
+  NMPC_HIP_TRY(hipEventRecord(s->ev_end[slot], st));
+  s->ev_pending[slot] = true;
+  s->n_solves++;
+  s->solved = true;
+  return NMPC_HIP_OK;
+}
+} // namespace
+
 extern "C"
 {
   int nmpc_hip_ddp_register_model(const ModelOps * ops)
@@ -722,34 +770,151 @@ extern "C"
     }
     NMPC_HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
-    s->last_stream = st;
-    const int slot = static_cast<int>(s->n_solves % nmpc_hip_ddp_solver::kEvPool);
+    return launchRecorded(s, st, d_t0, d_x0, d_u_init, true);
+  }
+
+  int nmpc_hip_ddp_mpc_default_options(nmpc_hip_ddp_mpc_options * opt)
+  {
+    if(!opt)
     {
-      int hrc = harvestSlot(s, slot); // only blocks when 128 solves are in flight
-      if(hrc != NMPC_HIP_OK)
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL options");
+    }
+    opt->n_ticks = 1;
+    opt->shift_warm_start = 1;
+    opt->max_iter_after_first = 0;
+    opt->sim_substeps = 0;
+    opt->sim_dt = 0.0;
+    opt->clamp_u0 = 1;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_mpc_run(nmpc_hip_ddp_handle s,
+                           const double * t0,
+                           const double * x0,
+                           const double * u_init,
+                           const nmpc_hip_ddp_mpc_options * opt,
+                           double * t_log,
+                           double * x_log,
+                           double * u0_log,
+                           int * iter_log,
+                           int * status_log,
+                           int * m0_log,
+                           double * x_final,
+                           double * t_final)
+  {
+    if(!s || !x0 || !u_init || !opt)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle, x0, u_init or options");
+    }
+    if(opt->n_ticks < 1)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "n_ticks should be >= 1");
+    }
+    if(!opt->shift_warm_start)
+    {
+      if(!s->ops->has_plant_step)
       {
-        return hrc;
+        return fail(NMPC_HIP_ERR_INVALID_ARGUMENT,
+                    "the plant pattern needs a problem type with stateEq(t, x, u, dt) (TestDDPCartPole.cpp:63-98)");
+      }
+      if(opt->sim_substeps < 1 || !(opt->sim_dt > 0))
+      {
+        return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "the plant pattern needs sim_substeps >= 1 and sim_dt > 0");
+      }
+      if(opt->clamp_u0 && !s->has_limits)
+      {
+        return fail(NMPC_HIP_ERR_RUNTIME, "clamp_u0 is set but no input limits were given");
       }
     }
-    NMPC_HIP_TRY(hipEventRecord(s->ev_begin[slot], st));
-    // ingest: reference layouts -> instance-minor device layout
-    if(d_t0)
+    if(s->cfg.with_input_constraint && !s->has_limits)
     {
-      NMPC_HIP_TRY(hipMemcpyAsync(s->d_t0, d_t0, sizeof(double) * s->B, hipMemcpyDeviceToDevice, st));
+      return fail(NMPC_HIP_ERR_RUNTIME, "with_input_constraint is set but no input limits were given "
+                                        "(setInputLimitsFunc, DDPSolver.h:282-285)");
     }
-    else
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    const size_t B = static_cast<size_t>(s->B), nt = static_cast<size_t>(opt->n_ticks);
+    const size_t nx = B * s->N, nu = B * s->T * s->MM;
+    // staging: inputs in the reference layout, then the logs
+    const size_t in_bytes = (nx + nu + B) * sizeof(double);
+    const size_t log_d = B * nt * (1 + s->N + s->MM); // doubles: t, x, u0
+    const size_t log_i = B * nt * 3; // ints: iterations, status, m0
+    int rc = ensureStage(&s->d_stage_in, &s->stage_in_bytes, in_bytes);
+    if(rc != NMPC_HIP_OK)
     {
-      NMPC_HIP_TRY(hipMemsetAsync(s->d_t0, 0, sizeof(double) * s->Bp, st));
+      return rc;
     }
-    NMPC_HIP_TRY(toTile<double>(d_x0, s->d_x0, s->B, s->N, s->Bp, 1, 0, st));
-    NMPC_HIP_TRY(toTile<double>(d_u_init, s->d_U, s->B, s->T * s->MM, s->Bp, 2, 0, st));
-    NMPC_HIP_TRY(hipEventRecord(s->ev_kernel[slot], st));
-    const DeviceBuffers buf = makeBuffers(s);
-    NMPC_HIP_TRY(s->ops->launch_solve(s->params.data(), s->cfg, buf, st));
-    NMPC_HIP_TRY(hipEventRecord(s->ev_end[slot], st));
-    s->ev_pending[slot] = true;
-    s->n_solves++;
-    s->solved = true;
+    rc = ensureStage(&s->d_stage_out, &s->stage_out_bytes,
+                     std::max(log_d * sizeof(double) + log_i * sizeof(int), nx * sizeof(double)));
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    double * dx = static_cast<double *>(s->d_stage_in);
+    double * du = dx + nx;
+    double * dt = du + nu;
+    NMPC_HIP_TRY(hipMemcpyAsync(dx, x0, nx * sizeof(double), hipMemcpyHostToDevice, st));
+    NMPC_HIP_TRY(hipMemcpyAsync(du, u_init, nu * sizeof(double), hipMemcpyHostToDevice, st));
+    if(t0)
+    {
+      NMPC_HIP_TRY(hipMemcpyAsync(dt, t0, B * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    nmpc_amd::hip::MpcAdvanceArgs args;
+    args.n_ticks = opt->n_ticks;
+    args.shift_warm_start = opt->shift_warm_start;
+    args.sim_substeps = opt->sim_substeps;
+    args.sim_dt = opt->sim_dt;
+    args.clamp_u0 = opt->clamp_u0;
+    args.t0 = s->d_t0;
+    args.x0 = s->d_x0;
+    args.t_log = static_cast<double *>(s->d_stage_out);
+    args.x_log = args.t_log + B * nt;
+    args.u0_log = args.x_log + B * nt * s->N;
+    args.iter_log = reinterpret_cast<int *>(args.u0_log + B * nt * s->MM);
+    args.status_log = args.iter_log + B * nt;
+    args.m0_log = args.status_log + B * nt;
+    const int max_iter_saved = s->cfg.max_iter;
+    for(int tick = 0; tick < opt->n_ticks && rc == NMPC_HIP_OK; tick++)
+    {
+      rc = launchRecorded(s, st, t0 ? dt : nullptr, dx, du, tick == 0);
+      if(rc != NMPC_HIP_OK)
+      {
+        break;
+      }
+      if(tick == 0 && opt->max_iter_after_first > 0)
+      {
+        s->cfg.max_iter = std::min(opt->max_iter_after_first, max_iter_saved); // the trace buffer was sized for it
+      }
+      args.tick = tick;
+      const DeviceBuffers buf = makeBuffers(s);
+      hipError_t e = s->ops->launch_mpc_advance(s->params.data(), buf, args, st);
+      if(e != hipSuccess)
+      {
+        rc = fail(NMPC_HIP_ERR_HIP, std::string("mpc_advance_kernel: ") + hipGetErrorString(e));
+      }
+    }
+    s->cfg.max_iter = max_iter_saved;
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    auto out = [&](void * host, const void * dev, size_t bytes) -> hipError_t {
+      return host ? hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
+    };
+    NMPC_HIP_TRY(out(t_log, args.t_log, B * nt * sizeof(double)));
+    NMPC_HIP_TRY(out(x_log, args.x_log, B * nt * s->N * sizeof(double)));
+    NMPC_HIP_TRY(out(u0_log, args.u0_log, B * nt * s->MM * sizeof(double)));
+    NMPC_HIP_TRY(out(iter_log, args.iter_log, B * nt * sizeof(int)));
+    NMPC_HIP_TRY(out(status_log, args.status_log, B * nt * sizeof(int)));
+    NMPC_HIP_TRY(out(m0_log, args.m0_log, B * nt * sizeof(int)));
+    NMPC_HIP_TRY(out(t_final, s->d_t0, B * sizeof(double)));
+    if(x_final)
+    {
+      // the logs have been queued for copy-out on the same stream: the staging buffer can be reused behind them
+      NMPC_HIP_TRY(toMajor<double>(s->d_x0, dx, nullptr, s->B, s->N, s->Bp, 1, st));
+      NMPC_HIP_TRY(hipMemcpyAsync(x_final, dx, nx * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    NMPC_HIP_TRY(hipStreamSynchronize(st));
     return NMPC_HIP_OK;
   }
 

@@ -80,6 +80,20 @@ class TraceData:
 
 
 @dataclass
+class MpcLog:
+    """Per-tick log of DDPSolverBatch.mpcRun (the columns the reference's MPC tests dump, e.g.
+    TestDDPBipedal.cpp:251-262): state handed to the solve of the tick, first input of its solution, iterations, status."""
+    t: np.ndarray  # (B, n_ticks)
+    x: np.ndarray  # (B, n_ticks, n)
+    u0: np.ndarray  # (B, n_ticks, MM)
+    iters: np.ndarray  # (B, n_ticks)
+    status: np.ndarray  # (B, n_ticks)
+    m0: np.ndarray  # (B, n_ticks) input dimension of the first timestep
+    x_final: np.ndarray  # (B, n) state after the last advance
+    t_final: np.ndarray  # (B,)
+
+
+@dataclass
 class ComputationDuration:
     """DDPSolver::ComputationDuration (DDPSolver.h:219-247) for the whole batch [msec]: `solve` is the HIP-event
     time of ingest + solve kernel, `opt` the solve kernel alone, `setup` their difference.  The per-phase
@@ -222,6 +236,38 @@ class DDPSolverBatch:
             if n_fail:
                 print(f"[DDP] Failure due to large lambda in {n_fail} of {B} instances.")
         return status == 1
+
+    # ---- the reference's receding-horizon caller loops, device-resident   ----
+    def mpcRun(self, current_t, current_x, initial_u_list, n_ticks: int, shift_warm_start: bool = True,
+               max_iter_after_first: int = 0, sim_substeps: int = 0, sim_dt: float = 0.0,
+               clamp_u0: bool = True) -> "MpcLog":
+        """n_ticks x { solve; advance (t, x, u_list) on the device }.  shift_warm_start=True is the loop of
+        TestDDPBipedal.cpp:243-268 / TestDDPVerticalMotion.cpp:290-326 / TestDDPCentroidalMotion.cpp:307-347,
+        False the plant loop of TestDDPCartPole.cpp:323-346,388-403 (see nmpc_hip_ddp_mpc_options)."""
+        B = self.batch_size
+        t0 = np.broadcast_to(np.asarray(current_t, dtype=np.float64), (B,)).copy()
+        x0 = np.ascontiguousarray(np.asarray(current_x, dtype=np.float64).reshape(B, self.n))
+        self._push_state()
+        u = self._pack_u(initial_u_list, t0)
+        opt = _capi.MpcOptions()
+        _capi.check(self._L.nmpc_hip_ddp_mpc_default_options(C.byref(opt)))
+        opt.n_ticks = int(n_ticks)
+        opt.shift_warm_start = 1 if shift_warm_start else 0
+        opt.max_iter_after_first = int(max_iter_after_first)
+        opt.sim_substeps = int(sim_substeps)
+        opt.sim_dt = float(sim_dt)
+        opt.clamp_u0 = 1 if clamp_u0 else 0
+        log = MpcLog(t=np.zeros((B, n_ticks)), x=np.zeros((B, n_ticks, self.n)), u0=np.zeros((B, n_ticks, self.mm)),
+                     iters=np.zeros((B, n_ticks), np.int32), status=np.zeros((B, n_ticks), np.int32),
+                     m0=np.zeros((B, n_ticks), np.int32), x_final=np.zeros((B, self.n)), t_final=np.zeros(B))
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        _capi.check(self._L.nmpc_hip_ddp_mpc_run(
+            self._h, t0.ctypes.data_as(dp), x0.ctypes.data_as(dp), u.ctypes.data_as(dp), C.byref(opt),
+            log.t.ctypes.data_as(dp), log.x.ctypes.data_as(dp), log.u0.ctypes.data_as(dp), log.iters.ctypes.data_as(ip),
+            log.status.ctypes.data_as(ip), log.m0.ctypes.data_as(ip), log.x_final.ctypes.data_as(dp),
+            log.t_final.ctypes.data_as(dp)))
+        self._cache = {}
+        return log
 
     def solveDevice(self, d_t0: Optional[int], d_x0: int, d_u_init: int, stream: Optional[int] = None) -> None:
         """Asynchronous solve from DEVICE pointers (integers, e.g. torch.Tensor.data_ptr()) in the reference

@@ -59,6 +59,7 @@ struct DeviceBuffers
   int * qp_ret; //!< [tile][T][64]  (constrained solves only)
   unsigned * qp_free; //!< [tile][T][64]
   int * input_dim; //!< [tile][T][64]
+  double * wpi_ws; //!< wave-per-instance kernel only (ddp_kernels_wpi.hpp): [B][WaveSolver::workspaceDoubles(T)]
   double lim_lo[kMaxInputDim]; //!< input lower limits (constant in time)
   double lim_hi[kMaxInputDim]; //!< input upper limits
 };

@@ -1,0 +1,1064 @@
+// gfx950 device code of the batched DDP solver, LANE MAPPING "WPI": ONE WAVEFRONT PER PROBLEM INSTANCE, for the shapes
+// whose blocks fill a matrix-core tile (9 <= n <= 16, m <= 16; BASELINE.json's quadrotor n 12 m 4 and manipulator
+// n 14 m 7).  The lane-per-instance kernels (ddp_kernels.hpp) keep a whole instance in one lane's registers; from n ~ 9
+// on that state (Vxx, Fx, Qxx ... ~ 6 n^2 doubles) spills, and a batch of 8192 instances occupies 128 of 1024 SIMDs.
+// Here the 64 lanes of a wavefront work on ONE instance and the batch fills the chip:
+//
+//   linearisation   lane = TIMESTEP: the problem functor's calcStateEqDeriv / calcRunningCostDeriv are scalar code per
+//                   (x_i, u_i); 64 timesteps of the same instance are evaluated at once, the derivative blocks go to the
+//                   instance's HBM workspace (DDPSolver.hpp:157-185 materialises them the same way)
+//   backward pass   lane = matrix entry: the n x n / m x n / m x m triple products of DDPSolver.hpp:386-441,522-527 run
+//                   on the matrix cores (v_mfma_f64_16x16x4_f64 on 16 x 16 tiles staged in LDS with leading dimension
+//                   17); the m x m factorisation and the vector recursions are lane-per-column
+//   line search     lane = STEP SIZE: all alpha_list entries (DDPSolver.h:50-60, 11 by default) roll out at once, each
+//                   lane its own candidate trajectory; the first accepted one in list order is taken, which is exactly
+//                   what the sequential loop of DDPSolver.hpp:242-265 selects
+//
+// The control flow of solve() / procOnce (DDPSolver.hpp:26-340) is wave-uniform: there is no divergence between
+// instances at all.  Arithmetic order: an MFMA accumulates k ascending with fused multiply-adds starting from the C
+// operand (measured: bit-identical to the scalar fma chain, scripts/ubench_mfma_f64.hip), i.e. the same order as the
+// lane-per-instance kernels; products are formed from zero and then added to the L-blocks, as the reference's
+// temporaries are.
+//
+// Scope: unconstrained solves of problems with a static input dimension.  Everything else (BoxQP, inputDim(t)) stays on
+// the lane-per-instance kernels.
+#pragma once
+
+#include <nmpc_amd/hip/ddp_kernels.hpp>
+
+namespace nmpc_amd
+{
+namespace hip
+{
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template<class Problem>
+struct WaveSolver
+{
+  static constexpr int N = Problem::kStateDim;
+  static constexpr int M = Problem::kInputDimMax;
+  static constexpr int MM = (M > 0) ? M : 1;
+  static_assert(N <= 16 && MM <= 16, "one 16 x 16 tile per block");
+  static_assert(!Problem::kDynamicInput, "static input dimension only");
+  using Lane = InstanceSolver<Problem, false>; // for the shared scalar helpers (ldltInPlace, ...)
+  using StateDimVector = typename Problem::StateDimVector;
+  using InputDimVector = typename Problem::InputDimVector;
+  using StateStateDimMatrix = typename Problem::StateStateDimMatrix;
+  using InputInputDimMatrix = typename Problem::InputInputDimMatrix;
+  using StateInputDimMatrix = typename Problem::StateInputDimMatrix;
+
+  // ---- LDS: 16 x 16 tiles, column-major with leading dimension 17 (conflict-free row AND column access) ----
+  static constexpr int LD = 17;
+  static constexpr int kTile = 16 * LD;
+  enum TileId
+  {
+    tVxx = 0,
+    tFx,
+    tFu,
+    tLxx,
+    tLxu, // N x M
+    tLuu,
+    tP, // products in flight: Fx^T Vxx
+    tP2, // Fu^T Vxx
+    tQxx,
+    tQux, // M x N (unregularised)
+    tQuxR, // M x N (regularised, reg_type 2)
+    tQuu, // M x M (unregularised)
+    tQuuF, // M x M (regularised)
+    tK, // M x N
+    tKtQuu, // N x M
+    tVnew,
+    kNumTiles
+  };
+  // vectors (16 doubles each) behind the tiles
+  enum VecId
+  {
+    vVx = 0,
+    vLx,
+    vLu,
+    vU,
+    vQx,
+    vQu,
+    vKff,
+    kNumVecs
+  };
+  static constexpr int kStageAt = kNumTiles * kTile + kNumVecs * 16; //!< line search: two slots for the nominal record
+  static constexpr int kLdsDoubles = kStageAt + 2 * 64 * ((2 * MM + MM * N + N + 63) / 64);
+  static constexpr size_t kLdsBytes = static_cast<size_t>(kLdsDoubles) * sizeof(double);
+
+  // ---- per-instance HBM workspace (doubles) ----
+  // Derivative block of one timestep: every matrix is stored column-major with its rows padded to 16 and its size
+  // padded to a multiple of 64 doubles (a "chunk"): lane l of a wavefront reads double 64 q + l of the block — one
+  // 512-byte segment per chunk — and knows at compile time which LDS tile chunk q belongs to.
+  NMPC_HD static constexpr int chunks(int cols)
+  {
+    return (16 * cols + 63) / 64;
+  }
+  static constexpr int cFx = 0; // chunk index where each matrix starts
+  static constexpr int cFu = cFx + chunks(N);
+  static constexpr int cLxx = cFu + chunks(MM);
+  static constexpr int cLxu = cLxx + chunks(N);
+  static constexpr int cLuu = cLxu + chunks(MM);
+  static constexpr int cVec = cLuu + chunks(MM); // one chunk: Lx at [0, 16), Lu at [16, 32), u_i at [32, 48)
+  static constexpr int kDerivChunks = cVec + 1;
+  static constexpr int kDeriv = 64 * kDerivChunks;
+  static constexpr int kGain = MM + MM * N; // k_i, K_i
+  NMPC_HD static size_t trajDoubles(int T)
+  {
+    return static_cast<size_t>(T + 1) * N + static_cast<size_t>(T) * MM + static_cast<size_t>(T + 1);
+  }
+  NMPC_HD static size_t workspaceDoubles(int T)
+  {
+    return trajDoubles(T) * (1 + NMPC_HIP_MAX_ALPHA) + static_cast<size_t>(T) * (kDeriv + kGain);
+  }
+
+  const Problem & problem;
+  const nmpc_hip_ddp_config & cfg;
+  const DeviceBuffers & buf;
+  const int b;
+  const int T;
+  const int lane;
+  double * lds;
+  double * ws; //!< this instance's workspace
+  double current_t;
+
+  NMPC_D WaveSolver(const Problem & p, const nmpc_hip_ddp_config & c, const DeviceBuffers & bf, int instance, double * lds_base)
+  : problem(p), cfg(c), buf(bf), b(instance), T(bf.T), lane(static_cast<int>(threadIdx.x)), lds(lds_base)
+  {
+    ws = bf.wpi_ws + static_cast<size_t>(instance) * workspaceDoubles(bf.T);
+  }
+
+  // workspace views
+  NMPC_D double * trajX(int which) const // which = 0: control_data_, 1 + j: candidate of alpha_list[j]
+  {
+    return ws + static_cast<size_t>(which) * trajDoubles(T);
+  }
+  NMPC_D double * trajU(int which) const
+  {
+    return trajX(which) + static_cast<size_t>(T + 1) * N;
+  }
+  NMPC_D double * trajC(int which) const
+  {
+    return trajU(which) + static_cast<size_t>(T) * MM;
+  }
+  NMPC_D double * derivBlock(int i) const
+  {
+    return ws + trajDoubles(T) * (1 + NMPC_HIP_MAX_ALPHA) + static_cast<size_t>(i) * kDeriv;
+  }
+  NMPC_D double * gainBlock(int i) const
+  {
+    return ws + trajDoubles(T) * (1 + NMPC_HIP_MAX_ALPHA) + static_cast<size_t>(T) * kDeriv + static_cast<size_t>(i) * kGain;
+  }
+  NMPC_D double * tile(int t) const
+  {
+    return lds + t * kTile;
+  }
+  NMPC_D double * vec(int v) const
+  {
+    return lds + kNumTiles * kTile + v * 16;
+  }
+  /** Phase boundary: what this wave wrote to HBM (derivative blocks, gains, candidates) is read back by other lanes of
+      the same wave in the next phase — wait for everything in flight (one wavefront per workgroup: no one to wait for). */
+  NMPC_D static void sync()
+  {
+    __syncthreads();
+  }
+  /** Inside a phase only LDS is exchanged between lanes.  The LDS executes one wave's instructions in order, so a
+      compiler fence is all that is needed — and prefetches / stores to HBM stay in flight. */
+  NMPC_D static void fence()
+  {
+    asm volatile("" ::: "memory");
+  }
+
+  // ===================================================================================================
+  // tiles
+  // ===================================================================================================
+  /** One chunk of a derivative block (register value v = double 64 q + lane of the matrix) -> its LDS tile. */
+  NMPC_D void chunkToTile(int t, int q_in_matrix, int rows, int cols, double v) const
+  {
+    const int em = 64 * q_in_matrix + lane; // entry index in the 16-row padded column-major matrix
+    const int r = em & 15, c = em >> 4;
+    if(r < rows && c < cols) // the padding of the HBM block is never written: keep the tiles' padding zero
+    {
+      tile(t)[r + LD * c] = v;
+    }
+  }
+  NMPC_D void zeroAllLds() const
+  {
+    for(int e = lane; e < kLdsDoubles; e += 64)
+    {
+      lds[e] = 0;
+    }
+  }
+  /** acc = op(A) * Bm over k < kdim, MFMA D layout: acc[r] = D(i = lane / 16 + 4 r, j = lane % 16) */
+  template<bool kTransA>
+  NMPC_D v4d mma(int tA, int tB, int kdim) const
+  {
+    const double * A = tile(tA);
+    const double * Bm = tile(tB);
+    const int lj = lane & 15, lk = lane >> 4;
+    v4d acc = {0, 0, 0, 0};
+    for(int k0 = 0; k0 < kdim; k0 += 4)
+    {
+      const int k = k0 + lk;
+      const double a = kTransA ? A[k + LD * lj] : A[lj + LD * k];
+      const double bb = Bm[k + LD * lj];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+  /** tile t <- acc (+ tile tAdd entry-wise when tAdd >= 0: "L + product", addition commutes) */
+  NMPC_D void storeAcc(int t, v4d acc, int tAdd = -1) const
+  {
+    double * d = tile(t);
+    const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+      const int at = (lk + 4 * r) + LD * lj;
+      d[at] = (tAdd >= 0) ? tile(tAdd)[at] + acc[r] : acc[r];
+    }
+  }
+
+  // ===================================================================================================
+  // model evaluation
+  // ===================================================================================================
+  NMPC_D void loadState(const double * g, StateDimVector & x) const
+  {
+#pragma unroll
+    for(int j = 0; j < N; j++)
+    {
+      x[j] = g[j];
+    }
+  }
+  NMPC_D void loadInput(const double * g, InputDimVector & u) const
+  {
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      u[a] = g[a];
+    }
+  }
+
+  /** Initial rollout (DDPSolver.hpp:83-95): every lane computes the same trajectory, lane 0 stores it. */
+  NMPC_D double initialRollout() const
+  {
+    const size_t tl = static_cast<size_t>(b) / kLanesPerBlock, ln = static_cast<size_t>(b) % kLanesPerBlock;
+    StateDimVector x;
+    for(int j = 0; j < N; j++)
+    {
+      x[j] = buf.x0[(tl * N + j) * kLanesPerBlock + ln];
+    }
+    double * X = trajX(0);
+    double * U = trajU(0);
+    double * Cc = trajC(0);
+    const double * Uin = buf.U + (tl * 2 + 0) * (static_cast<size_t>(T) * MM) * kLanesPerBlock + ln;
+    double J = 0;
+    for(int i = 0; i < T; i++)
+    {
+      const double t = current_t + i * problem.dt();
+      InputDimVector u;
+      for(int a = 0; a < MM; a++)
+      {
+        u[a] = Uin[(static_cast<size_t>(i) * MM + a) * kLanesPerBlock];
+      }
+      const double c = problem.runningCost(t, x, u);
+      if(lane == 0)
+      {
+        for(int j = 0; j < N; j++)
+        {
+          X[i * N + j] = x[j];
+        }
+        for(int a = 0; a < MM; a++)
+        {
+          U[i * MM + a] = u[a];
+        }
+        Cc[i] = c;
+      }
+      J += c;
+      x = problem.stateEq(t, x, u);
+    }
+    const double cT = problem.terminalCost(current_t + T * problem.dt(), x);
+    if(lane == 0)
+    {
+      for(int j = 0; j < N; j++)
+      {
+        X[T * N + j] = x[j];
+      }
+      Cc[T] = cT;
+    }
+    return J + cT;
+  }
+
+  /** Step 1 of procOnce (DDPSolver.hpp:157-185): lane = timestep. */
+  NMPC_D void linearise() const
+  {
+    const double * X = trajX(0);
+    const double * U = trajU(0);
+    for(int i0 = 0; i0 < T; i0 += 64)
+    {
+      const int i = i0 + lane;
+      if(i < T)
+      {
+        const double t = current_t + i * problem.dt();
+        StateDimVector x;
+        InputDimVector u;
+        loadState(X + static_cast<size_t>(i) * N, x);
+        loadInput(U + static_cast<size_t>(i) * MM, u);
+        StateStateDimMatrix Fx, Lxx;
+        StateInputDimMatrix Fu, Lxu;
+        StateDimVector Lx;
+        InputDimVector Lu;
+        InputInputDimMatrix Luu;
+        problem.calcStateEqDeriv(t, x, u, Fx, Fu);
+        problem.calcRunningCostDeriv(t, x, u, Lx, Lu, Lxx, Luu, Lxu);
+        double * d = derivBlock(i);
+#pragma unroll
+        for(int c = 0; c < N; c++)
+        {
+#pragma unroll
+          for(int r = 0; r < N; r++)
+          {
+            d[64 * cFx + r + 16 * c] = Fx(r, c);
+            d[64 * cLxx + r + 16 * c] = Lxx(r, c);
+          }
+        }
+#pragma unroll
+        for(int c = 0; c < MM; c++)
+        {
+#pragma unroll
+          for(int r = 0; r < N; r++)
+          {
+            d[64 * cFu + r + 16 * c] = Fu(r, c);
+            d[64 * cLxu + r + 16 * c] = Lxu(r, c);
+          }
+#pragma unroll
+          for(int r = 0; r < MM; r++)
+          {
+            d[64 * cLuu + r + 16 * c] = Luu(r, c);
+          }
+        }
+#pragma unroll
+        for(int e = 0; e < N; e++)
+        {
+          d[64 * cVec + e] = Lx[e];
+        }
+#pragma unroll
+        for(int e = 0; e < MM; e++)
+        {
+          d[64 * cVec + 16 + e] = Lu[e];
+          d[64 * cVec + 32 + e] = u[e];
+        }
+      }
+    }
+  }
+
+  // ===================================================================================================
+  // backward pass    DDPSolver.hpp:342-534
+  // ===================================================================================================
+  struct BackwardResult
+  {
+    bool ok;
+    double dV0, dV1, k_rel_norm;
+  };
+
+  NMPC_D BackwardResult backwardPass(double lambda) const
+  {
+    BackwardResult res;
+    res.ok = true;
+    res.dV0 = 0;
+    res.dV1 = 0;
+    res.k_rel_norm = 0;
+    // terminal value function    :346-365
+    {
+      StateDimVector xT, vx;
+      StateStateDimMatrix vxx;
+      loadState(trajX(0) + static_cast<size_t>(T) * N, xT);
+      problem.calcTerminalCostDeriv(current_t + T * problem.dt(), xT, vx, vxx);
+      sync();
+      if(lane == 0)
+      {
+        for(int j = 0; j < N; j++)
+        {
+          vec(vVx)[j] = vx[j];
+        }
+        for(int c = 0; c < N; c++)
+        {
+          for(int r = 0; r < N; r++)
+          {
+            tile(tVxx)[r + LD * c] = vxx(r, c);
+          }
+        }
+      }
+      sync();
+    }
+    // the derivative block of timestep i - 1 is requested while timestep i is processed (registers: one double per
+    // lane and chunk)
+    double pf[kDerivChunks];
+    {
+      const double * d = derivBlock(T - 1);
+#pragma unroll
+      for(int q = 0; q < kDerivChunks; q++)
+      {
+        pf[q] = d[64 * q + lane];
+      }
+    }
+    for(int i = T - 1; i >= 0; i--)
+    {
+      // ---- stage this timestep's derivatives
+#pragma unroll
+      for(int q = 0; q < kDerivChunks; q++)
+      {
+        const double v = pf[q];
+        if(q < cFu)
+        {
+          chunkToTile(tFx, q - cFx, N, N, v);
+        }
+        else if(q < cLxx)
+        {
+          chunkToTile(tFu, q - cFu, N, MM, v);
+        }
+        else if(q < cLxu)
+        {
+          chunkToTile(tLxx, q - cLxx, N, N, v);
+        }
+        else if(q < cLuu)
+        {
+          chunkToTile(tLxu, q - cLxu, N, MM, v);
+        }
+        else if(q < cVec)
+        {
+          chunkToTile(tLuu, q - cLuu, MM, MM, v);
+        }
+        else
+        {
+          const int seg = lane >> 4, at = lane & 15; // vLx, vLu, vU are consecutive
+          if(seg < 3 && at < (seg == 0 ? N : MM))
+          {
+            vec(vLx + seg)[at] = v;
+          }
+        }
+      }
+      {
+        const double * d = derivBlock(i > 0 ? i - 1 : 0);
+#pragma unroll
+        for(int q = 0; q < kDerivChunks; q++)
+        {
+          pf[q] = d[64 * q + lane];
+        }
+      }
+      fence();
+
+      // ---- Q terms    :386-408    (products left to right, formed from zero, then added to the L block)
+      // independent products are issued together so that their MFMA chains overlap
+      {
+        const v4d p1 = mma<true>(tFx, tVxx, N); // Fx^T Vxx
+        const v4d p2 = mma<true>(tFu, tVxx, N); // Fu^T Vxx   (M x N)
+        storeAcc(tP, p1);
+        storeAcc(tP2, p2);
+      }
+      fence();
+      {
+        const v4d qxx = mma<false>(tP, tFx, N);
+        const v4d qux = mma<false>(tP2, tFx, N);
+        const v4d quu = mma<false>(tP2, tFu, N);
+        storeAcc(tQxx, qxx, tLxx); // Lxx + (Fx^T Vxx) Fx
+        // Qux = Lxu^T + (Fu^T Vxx) Fx : the transposed L block is added entry-wise
+        const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for(int r = 0; r < 4; r++)
+        {
+          const int a = lk + 4 * r; // row of Qux = input index, column lj = state index
+          tile(tQux)[a + LD * lj] = tile(tLxu)[lj + LD * a] + qux[r];
+        }
+        storeAcc(tQuu, quu, tLuu); // Luu + (Fu^T Vxx) Fu
+      }
+      fence();
+      // ---- regularisation    :421-441
+      if(cfg.reg_type == 2)
+      {
+        for(int e = lane; e < 256; e += 64) // scratch tile: Vxx_reg = Vxx + lambda I
+        {
+          const int r = e & 15, c = e >> 4;
+          tile(tVnew)[r + LD * c] = (r == c && r < N) ? tile(tVxx)[r + LD * c] + lambda : tile(tVxx)[r + LD * c];
+        }
+        fence();
+        storeAcc(tP2, mma<true>(tFu, tVnew, N));
+        fence();
+        {
+          const v4d acc = mma<false>(tP2, tFx, N);
+          const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+          for(int r = 0; r < 4; r++)
+          {
+            const int a = lk + 4 * r;
+            tile(tQuxR)[a + LD * lj] = tile(tLxu)[lj + LD * a] + acc[r];
+          }
+          storeAcc(tQuuF, mma<false>(tP2, tFu, N), tLuu);
+        }
+      }
+      else
+      {
+        for(int e = lane; e < 256; e += 64)
+        {
+          const int r = e & 15, c = e >> 4;
+          tile(tQuxR)[r + LD * c] = tile(tQux)[r + LD * c];
+          const double q = tile(tQuu)[r + LD * c];
+          tile(tQuuF)[r + LD * c] = (r == c && r < MM && cfg.reg_type == 1) ? q + lambda : q;
+        }
+      }
+      // ---- Qx, Qu    :386-388   (lane r / lane a: ascending-k chains as in the lane-per-instance kernels)
+      if(lane < N)
+      {
+        double s = 0;
+        for(int k = 0; k < N; k++)
+        {
+          s += tile(tFx)[k + LD * lane] * vec(vVx)[k];
+        }
+        vec(vQx)[lane] = vec(vLx)[lane] + s;
+      }
+      if(lane < MM)
+      {
+        double s = 0;
+        for(int k = 0; k < N; k++)
+        {
+          s += tile(tFu)[k + LD * lane] * vec(vVx)[k];
+        }
+        vec(vQu)[lane] = vec(vLu)[lane] + s;
+      }
+      fence();
+
+      // ---- gains    :500-517   (every lane factorises the same M x M matrix; lane c solves column c of Qux)
+      double fac[MM * MM], inv_d[MM], Quu[MM * MM], Qu[MM], kff[MM];
+#pragma unroll
+      for(int e = 0; e < MM * MM; e++)
+      {
+        fac[e] = tile(tQuuF)[(e % MM) + LD * (e / MM)];
+        Quu[e] = tile(tQuu)[(e % MM) + LD * (e / MM)];
+      }
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        Qu[a] = vec(vQu)[a];
+        kff[a] = 0;
+      }
+      if(!Lane::template ldltInPlace<MM>(fac, inv_d, M))
+      {
+        res.ok = false; // wave-uniform: every lane factorised the same matrix
+        return res;
+      }
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        kff[a] = Qu[a];
+      }
+      Lane::template ldltSolveInPlace<MM, 1>(fac, inv_d, M, kff);
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        kff[a] = -1 * kff[a];
+      }
+      double Kcol[MM], Quxcol[MM];
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        Kcol[a] = 0;
+        Quxcol[a] = 0;
+      }
+      if(lane < N)
+      {
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          Kcol[a] = tile(tQuxR)[a + LD * lane];
+          Quxcol[a] = tile(tQux)[a + LD * lane];
+        }
+        Lane::template ldltSolveInPlace<MM, 1>(fac, inv_d, M, Kcol);
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          Kcol[a] = -1 * Kcol[a];
+          tile(tK)[a + LD * lane] = Kcol[a];
+        }
+      }
+
+      // ---- cost-to-go    :522-526
+      {
+        double kQu = 0, kQuuk = 0, Quu_k[MM];
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          kQu += kff[a] * Qu[a];
+          double s = 0;
+#pragma unroll
+          for(int p = 0; p < MM; p++)
+          {
+            s += Quu[a + p * MM] * kff[p];
+          }
+          Quu_k[a] = s;
+        }
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          kQuuk += kff[a] * Quu_k[a];
+        }
+        res.dV0 += kQu;
+        res.dV1 += 0.5 * kQuuk;
+      }
+      if(lane < N)
+      {
+        // row `lane` of K^T Quu, then Vx[lane] = ((Qx + K^T Quu k) + K^T Qu) + Qux^T k
+        double s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          double s = 0;
+#pragma unroll
+          for(int p = 0; p < MM; p++)
+          {
+            s += Kcol[p] * Quu[p + a * MM];
+          }
+          tile(tKtQuu)[lane + LD * a] = s;
+          s1 += s * kff[a];
+          s2 += Kcol[a] * Qu[a];
+          s3 += Quxcol[a] * kff[a];
+        }
+        vec(vVx)[lane] = ((vec(vQx)[lane] + s1) + s2) + s3;
+      }
+      fence();
+      // Vxx = Qxx + K^T Quu K + K^T Qux + Qux^T K, each product a temporary formed from zero    :526
+      {
+        const v4d t1 = mma<false>(tKtQuu, tK, M);
+        const v4d t2 = mma<true>(tK, tQux, M);
+        const v4d t3 = mma<true>(tQux, tK, M);
+        const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for(int r = 0; r < 4; r++)
+        {
+          const int at = (lk + 4 * r) + LD * lj;
+          tile(tVnew)[at] = ((tile(tQxx)[at] + t1[r]) + t2[r]) + t3[r];
+        }
+      }
+      fence();
+      for(int e = lane; e < 256; e += 64) // Vxx = 0.5 (Vxx + Vxx^T)    :527
+      {
+        const int r = e & 15, c = e >> 4;
+        tile(tVxx)[r + LD * c] = 0.5 * (tile(tVnew)[r + LD * c] + tile(tVnew)[c + LD * r]);
+      }
+      // ---- save gains    :529-530, running max of |k_i| / (|u_i| + 1)    :217-221
+      {
+        double * g = gainBlock(i);
+        if(lane < MM)
+        {
+          g[lane] = kff[lane];
+        }
+        if(lane < N)
+        {
+#pragma unroll
+          for(int a = 0; a < MM; a++)
+          {
+            g[MM + a + MM * lane] = Kcol[a];
+          }
+        }
+        double kn = 0, un = 0;
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          kn += kff[a] * kff[a];
+          const double ua = vec(vU)[a];
+          un += ua * ua;
+        }
+        const double knorm = (M == 1) ? fabs(kff[0]) : sqrt(kn);
+        const double unorm = (M == 1) ? fabs(vec(vU)[0]) : sqrt(un);
+        res.k_rel_norm = fmax(res.k_rel_norm, knorm * recipFast(unorm + 1.0));
+      }
+      fence();
+    }
+    return res;
+  }
+
+  // ===================================================================================================
+  // line search    DDPSolver.hpp:234-274, forwardPass :536-560 : lane j rolls out alpha_list[j]
+  // ===================================================================================================
+  static constexpr int kNom = kGain + N + MM; // per timestep: k_i, K_i, x_i, u_i (the same for every lane)
+  static constexpr int kNomChunks = (kNom + 63) / 64;
+  /** double e of the nominal record of timestep i */
+  NMPC_D double nominalWord(int i, int e) const
+  {
+    if(e < kGain)
+    {
+      return gainBlock(i)[e];
+    }
+    if(e < kGain + N)
+    {
+      return trajX(0)[static_cast<size_t>(i) * N + (e - kGain)];
+    }
+    return trajU(0)[static_cast<size_t>(i) * MM + (e - kGain - N)];
+  }
+
+  NMPC_D double forwardCandidate(double alpha, bool active) const
+  {
+    double * Xc = trajX(1 + lane);
+    double * Uc = trajU(1 + lane);
+    double * Cc = trajC(1 + lane);
+    // The nominal record is the same for all lanes: the wave fetches it once (one or two doubles per lane, requested one
+    // timestep ahead), passes it through LDS, and every lane reads it from there.
+    double nf[kNomChunks];
+#pragma unroll
+    for(int q = 0; q < kNomChunks; q++)
+    {
+      const int e = 64 * q + lane;
+      nf[q] = (e < kNom) ? nominalWord(0, e) : 0.0;
+    }
+    StateDimVector xc;
+    loadState(trajX(0), xc); // x'_0 = x_0
+    double J = 0;
+    for(int i = 0; i < T; i++)
+    {
+      const double t = current_t + i * problem.dt();
+      double * st = lds + kStageAt + (i & 1) * (64 * kNomChunks);
+#pragma unroll
+      for(int q = 0; q < kNomChunks; q++)
+      {
+        st[64 * q + lane] = nf[q];
+      }
+      if(i + 1 < T)
+      {
+#pragma unroll
+        for(int q = 0; q < kNomChunks; q++)
+        {
+          const int e = 64 * q + lane;
+          nf[q] = (e < kNom) ? nominalWord(i + 1, e) : 0.0;
+        }
+      }
+      fence();
+      const double * g = st;
+      const double * xn = st + kGain;
+      const double * un = st + kGain + N;
+      InputDimVector uc;
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        double s = 0;
+#pragma unroll
+        for(int c = 0; c < N; c++)
+        {
+          s += g[MM + a + MM * c] * (xc[c] - xn[c]);
+        }
+        uc[a] = (un[a] + alpha * g[a]) + s;
+      }
+      const double c = problem.runningCost(t, xc, uc);
+      if(active)
+      {
+#pragma unroll
+        for(int j = 0; j < N; j++)
+        {
+          Xc[static_cast<size_t>(i) * N + j] = xc[j];
+        }
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          Uc[static_cast<size_t>(i) * MM + a] = uc[a];
+        }
+        Cc[i] = c;
+      }
+      J += c;
+      xc = problem.stateEq(t, xc, uc);
+      fence();
+    }
+    const double cT = problem.terminalCost(current_t + T * problem.dt(), xc);
+    if(active)
+    {
+#pragma unroll
+      for(int j = 0; j < N; j++)
+      {
+        Xc[static_cast<size_t>(T) * N + j] = xc[j];
+      }
+      Cc[T] = cT;
+    }
+    return J + cT;
+  }
+
+  NMPC_D void adoptCandidate(int j) const
+  {
+    const size_t n = trajDoubles(T);
+    const double * src = trajX(1 + j);
+    double * dst = trajX(0);
+    for(size_t e = lane; e < n; e += 64)
+    {
+      dst[e] = src[e];
+    }
+  }
+
+  // ===================================================================================================
+  // solve    DDPSolver.hpp:26-141, procOnce :143-340
+  // ===================================================================================================
+  NMPC_D void writeTraceRow(int row, const double * tr) const
+  {
+    if(cfg.trace_level >= 1 && row < buf.trace_rows && lane < NMPC_HIP_NTRACE)
+    {
+      const size_t tl = static_cast<size_t>(b) / kLanesPerBlock, ln = static_cast<size_t>(b) % kLanesPerBlock;
+      double * p = buf.trace + (tl * (static_cast<size_t>(buf.trace_rows) * NMPC_HIP_NTRACE)) * kLanesPerBlock + ln;
+      p[(static_cast<size_t>(row) * NMPC_HIP_NTRACE + lane) * kLanesPerBlock] = tr[lane];
+    }
+  }
+
+#ifdef NMPC_AMD_PROFILE_WPI
+  // profiling build (scripts/profile_wpi.py): shader cycles per phase of instance 0, returned through qp_free
+  mutable unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
+  mutable unsigned long long prof_t0 = 0;
+  NMPC_D void profBegin() const
+  {
+    prof_t0 = __builtin_readcyclecounter();
+  }
+  NMPC_D void profEnd(int k) const
+  {
+    prof_acc[k] += __builtin_readcyclecounter() - prof_t0;
+  }
+  NMPC_D void profFlush() const
+  {
+    if(b == 0 && lane == 0)
+    {
+      for(int k = 0; k < 6; k++)
+      {
+        buf.qp_free[static_cast<size_t>(k) * kLanesPerBlock] = static_cast<unsigned>(prof_acc[k] >> 4);
+      }
+    }
+  }
+#else
+  NMPC_D void profBegin() const {}
+  NMPC_D void profEnd(int) const {}
+  NMPC_D void profFlush() const {}
+#endif
+
+  NMPC_D void solve()
+  {
+    current_t = buf.t0 ? buf.t0[b] : 0.0;
+    double lambda = cfg.initial_lambda, dlambda = cfg.initial_dlambda;
+    zeroAllLds();
+    sync();
+    profBegin();
+    double J_cur = initialRollout();
+    sync();
+    profEnd(0);
+
+    __shared__ double tr_sh[NMPC_HIP_NTRACE]; // trace row, indexed by lane when written out
+    double tr[NMPC_HIP_NTRACE];
+    for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+    {
+      tr[f] = 0;
+    }
+    tr[NMPC_HIP_TRACE_COST] = J_cur;
+    tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
+    tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
+    tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
+    auto flushTrace = [&](int row)
+    {
+      sync();
+      if(lane == 0)
+      {
+        for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+        {
+          tr_sh[f] = tr[f];
+        }
+      }
+      sync();
+      writeTraceRow(row, tr_sh);
+    };
+    flushTrace(0);
+
+    int retval = 0;
+    double dV0 = 0, dV1 = 0;
+    for(int iter = 1; iter <= cfg.max_iter; iter++)
+    {
+      for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+      {
+        tr[f] = 0;
+      }
+      tr[NMPC_HIP_TRACE_ITER] = iter;
+      tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
+      retval = 0;
+
+      profBegin();
+      linearise(); // Step 1
+      sync();
+      profEnd(1);
+      // Step 2: backward pass with regularisation retries    :188-214
+      int n_backward = 1;
+      bool bw_failed = false;
+      profBegin();
+      BackwardResult bw = backwardPass(lambda);
+      sync(); // the gains go to HBM and come back to other lanes in the line search
+      profEnd(2);
+      while(!bw.ok)
+      {
+        dlambda = fmax(dlambda * cfg.lambda_factor, cfg.lambda_factor);
+        lambda = fmax(lambda * dlambda, cfg.lambda_min);
+        if(lambda > cfg.lambda_max)
+        {
+          bw_failed = true;
+          break;
+        }
+        n_backward++;
+        bw = backwardPass(lambda);
+        sync();
+      }
+      tr[NMPC_HIP_TRACE_N_BACKWARD] = n_backward;
+      if(bw_failed)
+      {
+        retval = -1;
+      }
+      else
+      {
+        dV0 = bw.dV0;
+        dV1 = bw.dV1;
+        tr[NMPC_HIP_TRACE_K_REL_NORM] = bw.k_rel_norm;
+        if(bw.k_rel_norm < cfg.k_rel_norm_thre && lambda < cfg.lambda_thre)
+        {
+          retval = 1;
+        }
+        else
+        {
+          // Step 3: every step size at once; the sequential loop's choice is the first accepted one in list order
+          const bool active = lane < cfg.n_alpha;
+          const double alpha_l = cfg.alpha_list[active ? lane : 0];
+          profBegin();
+          const double J_cand = forwardCandidate(alpha_l, active);
+          profEnd(3);
+          const double actual_l = J_cur - J_cand;
+          const double expected_l = -1 * alpha_l * (dV0 + alpha_l * dV1);
+          double ratio_l = actual_l / expected_l;
+          if(expected_l < 0)
+          {
+            ratio_l = (actual_l >= 0 ? 1 : -1); // :251-259
+          }
+          const unsigned long long accept = __ballot(active && ratio_l > cfg.cost_update_ratio_thre);
+          const bool success = accept != 0;
+          const int ai = success ? __builtin_ctzll(accept) : cfg.n_alpha - 1;
+          const double alpha = __shfl(alpha_l, ai);
+          const double cost_update_actual = __shfl(actual_l, ai);
+          const double cost_update_expected = __shfl(expected_l, ai);
+          const double cost_update_ratio = __shfl(ratio_l, ai);
+          tr[NMPC_HIP_TRACE_ALPHA] = alpha;
+          tr[NMPC_HIP_TRACE_COST_UPDATE_ACTUAL] = cost_update_actual;
+          tr[NMPC_HIP_TRACE_COST_UPDATE_EXPECTED] = cost_update_expected;
+          tr[NMPC_HIP_TRACE_COST_UPDATE_RATIO] = cost_update_ratio;
+          tr[NMPC_HIP_TRACE_ALPHA_IDX] = ai;
+          tr[NMPC_HIP_TRACE_N_FORWARD] = success ? ai + 1 : cfg.n_alpha;
+          // Step 4    :280-333
+          if(success)
+          {
+            profBegin();
+            sync();
+            adoptCandidate(ai);
+            sync();
+            profEnd(4);
+            J_cur = __shfl(J_cand, ai);
+            if(cost_update_actual < cfg.cost_update_thre)
+            {
+              retval = 1;
+            }
+            dlambda = fmin(dlambda / cfg.lambda_factor, 1 / cfg.lambda_factor);
+            if(lambda >= cfg.lambda_min)
+            {
+              lambda *= dlambda;
+            }
+            else
+            {
+              lambda = 0;
+            }
+          }
+          else
+          {
+            dlambda = fmax(dlambda * cfg.lambda_factor, cfg.lambda_factor);
+            lambda = fmax(lambda * dlambda, cfg.lambda_min);
+            if(lambda > cfg.lambda_max)
+            {
+              retval = -1;
+            }
+          }
+          tr[NMPC_HIP_TRACE_COST] = J_cur;
+          tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
+          tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
+        }
+      }
+      flushTrace(iter);
+      if(retval != 0)
+      {
+        break;
+      }
+    }
+
+    // ---- results -> the handle's tile-major arrays (half 0), as the lane-per-instance kernels leave them
+    profBegin();
+    sync();
+    const size_t tl = static_cast<size_t>(b) / kLanesPerBlock, ln = static_cast<size_t>(b) % kLanesPerBlock;
+    const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;
+    {
+      double * Xo = buf.X + ((tl * 2 + 0) * rows_x) * kLanesPerBlock + ln;
+      const double * X = trajX(0);
+      for(size_t e = lane; e < rows_x; e += 64)
+      {
+        Xo[e * kLanesPerBlock] = X[e];
+      }
+      double * Uo = buf.U + ((tl * 2 + 0) * rows_u) * kLanesPerBlock + ln;
+      const double * U = trajU(0);
+      for(size_t e = lane; e < rows_u; e += 64)
+      {
+        Uo[e * kLanesPerBlock] = U[e];
+      }
+      double * Co = buf.cost + ((tl * 2 + 0) * static_cast<size_t>(T + 1)) * kLanesPerBlock + ln;
+      const double * Cc = trajC(0);
+      for(size_t e = lane; e < static_cast<size_t>(T + 1); e += 64)
+      {
+        Co[e * kLanesPerBlock] = Cc[e];
+      }
+      double * ko = buf.kff + (tl * rows_u) * kLanesPerBlock + ln;
+      double * Ko = buf.Kfb + (tl * rows_u * N) * kLanesPerBlock + ln;
+      for(size_t e = lane; e < static_cast<size_t>(T) * kGain; e += 64)
+      {
+        const size_t i = e / kGain, w = e % kGain;
+        const double v = gainBlock(static_cast<int>(i))[w];
+        if(w < static_cast<size_t>(MM))
+        {
+          ko[(i * MM + w) * kLanesPerBlock] = v;
+        }
+        else
+        {
+          Ko[(i * (N * MM) + (w - MM)) * kLanesPerBlock] = v;
+        }
+      }
+      for(size_t e = lane; e < static_cast<size_t>(T); e += 64)
+      {
+        buf.input_dim[(tl * T + e) * kLanesPerBlock + ln] = M;
+      }
+    }
+    if(lane < NMPC_HIP_NTRACE)
+    {
+      buf.trace_last[(tl * NMPC_HIP_NTRACE + lane) * kLanesPerBlock + ln] = tr_sh[lane];
+    }
+    if(lane == 0)
+    {
+      buf.status[b] = retval;
+      buf.iters[b] = static_cast<int>(tr[NMPC_HIP_TRACE_ITER]);
+      buf.sel[b] = 0;
+      buf.dV[(tl * 2 + 0) * kLanesPerBlock + ln] = dV0;
+      buf.dV[(tl * 2 + 1) * kLanesPerBlock + ln] = dV1;
+    }
+    profEnd(5);
+    profFlush();
+  }
+};
+
+/** The wave-per-instance solve kernel: grid = B workgroups of one wavefront. */
+template<class Problem>
+__global__ __launch_bounds__(kLanesPerBlock) void ddp_solve_wpi_kernel(const Problem problem,
+                                                                        const nmpc_hip_ddp_config cfg,
+                                                                        const DeviceBuffers buf)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds_wpi[];
+  WaveSolver<Problem> solver(problem, cfg, buf, static_cast<int>(blockIdx.x), lds_wpi);
+  solver.solve();
+}
+} // namespace hip
+} // namespace nmpc_amd

@@ -15,6 +15,7 @@
 
 #include <nmpc_amd/hip/ddp_kernels.hpp>
 #include <nmpc_amd/hip/ddp_kernels_2w.hpp>
+#include <nmpc_amd/hip/ddp_kernels_wpi.hpp>
 #include <nmpc_amd/hip/mpc_kernels.hpp>
 
 namespace nmpc_amd
@@ -49,6 +50,8 @@ struct ModelOps
                                    hipStream_t stream);
   //! 1 if the problem has the plant step stateEq(t, x, u, dt) the plant pattern integrates with
   int has_plant_step;
+  //! doubles of per-instance workspace the wave-per-instance kernel needs for horizon T (0: the model never uses it)
+  size_t (*wpi_workspace_doubles)(int T);
 };
 
 template<class Problem>
@@ -65,8 +68,33 @@ struct ModelOpsFor
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
     return PairSolver<Problem, false>::kFits && !(force && std::strcmp(force, "1w") == 0);
   }
+  /** Wave-per-instance (matrix-core) kernel: the shapes whose blocks fill a 16 x 16 tile, static input dimension;
+      unconstrained solves only (checked at launch). */
+  static constexpr bool kWpiShape =
+      Problem::kStateDim >= 9 && Problem::kStateDim <= 16 && Problem::kInputDimMax >= 1 && Problem::kInputDimMax <= 16
+      && !Problem::kDynamicInput;
+  static bool useWpi(bool constrained)
+  {
+    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
+    return kWpiShape && !constrained && !(force && std::strcmp(force, "1w") == 0);
+  }
+  static size_t wpiWorkspaceDoubles(int T)
+  {
+    if constexpr(kWpiShape)
+    {
+      return WaveSolver<Problem>::workspaceDoubles(T);
+    }
+    else
+    {
+      return 0;
+    }
+  }
   static const char * kernelName()
   {
+    if(useWpi(false))
+    {
+      return "ddp_solve_wpi_kernel";
+    }
     return useTwoWave() ? "ddp_solve_tpi2w_kernel" : "ddp_solve_tpi_kernel";
   }
   static hipError_t launchSolve(const void * params,
@@ -77,6 +105,15 @@ struct ModelOpsFor
     Problem problem;
     std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
     const int grid = buf.Bp / kLanesPerBlock;
+    if constexpr(kWpiShape)
+    {
+      if(useWpi(cfg.with_input_constraint != 0) && buf.wpi_ws != nullptr)
+      {
+        hipLaunchKernelGGL((ddp_solve_wpi_kernel<Problem>), dim3(buf.B), dim3(kLanesPerBlock),
+                           WaveSolver<Problem>::kLdsBytes, stream, problem, cfg, buf);
+        return hipGetLastError();
+      }
+    }
     if(useTwoWave())
     {
       if constexpr(PairSolver<Problem, false>::kFits)
@@ -173,6 +210,7 @@ struct ModelOpsFor
     ops.kernel_name = &kernelName;
     ops.launch_mpc_advance = &launchMpcAdvance;
     ops.has_plant_step = HasPlantStep<Problem>::value ? 1 : 0;
+    ops.wpi_workspace_doubles = &wpiWorkspaceDoubles;
     return ops;
   }
 };

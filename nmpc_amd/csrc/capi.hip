@@ -98,6 +98,7 @@ struct nmpc_hip_ddp_solver
   int * d_qp_ret = nullptr;
   unsigned * d_qp_free = nullptr;
   int * d_input_dim = nullptr;
+  double * d_wpi_ws = nullptr; // wave-per-instance kernel workspace (large models only)
   int trace_rows = 0;
   // staging in the reference layouts
   void * d_stage_in = nullptr; // x0 / u_init / t0 as handed over by the host entry point
@@ -173,6 +174,7 @@ DeviceBuffers makeBuffers(const nmpc_hip_ddp_solver * s)
   b.qp_ret = s->d_qp_ret;
   b.qp_free = s->d_qp_free;
   b.input_dim = s->d_input_dim;
+  b.wpi_ws = s->d_wpi_ws;
   for(int i = 0; i < nmpc_amd::hip::kMaxInputDim; i++)
   {
     b.lim_lo[i] = s->lim_lo[i];
@@ -616,6 +618,18 @@ extern "C"
     chk(devAlloc(&s->d_qp_ret, T * Bp));
     chk(devAlloc(&s->d_qp_free, T * Bp));
     chk(devAlloc(&s->d_input_dim, T * Bp));
+    if(m->wpi_workspace_doubles(s->T) > 0)
+    {
+      // wave-per-instance kernel (9 <= n <= 16): materialised derivatives, gains and one candidate trajectory per
+      // step size, per instance.  No memset: the kernel writes everything it reads.
+      if(hipMalloc(reinterpret_cast<void **>(&s->d_wpi_ws),
+                   m->wpi_workspace_doubles(s->T) * static_cast<size_t>(s->B) * sizeof(double))
+         != hipSuccess)
+      {
+        (void)hipGetLastError();
+        s->d_wpi_ws = nullptr; // not enough memory for the workspace: the lane-per-instance kernel needs none
+      }
+    }
     if(rc == NMPC_HIP_OK)
     {
       rc = allocTrace(s);
@@ -656,7 +670,7 @@ extern "C"
     }
     void * ptrs[] = {s->d_t0,     s->d_x0,     s->d_X,   s->d_U,      s->d_cost,    s->d_kff,       s->d_Kfb,
                      s->d_trace,  s->d_trace_last, s->d_dV, s->d_status, s->d_iters, s->d_sel,     s->d_qp_ret,
-                     s->d_qp_free, s->d_input_dim, s->d_stage_in, s->d_stage_out};
+                     s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_stage_in, s->d_stage_out};
     for(void * p : ptrs)
     {
       if(p)

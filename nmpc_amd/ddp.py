@@ -362,6 +362,7 @@ class DDPSolverBatch:
 
     def kernelName(self) -> str:
         """gfx950 kernel the next solve launches (lane mapping), as rocprofv3 lists it."""
+        self._push_state()  # the handle is created lazily (horizon_steps may still change before the first solve)
         name = C.c_char_p()
         _capi.check(self._L.nmpc_hip_ddp_kernel_name(self._h, C.byref(name)))
         return name.value.decode()

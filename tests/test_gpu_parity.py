@@ -420,3 +420,79 @@ def test_two_wave_and_single_wave_kernels_agree(model, monkeypatch):
     assert np.array_equal(a["trace"][..., INT_COLS], b["trace"][..., INT_COLS])
     for key in ("X", "U", "cost", "kff", "Kfb"):
         assert scaled_err(a[key], b[key]) <= TOL, key
+
+
+# ---------------------------------------------------------------------------------------------------
+# wave-per-instance kernel (ddp_kernels_wpi.hpp): quadrotor n = 12 m = 4, manipulator n = 14 m = 7
+# ---------------------------------------------------------------------------------------------------
+def _large(model, B, seed):
+    from nmpc_amd import workloads
+    return workloads.quadrotor_batch(B=B, T=50, seed=seed) if model == "quadrotor" else \
+        workloads.manipulator_batch(B=B, T=30, seed=seed)
+
+
+@pytest.mark.parametrize("model", ["quadrotor", "manipulator"])
+@pytest.mark.parametrize("cfg", [dict(max_iter=10), dict(max_iter=10, reg_type=2),
+                                 dict(max_iter=6, alpha_list=np.array([1.0, 0.3, 0.1, 0.03]))])
+def test_wave_per_instance_kernel_vs_oracle_and_lane_kernel(model, cfg, monkeypatch):
+    """The matrix-core kernel against the oracle (bar of this file) and against the lane-per-instance kernel, which
+    evaluates the same arithmetic in the same order: identical discrete decisions, values to rounding."""
+    wl = _large(model, 96, 77)
+    monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    s = make_solver(wl, **cfg)
+    assert s.kernelName() == "ddp_solve_wpi_kernel"
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_batch(wl, **cfg)
+    check_against_oracle(wl, s, ref)
+    assert len(np.unique(ref.iters)) > 1  # the batch really exercises different iteration counts
+    monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", "1w")
+    s1 = make_solver(wl, **cfg)
+    assert s1.kernelName() == "ddp_solve_tpi_kernel"
+    s1.solve(wl.t0, wl.x0, wl.u_init)
+    assert np.array_equal(s.status(), s1.status()) and np.array_equal(s.iters(), s1.iters())
+    assert np.array_equal(s.trace()[..., INT_COLS], s1.trace()[..., INT_COLS])
+    for a, b in ((s.X(), s1.X()), (s.U(), s1.U()), (s.cost(), s1.cost()), (s.kff(), s1.kff()), (s.Kfb(), s1.Kfb())):
+        assert scaled_err(a, b) <= TOL
+
+
+@pytest.mark.parametrize("model,B", [("quadrotor", 8192), ("manipulator", 8192)])
+def test_wave_per_instance_kernel_full_size(model, B):
+    """BASELINE.json configs 4 / 5 at their per-GPU batch (fp64): a sample of instances against the oracle, and
+    size-independent properties on all of them — the solve is a fixed point (re-solving from its own solution with
+    max_iter = 1 changes nothing beyond rounding), costs are monotone along the trace."""
+    wl = _large(model, B, 1234)
+    s = make_solver(wl, max_iter=6)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    status, iters, tr = s.status(), s.iters(), s.trace()
+    assert status.min() >= 0
+    sample = np.arange(0, B, B // 48)
+    ocfg = oracle.default_config(horizon_steps=wl.T, max_iter=6)
+    ref = oracle.solve_batch(wl.model, ocfg, wl.x0[sample], wl.u_init[sample], t0=wl.t0[sample], n_threads=8)
+    assert np.array_equal(status[sample], ref.status) and np.array_equal(iters[sample], ref.iters)
+    assert scaled_err(s.X()[sample], ref.X) <= TOL and scaled_err(s.U()[sample], ref.U) <= TOL
+    cost_rows = tr[:, :, 1]
+    for b in sample:
+        c = cost_rows[b, : iters[b] + 1]
+        assert np.all(np.diff(c) <= 1e-9 * np.abs(c[:-1]))  # an accepted step never increases the cost
+    # padding instances / scratch untouched: a second identical solve gives identical bits
+    X1 = s.X().copy()
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert np.array_equal(X1, s.X())
+
+
+def test_wave_per_instance_kernel_mpc_loop():
+    """The receding-horizon driver on top of the wave-per-instance kernel (shift pattern), against the oracle's loop."""
+    import nmpc_amd
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=16, T=50, seed=5)
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B)
+    c = s.config()
+    c.print_level = 0
+    c.horizon_steps = wl.T
+    c.max_iter = 5
+    log = s.mpcRun(0.0, wl.x0, np.zeros_like(wl.u_init), 20, shift_warm_start=True)  # oracle.mpc_run starts from u = 0
+    ocfg = oracle.default_config(horizon_steps=wl.T, max_iter=5)
+    for b in (0, 9):
+        r = oracle.mpc_run("quadrotor", ocfg, wl.x0[b], 20, shift_warm_start=True)
+        assert scaled_err(log.x[b], r.x) <= 1e-7 and scaled_err(log.u0[b], r.u0) <= 1e-7

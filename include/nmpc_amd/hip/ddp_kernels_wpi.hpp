@@ -47,29 +47,35 @@ struct WaveSolver
   using InputInputDimMatrix = typename Problem::InputInputDimMatrix;
   using StateInputDimMatrix = typename Problem::StateInputDimMatrix;
 
-  // ---- LDS: 16 x 16 tiles, column-major with leading dimension 17 (conflict-free row AND column access) ----
+  // ---- LDS: column-major tiles with leading dimension 17 (conflict-free row AND column access), 16 rows, as many
+  // columns as the block has (n or m).  Nothing relies on padding: mma() masks the contraction index, storeAcc() masks
+  // rows and columns, so reads beyond a tile's columns only ever feed results that are not stored.
   static constexpr int LD = 17;
-  static constexpr int kTile = 16 * LD;
   enum TileId
   {
-    tVxx = 0,
-    tFx,
-    tFu,
-    tLxx,
+    // m-column tiles first, then n-column tiles (reads beyond a tile stay inside the allocation)
+    tFu = 0, // N x M
     tLxu, // N x M
-    tLuu,
-    tP, // products in flight: Fx^T Vxx
-    tP2, // Fu^T Vxx
-    tQxx,
-    tQux, // M x N (unregularised)
-    tQuxR, // M x N (regularised, reg_type 2)
-    tQuu, // M x M (unregularised)
-    tQuuF, // M x M (regularised)
-    tK, // M x N
+    tLuu, // M x M
+    tQuu, // M x M   unregularised
+    tQuuF, // M x M   regularised
     tKtQuu, // N x M
-    tVnew,
+    tVxx, // N x N
+    tFx, // N x N
+    tQxx, // N x N   Lxx on arrival, Qxx = Lxx + Fx^T Vxx Fx in place
+    tP, // N x N   Fx^T Vxx; later Vxx_reg (reg_type 2) and the unsymmetrised new Vxx
+    tP2, // M x N   Fu^T Vxx
+    tQux, // M x N   unregularised
+    tQuxR, // M x N   regularised (reg_type 2)
+    tK, // M x N
     kNumTiles
   };
+  static constexpr int tLxx = tQxx, tVnew = tP;
+  static constexpr int kColsSmall = MM, kColsBig = N, kNumSmall = 6;
+  NMPC_HD static constexpr int tileAt(int t)
+  {
+    return t < kNumSmall ? t * (LD * kColsSmall) : kNumSmall * (LD * kColsSmall) + (t - kNumSmall) * (LD * kColsBig);
+  }
   // vectors (16 doubles each) behind the tiles
   enum VecId
   {
@@ -82,9 +88,14 @@ struct WaveSolver
     vKff,
     kNumVecs
   };
-  static constexpr int kStageAt = kNumTiles * kTile + kNumVecs * 16; //!< line search: two slots for the nominal record
+  static constexpr int kVecAt = tileAt(kNumTiles) + 16; // + 16: slack for the reads beyond the last tile's columns
+  static constexpr int kStageAt = kVecAt + kNumVecs * 16; //!< line search: two slots for the nominal record
   static constexpr int kLdsDoubles = kStageAt + 2 * 64 * ((2 * MM + MM * N + N + 63) / 64);
   static constexpr size_t kLdsBytes = static_cast<size_t>(kLdsDoubles) * sizeof(double);
+  /** Resident wavefronts per SIMD the kernel is compiled for: two (256 VGPRs, <= 20 KB of LDS each) when the records
+      fit, which hides part of the LDS / matrix-core latencies (quadrotor: +17 % measured); the manipulator's functor
+      code spills at 256 VGPRs (-30 %), it keeps one wavefront per SIMD and 512 VGPRs. */
+  static constexpr int kWavesPerSimd = (kLdsBytes <= 20 * 1024 && N * (N + MM) <= 200) ? 2 : 1;
 
   // ---- per-instance HBM workspace (doubles) ----
   // Derivative block of one timestep: every matrix is stored column-major with its rows padded to 16 and its size
@@ -151,11 +162,11 @@ struct WaveSolver
   }
   NMPC_D double * tile(int t) const
   {
-    return lds + t * kTile;
+    return lds + tileAt(t);
   }
   NMPC_D double * vec(int v) const
   {
-    return lds + kNumTiles * kTile + v * 16;
+    return lds + kVecAt + v * 16;
   }
   /** Phase boundary: what this wave wrote to HBM (derivative blocks, gains, candidates) is read back by other lanes of
       the same wave in the next phase — wait for everything in flight (one wavefront per workgroup: no one to wait for). */
@@ -183,14 +194,8 @@ struct WaveSolver
       tile(t)[r + LD * c] = v;
     }
   }
-  NMPC_D void zeroAllLds() const
-  {
-    for(int e = lane; e < kLdsDoubles; e += 64)
-    {
-      lds[e] = 0;
-    }
-  }
-  /** acc = op(A) * Bm over k < kdim, MFMA D layout: acc[r] = D(i = lane / 16 + 4 r, j = lane % 16) */
+  /** acc = op(A) * Bm over k < kdim, MFMA D layout: acc[r] = D(i = lane / 16 + 4 r, j = lane % 16).  Rows i beyond
+      op(A)'s rows and columns j beyond Bm's columns come out as garbage: storeAcc() never stores them. */
   template<bool kTransA>
   NMPC_D v4d mma(int tA, int tB, int kdim) const
   {
@@ -201,22 +206,28 @@ struct WaveSolver
     for(int k0 = 0; k0 < kdim; k0 += 4)
     {
       const int k = k0 + lk;
-      const double a = kTransA ? A[k + LD * lj] : A[lj + LD * k];
-      const double bb = Bm[k + LD * lj];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+      const bool kv = k < kdim;
+      const int kc = kv ? k : 0;
+      const double a = kTransA ? A[kc + LD * lj] : A[lj + LD * kc];
+      const double bb = Bm[kc + LD * lj];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kv ? a : 0.0, kv ? bb : 0.0, acc, 0, 0, 0);
     }
     return acc;
   }
-  /** tile t <- acc (+ tile tAdd entry-wise when tAdd >= 0: "L + product", addition commutes) */
-  NMPC_D void storeAcc(int t, v4d acc, int tAdd = -1) const
+  /** rows x cols of tile t <- acc (+ the same entry of tile tAdd when tAdd >= 0: "L + product"; tAdd may be t) */
+  NMPC_D void storeAcc(int t, v4d acc, int rows, int cols, int tAdd = -1) const
   {
     double * d = tile(t);
     const int lj = lane & 15, lk = lane >> 4;
 #pragma unroll
     for(int r = 0; r < 4; r++)
     {
-      const int at = (lk + 4 * r) + LD * lj;
-      d[at] = (tAdd >= 0) ? tile(tAdd)[at] + acc[r] : acc[r];
+      const int i = lk + 4 * r;
+      if(i < rows && lj < cols)
+      {
+        const int at = i + LD * lj;
+        d[at] = (tAdd >= 0) ? tile(tAdd)[at] + acc[r] : acc[r];
+      }
     }
   }
 
@@ -454,57 +465,77 @@ struct WaveSolver
       {
         const v4d p1 = mma<true>(tFx, tVxx, N); // Fx^T Vxx
         const v4d p2 = mma<true>(tFu, tVxx, N); // Fu^T Vxx   (M x N)
-        storeAcc(tP, p1);
-        storeAcc(tP2, p2);
+        storeAcc(tP, p1, N, N);
+        storeAcc(tP2, p2, MM, N);
       }
       fence();
       {
         const v4d qxx = mma<false>(tP, tFx, N);
         const v4d qux = mma<false>(tP2, tFx, N);
         const v4d quu = mma<false>(tP2, tFu, N);
-        storeAcc(tQxx, qxx, tLxx); // Lxx + (Fx^T Vxx) Fx
+        storeAcc(tQxx, qxx, N, N, tLxx); // Lxx + (Fx^T Vxx) Fx, in place
         // Qux = Lxu^T + (Fu^T Vxx) Fx : the transposed L block is added entry-wise
         const int lj = lane & 15, lk = lane >> 4;
 #pragma unroll
         for(int r = 0; r < 4; r++)
         {
           const int a = lk + 4 * r; // row of Qux = input index, column lj = state index
-          tile(tQux)[a + LD * lj] = tile(tLxu)[lj + LD * a] + qux[r];
+          if(a < MM && lj < N)
+          {
+            tile(tQux)[a + LD * lj] = tile(tLxu)[lj + LD * a] + qux[r];
+          }
         }
-        storeAcc(tQuu, quu, tLuu); // Luu + (Fu^T Vxx) Fu
+        storeAcc(tQuu, quu, MM, MM, tLuu); // Luu + (Fu^T Vxx) Fu
       }
       fence();
       // ---- regularisation    :421-441
       if(cfg.reg_type == 2)
       {
-        for(int e = lane; e < 256; e += 64) // scratch tile: Vxx_reg = Vxx + lambda I
+        for(int e = lane; e < 16 * N; e += 64) // Vxx_reg = Vxx + lambda I in the (free) product tile
         {
           const int r = e & 15, c = e >> 4;
-          tile(tVnew)[r + LD * c] = (r == c && r < N) ? tile(tVxx)[r + LD * c] + lambda : tile(tVxx)[r + LD * c];
+          if(r < N)
+          {
+            tile(tP)[r + LD * c] = (r == c) ? tile(tVxx)[r + LD * c] + lambda : tile(tVxx)[r + LD * c];
+          }
         }
         fence();
-        storeAcc(tP2, mma<true>(tFu, tVnew, N));
+        storeAcc(tP2, mma<true>(tFu, tP, N), MM, N);
         fence();
         {
           const v4d acc = mma<false>(tP2, tFx, N);
+          const v4d quf = mma<false>(tP2, tFu, N);
           const int lj = lane & 15, lk = lane >> 4;
 #pragma unroll
           for(int r = 0; r < 4; r++)
           {
             const int a = lk + 4 * r;
-            tile(tQuxR)[a + LD * lj] = tile(tLxu)[lj + LD * a] + acc[r];
+            if(a < MM && lj < N)
+            {
+              tile(tQuxR)[a + LD * lj] = tile(tLxu)[lj + LD * a] + acc[r];
+            }
           }
-          storeAcc(tQuuF, mma<false>(tP2, tFu, N), tLuu);
+          storeAcc(tQuuF, quf, MM, MM, tLuu); // Luu + Fu^T Vxx_reg Fu
         }
       }
       else
       {
-        for(int e = lane; e < 256; e += 64)
+        for(int e = lane; e < 16 * N; e += 64)
         {
           const int r = e & 15, c = e >> 4;
-          tile(tQuxR)[r + LD * c] = tile(tQux)[r + LD * c];
-          const double q = tile(tQuu)[r + LD * c];
-          tile(tQuuF)[r + LD * c] = (r == c && r < MM && cfg.reg_type == 1) ? q + lambda : q;
+          if(r < MM)
+          {
+            tile(tQuxR)[r + LD * c] = tile(tQux)[r + LD * c];
+          }
+        }
+        for(int e = lane; e < 16 * MM; e += 64)
+        {
+          const int r = e & 15, c = e >> 4;
+          if(r < MM)
+          {
+            const double q = tile(tQuu)[r + LD * c];
+            tile(tQuuF)[r + LD * c] = (r == c && cfg.reg_type == 1) ? q + lambda : q;
+          }
         }
       }
       // ---- Qx, Qu    :386-388   (lane r / lane a: ascending-k chains as in the lane-per-instance kernels)
@@ -636,14 +667,20 @@ struct WaveSolver
         for(int r = 0; r < 4; r++)
         {
           const int at = (lk + 4 * r) + LD * lj;
-          tile(tVnew)[at] = ((tile(tQxx)[at] + t1[r]) + t2[r]) + t3[r];
+          if(lk + 4 * r < N && lj < N)
+          {
+            tile(tVnew)[at] = ((tile(tQxx)[at] + t1[r]) + t2[r]) + t3[r];
+          }
         }
       }
       fence();
-      for(int e = lane; e < 256; e += 64) // Vxx = 0.5 (Vxx + Vxx^T)    :527
+      for(int e = lane; e < 16 * N; e += 64) // Vxx = 0.5 (Vxx + Vxx^T)    :527
       {
         const int r = e & 15, c = e >> 4;
-        tile(tVxx)[r + LD * c] = 0.5 * (tile(tVnew)[r + LD * c] + tile(tVnew)[c + LD * r]);
+        if(r < N)
+        {
+          tile(tVxx)[r + LD * c] = 0.5 * (tile(tVnew)[r + LD * c] + tile(tVnew)[c + LD * r]);
+        }
       }
       // ---- save gains    :529-530, running max of |k_i| / (|u_i| + 1)    :217-221
       {
@@ -835,8 +872,6 @@ struct WaveSolver
   {
     current_t = buf.t0 ? buf.t0[b] : 0.0;
     double lambda = cfg.initial_lambda, dlambda = cfg.initial_dlambda;
-    zeroAllLds();
-    sync();
     profBegin();
     double J_cur = initialRollout();
     sync();
@@ -1052,7 +1087,8 @@ struct WaveSolver
 
 /** The wave-per-instance solve kernel: grid = B workgroups of one wavefront. */
 template<class Problem>
-__global__ __launch_bounds__(kLanesPerBlock) void ddp_solve_wpi_kernel(const Problem problem,
+__global__ __launch_bounds__(kLanesPerBlock)
+    __attribute__((amdgpu_waves_per_eu(WaveSolver<Problem>::kWavesPerSimd, WaveSolver<Problem>::kWavesPerSimd))) void ddp_solve_wpi_kernel(const Problem problem,
                                                                         const nmpc_hip_ddp_config cfg,
                                                                         const DeviceBuffers buf)
 {

@@ -27,20 +27,49 @@ public:
   {
     return (j % 2 == 1) ? -q_ref_scale_ : q_ref_scale_;
   }
-  NMPC_HD double coupling(const StateDimVector & x, int i, int j) const
+  /** sin / cos of every joint-angle difference q_i - q_j and of the cumulative angles q_0 + ... + q_j, evaluated once
+      per model call: 21 + 7 sincosFast pairs (cos is even, sin is odd, the diagonal is exact) instead of one math-library
+      call per use — the Jacobian alone refers to them ~400 times. */
+  struct Trig
   {
-    return (i == j ? w_diag_ : 0.0) + w_off_ * cos(x[i] - x[j]);
+    double cd[kJoints][kJoints], sd[kJoints][kJoints]; // cos / sin (q_i - q_j)
+    double cum_angle[kJoints], sc[kJoints], cc[kJoints]; // cumulative angle, its sin / cos
+    NMPC_HD explicit Trig(const StateDimVector & x)
+    {
+      for(int i = 0; i < kJoints; i++)
+      {
+        cd[i][i] = 1.0;
+        sd[i][i] = 0.0;
+        for(int j = i + 1; j < kJoints; j++)
+        {
+          double s, c;
+          sincosFast(x[i] - x[j], s, c);
+          cd[i][j] = c;
+          cd[j][i] = c;
+          sd[i][j] = s;
+          sd[j][i] = -s;
+        }
+      }
+      double angle = 0;
+      for(int j = 0; j < kJoints; j++)
+      {
+        angle += x[j];
+        cum_angle[j] = angle;
+        sincosFast(angle, sc[j], cc[j]);
+      }
+    }
+  };
+  NMPC_HD double coupling(const Trig & g, int i, int j) const
+  {
+    return (i == j ? w_diag_ : 0.0) + w_off_ * g.cd[i][j];
   }
 
-  /** Net joint torques r and cumulative angles. */
-  NMPC_HD void netTorque(const StateDimVector & x, const InputDimVector & u, double * r, double * cum_angle) const
+  /** Net joint torques r. */
+  NMPC_HD void netTorque(const Trig & g, const StateDimVector & x, const InputDimVector & u, double * r) const
   {
-    double angle = 0;
     for(int j = 0; j < kJoints; j++)
     {
-      angle += x[j];
-      cum_angle[j] = angle;
-      r[j] = (u[j] - damping_ * x[kJoints + j]) - gravityGain(j) * sin(angle);
+      r[j] = (u[j] - damping_ * x[kJoints + j]) - gravityGain(j) * g.sc[j];
     }
   }
 
@@ -48,15 +77,16 @@ public:
                                  const StateDimVector & x,
                                  const InputDimVector & u) const
   {
-    double r[kJoints], cum_angle[kJoints];
-    netTorque(x, u, r, cum_angle);
+    const Trig g(x);
+    double r[kJoints];
+    netTorque(g, x, u, r);
     StateDimVector x_next;
     for(int i = 0; i < kJoints; i++)
     {
       double acc = 0;
       for(int j = 0; j < kJoints; j++)
       {
-        acc += coupling(x, i, j) * r[j];
+        acc += coupling(g, i, j) * r[j];
       }
       x_next[i] = x[i] + dt_ * x[kJoints + i];
       x_next[kJoints + i] = x[kJoints + i] + dt_ * acc;
@@ -100,8 +130,9 @@ public:
                                 StateStateDimMatrix & state_eq_deriv_x,
                                 StateInputDimMatrix & state_eq_deriv_u) const
   {
-    double r[kJoints], cum_angle[kJoints];
-    netTorque(x, u, r, cum_angle);
+    const Trig g(x);
+    double r[kJoints];
+    netTorque(g, x, u, r);
 
     state_eq_deriv_x.setIdentity();
     state_eq_deriv_u.setZero();
@@ -113,11 +144,11 @@ public:
       double own = 0;
       for(int j = 0; j < kJoints; j++)
       {
-        own += sin(x[i] - x[j]) * r[j];
+        own += g.sd[i][j] * r[j];
       }
       for(int l = 0; l < kJoints; l++)
       {
-        double d_coupling = w_off_ * sin(x[i] - x[l]) * r[l];
+        double d_coupling = w_off_ * g.sd[i][l] * r[l];
         if(l == i)
         {
           d_coupling += -w_off_ * own;
@@ -126,11 +157,11 @@ public:
         double d_gravity = 0;
         for(int j = l; j < kJoints; j++)
         {
-          d_gravity += coupling(x, i, j) * (gravityGain(j) * cos(cum_angle[j]));
+          d_gravity += coupling(g, i, j) * (gravityGain(j) * g.cc[j]);
         }
         state_eq_deriv_x(kJoints + i, l) += dt_ * (d_coupling - d_gravity);
-        state_eq_deriv_x(kJoints + i, kJoints + l) += dt_ * (-coupling(x, i, l) * damping_);
-        state_eq_deriv_u(kJoints + i, l) = dt_ * coupling(x, i, l);
+        state_eq_deriv_x(kJoints + i, kJoints + l) += dt_ * (-coupling(g, i, l) * damping_);
+        state_eq_deriv_u(kJoints + i, l) = dt_ * coupling(g, i, l);
       }
     }
   }

@@ -37,8 +37,13 @@ public:
   {
     double sr, cr, sp, cp, sy, cy, tp;
     NMPC_HD explicit Trig(const StateDimVector & x)
-    : sr(sin(x[3])), cr(cos(x[3])), sp(sin(x[4])), cp(cos(x[4])), sy(sin(x[5])), cy(cos(x[5])), tp(sp / cp)
     {
+      // attitude angles are physical (|angle| << 2^27 rad): sincosFast, ~130 cycles per pair on gfx950 instead of
+      // ~640 for the math library's sin + cos (linalg.hpp)
+      sincosFast(x[3], sr, cr);
+      sincosFast(x[4], sp, cp);
+      sincosFast(x[5], sy, cy);
+      tp = sp / cp;
     }
   };
 

@@ -39,13 +39,32 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+# name -> (generator in nmpc_amd.workloads, per-GPU batch, horizon, description)
+WORKLOADS = {
+    "c2": ("cartpole_batch", 4096, 100,
+           "C2 batched cart-pole swing-up: nx=4, nu=1, T=%d, batch=%d per GPU, fp64, "
+           "x0~U([-1,1]x[-pi,pi]x[-1,1]x[-1,1]) splitmix64 seed %d, u_init=0, unconstrained"),
+    "c3": ("bipedal_batch", 1024, 300,
+           "C3 bipedal CoM-ZMP: nx=2, nu=1, T=%d, batch=%d per GPU, fp64, t0~U[0,17] s on the reference's ref_zmp / "
+           "omega^2 schedule, splitmix64 seed %d, u_init=0"),
+    "c4": ("quadrotor_batch", 8192, 50,
+           "C4-shape quadrotor: nx=12, nu=4, T=%d, batch=%d per GPU, fp64 (BASELINE names fp32), hover-perturbed x0 "
+           "splitmix64 seed %d, u_init=hover"),
+    "c5": ("manipulator_batch", 8192, 30,
+           "C5-shape manipulator: nx=14, nu=7, T=%d, batch=%d per GPU (65536 over 8 GPUs), fp64, splitmix64 seed %d"),
+}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
-    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
+                    help="c2 (default) is BASELINE.json's metric configuration; c3 / c4 / c5 are the other configs "
+                         "(parity-test cases) measured with the same harness")
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (0: the workload's own)")
+    ap.add_argument("--horizon", type=int, default=0, help="horizon_steps (0: the workload's own)")
     ap.add_argument("--iters-per-solve", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0,
@@ -109,7 +128,8 @@ def main():
     from nmpc_amd import _capi, workloads
 
     # per-rank shard: rank r owns instances [r*B, (r+1)*B) of the global splitmix64 stream
-    wl = workloads.cartpole_batch(B=args.batch, T=args.horizon, seed=args.seed + 7919 * rank)
+    gen, wl_batch, wl_horizon, wl_text = WORKLOADS[args.workload]
+    wl = getattr(workloads, gen)(B=args.batch or wl_batch, T=args.horizon or wl_horizon, seed=args.seed + 7919 * rank)
     solver = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B, device=local_rank)
     cfg = solver.config()
     cfg.print_level = 0
@@ -177,7 +197,7 @@ def main():
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
         value = world * args.steps * (inst_it_per_solve / wl.B) / elapsed
         out = {
-            "metric": "DDP iterations/s (whole node), batch=4096, T=100",
+            "metric": "DDP iterations/s (whole node), batch=%d, T=%d" % (wl.B, wl.T),
             "value": value,
             "unit": "DDP iterations/s (one iteration = procOnce over a batch of %d instances per GPU)" % wl.B,
             "n_gpus": world,
@@ -190,10 +210,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "C2 batched cart-pole swing-up: nx=4, nu=1, T=%d, batch=%d per GPU, fp64, "
-                            "x0~U([-1,1]x[-pi,pi]x[-1,1]x[-1,1]) splitmix64 seed %d, u_init=0, unconstrained, "
-                            "default DDPSolver::Configuration with max_iter = iterations_per_step"
-                            % (wl.T, wl.B, args.seed),
+                "workload": (wl_text % (wl.T, wl.B, args.seed))
+                            + ", default DDPSolver::Configuration with max_iter = iterations_per_step",
                 "iterations_per_step": args.iters_per_solve,
                 "instance_iterations_per_step": inst_it_per_solve,
                 "backward_passes_per_iteration": n_bw,
@@ -205,7 +223,7 @@ def main():
             "instance_iterations_per_s": value * wl.B,
             "roofline": {
                 "bound": "hbm",
-                "kernel": solver.kernelName() + "<DDPProblemCartPole, false>",
+                "kernel": solver.kernelName() + "<%s>" % wl.model,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -228,7 +246,8 @@ def main():
         if os.path.exists(traffic_file):
             try:
                 tf = json.load(open(traffic_file))
-                if tf.get("batch") == wl.B and tf.get("iterations_per_step") == args.iters_per_solve:
+                if (args.workload == "c2" and tf.get("batch") == wl.B
+                        and tf.get("iterations_per_step") == args.iters_per_solve):
                     out["roofline"]["traffic"] = tf.get("hbm_bytes_per_launch")
                     out["roofline"]["traffic_source"] = tf.get("source")
             except Exception:

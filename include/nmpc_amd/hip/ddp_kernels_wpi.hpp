@@ -185,48 +185,66 @@ struct WaveSolver
   // tiles
   // ===================================================================================================
   /** One chunk of a derivative block (register value v = double 64 q + lane of the matrix) -> its LDS tile. */
-  NMPC_D void chunkToTile(int t, int q_in_matrix, int rows, int cols, double v) const
+  template<int ROWS, int COLS>
+  NMPC_D void chunkToTile(int t, int q_in_matrix, double v) const
   {
-    const int em = 64 * q_in_matrix + lane; // entry index in the 16-row padded column-major matrix
-    const int r = em & 15, c = em >> 4;
-    if(r < rows && c < cols) // the padding of the HBM block is never written: keep the tiles' padding zero
+    const int r = lane & 15, c = 4 * q_in_matrix + (lane >> 4); // entry 64 q + lane of the 16-row padded matrix
+    const bool col_ok = (4 * q_in_matrix + 3 < COLS) ? true : (c < COLS);
+    if(r < ROWS && col_ok) // the padding of the HBM block is never written
     {
       tile(t)[r + LD * c] = v;
     }
   }
   /** acc = op(A) * Bm over k < kdim, MFMA D layout: acc[r] = D(i = lane / 16 + 4 r, j = lane % 16).  Rows i beyond
       op(A)'s rows and columns j beyond Bm's columns come out as garbage: storeAcc() never stores them. */
-  template<bool kTransA>
-  NMPC_D v4d mma(int tA, int tB, int kdim) const
+  template<bool kTransA, int KDIM>
+  NMPC_D v4d mma(int tA, int tB) const
   {
     const double * A = tile(tA);
     const double * Bm = tile(tB);
     const int lj = lane & 15, lk = lane >> 4;
     v4d acc = {0, 0, 0, 0};
-    for(int k0 = 0; k0 < kdim; k0 += 4)
+#pragma unroll
+    for(int k0 = 0; k0 < KDIM; k0 += 4)
     {
       const int k = k0 + lk;
-      const bool kv = k < kdim;
-      const int kc = kv ? k : 0;
-      const double a = kTransA ? A[kc + LD * lj] : A[lj + LD * kc];
-      const double bb = Bm[kc + LD * lj];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kv ? a : 0.0, kv ? bb : 0.0, acc, 0, 0, 0);
+      if constexpr(KDIM % 4 == 0)
+      {
+        const double a = kTransA ? A[k + LD * lj] : A[lj + LD * k];
+        const double bb = Bm[k + LD * lj];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+      }
+      else
+      {
+        // only the last group of four can run past KDIM: mask it (the tiles hold nothing meaningful there)
+        const bool kv = (k0 + 4 <= KDIM) || k < KDIM;
+        const int kc = kv ? k : 0;
+        const double a = kTransA ? A[kc + LD * lj] : A[lj + LD * kc];
+        const double bb = Bm[kc + LD * lj];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kv ? a : 0.0, kv ? bb : 0.0, acc, 0, 0, 0);
+      }
     }
     return acc;
   }
-  /** rows x cols of tile t <- acc (+ the same entry of tile tAdd when tAdd >= 0: "L + product"; tAdd may be t) */
-  NMPC_D void storeAcc(int t, v4d acc, int rows, int cols, int tAdd = -1) const
+  /** ROWS x COLS of tile t <- acc (+ the same entry of tile tAdd when tAdd >= 0: "L + product"; tAdd may be t).
+      The row test is decided at compile time wherever ROWS allows, the column test is one lane mask. */
+  template<int ROWS, int COLS>
+  NMPC_D void storeAcc(int t, v4d acc, int tAdd = -1) const
   {
     double * d = tile(t);
     const int lj = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for(int r = 0; r < 4; r++)
+    if(lj < COLS)
     {
-      const int i = lk + 4 * r;
-      if(i < rows && lj < cols)
+#pragma unroll
+      for(int r = 0; r < 4; r++)
       {
-        const int at = i + LD * lj;
-        d[at] = (tAdd >= 0) ? tile(tAdd)[at] + acc[r] : acc[r];
+        const int i = lk + 4 * r;
+        const bool row_ok = (4 * r + 3 < ROWS) ? true : ((4 * r < ROWS) ? (i < ROWS) : false);
+        if(row_ok)
+        {
+          const int at = i + LD * lj;
+          d[at] = (tAdd >= 0) ? tile(tAdd)[at] + acc[r] : acc[r];
+        }
       }
     }
   }
@@ -423,23 +441,23 @@ struct WaveSolver
         const double v = pf[q];
         if(q < cFu)
         {
-          chunkToTile(tFx, q - cFx, N, N, v);
+          chunkToTile<N, N>(tFx, q - cFx, v);
         }
         else if(q < cLxx)
         {
-          chunkToTile(tFu, q - cFu, N, MM, v);
+          chunkToTile<N, MM>(tFu, q - cFu, v);
         }
         else if(q < cLxu)
         {
-          chunkToTile(tLxx, q - cLxx, N, N, v);
+          chunkToTile<N, N>(tLxx, q - cLxx, v);
         }
         else if(q < cLuu)
         {
-          chunkToTile(tLxu, q - cLxu, N, MM, v);
+          chunkToTile<N, MM>(tLxu, q - cLxu, v);
         }
         else if(q < cVec)
         {
-          chunkToTile(tLuu, q - cLuu, MM, MM, v);
+          chunkToTile<MM, MM>(tLuu, q - cLuu, v);
         }
         else
         {
@@ -463,17 +481,17 @@ struct WaveSolver
       // ---- Q terms    :386-408    (products left to right, formed from zero, then added to the L block)
       // independent products are issued together so that their MFMA chains overlap
       {
-        const v4d p1 = mma<true>(tFx, tVxx, N); // Fx^T Vxx
-        const v4d p2 = mma<true>(tFu, tVxx, N); // Fu^T Vxx   (M x N)
-        storeAcc(tP, p1, N, N);
-        storeAcc(tP2, p2, MM, N);
+        const v4d p1 = mma<true, N>(tFx, tVxx); // Fx^T Vxx
+        const v4d p2 = mma<true, N>(tFu, tVxx); // Fu^T Vxx   (M x N)
+        storeAcc<N, N>(tP, p1);
+        storeAcc<MM, N>(tP2, p2);
       }
       fence();
       {
-        const v4d qxx = mma<false>(tP, tFx, N);
-        const v4d qux = mma<false>(tP2, tFx, N);
-        const v4d quu = mma<false>(tP2, tFu, N);
-        storeAcc(tQxx, qxx, N, N, tLxx); // Lxx + (Fx^T Vxx) Fx, in place
+        const v4d qxx = mma<false, N>(tP, tFx);
+        const v4d qux = mma<false, N>(tP2, tFx);
+        const v4d quu = mma<false, N>(tP2, tFu);
+        storeAcc<N, N>(tQxx, qxx, tLxx); // Lxx + (Fx^T Vxx) Fx, in place
         // Qux = Lxu^T + (Fu^T Vxx) Fx : the transposed L block is added entry-wise
         const int lj = lane & 15, lk = lane >> 4;
 #pragma unroll
@@ -485,7 +503,7 @@ struct WaveSolver
             tile(tQux)[a + LD * lj] = tile(tLxu)[lj + LD * a] + qux[r];
           }
         }
-        storeAcc(tQuu, quu, MM, MM, tLuu); // Luu + (Fu^T Vxx) Fu
+        storeAcc<MM, MM>(tQuu, quu, tLuu); // Luu + (Fu^T Vxx) Fu
       }
       fence();
       // ---- regularisation    :421-441
@@ -500,11 +518,11 @@ struct WaveSolver
           }
         }
         fence();
-        storeAcc(tP2, mma<true>(tFu, tP, N), MM, N);
+        storeAcc<MM, N>(tP2, mma<true, N>(tFu, tP));
         fence();
         {
-          const v4d acc = mma<false>(tP2, tFx, N);
-          const v4d quf = mma<false>(tP2, tFu, N);
+          const v4d acc = mma<false, N>(tP2, tFx);
+          const v4d quf = mma<false, N>(tP2, tFu);
           const int lj = lane & 15, lk = lane >> 4;
 #pragma unroll
           for(int r = 0; r < 4; r++)
@@ -515,7 +533,7 @@ struct WaveSolver
               tile(tQuxR)[a + LD * lj] = tile(tLxu)[lj + LD * a] + acc[r];
             }
           }
-          storeAcc(tQuuF, quf, MM, MM, tLuu); // Luu + Fu^T Vxx_reg Fu
+          storeAcc<MM, MM>(tQuuF, quf, tLuu); // Luu + Fu^T Vxx_reg Fu
         }
       }
       else
@@ -659,9 +677,9 @@ struct WaveSolver
       fence();
       // Vxx = Qxx + K^T Quu K + K^T Qux + Qux^T K, each product a temporary formed from zero    :526
       {
-        const v4d t1 = mma<false>(tKtQuu, tK, M);
-        const v4d t2 = mma<true>(tK, tQux, M);
-        const v4d t3 = mma<true>(tQux, tK, M);
+        const v4d t1 = mma<false, M>(tKtQuu, tK);
+        const v4d t2 = mma<true, M>(tK, tQux);
+        const v4d t3 = mma<true, M>(tQux, tK);
         const int lj = lane & 15, lk = lane >> 4;
 #pragma unroll
         for(int r = 0; r < 4; r++)

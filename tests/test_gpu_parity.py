@@ -496,3 +496,35 @@ def test_wave_per_instance_kernel_mpc_loop():
     for b in (0, 9):
         r = oracle.mpc_run("quadrotor", ocfg, wl.x0[b], 20, shift_warm_start=True)
         assert scaled_err(log.x[b], r.x) <= 1e-7 and scaled_err(log.u0[b], r.u0) <= 1e-7
+
+
+@pytest.mark.parametrize("B,T,max_iter", [(1, 50, 5), (65, 70, 4), (7, 3, 6), (3, 50, 0)])
+def test_wave_per_instance_kernel_edge_shapes(B, T, max_iter):
+    """Ragged batches (grid = B wavefronts, tile-major results of the other 63 lanes untouched), horizons longer than one
+    wavefront of timesteps (the linearisation then runs in chunks of 64), tiny horizons, zero iterations."""
+    from nmpc_amd import workloads
+    wl = workloads.quadrotor_batch(B=B, T=T, seed=100 + B)
+    s = make_solver(wl, max_iter=max_iter)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    check_against_oracle(wl, s, oracle_batch(wl, max_iter=max_iter), check_gains=max_iter > 0)
+
+
+def test_wave_per_instance_kernel_failure_status():
+    """Quu_F never positive definite (negative input weight): every backward pass fails, lambda climbs past lambda_max,
+    status -1 with the same trace as the oracle (DDPSolver.hpp:196-204)."""
+    import nmpc_amd
+    from nmpc_amd import workloads
+    wl = workloads.manipulator_batch(B=24, T=30, seed=9)
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.DDPProblemManipulator(wu=-1.0), wl.B)
+    c = s.config()
+    c.print_level = 0
+    c.horizon_steps = wl.T
+    c.lambda_max = 1e-3
+    assert s.kernelName() == "ddp_solve_wpi_kernel"
+    ok = s.solve(wl.t0, wl.x0, wl.u_init)
+    ocfg = oracle.default_config(horizon_steps=wl.T, lambda_max=1e-3)
+    ref = oracle.solve_batch("manipulator", ocfg, wl.x0, wl.u_init, params=oracle.default_params("manipulator", wu=-1.0))
+    assert not ok.any() and (ref.status == -1).all()
+    np.testing.assert_array_equal(s.status(), ref.status)
+    np.testing.assert_array_equal(s.iters(), ref.iters)
+    np.testing.assert_array_equal(s.traceLast()[:, INT_COLS], ref.trace_last[:, INT_COLS])

@@ -1,6 +1,6 @@
 // gfx950 device code of the batched DDP solver, LANE MAPPING "WPI": ONE WAVEFRONT PER PROBLEM INSTANCE, for the shapes
 // whose blocks fill a matrix-core tile (9 <= n <= 16, m <= 16; BASELINE.json's quadrotor n 12 m 4 and manipulator
-// n 14 m 7).  The lane-per-instance kernels (ddp_kernels.hpp) keep a whole instance in one lane's registers; from n ~ 9
+// n 14 m 7, the reference's centroidal-motion test n 9 m 16).  The lane-per-instance kernels (ddp_kernels.hpp) keep a whole instance in one lane's registers; from n ~ 9
 // on that state (Vxx, Fx, Qxx ... ~ 6 n^2 doubles) spills, and a batch of 8192 instances occupies 128 of 1024 SIMDs.
 // Here the 64 lanes of a wavefront work on ONE instance and the batch fills the chip:
 //
@@ -20,8 +20,9 @@
 // lane-per-instance kernels; products are formed from zero and then added to the L-blocks, as the reference's
 // temporaries are.
 //
-// Scope: unconstrained solves of problems with a static input dimension.  Everything else (BoxQP, inputDim(t)) stays on
-// the lane-per-instance kernels.
+// Scope: unconstrained solves, 9 <= n <= 16, m <= 16, static or time-varying input dimension (inputDim(t) and m > 8 take
+// the gains through LDS: cooperative L D L^T, per-lane column solves; centroidal motion n 9, m 16 / 0).  Box-constrained
+// solves (BoxQP) stay on the lane-per-instance kernel.
 #pragma once
 
 #include <nmpc_amd/hip/ddp_kernels.hpp>
@@ -39,7 +40,10 @@ struct WaveSolver
   static constexpr int M = Problem::kInputDimMax;
   static constexpr int MM = (M > 0) ? M : 1;
   static_assert(N <= 16 && MM <= 16, "one 16 x 16 tile per block");
-  static_assert(!Problem::kDynamicInput, "static input dimension only");
+  /** Gains through LDS with run-time input dimension (cooperative L D L^T, per-lane column solves in place) instead of
+      per-lane register copies of the M x M blocks: for inputDim(t) problems and for m > 8 (16 x 16 doubles do not fit a
+      lane's registers).  Centroidal motion (n 9, m 16 / 0) takes this path. */
+  static constexpr bool kLdsGains = Problem::kDynamicInput || MM > 8;
   using Lane = InstanceSolver<Problem, false>; // for the shared scalar helpers (ldltInPlace, ...)
   using StateDimVector = typename Problem::StateDimVector;
   using InputDimVector = typename Problem::InputDimVector;
@@ -86,6 +90,7 @@ struct WaveSolver
     vQx,
     vQu,
     vKff,
+    vInvD, // reciprocals of D (LDS-gains path)
     kNumVecs
   };
   static constexpr int kVecAt = tileAt(kNumTiles) + 16; // + 16: slack for the reads beyond the last tile's columns
@@ -168,6 +173,18 @@ struct WaveSolver
   {
     return lds + kVecAt + v * 16;
   }
+  /** inputDim(t_i): wave-uniform */
+  NMPC_D int inputDimAt(int i) const
+  {
+    if constexpr(Problem::kDynamicInput)
+    {
+      return problem.inputDim(current_t + i * problem.dt());
+    }
+    else
+    {
+      return M;
+    }
+  }
   /** Phase boundary: what this wave wrote to HBM (derivative blocks, gains, candidates) is read back by other lanes of
       the same wave in the next phase — wait for everything in flight (one wavefront per workgroup: no one to wait for). */
   NMPC_D static void sync()
@@ -226,6 +243,49 @@ struct WaveSolver
     }
     return acc;
   }
+  /** Run-time contraction length (LDS-gains path). */
+  template<bool kTransA>
+  NMPC_D v4d mmaDyn(int tA, int tB, int kdim) const
+  {
+    const double * A = tile(tA);
+    const double * Bm = tile(tB);
+    const int lj = lane & 15, lk = lane >> 4;
+    v4d acc = {0, 0, 0, 0};
+    for(int k0 = 0; k0 < kdim; k0 += 4)
+    {
+      const int k = k0 + lk;
+      const bool kv = k < kdim;
+      const int kc = kv ? k : 0;
+      const double a = kTransA ? A[kc + LD * lj] : A[lj + LD * kc];
+      const double bb = Bm[kc + LD * lj];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kv ? a : 0.0, kv ? bb : 0.0, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+  NMPC_D void storeAccDyn(int t, v4d acc, int rows, int cols, int tAdd = -1) const
+  {
+    double * d = tile(t);
+    const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+      const int i = lk + 4 * r;
+      if(i < rows && lj < cols)
+      {
+        const int at = i + LD * lj;
+        d[at] = (tAdd >= 0) ? tile(tAdd)[at] + acc[r] : acc[r];
+      }
+    }
+  }
+  NMPC_D void chunkToTileDyn(int t, int q_in_matrix, int rows, int cols, double v) const
+  {
+    const int r = lane & 15, c = 4 * q_in_matrix + (lane >> 4);
+    if(r < rows && c < cols)
+    {
+      tile(t)[r + LD * c] = v;
+    }
+  }
+
   /** ROWS x COLS of tile t <- acc (+ the same entry of tile tAdd when tAdd >= 0: "L + product"; tAdd may be t).
       The row test is decided at compile time wherever ROWS allows, the column test is one lane mask. */
   template<int ROWS, int COLS>
@@ -286,10 +346,12 @@ struct WaveSolver
     for(int i = 0; i < T; i++)
     {
       const double t = current_t + i * problem.dt();
+      const int m = inputDimAt(i);
       InputDimVector u;
+      u.resize(m);
       for(int a = 0; a < MM; a++)
       {
-        u[a] = Uin[(static_cast<size_t>(i) * MM + a) * kLanesPerBlock];
+        u[a] = (a < m) ? Uin[(static_cast<size_t>(i) * MM + a) * kLanesPerBlock] : 0.0; // zero beyond inputDim(t)
       }
       const double c = problem.runningCost(t, x, u);
       if(lane == 0)
@@ -339,6 +401,15 @@ struct WaveSolver
         StateDimVector Lx;
         InputDimVector Lu;
         InputInputDimMatrix Luu;
+        if constexpr(Problem::kDynamicInput)
+        {
+          const int m = inputDimAt(i); // per lane: columns / entries beyond m are never read back
+          u.resize(m);
+          Fu.resize(N, m);
+          Lxu.resize(N, m);
+          Lu.resize(m);
+          Luu.resize(m, m);
+        }
         problem.calcStateEqDeriv(t, x, u, Fx, Fu);
         problem.calcRunningCostDeriv(t, x, u, Lx, Lu, Lxx, Luu, Lxu);
         double * d = derivBlock(i);
@@ -733,6 +804,370 @@ struct WaveSolver
   }
 
   // ===================================================================================================
+  // backward pass, gains through LDS (run-time input dimension m, any m <= 16)
+  // ===================================================================================================
+  /** In-place solve (L D L^T) x = rhs on a column that lives in LDS (x = col[0 .. m)); L, D^-1 from tQuuF / vInvD.
+      Same operation order as InstanceSolver::ldltSolveInPlace. */
+  NMPC_D void solveColumnLds(double * col, int m) const
+  {
+    const double * L = tile(tQuuF);
+    const double * inv_d = vec(vInvD);
+    for(int i = 0; i < m; i++)
+    {
+      double s = col[i];
+      for(int j = 0; j < i; j++)
+      {
+        s -= L[i + LD * j] * col[j];
+      }
+      col[i] = s;
+    }
+    for(int i = m - 1; i >= 0; i--)
+    {
+      double s = col[i] * inv_d[i];
+      for(int j = i + 1; j < m; j++)
+      {
+        s -= L[j + LD * i] * col[j];
+      }
+      col[i] = s;
+    }
+  }
+
+  NMPC_D BackwardResult backwardPassLds(double lambda) const
+  {
+    BackwardResult res;
+    res.ok = true;
+    res.dV0 = 0;
+    res.dV1 = 0;
+    res.k_rel_norm = 0;
+    {
+      StateDimVector xT, vx;
+      StateStateDimMatrix vxx;
+      loadState(trajX(0) + static_cast<size_t>(T) * N, xT);
+      problem.calcTerminalCostDeriv(current_t + T * problem.dt(), xT, vx, vxx);
+      sync();
+      if(lane == 0)
+      {
+        for(int j = 0; j < N; j++)
+        {
+          vec(vVx)[j] = vx[j];
+        }
+        for(int c = 0; c < N; c++)
+        {
+          for(int r = 0; r < N; r++)
+          {
+            tile(tVxx)[r + LD * c] = vxx(r, c);
+          }
+        }
+      }
+      sync();
+    }
+    double pf[kDerivChunks];
+    {
+      const double * d = derivBlock(T - 1);
+#pragma unroll
+      for(int q = 0; q < kDerivChunks; q++)
+      {
+        pf[q] = d[64 * q + lane];
+      }
+    }
+    for(int i = T - 1; i >= 0; i--)
+    {
+      const int m = inputDimAt(i);
+      // ---- stage this timestep's derivatives
+#pragma unroll
+      for(int q = 0; q < kDerivChunks; q++)
+      {
+        const double v = pf[q];
+        if(q < cFu)
+        {
+          chunkToTileDyn(tFx, q - cFx, N, N, v);
+        }
+        else if(q < cLxx)
+        {
+          chunkToTileDyn(tFu, q - cFu, N, m, v);
+        }
+        else if(q < cLxu)
+        {
+          chunkToTileDyn(tLxx, q - cLxx, N, N, v);
+        }
+        else if(q < cLuu)
+        {
+          chunkToTileDyn(tLxu, q - cLxu, N, m, v);
+        }
+        else if(q < cVec)
+        {
+          chunkToTileDyn(tLuu, q - cLuu, m, m, v);
+        }
+        else
+        {
+          const int seg = lane >> 4, at = lane & 15;
+          if(seg < 3 && at < (seg == 0 ? N : m))
+          {
+            vec(vLx + seg)[at] = v;
+          }
+        }
+      }
+      {
+        const double * d = derivBlock(i > 0 ? i - 1 : 0);
+#pragma unroll
+        for(int q = 0; q < kDerivChunks; q++)
+        {
+          pf[q] = d[64 * q + lane];
+        }
+      }
+      fence();
+
+      // ---- Q terms    :386-408
+      {
+        const v4d p1 = mma<true, N>(tFx, tVxx);
+        const v4d p2 = mma<true, N>(tFu, tVxx);
+        storeAcc<N, N>(tP, p1);
+        storeAccDyn(tP2, p2, m, N);
+      }
+      fence();
+      {
+        const v4d qxx = mma<false, N>(tP, tFx);
+        const v4d qux = mma<false, N>(tP2, tFx);
+        const v4d quu = mma<false, N>(tP2, tFu);
+        storeAcc<N, N>(tQxx, qxx, tLxx);
+        const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for(int r = 0; r < 4; r++)
+        {
+          const int a = lk + 4 * r;
+          if(a < m && lj < N)
+          {
+            tile(tQux)[a + LD * lj] = tile(tLxu)[lj + LD * a] + qux[r];
+          }
+        }
+        storeAccDyn(tQuu, quu, m, m, tLuu);
+      }
+      fence();
+      // ---- regularisation    :421-441
+      if(cfg.reg_type == 2)
+      {
+        for(int e = lane; e < 16 * N; e += 64)
+        {
+          const int r = e & 15, c = e >> 4;
+          if(r < N)
+          {
+            tile(tP)[r + LD * c] = (r == c) ? tile(tVxx)[r + LD * c] + lambda : tile(tVxx)[r + LD * c];
+          }
+        }
+        fence();
+        storeAccDyn(tP2, mma<true, N>(tFu, tP), m, N);
+        fence();
+        {
+          const v4d acc = mma<false, N>(tP2, tFx);
+          const v4d quf = mma<false, N>(tP2, tFu);
+          const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+          for(int r = 0; r < 4; r++)
+          {
+            const int a = lk + 4 * r;
+            if(a < m && lj < N)
+            {
+              tile(tQuxR)[a + LD * lj] = tile(tLxu)[lj + LD * a] + acc[r];
+            }
+          }
+          storeAccDyn(tQuuF, quf, m, m, tLuu);
+        }
+      }
+      else
+      {
+        for(int e = lane; e < 16 * N; e += 64)
+        {
+          const int r = e & 15, c = e >> 4;
+          if(r < m)
+          {
+            tile(tQuxR)[r + LD * c] = tile(tQux)[r + LD * c];
+          }
+        }
+        for(int e = lane; e < 16 * MM; e += 64)
+        {
+          const int r = e & 15, c = e >> 4;
+          if(r < m && c < m)
+          {
+            const double q = tile(tQuu)[r + LD * c];
+            tile(tQuuF)[r + LD * c] = (r == c && cfg.reg_type == 1) ? q + lambda : q;
+          }
+        }
+      }
+      // ---- Qx, Qu    :386-388
+      if(lane < N)
+      {
+        double sacc = 0;
+        for(int k = 0; k < N; k++)
+        {
+          sacc += tile(tFx)[k + LD * lane] * vec(vVx)[k];
+        }
+        vec(vQx)[lane] = vec(vLx)[lane] + sacc;
+      }
+      if(lane < m)
+      {
+        double sacc = 0;
+        for(int k = 0; k < N; k++)
+        {
+          sacc += tile(tFu)[k + LD * lane] * vec(vVx)[k];
+        }
+        vec(vQu)[lane] = vec(vLu)[lane] + sacc;
+      }
+      fence();
+
+      // ---- L D L^T of Quu_F in place in LDS, column by column; same operation order as ldltInPlace    :500-508
+      {
+        double * A = tile(tQuuF);
+        for(int k = 0; k < m; k++)
+        {
+          double d = A[k + LD * k];
+          for(int j = 0; j < k; j++)
+          {
+            d -= (A[k + LD * j] * A[k + LD * j]) * A[j + LD * j];
+          }
+          if(d <= 0) // every lane computed the same pivot
+          {
+            res.ok = false;
+            return res;
+          }
+          const double r = recipFast(d);
+          fence(); // all lanes have read column k before it is overwritten
+          if(lane > k && lane < m)
+          {
+            double sacc = A[lane + LD * k];
+            for(int j = 0; j < k; j++)
+            {
+              sacc -= (A[lane + LD * j] * A[k + LD * j]) * A[j + LD * j];
+            }
+            A[lane + LD * k] = sacc * r;
+          }
+          if(lane == 0)
+          {
+            A[k + LD * k] = d;
+            vec(vInvD)[k] = r;
+          }
+          fence();
+        }
+      }
+      // ---- gains    :509-517: lane c < N solves column c of Qux_reg in place (tile tK), lane N solves Qu -> k
+      if(lane < N)
+      {
+        for(int a = 0; a < m; a++)
+        {
+          tile(tK)[a + LD * lane] = tile(tQuxR)[a + LD * lane];
+        }
+        solveColumnLds(tile(tK) + LD * lane, m);
+        for(int a = 0; a < m; a++)
+        {
+          tile(tK)[a + LD * lane] = -1 * tile(tK)[a + LD * lane];
+        }
+      }
+      else if(lane == N)
+      {
+        for(int a = 0; a < m; a++)
+        {
+          vec(vKff)[a] = vec(vQu)[a];
+        }
+        solveColumnLds(vec(vKff), m);
+        for(int a = 0; a < m; a++)
+        {
+          vec(vKff)[a] = -1 * vec(vKff)[a];
+        }
+      }
+      fence();
+      // ---- cost-to-go    :522-526
+      {
+        double kQu = 0, kQuuk = 0;
+        for(int a = 0; a < m; a++)
+        {
+          kQu += vec(vKff)[a] * vec(vQu)[a];
+        }
+        // Quu k first (as the lane kernels do), then k^T (Quu k)
+        for(int a = 0; a < m; a++)
+        {
+          double sacc = 0;
+          for(int q = 0; q < m; q++)
+          {
+            sacc += tile(tQuu)[a + LD * q] * vec(vKff)[q];
+          }
+          kQuuk += vec(vKff)[a] * sacc;
+        }
+        res.dV0 += kQu;
+        res.dV1 += 0.5 * kQuuk;
+      }
+      if(lane < N)
+      {
+        double s1 = 0, s2 = 0, s3 = 0;
+        const double * Kc = tile(tK) + LD * lane;
+        for(int a = 0; a < m; a++)
+        {
+          double sacc = 0;
+          for(int q = 0; q < m; q++)
+          {
+            sacc += Kc[q] * tile(tQuu)[q + LD * a];
+          }
+          tile(tKtQuu)[lane + LD * a] = sacc;
+          s1 += sacc * vec(vKff)[a];
+          s2 += Kc[a] * vec(vQu)[a];
+          s3 += tile(tQux)[a + LD * lane] * vec(vKff)[a];
+        }
+        vec(vVx)[lane] = ((vec(vQx)[lane] + s1) + s2) + s3;
+      }
+      fence();
+      {
+        const v4d t1 = mmaDyn<false>(tKtQuu, tK, m);
+        const v4d t2 = mmaDyn<true>(tK, tQux, m);
+        const v4d t3 = mmaDyn<true>(tQux, tK, m);
+        const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for(int r = 0; r < 4; r++)
+        {
+          const int at = (lk + 4 * r) + LD * lj;
+          if(lk + 4 * r < N && lj < N)
+          {
+            tile(tVnew)[at] = ((tile(tQxx)[at] + t1[r]) + t2[r]) + t3[r];
+          }
+        }
+      }
+      fence();
+      for(int e = lane; e < 16 * N; e += 64)
+      {
+        const int r = e & 15, c = e >> 4;
+        if(r < N)
+        {
+          tile(tVxx)[r + LD * c] = 0.5 * (tile(tVnew)[r + LD * c] + tile(tVnew)[c + LD * r]);
+        }
+      }
+      // ---- save gains (zero beyond the input dimension), |k_i| / (|u_i| + 1)
+      {
+        double * g = gainBlock(i);
+        if(lane < MM)
+        {
+          g[lane] = (lane < m) ? vec(vKff)[lane] : 0.0;
+        }
+        if(lane < N)
+        {
+          for(int a = 0; a < MM; a++)
+          {
+            g[MM + a + MM * lane] = (a < m) ? tile(tK)[a + LD * lane] : 0.0;
+          }
+        }
+        double kn = 0, un = 0;
+        for(int a = 0; a < m; a++)
+        {
+          const double ka = vec(vKff)[a], ua = vec(vU)[a];
+          kn += ka * ka;
+          un += ua * ua;
+        }
+        const double knorm = (M == 1) ? fabs(m > 0 ? vec(vKff)[0] : 0.0) : sqrt(kn);
+        const double unorm = (M == 1) ? fabs(m > 0 ? vec(vU)[0] : 0.0) : sqrt(un);
+        res.k_rel_norm = fmax(res.k_rel_norm, knorm * recipFast(unorm + 1.0));
+      }
+      fence();
+    }
+    return res;
+  }
+
+  // ===================================================================================================
   // line search    DDPSolver.hpp:234-274, forwardPass :536-560 : lane j rolls out alpha_list[j]
   // ===================================================================================================
   static constexpr int kNom = kGain + N + MM; // per timestep: k_i, K_i, x_i, u_i (the same for every lane)
@@ -790,7 +1225,9 @@ struct WaveSolver
       const double * g = st;
       const double * xn = st + kGain;
       const double * un = st + kGain + N;
+      const int m = inputDimAt(i);
       InputDimVector uc;
+      uc.resize(m);
 #pragma unroll
       for(int a = 0; a < MM; a++)
       {
@@ -800,7 +1237,7 @@ struct WaveSolver
         {
           s += g[MM + a + MM * c] * (xc[c] - xn[c]);
         }
-        uc[a] = (un[a] + alpha * g[a]) + s;
+        uc[a] = (a < m) ? (un[a] + alpha * g[a]) + s : 0.0;
       }
       const double c = problem.runningCost(t, xc, uc);
       if(active)
@@ -886,6 +1323,18 @@ struct WaveSolver
   NMPC_D void profFlush() const {}
 #endif
 
+  NMPC_D BackwardResult runBackward(double lambda) const
+  {
+    if constexpr(kLdsGains)
+    {
+      return backwardPassLds(lambda);
+    }
+    else
+    {
+      return backwardPass(lambda);
+    }
+  }
+
   NMPC_D void solve()
   {
     current_t = buf.t0 ? buf.t0[b] : 0.0;
@@ -940,7 +1389,7 @@ struct WaveSolver
       int n_backward = 1;
       bool bw_failed = false;
       profBegin();
-      BackwardResult bw = backwardPass(lambda);
+      BackwardResult bw = runBackward(lambda);
       sync(); // the gains go to HBM and come back to other lanes in the line search
       profEnd(2);
       while(!bw.ok)
@@ -953,7 +1402,7 @@ struct WaveSolver
           break;
         }
         n_backward++;
-        bw = backwardPass(lambda);
+        bw = runBackward(lambda);
         sync();
       }
       tr[NMPC_HIP_TRACE_N_BACKWARD] = n_backward;
@@ -1083,7 +1532,7 @@ struct WaveSolver
       }
       for(size_t e = lane; e < static_cast<size_t>(T); e += 64)
       {
-        buf.input_dim[(tl * T + e) * kLanesPerBlock + ln] = M;
+        buf.input_dim[(tl * T + e) * kLanesPerBlock + ln] = inputDimAt(static_cast<int>(e));
       }
     }
     if(lane < NMPC_HIP_NTRACE)

@@ -68,11 +68,10 @@ struct ModelOpsFor
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
     return PairSolver<Problem, false>::kFits && !(force && std::strcmp(force, "1w") == 0);
   }
-  /** Wave-per-instance (matrix-core) kernel: the shapes whose blocks fill a 16 x 16 tile, static input dimension;
-      unconstrained solves only (checked at launch). */
+  /** Wave-per-instance (matrix-core) kernel: the shapes whose blocks fill a 16 x 16 tile; unconstrained solves only
+      (checked at launch). */
   static constexpr bool kWpiShape =
-      Problem::kStateDim >= 9 && Problem::kStateDim <= 16 && Problem::kInputDimMax >= 1 && Problem::kInputDimMax <= 16
-      && !Problem::kDynamicInput;
+      Problem::kStateDim >= 9 && Problem::kStateDim <= 16 && Problem::kInputDimMax >= 1 && Problem::kInputDimMax <= 16;
   static bool useWpi(bool constrained)
   {
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");

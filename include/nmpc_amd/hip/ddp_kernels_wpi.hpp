@@ -776,7 +776,13 @@ struct WaveSolver
         double * g = gainBlock(i);
         if(lane < MM)
         {
-          g[lane] = kff[lane];
+          double mine = 0; // kff[lane] without indexing a register array by the lane id
+#pragma unroll
+          for(int a = 0; a < MM; a++)
+          {
+            mine = (lane == a) ? kff[a] : mine;
+          }
+          g[lane] = mine;
         }
         if(lane < N)
         {

@@ -1,7 +1,7 @@
 // Host-side use of the batched solver from plain C++ (compiled with g++, no HIP headers needed): the calling
 // pattern of the reference's TestDDPCartPole (nmpc_ddp/tests/src/TestDDPCartPole.cpp:266-306, 388-403) with a
 // batch axis.  Build + run:
-//   g++ -std=c++17 -O2 -Iinclude examples/cartpole_batch.cpp -Lnmpc_amd/lib -lnmpc_hip_ddp \
+//   g++ -std=c++17 -O2 -Iinclude examples/cartpole_batch.cpp -Lnmpc_amd/lib -lnmpc_hip_ddp
 //       -Wl,-rpath,$PWD/nmpc_amd/lib -o /tmp/cartpole_batch && /tmp/cartpole_batch
 #include <cmath>
 #include <cstdio>

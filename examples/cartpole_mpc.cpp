@@ -2,7 +2,7 @@
 // (nmpc_ddp/tests/src/TestDDPCartPole.cpp:236-403 with the parameters of tests/test/TestDDPCartPole.test:14-26:
 // horizon 2 s at dt 0.01, +-15 N input box, max_iter 3, MPC every 4 ms, plant integrated at 2 ms, 10 s) with a batch
 // axis, through DDPSolverBatch::mpcRun — one call, no host round trip between the 2500 solves.  Build + run:
-//   g++ -std=c++17 -O2 -Iinclude examples/cartpole_mpc.cpp -Lnmpc_amd/lib -lnmpc_hip_ddp \
+//   g++ -std=c++17 -O2 -Iinclude examples/cartpole_mpc.cpp -Lnmpc_amd/lib -lnmpc_hip_ddp
 //       -Wl,-rpath,$PWD/nmpc_amd/lib -o /tmp/cartpole_mpc && /tmp/cartpole_mpc 64
 #include <array>
 #include <cmath>

@@ -15,6 +15,14 @@
 #else
 #  define NMPC_HD inline
 #endif
+// full unrolling of the small fixed-trip loops below: clang / hipcc spelling, GCC spelling for host-only builds
+#if defined(__clang__)
+#  define NMPC_UNROLL _Pragma("unroll")
+#elif defined(__GNUC__)
+#  define NMPC_UNROLL _Pragma("GCC unroll 64")
+#else
+#  define NMPC_UNROLL
+#endif
 
 namespace nmpc_amd
 {
@@ -214,7 +222,7 @@ public:
 
   NMPC_HD Matrix & setConstant(Scalar v)
   {
-#pragma unroll
+    NMPC_UNROLL
     for(int i = 0; i < kCapacity; i++)
     {
       d_[i] = v;
@@ -229,7 +237,7 @@ public:
   {
     setZero();
     constexpr int kDiag = RMAX < CMAX ? RMAX : CMAX;
-#pragma unroll
+    NMPC_UNROLL
     for(int i = 0; i < kDiag; i++)
     {
       d_[i + i * RMAX] = Scalar(1);
@@ -240,7 +248,7 @@ public:
   NMPC_HD Matrix & addToDiagonal(Scalar v)
   {
     constexpr int kDiag = RMAX < CMAX ? RMAX : CMAX;
-#pragma unroll
+    NMPC_UNROLL
     for(int i = 0; i < kDiag; i++)
     {
       if(i < rows() && i < cols())
@@ -256,7 +264,7 @@ public:
       (TestDDPCartPole.cpp:136-153) sparse for the solver kernels (ddp_kernels.hpp, macc()); exact for finite s. */
   NMPC_HD Matrix & operator*=(Scalar s)
   {
-#pragma unroll
+    NMPC_UNROLL
     for(int i = 0; i < kCapacity; i++)
     {
       if(!(__builtin_constant_p(d_[i]) && d_[i] == Scalar(0)))
@@ -268,7 +276,7 @@ public:
   }
   NMPC_HD Matrix & operator+=(const Matrix & o)
   {
-#pragma unroll
+    NMPC_UNROLL
     for(int i = 0; i < kCapacity; i++)
     {
       d_[i] += o.d_[i];
@@ -284,7 +292,7 @@ public:
   NMPC_HD Matrix operator-(const Matrix & o) const
   {
     Matrix r(*this);
-#pragma unroll
+    NMPC_UNROLL
     for(int i = 0; i < kCapacity; i++)
     {
       r.d_[i] -= o.d_[i];
@@ -334,7 +342,7 @@ public:
   NMPC_HD Matrix cwiseProduct(const Matrix & o) const
   {
     Matrix r(*this);
-#pragma unroll
+    NMPC_UNROLL
     for(int i = 0; i < kCapacity; i++)
     {
       r.d_[i] *= o.d_[i];

@@ -66,6 +66,11 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (0: the workload's own)")
     ap.add_argument("--horizon", type=int, default=0, help="horizon_steps (0: the workload's own)")
     ap.add_argument("--iters-per-solve", type=int, default=8)
+    ap.add_argument("--mode", choices=("nominal", "m1", "m2"), default="nominal",
+                    help="nominal (default): reference defaults with max_iter = --iters-per-solve.  m1 / m2 are the two "
+                         "timing modes of SURVEY.md 8(d): m1 = termination tests disabled (k_rel_norm_thre = 0, "
+                         "cost_update_thre = -inf), every instance executes exactly --iters-per-solve iterations unless "
+                         "lambda exceeds lambda_max; m2 = solve to convergence with the reference defaults (max_iter 500)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0,
                     help="sizing target of the CPU baseline sample (the sustained all-core rate is ~3x below the probe: ~20 s)")
@@ -73,12 +78,21 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(wl, iters_per_solve: int, target_seconds: float):
+def mode_config(mode: str, iters_per_solve: int) -> dict:
+    """Configuration overrides of the three timing modes (same for the GPU solver and the CPU oracle)."""
+    if mode == "m1":
+        return dict(max_iter=iters_per_solve, k_rel_norm_thre=0.0, cost_update_thre=-1e300)
+    if mode == "m2":
+        return dict(max_iter=500)
+    return dict(max_iter=iters_per_solve)
+
+
+def cpu_baseline(wl, mode: str, iters_per_solve: int, target_seconds: float):
     """Time the CPU oracle (kind "port") on a bounded sample of the same workload, all host cores."""
     import oracle
     cores = os.cpu_count() or 1
     build_dir = tempfile.mkdtemp(prefix="oracle_native_")
-    cfg = oracle.default_config(max_iter=iters_per_solve, horizon_steps=wl.T)
+    cfg = oracle.default_config(horizon_steps=wl.T, **mode_config(mode, iters_per_solve))
 
     def run(nb, threads):
         # the sample is the workload's own instances, repeated cyclically when more than one batch is needed
@@ -90,7 +104,7 @@ def cpu_baseline(wl, iters_per_solve: int, target_seconds: float):
     probe = 16 * cores
     it, sec = run(probe, cores)
     rate = it / max(sec, 1e-9)  # instance-iterations / s
-    nb = int(max(probe, rate * target_seconds / iters_per_solve))
+    nb = int(max(probe, rate * target_seconds / max(it / probe, 1.0)))  # iterations per solve as measured by the probe
     it, sec = run(nb, cores)
     nb1 = max(64, int(nb / cores / 4))
     it1, sec1 = run(nb1, 1)
@@ -99,9 +113,9 @@ def cpu_baseline(wl, iters_per_solve: int, target_seconds: float):
         "unit": "DDP iterations/s (batch=%d)" % wl.B,
         "cores": cores,
         "kind": "port",
-        "sample": "%d solves (the workload's %d instances, cycled) x max_iter %d = %d iterations, %d threads, %.1f s; "
+        "sample": "%d solves (the workload's %d instances, cycled), mode %s, max_iter %d: %d iterations, %d threads, %.1f s; "
                   "1-core leg %d solves, %.1f s; oracle/ built -O3 -march=native"
-                  % (nb, wl.B, iters_per_solve, it, cores, sec, nb1, sec1),
+                  % (nb, wl.B, mode, cfg.max_iter, it, cores, sec, nb1, sec1),
         "instance_iterations_per_s": it / sec,
         "instance_iterations_per_s_1core": it1 / sec1,
     }
@@ -134,7 +148,8 @@ def main():
     cfg = solver.config()
     cfg.print_level = 0
     cfg.horizon_steps = wl.T
-    cfg.max_iter = args.iters_per_solve
+    for key, val in mode_config(args.mode, args.iters_per_solve).items():
+        setattr(cfg, key, val)
     cfg.trace_level = 1
 
     d_x0 = torch.from_numpy(wl.x0).to(dev)
@@ -212,7 +227,10 @@ def main():
             "config": {
                 "workload": (wl_text % (wl.T, wl.B, args.seed))
                             + ", default DDPSolver::Configuration with max_iter = iterations_per_step",
-                "iterations_per_step": args.iters_per_solve,
+                "mode": args.mode,
+                "iterations_per_step": args.iters_per_solve if args.mode != "m2" else 500,
+                "solves_per_s": world * args.steps * wl.B / elapsed,
+                "iteration_histogram": {str(k): int(v) for k, v in zip(*np.unique(iters, return_counts=True))},
                 "instance_iterations_per_step": inst_it_per_solve,
                 "backward_passes_per_iteration": n_bw,
                 "forward_passes_per_iteration": n_fw,
@@ -238,7 +256,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(wl, args.iters_per_solve, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(wl, args.mode, args.iters_per_solve, args.cpu_seconds)
             except Exception as e:  # the GPU number stands on its own; say why the baseline is missing
                 out["cpu_baseline"] = {"value": None, "unit": "DDP iterations/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": "failed: %r" % (e,)}
@@ -246,7 +264,7 @@ def main():
         if os.path.exists(traffic_file):
             try:
                 tf = json.load(open(traffic_file))
-                if (args.workload == "c2" and tf.get("batch") == wl.B
+                if (args.workload == "c2" and args.mode == "nominal" and tf.get("batch") == wl.B
                         and tf.get("iterations_per_step") == args.iters_per_solve):
                     out["roofline"]["traffic"] = tf.get("hbm_bytes_per_launch")
                     out["roofline"]["traffic_source"] = tf.get("source")

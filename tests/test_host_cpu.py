@@ -83,6 +83,15 @@ def test_misuse_is_reported_not_crashed():
     assert L.nmpc_hip_ddp_destroy(None) == 0
     buf = (C.c_double * 3)()
     assert L.nmpc_hip_ddp_model_default_params(b"cartpole", buf, 24) == _capi.ERR_INVALID_ARGUMENT
+    # receding-horizon entry points
+    opt = _capi.MpcOptions()
+    assert L.nmpc_hip_ddp_mpc_default_options(None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.nmpc_hip_ddp_mpc_default_options(C.byref(opt)) == 0
+    assert (opt.n_ticks, opt.shift_warm_start, opt.max_iter_after_first, opt.sim_substeps, opt.sim_dt, opt.clamp_u0) \
+        == (1, 1, 0, 0, 0.0, 1)
+    assert L.nmpc_hip_ddp_mpc_run(None, None, None, None, C.byref(opt), None, None, None, None, None, None, None,
+                                  None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.nmpc_hip_ddp_kernel_name(None, None) == _capi.ERR_INVALID_ARGUMENT
 
 
 def test_no_cpu_fallback_without_a_gpu():

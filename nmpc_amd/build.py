@@ -16,7 +16,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(ROOT, "nmpc_amd", "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libnmpc_hip_ddp.so")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
-SOURCES = ("capi.hip", "builtin_models.hip", "builder_models.hip")
+SOURCES = ("capi.hip", "builtin_models.hip", "model_centroidal.hip", "model_quadrotor.hip", "model_manipulator.hip")
 ARCH = "gfx950"
 
 

@@ -33,7 +33,7 @@ namespace hip
 {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template<class Problem>
+template<class Problem, bool kConstrained = false>
 struct WaveSolver
 {
   static constexpr int N = Problem::kStateDim;
@@ -44,6 +44,7 @@ struct WaveSolver
       per-lane register copies of the M x M blocks: for inputDim(t) problems and for m > 8 (16 x 16 doubles do not fit a
       lane's registers).  Centroidal motion (n 9, m 16 / 0) takes this path. */
   static constexpr bool kLdsGains = Problem::kDynamicInput || MM > 8;
+  static_assert(!(kConstrained && kLdsGains), "BoxQP is implemented on the register path only (static m <= 8)");
   using Lane = InstanceSolver<Problem, false>; // for the shared scalar helpers (ldltInPlace, ...)
   using StateDimVector = typename Problem::StateDimVector;
   using InputDimVector = typename Problem::InputDimVector;
@@ -503,6 +504,12 @@ struct WaveSolver
         pf[q] = d[64 * q + lane];
       }
     }
+    double k_next[MM]; // constrained solves: k of the previous (later) timestep, the BoxQP warm start
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      k_next[a] = 0;
+    }
     for(int i = T - 1; i >= 0; i--)
     {
       // ---- stage this timestep's derivatives
@@ -662,6 +669,79 @@ struct WaveSolver
         Qu[a] = vec(vQu)[a];
         kff[a] = 0;
       }
+      double Kcol[MM], Quxcol[MM];
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        Kcol[a] = 0;
+        Quxcol[a] = 0;
+      }
+      if constexpr(kConstrained)
+      {
+        // ---- box-constrained gains    :450-497: every lane solves the same small QP (BoxQP.h:141-347, the lane kernel's
+        // implementation), lane c then solves column c of K on the free rows
+        double initial_k[MM], lo[MM], up[MM];
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          initial_k[a] = (i != T - 1) ? k_next[a] : 0.0; // warm start from k_{i+1} (same dimension), :452-467
+          lo[a] = buf.lim_lo[a] - vec(vU)[a]; // :470-472
+          up[a] = buf.lim_hi[a] - vec(vU)[a];
+        }
+        const Lane lane_code(problem, cfg, buf, b);
+        typename Lane::QPOut qp;
+        lane_code.boxQP(M, fac, Qu, lo, up, initial_k, qp);
+        unsigned free_mask = 0;
+        for(int j = 0; j < qp.n_free; j++)
+        {
+          free_mask |= (1u << qp.free_idx[j]);
+        }
+        if(lane == 0)
+        {
+          const size_t tl = static_cast<size_t>(b) / kLanesPerBlock, ln = static_cast<size_t>(b) % kLanesPerBlock;
+          buf.qp_ret[(tl * T + i) * kLanesPerBlock + ln] = qp.retval;
+          buf.qp_free[(tl * T + i) * kLanesPerBlock + ln] = free_mask;
+        }
+        if(qp.retval < 0)
+        {
+          res.ok = false; // :473-480
+          return res;
+        }
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          kff[a] = qp.x[a];
+          k_next[a] = qp.x[a];
+        }
+        if(lane < N)
+        {
+#pragma unroll
+          for(int a = 0; a < MM; a++)
+          {
+            Quxcol[a] = tile(tQux)[a + LD * lane];
+          }
+          if(qp.n_free > 0)
+          {
+            double col[MM];
+            for(int j = 0; j < qp.n_free; j++)
+            {
+              col[j] = tile(tQuxR)[qp.free_idx[j] + LD * lane];
+            }
+            Lane::template ldltSolveInPlace<MM, 1>(qp.fac, qp.inv_d, qp.n_free, col);
+            for(int j = 0; j < qp.n_free; j++)
+            {
+              Kcol[qp.free_idx[j]] = -1 * col[j];
+            }
+          }
+#pragma unroll
+          for(int a = 0; a < MM; a++)
+          {
+            tile(tK)[a + LD * lane] = Kcol[a];
+          }
+        }
+      }
+      else
+      {
       if(!Lane::template ldltInPlace<MM>(fac, inv_d, M))
       {
         res.ok = false; // wave-uniform: every lane factorised the same matrix
@@ -678,13 +758,6 @@ struct WaveSolver
       {
         kff[a] = -1 * kff[a];
       }
-      double Kcol[MM], Quxcol[MM];
-#pragma unroll
-      for(int a = 0; a < MM; a++)
-      {
-        Kcol[a] = 0;
-        Quxcol[a] = 0;
-      }
       if(lane < N)
       {
 #pragma unroll
@@ -700,6 +773,7 @@ struct WaveSolver
           Kcol[a] = -1 * Kcol[a];
           tile(tK)[a + LD * lane] = Kcol[a];
         }
+      }
       }
 
       // ---- cost-to-go    :522-526
@@ -1559,14 +1633,15 @@ struct WaveSolver
 };
 
 /** The wave-per-instance solve kernel: grid = B workgroups of one wavefront. */
-template<class Problem>
+template<class Problem, bool kConstrained>
 __global__ __launch_bounds__(kLanesPerBlock)
-    __attribute__((amdgpu_waves_per_eu(WaveSolver<Problem>::kWavesPerSimd, WaveSolver<Problem>::kWavesPerSimd))) void ddp_solve_wpi_kernel(const Problem problem,
+    __attribute__((amdgpu_waves_per_eu(WaveSolver<Problem, kConstrained>::kWavesPerSimd,
+                                       WaveSolver<Problem, kConstrained>::kWavesPerSimd))) void ddp_solve_wpi_kernel(const Problem problem,
                                                                         const nmpc_hip_ddp_config cfg,
                                                                         const DeviceBuffers buf)
 {
   extern __shared__ __attribute__((aligned(16))) double lds_wpi[];
-  WaveSolver<Problem> solver(problem, cfg, buf, static_cast<int>(blockIdx.x), lds_wpi);
+  WaveSolver<Problem, kConstrained> solver(problem, cfg, buf, static_cast<int>(blockIdx.x), lds_wpi);
   solver.solve();
 }
 } // namespace hip

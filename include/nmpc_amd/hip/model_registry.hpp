@@ -72,10 +72,12 @@ struct ModelOpsFor
       (checked at launch). */
   static constexpr bool kWpiShape =
       Problem::kStateDim >= 9 && Problem::kStateDim <= 16 && Problem::kInputDimMax >= 1 && Problem::kInputDimMax <= 16;
+  //! box-constrained solves on the wave-per-instance kernel: register-path shapes only (static m <= 8)
+  static constexpr bool kWpiBoxQP = kWpiShape && !Problem::kDynamicInput && Problem::kInputDimMax <= 8;
   static bool useWpi(bool constrained)
   {
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
-    return kWpiShape && !constrained && !(force && std::strcmp(force, "1w") == 0);
+    return kWpiShape && (!constrained || kWpiBoxQP) && !(force && std::strcmp(force, "1w") == 0);
   }
   static size_t wpiWorkspaceDoubles(int T)
   {
@@ -90,7 +92,7 @@ struct ModelOpsFor
   }
   static const char * kernelName()
   {
-    if(useWpi(false))
+    if(useWpi(false)) // (a box-constrained solve of an LDS-gains shape still goes to the lane kernel, see launchSolve)
     {
       return "ddp_solve_wpi_kernel";
     }
@@ -108,8 +110,18 @@ struct ModelOpsFor
     {
       if(useWpi(cfg.with_input_constraint != 0) && buf.wpi_ws != nullptr)
       {
-        hipLaunchKernelGGL((ddp_solve_wpi_kernel<Problem>), dim3(buf.B), dim3(kLanesPerBlock),
-                           WaveSolver<Problem>::kLdsBytes, stream, problem, cfg, buf);
+        constexpr size_t wpi_lds = WaveSolver<Problem, false>::kLdsBytes; // same layout with and without BoxQP
+        if constexpr(kWpiBoxQP)
+        {
+          if(cfg.with_input_constraint)
+          {
+            hipLaunchKernelGGL((ddp_solve_wpi_kernel<Problem, true>), dim3(buf.B), dim3(kLanesPerBlock), wpi_lds, stream,
+                               problem, cfg, buf);
+            return hipGetLastError();
+          }
+        }
+        hipLaunchKernelGGL((ddp_solve_wpi_kernel<Problem, false>), dim3(buf.B), dim3(kLanesPerBlock), wpi_lds, stream,
+                           problem, cfg, buf);
         return hipGetLastError();
       }
     }

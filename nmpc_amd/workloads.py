@@ -94,17 +94,19 @@ def _normal_from_uniform(u1: np.ndarray, u2: np.ndarray) -> np.ndarray:
     return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
 
 
-def quadrotor_batch(B: int = 8192, T: int = 50, seed: int = 1234) -> Workload:
+def quadrotor_batch(B: int = 8192, T: int = 50, seed: int = 1234, constrained: bool = False) -> Workload:
     """C4: hover perturbation x0 ~ N(0, 0.3^2) around (0,0,1) (Box-Muller on the splitmix stream), u_init = hover
     thrust m g / 4, dt = 0.02."""
     u = splitmix64_uniform(seed, 24 * B).reshape(B, 24)
     x0 = 0.3 * _normal_from_uniform(u[:, :12], u[:, 12:])
     x0[:, 2] += 1.0
     hover = 1.0 * 9.80665 / 4
-    return Workload("quadrotor_batch", "quadrotor", 12, 4, T, B, 0.02, x0, np.full((B, T, 4), hover), np.zeros(B))
+    limits = (np.full(4, 0.7 * hover), np.full(4, 1.3 * hover)) if constrained else None  # rotor thrust box
+    return Workload("quadrotor_batch", "quadrotor", 12, 4, T, B, 0.02, x0, np.full((B, T, 4), hover), np.zeros(B),
+                    limits=limits)
 
 
-def manipulator_batch(B: int = 8192, T: int = 30, seed: int = 1234) -> Workload:
+def manipulator_batch(B: int = 8192, T: int = 30, seed: int = 1234, constrained: bool = False) -> Workload:
     """C5 (per-GPU shard): q0 ~ U[-1,1]^7, qd0 ~ U[-0.5,0.5]^7, u_init = gravity compensation at q0, dt = 0.01."""
     u = splitmix64_uniform(seed, 14 * B).reshape(B, 14)
     q0 = -1.0 + 2.0 * u[:, :7]
@@ -112,8 +114,9 @@ def manipulator_batch(B: int = 8192, T: int = 30, seed: int = 1234) -> Workload:
     x0 = np.concatenate([q0, qd0], axis=1)
     grav = 4.0 * (7 - np.arange(7)) / 7.0
     u_gc = grav[None, :] * np.sin(np.cumsum(q0, axis=1))
+    limits = (np.full(7, -3.0), np.full(7, 3.0)) if constrained else None  # joint torque box
     return Workload("manipulator_batch", "manipulator", 14, 7, T, B, 0.01, x0,
-                    np.repeat(u_gc[:, None, :], T, axis=1).copy(), np.zeros(B))
+                    np.repeat(u_gc[:, None, :], T, axis=1).copy(), np.zeros(B), limits=limits)
 
 
 def algorithmic_words_per_instance_iteration(n: int, m: int, T: int, n_bw: float = 1.0, n_fw: float = 1.0) -> float:

@@ -528,3 +528,40 @@ def test_wave_per_instance_kernel_failure_status():
     np.testing.assert_array_equal(s.status(), ref.status)
     np.testing.assert_array_equal(s.iters(), ref.iters)
     np.testing.assert_array_equal(s.traceLast()[:, INT_COLS], ref.trace_last[:, INT_COLS])
+
+
+@pytest.mark.parametrize("model", ["quadrotor", "manipulator"])
+def test_wave_per_instance_kernel_box_constrained(model, monkeypatch):
+    """with_input_constraint on the matrix-core kernel (every lane runs the same BoxQP, lane c solves column c of K on the
+    free rows), against the oracle and the lane kernel.  Tightly boxed problems spend iterations in rejected line
+    searches, where the reference algorithm is not decision-stable: indices are compared on the oracle's
+    decision-stable set, as for the box-constrained vertical-motion problem."""
+    from nmpc_amd import workloads
+    wl = (workloads.quadrotor_batch(B=64, T=50, seed=31, constrained=True) if model == "quadrotor" else
+          workloads.manipulator_batch(B=64, T=30, seed=32, constrained=True))
+    cfg = dict(with_input_constraint=True, max_iter=10)
+    monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    s = make_solver(wl, **cfg)
+    assert s.kernelName() == "ddp_solve_wpi_kernel"
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_batch(wl, **cfg)
+    stable = decision_stable_mask(wl, ref, **cfg)
+    assert stable.mean() >= 0.75
+    check_against_oracle(wl, s, ref, mask=stable)
+    ocfg = oracle.default_config(horizon_steps=wl.T, with_input_constraint=1, max_iter=10)
+    qret, qfree = s.qpRetval(), s.qpFreeMask()
+    n_clamped = 0
+    for b in np.nonzero(stable)[0][::7]:
+        r = oracle.solve(wl.model, ocfg, wl.x0[b], wl.u_init[b], lower=wl.limits[0], upper=wl.limits[1])
+        if r.status < 0:
+            continue
+        np.testing.assert_array_equal(qret[b], r.qp_retval)
+        np.testing.assert_array_equal(qfree[b], r.qp_free_mask)
+        n_clamped += int((r.qp_free_mask != (1 << wl.m) - 1).sum())
+    assert n_clamped > 0, "the sample never hit the bounds"
+    monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", "1w")
+    s1 = make_solver(wl, **cfg)
+    s1.solve(wl.t0, wl.x0, wl.u_init)
+    assert np.array_equal(s.status()[stable], s1.status()[stable]) and np.array_equal(s.iters()[stable], s1.iters()[stable])
+    assert np.array_equal(qret[stable], s1.qpRetval()[stable]) and np.array_equal(qfree[stable], s1.qpFreeMask()[stable])
+    assert scaled_err(s.X()[stable], s1.X()[stable]) <= TOL and scaled_err(s.U()[stable], s1.U()[stable]) <= TOL

@@ -22,7 +22,7 @@
 //
 // Scope: unconstrained solves, 9 <= n <= 16, m <= 16, static or time-varying input dimension (inputDim(t) and m > 8 take
 // the gains through LDS: cooperative L D L^T, per-lane column solves; centroidal motion n 9, m 16 / 0).  Box-constrained
-// solves (BoxQP) stay on the lane-per-instance kernel.
+// solves (BoxQP): static m <= 8 here (kConstrained), everything else on the lane-per-instance kernel.
 #pragma once
 
 #include <nmpc_amd/hip/ddp_kernels.hpp>

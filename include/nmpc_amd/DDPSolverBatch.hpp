@@ -174,6 +174,20 @@ public:
     }
   }
 
+  /** \brief One problem object per instance — the batch then behaves like `batch` DDPSolver objects each constructed
+      with its own problem (DDPSolver.hpp:20-24).  An empty vector goes back to the shared problem.  dt() and
+      inputDim(t) must be those of the shared problem. */
+  inline void setProblemBatch(const std::vector<Problem> & problems)
+  {
+    if(!problems.empty() && static_cast<int>(problems.size()) != batch_size_)
+    {
+      throw std::invalid_argument("problem batch should be " + std::to_string(batch_size_) + " but "
+                                  + std::to_string(problems.size()) + ".");
+    }
+    problem_batch_ = problems;
+    problem_batch_dirty_ = true;
+  }
+
   /** \brief Solve optimization for every instance of the batch (DDPSolver::solve, DDPSolver.h:275).
       \param current_t current time of each instance [sec] (size batch)
       \param current_x current state of each instance (size batch)
@@ -336,11 +350,18 @@ protected:
     handle_ = nullptr;
     check(nmpc_hip_ddp_create(Problem::kName, config_.horizon_steps, batch_size_, device_, &handle_));
     handle_T_ = config_.horizon_steps;
+    problem_batch_dirty_ = !problem_batch_.empty(); // a new handle starts with the shared problem
   }
 
   void pushState()
   {
     check(nmpc_hip_ddp_set_model_params(handle_, problem_.get(), sizeof(Problem)));
+    if(problem_batch_dirty_)
+    {
+      check(nmpc_hip_ddp_set_model_params_batch(handle_, problem_batch_.empty() ? nullptr : problem_batch_.data(),
+                                                sizeof(Problem)));
+      problem_batch_dirty_ = false;
+    }
     nmpc_hip_ddp_config c;
     nmpc_hip_ddp_default_config(&c);
     c.with_input_constraint = config_.with_input_constraint ? 1 : 0;
@@ -522,6 +543,8 @@ protected:
   double lower_[MM];
   double upper_[MM];
   bool fetched_ = false;
+  std::vector<Problem> problem_batch_;
+  bool problem_batch_dirty_ = false;
   std::vector<ControlData> control_data_;
   std::vector<std::vector<TraceData>> trace_data_list_;
   std::vector<std::vector<InputDimVector>> k_list_;

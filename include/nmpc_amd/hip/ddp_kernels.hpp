@@ -60,6 +60,7 @@ struct DeviceBuffers
   unsigned * qp_free; //!< [tile][T][64]
   int * input_dim; //!< [tile][T][64]
   double * wpi_ws; //!< wave-per-instance kernel only (ddp_kernels_wpi.hpp): [B][WaveSolver::workspaceDoubles(T)]
+  const unsigned char * params_batch; //!< per-instance problem objects [Bp][sizeof(Problem)], or nullptr: one for all
   double lim_lo[kMaxInputDim]; //!< input lower limits (constant in time)
   double lim_hi[kMaxInputDim]; //!< input upper limits
 };
@@ -80,6 +81,27 @@ struct Unroll
   static constexpr int kFactor = kFull ? 64 : ((N * N * (N + MM) <= 2400) ? 16 : 8);
 };
 } // namespace detail
+
+/** The problem object instance b solves: the handle's shared one, or its own when per-instance objects were given
+    (nmpc_hip_ddp_set_model_params_batch: a batch of solvers with different robots / weights). */
+template<class Problem>
+NMPC_D Problem instanceProblem(const Problem & shared, const DeviceBuffers & buf, int b)
+{
+  Problem mine = shared;
+  if(buf.params_batch != nullptr)
+  {
+    // trivially copyable (static_assert in model_registry.hpp): word-wise copy keeps the loads coalescable per field
+    constexpr size_t kWords = sizeof(Problem) / sizeof(unsigned);
+    const unsigned * src = reinterpret_cast<const unsigned *>(buf.params_batch + static_cast<size_t>(b) * sizeof(Problem));
+    unsigned * dst = reinterpret_cast<unsigned *>(&mine);
+#pragma unroll
+    for(size_t w = 0; w < kWords; w++)
+    {
+      dst[w] = src[w];
+    }
+  }
+  return mine;
+}
 
 /** One DDP problem instance, executed by one lane.
     \tparam kConstrained compile-time value of Configuration::with_input_constraint (DDPSolver.h:70): the

@@ -1280,7 +1280,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 };
 
 /** The 2-wave solve kernel: grid = Bp / 64 workgroups of 128 threads; wave 0 = master, wave 1 = helper. */
-template<class Problem, bool kConstrained>
+template<class Problem, bool kConstrained, bool kOwnProblem = false>
 __global__ __launch_bounds__(2 * kLanesPerBlock) void ddp_solve_tpi2w_kernel(const Problem problem,
                                                                               const nmpc_hip_ddp_config cfg,
                                                                               const DeviceBuffers buf)
@@ -1289,7 +1289,10 @@ __global__ __launch_bounds__(2 * kLanesPerBlock) void ddp_solve_tpi2w_kernel(con
   extern __shared__ __attribute__((aligned(16))) double lds_2w[];
   const int wave = threadIdx.x / kLanesPerBlock;
   const int b = blockIdx.x * kLanesPerBlock + (threadIdx.x % kLanesPerBlock);
-  Solver solver(problem, cfg, buf, b, lds_2w);
+  // kOwnProblem: every instance has its own problem object (nmpc_hip_ddp_set_model_params_batch).  A separate
+  // instantiation: with it the problem's fields live in VGPRs, which costs the shared-object kernel ~1 % if merged in.
+  const Problem mine = kOwnProblem ? instanceProblem(problem, buf, b) : problem;
+  Solver solver(mine, cfg, buf, b, lds_2w);
   if(wave == 0)
   {
     solver.solveMaster(b < buf.B);

@@ -1633,7 +1633,7 @@ struct WaveSolver
 };
 
 /** The wave-per-instance solve kernel: grid = B workgroups of one wavefront. */
-template<class Problem, bool kConstrained>
+template<class Problem, bool kConstrained, bool kOwnProblem = false>
 __global__ __launch_bounds__(kLanesPerBlock)
     __attribute__((amdgpu_waves_per_eu(WaveSolver<Problem, kConstrained>::kWavesPerSimd,
                                        WaveSolver<Problem, kConstrained>::kWavesPerSimd))) void ddp_solve_wpi_kernel(const Problem problem,
@@ -1641,7 +1641,8 @@ __global__ __launch_bounds__(kLanesPerBlock)
                                                                         const DeviceBuffers buf)
 {
   extern __shared__ __attribute__((aligned(16))) double lds_wpi[];
-  WaveSolver<Problem, kConstrained> solver(problem, cfg, buf, static_cast<int>(blockIdx.x), lds_wpi);
+  const Problem mine = kOwnProblem ? instanceProblem(problem, buf, static_cast<int>(blockIdx.x)) : problem;
+  WaveSolver<Problem, kConstrained> solver(mine, cfg, buf, static_cast<int>(blockIdx.x), lds_wpi);
   solver.solve();
 }
 } // namespace hip

@@ -106,22 +106,35 @@ struct ModelOpsFor
     Problem problem;
     std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
     const int grid = buf.Bp / kLanesPerBlock;
+    const bool own = buf.params_batch != nullptr; // per-instance problem objects: separate instantiations (kOwnProblem)
+    const bool con = cfg.with_input_constraint != 0;
     if constexpr(kWpiShape)
     {
-      if(useWpi(cfg.with_input_constraint != 0) && buf.wpi_ws != nullptr)
+      if(useWpi(con) && buf.wpi_ws != nullptr)
       {
         constexpr size_t wpi_lds = WaveSolver<Problem, false>::kLdsBytes; // same layout with and without BoxQP
+        const dim3 g(buf.B), blk(kLanesPerBlock);
         if constexpr(kWpiBoxQP)
         {
-          if(cfg.with_input_constraint)
+          if(con && own)
           {
-            hipLaunchKernelGGL((ddp_solve_wpi_kernel<Problem, true>), dim3(buf.B), dim3(kLanesPerBlock), wpi_lds, stream,
-                               problem, cfg, buf);
+            hipLaunchKernelGGL((ddp_solve_wpi_kernel<Problem, true, true>), g, blk, wpi_lds, stream, problem, cfg, buf);
+            return hipGetLastError();
+          }
+          if(con)
+          {
+            hipLaunchKernelGGL((ddp_solve_wpi_kernel<Problem, true, false>), g, blk, wpi_lds, stream, problem, cfg, buf);
             return hipGetLastError();
           }
         }
-        hipLaunchKernelGGL((ddp_solve_wpi_kernel<Problem, false>), dim3(buf.B), dim3(kLanesPerBlock), wpi_lds, stream,
-                           problem, cfg, buf);
+        if(own)
+        {
+          hipLaunchKernelGGL((ddp_solve_wpi_kernel<Problem, false, true>), g, blk, wpi_lds, stream, problem, cfg, buf);
+        }
+        else
+        {
+          hipLaunchKernelGGL((ddp_solve_wpi_kernel<Problem, false, false>), g, blk, wpi_lds, stream, problem, cfg, buf);
+        }
         return hipGetLastError();
       }
     }
@@ -131,33 +144,32 @@ struct ModelOpsFor
       {
         using Pair = PairSolver<Problem, false>; // record layout does not depend on kConstrained
         constexpr size_t lds_bytes = Pair::kLdsBytes;
-        if constexpr(lds_bytes > 64 * 1024)
+        static_assert(lds_bytes <= 64 * 1024, "kFits keeps the records within the default dynamic LDS limit");
+        const dim3 g(grid), blk(2 * kLanesPerBlock);
+        if(con && own)
         {
-          static const hipError_t attr_rc = []() {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ddp_solve_tpi2w_kernel<Problem, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-            hipError_t f = hipFuncSetAttribute(reinterpret_cast<const void *>(&ddp_solve_tpi2w_kernel<Problem, false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-            return e != hipSuccess ? e : f;
-          }();
-          if(attr_rc != hipSuccess)
-          {
-            return attr_rc;
-          }
+          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, true, true>), g, blk, lds_bytes, stream, problem, cfg, buf);
         }
-        if(cfg.with_input_constraint)
+        else if(con)
         {
-          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, true>), dim3(grid), dim3(2 * kLanesPerBlock), lds_bytes,
-                             stream, problem, cfg, buf);
+          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, true, false>), g, blk, lds_bytes, stream, problem, cfg, buf);
+        }
+        else if(own)
+        {
+          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, false, true>), g, blk, lds_bytes, stream, problem, cfg, buf);
         }
         else
         {
-          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, false>), dim3(grid), dim3(2 * kLanesPerBlock), lds_bytes,
-                             stream, problem, cfg, buf);
+          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, false, false>), g, blk, lds_bytes, stream, problem, cfg, buf);
         }
+        return hipGetLastError();
       }
     }
-    else if(cfg.with_input_constraint)
+    if(own)
+    {
+      return hipErrorNotSupported; // the single-wavefront kernel has no per-instance-problem instantiation
+    }
+    if(con)
     {
       hipLaunchKernelGGL((ddp_solve_tpi_kernel<Problem, true>), dim3(grid), dim3(kLanesPerBlock), 0, stream, problem, cfg,
                          buf);

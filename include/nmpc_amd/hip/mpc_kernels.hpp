@@ -58,7 +58,7 @@ struct HasPlantStep<Problem,
 };
 
 template<class Problem>
-__global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Problem problem,
+__global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Problem shared_problem,
                                                                      const DeviceBuffers buf,
                                                                      const MpcAdvanceArgs args)
 {
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
   {
     return;
   }
+  const Problem problem = instanceProblem(shared_problem, buf, b); // its own object if the batch has per-instance ones
   const size_t tile = static_cast<size_t>(b) / LW, lane = static_cast<size_t>(b) % LW;
   const int T = buf.T;
   const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;

@@ -141,6 +141,14 @@ extern "C"
   /** The problem object the solver co-owns (DDPSolver.h:332): overwrite it with a caller-built blob. */
   int nmpc_hip_ddp_set_model_params(nmpc_hip_ddp_handle h, const void * params, size_t bytes);
 
+  /** One problem object PER INSTANCE: params points to batch blobs of bytes_per_instance = param_bytes each (instance b at
+      params + b * bytes_per_instance); NULL goes back to the shared object.  The reference equivalent is a batch of
+      DDPSolver objects each constructed with its own problem (DDPSolver.hpp:20-24): different robots, weights or
+      reference trajectories in one launch.  Restrictions: dt() and inputDim(t) must be the same for every instance (they
+      define the shape of the batch); served by the model's default kernel (two-wavefront / wave-per-instance), a solve
+      that would need the single-wavefront kernel reports NMPC_HIP_ERR_RUNTIME. */
+  int nmpc_hip_ddp_set_model_params_batch(nmpc_hip_ddp_handle h, const void * params, size_t bytes_per_instance);
+
   /** problem->inputDim(t0 + i * dt) for i < horizon_steps, evaluated on the host from the handle's problem object:
       what DDPSolver::solve validates initial_u_list against (DDPSolver.hpp:46-58).  out has room for T ints. */
   int nmpc_hip_ddp_input_dims(nmpc_hip_ddp_handle h, double t0, int * out);

@@ -99,6 +99,7 @@ struct nmpc_hip_ddp_solver
   unsigned * d_qp_free = nullptr;
   int * d_input_dim = nullptr;
   double * d_wpi_ws = nullptr; // wave-per-instance kernel workspace (large models only)
+  unsigned char * d_params_batch = nullptr; // [Bp][param_bytes] per-instance problem objects, or nullptr
   int trace_rows = 0;
   // staging in the reference layouts
   void * d_stage_in = nullptr; // x0 / u_init / t0 as handed over by the host entry point
@@ -175,6 +176,7 @@ DeviceBuffers makeBuffers(const nmpc_hip_ddp_solver * s)
   b.qp_free = s->d_qp_free;
   b.input_dim = s->d_input_dim;
   b.wpi_ws = s->d_wpi_ws;
+  b.params_batch = s->d_params_batch;
   for(int i = 0; i < nmpc_amd::hip::kMaxInputDim; i++)
   {
     b.lim_lo[i] = s->lim_lo[i];
@@ -415,7 +417,15 @@ int launchRecorded(nmpc_hip_ddp_solver * s,
   }
   NMPC_HIP_TRY(hipEventRecord(s->ev_kernel[slot], st));
   const DeviceBuffers buf = makeBuffers(s);
-  NMPC_HIP_TRY(s->ops->launch_solve(s->params.data(), s->cfg, buf, st));
+  {
+    const hipError_t le = s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
+    if(le == hipErrorNotSupported)
+    {
+      return fail(NMPC_HIP_ERR_RUNTIME, "per-instance problem objects (set_model_params_batch) are served by the model's "
+                                        "default kernel only; this solve needs the single-wavefront kernel");
+    }
+    NMPC_HIP_TRY(le);
+  }
   NMPC_HIP_TRY(hipEventRecord(s->ev_end[slot], st));
   s->ev_pending[slot] = true;
   s->n_solves++;
@@ -670,7 +680,7 @@ extern "C"
     }
     void * ptrs[] = {s->d_t0,     s->d_x0,     s->d_X,   s->d_U,      s->d_cost,    s->d_kff,       s->d_Kfb,
                      s->d_trace,  s->d_trace_last, s->d_dV, s->d_status, s->d_iters, s->d_sel,     s->d_qp_ret,
-                     s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_stage_in, s->d_stage_out};
+                     s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_params_batch, s->d_stage_in, s->d_stage_out};
     for(void * p : ptrs)
     {
       if(p)
@@ -739,6 +749,56 @@ extern "C"
                                                      + " but " + std::to_string(bytes) + ".");
     }
     std::memcpy(s->params.data(), params, bytes);
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_set_model_params_batch(nmpc_hip_ddp_handle s, const void * params, size_t bytes_per_instance)
+  {
+    if(!s)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    if(!params)
+    {
+      if(s->d_params_batch)
+      {
+        NMPC_HIP_TRY(hipStreamSynchronize(s->stream));
+        NMPC_HIP_TRY(hipFree(s->d_params_batch));
+        s->d_params_batch = nullptr;
+      }
+      return NMPC_HIP_OK;
+    }
+    const size_t pb = s->ops->param_bytes;
+    if(bytes_per_instance != pb)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "params size per instance should be " + std::to_string(pb) + " but "
+                                                     + std::to_string(bytes_per_instance) + ".");
+    }
+    // dt() shapes the batch: it has to be the shared object's for every instance
+    const double dt_shared = s->ops->dt(s->params.data());
+    const unsigned char * src = static_cast<const unsigned char *>(params);
+    for(int b = 0; b < s->B; b++)
+    {
+      if(s->ops->dt(src + static_cast<size_t>(b) * pb) != dt_shared)
+      {
+        return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "instance " + std::to_string(b) + " has a different dt() than the "
+                                                       "handle's shared problem object");
+      }
+    }
+    if(!s->d_params_batch)
+    {
+      NMPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_params_batch), static_cast<size_t>(s->Bp) * pb));
+    }
+    // padding lanes (b >= B) run on the shared object
+    std::vector<unsigned char> host(static_cast<size_t>(s->Bp) * pb);
+    std::memcpy(host.data(), src, static_cast<size_t>(s->B) * pb);
+    for(int b = s->B; b < s->Bp; b++)
+    {
+      std::memcpy(host.data() + static_cast<size_t>(b) * pb, s->params.data(), pb);
+    }
+    NMPC_HIP_TRY(hipStreamSynchronize(s->stream));
+    NMPC_HIP_TRY(hipMemcpy(s->d_params_batch, host.data(), host.size(), hipMemcpyHostToDevice));
     return NMPC_HIP_OK;
   }
 

@@ -155,6 +155,7 @@ class DDPSolverBatch:
         _capi.check(self._L.nmpc_hip_ddp_create(self.problem.name.encode(), T, self.batch_size, self.device,
                                                 C.byref(self._h)))
         self._h_T = T
+        self._problem_batch_dirty = getattr(self, "_problem_batch", None) is not None  # a new handle starts shared
 
     def close(self):
         if getattr(self, "_h", None):
@@ -172,12 +173,29 @@ class DDPSolverBatch:
         self._ensure_handle()
         _capi.check(self._L.nmpc_hip_ddp_set_model_params(self._h, C.byref(self.problem.blob),
                                                           C.sizeof(self.problem.blob)))
+        if getattr(self, "_problem_batch_dirty", False):
+            if self._problem_batch is None:
+                _capi.check(self._L.nmpc_hip_ddp_set_model_params_batch(self._h, None, 0))
+            else:
+                nb = C.sizeof(self.problem.blob)
+                raw = b"".join(bytes(p.blob) for p in self._problem_batch)
+                _capi.check(self._L.nmpc_hip_ddp_set_model_params_batch(self._h, raw, nb))
+            self._problem_batch_dirty = False
         c = self._config.to_c()
         _capi.check(self._L.nmpc_hip_ddp_set_config(self._h, C.byref(c)))
         if self._limits is not None:
             lo, up = self._limits
             _capi.check(self._L.nmpc_hip_ddp_set_input_limits(
                 self._h, lo.ctypes.data_as(C.POINTER(C.c_double)), up.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def setProblemBatch(self, problems: Optional[Sequence[_Problem]]) -> None:
+        """One problem object per instance (a batch of DDPSolver objects each built with its own problem,
+        DDPSolver.hpp:20-24), or None to go back to the shared one.  dt and inputDim(t) must agree with the shared
+        problem."""
+        self._problem_batch = None if problems is None else list(problems)
+        if self._problem_batch is not None and len(self._problem_batch) != self.batch_size:
+            raise ValueError(f"problem batch should be {self.batch_size} but {len(self._problem_batch)}.")
+        self._problem_batch_dirty = True
 
     def inputDims(self, t0: float) -> np.ndarray:
         """problem->inputDim(t0 + i dt) for every step of the horizon."""

@@ -565,3 +565,49 @@ def test_wave_per_instance_kernel_box_constrained(model, monkeypatch):
     assert np.array_equal(s.status()[stable], s1.status()[stable]) and np.array_equal(s.iters()[stable], s1.iters()[stable])
     assert np.array_equal(qret[stable], s1.qpRetval()[stable]) and np.array_equal(qfree[stable], s1.qpFreeMask()[stable])
     assert scaled_err(s.X()[stable], s1.X()[stable]) <= TOL and scaled_err(s.U()[stable], s1.U()[stable]) <= TOL
+
+
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+def test_per_instance_problem_objects(model):
+    """nmpc_hip_ddp_set_model_params_batch: every instance solves its own problem object (different masses / lengths /
+    weights), as a batch of DDPSolver objects each built with its own problem would; instance by instance against the
+    oracle with the same parameters.  Covers the two-wavefront and the wave-per-instance kernel, and the MPC driver."""
+    import nmpc_amd
+    from nmpc_amd import workloads
+
+    rng = np.random.default_rng(55)
+    if model == "cartpole":
+        wl = workloads.cartpole_batch(B=70, T=60, seed=8)
+        probs, oparams = [], []
+        for b in range(wl.B):
+            kw = dict(cart_mass=float(rng.uniform(0.7, 1.5)), pole_mass=float(rng.uniform(0.3, 0.8)),
+                      pole_length=float(rng.uniform(1.0, 2.5)), running_u=float(rng.uniform(5e-4, 5e-3)))
+            probs.append(nmpc_amd.DDPProblemCartPole(cart_mass=kw["cart_mass"], pole_mass=kw["pole_mass"],
+                                                     pole_length=kw["pole_length"], running_u=[kw["running_u"]]))
+            oparams.append(oracle.default_params("cartpole", **kw))
+        max_iter = 25
+    else:
+        wl = workloads.quadrotor_batch(B=20, T=50, seed=8)
+        probs, oparams = [], []
+        for b in range(wl.B):
+            probs.append(nmpc_amd.DDPProblemQuadrotor(mass=float(rng.uniform(0.8, 1.3))))
+            oparams.append(oracle.default_params("quadrotor", mass=probs[-1].get("mass")))
+        max_iter = 8
+    s = make_solver(wl, max_iter=max_iter)
+    s.setProblemBatch(probs)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ocfg = oracle.default_config(horizon_steps=wl.T, max_iter=max_iter)
+    X, U, st, it = s.X(), s.U(), s.status(), s.iters()
+    differs = 0
+    for b in range(wl.B):
+        r = oracle.solve(wl.model, ocfg, wl.x0[b], wl.u_init[b], params=oparams[b])
+        assert st[b] == r.status and it[b] == r.iters
+        assert scaled_err(X[b], r.X) <= TOL and scaled_err(U[b], r.U) <= TOL
+        r_shared = oracle.solve(wl.model, ocfg, wl.x0[b], wl.u_init[b])
+        differs += int(np.abs(r_shared.U - r.U).max() > 1e-3)
+    assert differs > wl.B // 2  # the per-instance parameters really change the solutions
+    # back to the shared object
+    s.setProblemBatch(None)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_batch(wl, max_iter=max_iter)
+    assert np.array_equal(s.status(), ref.status) and scaled_err(s.X(), ref.X) <= TOL

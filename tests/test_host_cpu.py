@@ -92,6 +92,7 @@ def test_misuse_is_reported_not_crashed():
     assert L.nmpc_hip_ddp_mpc_run(None, None, None, None, C.byref(opt), None, None, None, None, None, None, None,
                                   None) == _capi.ERR_INVALID_ARGUMENT
     assert L.nmpc_hip_ddp_kernel_name(None, None) == _capi.ERR_INVALID_ARGUMENT
+    assert L.nmpc_hip_ddp_set_model_params_batch(None, None, 0) == _capi.ERR_INVALID_ARGUMENT
 
 
 def test_no_cpu_fallback_without_a_gpu():

@@ -201,7 +201,12 @@ def main():
     n_it = int(executed.sum())
     n_bw = float(rows[:, :, _capi.TRACE_COLUMNS.index("n_backward")][executed].sum()) / max(n_it, 1)
     n_fw = float(rows[:, :, _capi.TRACE_COLUMNS.index("n_forward")][executed].sum()) / max(n_it, 1)
-    inst_it_per_solve = float(iters.sum())
+    inst_it_per_solve = float(iters.sum())  # this rank's shard
+    # whole-job count: every rank solves its own instances (different seeds), so sum the executed iterations over ranks
+    job_it = torch.tensor([inst_it_per_solve], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(job_it, op=dist.ReduceOp.SUM)
+    job_it_per_solve = float(job_it[0])
     status = solver.status()
 
     if rank == 0:
@@ -210,7 +215,7 @@ def main():
         k_ms = kernel_ms / max(n_solves, 1)
         bytes_per_launch = words * 8.0 * inst_it_per_solve
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-        value = world * args.steps * (inst_it_per_solve / wl.B) / elapsed
+        value = args.steps * (job_it_per_solve / wl.B) / elapsed
         out = {
             "metric": "DDP iterations/s (whole node), batch=%d, T=%d" % (wl.B, wl.T),
             "value": value,
@@ -231,7 +236,7 @@ def main():
                 "iterations_per_step": args.iters_per_solve if args.mode != "m2" else 500,
                 "solves_per_s": world * args.steps * wl.B / elapsed,
                 "iteration_histogram": {str(k): int(v) for k, v in zip(*np.unique(iters, return_counts=True))},
-                "instance_iterations_per_step": inst_it_per_solve,
+                "instance_iterations_per_step": job_it_per_solve,
                 "backward_passes_per_iteration": n_bw,
                 "forward_passes_per_iteration": n_fw,
                 "status_counts": {str(k): int(v) for k, v in zip(*np.unique(status, return_counts=True))},

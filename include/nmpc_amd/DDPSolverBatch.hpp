@@ -174,6 +174,29 @@ public:
     }
   }
 
+  /** \brief Per-instance input limits (constant in time): limits[b] = {lower, upper} of instance b — a batch of
+      DDPSolver objects each with its own setInputLimitsFunc (DDPSolver.h:282-285).  An empty vector goes back to the
+      shared limits. */
+  inline void setInputLimitsBatch(const std::vector<std::array<InputDimVector, 2>> & limits)
+  {
+    if(!limits.empty() && static_cast<int>(limits.size()) != batch_size_)
+    {
+      throw std::invalid_argument("limits batch should be " + std::to_string(batch_size_) + " but "
+                                  + std::to_string(limits.size()) + ".");
+    }
+    limits_batch_lo_.assign(limits.size() * MM, -INFINITY);
+    limits_batch_up_.assign(limits.size() * MM, INFINITY);
+    for(size_t b = 0; b < limits.size(); b++)
+    {
+      for(int a = 0; a < MM && a < limits[b][0].size() && a < limits[b][1].size(); a++)
+      {
+        limits_batch_lo_[b * MM + a] = limits[b][0][a];
+        limits_batch_up_[b * MM + a] = limits[b][1][a];
+      }
+    }
+    limits_batch_dirty_ = true;
+  }
+
   /** \brief One problem object per instance — the batch then behaves like `batch` DDPSolver objects each constructed
       with its own problem (DDPSolver.hpp:20-24).  An empty vector goes back to the shared problem.  dt() and
       inputDim(t) must be those of the shared problem. */
@@ -351,6 +374,7 @@ protected:
     check(nmpc_hip_ddp_create(Problem::kName, config_.horizon_steps, batch_size_, device_, &handle_));
     handle_T_ = config_.horizon_steps;
     problem_batch_dirty_ = !problem_batch_.empty(); // a new handle starts with the shared problem
+    limits_batch_dirty_ = !limits_batch_lo_.empty();
   }
 
   void pushState()
@@ -361,6 +385,13 @@ protected:
       check(nmpc_hip_ddp_set_model_params_batch(handle_, problem_batch_.empty() ? nullptr : problem_batch_.data(),
                                                 sizeof(Problem)));
       problem_batch_dirty_ = false;
+    }
+    if(limits_batch_dirty_)
+    {
+      const bool none = limits_batch_lo_.empty();
+      check(nmpc_hip_ddp_set_input_limits_batch(handle_, none ? nullptr : limits_batch_lo_.data(),
+                                                none ? nullptr : limits_batch_up_.data()));
+      limits_batch_dirty_ = false;
     }
     nmpc_hip_ddp_config c;
     nmpc_hip_ddp_default_config(&c);
@@ -545,6 +576,8 @@ protected:
   bool fetched_ = false;
   std::vector<Problem> problem_batch_;
   bool problem_batch_dirty_ = false;
+  std::vector<double> limits_batch_lo_, limits_batch_up_;
+  bool limits_batch_dirty_ = false;
   std::vector<ControlData> control_data_;
   std::vector<std::vector<TraceData>> trace_data_list_;
   std::vector<std::vector<InputDimVector>> k_list_;

@@ -61,6 +61,7 @@ struct DeviceBuffers
   int * input_dim; //!< [tile][T][64]
   double * wpi_ws; //!< wave-per-instance kernel only (ddp_kernels_wpi.hpp): [B][WaveSolver::workspaceDoubles(T)]
   const unsigned char * params_batch; //!< per-instance problem objects [Bp][sizeof(Problem)], or nullptr: one for all
+  const double * lim_batch; //!< per-instance input limits [Bp][2][kMaxInputDim] (lower, upper), or nullptr: lim_lo / lim_hi
   double lim_lo[kMaxInputDim]; //!< input lower limits (constant in time)
   double lim_hi[kMaxInputDim]; //!< input upper limits
 };
@@ -81,6 +82,16 @@ struct Unroll
   static constexpr int kFactor = kFull ? 64 : ((N * N * (N + MM) <= 2400) ? 16 : 8);
 };
 } // namespace detail
+
+/** Input limits of instance b (constant in time): its own if per-instance limits were given, else the shared ones. */
+NMPC_D inline double inputLimitLo(const DeviceBuffers & buf, int b, int a)
+{
+  return buf.lim_batch ? buf.lim_batch[(static_cast<size_t>(b) * 2 + 0) * kMaxInputDim + a] : buf.lim_lo[a];
+}
+NMPC_D inline double inputLimitHi(const DeviceBuffers & buf, int b, int a)
+{
+  return buf.lim_batch ? buf.lim_batch[(static_cast<size_t>(b) * 2 + 1) * kMaxInputDim + a] : buf.lim_hi[a];
+}
 
 /** The problem object instance b solves: the handle's shared one, or its own when per-instance objects were given
     (nmpc_hip_ddp_set_model_params_batch: a batch of solvers with different robots / weights). */
@@ -967,8 +978,8 @@ struct InstanceSolver
           {
             // warm start from k_list_[i+1] when its size matches    :452-467
             initial_k[a] = (i != T - 1 && m_next == m) ? k_next[a] : 0.0;
-            lo[a] = buf.lim_lo[a] - u[a]; // :470-472
-            up[a] = buf.lim_hi[a] - u[a];
+            lo[a] = inputLimitLo(buf, b, a) - u[a]; // :470-472
+            up[a] = inputLimitHi(buf, b, a) - u[a];
           }
           QPOut qp;
           boxQP(m, Quu_F, Qu, lo, up, initial_k, qp);

@@ -141,6 +141,11 @@ extern "C"
   /** The problem object the solver co-owns (DDPSolver.h:332): overwrite it with a caller-built blob. */
   int nmpc_hip_ddp_set_model_params(nmpc_hip_ddp_handle h, const void * params, size_t bytes);
 
+  /** Per-instance input limits (constant in time): lower[batch][MM], upper[batch][MM]; both NULL go back to the shared
+      limits of nmpc_hip_ddp_set_input_limits.  Reference equivalent: a batch of DDPSolver objects, each with its own
+      setInputLimitsFunc (DDPSolver.h:282-285). */
+  int nmpc_hip_ddp_set_input_limits_batch(nmpc_hip_ddp_handle h, const double * lower, const double * upper);
+
   /** One problem object PER INSTANCE: params points to batch blobs of bytes_per_instance = param_bytes each (instance b at
       params + b * bytes_per_instance); NULL goes back to the shared object.  The reference equivalent is a batch of
       DDPSolver objects each constructed with its own problem (DDPSolver.hpp:20-24): different robots, weights or

@@ -100,6 +100,7 @@ struct nmpc_hip_ddp_solver
   int * d_input_dim = nullptr;
   double * d_wpi_ws = nullptr; // wave-per-instance kernel workspace (large models only)
   unsigned char * d_params_batch = nullptr; // [Bp][param_bytes] per-instance problem objects, or nullptr
+  double * d_lim_batch = nullptr; // [Bp][2][kMaxInputDim] per-instance input limits, or nullptr
   int trace_rows = 0;
   // staging in the reference layouts
   void * d_stage_in = nullptr; // x0 / u_init / t0 as handed over by the host entry point
@@ -177,6 +178,7 @@ DeviceBuffers makeBuffers(const nmpc_hip_ddp_solver * s)
   b.input_dim = s->d_input_dim;
   b.wpi_ws = s->d_wpi_ws;
   b.params_batch = s->d_params_batch;
+  b.lim_batch = s->d_lim_batch;
   for(int i = 0; i < nmpc_amd::hip::kMaxInputDim; i++)
   {
     b.lim_lo[i] = s->lim_lo[i];
@@ -680,7 +682,7 @@ extern "C"
     }
     void * ptrs[] = {s->d_t0,     s->d_x0,     s->d_X,   s->d_U,      s->d_cost,    s->d_kff,       s->d_Kfb,
                      s->d_trace,  s->d_trace_last, s->d_dV, s->d_status, s->d_iters, s->d_sel,     s->d_qp_ret,
-                     s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_params_batch, s->d_stage_in, s->d_stage_out};
+                     s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_params_batch, s->d_lim_batch, s->d_stage_in, s->d_stage_out};
     for(void * p : ptrs)
     {
       if(p)
@@ -749,6 +751,43 @@ extern "C"
                                                      + " but " + std::to_string(bytes) + ".");
     }
     std::memcpy(s->params.data(), params, bytes);
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_set_input_limits_batch(nmpc_hip_ddp_handle s, const double * lower, const double * upper)
+  {
+    if(!s || (lower == nullptr) != (upper == nullptr))
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle, or only one of lower / upper given");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    NMPC_HIP_TRY(hipStreamSynchronize(s->stream));
+    if(!lower)
+    {
+      if(s->d_lim_batch)
+      {
+        NMPC_HIP_TRY(hipFree(s->d_lim_batch));
+        s->d_lim_batch = nullptr;
+      }
+      return NMPC_HIP_OK;
+    }
+    constexpr int kMax = nmpc_amd::hip::kMaxInputDim;
+    std::vector<double> host(static_cast<size_t>(s->Bp) * 2 * kMax);
+    for(int b = 0; b < s->Bp; b++)
+    {
+      for(int a = 0; a < kMax; a++)
+      {
+        const bool valid = b < s->B && a < s->MM;
+        host[(static_cast<size_t>(b) * 2 + 0) * kMax + a] = valid ? lower[static_cast<size_t>(b) * s->MM + a] : -INFINITY;
+        host[(static_cast<size_t>(b) * 2 + 1) * kMax + a] = valid ? upper[static_cast<size_t>(b) * s->MM + a] : INFINITY;
+      }
+    }
+    if(!s->d_lim_batch)
+    {
+      NMPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_lim_batch), host.size() * sizeof(double)));
+    }
+    NMPC_HIP_TRY(hipMemcpy(s->d_lim_batch, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+    s->has_limits = true;
     return NMPC_HIP_OK;
   }
 

@@ -146,6 +146,17 @@ class DDPSolverBatch:
             up[:] = upper[0]
         self._limits = (lo, up)
 
+    def setInputLimitsBatch(self, lower, upper) -> None:
+        """Per-instance limits: lower, upper of shape (B, MM) (constant in time), or None, None to go back to the shared
+        ones.  A batch of DDPSolver objects each with its own setInputLimitsFunc."""
+        if lower is None and upper is None:
+            self._limits_batch = None
+        else:
+            lo = np.ascontiguousarray(np.asarray(lower, dtype=np.float64).reshape(self.batch_size, self.mm))
+            up = np.ascontiguousarray(np.asarray(upper, dtype=np.float64).reshape(self.batch_size, self.mm))
+            self._limits_batch = (lo, up)
+        self._limits_batch_dirty = True
+
     # ---- handle management ----
     def _ensure_handle(self):
         T = int(self._config.horizon_steps)
@@ -156,6 +167,7 @@ class DDPSolverBatch:
                                                 C.byref(self._h)))
         self._h_T = T
         self._problem_batch_dirty = getattr(self, "_problem_batch", None) is not None  # a new handle starts shared
+        self._limits_batch_dirty = getattr(self, "_limits_batch", None) is not None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -187,6 +199,15 @@ class DDPSolverBatch:
             lo, up = self._limits
             _capi.check(self._L.nmpc_hip_ddp_set_input_limits(
                 self._h, lo.ctypes.data_as(C.POINTER(C.c_double)), up.ctypes.data_as(C.POINTER(C.c_double))))
+        if getattr(self, "_limits_batch_dirty", False):
+            dp = C.POINTER(C.c_double)
+            if self._limits_batch is None:
+                _capi.check(self._L.nmpc_hip_ddp_set_input_limits_batch(self._h, None, None))
+            else:
+                lo, up = self._limits_batch
+                _capi.check(self._L.nmpc_hip_ddp_set_input_limits_batch(self._h, lo.ctypes.data_as(dp),
+                                                                        up.ctypes.data_as(dp)))
+            self._limits_batch_dirty = False
 
     def setProblemBatch(self, problems: Optional[Sequence[_Problem]]) -> None:
         """One problem object per instance (a batch of DDPSolver objects each built with its own problem,

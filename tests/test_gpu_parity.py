@@ -611,3 +611,43 @@ def test_per_instance_problem_objects(model):
     s.solve(wl.t0, wl.x0, wl.u_init)
     ref = oracle_batch(wl, max_iter=max_iter)
     assert np.array_equal(s.status(), ref.status) and scaled_err(s.X(), ref.X) <= TOL
+
+
+def test_per_instance_input_limits():
+    """nmpc_hip_ddp_set_input_limits_batch: every instance its own box (a batch of solvers each with its own
+    setInputLimitsFunc), against the oracle instance by instance; two-wavefront and wave-per-instance kernel.  Where the
+    GPU and the oracle disagree the oracle itself has to be decision-unstable for that instance (boxed
+    problems spend iterations in rejected line searches): a 1e-14 perturbation of x0 changes its own answer."""
+    from nmpc_amd import workloads
+    rng = np.random.default_rng(77)
+    for wl, max_iter in ((workloads.cartpole_batch(B=70, T=60, seed=21), 25), (workloads.manipulator_batch(B=24, T=30, seed=22), 8)):
+        mm = max(wl.m, 1)
+        half = rng.uniform(2.0, 20.0, (wl.B, 1)) if wl.model == "cartpole" else rng.uniform(1.5, 4.0, (wl.B, 1))
+        lo, up = -half * np.ones((1, mm)), half * np.ones((1, mm))
+        s = make_solver(wl, with_input_constraint=True, max_iter=max_iter)
+        s.setInputLimitsBatch(lo, up)
+        s.solve(wl.t0, wl.x0, wl.u_init)
+        ocfg = oracle.default_config(horizon_steps=wl.T, with_input_constraint=1, max_iter=max_iter)
+        X, st, it, qret = s.X(), s.status(), s.iters(), s.qpRetval()
+        agree = 0
+        for b in range(wl.B):
+            r = oracle.solve(wl.model, ocfg, wl.x0[b], wl.u_init[b], lower=lo[b], upper=up[b])
+            ok = st[b] == r.status and it[b] == r.iters and scaled_err(X[b], r.X) <= TOL
+            if ok and r.status >= 0:
+                assert np.array_equal(qret[b], r.qp_retval)
+            if not ok:
+                flips = False
+                for eps in (1e-14, -1e-14, 3e-14, 1e-13, 1e-12):
+                    rp = oracle.solve(wl.model, ocfg, wl.x0[b] * (1 + eps), wl.u_init[b], lower=lo[b], upper=up[b])
+                    flips |= rp.status != r.status or rp.iters != r.iters or np.abs(rp.U - r.U).max() > 1e-6
+                assert flips, f"{wl.model} instance {b}: GPU and oracle disagree on a decision-stable instance"
+            agree += int(ok)
+        assert agree >= 0.6 * wl.B
+        # the same box for everyone through the batch entry point == the shared entry point, bit for bit
+        s.setInputLimitsBatch(np.repeat(lo[:1], wl.B, 0), np.repeat(up[:1], wl.B, 0))
+        s.solve(wl.t0, wl.x0, wl.u_init)
+        Xb, itb = s.X().copy(), s.iters().copy()
+        s.setInputLimitsBatch(None, None)
+        s.setInputLimits(lo[0], up[0])
+        s.solve(wl.t0, wl.x0, wl.u_init)
+        assert np.array_equal(Xb, s.X()) and np.array_equal(itb, s.iters())

@@ -93,6 +93,7 @@ def test_misuse_is_reported_not_crashed():
                                   None) == _capi.ERR_INVALID_ARGUMENT
     assert L.nmpc_hip_ddp_kernel_name(None, None) == _capi.ERR_INVALID_ARGUMENT
     assert L.nmpc_hip_ddp_set_model_params_batch(None, None, 0) == _capi.ERR_INVALID_ARGUMENT
+    assert L.nmpc_hip_ddp_set_input_limits_batch(None, None, None) == _capi.ERR_INVALID_ARGUMENT
 
 
 def test_no_cpu_fallback_without_a_gpu():

@@ -27,10 +27,13 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the MI355X path cannot be built (there is no CPU fallback)")
 
 
+HOST_ONLY_HEADERS = ("DDPSolverBatch.hpp",)  # mirrors over the C-ABI: no translation unit of the library includes them
+
+
 def _headers():
     out = []
     for base, _, files in os.walk(INCLUDE):
-        out += [os.path.join(base, f) for f in files]
+        out += [os.path.join(base, f) for f in files if f not in HOST_ONLY_HEADERS]
     return out
 
 

@@ -213,3 +213,40 @@ def test_cpp_mirror_mpc_example(tmp_path):
     for b, row in enumerate(rows):
         assert abs(float(row[1]) - log.t_final[b]) <= 1e-9
         assert np.all(np.abs(np.array([float(v) for v in row[2:6]]) - log.x_final[b]) <= 1e-8)
+
+
+def test_closed_loop_with_per_instance_problems():
+    """Eight cart-poles with different masses / pole lengths / input boxes in one device-resident MPC run (plant pattern):
+    the solver kernel AND the plant step of the advance kernel use each instance's own problem object and limits."""
+    import nmpc_amd
+
+    B, T, ticks = 8, 100, 300
+    rng = np.random.default_rng(31)
+    probs, oparams, lo, up = [], [], [], []
+    for b in range(B):
+        kw = dict(cart_mass=float(rng.uniform(0.8, 1.4)), pole_mass=float(rng.uniform(0.3, 0.7)),
+                  pole_length=float(rng.uniform(1.5, 2.5)))
+        probs.append(nmpc_amd.DDPProblemCartPole(running_u=[0.01], **kw))
+        oparams.append(oracle.default_params("cartpole", running_u=0.01, **kw))
+        lim = float(rng.uniform(10.0, 20.0))
+        lo.append([-lim])
+        up.append([lim])
+    lo, up = np.array(lo), np.array(up)
+    x0 = np.tile(np.array([0.0, np.pi, 0.0, 0.0]), (B, 1))
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.DDPProblemCartPole(running_u=[0.01]), B)
+    c = s.config()
+    c.print_level = 0
+    c.horizon_steps = T
+    c.max_iter = 3
+    c.with_input_constraint = True
+    s.setProblemBatch(probs)
+    s.setInputLimitsBatch(lo, up)
+    log = s.mpcRun(0.0, x0, np.zeros((B, T, 1)), ticks, shift_warm_start=False, sim_substeps=2, sim_dt=0.002)
+    cfg = oracle.default_config(horizon_steps=T, max_iter=3, with_input_constraint=1)
+    for b in range(B):
+        ref = oracle.mpc_run("cartpole", cfg, x0[b], ticks, params=oparams[b], shift_warm_start=False, sim_substeps=2,
+                             sim_dt=0.002, lower=lo[b], upper=up[b])
+        assert scaled_err(log.x[b], ref.x) <= 1e-4 and scaled_err(log.u0[b], ref.u0) <= 1e-3
+        assert np.all(np.abs(log.u0[b]) <= up[b, 0] + 1e-12)
+    # the instances really behave differently
+    assert np.abs(log.x_final - log.x_final[0]).max() > 1e-2

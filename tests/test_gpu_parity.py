@@ -651,3 +651,32 @@ def test_per_instance_input_limits():
         s.setInputLimits(lo[0], up[0])
         s.solve(wl.t0, wl.x0, wl.u_init)
         assert np.array_equal(Xb, s.X()) and np.array_equal(itb, s.iters())
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/c_api.c: the C-ABI used from C99 (gcc, no C++ on the caller's side) gives the Python mirror's numbers."""
+    import os
+    import re
+    import subprocess
+    import nmpc_amd
+    from nmpc_amd import build as hip_build
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_api")
+    libdir = os.path.dirname(hip_build.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-O2", "-D_DEFAULT_SOURCE", f"-I{root}/include", f"{root}/examples/c_api.c", f"-L{libdir}",
+           "-lnmpc_hip_ddp", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = re.findall(r"instance (\d+) status (-?\d+) iter (\d+) u0 (\S+) \((\w+)\)", r.stdout)
+    assert len(rows) == 4
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.DDPProblemCartPole(), 4)
+    s.config().print_level = 0
+    x0 = np.array([[0.0, np.pi - 0.3 * b, 0.0, 0.0] for b in range(4)])
+    s.solve(0.0, x0, np.zeros((4, 100, 1)))
+    for b, (_, st, it, u0, kern) in enumerate(rows):
+        assert int(st) == int(s.status()[b]) and int(it) == int(s.iters()[b]) and kern == s.kernelName()
+        assert abs(float(u0) - s.U()[b, 0, 0]) <= 1e-10 * (1 + abs(float(u0)))
+    assert int(rows[0][2]) == 17

@@ -890,25 +890,55 @@ struct WaveSolver
       Same operation order as InstanceSolver::ldltSolveInPlace. */
   NMPC_D void solveColumnLds(double * col, int m) const
   {
+    // The column goes to registers and the loops are fully unrolled with masks: rolled loops would make every
+    // multiply-subtract wait for two dependent LDS reads (~130 cycles each time, m^2 times).  The reads of L are
+    // wave-uniform broadcasts and independent of the arithmetic, so they stream.
     const double * L = tile(tQuuF);
     const double * inv_d = vec(vInvD);
-    for(int i = 0; i < m; i++)
+    double x[MM];
+#pragma unroll
+    for(int i = 0; i < MM; i++)
     {
-      double s = col[i];
-      for(int j = 0; j < i; j++)
-      {
-        s -= L[i + LD * j] * col[j];
-      }
-      col[i] = s;
+      x[i] = (i < m) ? col[i] : 0.0;
     }
-    for(int i = m - 1; i >= 0; i--)
+#pragma unroll
+    for(int i = 0; i < MM; i++)
     {
-      double s = col[i] * inv_d[i];
-      for(int j = i + 1; j < m; j++)
+      double s = x[i];
+#pragma unroll
+      for(int j = 0; j < MM; j++)
       {
-        s -= L[j + LD * i] * col[j];
+        if(j < i)
+        {
+          const double l = (i < m) ? L[i + LD * j] : 0.0;
+          s -= l * x[j];
+        }
       }
-      col[i] = s;
+      x[i] = s;
+    }
+#pragma unroll
+    for(int ii = 0; ii < MM; ii++)
+    {
+      const int i = MM - 1 - ii;
+      double s = x[i] * ((i < m) ? inv_d[i] : 0.0);
+#pragma unroll
+      for(int j = 0; j < MM; j++)
+      {
+        if(j > i)
+        {
+          const double l = (j < m) ? L[j + LD * i] : 0.0;
+          s -= l * x[j];
+        }
+      }
+      x[i] = s;
+    }
+#pragma unroll
+    for(int i = 0; i < MM; i++)
+    {
+      if(i < m)
+      {
+        col[i] = x[i];
+      }
     }
   }
 
@@ -1100,9 +1130,13 @@ struct WaveSolver
         for(int k = 0; k < m; k++)
         {
           double d = A[k + LD * k];
-          for(int j = 0; j < k; j++)
+#pragma unroll
+          for(int j = 0; j < MM; j++) // masked and unrolled: the LDS reads stream instead of being waited for one by one
           {
-            d -= (A[k + LD * j] * A[k + LD * j]) * A[j + LD * j];
+            if(j < k)
+            {
+              d -= (A[k + LD * j] * A[k + LD * j]) * A[j + LD * j];
+            }
           }
           if(d <= 0) // every lane computed the same pivot
           {
@@ -1114,9 +1148,13 @@ struct WaveSolver
           if(lane > k && lane < m)
           {
             double sacc = A[lane + LD * k];
-            for(int j = 0; j < k; j++)
+#pragma unroll
+            for(int j = 0; j < MM; j++)
             {
-              sacc -= (A[lane + LD * j] * A[k + LD * j]) * A[j + LD * j];
+              if(j < k)
+              {
+                sacc -= (A[lane + LD * j] * A[k + LD * j]) * A[j + LD * j];
+              }
             }
             A[lane + LD * k] = sacc * r;
           }
@@ -1156,39 +1194,68 @@ struct WaveSolver
       fence();
       // ---- cost-to-go    :522-526
       {
-        double kQu = 0, kQuuk = 0;
-        for(int a = 0; a < m; a++)
+        double kQu = 0, kQuuk = 0, kf[MM];
+#pragma unroll
+        for(int a = 0; a < MM; a++)
         {
-          kQu += vec(vKff)[a] * vec(vQu)[a];
+          kf[a] = (a < m) ? vec(vKff)[a] : 0.0;
+        }
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
+          {
+            kQu += kf[a] * vec(vQu)[a];
+          }
         }
         // Quu k first (as the lane kernels do), then k^T (Quu k)
-        for(int a = 0; a < m; a++)
+#pragma unroll
+        for(int a = 0; a < MM; a++)
         {
-          double sacc = 0;
-          for(int q = 0; q < m; q++)
+          if(a < m)
           {
-            sacc += tile(tQuu)[a + LD * q] * vec(vKff)[q];
+            double sacc = 0;
+#pragma unroll
+            for(int q = 0; q < MM; q++)
+            {
+              if(q < m)
+              {
+                sacc += tile(tQuu)[a + LD * q] * kf[q];
+              }
+            }
+            kQuuk += kf[a] * sacc;
           }
-          kQuuk += vec(vKff)[a] * sacc;
         }
         res.dV0 += kQu;
         res.dV1 += 0.5 * kQuuk;
       }
       if(lane < N)
       {
-        double s1 = 0, s2 = 0, s3 = 0;
-        const double * Kc = tile(tK) + LD * lane;
-        for(int a = 0; a < m; a++)
+        double s1 = 0, s2 = 0, s3 = 0, Kc[MM];
+#pragma unroll
+        for(int a = 0; a < MM; a++)
         {
-          double sacc = 0;
-          for(int q = 0; q < m; q++)
+          Kc[a] = (a < m) ? tile(tK)[a + LD * lane] : 0.0;
+        }
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          if(a < m)
           {
-            sacc += Kc[q] * tile(tQuu)[q + LD * a];
+            double sacc = 0;
+#pragma unroll
+            for(int q = 0; q < MM; q++)
+            {
+              if(q < m)
+              {
+                sacc += Kc[q] * tile(tQuu)[q + LD * a];
+              }
+            }
+            tile(tKtQuu)[lane + LD * a] = sacc;
+            s1 += sacc * vec(vKff)[a];
+            s2 += Kc[a] * vec(vQu)[a];
+            s3 += tile(tQux)[a + LD * lane] * vec(vKff)[a];
           }
-          tile(tKtQuu)[lane + LD * a] = sacc;
-          s1 += sacc * vec(vKff)[a];
-          s2 += Kc[a] * vec(vQu)[a];
-          s3 += tile(tQux)[a + LD * lane] * vec(vKff)[a];
         }
         vec(vVx)[lane] = ((vec(vQx)[lane] + s1) + s2) + s3;
       }

@@ -5,7 +5,8 @@ import numpy as np, nmpc_amd
 from nmpc_amd import workloads
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 for name, wl in (("quadrotor", workloads.quadrotor_batch(B=B, T=50, seed=1234)),
-                 ("manipulator", workloads.manipulator_batch(B=B, T=30, seed=1234))):
+                 ("manipulator", workloads.manipulator_batch(B=B, T=30, seed=1234)),
+                 ("centroidal", workloads.centroidal_batch(B=min(B, 256), T=100, seed=1234))):
     s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B)
     c = s.config(); c.print_level = 0; c.horizon_steps = wl.T; c.max_iter = 4
     for _ in range(2):

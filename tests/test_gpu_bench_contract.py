@@ -1,0 +1,49 @@
+"""bench.py keeps its contract: one JSON line on stdout with the driver's keys, the roofline and cpu_baseline objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+                        "--cpu-seconds", "0.5", *extra], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # exactly one line on stdout
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_keys():
+    d = run_bench()
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), key
+    assert "vs_baseline" in d and d["vs_baseline"] is None  # BASELINE.md holds no published number
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "batch=4096" in d["metric"] and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 2.0
+    assert rf["kernel"].startswith("ddp_solve_tpi2w_kernel")
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
+    assert d["value"] > cb["value"]  # both are batch-iterations / s of the same workload
+    # value = executed iterations: consistent with the step time
+    it_per_step = d["config"]["instance_iterations_per_step"] / 4096
+    assert abs(d["value"] - it_per_step / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_other_workload_and_modes_run():
+    d = run_bench("--workload", "c3", "--no-cpu-baseline")
+    assert "batch=1024" in d["metric"] and "cpu_baseline" not in d
+    d = run_bench("--mode", "m1", "--no-cpu-baseline")
+    assert d["config"]["mode"] == "m1" and d["config"]["status_counts"].get("1", 0) == 0  # nobody may terminate early

@@ -1229,31 +1229,20 @@ struct WaveSolver
         res.dV0 += kQu;
         res.dV1 += 0.5 * kQuuk;
       }
+      // K^T Quu on the matrix cores (N x m, contraction over m: the same ascending chain the per-lane loop would run),
+      // then row r of it, of K^T and of Qux^T against k / Qu in lane r
+      storeAccDyn(tKtQuu, mmaDyn<true>(tK, tQuu, m), N, m);
+      fence();
       if(lane < N)
       {
-        double s1 = 0, s2 = 0, s3 = 0, Kc[MM];
-#pragma unroll
-        for(int a = 0; a < MM; a++)
-        {
-          Kc[a] = (a < m) ? tile(tK)[a + LD * lane] : 0.0;
-        }
+        double s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
         for(int a = 0; a < MM; a++)
         {
           if(a < m)
           {
-            double sacc = 0;
-#pragma unroll
-            for(int q = 0; q < MM; q++)
-            {
-              if(q < m)
-              {
-                sacc += Kc[q] * tile(tQuu)[q + LD * a];
-              }
-            }
-            tile(tKtQuu)[lane + LD * a] = sacc;
-            s1 += sacc * vec(vKff)[a];
-            s2 += Kc[a] * vec(vQu)[a];
+            s1 += tile(tKtQuu)[lane + LD * a] * vec(vKff)[a];
+            s2 += tile(tK)[a + LD * lane] * vec(vQu)[a];
             s3 += tile(tQux)[a + LD * lane] * vec(vKff)[a];
           }
         }

@@ -1124,44 +1124,38 @@ struct WaveSolver
       }
       fence();
 
-      // ---- L D L^T of Quu_F in place in LDS, column by column; same operation order as ldltInPlace    :500-508
+      // ---- L D L^T of Quu_F in place in LDS    :500-508.  Right-looking (after pivot j the trailing block receives its
+      // rank-one update, 4 entries per lane) — but every entry still receives exactly the subtractions
+      // (L_ij L_kj) d_j in ascending j that ldltInPlace's left-looking loops apply, so the factor is the same bits.
       {
         double * A = tile(tQuuF);
-        for(int k = 0; k < m; k++)
+        for(int j = 0; j < m; j++)
         {
-          double d = A[k + LD * k];
-#pragma unroll
-          for(int j = 0; j < MM; j++) // masked and unrolled: the LDS reads stream instead of being waited for one by one
-          {
-            if(j < k)
-            {
-              d -= (A[k + LD * j] * A[k + LD * j]) * A[j + LD * j];
-            }
-          }
-          if(d <= 0) // every lane computed the same pivot
+          const double d = A[j + LD * j];
+          if(d <= 0) // every lane reads the same pivot
           {
             res.ok = false;
             return res;
           }
           const double r = recipFast(d);
-          fence(); // all lanes have read column k before it is overwritten
-          if(lane > k && lane < m)
+          fence();
+          if(lane > j && lane < m)
           {
-            double sacc = A[lane + LD * k];
-#pragma unroll
-            for(int j = 0; j < MM; j++)
-            {
-              if(j < k)
-              {
-                sacc -= (A[lane + LD * j] * A[k + LD * j]) * A[j + LD * j];
-              }
-            }
-            A[lane + LD * k] = sacc * r;
+            A[lane + LD * j] = A[lane + LD * j] * r;
           }
           if(lane == 0)
           {
-            A[k + LD * k] = d;
-            vec(vInvD)[k] = r;
+            vec(vInvD)[j] = r;
+          }
+          fence();
+#pragma unroll
+          for(int q = 0; q < 4; q++)
+          {
+            const int e = lane + 64 * q, i = e & 15, k = e >> 4;
+            if(k > j && i >= k && i < m)
+            {
+              A[i + LD * k] -= (A[i + LD * j] * A[k + LD * j]) * d;
+            }
           }
           fence();
         }

@@ -84,11 +84,11 @@ struct Unroll
 } // namespace detail
 
 /** Input limits of instance b (constant in time): its own if per-instance limits were given, else the shared ones. */
-NMPC_D inline double inputLimitLo(const DeviceBuffers & buf, int b, int a)
+NMPC_D double inputLimitLo(const DeviceBuffers & buf, int b, int a)
 {
   return buf.lim_batch ? buf.lim_batch[(static_cast<size_t>(b) * 2 + 0) * kMaxInputDim + a] : buf.lim_lo[a];
 }
-NMPC_D inline double inputLimitHi(const DeviceBuffers & buf, int b, int a)
+NMPC_D double inputLimitHi(const DeviceBuffers & buf, int b, int a)
 {
   return buf.lim_batch ? buf.lim_batch[(static_cast<size_t>(b) * 2 + 1) * kMaxInputDim + a] : buf.lim_hi[a];
 }

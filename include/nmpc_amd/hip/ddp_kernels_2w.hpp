@@ -32,7 +32,9 @@ namespace nmpc_amd
 {
 namespace hip
 {
-template<class Problem, bool kConstrained>
+/** \tparam kForwardRecordsOnly the LDS records carry only the forward hand-off (x', u'): for solvers that replace the
+    backward pass of this class (ddp_kernels_quad.hpp) */
+template<class Problem, bool kConstrained, bool kForwardRecordsOnly = false>
 struct PairSolver : InstanceSolver<Problem, kConstrained>
 {
   using Base = InstanceSolver<Problem, kConstrained>;
@@ -78,7 +80,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   static constexpr int oXc = 0;
   static constexpr int oUc = oXc + N;
   static constexpr int kFwdRec = oUc + MM;
-  static constexpr int kRec = kBwdRec > kFwdRec ? kBwdRec : kFwdRec;
+  static constexpr int kRec = (kBwdRec > kFwdRec && !kForwardRecordsOnly) ? kBwdRec : kFwdRec;
   //! LDS doubles per workgroup: two record slots + per-lane mailboxes (flags, J_cand)
   static constexpr int kLdsDoubles = (2 * kRec + 2) * static_cast<int>(LW);
   static constexpr size_t kLdsBytes = static_cast<size_t>(kLdsDoubles) * sizeof(double);
@@ -1079,6 +1081,21 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   // ===================================================================================================
   NMPC_D void solveMaster(bool valid)
   {
+    solveMasterWith(valid,
+                    [this](bool need)
+                    {
+                      post(kCmdBackward);
+                      profBegin();
+                      const bool ok = backwardMaster(need);
+                      profEnd(0);
+                      return ok;
+                    });
+  }
+
+  /** \param runBackward (need) -> ok: one backward pass for the lanes in `need`, entered by the whole wave */
+  template<class BackwardFn>
+  NMPC_D void solveMasterWith(bool valid, BackwardFn && runBackward)
+  {
     current_t = buf.t0 ? Base::tileBase(buf.t0, 1)[lane] : 0.0;
     lambda = cfg.initial_lambda;
     dlambda = cfg.initial_dlambda;
@@ -1129,10 +1146,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       int n_backward = 0;
       while(__any(need_bw))
       {
-        post(kCmdBackward);
-        profBegin();
-        const bool ok = backwardMaster(need_bw);
-        profEnd(0);
+        const bool ok = runBackward(need_bw);
         if(need_bw)
         {
           n_backward++;

@@ -1,0 +1,458 @@
+// gfx950 device code of the batched DDP solver, LANE MAPPING "QUAD": for problems with n <= 4 states and one input
+// (cart-pole, bipedal), the BACKWARD pass runs on the fp64 matrix cores with sixteen lanes per instance, and its
+// linearisation is parallel over the horizon; the forward pass and the solver state machine are the two-wave kernel's
+// (ddp_kernels_2w.hpp: one lane per instance, master + helper wavefront).
+//
+//   workgroup    = 16 instances, 4 wavefronts (256 threads); 4096 instances = 256 workgroups = one per CU, one
+//                  wavefront per SIMD — the 2-wave kernel keeps 128 of the chip's 1024 SIMDs busy on that batch
+//   backward     every wavefront owns 4 instances.  v_mfma_f64_4x4x4_4b_f64 computes four independent 4x4x4 products
+//                per instruction, one per "block" of 16 lanes; lane l holds entry (row l / 16, column l % 4) of block
+//                (l / 4) % 4 for the B and C/D operands and the transposed entry for A (scripts/ubench_mfma_f64_4x4.hip),
+//                so mfma(X, Y, C) = X^T Y + C on registers in that "natural" layout.  One timestep of the Riccati
+//                recursion (DDPSolver.hpp:386-530) is 13 such instructions plus ~60 VALU/LDS instructions, instead of
+//                ~330 VALU instructions per timestep on the master wave of the 2-wave kernel.
+//   linearise    the derivatives of 16 timesteps x 4 instances are evaluated by the 64 lanes at once (they do not
+//                depend on the recursion) into a wave-private LDS chunk, which the next 16 recursion steps read.
+//   forward      wave 0 = master, wave 1 = helper of PairSolver, lanes 0..15 (the other lanes mirror them: same
+//                instance, same addresses, same values); waves 2 and 3 only take part in the barriers.
+//
+// Rounding: the matrix core accumulates fma(a_k, b_k, acc) for k ascending starting from C (bit-identical to a scalar
+// FMA chain, profiles/r01_ubench.txt), in the same association as the reference's expressions ((Fx^T Vxx) Fx, ...);
+// sums the lane kernels start from zero and add to L afterwards start from L here, so values agree with the lane
+// kernels to rounding (tests/test_gpu_parity.py), not bit for bit.
+#pragma once
+
+#include <nmpc_amd/hip/ddp_kernels_2w.hpp>
+
+namespace nmpc_amd
+{
+namespace hip
+{
+constexpr int kQuadInstances = 16; //!< instances per workgroup of the quad kernel
+constexpr int kQuadWaves = 4;
+
+template<class Problem, bool kConstrained>
+struct QuadSolver : PairSolver<Problem, kConstrained, true>
+{
+  using Pair = PairSolver<Problem, kConstrained, true>;
+  using Base = typename Pair::Base;
+  using Base::b;
+  using Base::buf;
+  using Base::cfg;
+  using Base::current_t;
+  using Base::dV0;
+  using Base::dV1;
+  using Base::k_rel_norm;
+  using Base::lambda;
+  using Base::lane;
+  using Base::problem;
+  using Base::sel;
+  using Base::T;
+  static constexpr int N = Base::N;
+  static constexpr int M = Base::M;
+  static constexpr int MM = Base::MM;
+  static constexpr size_t LW = Base::LW;
+  using typename Base::InputDimVector;
+  using typename Base::InputInputDimMatrix;
+  using typename Base::QPOut;
+  using typename Base::StateDimVector;
+  using typename Base::StateInputDimMatrix;
+  using typename Base::StateStateDimMatrix;
+
+  static constexpr bool kShape = (N >= 1 && N <= 4 && M == 1 && !Problem::kDynamicInput);
+
+  // ---- derivative record of one (instance, timestep), doubles; 4 x 4 blocks row-major, zero-padded beyond n ----
+  static constexpr int oFx = 0;
+  static constexpr int oLxx = 16;
+  static constexpr int oFu = 32;
+  static constexpr int oLxu = 36; // Lxu then Lx: columns 0 and 1 of one 4 x 4 operand
+  static constexpr int oLx = 40;
+  static constexpr int oLuu = 44; // Luu then Lu: entries (0, 0) and (0, 1) of one 4 x 4 operand
+  static constexpr int oLu = 45;
+  static constexpr int oU = 46;
+  static constexpr int kRecQ = 47; // odd: the 64 lanes of the linearisation write conflict-free
+  static constexpr int kChunkSteps = 16;
+  static constexpr int kChunkDoubles = 64 * kRecQ;
+  // ---- mailboxes master <-> backward waves, per instance of the workgroup ----
+  static constexpr int kMailIn = 4; // need, lambda, sel, t0
+  static constexpr int kMailOut = 4; // ok, dV0, dV1, k_rel_norm
+  static constexpr int kMailDoubles = (kMailIn + kMailOut) * kQuadInstances;
+  static constexpr int kLdsDoubles = Pair::kLdsDoubles + kMailDoubles + kQuadWaves * kChunkDoubles;
+  static constexpr size_t kLdsBytes = static_cast<size_t>(kLdsDoubles) * sizeof(double);
+
+  const int wave; //!< 0 .. 3
+  const int wl; //!< lane within the wavefront
+  // natural layout of this lane: entry (row, col) of block blk
+  const int row, blk, col;
+  double * mail;
+  double * chunk; //!< this wave's derivative chunk
+
+  NMPC_D QuadSolver(const Problem & p,
+                    const nmpc_hip_ddp_config & c,
+                    const DeviceBuffers & bf,
+                    int global_lane,
+                    double * lds_base)
+  : Pair(p, c, bf, global_lane, lds_base), wave(threadIdx.x / 64), wl(threadIdx.x % 64), row(wl / 16), blk((wl / 4) % 4),
+    col(wl % 4), mail(lds_base + Pair::kLdsDoubles),
+    chunk(lds_base + Pair::kLdsDoubles + kMailDoubles + (threadIdx.x / 64) * kChunkDoubles)
+  {
+  }
+
+  NMPC_D double & mailIn(int inst, int f) const
+  {
+    return mail[f * kQuadInstances + inst];
+  }
+  NMPC_D double & mailOut(int inst, int f) const
+  {
+    return mail[(kMailIn + f) * kQuadInstances + inst];
+  }
+
+  NMPC_D static double mma(double a, double b_, double c)
+  {
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b_, c, 0, 0, 0);
+  }
+  /** Entry `kSrc` of this lane's quad (= column kSrc of the same row and block) in all four lanes of the quad. */
+  template<int kSrc>
+  NMPC_D static double quadBroadcast(double v)
+  {
+    constexpr int ctrl = kSrc | (kSrc << 2) | (kSrc << 4) | (kSrc << 6); // DPP quad_perm:[s,s,s,s]
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  }
+  NMPC_D static double pick(bool p, double v)
+  {
+    return p ? v : 0.0;
+  }
+
+  /** Derivatives of timestep i of instance `inst_l` (this lane's instance in the LINEARISATION mapping) -> record. */
+  NMPC_D void lineariseStep(int i, double t0_l, const double * px, const double * pu, double * rec) const
+  {
+    const double t = t0_l + i * problem.dt();
+    StateDimVector x;
+    InputDimVector u;
+    u.resize(M);
+#pragma unroll
+    for(int j = 0; j < N; j++)
+    {
+      x[j] = px[(static_cast<size_t>(i) * N + j) * LW];
+    }
+    u[0] = pu[static_cast<size_t>(i) * LW];
+    StateStateDimMatrix Fx, Lxx;
+    StateInputDimMatrix Fu, Lxu;
+    StateDimVector Lx;
+    InputDimVector Lu;
+    InputInputDimMatrix Luu;
+    Fu.resize(N, M);
+    Lxu.resize(N, M);
+    Lu.resize(M);
+    Luu.resize(M, M);
+    problem.calcStateEqDeriv(t, x, u, Fx, Fu);
+    problem.calcRunningCostDeriv(t, x, u, Lx, Lu, Lxx, Luu, Lxu);
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+#pragma unroll
+      for(int c = 0; c < 4; c++)
+      {
+        rec[oFx + 4 * r + c] = (r < N && c < N) ? Fx(r < N ? r : 0, c < N ? c : 0) : 0.0;
+        rec[oLxx + 4 * r + c] = (r < N && c < N) ? Lxx(r < N ? r : 0, c < N ? c : 0) : 0.0;
+      }
+      rec[oFu + r] = (r < N) ? Fu(r < N ? r : 0, 0) : 0.0;
+      rec[oLxu + r] = (r < N) ? Lxu(r < N ? r : 0, 0) : 0.0;
+      rec[oLx + r] = (r < N) ? Lx[r < N ? r : 0] : 0.0;
+    }
+    rec[oLuu] = Luu(0, 0);
+    rec[oLu] = Lu[0];
+    rec[oU] = u[0];
+  }
+
+  /** One backward pass (DDPSolver::backwardPass, DDPSolver.hpp:342-534) of the four instances of this wave.  Entered by
+      all four waves after the master's post(kCmdBackward); inputs and results go through the LDS mailboxes. */
+  NMPC_D void backwardQuad() const
+  {
+    // ---- this lane in the RECURSION mapping: entry (row, col) of instance 4 * wave + blk ----
+    const int inst = wave * 4 + blk;
+    const bool need = mailIn(inst, 0) != 0.0;
+    const double lam = mailIn(inst, 1);
+    const int lane_q = static_cast<int>(lane - lane % kQuadInstances) + inst; // lane of that instance in its tile
+    // ---- this lane in the LINEARISATION mapping: timestep offset wl % 16 of instance 4 * wave + wl / 16 ----
+    const int inst_l = wave * 4 + wl / 16;
+    const int ts_l = wl % 16;
+    const int sel_l = static_cast<int>(mailIn(inst_l, 2));
+    const double t0_l = mailIn(inst_l, 3);
+    const int lane_l = static_cast<int>(lane - lane % kQuadInstances) + inst_l;
+    const double * px = Base::Xt + static_cast<size_t>(sel_l) * (Base::rowsX() * LW) + lane_l;
+    const double * pu = Base::Ut + static_cast<size_t>(sel_l) * (Base::rowsU() * LW) + lane_l;
+    double * rec_l = chunk + static_cast<size_t>(wl) * kRecQ;
+    const double * rec_q = chunk + static_cast<size_t>(blk * 16) * kRecQ;
+
+    // lane predicates of the natural layout
+    const bool c0 = col == 0, c1 = col == 1, r0 = row == 0, r1 = row == 1, r2 = row == 2;
+    const double e0 = r0 ? 1.0 : 0.0; // mma(e0, X, 0) replicates row 0 of X into every row
+
+    // ---- terminal value function    DDPSolver.hpp:349-352
+    if(ts_l == 0)
+    {
+      StateDimVector xT, vx;
+      StateStateDimMatrix vxx;
+#pragma unroll
+      for(int j = 0; j < N; j++)
+      {
+        xT[j] = px[(static_cast<size_t>(T) * N + j) * LW];
+      }
+      problem.calcTerminalCostDeriv(t0_l + T * problem.dt(), xT, vx, vxx);
+#pragma unroll
+      for(int r = 0; r < 4; r++)
+      {
+#pragma unroll
+        for(int c = 0; c < 4; c++)
+        {
+          rec_l[4 * r + c] = (r < N && c < N) ? vxx(r < N ? r : 0, c < N ? c : 0) : 0.0;
+        }
+        rec_l[16 + r] = (r < N) ? vx[r < N ? r : 0] : 0.0;
+      }
+    }
+    double Vxx = rec_q[4 * row + col];
+    double VxM = pick(c1, rec_q[16 + row]); // Vx in column 1, zero elsewhere
+
+    double dV0_l = 0, dV1_l = 0, krn = 0;
+    bool ok = true;
+    double k_next = 0;
+    bool have_next = false;
+    const size_t tile_T = static_cast<size_t>(T);
+
+    const int n_chunks = (T + kChunkSteps - 1) / kChunkSteps;
+    for(int ch = n_chunks - 1; ch >= 0; ch--)
+    {
+      const int i0 = ch * kChunkSteps;
+      {
+#ifdef NMPC_AMD_PROFILE_2W
+        const unsigned long long tl = __builtin_readcyclecounter();
+#endif
+        const int i = (i0 + ts_l < T) ? i0 + ts_l : T - 1;
+        lineariseStep(i, t0_l, px, pu, rec_l);
+#ifdef NMPC_AMD_PROFILE_2W
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        Pair::prof_wait += __builtin_readcyclecounter() - tl; // reported as "barrier wait": the linearisation share
+#endif
+      }
+      const int hi = (i0 + kChunkSteps - 1 < T) ? i0 + kChunkSteps - 1 : T - 1;
+      for(int i = hi; i >= i0; i--)
+      {
+        const double * R = rec_q + static_cast<size_t>(i - i0) * kRecQ;
+        const double Fx = R[oFx + 4 * row + col];
+        const double Lxx = R[oLxx + 4 * row + col];
+        const double LxxT = R[oLxx + 4 * col + row];
+        const double FuM = pick(c0, R[oFu + row]); // [Fu | 0 | 0 | 0]
+        const double LM = pick(c0 || c1, R[oLxu + 4 * (col & 1) + row]); // [Lxu | Lx | 0 | 0]
+        const double LMT = pick(r0 || r1, R[oLxu + 4 * (row & 1) + col]); // its transpose
+        const double CM = pick(r0 && (c0 || c1), R[oLuu + (col & 1)]); // (0, 0) = Luu, (0, 1) = Lu
+        const double u = R[oU];
+
+        // ---- Q terms    DDPSolver.hpp:386-408   (mma(X, Y, C) = X^T Y + C)
+        const double P = mma(Vxx, Fx, 0.0); // Vxx^T Fx = (Fx^T Vxx)^T
+        const double Rm = mma(Vxx, FuM, VxM); // [(Fu^T Vxx)^T | Vx | 0 | 0]
+        const double Qxx = mma(P, Fx, Lxx); // Lxx + (Fx^T Vxx) Fx
+        const double QxxT = mma(Fx, P, LxxT); // the same entries, transposed
+        const double S = mma(Fx, Rm, LM); // column 1 = Qx
+        const double ST = mma(Rm, Fx, LMT); // row 0 = Qux, row 1 = Qx^T
+        const double W = mma(FuM, Rm, CM); // (0, 0) = Quu, (0, 1) = Qu
+        const double WR = mma(e0, W, 0.0);
+        const double Quu = quadBroadcast<0>(WR);
+        const double Qu = quadBroadcast<1>(WR);
+        const double QA = mma(e0, ST, 0.0); // Qux[col] in every row
+
+        // ---- regularisation    :421-441
+        double Quu_F = Quu, QAr = QA;
+        if(cfg.reg_type == 2)
+        {
+          const double VxxReg = (row == col) ? Vxx + lam : Vxx;
+          const double R2 = mma(VxxReg, FuM, 0.0);
+          const double ST2 = mma(R2, Fx, LMT);
+          const double W2 = mma(FuM, R2, CM);
+          QAr = mma(e0, ST2, 0.0);
+          Quu_F = quadBroadcast<0>(mma(e0, W2, 0.0));
+        }
+        else if(cfg.reg_type == 1)
+        {
+          Quu_F = Quu + lam;
+        }
+
+        // ---- gains    :448-517   (m = 1: the factorisation is the pivot itself)
+        double k = 0, Kc = 0; // Kc = K[col]
+        bool step_ok = true;
+        if constexpr(kConstrained)
+        {
+          const double initial_k = (i != T - 1 && have_next) ? k_next : 0.0;
+          const double lo = inputLimitLo(buf, b - static_cast<int>(lane) + lane_q, 0) - u;
+          const double up = inputLimitHi(buf, b - static_cast<int>(lane) + lane_q, 0) - u;
+          QPOut qp;
+          Base::boxQP(1, &Quu_F, &Qu, &lo, &up, &initial_k, qp);
+          if(need && ok && r0 && c0)
+          {
+            Base::tileBase(buf.qp_ret, tile_T)[static_cast<size_t>(i) * LW + lane_q] = qp.retval;
+            Base::tileBase(buf.qp_free, tile_T)[static_cast<size_t>(i) * LW + lane_q] = (qp.n_free > 0) ? 1u : 0u;
+          }
+          if(qp.retval < 0)
+          {
+            step_ok = false;
+          }
+          else
+          {
+            k = qp.x[0];
+            if(qp.n_free > 0)
+            {
+              Kc = -1 * (QAr * qp.inv_d[0]);
+            }
+          }
+        }
+        else
+        {
+          if(Quu_F <= 0)
+          {
+            step_ok = false;
+          }
+          else
+          {
+            const double inv_d = recipFast(Quu_F);
+            k = -1 * (Qu * inv_d);
+            Kc = -1 * (QAr * inv_d);
+          }
+        }
+        const bool live = need && ok && step_ok;
+        ok = ok && step_ok;
+
+        // ---- cost-to-go update    :522-527
+        if(live)
+        {
+          dV0_l += k * Qu;
+          dV1_l += 0.5 * (k * (Quu * k));
+        }
+        const double KtQuu = Kc * Quu;
+        const double X6 = r0 ? KtQuu : (r1 ? Kc : (r2 ? QA : 0.0)); // rows: K^T Quu, K, Qux
+        const double B6 = r0 ? Kc : (r1 ? QA : (r2 ? Kc : 0.0)); // rows: K, Qux, K
+        const double B7 = pick(c1, r0 ? k : (r1 ? Qu : (r2 ? k : 0.0))); // column 1: k, Qu, k
+        const double Vn = mma(X6, B6, Qxx); // Qxx + K^T Quu K + K^T Qux + Qux^T K
+        const double VnT = mma(B6, X6, QxxT);
+        VxM = mma(X6, B7, pick(c1, S)); // column 1: Qx + K^T Quu k + K^T Qu + Qux^T k
+        Vxx = 0.5 * (Vn + VnT);
+
+        // ---- save gains    :529-530, running max of |k_i| / (|u_i| + 1)    :217-221
+        if(live)
+        {
+          if(r0)
+          {
+            if(c0)
+            {
+              Base::kt[static_cast<size_t>(i) * LW + lane_q] = k;
+            }
+            if(col < N)
+            {
+              Base::Kt[(static_cast<size_t>(i) * N + col) * LW + lane_q] = Kc;
+            }
+          }
+          k_next = k;
+          have_next = true;
+          krn = fmax(krn, fabs(k) * recipFast(fabs(u) + 1.0));
+        }
+      }
+    }
+    if(r0 && c0)
+    {
+      mailOut(inst, 0) = ok ? 1.0 : 0.0;
+      mailOut(inst, 1) = dV0_l;
+      mailOut(inst, 2) = dV1_l;
+      mailOut(inst, 3) = krn;
+    }
+    __syncthreads(); // closes the pass: results in the mailboxes, gains in HBM
+  }
+
+  /** Master side of one backward pass: publish the inputs, run this wave's share, collect the results. */
+  NMPC_D bool backwardMasterQuad(bool need)
+  {
+    const int inst = wl % kQuadInstances;
+    if(wl < kQuadInstances)
+    {
+      mailIn(inst, 0) = need ? 1.0 : 0.0;
+      mailIn(inst, 1) = lambda;
+      mailIn(inst, 2) = static_cast<double>(sel);
+      mailIn(inst, 3) = current_t;
+    }
+    Pair::post(Pair::kCmdBackward);
+    Pair::profBegin();
+    backwardQuad();
+    Pair::profEnd(0);
+    const bool ok = mailOut(inst, 0) != 0.0;
+    if(need)
+    {
+      dV0 = mailOut(inst, 1);
+      dV1 = mailOut(inst, 2);
+      k_rel_norm = mailOut(inst, 3);
+    }
+    return ok;
+  }
+
+  NMPC_D void solveMasterQuad(bool valid)
+  {
+    Pair::solveMasterWith(valid, [this](bool need) { return backwardMasterQuad(need); });
+  }
+
+  /** Waves 1 .. 3: follow the master's commands.  Wave 1 is the forward helper of PairSolver, waves 2 and 3 only
+      attend the forward pass's barriers. */
+  NMPC_D void followerLoop() const
+  {
+    for(;;)
+    {
+      __syncthreads(); // barrier P of PairSolver::post()
+      const int word = static_cast<int>(Pair::mailFlags());
+      const int cmd = __builtin_amdgcn_readfirstlane(word >> 1);
+      const int sel_h = word & 1;
+      if(cmd == Pair::kCmdExit)
+      {
+        return;
+      }
+      if(cmd == Pair::kCmdBackward)
+      {
+        backwardQuad();
+      }
+      else if(wave == 1)
+      {
+        Pair::forwardHelper(sel_h);
+      }
+      else
+      {
+        for(int i = 0; i < T + 2; i++)
+        {
+          Pair::wgBarrier();
+        }
+      }
+    }
+  }
+};
+
+/** The quad solve kernel: grid = Bp / 16 workgroups of 256 threads. */
+template<class Problem, bool kConstrained>
+__global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const Problem problem,
+                                                                         const nmpc_hip_ddp_config cfg,
+                                                                         const DeviceBuffers buf)
+{
+  using Solver = QuadSolver<Problem, kConstrained>;
+  extern __shared__ __attribute__((aligned(16))) double lds_quad[];
+  const int wl = threadIdx.x % 64;
+  // in the lane-per-instance roles (master, forward helper) every group of 16 lanes mirrors the workgroup's 16
+  // instances: same inputs, same instruction stream, hence the same values and decisions, written to the same places
+  const int b = blockIdx.x * kQuadInstances + wl % kQuadInstances;
+  Solver solver(problem, cfg, buf, b, lds_quad);
+  if(threadIdx.x / 64 == 0)
+  {
+    solver.solveMasterQuad(b < buf.B);
+  }
+  else
+  {
+    solver.current_t = buf.t0 ? solver.tileBase(buf.t0, 1)[solver.lane] : 0.0;
+    solver.followerLoop();
+  }
+}
+} // namespace hip
+} // namespace nmpc_amd

@@ -15,6 +15,7 @@
 
 #include <nmpc_amd/hip/ddp_kernels.hpp>
 #include <nmpc_amd/hip/ddp_kernels_2w.hpp>
+#include <nmpc_amd/hip/ddp_kernels_quad.hpp>
 #include <nmpc_amd/hip/ddp_kernels_wpi.hpp>
 #include <nmpc_amd/hip/mpc_kernels.hpp>
 
@@ -41,8 +42,8 @@ struct ModelOps
   void (*input_dims)(const void * params, double t0, int T, int * out);
   //! dt() of the problem object
   double (*dt)(const void * params);
-  //! name of the kernel launch_solve launches (lane mapping, see launchSolve)
-  const char * (*kernel_name)();
+  //! name of the kernel launch_solve launches for a batch of `batch` instances (lane mapping, see launchSolve)
+  const char * (*kernel_name)(int batch);
   //! launches the receding-horizon advance step (mpc_kernels.hpp) between two solves
   hipError_t (*launch_mpc_advance)(const void * params,
                                    const DeviceBuffers & buf,
@@ -90,8 +91,27 @@ struct ModelOpsFor
       return 0;
     }
   }
-  static const char * kernelName()
+  /** Quad kernel (matrix-core backward pass, 16 instances per workgroup): n <= 4, one input.  It wins while its
+      workgroups fit on the chip in one round (one per CU: 16 * 256 instances); larger batches go to the 2-wave kernel,
+      whose 64-instance workgroups keep the latency flat up to 16384 instances.  NMPC_HIP_DDP_KERNEL=quad / 2w force. */
+  static constexpr bool kQuadShape = QuadSolver<Problem, false>::kShape;
+  static constexpr int kQuadMaxBatch = 4096;
+  static bool useQuad(int batch_padded, bool own)
   {
+    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
+    if(!kQuadShape || own || (force && (std::strcmp(force, "1w") == 0 || std::strcmp(force, "2w") == 0)))
+    {
+      return false;
+    }
+    return batch_padded <= kQuadMaxBatch || (force && std::strcmp(force, "quad") == 0);
+  }
+  static const char * kernelName(int batch)
+  {
+    const int padded = (batch + kLanesPerBlock - 1) / kLanesPerBlock * kLanesPerBlock;
+    if(useQuad(padded, false))
+    {
+      return "ddp_solve_quad_kernel";
+    }
     if(useWpi(false)) // (a box-constrained solve of an LDS-gains shape still goes to the lane kernel, see launchSolve)
     {
       return "ddp_solve_wpi_kernel";
@@ -134,6 +154,34 @@ struct ModelOpsFor
         else
         {
           hipLaunchKernelGGL((ddp_solve_wpi_kernel<Problem, false, false>), g, blk, wpi_lds, stream, problem, cfg, buf);
+        }
+        return hipGetLastError();
+      }
+    }
+    if constexpr(kQuadShape)
+    {
+      if(useQuad(buf.Bp, own))
+      {
+        constexpr size_t quad_lds = QuadSolver<Problem, false>::kLdsBytes;
+        const dim3 g(buf.Bp / kQuadInstances), blk(kQuadWaves * 64);
+        // > 64 KB of dynamic LDS has to be requested per kernel
+        static const hipError_t attr_u = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(quad_lds));
+        static const hipError_t attr_c = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(quad_lds));
+        if(attr_u != hipSuccess || attr_c != hipSuccess)
+        {
+          return attr_u != hipSuccess ? attr_u : attr_c;
+        }
+        if(con)
+        {
+          hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, true>), g, blk, quad_lds, stream, problem, cfg, buf);
+        }
+        else
+        {
+          hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, false>), g, blk, quad_lds, stream, problem, cfg, buf);
         }
         return hipGetLastError();
       }

@@ -1188,7 +1188,7 @@ extern "C"
     {
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output pointer");
     }
-    *name = s->ops->kernel_name();
+    *name = s->ops->kernel_name(s->B);
     return NMPC_HIP_OK;
   }
 

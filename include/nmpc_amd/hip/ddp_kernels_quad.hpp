@@ -9,7 +9,7 @@
 //                per instruction, one per "block" of 16 lanes; lane l holds entry (row l / 16, column l % 4) of block
 //                (l / 4) % 4 for the B and C/D operands and the transposed entry for A (scripts/ubench_mfma_f64_4x4.hip),
 //                so mfma(X, Y, C) = X^T Y + C on registers in that "natural" layout.  One timestep of the Riccati
-//                recursion (DDPSolver.hpp:386-530) is 13 such instructions plus ~60 VALU/LDS instructions, instead of
+//                recursion (DDPSolver.hpp:386-530) is 7 such instructions plus ~100 VALU/DPP/LDS instructions, instead of
 //                ~330 VALU instructions per timestep on the master wave of the 2-wave kernel.
 //   linearise    the derivatives of 16 timesteps x 4 instances are evaluated by the 64 lanes at once (they do not
 //                depend on the recursion) into a wave-private LDS chunk, which the next 16 recursion steps read.
@@ -70,7 +70,8 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
   static constexpr int oLuu = 44; // Luu then Lu: entries (0, 0) and (0, 1) of one 4 x 4 operand
   static constexpr int oLu = 45;
   static constexpr int oU = 46;
-  static constexpr int kRecQ = 47; // odd: the 64 lanes of the linearisation write conflict-free
+  static constexpr int oZero = 47; // 0.0: what the lanes outside a masked operand read
+  static constexpr int kRecQ = 49; // odd: the 64 lanes of the linearisation write conflict-free
   static constexpr int kChunkSteps = 16;
   static constexpr int kChunkDoubles = 64 * kRecQ;
   // ---- mailboxes master <-> backward waves, per instance of the workgroup ----
@@ -165,6 +166,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
     rec[oLuu] = Luu(0, 0);
     rec[oLu] = Lu[0];
     rec[oU] = u[0];
+    rec[oZero] = 0.0;
   }
 
   /** One backward pass (DDPSolver::backwardPass, DDPSolver.hpp:342-534) of the four instances of this wave.  Entered by
@@ -188,8 +190,32 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
     const double * rec_q = chunk + static_cast<size_t>(blk * 16) * kRecQ;
 
     // lane predicates of the natural layout
-    const bool c0 = col == 0, c1 = col == 1, r0 = row == 0, r1 = row == 1, r2 = row == 2;
-    const double e0 = r0 ? 1.0 : 0.0; // mma(e0, X, 0) replicates row 0 of X into every row
+    const bool c0 = col == 0, c1 = col == 1, r0 = row == 0;
+    // this lane's offsets into a record: masked operands read the record's zero slot instead of being selected
+    const int aE = 4 * row + col; // entry (row, col) of a 4 x 4 block
+    const int aT = 4 * col + row; // the transposed entry
+    const int aFuM = c0 ? oFu + row : oZero; // [Fu | 0 | 0 | 0]
+    const int aFuB = oFu + row; // Fu in every column
+    const int aLM = c0 ? oLxu + row : (c1 ? oLx + row : oZero); // [Lxu | Lx | 0 | 0]
+    const int aCM = c0 ? oLuu : (c1 ? oLu : oZero); // [Luu, Lu, 0, 0] in every row
+    const int aLxuRow = oLxu + col; // Lxu^T in every row
+    struct Operands
+    {
+      double Fx, Lxx, LxxT, FuM, FuB, LM, CM, LxuRow, u;
+    };
+    auto loadOperands = [&](int ts, Operands & o)
+    {
+      const double * R = rec_q + static_cast<size_t>(ts) * kRecQ;
+      o.Fx = R[oFx + aE];
+      o.Lxx = R[oLxx + aE];
+      o.LxxT = R[oLxx + aT];
+      o.FuM = R[aFuM];
+      o.FuB = R[aFuB];
+      o.LM = R[aLM];
+      o.CM = R[aCM];
+      o.LxuRow = R[aLxuRow];
+      o.u = R[oU];
+    };
 
     // ---- terminal value function    DDPSolver.hpp:349-352
     if(ts_l == 0)
@@ -213,7 +239,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
         rec_l[16 + r] = (r < N) ? vx[r < N ? r : 0] : 0.0;
       }
     }
-    double Vxx = rec_q[4 * row + col];
+    double Vxx = rec_q[aE];
     double VxM = pick(c1, rec_q[16 + row]); // Vx in column 1, zero elsewhere
 
     double dV0_l = 0, dV1_l = 0, krn = 0;
@@ -221,6 +247,104 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
     double k_next = 0;
     bool have_next = false;
     const size_t tile_T = static_cast<size_t>(T);
+    const int b_q = b - static_cast<int>(lane) + lane_q; // global index of this lane's instance
+
+    /** One timestep of the recursion on the operands `o`; requests the operands of record `ts_next` into `o_next`
+        first (they do not depend on the recursion: their LDS latency hides behind this timestep). */
+    auto step = [&](int i, const Operands & o, int ts_next, Operands & o_next)
+    {
+      loadOperands(ts_next, o_next);
+      // ---- Q terms    DDPSolver.hpp:386-408   (mma(X, Y, C) = X^T Y + C)
+      const double P = mma(Vxx, o.Fx, 0.0); // Vxx^T Fx = (Fx^T Vxx)^T
+      const double Rm = mma(Vxx, o.FuM, VxM); // [(Fu^T Vxx)^T | Vx | 0 | 0]
+      const double Qxx = mma(P, o.Fx, o.Lxx); // Lxx + (Fx^T Vxx) Fx
+      const double QxxT = mma(o.Fx, P, o.LxxT); // the same entries, transposed
+      const double S = mma(o.Fx, Rm, o.LM); // column 0 = Qux^T, column 1 = Qx
+      const double Wq = mma(o.FuB, Rm, o.CM); // every row: [Quu, Qu, 0, 0]
+      const double QA = mma(quadBroadcast<0>(Rm), o.Fx, o.LxuRow); // Qux[col] in every row
+      const double Quu = quadBroadcast<0>(Wq);
+      const double Qu = quadBroadcast<1>(Wq);
+      const double Qr = quadBroadcast<0>(S); // Qux[row]
+      const double Qxr = quadBroadcast<1>(S); // Qx[row]
+
+      // ---- regularisation    :421-441
+      double Quu_F = Quu, QAr = QA, Qrr = Qr;
+      if(cfg.reg_type == 2)
+      {
+        const double VxxReg = (row == col) ? Vxx + lam : Vxx;
+        const double R2 = mma(VxxReg, o.FuM, 0.0);
+        Quu_F = quadBroadcast<0>(mma(o.FuB, R2, o.CM));
+        QAr = mma(quadBroadcast<0>(R2), o.Fx, o.LxuRow);
+        Qrr = quadBroadcast<0>(mma(o.Fx, R2, o.LM));
+      }
+      else if(cfg.reg_type == 1)
+      {
+        Quu_F = Quu + lam;
+      }
+
+      // ---- gains    :448-517   (m = 1: the factorisation is the pivot itself; inv = 0 leaves k = K = 0)
+      double k, inv;
+      bool step_ok;
+      if constexpr(kConstrained)
+      {
+        const double initial_k = (i != T - 1 && have_next) ? k_next : 0.0;
+        const double lo = inputLimitLo(buf, b_q, 0) - o.u;
+        const double up = inputLimitHi(buf, b_q, 0) - o.u;
+        QPOut qp;
+        Base::boxQP(1, &Quu_F, &Qu, &lo, &up, &initial_k, qp);
+        if(need && ok && r0 && c0)
+        {
+          Base::tileBase(buf.qp_ret, tile_T)[static_cast<size_t>(i) * LW + lane_q] = qp.retval;
+          Base::tileBase(buf.qp_free, tile_T)[static_cast<size_t>(i) * LW + lane_q] = (qp.n_free > 0) ? 1u : 0u;
+        }
+        step_ok = qp.retval >= 0;
+        k = step_ok ? qp.x[0] : 0.0;
+        inv = (step_ok && qp.n_free > 0) ? qp.inv_d[0] : 0.0;
+      }
+      else
+      {
+        step_ok = !(Quu_F <= 0);
+        inv = step_ok ? recipFast(Quu_F) : 0.0;
+        k = -1 * (Qu * inv);
+      }
+      const double Kc = -1 * (QAr * inv); // K[col]
+      const double Kr = -1 * (Qrr * inv); // K[row]
+      const bool live = need && ok && step_ok;
+      ok = ok && step_ok;
+
+      // ---- cost-to-go update    :522-527
+      if(live)
+      {
+        dV0_l += k * Qu;
+        dV1_l += 0.5 * (k * (Quu * k));
+      }
+      const double KQr = Kr * Quu, KQc = Kc * Quu; // (K^T Quu)[row], [col]
+      // Qxx + K^T Quu K + K^T Qux + Qux^T K, entry (row, col) and entry (col, row)
+      const double Vn = fma(Qr, Kc, fma(Kr, QA, fma(KQr, Kc, Qxx)));
+      const double VnT = fma(QA, Kr, fma(Kc, Qr, fma(KQc, Kr, QxxT)));
+      Vxx = 0.5 * (Vn + VnT);
+      // Qx + K^T Quu k + K^T Qu + Qux^T k
+      VxM = pick(c1, fma(Qr, k, fma(Kr, Qu, fma(KQr, k, Qxr))));
+
+      // ---- save gains    :529-530, running max of |k_i| / (|u_i| + 1)    :217-221
+      if(live)
+      {
+        if(r0)
+        {
+          if(c0)
+          {
+            Base::kt[static_cast<size_t>(i) * LW + lane_q] = k;
+          }
+          if(col < N)
+          {
+            Base::Kt[(static_cast<size_t>(i) * N + col) * LW + lane_q] = Kc;
+          }
+        }
+        k_next = k;
+        have_next = true;
+        krn = fmax(krn, fabs(k) * recipFast(fabs(o.u) + 1.0));
+      }
+    };
 
     const int n_chunks = (T + kChunkSteps - 1) / kChunkSteps;
     for(int ch = n_chunks - 1; ch >= 0; ch--)
@@ -238,124 +362,18 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
 #endif
       }
       const int hi = (i0 + kChunkSteps - 1 < T) ? i0 + kChunkSteps - 1 : T - 1;
-      for(int i = hi; i >= i0; i--)
+      // two operand sets, loop unrolled by two: no register copies between timesteps
+      Operands oa, ob;
+      loadOperands(hi - i0, oa);
+      int i = hi;
+      for(; i - 1 >= i0; i -= 2)
       {
-        const double * R = rec_q + static_cast<size_t>(i - i0) * kRecQ;
-        const double Fx = R[oFx + 4 * row + col];
-        const double Lxx = R[oLxx + 4 * row + col];
-        const double LxxT = R[oLxx + 4 * col + row];
-        const double FuM = pick(c0, R[oFu + row]); // [Fu | 0 | 0 | 0]
-        const double LM = pick(c0 || c1, R[oLxu + 4 * (col & 1) + row]); // [Lxu | Lx | 0 | 0]
-        const double LMT = pick(r0 || r1, R[oLxu + 4 * (row & 1) + col]); // its transpose
-        const double CM = pick(r0 && (c0 || c1), R[oLuu + (col & 1)]); // (0, 0) = Luu, (0, 1) = Lu
-        const double u = R[oU];
-
-        // ---- Q terms    DDPSolver.hpp:386-408   (mma(X, Y, C) = X^T Y + C)
-        const double P = mma(Vxx, Fx, 0.0); // Vxx^T Fx = (Fx^T Vxx)^T
-        const double Rm = mma(Vxx, FuM, VxM); // [(Fu^T Vxx)^T | Vx | 0 | 0]
-        const double Qxx = mma(P, Fx, Lxx); // Lxx + (Fx^T Vxx) Fx
-        const double QxxT = mma(Fx, P, LxxT); // the same entries, transposed
-        const double S = mma(Fx, Rm, LM); // column 1 = Qx
-        const double ST = mma(Rm, Fx, LMT); // row 0 = Qux, row 1 = Qx^T
-        const double W = mma(FuM, Rm, CM); // (0, 0) = Quu, (0, 1) = Qu
-        const double WR = mma(e0, W, 0.0);
-        const double Quu = quadBroadcast<0>(WR);
-        const double Qu = quadBroadcast<1>(WR);
-        const double QA = mma(e0, ST, 0.0); // Qux[col] in every row
-
-        // ---- regularisation    :421-441
-        double Quu_F = Quu, QAr = QA;
-        if(cfg.reg_type == 2)
-        {
-          const double VxxReg = (row == col) ? Vxx + lam : Vxx;
-          const double R2 = mma(VxxReg, FuM, 0.0);
-          const double ST2 = mma(R2, Fx, LMT);
-          const double W2 = mma(FuM, R2, CM);
-          QAr = mma(e0, ST2, 0.0);
-          Quu_F = quadBroadcast<0>(mma(e0, W2, 0.0));
-        }
-        else if(cfg.reg_type == 1)
-        {
-          Quu_F = Quu + lam;
-        }
-
-        // ---- gains    :448-517   (m = 1: the factorisation is the pivot itself)
-        double k = 0, Kc = 0; // Kc = K[col]
-        bool step_ok = true;
-        if constexpr(kConstrained)
-        {
-          const double initial_k = (i != T - 1 && have_next) ? k_next : 0.0;
-          const double lo = inputLimitLo(buf, b - static_cast<int>(lane) + lane_q, 0) - u;
-          const double up = inputLimitHi(buf, b - static_cast<int>(lane) + lane_q, 0) - u;
-          QPOut qp;
-          Base::boxQP(1, &Quu_F, &Qu, &lo, &up, &initial_k, qp);
-          if(need && ok && r0 && c0)
-          {
-            Base::tileBase(buf.qp_ret, tile_T)[static_cast<size_t>(i) * LW + lane_q] = qp.retval;
-            Base::tileBase(buf.qp_free, tile_T)[static_cast<size_t>(i) * LW + lane_q] = (qp.n_free > 0) ? 1u : 0u;
-          }
-          if(qp.retval < 0)
-          {
-            step_ok = false;
-          }
-          else
-          {
-            k = qp.x[0];
-            if(qp.n_free > 0)
-            {
-              Kc = -1 * (QAr * qp.inv_d[0]);
-            }
-          }
-        }
-        else
-        {
-          if(Quu_F <= 0)
-          {
-            step_ok = false;
-          }
-          else
-          {
-            const double inv_d = recipFast(Quu_F);
-            k = -1 * (Qu * inv_d);
-            Kc = -1 * (QAr * inv_d);
-          }
-        }
-        const bool live = need && ok && step_ok;
-        ok = ok && step_ok;
-
-        // ---- cost-to-go update    :522-527
-        if(live)
-        {
-          dV0_l += k * Qu;
-          dV1_l += 0.5 * (k * (Quu * k));
-        }
-        const double KtQuu = Kc * Quu;
-        const double X6 = r0 ? KtQuu : (r1 ? Kc : (r2 ? QA : 0.0)); // rows: K^T Quu, K, Qux
-        const double B6 = r0 ? Kc : (r1 ? QA : (r2 ? Kc : 0.0)); // rows: K, Qux, K
-        const double B7 = pick(c1, r0 ? k : (r1 ? Qu : (r2 ? k : 0.0))); // column 1: k, Qu, k
-        const double Vn = mma(X6, B6, Qxx); // Qxx + K^T Quu K + K^T Qux + Qux^T K
-        const double VnT = mma(B6, X6, QxxT);
-        VxM = mma(X6, B7, pick(c1, S)); // column 1: Qx + K^T Quu k + K^T Qu + Qux^T k
-        Vxx = 0.5 * (Vn + VnT);
-
-        // ---- save gains    :529-530, running max of |k_i| / (|u_i| + 1)    :217-221
-        if(live)
-        {
-          if(r0)
-          {
-            if(c0)
-            {
-              Base::kt[static_cast<size_t>(i) * LW + lane_q] = k;
-            }
-            if(col < N)
-            {
-              Base::Kt[(static_cast<size_t>(i) * N + col) * LW + lane_q] = Kc;
-            }
-          }
-          k_next = k;
-          have_next = true;
-          krn = fmax(krn, fabs(k) * recipFast(fabs(u) + 1.0));
-        }
+        step(i, oa, i - 1 - i0, ob);
+        step(i - 1, ob, (i - 2 >= i0) ? i - 2 - i0 : 0, oa);
+      }
+      if(i >= i0)
+      {
+        step(i, oa, 0, ob);
       }
     }
     if(r0 && c0)

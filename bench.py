@@ -37,6 +37,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+LANE_MAPPINGS = {
+    "ddp_solve_quad_kernel": "quad: 16 instances per workgroup of 4 wavefronts; backward pass on the fp64 matrix cores "
+                             "(16 lanes per instance, v_mfma_f64_4x4x4), linearisation parallel over the horizon, "
+                             "forward pass one lane per instance (master + helper wavefront)",
+    "ddp_solve_tpi2w_kernel": "one lane per instance, 64 instances per workgroup, master + helper wavefront",
+    "ddp_solve_tpi_kernel": "one lane per instance, 64 instances per single-wavefront workgroup",
+    "ddp_solve_wpi_kernel": "one wavefront per instance: lane = timestep / matrix entry (v_mfma_f64_16x16x4) / step size",
+}
 
 
 # name -> (generator in nmpc_amd.workloads, per-GPU batch, horizon, description)
@@ -240,7 +248,7 @@ def main():
                 "backward_passes_per_iteration": n_bw,
                 "forward_passes_per_iteration": n_fw,
                 "status_counts": {str(k): int(v) for k, v in zip(*np.unique(status, return_counts=True))},
-                "lane_mapping": "one lane per instance, 64 instances per workgroup (%s)" % solver.kernelName(),
+                "lane_mapping": LANE_MAPPINGS.get(solver.kernelName(), solver.kernelName()),
                 "final_gather_ms": 1e3 * gather_s,
             },
             "instance_iterations_per_s": value * wl.B,

@@ -428,6 +428,12 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
       const int sel_h = word & 1;
       if(cmd == Pair::kCmdExit)
       {
+#ifdef NMPC_AMD_PROFILE_2W
+        if(blockIdx.x == 0 && wl == 0)
+        {
+          buf.qp_free[static_cast<size_t>(4 + wave) * LW] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+        }
+#endif
         return;
       }
       if(cmd == Pair::kCmdBackward)
@@ -449,9 +455,11 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
   }
 };
 
-/** The quad solve kernel: grid = Bp / 16 workgroups of 256 threads. */
+/** The quad solve kernel: grid = Bp / 16 workgroups of 256 threads.  amdgpu_waves_per_eu(2): with at most 256 registers
+    per lane the compiler keeps the matrix-core results in ordinary VGPRs; with the 512 a one-wave-per-SIMD kernel may
+    use it places them in accumulation registers and spends ~30 v_accvgpr_read/write per timestep moving them. */
 template<class Problem, bool kConstrained>
-__global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const Problem problem,
+__global__ __launch_bounds__(kQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(2))) void ddp_solve_quad_kernel(const Problem problem,
                                                                          const nmpc_hip_ddp_config cfg,
                                                                          const DeviceBuffers buf)
 {

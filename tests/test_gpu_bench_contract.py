@@ -33,7 +33,7 @@ def test_default_line_has_the_contract_keys():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 2.0
-    assert rf["kernel"].startswith("ddp_solve_tpi2w_kernel")
+    assert rf["kernel"].startswith("ddp_solve_quad_kernel")  # 4096 instances: one quad workgroup per CU
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
     assert d["value"] > cb["value"]  # both are batch-iterations / s of the same workload

@@ -408,18 +408,69 @@ def test_two_wave_and_single_wave_kernels_agree(model, monkeypatch):
     if model == "vertical":
         cfg["initial_lambda"] = 1e-6
     out = {}
-    for kernel in ("2w", "1w"):
+    names = {"2w": "ddp_solve_tpi2w_kernel", "1w": "ddp_solve_tpi_kernel", "quad": "ddp_solve_quad_kernel"}
+    kernels = ("2w", "1w") if model == "vertical" else ("2w", "1w", "quad")  # quad: n <= 4, one input
+    for kernel in kernels:
         monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", kernel)
         s = make_solver(wl, **cfg)
         s.solve(wl.t0, wl.x0, wl.u_init)
+        assert s.kernelName() == names[kernel]
         out[kernel] = dict(status=s.status(), iters=s.iters(), X=s.X(), U=s.U(), cost=s.cost(), kff=s.kff(),
                            Kfb=s.Kfb(), trace=s.trace(), qp=s.qpRetval(), free=s.qpFreeMask())
-    a, b = out["2w"], out["1w"]
-    for key in ("status", "iters", "qp", "free"):
-        assert np.array_equal(a[key], b[key]), key
-    assert np.array_equal(a["trace"][..., INT_COLS], b["trace"][..., INT_COLS])
-    for key in ("X", "U", "cost", "kff", "Kfb"):
-        assert scaled_err(a[key], b[key]) <= TOL, key
+    a = out["2w"]
+    for other in kernels[1:]:
+        b = out[other]
+        for key in ("status", "iters", "qp", "free"):
+            assert np.array_equal(a[key], b[key]), (other, key)
+        assert np.array_equal(a["trace"][..., INT_COLS], b["trace"][..., INT_COLS]), other
+        for key in ("X", "U", "cost", "kff", "Kfb"):
+            assert scaled_err(a[key], b[key]) <= TOL, (other, key)
+
+
+# ---------------------------------------------------------------------------------------------------
+# quad kernel (ddp_kernels_quad.hpp): n <= 4, one input; backward pass on the fp64 matrix cores
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["cartpole", "cartpole_constrained", "cartpole_reg2_alpha", "cartpole_ragged",
+                                  "cartpole_short", "bipedal"])
+def test_quad_kernel_vs_oracle(case, monkeypatch):
+    """The quad kernel is the default for these shapes up to 4096 instances: every discrete decision equals the
+    oracle's, values within the tolerances of this file — including horizons that are not a multiple of its
+    16-timestep linearisation chunk, batches that are not a multiple of its 16-instance workgroup, BoxQP, the other
+    regularisation type and a shortened step-size list (failing solves: test_failure_status_matches)."""
+    from nmpc_amd import workloads
+
+    monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    cfg = dict(max_iter=30)
+    if case == "cartpole":
+        wl = workloads.cartpole_batch(B=256, T=100, seed=21)
+    elif case == "cartpole_constrained":
+        wl = workloads.cartpole_batch(B=200, T=60, seed=22, constrained=True)
+        cfg["with_input_constraint"] = True
+    elif case == "cartpole_reg2_alpha":
+        wl = workloads.cartpole_batch(B=96, T=50, seed=23)
+        cfg.update(reg_type=2, alpha_list=np.array([1.0, 0.5, 0.25, 0.05]))
+    elif case == "cartpole_ragged":
+        wl = workloads.cartpole_batch(B=77, T=37, seed=24)
+    elif case == "cartpole_short":
+        wl = workloads.cartpole_batch(B=5, T=3, seed=25)
+        cfg["max_iter"] = 6
+    else:
+        wl = workloads.bipedal_batch(B=130, T=40, seed=26)
+    s = make_solver(wl, **cfg)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert s.kernelName() == "ddp_solve_quad_kernel"
+    ref = oracle_batch(wl, **cfg)
+    check_against_oracle(wl, s, ref)
+
+
+def test_quad_kernel_batch_threshold(monkeypatch):
+    """More than 4096 instances (more quad workgroups than CUs) go to the two-wave kernel."""
+    import nmpc_amd
+
+    monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    prob = nmpc_amd.make_problem("cartpole")
+    assert nmpc_amd.DDPSolverBatch(prob, 4096).kernelName() == "ddp_solve_quad_kernel"
+    assert nmpc_amd.DDPSolverBatch(prob, 4097).kernelName() == "ddp_solve_tpi2w_kernel"
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -22,6 +22,8 @@
 // kernels to rounding (tests/test_gpu_parity.py), not bit for bit.
 #pragma once
 
+#include <type_traits>
+
 #include <nmpc_amd/hip/ddp_kernels_2w.hpp>
 
 namespace nmpc_amd
@@ -71,6 +73,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
   static constexpr int oLu = 45;
   static constexpr int oU = 46;
   static constexpr int oZero = 47; // 0.0: what the lanes outside a masked operand read
+  static constexpr int oUinv = 48; // 1 / (|u| + 1) for the running max of |k| / (|u| + 1)
   static constexpr int kRecQ = 49; // odd: the 64 lanes of the linearisation write conflict-free
   static constexpr int kChunkSteps = 16;
   static constexpr int kChunkDoubles = 64 * kRecQ;
@@ -167,6 +170,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
     rec[oLu] = Lu[0];
     rec[oU] = u[0];
     rec[oZero] = 0.0;
+    rec[oUinv] = recipFast(fabs(u[0]) + 1.0);
   }
 
   /** One backward pass (DDPSolver::backwardPass, DDPSolver.hpp:342-534) of the four instances of this wave.  Entered by
@@ -201,7 +205,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
     const int aLxuRow = oLxu + col; // Lxu^T in every row
     struct Operands
     {
-      double Fx, Lxx, LxxT, FuM, FuB, LM, CM, LxuRow, u;
+      double Fx, Lxx, LxxT, FuM, FuB, LM, CM, LxuRow, u, uinv;
     };
     auto loadOperands = [&](int ts, Operands & o)
     {
@@ -214,7 +218,11 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
       o.LM = R[aLM];
       o.CM = R[aCM];
       o.LxuRow = R[aLxuRow];
-      o.u = R[oU];
+      if constexpr(kConstrained)
+      {
+        o.u = R[oU];
+      }
+      o.uinv = R[oUinv];
     };
 
     // ---- terminal value function    DDPSolver.hpp:349-352
@@ -251,8 +259,9 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
 
     /** One timestep of the recursion on the operands `o`; requests the operands of record `ts_next` into `o_next`
         first (they do not depend on the recursion: their LDS latency hides behind this timestep). */
-    auto step = [&](int i, const Operands & o, int ts_next, Operands & o_next)
+    auto step = [&](auto reg_tag, int i, const Operands & o, int ts_next, Operands & o_next)
     {
+      constexpr int kReg = decltype(reg_tag)::value; // Configuration::reg_type, a compile-time constant in here
       loadOperands(ts_next, o_next);
       // ---- Q terms    DDPSolver.hpp:386-408   (mma(X, Y, C) = X^T Y + C)
       const double P = mma(Vxx, o.Fx, 0.0); // Vxx^T Fx = (Fx^T Vxx)^T
@@ -269,7 +278,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
 
       // ---- regularisation    :421-441
       double Quu_F = Quu, QAr = QA, Qrr = Qr;
-      if(cfg.reg_type == 2)
+      if constexpr(kReg == 2)
       {
         const double VxxReg = (row == col) ? Vxx + lam : Vxx;
         const double R2 = mma(VxxReg, o.FuM, 0.0);
@@ -277,7 +286,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
         QAr = mma(quadBroadcast<0>(R2), o.Fx, o.LxuRow);
         Qrr = quadBroadcast<0>(mma(o.Fx, R2, o.LM));
       }
-      else if(cfg.reg_type == 1)
+      else if constexpr(kReg == 1)
       {
         Quu_F = Quu + lam;
       }
@@ -340,12 +349,15 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
             Base::Kt[(static_cast<size_t>(i) * N + col) * LW + lane_q] = Kc;
           }
         }
-        k_next = k;
-        have_next = true;
-        krn = fmax(krn, fabs(k) * recipFast(fabs(o.u) + 1.0));
       }
+      // (what a lane computes after it stopped being live is never read: a failed pass is retried or ends the solve)
+      k_next = k;
+      have_next = true;
+      krn = fmax(krn, fabs(k) * o.uinv);
     };
 
+    auto runChunks = [&](auto reg_tag)
+    {
     const int n_chunks = (T + kChunkSteps - 1) / kChunkSteps;
     for(int ch = n_chunks - 1; ch >= 0; ch--)
     {
@@ -368,13 +380,26 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
       int i = hi;
       for(; i - 1 >= i0; i -= 2)
       {
-        step(i, oa, i - 1 - i0, ob);
-        step(i - 1, ob, (i - 2 >= i0) ? i - 2 - i0 : 0, oa);
+        step(reg_tag, i, oa, i - 1 - i0, ob);
+        step(reg_tag, i - 1, ob, (i - 2 >= i0) ? i - 2 - i0 : 0, oa);
       }
       if(i >= i0)
       {
-        step(i, oa, 0, ob);
+        step(reg_tag, i, oa, 0, ob);
       }
+    }
+    };
+    if(cfg.reg_type == 2)
+    {
+      runChunks(std::integral_constant<int, 2>());
+    }
+    else if(cfg.reg_type == 1)
+    {
+      runChunks(std::integral_constant<int, 1>());
+    }
+    else
+    {
+      runChunks(std::integral_constant<int, 0>());
     }
     if(r0 && c0)
     {

@@ -76,7 +76,13 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
   static constexpr int oUinv = 48; // 1 / (|u| + 1) for the running max of |k| / (|u| + 1)
   static constexpr int kRecQ = 49; // odd: the 64 lanes of the linearisation write conflict-free
   static constexpr int kChunkSteps = 16;
-  static constexpr int kChunkDoubles = 64 * kRecQ;
+  // gains of the chunk's 64 (instance, timestep) pairs, staged in LDS and written to HBM at the chunk boundary
+  static constexpr int gK = 0; // k
+  static constexpr int gKfb = 1; // K[0 .. 3]
+  static constexpr int gLive = 5; // 1.0: this timestep's gains are to be saved (DDPSolver.hpp:529-530 was reached)
+  static constexpr int gDummy = 6;
+  static constexpr int kGainRec = 7;
+  static constexpr int kChunkDoubles = 64 * (kRecQ + kGainRec);
   // ---- mailboxes master <-> backward waves, per instance of the workgroup ----
   static constexpr int kMailIn = 4; // need, lambda, sel, t0
   static constexpr int kMailOut = 4; // ok, dV0, dV1, k_rel_norm
@@ -130,7 +136,20 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
   }
 
   /** Derivatives of timestep i of instance `inst_l` (this lane's instance in the LINEARISATION mapping) -> record. */
-  NMPC_D void lineariseStep(int i, double t0_l, const double * px, const double * pu, double * rec) const
+  struct PointQ
+  {
+    double x[N], u;
+  };
+  NMPC_D static void loadPointQ(int i, const double * px, const double * pu, PointQ & p)
+  {
+#pragma unroll
+    for(int j = 0; j < N; j++)
+    {
+      p.x[j] = px[(static_cast<size_t>(i) * N + j) * LW];
+    }
+    p.u = pu[static_cast<size_t>(i) * LW];
+  }
+  NMPC_D void lineariseStep(int i, double t0_l, const PointQ & p, double * rec) const
   {
     const double t = t0_l + i * problem.dt();
     StateDimVector x;
@@ -139,9 +158,9 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
 #pragma unroll
     for(int j = 0; j < N; j++)
     {
-      x[j] = px[(static_cast<size_t>(i) * N + j) * LW];
+      x[j] = p.x[j];
     }
-    u[0] = pu[static_cast<size_t>(i) * LW];
+    u[0] = p.u;
     StateStateDimMatrix Fx, Lxx;
     StateInputDimMatrix Fu, Lxu;
     StateDimVector Lx;
@@ -191,6 +210,11 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
     const double * px = Base::Xt + static_cast<size_t>(sel_l) * (Base::rowsX() * LW) + lane_l;
     const double * pu = Base::Ut + static_cast<size_t>(sel_l) * (Base::rowsU() * LW) + lane_l;
     double * rec_l = chunk + static_cast<size_t>(wl) * kRecQ;
+    double * gains = chunk + 64 * kRecQ;
+    const double * gain_l = gains + static_cast<size_t>(wl) * kGainRec; // linearisation mapping: read at the chunk boundary
+    // recursion mapping: rows 0 and 1 of the block write [K | k, live, -, -] of the timestep, one double per lane
+    double * gain_q = gains + static_cast<size_t>(blk * 16) * kGainRec
+                      + (row == 0 ? gKfb + col : (col == 0 ? gK : (col == 1 ? gLive : gDummy)));
     const double * rec_q = chunk + static_cast<size_t>(blk * 16) * kRecQ;
 
     // lane predicates of the natural layout
@@ -259,7 +283,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
 
     /** One timestep of the recursion on the operands `o`; requests the operands of record `ts_next` into `o_next`
         first (they do not depend on the recursion: their LDS latency hides behind this timestep). */
-    auto step = [&](auto reg_tag, int i, const Operands & o, int ts_next, Operands & o_next)
+    auto step = [&](auto reg_tag, int i, int ts, const Operands & o, int ts_next, Operands & o_next)
     {
       constexpr int kReg = decltype(reg_tag)::value; // Configuration::reg_type, a compile-time constant in here
       loadOperands(ts_next, o_next);
@@ -335,20 +359,10 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
       // Qx + K^T Quu k + K^T Qu + Qux^T k
       VxM = pick(c1, fma(Qr, k, fma(Kr, Qu, fma(KQr, k, Qxr))));
 
-      // ---- save gains    :529-530, running max of |k_i| / (|u_i| + 1)    :217-221
-      if(live)
+      // ---- save gains    :529-530 (staged, see flushGains), running max of |k_i| / (|u_i| + 1)    :217-221
+      if(row < 2)
       {
-        if(r0)
-        {
-          if(c0)
-          {
-            Base::kt[static_cast<size_t>(i) * LW + lane_q] = k;
-          }
-          if(col < N)
-          {
-            Base::Kt[(static_cast<size_t>(i) * N + col) * LW + lane_q] = Kc;
-          }
-        }
+        gain_q[static_cast<size_t>(ts) * kGainRec] = r0 ? Kc : (c0 ? k : (live ? 1.0 : 0.0));
       }
       // (what a lane computes after it stopped being live is never read: a failed pass is retried or ends the solve)
       k_next = k;
@@ -356,9 +370,29 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
       krn = fmax(krn, fabs(k) * o.uinv);
     };
 
+    /** Gains of the chunk starting at timestep i_first: LDS -> k_list_ / K_list_ in HBM, by the lane of each (instance,
+        timestep) pair in the linearisation mapping. */
+    auto flushGains = [&](int i_first)
+    {
+      const int i = i_first + ts_l;
+      if(i < T && gain_l[gLive] != 0.0)
+      {
+        Base::kt[static_cast<size_t>(i) * LW + lane_l] = gain_l[gK];
+#pragma unroll
+        for(int c = 0; c < N; c++)
+        {
+          Base::Kt[(static_cast<size_t>(i) * N + c) * LW + lane_l] = gain_l[gKfb + c];
+        }
+      }
+    };
     auto runChunks = [&](auto reg_tag)
     {
     const int n_chunks = (T + kChunkSteps - 1) / kChunkSteps;
+    PointQ pt;
+    {
+      const int i = ((n_chunks - 1) * kChunkSteps + ts_l < T) ? (n_chunks - 1) * kChunkSteps + ts_l : T - 1;
+      loadPointQ(i, px, pu, pt);
+    }
     for(int ch = n_chunks - 1; ch >= 0; ch--)
     {
       const int i0 = ch * kChunkSteps;
@@ -367,11 +401,21 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
         const unsigned long long tl = __builtin_readcyclecounter();
 #endif
         const int i = (i0 + ts_l < T) ? i0 + ts_l : T - 1;
-        lineariseStep(i, t0_l, px, pu, rec_l);
+        lineariseStep(i, t0_l, pt, rec_l);
 #ifdef NMPC_AMD_PROFILE_2W
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         Pair::prof_wait += __builtin_readcyclecounter() - tl; // reported as "barrier wait": the linearisation share
 #endif
+      }
+      // HBM traffic of this wave happens here, one chunk behind / ahead of the recursion: the previous chunk's gains
+      // go out, then the next chunk's (x, u) are requested — both have the 16 recursion steps below to complete
+      if(ch + 1 < n_chunks)
+      {
+        flushGains(i0 + kChunkSteps);
+      }
+      {
+        const int in = i0 - kChunkSteps + ts_l; // (unconditional, clamped: the last request is never used)
+        loadPointQ(in > 0 ? in : 0, px, pu, pt);
       }
       const int hi = (i0 + kChunkSteps - 1 < T) ? i0 + kChunkSteps - 1 : T - 1;
       // two operand sets, loop unrolled by two: no register copies between timesteps
@@ -380,14 +424,15 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
       int i = hi;
       for(; i - 1 >= i0; i -= 2)
       {
-        step(reg_tag, i, oa, i - 1 - i0, ob);
-        step(reg_tag, i - 1, ob, (i - 2 >= i0) ? i - 2 - i0 : 0, oa);
+        step(reg_tag, i, i - i0, oa, i - 1 - i0, ob);
+        step(reg_tag, i - 1, i - 1 - i0, ob, (i - 2 >= i0) ? i - 2 - i0 : 0, oa);
       }
       if(i >= i0)
       {
-        step(reg_tag, i, oa, 0, ob);
+        step(reg_tag, i, i - i0, oa, 0, ob);
       }
     }
+    flushGains(0);
     };
     if(cfg.reg_type == 2)
     {
@@ -480,11 +525,12 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
   }
 };
 
-/** The quad solve kernel: grid = Bp / 16 workgroups of 256 threads.  amdgpu_waves_per_eu(2): with at most 256 registers
-    per lane the compiler keeps the matrix-core results in ordinary VGPRs; with the 512 a one-wave-per-SIMD kernel may
-    use it places them in accumulation registers and spends ~30 v_accvgpr_read/write per timestep moving them. */
+/** The quad solve kernel: grid = Bp / 16 workgroups of 256 threads.  Compile the translation unit with
+    `-mllvm --amdgpu-mfma-vgpr-form` (nmpc_amd/build.py does): by default a kernel that may use 512 registers gets its
+    matrix-core results in accumulation registers and spends ~30 v_accvgpr_read/write per timestep moving them to the
+    VALU / DPP instructions that consume them (10.3k -> 10.6k iterations/s on the headline workload). */
 template<class Problem, bool kConstrained>
-__global__ __launch_bounds__(kQuadWaves * 64) __attribute__((amdgpu_waves_per_eu(2))) void ddp_solve_quad_kernel(const Problem problem,
+__global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const Problem problem,
                                                                          const nmpc_hip_ddp_config cfg,
                                                                          const DeviceBuffers buf)
 {

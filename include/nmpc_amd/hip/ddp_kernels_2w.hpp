@@ -867,14 +867,19 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       candidate trajectory (the helper issues ONLY stores during this pass, the master ONLY loads: a wave with both
       kinds in flight has to drain them all at every wait), returns the candidate total cost through
       LDS. */
-  NMPC_D void forwardHelper(int sel_h) const
+  NMPC_D void forwardHelper(int sel_h, bool initial = false) const
   {
-    const int cs = 1 - sel_h;
+    // forward pass: the candidate half; initial rollout (rolloutMaster): the trajectory half itself
+    const int cs = initial ? sel_h : 1 - sel_h;
     const unsigned cx = Base::offX(cs), cu = Base::offU(cs), cc = Base::offC(cs);
     double J = 0;
     for(int i = 0; i < T; i++)
     {
       wgBarrier(); // barrier i: the master wrote "out" of step i
+      if(initial)
+      {
+        Base::elem(buf.input_dim, T, i) = Base::inputDimAt(current_t + i * problem.dt());
+      }
       J += consumeStep(i, cx, cu, cc);
     }
     // terminal state x'_T is in the "out" part of slot T & 1 (written by the master after barrier T-1)
@@ -983,6 +988,78 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     wgBarrier(); // barrier i
   }
 
+  /** Initial rollout (DDPSolver.hpp:83-95) in the master / helper split of the forward pass: the master keeps the
+      chain x_{i+1} = stateEq(x_i, u_i) and prefetches u (ring of kFwdAhead), the helper evaluates the costs and does
+      all stores (a lone wave doing both waits for every load of u behind its own stores: ~1000 cycles per timestep). */
+  NMPC_D void rolloutStep(int i, unsigned ou, InputDimVector & u_ring, StateDimVector & x) const
+  {
+    const int slot = i & 1;
+    const double t = current_t + i * problem.dt();
+    const int m = Base::inputDimAt(t);
+    InputDimVector u;
+    u.resize(m);
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      pin(u_ring[a]);
+      u[a] = (a < m) ? u_ring[a] : 0.0;
+    }
+    Base::loadU(Base::uRow(i + kFwdAhead < T ? i + kFwdAhead : T - 1), ou, u_ring, MM);
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      rec(slot, oXc + j) = x[j];
+    }
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      rec(slot, oUc + a) = u[a];
+    }
+    x = problem.stateEq(t, x, u);
+    wgBarrier(); // barrier i
+  }
+
+  NMPC_D void rolloutMaster()
+  {
+    static_assert(kFwdAhead == 4, "rolloutMaster is written for a ring of four register sets");
+    const unsigned ou = Base::offU(sel);
+    StateDimVector x;
+    Base::loadX(Base::tileBase(buf.x0, N), Base::offB(), x);
+    InputDimVector u0, u1, u2, u3;
+    Base::loadU(Base::uRow(0), ou, u0, MM);
+    Base::loadU(Base::uRow(T > 1 ? 1 : T - 1), ou, u1, MM);
+    Base::loadU(Base::uRow(T > 2 ? 2 : T - 1), ou, u2, MM);
+    Base::loadU(Base::uRow(T > 3 ? 3 : T - 1), ou, u3, MM);
+    int i = 0;
+    for(; i + 3 < T; i += 4)
+    {
+      rolloutStep(i, ou, u0, x);
+      rolloutStep(i + 1, ou, u1, x);
+      rolloutStep(i + 2, ou, u2, x);
+      rolloutStep(i + 3, ou, u3, x);
+    }
+    if(i < T)
+    {
+      rolloutStep(i, ou, u0, x);
+    }
+    if(i + 1 < T)
+    {
+      rolloutStep(i + 1, ou, u1, x);
+    }
+    if(i + 2 < T)
+    {
+      rolloutStep(i + 2, ou, u2, x);
+    }
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      rec(T & 1, oXc + j) = x[j];
+    }
+    wgBarrier(); // barrier E
+    wgBarrier(); // barrier F
+    J_cur = mailCost();
+  }
+
   NMPC_D void forwardMaster(double alpha)
   {
     // kFwdAhead register sets form a ring: set r holds timestep i with i % kFwdAhead == r, the loop is unrolled by
@@ -1036,7 +1113,8 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   {
     kCmdExit = 0,
     kCmdBackward = 1,
-    kCmdForward = 2
+    kCmdForward = 2,
+    kCmdRollout = 3
   };
 
   NMPC_D void post(int cmd) const
@@ -1069,7 +1147,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       }
       else
       {
-        forwardHelper(sel_h);
+        forwardHelper(sel_h, cmd == kCmdRollout);
         profEnd(1);
       }
     }
@@ -1103,7 +1181,8 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     dV0 = dV1 = 0;
     k_rel_norm = 0;
     J_cand = 0;
-    Base::initialRollout();
+    post(kCmdRollout);
+    rolloutMaster();
 
     double tr[NMPC_HIP_NTRACE];
 #pragma unroll

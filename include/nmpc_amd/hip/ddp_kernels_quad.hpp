@@ -512,7 +512,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
       }
       else if(wave == 1)
       {
-        Pair::forwardHelper(sel_h);
+        Pair::forwardHelper(sel_h, cmd == Pair::kCmdRollout);
       }
       else
       {

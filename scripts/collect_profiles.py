@@ -20,6 +20,9 @@ shutil.copy(os.path.join(src, "stats_kernel_stats.csv"), os.path.join(dst, f"{ta
 shutil.copy(os.path.join(src, "ubench_clock.txt"), os.path.join(dst, f"{tag}_ubench.txt"))
 if os.path.exists(os.path.join(src, "roles.txt")):  # per-role cycle counters of the -DNMPC_AMD_PROFILE_2W build
     shutil.copy(os.path.join(src, "roles.txt"), os.path.join(dst, f"{tag}_roles.txt"))
+for extra in ("batch_scaling.txt", "ubench_mfma4.txt"):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
 
 def means(pattern_file, kernel_pat):
     out = collections.defaultdict(list)
@@ -48,7 +51,7 @@ json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
 hbm_bytes = (pm["FETCH_SIZE"] * fetch_scale + pm["WRITE_SIZE"] * write_scale) * 1024.0
 with open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w") as f:
     f.write(f"kernel: {bench['roofline']['kernel']} (bench.py --steps 10 --warmup 2, batch 4096, 8 iterations per launch)\n")
-    f.write("per-launch means; SQ_* cycle counters are in quad-cycles (x4 = shader cycles), summed over the 64 waves\n")
+    f.write("per-launch means; SQ_* cycle counters are in quad-cycles (x4 = shader cycles), summed over all waves of the launch\n")
     for k in sorted(pm):
         f.write(f"  {k:28s} n={cnt[k]:3d} mean={pm[k]:18.1f}\n")
     wc = pm.get("SQ_WAVE_CYCLES", 0.0)
@@ -57,8 +60,8 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w") as f:
         f.write(f"  VALU-active share of wave cycles   {pm['SQ_ACTIVE_INST_VALU'] / wc:6.3f}\n")
         f.write(f"  s_waitcnt (memory) share           {pm['SQ_WAIT_ANY'] / wc:6.3f}\n")
         f.write(f"  issue-stall share                  {pm['SQ_WAIT_INST_ANY'] / wc:6.3f}\n")
-        f.write(f"  VALU instructions per wave         {pm['SQ_INSTS_VALU'] / 64:12.0f}\n")
-        f.write(f"  fp64 FMA+MUL+ADD per wave          {(pm['SQ_INSTS_VALU_FMA_F64'] + pm['SQ_INSTS_VALU_MUL_F64'] + pm['SQ_INSTS_VALU_ADD_F64']) / 64:12.0f}\n")
+        f.write(f"  VALU instructions per wave         {pm['SQ_INSTS_VALU'] / max(pm.get('SQ_WAVES', 64.0), 1.0):12.0f}\n")
+        f.write(f"  fp64 FMA+MUL+ADD per wave          {(pm['SQ_INSTS_VALU_FMA_F64'] + pm['SQ_INSTS_VALU_MUL_F64'] + pm['SQ_INSTS_VALU_ADD_F64']) / max(pm.get('SQ_WAVES', 64.0), 1.0):12.0f}\n")
         f.write(f"  MFMA f64 instructions              {pm.get('SQ_INSTS_VALU_MFMA_F64', 0):12.0f}\n")
     f.write(f"\nHBM-side traffic per launch (corrected): fetch {pm['FETCH_SIZE'] * fetch_scale * 1024 / 1e6:.1f} MB"
             f" + write {pm['WRITE_SIZE'] * write_scale * 1024 / 1e6:.1f} MB = {hbm_bytes / 1e6:.1f} MB\n")

@@ -20,5 +20,12 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o calW -- ./scripts/uben
 ./scripts/ubench_clock > $OUT/ubench_clock.txt 2>&1
 ./scripts/ubench_latency >> $OUT/ubench_clock.txt 2>&1
 ./scripts/ubench_recip >> $OUT/ubench_clock.txt 2>&1
-if [ -f nmpc_amd/lib/alt/prof.so ]; then NMPC_HIP_DDP_LIB=$PWD/nmpc_amd/lib/alt/prof.so python scripts/profile_2w.py > $OUT/roles.txt 2>&1; fi
+if [ -f nmpc_amd/lib/alt/prof.so ]; then
+  echo "== quad kernel (default for this batch)" > $OUT/roles.txt
+  NMPC_HIP_DDP_LIB=$PWD/nmpc_amd/lib/alt/prof.so python scripts/profile_quad.py >> $OUT/roles.txt 2>&1
+  echo "== two-wave kernel (NMPC_HIP_DDP_KERNEL=2w)" >> $OUT/roles.txt
+  NMPC_HIP_DDP_KERNEL=2w NMPC_HIP_DDP_LIB=$PWD/nmpc_amd/lib/alt/prof.so python scripts/profile_2w.py >> $OUT/roles.txt 2>&1
+fi
+python scripts/batch_scaling.py > $OUT/batch_scaling.txt 2>&1
+./scripts/ubench_mfma4 > $OUT/ubench_mfma4.txt 2>&1
 ls $OUT

@@ -164,16 +164,24 @@ struct ModelOpsFor
       {
         constexpr size_t quad_lds = QuadSolver<Problem, false>::kLdsBytes;
         const dim3 g(buf.Bp / kQuadInstances), blk(kQuadWaves * 64);
-        // > 64 KB of dynamic LDS has to be requested per kernel
-        static const hipError_t attr_u = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(quad_lds));
-        static const hipError_t attr_c = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(quad_lds));
-        if(attr_u != hipSuccess || attr_c != hipSuccess)
+        // > 64 KB of dynamic LDS has to be requested per kernel and device (once: remembered per device ordinal)
+        static bool requested[64] = {};
+        int dev = 0;
+        if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
         {
-          return attr_u != hipSuccess ? attr_u : attr_c;
+          return hipErrorInvalidDevice;
+        }
+        if(!requested[dev])
+        {
+          const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(quad_lds));
+          const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(quad_lds));
+          if(attr_u != hipSuccess || attr_c != hipSuccess)
+          {
+            return attr_u != hipSuccess ? attr_u : attr_c;
+          }
+          requested[dev] = true;
         }
         if(con)
         {

@@ -213,8 +213,9 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
     double * gains = chunk + 64 * kRecQ;
     const double * gain_l = gains + static_cast<size_t>(wl) * kGainRec; // linearisation mapping: read at the chunk boundary
     // recursion mapping: rows 0 and 1 of the block write [K | k, live, -, -] of the timestep, one double per lane
+    // (rows 2 and 3 write the record's dummy slot: no branch in the recursion loop)
     double * gain_q = gains + static_cast<size_t>(blk * 16) * kGainRec
-                      + (row == 0 ? gKfb + col : (col == 0 ? gK : (col == 1 ? gLive : gDummy)));
+                      + (row == 0 ? gKfb + col : ((row == 1 && col == 0) ? gK : ((row == 1 && col == 1) ? gLive : gDummy)));
     const double * rec_q = chunk + static_cast<size_t>(blk * 16) * kRecQ;
 
     // lane predicates of the natural layout
@@ -360,10 +361,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
       VxM = pick(c1, fma(Qr, k, fma(Kr, Qu, fma(KQr, k, Qxr))));
 
       // ---- save gains    :529-530 (staged, see flushGains), running max of |k_i| / (|u_i| + 1)    :217-221
-      if(row < 2)
-      {
-        gain_q[static_cast<size_t>(ts) * kGainRec] = r0 ? Kc : (c0 ? k : (live ? 1.0 : 0.0));
-      }
+      gain_q[static_cast<size_t>(ts) * kGainRec] = r0 ? Kc : (c0 ? k : (live ? 1.0 : 0.0));
       // (what a lane computes after it stopped being live is never read: a failed pass is retried or ends the solve)
       k_next = k;
       have_next = true;
@@ -418,6 +416,23 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
         loadPointQ(in > 0 ? in : 0, px, pu, pt);
       }
       const int hi = (i0 + kChunkSteps - 1 < T) ? i0 + kChunkSteps - 1 : T - 1;
+      if constexpr(!kConstrained)
+      {
+        if(hi - i0 + 1 == kChunkSteps)
+        {
+          // a full chunk as straight-line code: one scheduling region for the 16 timesteps (the compiler fills the
+          // recursion's dependency stalls across timesteps) and immediate LDS offsets.  (The BoxQP variant would not
+          // fit the instruction cache.)
+          Operands o2[2];
+          loadOperands(kChunkSteps - 1, o2[(kChunkSteps - 1) & 1]);
+#pragma unroll
+          for(int ts = kChunkSteps - 1; ts >= 0; ts--)
+          {
+            step(reg_tag, i0 + ts, ts, o2[ts & 1], ts > 0 ? ts - 1 : 0, o2[(ts & 1) ^ 1]);
+          }
+          continue;
+        }
+      }
       // two operand sets, loop unrolled by two: no register copies between timesteps
       Operands oa, ob;
       loadOperands(hi - i0, oa);

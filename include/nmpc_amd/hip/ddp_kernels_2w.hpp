@@ -971,6 +971,11 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
         uc[a] = 0;
       }
     }
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      pin(uc[a]); // u' is complete: the register set of `nom` is dead and the requests below can land in it (no copies)
+    }
     // unconditional (the last two requests re-read timestep T-1 and are never used): with a branch around the loads
     // the compiler cannot count the requests in flight and falls back to waiting for all of them at every timestep
     loadNominal(i + kFwdAhead < T ? i + kFwdAhead : T - 1, sel, nom);

@@ -385,69 +385,69 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
     };
     auto runChunks = [&](auto reg_tag)
     {
-    const int n_chunks = (T + kChunkSteps - 1) / kChunkSteps;
-    PointQ pt;
-    {
-      const int i = ((n_chunks - 1) * kChunkSteps + ts_l < T) ? (n_chunks - 1) * kChunkSteps + ts_l : T - 1;
-      loadPointQ(i, px, pu, pt);
-    }
-    for(int ch = n_chunks - 1; ch >= 0; ch--)
-    {
-      const int i0 = ch * kChunkSteps;
+      const int n_chunks = (T + kChunkSteps - 1) / kChunkSteps;
+      PointQ pt;
       {
-#ifdef NMPC_AMD_PROFILE_2W
-        const unsigned long long tl = __builtin_readcyclecounter();
-#endif
-        const int i = (i0 + ts_l < T) ? i0 + ts_l : T - 1;
-        lineariseStep(i, t0_l, pt, rec_l);
-#ifdef NMPC_AMD_PROFILE_2W
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        Pair::prof_wait += __builtin_readcyclecounter() - tl; // reported as "barrier wait": the linearisation share
-#endif
+        const int i = ((n_chunks - 1) * kChunkSteps + ts_l < T) ? (n_chunks - 1) * kChunkSteps + ts_l : T - 1;
+        loadPointQ(i, px, pu, pt);
       }
-      // HBM traffic of this wave happens here, one chunk behind / ahead of the recursion: the previous chunk's gains
-      // go out, then the next chunk's (x, u) are requested — both have the 16 recursion steps below to complete
-      if(ch + 1 < n_chunks)
+      for(int ch = n_chunks - 1; ch >= 0; ch--)
       {
-        flushGains(i0 + kChunkSteps);
-      }
-      {
-        const int in = i0 - kChunkSteps + ts_l; // (unconditional, clamped: the last request is never used)
-        loadPointQ(in > 0 ? in : 0, px, pu, pt);
-      }
-      const int hi = (i0 + kChunkSteps - 1 < T) ? i0 + kChunkSteps - 1 : T - 1;
-      if constexpr(!kConstrained)
-      {
-        if(hi - i0 + 1 == kChunkSteps)
+        const int i0 = ch * kChunkSteps;
         {
-          // a full chunk as straight-line code: one scheduling region for the 16 timesteps (the compiler fills the
-          // recursion's dependency stalls across timesteps) and immediate LDS offsets.  (The BoxQP variant would not
-          // fit the instruction cache.)
-          Operands o2[2];
-          loadOperands(kChunkSteps - 1, o2[(kChunkSteps - 1) & 1]);
-#pragma unroll
-          for(int ts = kChunkSteps - 1; ts >= 0; ts--)
+#ifdef NMPC_AMD_PROFILE_2W
+          const unsigned long long tl = __builtin_readcyclecounter();
+#endif
+          const int i = (i0 + ts_l < T) ? i0 + ts_l : T - 1;
+          lineariseStep(i, t0_l, pt, rec_l);
+#ifdef NMPC_AMD_PROFILE_2W
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          Pair::prof_wait += __builtin_readcyclecounter() - tl; // reported as "barrier wait": the linearisation share
+#endif
+        }
+        // HBM traffic of this wave happens here, one chunk behind / ahead of the recursion: the previous chunk's gains
+        // go out, then the next chunk's (x, u) are requested — both have the 16 recursion steps below to complete
+        if(ch + 1 < n_chunks)
+        {
+          flushGains(i0 + kChunkSteps);
+        }
+        {
+          const int in = i0 - kChunkSteps + ts_l; // (unconditional, clamped: the last request is never used)
+          loadPointQ(in > 0 ? in : 0, px, pu, pt);
+        }
+        const int hi = (i0 + kChunkSteps - 1 < T) ? i0 + kChunkSteps - 1 : T - 1;
+        if constexpr(!kConstrained)
+        {
+          if(hi - i0 + 1 == kChunkSteps)
           {
-            step(reg_tag, i0 + ts, ts, o2[ts & 1], ts > 0 ? ts - 1 : 0, o2[(ts & 1) ^ 1]);
+            // a full chunk as straight-line code: one scheduling region for the 16 timesteps (the compiler fills the
+            // recursion's dependency stalls across timesteps) and immediate LDS offsets.  (The BoxQP variant would not
+            // fit the instruction cache.)
+            Operands o2[2];
+            loadOperands(kChunkSteps - 1, o2[(kChunkSteps - 1) & 1]);
+#pragma unroll
+            for(int ts = kChunkSteps - 1; ts >= 0; ts--)
+            {
+              step(reg_tag, i0 + ts, ts, o2[ts & 1], ts > 0 ? ts - 1 : 0, o2[(ts & 1) ^ 1]);
+            }
+            continue;
           }
-          continue;
+        }
+        // two operand sets, loop unrolled by two: no register copies between timesteps
+        Operands oa, ob;
+        loadOperands(hi - i0, oa);
+        int i = hi;
+        for(; i - 1 >= i0; i -= 2)
+        {
+          step(reg_tag, i, i - i0, oa, i - 1 - i0, ob);
+          step(reg_tag, i - 1, i - 1 - i0, ob, (i - 2 >= i0) ? i - 2 - i0 : 0, oa);
+        }
+        if(i >= i0)
+        {
+          step(reg_tag, i, i - i0, oa, 0, ob);
         }
       }
-      // two operand sets, loop unrolled by two: no register copies between timesteps
-      Operands oa, ob;
-      loadOperands(hi - i0, oa);
-      int i = hi;
-      for(; i - 1 >= i0; i -= 2)
-      {
-        step(reg_tag, i, i - i0, oa, i - 1 - i0, ob);
-        step(reg_tag, i - 1, i - 1 - i0, ob, (i - 2 >= i0) ? i - 2 - i0 : 0, oa);
-      }
-      if(i >= i0)
-      {
-        step(reg_tag, i, i - i0, oa, 0, ob);
-      }
-    }
-    flushGains(0);
+      flushGains(0);
     };
     if(cfg.reg_type == 2)
     {

@@ -82,7 +82,11 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   static constexpr int kFwdRec = oUc + MM;
   static constexpr int kRec = (kBwdRec > kFwdRec && !kForwardRecordsOnly) ? kBwdRec : kFwdRec;
   //! LDS doubles per workgroup: two record slots + per-lane mailboxes (flags, J_cand)
-  static constexpr int kLdsDoubles = (2 * kRec + 2) * static_cast<int>(LW);
+  //! forward hand-off: one barrier per kFwdGroup timesteps; two groups of record slots + one slot for x'_T
+  static constexpr int kFwdGroup = 4;
+  static constexpr int kFwdSlots = 2 * kFwdGroup + 1;
+  static constexpr int kRecArea = (2 * kRec > kFwdSlots * kFwdRec) ? 2 * kRec : kFwdSlots * kFwdRec;
+  static constexpr int kLdsDoubles = (kRecArea + 2) * static_cast<int>(LW);
   static constexpr size_t kLdsBytes = static_cast<size_t>(kLdsDoubles) * sizeof(double);
   static constexpr bool kFits = kLdsBytes <= 64 * 1024;
 
@@ -101,13 +105,17 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   {
     return lds[(static_cast<size_t>(slot) * kRec + idx) * LW + lane];
   }
+  NMPC_D double & frec(int slot, int idx) const
+  {
+    return lds[(static_cast<size_t>(slot) * kFwdRec + idx) * LW + lane];
+  }
   NMPC_D double & mailFlags() const
   {
-    return lds[(2 * static_cast<size_t>(kRec)) * LW + lane];
+    return lds[static_cast<size_t>(kRecArea) * LW + lane];
   }
   NMPC_D double & mailCost() const
   {
-    return lds[(2 * static_cast<size_t>(kRec) + 1) * LW + lane];
+    return lds[(static_cast<size_t>(kRecArea) + 1) * LW + lane];
   }
   /** Workgroup barrier for the LDS hand-off.  Only LDS traffic has to be complete (lgkmcnt); __syncthreads() would
       also wait for vmcnt(0), i.e. drain the helper's HBM prefetches and the stores of every timestep. */
@@ -873,23 +881,36 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     const int cs = initial ? sel_h : 1 - sel_h;
     const unsigned cx = Base::offX(cs), cu = Base::offU(cs), cc = Base::offC(cs);
     double J = 0;
-    for(int i = 0; i < T; i++)
+    const int n_full = T / kFwdGroup;
+    for(int g = 0; g < n_full; g++)
     {
-      wgBarrier(); // barrier i: the master wrote "out" of step i
+      wgBarrier(); // barrier g: the master wrote the records of timesteps 4 g .. 4 g + 3
+#pragma unroll
+      for(int r = 0; r < kFwdGroup; r++)
+      {
+        const int i = g * kFwdGroup + r;
+        if(initial)
+        {
+          Base::elem(buf.input_dim, T, i) = Base::inputDimAt(current_t + i * problem.dt());
+        }
+        J += consumeStep(i, cx, cu, cc);
+      }
+    }
+    wgBarrier(); // barrier E: the remaining timesteps and x'_T (slot 2 * kFwdGroup) are available
+    for(int i = n_full * kFwdGroup; i < T; i++)
+    {
       if(initial)
       {
         Base::elem(buf.input_dim, T, i) = Base::inputDimAt(current_t + i * problem.dt());
       }
       J += consumeStep(i, cx, cu, cc);
     }
-    // terminal state x'_T is in the "out" part of slot T & 1 (written by the master after barrier T-1)
-    wgBarrier(); // barrier E: x'_T available
     {
       StateDimVector xT;
 #pragma unroll kU
       for(int j = 0; j < N; j++)
       {
-        xT[j] = rec(T & 1, oXc + j);
+        xT[j] = frec(2 * kFwdGroup, oXc + j);
       }
       Base::storeX(Base::xRow(T), cx, xT);
       const double cT = problem.terminalCost(current_t + T * problem.dt(), xT);
@@ -903,7 +924,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   /** Helper: cost + stores of step i from the "out" record the master wrote. */
   NMPC_D double consumeStep(int i, unsigned cx, unsigned cu, unsigned cc) const
   {
-    const int slot = i & 1;
+    const int slot = i % (2 * kFwdGroup);
     const double t = current_t + i * problem.dt();
     const int m = Base::inputDimAt(t);
     StateDimVector x;
@@ -912,12 +933,12 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 #pragma unroll kU
     for(int j = 0; j < N; j++)
     {
-      x[j] = rec(slot, oXc + j);
+      x[j] = frec(slot, oXc + j);
     }
 #pragma unroll kU
     for(int a = 0; a < MM; a++)
     {
-      u[a] = rec(slot, oUc + a);
+      u[a] = frec(slot, oUc + a);
     }
     Base::storeX(Base::xRow(i), cx, x);
     Base::storeU(Base::uRow(i), cu, u, m);
@@ -932,7 +953,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   static constexpr int kFwdAhead = 4;
   NMPC_D void forwardStep(int i, double alpha, Nominal & nom, StateDimVector & xc) const
   {
-    const int slot = i & 1;
+    const int slot = i % (2 * kFwdGroup);
     const double t = current_t + i * problem.dt();
     const int m = Base::inputDimAt(t);
 #pragma unroll kU
@@ -982,15 +1003,14 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 #pragma unroll kU
     for(int j = 0; j < N; j++)
     {
-      rec(slot, oXc + j) = xc[j];
+      frec(slot, oXc + j) = xc[j];
     }
 #pragma unroll kU
     for(int a = 0; a < MM; a++)
     {
-      rec(slot, oUc + a) = uc[a];
+      frec(slot, oUc + a) = uc[a];
     }
     xc = problem.stateEq(t, xc, uc);
-    wgBarrier(); // barrier i
   }
 
   /** Initial rollout (DDPSolver.hpp:83-95) in the master / helper split of the forward pass: the master keeps the
@@ -998,7 +1018,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       all stores (a lone wave doing both waits for every load of u behind its own stores: ~1000 cycles per timestep). */
   NMPC_D void rolloutStep(int i, unsigned ou, InputDimVector & u_ring, StateDimVector & x) const
   {
-    const int slot = i & 1;
+    const int slot = i % (2 * kFwdGroup);
     const double t = current_t + i * problem.dt();
     const int m = Base::inputDimAt(t);
     InputDimVector u;
@@ -1013,15 +1033,14 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 #pragma unroll kU
     for(int j = 0; j < N; j++)
     {
-      rec(slot, oXc + j) = x[j];
+      frec(slot, oXc + j) = x[j];
     }
 #pragma unroll kU
     for(int a = 0; a < MM; a++)
     {
-      rec(slot, oUc + a) = u[a];
+      frec(slot, oUc + a) = u[a];
     }
     x = problem.stateEq(t, x, u);
-    wgBarrier(); // barrier i
   }
 
   NMPC_D void rolloutMaster()
@@ -1042,6 +1061,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       rolloutStep(i + 1, ou, u1, x);
       rolloutStep(i + 2, ou, u2, x);
       rolloutStep(i + 3, ou, u3, x);
+      wgBarrier(); // barrier of this group of kFwdGroup timesteps
     }
     if(i < T)
     {
@@ -1058,7 +1078,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 #pragma unroll kU
     for(int j = 0; j < N; j++)
     {
-      rec(T & 1, oXc + j) = x[j];
+      frec(2 * kFwdGroup, oXc + j) = x[j];
     }
     wgBarrier(); // barrier E
     wgBarrier(); // barrier F
@@ -1070,7 +1090,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     // kFwdAhead register sets form a ring: set r holds timestep i with i % kFwdAhead == r, the loop is unrolled by
     // kFwdAhead so that every set keeps its registers (no copies) and the compiler can count the requests in flight
     Nominal n0, n1, n2, n3;
-    static_assert(kFwdAhead == 4, "forwardMaster is written for a ring of four register sets");
+    static_assert(kFwdAhead == 4 && kFwdGroup == 4, "forwardMaster is written for a ring of four register sets");
     loadNominal(0, sel, n0);
     loadNominal(T > 1 ? 1 : T - 1, sel, n1);
     loadNominal(T > 2 ? 2 : T - 1, sel, n2);
@@ -1088,6 +1108,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       forwardStep(i + 1, alpha, n1, xc);
       forwardStep(i + 2, alpha, n2, xc);
       forwardStep(i + 3, alpha, n3, xc);
+      wgBarrier(); // barrier of this group of kFwdGroup timesteps
     }
     if(i < T)
     {
@@ -1104,7 +1125,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 #pragma unroll kU
     for(int j = 0; j < N; j++)
     {
-      rec(T & 1, oXc + j) = xc[j];
+      frec(2 * kFwdGroup, oXc + j) = xc[j];
     }
     wgBarrier(); // barrier E
     wgBarrier(); // barrier F

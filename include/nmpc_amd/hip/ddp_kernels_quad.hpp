@@ -531,7 +531,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
       }
       else
       {
-        for(int i = 0; i < T + 2; i++)
+        for(int i = 0; i < T / Pair::kFwdGroup + 2; i++) // one barrier per group of timesteps, then E and F
         {
           Pair::wgBarrier();
         }

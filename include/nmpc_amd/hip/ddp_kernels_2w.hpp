@@ -951,11 +951,14 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       i + kFwdAhead is requested while timestep i is computed: a request takes 500 .. 1500 cycles (L2 / MALL / HBM), a
       timestep ~500.  The candidate (x', u') goes to the helper through LDS. */
   static constexpr int kFwdAhead = 4;
+  template<bool kPinInputs = true>
   NMPC_D void forwardStep(int i, double alpha, Nominal & nom, StateDimVector & xc) const
   {
     const int slot = i % (2 * kFwdGroup);
     const double t = current_t + i * problem.dt();
     const int m = Base::inputDimAt(t);
+    if constexpr(kPinInputs)
+    {
 #pragma unroll kU
     for(int j = 0; j < N; j++)
     {
@@ -971,6 +974,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     for(int e = 0; e < MM * N; e++)
     {
       pin(nom.K[e]);
+    }
     }
     InputDimVector uc;
     uc.resize(m);
@@ -1105,9 +1109,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     for(; i + 3 < T; i += 4)
     {
       forwardStep(i, alpha, n0, xc);
-      forwardStep(i + 1, alpha, n1, xc);
-      forwardStep(i + 2, alpha, n2, xc);
-      forwardStep(i + 3, alpha, n3, xc);
+      forwardStep<false>(i + 1, alpha, n1, xc);
+      forwardStep<false>(i + 2, alpha, n2, xc);
+      forwardStep<false>(i + 3, alpha, n3, xc);
       wgBarrier(); // barrier of this group of kFwdGroup timesteps
     }
     if(i < T)

@@ -1,6 +1,6 @@
 // gfx950 device code of the batched DDP solver, LANE MAPPING "TPI-2W": one lane per problem instance as in
 // ddp_kernels.hpp, but TWO wavefronts per 64 instances in one workgroup, specialised by role and coupled through
-// LDS records (one s_barrier per timestep):
+// LDS records (one s_barrier per backward timestep, one per four forward timesteps):
 //
 //   master wave   owns the per-instance solver state and executes only what is on the sequential dependency
 //                 chain: the Riccati recursion (backward) and u' -> x' (forward);
@@ -8,7 +8,7 @@
 //                           (they do not depend on the recursion) and stages them in an LDS record;
 //                 forward : takes the master's (x', u') to evaluate runningCost / terminalCost, accumulate the
 //                           candidate cost and do all HBM stores (the master prefetches the nominal x, u, k, K itself,
-//                           two timesteps ahead).
+//                           four timesteps ahead); the initial rollout uses the same split.
 //
 // Every wave has only ONE kind of global memory operation in flight in any pass (backward: helper loads, master
 // stores; forward: master loads, helper stores).  gfx9 counts loads and stores in one vmcnt and they may complete out

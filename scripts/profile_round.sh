@@ -6,6 +6,14 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${1:-r01}
 OUT=gpurun_out/profile_$TAG
 mkdir -p $OUT
+# microbenchmark binaries (git-ignored): build what is missing
+build_ubench() { [ -x scripts/$2 ] || hipcc --offload-arch=gfx950 -O2 -w scripts/$1 -o scripts/$2; }
+build_ubench ubench_clock.hip ubench_clock
+build_ubench ubench_latency.hip ubench_latency
+build_ubench ubench_recip.hip ubench_recip
+build_ubench ubench_hbm_counters.hip ubench_hbm_counters
+build_ubench ubench_mfma_f64_4x4.hip ubench_mfma4
+build_ubench ubench_mfma4_rate.hip ubench_mfma4_rate
 BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 echo "== bench (unprofiled)" > $OUT/bench.txt
 python bench.py --steps 50 --warmup 5 >> $OUT/bench.txt 2>&1
@@ -28,4 +36,5 @@ if [ -f nmpc_amd/lib/alt/prof.so ]; then
 fi
 python scripts/batch_scaling.py > $OUT/batch_scaling.txt 2>&1
 ./scripts/ubench_mfma4 > $OUT/ubench_mfma4.txt 2>&1
+./scripts/ubench_mfma4_rate >> $OUT/ubench_mfma4.txt 2>&1
 ls $OUT

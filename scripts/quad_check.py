@@ -1,3 +1,6 @@
+"""A/B check of the quad kernel against the two-wave kernel (NMPC_HIP_DDP_KERNEL=quad / 2w) on a few small workloads:
+status / iteration counts / BoxQP return codes must be identical, values agree to rounding.  (The parity tests proper
+are tests/test_gpu_parity.py::test_quad_kernel_vs_oracle and ::test_two_wave_and_single_wave_kernels_agree.)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")

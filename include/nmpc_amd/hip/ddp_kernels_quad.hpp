@@ -90,6 +90,9 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
   static constexpr int kLdsDoubles = Pair::kLdsDoubles + kMailDoubles + kQuadWaves * kChunkDoubles;
   static constexpr size_t kLdsBytes = static_cast<size_t>(kLdsDoubles) * sizeof(double);
 
+  //! the problem object of this lane's instance in the LINEARISATION mapping (= `problem` unless the batch has
+  //! per-instance objects, nmpc_hip_ddp_set_model_params_batch)
+  const Problem & lin_problem;
   const int wave; //!< 0 .. 3
   const int wl; //!< lane within the wavefront
   // natural layout of this lane: entry (row, col) of block blk
@@ -98,11 +101,12 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
   double * chunk; //!< this wave's derivative chunk
 
   NMPC_D QuadSolver(const Problem & p,
+                    const Problem & p_lin,
                     const nmpc_hip_ddp_config & c,
                     const DeviceBuffers & bf,
                     int global_lane,
                     double * lds_base)
-  : Pair(p, c, bf, global_lane, lds_base), wave(threadIdx.x / 64), wl(threadIdx.x % 64), row(wl / 16), blk((wl / 4) % 4),
+  : Pair(p, c, bf, global_lane, lds_base), lin_problem(p_lin), wave(threadIdx.x / 64), wl(threadIdx.x % 64), row(wl / 16), blk((wl / 4) % 4),
     col(wl % 4), mail(lds_base + Pair::kLdsDoubles),
     chunk(lds_base + Pair::kLdsDoubles + kMailDoubles + (threadIdx.x / 64) * kChunkDoubles)
   {
@@ -151,7 +155,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
   }
   NMPC_D void lineariseStep(int i, double t0_l, const PointQ & p, double * rec) const
   {
-    const double t = t0_l + i * problem.dt();
+    const double t = t0_l + i * lin_problem.dt();
     StateDimVector x;
     InputDimVector u;
     u.resize(M);
@@ -170,8 +174,8 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
     Lxu.resize(N, M);
     Lu.resize(M);
     Luu.resize(M, M);
-    problem.calcStateEqDeriv(t, x, u, Fx, Fu);
-    problem.calcRunningCostDeriv(t, x, u, Lx, Lu, Lxx, Luu, Lxu);
+    lin_problem.calcStateEqDeriv(t, x, u, Fx, Fu);
+    lin_problem.calcRunningCostDeriv(t, x, u, Lx, Lu, Lxx, Luu, Lxu);
 #pragma unroll
     for(int r = 0; r < 4; r++)
     {
@@ -260,7 +264,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
       {
         xT[j] = px[(static_cast<size_t>(T) * N + j) * LW];
       }
-      problem.calcTerminalCostDeriv(t0_l + T * problem.dt(), xT, vx, vxx);
+      lin_problem.calcTerminalCostDeriv(t0_l + T * lin_problem.dt(), xT, vx, vxx);
 #pragma unroll
       for(int r = 0; r < 4; r++)
       {
@@ -544,7 +548,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
     `-mllvm --amdgpu-mfma-vgpr-form` (nmpc_amd/build.py does): by default a kernel that may use 512 registers gets its
     matrix-core results in accumulation registers and spends ~30 v_accvgpr_read/write per timestep moving them to the
     VALU / DPP instructions that consume them (10.3k -> 10.6k iterations/s on the headline workload). */
-template<class Problem, bool kConstrained>
+template<class Problem, bool kConstrained, bool kOwnProblem = false>
 __global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const Problem problem,
                                                                          const nmpc_hip_ddp_config cfg,
                                                                          const DeviceBuffers buf)
@@ -555,7 +559,12 @@ __global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const P
   // in the lane-per-instance roles (master, forward helper) every group of 16 lanes mirrors the workgroup's 16
   // instances: same inputs, same instruction stream, hence the same values and decisions, written to the same places
   const int b = blockIdx.x * kQuadInstances + wl % kQuadInstances;
-  Solver solver(problem, cfg, buf, b, lds_quad);
+  // kOwnProblem: per-instance problem objects (a separate instantiation, as in the two-wave kernel).  A lane serves two
+  // instances: b in the lane-per-instance roles, b_lin when it linearises (timestep wl % 16 of instance 4 wave + wl / 16).
+  const int b_lin = blockIdx.x * kQuadInstances + (threadIdx.x / 64) * 4 + wl / 16;
+  const Problem mine = kOwnProblem ? instanceProblem(problem, buf, b) : problem;
+  const Problem mine_lin = kOwnProblem ? instanceProblem(problem, buf, b_lin) : problem;
+  Solver solver(mine, kOwnProblem ? mine_lin : mine, cfg, buf, b, lds_quad);
   if(threadIdx.x / 64 == 0)
   {
     solver.solveMasterQuad(b < buf.B);

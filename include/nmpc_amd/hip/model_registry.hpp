@@ -99,7 +99,8 @@ struct ModelOpsFor
   static bool useQuad(int batch_padded, bool own)
   {
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
-    if(!kQuadShape || own || (force && (std::strcmp(force, "1w") == 0 || std::strcmp(force, "2w") == 0)))
+    (void)own; // per-instance problem objects have their own instantiation of the quad kernel
+    if(!kQuadShape || (force && (std::strcmp(force, "1w") == 0 || std::strcmp(force, "2w") == 0)))
     {
       return false;
     }
@@ -173,23 +174,36 @@ struct ModelOpsFor
         }
         if(!requested[dev])
         {
-          const hipError_t attr_u = hipFuncSetAttribute(reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(quad_lds));
-          const hipError_t attr_c = hipFuncSetAttribute(reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(quad_lds));
-          if(attr_u != hipSuccess || attr_c != hipSuccess)
+          const void * variants[4] = {reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, false>),
+                                      reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true, false>),
+                                      reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, true>),
+                                      reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true, true>)};
+          for(const void * fn : variants)
           {
-            return attr_u != hipSuccess ? attr_u : attr_c;
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     static_cast<int>(quad_lds));
+            if(e != hipSuccess)
+            {
+              return e;
+            }
           }
           requested[dev] = true;
         }
-        if(con)
+        if(con && own)
         {
-          hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, true>), g, blk, quad_lds, stream, problem, cfg, buf);
+          hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, true, true>), g, blk, quad_lds, stream, problem, cfg, buf);
+        }
+        else if(con)
+        {
+          hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, true, false>), g, blk, quad_lds, stream, problem, cfg, buf);
+        }
+        else if(own)
+        {
+          hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, false, true>), g, blk, quad_lds, stream, problem, cfg, buf);
         }
         else
         {
-          hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, false>), g, blk, quad_lds, stream, problem, cfg, buf);
+          hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, false, false>), g, blk, quad_lds, stream, problem, cfg, buf);
         }
         return hipGetLastError();
       }

@@ -463,6 +463,34 @@ def test_quad_kernel_vs_oracle(case, monkeypatch):
     check_against_oracle(wl, s, ref)
 
 
+def test_quad_kernel_is_deterministic(monkeypatch):
+    """Repeated solves of the full-size workload are bit-identical (the four wavefronts of a workgroup exchange data
+    through LDS mailboxes, record rings and staged gains: a race would show up as run-to-run differences), and equal to
+    the two-wave kernel in every discrete output."""
+    from nmpc_amd import workloads
+
+    monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    wl = workloads.cartpole_batch(B=4096, T=100, seed=77)
+    s = make_solver(wl, max_iter=8)
+    first = None
+    for _ in range(12):
+        s.solve(wl.t0, wl.x0, wl.u_init)
+        out = (s.status().copy(), s.iters().copy(), s.X().copy(), s.U().copy(), s.kff().copy(), s.Kfb().copy(),
+               s.cost().copy(), s.trace().copy())
+        if first is None:
+            first = out
+        else:
+            for a, b in zip(first, out):
+                assert np.array_equal(a, b)
+    assert s.kernelName() == "ddp_solve_quad_kernel"
+    monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", "2w")
+    s2 = make_solver(wl, max_iter=8)
+    s2.solve(wl.t0, wl.x0, wl.u_init)
+    assert np.array_equal(first[0], s2.status()) and np.array_equal(first[1], s2.iters())
+    assert np.array_equal(first[7][..., INT_COLS], s2.trace()[..., INT_COLS])
+    assert scaled_err(first[2], s2.X()) <= TOL and scaled_err(first[3], s2.U()) <= TOL
+
+
 def test_quad_kernel_batch_threshold(monkeypatch):
     """More than 4096 instances (more quad workgroups than CUs) go to the two-wave kernel."""
     import nmpc_amd

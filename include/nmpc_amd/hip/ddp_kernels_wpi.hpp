@@ -310,6 +310,39 @@ struct WaveSolver
     }
   }
 
+  // ---- "natural" register layout of a 16 x 16 block: register r of lane (q = lane / 16, j = lane % 16) holds
+  // X[4 r + q][j].  That is the matrix core's C / D layout; its four registers are at the same time the four k-slices of a
+  // B operand, and passed as A operand they are the transposed matrix (scripts/ubench_mfma_f64.hip): mmaNat(X, Y) = X^T Y
+  // without any LDS round trip between products.  Entries outside ROWS x COLS are zero.
+  template<int ROWS, int COLS>
+  NMPC_D v4d loadNat(int t) const
+  {
+    const double * d = tile(t);
+    const int lj = lane & 15, lk = lane >> 4;
+    v4d x;
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+      const int i = lk + 4 * r;
+      const bool in = (i < ROWS) && (lj < COLS);
+      const double v = d[in ? i + LD * lj : 0];
+      x[r] = in ? v : 0.0;
+    }
+    return x;
+  }
+  /** X^T Y, formed from zero, over the first KDIM rows of X and Y (k ascending: the order of mma()). */
+  template<int KDIM>
+  NMPC_D static v4d mmaNat(v4d X, v4d Y)
+  {
+    v4d acc = {0, 0, 0, 0};
+#pragma unroll
+    for(int s = 0; s < (KDIM + 3) / 4; s++)
+    {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[s], Y[s], acc, 0, 0, 0);
+    }
+    return acc;
+  }
+
   // ===================================================================================================
   // model evaluation
   // ===================================================================================================
@@ -556,32 +589,59 @@ struct WaveSolver
       }
       fence();
 
-      // ---- Q terms    :386-408    (products left to right, formed from zero, then added to the L block)
-      // independent products are issued together so that their MFMA chains overlap
+      // ---- Q terms    :386-408    (products formed from zero in the reference's association, then added to the L block)
+      // All five products stay in registers in the natural layout (see loadNat): P = Vxx^T Fx is (Fx^T Vxx)^T entry by
+      // entry; R = Vxx^T [Fu | 0] with Vx placed in column M afterwards, so that S = Fx^T R carries (Fu^T Vxx Fx)^T in
+      // columns < M and Fx^T Vx in column M, and W = R^T Fu carries (Fu^T Vxx) Fu in rows < M and Vx^T Fu in row M — the
+      // same products in the same order as the lane kernels' chains, without staging Fx^T Vxx / Fu^T Vxx in LDS.
       {
-        const v4d p1 = mma<true, N>(tFx, tVxx); // Fx^T Vxx
-        const v4d p2 = mma<true, N>(tFu, tVxx); // Fu^T Vxx   (M x N)
-        storeAcc<N, N>(tP, p1);
-        storeAcc<MM, N>(tP2, p2);
-      }
-      fence();
-      {
-        const v4d qxx = mma<false, N>(tP, tFx);
-        const v4d qux = mma<false, N>(tP2, tFx);
-        const v4d quu = mma<false, N>(tP2, tFu);
-        storeAcc<N, N>(tQxx, qxx, tLxx); // Lxx + (Fx^T Vxx) Fx, in place
-        // Qux = Lxu^T + (Fu^T Vxx) Fx : the transposed L block is added entry-wise
         const int lj = lane & 15, lk = lane >> 4;
+        const v4d Vxx_n = loadNat<N, N>(tVxx);
+        const v4d Fx_n = loadNat<N, N>(tFx);
+        const v4d Fu_n = loadNat<N, MM>(tFu);
+        const v4d P = mmaNat<N>(Vxx_n, Fx_n);
+        v4d R = mmaNat<N>(Vxx_n, Fu_n);
+        if(lj == MM) // (M < 16 for every shape of this kernel's register path: column M is free)
+        {
+#pragma unroll
+          for(int r = 0; r < 4; r++)
+          {
+            const int k = lk + 4 * r;
+            R[r] = (k < N) ? vec(vVx)[k < N ? k : 0] : 0.0;
+          }
+        }
+        const v4d qxx = mmaNat<N>(P, Fx_n);
+        const v4d S = mmaNat<N>(Fx_n, R);
+        const v4d W = mmaNat<N>(R, Fu_n);
+        storeAcc<N, N>(tQxx, qxx, tLxx); // Lxx + (Fx^T Vxx) Fx, in place
 #pragma unroll
         for(int r = 0; r < 4; r++)
         {
-          const int a = lk + 4 * r; // row of Qux = input index, column lj = state index
-          if(a < MM && lj < N)
+          const int c = lk + 4 * r; // S: row = state index c, column = input index (or M: the Qx column)
+          if(c < N)
           {
-            tile(tQux)[a + LD * lj] = tile(tLxu)[lj + LD * a] + qux[r];
+            if(lj < MM)
+            {
+              tile(tQux)[lj + LD * c] = tile(tLxu)[c + LD * lj] + S[r];
+            }
+            else if(lj == MM)
+            {
+              vec(vQx)[c] = vec(vLx)[c] + S[r];
+            }
+          }
+          const int a = lk + 4 * r; // W: row = input index a (or M: the Qu row), column = input index
+          if(lj < MM)
+          {
+            if(a < MM)
+            {
+              tile(tQuu)[a + LD * lj] = tile(tLuu)[a + LD * lj] + W[r];
+            }
+            else if(a == MM)
+            {
+              vec(vQu)[lj] = vec(vLu)[lj] + W[r];
+            }
           }
         }
-        storeAcc<MM, MM>(tQuu, quu, tLuu); // Luu + (Fu^T Vxx) Fu
       }
       fence();
       // ---- regularisation    :421-441
@@ -634,26 +694,7 @@ struct WaveSolver
           }
         }
       }
-      // ---- Qx, Qu    :386-388   (lane r / lane a: ascending-k chains as in the lane-per-instance kernels)
-      if(lane < N)
-      {
-        double s = 0;
-        for(int k = 0; k < N; k++)
-        {
-          s += tile(tFx)[k + LD * lane] * vec(vVx)[k];
-        }
-        vec(vQx)[lane] = vec(vLx)[lane] + s;
-      }
-      if(lane < MM)
-      {
-        double s = 0;
-        for(int k = 0; k < N; k++)
-        {
-          s += tile(tFu)[k + LD * lane] * vec(vVx)[k];
-        }
-        vec(vQu)[lane] = vec(vLu)[lane] + s;
-      }
-      fence();
+      fence(); // (Qx, Qu came out of the Q-term products above)
 
       // ---- gains    :500-517   (every lane factorises the same M x M matrix; lane c solves column c of Qux)
       double fac[MM * MM], inv_d[MM], Quu[MM * MM], Qu[MM], kff[MM];

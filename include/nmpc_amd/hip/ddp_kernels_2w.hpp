@@ -33,8 +33,10 @@ namespace nmpc_amd
 namespace hip
 {
 /** \tparam kForwardRecordsOnly the LDS records carry only the forward hand-off (x', u'): for solvers that replace the
-    backward pass of this class (ddp_kernels_quad.hpp) */
-template<class Problem, bool kConstrained, bool kForwardRecordsOnly = false>
+    backward pass of this class (ddp_kernels_quad.hpp)
+    \tparam kAlphaGroups lane groups of the master / helper wave that hold the SAME instances (ddp_kernels_quad.hpp: 4
+    groups of 16): the line search then tries kAlphaGroups step sizes per forward pass, one per group */
+template<class Problem, bool kConstrained, bool kForwardRecordsOnly = false, int kAlphaGroups = 1>
 struct PairSolver : InstanceSolver<Problem, kConstrained>
 {
   using Base = InstanceSolver<Problem, kConstrained>;
@@ -86,7 +88,8 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   static constexpr int kFwdGroup = 4;
   static constexpr int kFwdSlots = 2 * kFwdGroup + 1;
   static constexpr int kRecArea = (2 * kRec > kFwdSlots * kFwdRec) ? 2 * kRec : kFwdSlots * kFwdRec;
-  static constexpr int kLdsDoubles = (kRecArea + 2) * static_cast<int>(LW);
+  //! + per-lane mailboxes (flags, J_cand) + the last trace row of every lane (kept in LDS until the solve ends)
+  static constexpr int kLdsDoubles = (kRecArea + 2 + NMPC_HIP_NTRACE) * static_cast<int>(LW);
   static constexpr size_t kLdsBytes = static_cast<size_t>(kLdsDoubles) * sizeof(double);
   static constexpr bool kFits = kLdsBytes <= 64 * 1024;
 
@@ -105,17 +108,37 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   {
     return lds[(static_cast<size_t>(slot) * kRec + idx) * LW + lane];
   }
+  // forward records and mailboxes are per lane OF THE WAVE (= `lane` in the two-wave kernel; with lane groups, every
+  // group has its own cells: the groups roll out different step sizes)
+  NMPC_D static unsigned waveLane()
+  {
+    return threadIdx.x % kLanesPerBlock;
+  }
   NMPC_D double & frec(int slot, int idx) const
   {
-    return lds[(static_cast<size_t>(slot) * kFwdRec + idx) * LW + lane];
+    return lds[(static_cast<size_t>(slot) * kFwdRec + idx) * LW + waveLane()];
   }
   NMPC_D double & mailFlags() const
   {
-    return lds[static_cast<size_t>(kRecArea) * LW + lane];
+    return lds[static_cast<size_t>(kRecArea) * LW + waveLane()];
+  }
+  NMPC_D double & mailCostAt(unsigned wave_lane) const
+  {
+    return lds[(static_cast<size_t>(kRecArea) + 1) * LW + wave_lane];
   }
   NMPC_D double & mailCost() const
   {
-    return lds[(static_cast<size_t>(kRecArea) + 1) * LW + lane];
+    return mailCostAt(waveLane());
+  }
+  NMPC_D double & lastRow(int field) const
+  {
+    return lds[(static_cast<size_t>(kRecArea) + 2 + field) * LW + waveLane()];
+  }
+  static constexpr unsigned kGroupLanes = kLanesPerBlock / kAlphaGroups;
+  //! lane group of this lane (0 when there are none); only group 0 writes trajectories to HBM
+  NMPC_D static unsigned laneGroup()
+  {
+    return (kAlphaGroups > 1) ? waveLane() / kGroupLanes : 0u;
   }
   /** Workgroup barrier for the LDS hand-off.  Only LDS traffic has to be complete (lgkmcnt); __syncthreads() would
       also wait for vmcnt(0), i.e. drain the helper's HBM prefetches and the stores of every timestep. */
@@ -875,6 +898,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       candidate trajectory (the helper issues ONLY stores during this pass, the master ONLY loads: a wave with both
       kinds in flight has to drain them all at every wait), returns the candidate total cost through
       LDS. */
+  /** \tparam kFanOut the lane groups roll out DIFFERENT step sizes (line search after a failed first trial): only group
+      0 writes its trajectory; otherwise the groups are mirrors and all of them write (the same values) */
+  template<bool kFanOut = false>
   NMPC_D void forwardHelper(int sel_h, bool initial = false) const
   {
     // forward pass: the candidate half; initial rollout (rolloutMaster): the trajectory half itself
@@ -893,7 +919,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
         {
           Base::elem(buf.input_dim, T, i) = Base::inputDimAt(current_t + i * problem.dt());
         }
-        J += consumeStep(i, cx, cu, cc);
+        J += consumeStep<kFanOut>(i, cx, cu, cc);
       }
     }
     wgBarrier(); // barrier E: the remaining timesteps and x'_T (slot 2 * kFwdGroup) are available
@@ -903,7 +929,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       {
         Base::elem(buf.input_dim, T, i) = Base::inputDimAt(current_t + i * problem.dt());
       }
-      J += consumeStep(i, cx, cu, cc);
+      J += consumeStep<kFanOut>(i, cx, cu, cc);
     }
     {
       StateDimVector xT;
@@ -912,9 +938,12 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       {
         xT[j] = frec(2 * kFwdGroup, oXc + j);
       }
-      Base::storeX(Base::xRow(T), cx, xT);
       const double cT = problem.terminalCost(current_t + T * problem.dt(), xT);
-      Base::st(Base::costRow(T), cc, cT);
+      if(!kFanOut || laneGroup() == 0)
+      {
+        Base::storeX(Base::xRow(T), cx, xT);
+        Base::st(Base::costRow(T), cc, cT);
+      }
       J += cT;
     }
     mailCost() = J;
@@ -922,6 +951,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   }
 
   /** Helper: cost + stores of step i from the "out" record the master wrote. */
+  template<bool kFanOut>
   NMPC_D double consumeStep(int i, unsigned cx, unsigned cu, unsigned cc) const
   {
     const int slot = i % (2 * kFwdGroup);
@@ -940,10 +970,13 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     {
       u[a] = frec(slot, oUc + a);
     }
-    Base::storeX(Base::xRow(i), cx, x);
-    Base::storeU(Base::uRow(i), cu, u, m);
     const double c = problem.runningCost(t, x, u);
-    Base::st(Base::costRow(i), cc, c);
+    if(!kFanOut || laneGroup() == 0)
+    {
+      Base::storeX(Base::xRow(i), cx, x);
+      Base::storeU(Base::uRow(i), cu, u, m);
+      Base::st(Base::costRow(i), cc, c);
+    }
     return c;
   }
 
@@ -1144,7 +1177,8 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     kCmdExit = 0,
     kCmdBackward = 1,
     kCmdForward = 2,
-    kCmdRollout = 3
+    kCmdRollout = 3,
+    kCmdForwardFanOut = 4 //!< forward pass in which every lane group rolls out its own step size
   };
 
   NMPC_D void post(int cmd) const
@@ -1174,6 +1208,11 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       {
         backwardHelper(sel_h);
         profEnd(0);
+      }
+      else if(cmd == kCmdForwardFanOut)
+      {
+        forwardHelper<true>(sel_h);
+        profEnd(1);
       }
       else
       {
@@ -1395,6 +1434,287 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       }
       buf.status[b] = retval;
       buf.iters[b] = static_cast<int>(tr[NMPC_HIP_TRACE_ITER]);
+      buf.sel[b] = sel;
+      Base::elem(buf.dV, 2, 0) = dV0;
+      Base::elem(buf.dV, 2, 1) = dV1;
+    }
+  }
+  /** solveMasterWith() for solvers with lane groups (kAlphaGroups > 1): the same state machine with the step-size fan-out
+      in the line search and the last trace row kept in LDS.  A separate function so that the code of the kernels without
+      lane groups — the headline workload's — stays exactly as it is (it is sensitive to register allocation: -1.5 % with
+      the two merged). */
+  template<class BackwardFn>
+  NMPC_D void solveMasterFanOut(bool valid, BackwardFn && runBackward)
+  {
+    current_t = buf.t0 ? Base::tileBase(buf.t0, 1)[lane] : 0.0;
+    lambda = cfg.initial_lambda;
+    dlambda = cfg.initial_dlambda;
+    sel = 0;
+    dV0 = dV1 = 0;
+    k_rel_norm = 0;
+    J_cand = 0;
+    post(kCmdRollout);
+    rolloutMaster();
+
+    // The trace row of an iteration is assembled and written at its end; the last row of every lane waits in LDS for the
+    // end of the solve (in registers it is 24 VGPRs that are live across every pass; written to HBM every iteration it is
+    // a store in front of the next pass's loads).
+    auto writeLastRow = [&](const double * tr, int)
+    {
+#pragma unroll
+      for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+      {
+        lastRow(f) = tr[f];
+      }
+    };
+    {
+      double tr[NMPC_HIP_NTRACE];
+#pragma unroll
+      for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+      {
+        tr[f] = 0;
+      }
+      tr[NMPC_HIP_TRACE_COST] = J_cur;
+      tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
+      tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
+      tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
+      if(valid)
+      {
+        Base::writeTraceRow(0, tr);
+        writeLastRow(tr, 0);
+      }
+    }
+
+    int retval = 0;
+    bool active = valid; // this lane still iterates
+    for(int iter = 1; iter <= cfg.max_iter; iter++)
+    {
+      if(!__any(active))
+      {
+        break;
+      }
+      if(active)
+      {
+        retval = 0;
+      }
+
+      // ---- Step 2 (+ Step 1 in the helper): backward pass with regularisation retries    :188-214
+      bool need_bw = active;
+      bool bw_ok = false;
+      int n_backward = 0;
+      while(__any(need_bw))
+      {
+        const bool ok = runBackward(need_bw);
+        if(need_bw)
+        {
+          n_backward++;
+          if(ok)
+          {
+            bw_ok = true;
+            need_bw = false;
+          }
+          else
+          {
+            dlambda = fmax(dlambda * cfg.lambda_factor, cfg.lambda_factor);
+            lambda = fmax(lambda * dlambda, cfg.lambda_min);
+            if(lambda > cfg.lambda_max)
+            {
+              need_bw = false; // failure    :196-204
+            }
+          }
+        }
+      }
+
+      bool need_fw = false;
+      if(active)
+      {
+        if(!bw_ok)
+        {
+          retval = -1;
+        }
+        else
+        {
+          if(k_rel_norm < cfg.k_rel_norm_thre && lambda < cfg.lambda_thre)
+          {
+            retval = 1; // :223-231
+          }
+          else
+          {
+            need_fw = true;
+          }
+        }
+      }
+
+      // ---- Step 3: backtracking line search    :234-274.  Every forward pass tries kAlphaGroups consecutive step sizes,
+      // one per lane group (the trials of the reference's loop are independent: same nominal, same gains); the
+      // instance takes the FIRST one that passes, as the sequential loop does.  Only group 0's rollout is written to
+      // HBM, so a step size accepted from another group is rolled out once more, then by every group.
+      const bool searched = need_fw;
+      bool forward_pass_success = false;
+      double alpha = 0, cost_update_actual = 0, cost_update_expected = 0, cost_update_ratio = 0;
+      int ai_used = 0;
+      const int last_ai = cfg.n_alpha - 1;
+      // The first trial (the one the nominal regime accepts) is rolled out by every group alike; only when it fails do
+      // the groups fan out over the next kAlphaGroups step sizes per pass.
+      for(int ai0 = 0, n_par = 1; ai0 < cfg.n_alpha; ai0 += n_par, n_par = kAlphaGroups)
+      {
+        if(!__any(need_fw))
+        {
+          break;
+        }
+        int g_acc = -1;
+        double J_acc = 0;
+        auto judge = [&](int gg, double Jc)
+        {
+          alpha = cfg.alpha_list[ai0 + gg];
+          ai_used = ai0 + gg;
+          cost_update_actual = J_cur - Jc;
+          cost_update_expected = -1 * alpha * (dV0 + alpha * dV1);
+          cost_update_ratio = cost_update_actual / cost_update_expected;
+          if(cost_update_expected < 0)
+          {
+            cost_update_ratio = (cost_update_actual >= 0 ? 1 : -1); // :251-259
+          }
+          if(cost_update_ratio > cfg.cost_update_ratio_thre)
+          {
+            g_acc = gg;
+            J_acc = Jc;
+          }
+        };
+        if(kAlphaGroups == 1 || n_par == 1)
+        {
+          post(kCmdForward);
+          profBegin();
+          forwardMaster(cfg.alpha_list[ai0]); // (a wave-uniform step size: the two-wave kernel's code path)
+          profEnd(1);
+          if(need_fw)
+          {
+            judge(0, J_cand);
+          }
+        }
+        else
+        {
+          // this lane group's step size, selected from uniformly indexed (scalar) reads of the list
+          double my_alpha = cfg.alpha_list[ai0];
+#pragma unroll
+          for(int gg = 1; gg < kAlphaGroups; gg++)
+          {
+            const double a = cfg.alpha_list[ai0 + gg < last_ai ? ai0 + gg : last_ai];
+            my_alpha = (laneGroup() == static_cast<unsigned>(gg)) ? a : my_alpha;
+          }
+          post(kCmdForwardFanOut);
+          profBegin();
+          forwardMaster(my_alpha);
+          profEnd(1);
+          if(need_fw)
+          {
+#pragma unroll
+            for(int gg = 0; gg < kAlphaGroups; gg++)
+            {
+              if(ai0 + gg <= last_ai && g_acc < 0)
+              {
+                judge(gg, mailCostAt(waveLane() % kGroupLanes + gg * kGroupLanes));
+              }
+            }
+          }
+        }
+        if constexpr(kAlphaGroups > 1)
+        {
+          if(__any(need_fw && g_acc > 0))
+          {
+            // (instances that accepted group 0's step size re-create the same candidate, the others do not care)
+            post(kCmdForward);
+            profBegin();
+            forwardMaster((need_fw && g_acc > 0) ? alpha : cfg.alpha_list[ai0]);
+            profEnd(1);
+          }
+        }
+        if(need_fw && g_acc >= 0)
+        {
+          forward_pass_success = true;
+          need_fw = false;
+          // accept immediately: later trials of other lanes write their candidate into THEIR candidate half
+          sel = 1 - sel;
+          J_cur = J_acc;
+        }
+      }
+
+      if(searched)
+      {
+        // ---- Step 4: accept / reject and the lambda schedule    :280-333
+        if(forward_pass_success)
+        {
+          if(cost_update_actual < cfg.cost_update_thre)
+          {
+            retval = 1;
+          }
+          dlambda = fmin(dlambda / cfg.lambda_factor, 1 / cfg.lambda_factor);
+          if(lambda >= cfg.lambda_min)
+          {
+            lambda *= dlambda;
+          }
+          else
+          {
+            lambda = 0;
+          }
+        }
+        else
+        {
+          dlambda = fmax(dlambda * cfg.lambda_factor, cfg.lambda_factor);
+          lambda = fmax(lambda * dlambda, cfg.lambda_min);
+          if(lambda > cfg.lambda_max)
+          {
+            retval = -1;
+          }
+        }
+      }
+      if(active)
+      {
+        double tr[NMPC_HIP_NTRACE];
+#pragma unroll
+        for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+        {
+          tr[f] = 0;
+        }
+        tr[NMPC_HIP_TRACE_ITER] = iter;
+        tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
+        tr[NMPC_HIP_TRACE_N_BACKWARD] = n_backward;
+        if(bw_ok)
+        {
+          tr[NMPC_HIP_TRACE_K_REL_NORM] = k_rel_norm;
+        }
+        if(searched)
+        {
+          tr[NMPC_HIP_TRACE_ALPHA] = alpha;
+          tr[NMPC_HIP_TRACE_COST_UPDATE_ACTUAL] = cost_update_actual;
+          tr[NMPC_HIP_TRACE_COST_UPDATE_EXPECTED] = cost_update_expected;
+          tr[NMPC_HIP_TRACE_COST_UPDATE_RATIO] = cost_update_ratio;
+          tr[NMPC_HIP_TRACE_ALPHA_IDX] = ai_used;
+          tr[NMPC_HIP_TRACE_N_FORWARD] = ai_used + 1;
+          tr[NMPC_HIP_TRACE_COST] = J_cur;
+          tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
+          tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
+        }
+        Base::writeTraceRow(iter, tr);
+        writeLastRow(tr, iter);
+        if(retval != 0)
+        {
+          active = false;
+        }
+      }
+    }
+    post(kCmdExit);
+    profFlush(0);
+
+    if(valid)
+    {
+#pragma unroll
+      for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+      {
+        Base::elem(buf.trace_last, NMPC_HIP_NTRACE, f) = lastRow(f);
+      }
+      buf.iters[b] = static_cast<int>(lastRow(NMPC_HIP_TRACE_ITER));
+      buf.status[b] = retval;
       buf.sel[b] = sel;
       Base::elem(buf.dV, 2, 0) = dV0;
       Base::elem(buf.dV, 2, 1) = dV1;

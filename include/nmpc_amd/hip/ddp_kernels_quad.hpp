@@ -34,9 +34,13 @@ constexpr int kQuadInstances = 16; //!< instances per workgroup of the quad kern
 constexpr int kQuadWaves = 4;
 
 template<class Problem, bool kConstrained>
-struct QuadSolver : PairSolver<Problem, kConstrained, true>
+struct QuadSolver : PairSolver<Problem, kConstrained, true, kConstrained ? 4 : 1>
 {
-  using Pair = PairSolver<Problem, kConstrained, true>;
+  // Box-constrained solves backtrack often (cart-pole with a +-15 N box: ~3 forward passes per iteration): there the
+  // four lane groups of 16 — mirrors of one another otherwise — try four step sizes per forward pass once the first
+  // trial has failed.  The unconstrained kernel keeps the sequential search: the extra code costs 1.7 % on the nominal
+  // workload (register allocation in the hot loops), where the first step size is accepted anyway.
+  using Pair = PairSolver<Problem, kConstrained, true, kConstrained ? 4 : 1>;
   using Base = typename Pair::Base;
   using Base::b;
   using Base::buf;
@@ -502,7 +506,14 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
 
   NMPC_D void solveMasterQuad(bool valid)
   {
-    Pair::solveMasterWith(valid, [this](bool need) { return backwardMasterQuad(need); });
+    if constexpr(kConstrained)
+    {
+      Pair::solveMasterFanOut(valid, [this](bool need) { return backwardMasterQuad(need); });
+    }
+    else
+    {
+      Pair::solveMasterWith(valid, [this](bool need) { return backwardMasterQuad(need); });
+    }
   }
 
   /** Waves 1 .. 3: follow the master's commands.  Wave 1 is the forward helper of PairSolver, waves 2 and 3 only
@@ -531,7 +542,14 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true>
       }
       else if(wave == 1)
       {
-        Pair::forwardHelper(sel_h, cmd == Pair::kCmdRollout);
+        if(cmd == Pair::kCmdForwardFanOut)
+        {
+          Pair::template forwardHelper<true>(sel_h);
+        }
+        else
+        {
+          Pair::forwardHelper(sel_h, cmd == Pair::kCmdRollout);
+        }
       }
       else
       {

@@ -463,6 +463,26 @@ def test_quad_kernel_vs_oracle(case, monkeypatch):
     check_against_oracle(wl, s, ref)
 
 
+def test_quad_kernel_step_size_fan_out(monkeypatch):
+    """Box-constrained solves on the quad kernel try four step sizes per forward pass after a failed first trial (the
+    mirror lane groups fan out over alpha_list).  The accepted index, the number of trials it stands for and everything
+    downstream must be what the sequential loop of DDPSolver.hpp:234-274 gives: compared with the oracle on a workload
+    whose iterations end at every index of the list, including exhausted searches."""
+    from nmpc_amd import workloads
+
+    monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    wl = workloads.cartpole_batch(B=1024, T=100, seed=1, constrained=True)
+    cfg = dict(max_iter=30, with_input_constraint=True)
+    s = make_solver(wl, **cfg)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert s.kernelName() == "ddp_solve_quad_kernel"
+    idx = s.trace()[:, 1:, 9].astype(int)
+    seen = set(np.unique(idx[idx >= 0]).tolist())
+    assert {0, 1, 2, 10} <= seen and len(seen) >= 6, seen  # first trial, fan-out rounds, exhausted searches
+    ref = oracle_batch(wl, **cfg)
+    check_against_oracle(wl, s, ref, mask=decision_stable_mask(wl, ref, **cfg))
+
+
 def test_quad_kernel_is_deterministic(monkeypatch):
     """Repeated solves of the full-size workload are bit-identical (the four wavefronts of a workgroup exchange data
     through LDS mailboxes, record rings and staged gains: a race would show up as run-to-run differences), and equal to

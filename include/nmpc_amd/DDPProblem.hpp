@@ -31,12 +31,16 @@
 
 namespace nmpc_amd
 {
-/** \brief DDP problem.
+/** \brief DDP problem, arithmetic type as a template parameter.
+    The reference computes in double throughout (DDPProblem.h:20-35); BASELINE.json's config 4 narrows the same
+    interface to fp32, so the scalar type is the first template parameter here and nmpc_amd::DDPProblem below fixes
+    it to double (the reference's signature).
+    \tparam ScalarT double or float
     \tparam StateDim state dimension (fixed only)
     \tparam InputDim input dimension (fixed, or nmpc_amd::Dynamic)
     \tparam MaxInputDim capacity of the input dimension when InputDim is Dynamic (ignored otherwise) */
-template<int StateDim, int InputDim, int MaxInputDim = InputDim>
-class DDPProblem
+template<class ScalarT, int StateDim, int InputDim, int MaxInputDim = InputDim>
+class DDPProblemT
 {
   static_assert(StateDim > 0, "[DDP] Template param StateDim should be positive.");
   static_assert(InputDim >= 0 || InputDim == Dynamic,
@@ -44,27 +48,27 @@ class DDPProblem
   static_assert(InputDim != Dynamic || MaxInputDim >= 0, "[DDP] Dynamic input dimension needs MaxInputDim.");
 
 public:
-  using Scalar = double;
+  using Scalar = ScalarT;
   static constexpr int kStateDim = StateDim;
   static constexpr bool kDynamicInput = (InputDim == Dynamic);
   static constexpr int kInputDimMax = kDynamicInput ? MaxInputDim : InputDim;
 
   /** \brief Type of vector of state dimension. */
-  using StateDimVector = Matrix<double, StateDim, 1>;
+  using StateDimVector = Matrix<Scalar, StateDim, 1>;
   /** \brief Type of vector of input dimension. */
-  using InputDimVector = Matrix<double, kInputDimMax, 1, kDynamicInput, false>;
+  using InputDimVector = Matrix<Scalar, kInputDimMax, 1, kDynamicInput, false>;
   /** \brief Type of matrix of state x state dimension. */
-  using StateStateDimMatrix = Matrix<double, StateDim, StateDim>;
+  using StateStateDimMatrix = Matrix<Scalar, StateDim, StateDim>;
   /** \brief Type of matrix of input x input dimension. */
-  using InputInputDimMatrix = Matrix<double, kInputDimMax, kInputDimMax, kDynamicInput, kDynamicInput>;
+  using InputInputDimMatrix = Matrix<Scalar, kInputDimMax, kInputDimMax, kDynamicInput, kDynamicInput>;
   /** \brief Type of matrix of state x input dimension. */
-  using StateInputDimMatrix = Matrix<double, StateDim, kInputDimMax, false, kDynamicInput>;
+  using StateInputDimMatrix = Matrix<Scalar, StateDim, kInputDimMax, false, kDynamicInput>;
   /** \brief Type of matrix of input x state dimension. */
-  using InputStateDimMatrix = Matrix<double, kInputDimMax, StateDim, kDynamicInput, false>;
+  using InputStateDimMatrix = Matrix<Scalar, kInputDimMax, StateDim, kDynamicInput, false>;
 
   /** \brief Constructor.
       \param dt discretization timestep [sec] */
-  NMPC_HD explicit DDPProblem(double dt) : dt_(dt) {}
+  NMPC_HD explicit DDPProblemT(Scalar dt) : dt_(dt) {}
 
   /** \brief Gets the state dimension. */
   NMPC_HD static constexpr int stateDim()
@@ -80,17 +84,26 @@ public:
   }
 
   /** \brief Gets the input dimension at time t.  Must be shadowed by the problem if InputDim is Dynamic. */
-  NMPC_HD int inputDim(double) const
+  NMPC_HD int inputDim(Scalar) const
   {
     return kInputDimMax;
   }
 
   /** \brief Gets the discretization timestep [sec]. */
-  NMPC_HD double dt() const
+  NMPC_HD Scalar dt() const
   {
     return dt_;
   }
 
-  double dt_ = 0;
+  Scalar dt_ = 0;
+};
+
+/** \brief DDP problem in the reference's arithmetic (double): nmpc_ddp::DDPProblem<StateDim, InputDim>
+    (DDPProblem.h:15-203). */
+template<int StateDim, int InputDim, int MaxInputDim = InputDim>
+class DDPProblem : public DDPProblemT<double, StateDim, InputDim, MaxInputDim>
+{
+public:
+  NMPC_HD explicit DDPProblem(double dt) : DDPProblemT<double, StateDim, InputDim, MaxInputDim>(dt) {}
 };
 } // namespace nmpc_amd

@@ -37,34 +37,38 @@ constexpr int kLanesPerBlock = 64; //!< one wavefront per workgroup
     Every array is tile-major: element (half s, row r) of instance b sits at
         ((b / 64) * halves + s) * rows * 64  +  r * 64  +  b % 64
     with the per-array `rows` / `halves` listed below ("[tile]" = that leading index). */
-struct DeviceBuffers
+template<class S>
+struct DeviceBuffersT
 {
   int B; //!< number of valid instances
   int Bp; //!< padded batch
   int T; //!< horizon_steps
   int trace_rows; //!< allocated trace rows (max_iter+1 if trace_level >= 1, else 1)
-  const double * t0; //!< [tile][1][64]
-  const double * x0; //!< [tile][N][64]
-  double * X; //!< [tile][2][(T+1)*N][64]   current / candidate state sequences (x_list), row = i*N + j
-  double * U; //!< [tile][2][T*MM][64]      current / candidate input sequences (u_list); half 0 = u_init on entry
-  double * cost; //!< [tile][2][T+1][64]    current / candidate cost sequences (cost_list)
-  double * kff; //!< [tile][T*MM][64]         k_list_
-  double * Kfb; //!< [tile][T*N*MM][64]       K_list_, row = i*N*MM + (a + c*MM) of the m x N gain
-  double * trace; //!< [tile][trace_rows*NMPC_HIP_NTRACE][64]
-  double * trace_last; //!< [tile][NMPC_HIP_NTRACE][64]
-  double * dV; //!< [tile][2][64]
+  const S * t0; //!< [tile][1][64]
+  const S * x0; //!< [tile][N][64]
+  S * X; //!< [tile][2][(T+1)*N][64]   current / candidate state sequences (x_list), row = i*N + j
+  S * U; //!< [tile][2][T*MM][64]      current / candidate input sequences (u_list); half 0 = u_init on entry
+  S * cost; //!< [tile][2][T+1][64]    current / candidate cost sequences (cost_list)
+  S * kff; //!< [tile][T*MM][64]         k_list_
+  S * Kfb; //!< [tile][T*N*MM][64]       K_list_, row = i*N*MM + (a + c*MM) of the m x N gain
+  S * trace; //!< [tile][trace_rows*NMPC_HIP_NTRACE][64]
+  S * trace_last; //!< [tile][NMPC_HIP_NTRACE][64]
+  S * dV; //!< [tile][2][64]
   int * status; //!< [tile][1][64]
   int * iters; //!< [tile][1][64]
   int * sel; //!< [tile][1][64]  which half of X/U/cost holds control_data_ after the solve
   int * qp_ret; //!< [tile][T][64]  (constrained solves only)
   unsigned * qp_free; //!< [tile][T][64]
   int * input_dim; //!< [tile][T][64]
-  double * wpi_ws; //!< wave-per-instance kernel only (ddp_kernels_wpi.hpp): [B][WaveSolver::workspaceDoubles(T)]
+  S * wpi_ws; //!< per-instance workspace [B][ModelOps::wpi_workspace_doubles(T)] elements of S: wave-per-instance kernel
+             //!< (ddp_kernels_wpi.hpp: derivatives, gains, candidates), fp32 tile kernel (ddp_kernels_tile32.hpp: gains)
   const unsigned char * params_batch; //!< per-instance problem objects [Bp][sizeof(Problem)], or nullptr: one for all
   const double * lim_batch; //!< per-instance input limits [Bp][2][kMaxInputDim] (lower, upper), or nullptr: lim_lo / lim_hi
   double lim_lo[kMaxInputDim]; //!< input lower limits (constant in time)
   double lim_hi[kMaxInputDim]; //!< input upper limits
 };
+/** The reference computes in double (DDPProblem.h:20-35): every kernel but the fp32 tile kernel uses this one. */
+using DeviceBuffers = DeviceBuffersT<double>;
 
 namespace detail
 {
@@ -1483,25 +1487,26 @@ __global__ __launch_bounds__(kLanesPerBlock) void ddp_solve_tpi_kernel(const Pro
 // One workgroup moves a 64-instance x 64-row block through LDS so that both the global read and the global
 // write are contiguous 512-byte segments per wavefront.
 // ---------------------------------------------------------------------------------------------------------
-/** in [B][R] -> out [tile][halves][R][64], written into half `half`. */
-template<class T>
-__global__ __launch_bounds__(256) void batch_major_to_tile_kernel(const T * __restrict__ in,
-                                                                   T * __restrict__ out,
+/** in [B][R] -> out [tile][halves][R][64], written into half `half`.  TIn != TOut converts (the C-ABI exchanges doubles,
+    the fp32 tile kernel stores floats). */
+template<class TIn, class TOut = TIn>
+__global__ __launch_bounds__(256) void batch_major_to_tile_kernel(const TIn * __restrict__ in,
+                                                                   TOut * __restrict__ out,
                                                                    int B,
                                                                    int R,
                                                                    int halves,
                                                                    int half)
 {
-  __shared__ T blk[64][65];
+  __shared__ TOut blk[64][65];
   const int r0 = blockIdx.x * 64, tile = blockIdx.y;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 64 x 4
   for(int k = ty; k < 64; k += 4)
   {
     const int bb = tile * 64 + k, r = r0 + tx;
-    blk[k][tx] = (bb < B && r < R) ? in[static_cast<size_t>(bb) * R + r] : T(0);
+    blk[k][tx] = (bb < B && r < R) ? static_cast<TOut>(in[static_cast<size_t>(bb) * R + r]) : TOut(0);
   }
   __syncthreads();
-  T * o = out + (static_cast<size_t>(tile) * halves + half) * R * 64;
+  TOut * o = out + (static_cast<size_t>(tile) * halves + half) * R * 64;
   for(int k = ty; k < 64; k += 4)
   {
     const int r = r0 + k;
@@ -1512,26 +1517,31 @@ __global__ __launch_bounds__(256) void batch_major_to_tile_kernel(const T * __re
   }
 }
 
-/** in [tile][halves][R][64], half selected per instance by sel (sel == nullptr: half 0) -> out [B][R]. */
-template<class T>
-__global__ __launch_bounds__(256) void tile_to_batch_major_kernel(const T * __restrict__ in,
-                                                                   T * __restrict__ out,
+/** in [tile][halves][R][64], half selected per instance by sel (sel == nullptr: half 0) -> out [B][R].
+    row_limit != nullptr: rows >= (row_limit[b] + 1) * row_unit of instance b are written as 0 — the trace of a reused
+    handle keeps rows of earlier solves beyond iters[b]; traceDataList() ends at the last iteration (DDPSolver.h:294). */
+template<class TIn, class TOut = TIn>
+__global__ __launch_bounds__(256) void tile_to_batch_major_kernel(const TIn * __restrict__ in,
+                                                                   TOut * __restrict__ out,
                                                                    const int * __restrict__ sel,
                                                                    int B,
                                                                    int R,
-                                                                   int halves)
+                                                                   int halves,
+                                                                   const int * __restrict__ row_limit,
+                                                                   int row_unit)
 {
-  __shared__ T blk[64][65];
+  __shared__ TOut blk[64][65];
   const int r0 = blockIdx.x * 64, tile = blockIdx.y;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   {
     const int bb = tile * 64 + tx;
     const int s = (sel != nullptr && bb < B) ? sel[bb] : 0;
-    const T * src = in + (static_cast<size_t>(tile) * halves + s) * R * 64;
+    const int valid = (row_limit != nullptr && bb < B) ? (row_limit[bb] + 1) * row_unit : R;
+    const TIn * src = in + (static_cast<size_t>(tile) * halves + s) * R * 64;
     for(int k = ty; k < 64; k += 4)
     {
       const int r = r0 + k;
-      blk[k][tx] = (r < R) ? src[static_cast<size_t>(r) * 64 + tx] : T(0);
+      blk[k][tx] = (r < R && r < valid) ? static_cast<TOut>(src[static_cast<size_t>(r) * 64 + tx]) : TOut(0);
     }
   }
   __syncthreads();
@@ -1542,6 +1552,24 @@ __global__ __launch_bounds__(256) void tile_to_batch_major_kernel(const T * __re
     {
       out[static_cast<size_t>(bb) * R + r] = blk[tx][k];
     }
+  }
+}
+
+/** Instance-major gain records [B][T][rec] (k_i then K_i, as the fp32 tile kernel stores them) -> one of the reference
+    layouts KFF [B][T][MM] / KFB [B][T][N][MM]: `per_step` consecutive words starting at word `offset` of every record. */
+template<class TIn>
+__global__ __launch_bounds__(256) void gain_records_to_batch_major_kernel(const TIn * __restrict__ ws,
+                                                                           double * __restrict__ out,
+                                                                           size_t total,
+                                                                           int rec,
+                                                                           int per_step,
+                                                                           int offset)
+{
+  const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  if(idx < total)
+  {
+    const size_t bt = idx / per_step, w = idx % per_step;
+    out[idx] = static_cast<double>(ws[bt * rec + offset + w]);
   }
 }
 } // namespace hip

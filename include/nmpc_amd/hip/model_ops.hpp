@@ -1,0 +1,72 @@
+// Type-erased description of one registered problem type: what the C-ABI (nmpc_amd/csrc/capi.hip) knows about a problem
+// class compiled into gfx950 code.  Kernel families fill it: model_registry.hpp (fp64 lane / two-wave / quad / wave-per-
+// instance kernels), ddp_kernels_tile32.hpp (fp32 tile kernel).
+#pragma once
+
+#include <cstddef>
+
+#include <hip/hip_runtime.h>
+
+#include <nmpc_amd/hip/ddp_kernels.hpp>
+#include <nmpc_amd/hip/mpc_args.hpp>
+
+namespace nmpc_amd
+{
+namespace hip
+{
+/** Type-erased operations of one registered problem type. */
+struct ModelOps
+{
+  const char * name;
+  int state_dim;
+  int input_dim_max;
+  int dynamic_input;
+  size_t param_bytes;
+  //! placement-constructs a default problem object into out
+  void (*default_params)(void * out);
+  //! launches the solve kernel; params points to a host copy of the problem object
+  hipError_t (*launch_solve)(const void * params,
+                             const nmpc_hip_ddp_config & cfg,
+                             const DeviceBuffers & buf,
+                             hipStream_t stream);
+  //! host-side inputDim(t0 + i dt) for i < T (validation of initial_u_list, DDPSolver.hpp:46-58)
+  void (*input_dims)(const void * params, double t0, int T, int * out);
+  //! dt() of the problem object
+  double (*dt)(const void * params);
+  //! name of the kernel launch_solve launches for a batch of `batch` instances (lane mapping, see launchSolve)
+  const char * (*kernel_name)(int batch);
+  //! launches the receding-horizon advance step (mpc_kernels.hpp) between two solves
+  hipError_t (*launch_mpc_advance)(const void * params,
+                                   const DeviceBuffers & buf,
+                                   const MpcAdvanceArgs & args,
+                                   hipStream_t stream);
+  //! 1 if the problem has the plant step stateEq(t, x, u, dt) the plant pattern integrates with
+  int has_plant_step;
+  //! elements (of the problem's scalar type) of per-instance workspace the model's kernel needs for horizon T (0: none)
+  size_t (*wpi_workspace_doubles)(int T);
+  //! sizeof(Problem::Scalar): 8 for the reference's arithmetic, 4 for the fp32 problem types (every Scalar device array
+  //! of the handle has this element size; the C-ABI exchanges doubles either way)
+  int scalar_bytes;
+  //! 0: k_list_ / K_list_ live in the handle's tile-major kff / Kfb arrays; 1: in the workspace, instance-major records
+  //! [B][T][MM + MM * N] (k_i, then K_i column-major) as the fp32 tile kernel writes them
+  int gain_layout;
+};
+
+} // namespace hip
+} // namespace nmpc_amd
+
+extern "C" int nmpc_hip_ddp_register_model(const nmpc_amd::hip::ModelOps * ops);
+
+/** Registers the problem type under ProblemType::kName with the operations `OpsMaker::make()` returns. */
+#define NMPC_AMD_REGISTER_PROBLEM_WITH(ProblemType, OpsMaker)                                         \
+  namespace                                                                                           \
+  {                                                                                                   \
+  struct ProblemType##Registrar                                                                       \
+  {                                                                                                   \
+    ProblemType##Registrar()                                                                          \
+    {                                                                                                 \
+      static const nmpc_amd::hip::ModelOps ops = OpsMaker::make();                                    \
+      nmpc_hip_ddp_register_model(&ops);                                                              \
+    }                                                                                                 \
+  } g_##ProblemType##_registrar;                                                                      \
+  }

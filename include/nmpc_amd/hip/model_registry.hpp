@@ -13,6 +13,7 @@
 #include <new>
 #include <type_traits>
 
+#include <nmpc_amd/hip/model_ops.hpp>
 #include <nmpc_amd/hip/ddp_kernels.hpp>
 #include <nmpc_amd/hip/ddp_kernels_2w.hpp>
 #include <nmpc_amd/hip/ddp_kernels_quad.hpp>
@@ -23,38 +24,6 @@ namespace nmpc_amd
 {
 namespace hip
 {
-/** Type-erased operations of one registered problem type. */
-struct ModelOps
-{
-  const char * name;
-  int state_dim;
-  int input_dim_max;
-  int dynamic_input;
-  size_t param_bytes;
-  //! placement-constructs a default problem object into out
-  void (*default_params)(void * out);
-  //! launches the solve kernel; params points to a host copy of the problem object
-  hipError_t (*launch_solve)(const void * params,
-                             const nmpc_hip_ddp_config & cfg,
-                             const DeviceBuffers & buf,
-                             hipStream_t stream);
-  //! host-side inputDim(t0 + i dt) for i < T (validation of initial_u_list, DDPSolver.hpp:46-58)
-  void (*input_dims)(const void * params, double t0, int T, int * out);
-  //! dt() of the problem object
-  double (*dt)(const void * params);
-  //! name of the kernel launch_solve launches for a batch of `batch` instances (lane mapping, see launchSolve)
-  const char * (*kernel_name)(int batch);
-  //! launches the receding-horizon advance step (mpc_kernels.hpp) between two solves
-  hipError_t (*launch_mpc_advance)(const void * params,
-                                   const DeviceBuffers & buf,
-                                   const MpcAdvanceArgs & args,
-                                   hipStream_t stream);
-  //! 1 if the problem has the plant step stateEq(t, x, u, dt) the plant pattern integrates with
-  int has_plant_step;
-  //! doubles of per-instance workspace the wave-per-instance kernel needs for horizon T (0: the model never uses it)
-  size_t (*wpi_workspace_doubles)(int T);
-};
-
 template<class Problem>
 struct ModelOpsFor
 {
@@ -304,23 +273,14 @@ struct ModelOpsFor
     ops.launch_mpc_advance = &launchMpcAdvance;
     ops.has_plant_step = HasPlantStep<Problem>::value ? 1 : 0;
     ops.wpi_workspace_doubles = &wpiWorkspaceDoubles;
+    ops.scalar_bytes = static_cast<int>(sizeof(typename Problem::Scalar));
+    ops.gain_layout = 0;
+    static_assert(sizeof(typename Problem::Scalar) == 8, "these kernel families compute in double; fp32 problem types register "
+                                                         "through ddp_kernels_tile32.hpp");
     return ops;
   }
 };
 } // namespace hip
 } // namespace nmpc_amd
 
-extern "C" int nmpc_hip_ddp_register_model(const nmpc_amd::hip::ModelOps * ops);
-
-#define NMPC_AMD_REGISTER_PROBLEM(ProblemType)                                                        \
-  namespace                                                                                           \
-  {                                                                                                   \
-  struct ProblemType##Registrar                                                                       \
-  {                                                                                                   \
-    ProblemType##Registrar()                                                                          \
-    {                                                                                                 \
-      static const nmpc_amd::hip::ModelOps ops = nmpc_amd::hip::ModelOpsFor<ProblemType>::make();     \
-      nmpc_hip_ddp_register_model(&ops);                                                              \
-    }                                                                                                 \
-  } g_##ProblemType##_registrar;                                                                      \
-  }
+#define NMPC_AMD_REGISTER_PROBLEM(ProblemType) NMPC_AMD_REGISTER_PROBLEM_WITH(ProblemType, nmpc_amd::hip::ModelOpsFor<ProblemType>)

@@ -102,6 +102,51 @@ NMPC_HD double recipFast(double x)
 #endif
 }
 
+/** Single-precision sin and cos of the same angle for |x| < 2^15 rad (NaN beyond, like the double version): three-term
+    Cody-Waite reduction by pi/2 (8 + 11 + 24 bits, k * piece exact for |k| < 2^16) with FMAs, then the classic degree-7 /
+    degree-8 minimax kernels on [-pi/4, pi/4] (<= 2 ulp there).  ~20 instructions, branch-free; used by the fp32 problem
+    types (BASELINE.json config 4). */
+NMPC_HD void sincosFast(float x, float & s, float & c)
+{
+  constexpr float kTwoOverPi = 0.636619772367581343f;
+  constexpr float kP1 = 1.5703125f; // pi/2, leading 8 bits
+  constexpr float kP2 = 4.837512969970703125e-4f;
+  constexpr float kP3 = 7.54978995489188216e-8f;
+  const float k = rintf(x * kTwoOverPi);
+  float r = fmaf(-k, kP1, x);
+  r = fmaf(-k, kP2, r);
+  r = fmaf(-k, kP3, r);
+  const float z = r * r;
+  float ps = -1.9515295891e-4f;
+  ps = fmaf(ps, z, 8.3321608736e-3f);
+  ps = fmaf(ps, z, -1.6666654611e-1f);
+  const float sr = fmaf(r * z, ps, r);
+  float pc = 2.443315711809948e-5f;
+  pc = fmaf(pc, z, -1.388731625493765e-3f);
+  pc = fmaf(pc, z, 4.166664568298827e-2f);
+  const float cr = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+  const bool in_range = fabsf(x) < 32768.0f;
+  const int q = static_cast<int>(k) & 3;
+  const float s0 = (q & 1) ? cr : sr;
+  const float c0 = (q & 1) ? sr : cr;
+  const float nan = __builtin_nanf("");
+  s = in_range ? ((q & 2) ? -s0 : s0) : nan;
+  c = in_range ? (((q + 1) & 2) ? -c0 : c0) : nan;
+}
+
+/** Single precision 1 / x for a finite, normal-range x != 0: the hardware estimate (1 ulp) plus one Newton step on
+    gfx950, the plain divide on the host. */
+NMPC_HD float recipFast(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r = __builtin_amdgcn_rcpf(x);
+  r = fmaf(fmaf(-x, r, 1.0f), r, r);
+  return r;
+#else
+  return 1.0f / x;
+#endif
+}
+
 //! Marker for a run-time input dimension (the reference's Eigen::Dynamic).
 constexpr int Dynamic = -1;
 

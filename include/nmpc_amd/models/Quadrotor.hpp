@@ -9,25 +9,36 @@
 
 namespace nmpc_amd
 {
-class DDPProblemQuadrotor : public DDPProblem<12, 4>
+/** \tparam Real Real: the reference's arithmetic, registered as "quadrotor"; float: BASELINE.json config 4 ("fp32"),
+    registered as "quadrotor_f32".  The statements are the same; every constant is converted to Real once. */
+template<class Real>
+class DDPProblemQuadrotorT : public DDPProblemT<Real, 12, 4>
 {
+  using Base = DDPProblemT<Real, 12, 4>;
+  using Base::dt_;
+
 public:
-  static constexpr const char * kName = "quadrotor";
-  static constexpr double g_ = 9.80665; // [m/s^2]
+  using typename Base::InputDimVector;
+  using typename Base::InputInputDimMatrix;
+  using typename Base::StateDimVector;
+  using typename Base::StateInputDimMatrix;
+  using typename Base::StateStateDimMatrix;
+  static constexpr const char * kName = sizeof(Real) == 8 ? "quadrotor" : "quadrotor_f32";
+  static constexpr Real g_ = Real(9.80665); // [m/s^2]
 
-  NMPC_HD explicit DDPProblemQuadrotor(double dt = 0.02) : DDPProblem(dt) {}
+  NMPC_HD explicit DDPProblemQuadrotorT(Real dt = Real(0.02)) : Base(dt) {}
 
-  NMPC_HD double hoverThrust() const
+  NMPC_HD Real hoverThrust() const
   {
     return mass_ * g_ / 4;
   }
 
-  NMPC_HD double stateWeight(int i) const
+  NMPC_HD Real stateWeight(int i) const
   {
     return i < 3 ? w_pos_ : (i < 6 ? w_rpy_ : (i < 9 ? w_vel_ : w_omega_));
   }
 
-  NMPC_HD double stateError(const StateDimVector & x, int i) const
+  NMPC_HD Real stateError(const StateDimVector & x, int i) const
   {
     return i < 3 ? x[i] - ref_pos_[i] : x[i];
   }
@@ -35,7 +46,7 @@ public:
   /** Trigonometry of the attitude shared by the dynamics and its Jacobian. */
   struct Trig
   {
-    double sr, cr, sp, cp, sy, cy, tp;
+    Real sr, cr, sp, cp, sy, cy, tp;
     NMPC_HD explicit Trig(const StateDimVector & x)
     {
       // attitude angles are physical (|angle| << 2^27 rad): sincosFast, ~130 cycles per pair on gfx950 instead of
@@ -47,18 +58,18 @@ public:
     }
   };
 
-  NMPC_HD StateDimVector stateEq(double, // t
+  NMPC_HD StateDimVector stateEq(Real, // t
                                  const StateDimVector & x,
                                  const InputDimVector & u) const
   {
     const Trig g(x);
-    const double p = x[9], q = x[10], r = x[11];
-    const double thrust = ((u[0] + u[1]) + u[2]) + u[3];
+    const Real p = x[9], q = x[10], r = x[11];
+    const Real thrust = ((u[0] + u[1]) + u[2]) + u[3];
     // body z axis expressed in the world frame
-    const double bz[3] = {g.cr * g.sp * g.cy + g.sr * g.sy, g.cr * g.sp * g.sy - g.sr * g.cy, g.cr * g.cp};
-    const double torque[3] = {arm_ * (u[1] - u[3]), arm_ * (u[2] - u[0]), yaw_coef_ * (((u[0] - u[1]) + u[2]) - u[3])};
+    const Real bz[3] = {g.cr * g.sp * g.cy + g.sr * g.sy, g.cr * g.sp * g.sy - g.sr * g.cy, g.cr * g.cp};
+    const Real torque[3] = {arm_ * (u[1] - u[3]), arm_ * (u[2] - u[0]), yaw_coef_ * (((u[0] - u[1]) + u[2]) - u[3])};
 
-    double x_dot[12];
+    Real x_dot[12];
     x_dot[0] = x[6];
     x_dot[1] = x[7];
     x_dot[2] = x[8];
@@ -80,45 +91,45 @@ public:
     return x_next;
   }
 
-  NMPC_HD double runningCost(double, const StateDimVector & x, const InputDimVector & u) const
+  NMPC_HD Real runningCost(Real, const StateDimVector & x, const InputDimVector & u) const
   {
-    double cost_x = 0;
+    Real cost_x = 0;
     for(int i = 0; i < 12; i++)
     {
-      const double e = stateError(x, i);
+      const Real e = stateError(x, i);
       cost_x += stateWeight(i) * (e * e);
     }
-    double cost_u = 0;
+    Real cost_u = 0;
     for(int i = 0; i < 4; i++)
     {
-      const double e = u[i] - hoverThrust();
+      const Real e = u[i] - hoverThrust();
       cost_u += e * e;
     }
-    return 0.5 * cost_x + 0.5 * w_u_ * cost_u;
+    return Real(0.5) * cost_x + Real(0.5) * w_u_ * cost_u;
   }
 
-  NMPC_HD double terminalCost(double, const StateDimVector & x) const
+  NMPC_HD Real terminalCost(Real, const StateDimVector & x) const
   {
-    double cost_x = 0;
+    Real cost_x = 0;
     for(int i = 0; i < 12; i++)
     {
-      const double e = stateError(x, i);
+      const Real e = stateError(x, i);
       cost_x += (wt_scale_ * stateWeight(i)) * (e * e);
     }
-    return 0.5 * cost_x;
+    return Real(0.5) * cost_x;
   }
 
-  NMPC_HD void calcStateEqDeriv(double, // t
+  NMPC_HD void calcStateEqDeriv(Real, // t
                                 const StateDimVector & x,
                                 const InputDimVector & u,
                                 StateStateDimMatrix & state_eq_deriv_x,
                                 StateInputDimMatrix & state_eq_deriv_u) const
   {
     const Trig g(x);
-    const double p = x[9], q = x[10], r = x[11];
-    const double thrust = ((u[0] + u[1]) + u[2]) + u[3];
-    const double acc = thrust / mass_;
-    const double cp2 = g.cp * g.cp;
+    const Real p = x[9], q = x[10], r = x[11];
+    const Real thrust = ((u[0] + u[1]) + u[2]) + u[3];
+    const Real acc = thrust / mass_;
+    const Real cp2 = g.cp * g.cp;
 
     StateStateDimMatrix & A = state_eq_deriv_x; // filled with d(x_dot)/dx, then scaled
     A.setZero();
@@ -155,9 +166,9 @@ public:
     A(11, 9) = -(inertia_[1] - inertia_[0]) * q / inertia_[2];
     A(11, 10) = -(inertia_[1] - inertia_[0]) * p / inertia_[2];
     A *= dt_;
-    A.addToDiagonal(1.0);
+    A.addToDiagonal(Real(1));
 
-    const double bz[3] = {g.cr * g.sp * g.cy + g.sr * g.sy, g.cr * g.sp * g.sy - g.sr * g.cy, g.cr * g.cp};
+    const Real bz[3] = {g.cr * g.sp * g.cy + g.sr * g.sy, g.cr * g.sp * g.sy - g.sr * g.cy, g.cr * g.cp};
     StateInputDimMatrix & Bm = state_eq_deriv_u;
     Bm.setZero();
     for(int i = 0; i < 4; i++)
@@ -173,7 +184,7 @@ public:
     Bm(10, 0) = dt_ * (-arm_ / inertia_[1]);
   }
 
-  NMPC_HD void calcRunningCostDeriv(double, // t
+  NMPC_HD void calcRunningCostDeriv(Real, // t
                                     const StateDimVector & x,
                                     const InputDimVector & u,
                                     StateDimVector & running_cost_deriv_x,
@@ -197,7 +208,7 @@ public:
     running_cost_deriv_xu.setZero();
   }
 
-  NMPC_HD void calcTerminalCostDeriv(double, // t
+  NMPC_HD void calcTerminalCostDeriv(Real, // t
                                      const StateDimVector & x,
                                      StateDimVector & terminal_cost_deriv_x,
                                      StateStateDimMatrix & terminal_cost_deriv_xx) const
@@ -211,13 +222,16 @@ public:
   }
 
 public:
-  double mass_ = 1.0; // [kg]
-  double inertia_[3] = {0.01, 0.01, 0.02}; // [kg m^2]
-  double arm_ = 0.2; // [m]
-  double yaw_coef_ = 0.05; // rotor drag torque per unit thrust [m]
-  double w_pos_ = 1.0, w_rpy_ = 0.5, w_vel_ = 0.1, w_omega_ = 0.05;
-  double w_u_ = 0.01;
-  double wt_scale_ = 10.0; // terminal weight = wt_scale * running weight
-  double ref_pos_[3] = {0.0, 0.0, 1.0}; // [m]
+  Real mass_ = Real(1.0); // [kg]
+  Real inertia_[3] = {Real(0.01), Real(0.01), Real(0.02)}; // [kg m^2]
+  Real arm_ = Real(0.2); // [m]
+  Real yaw_coef_ = Real(0.05); // rotor drag torque per unit thrust [m]
+  Real w_pos_ = Real(1.0), w_rpy_ = Real(0.5), w_vel_ = Real(0.1), w_omega_ = Real(0.05);
+  Real w_u_ = Real(0.01);
+  Real wt_scale_ = Real(10.0); // terminal weight = wt_scale * running weight
+  Real ref_pos_[3] = {Real(0.0), Real(0.0), Real(1.0)}; // [m]
 };
+
+using DDPProblemQuadrotor = DDPProblemQuadrotorT<double>;
+using DDPProblemQuadrotorF32 = DDPProblemQuadrotorT<float>;
 } // namespace nmpc_amd

@@ -125,6 +125,11 @@ extern "C"
   int nmpc_hip_ddp_model_name(int index, const char ** name);
   int nmpc_hip_ddp_model_info(const char * model, int * state_dim, int * input_dim_max, int * dynamic_input,
                               size_t * param_bytes);
+  /** Arithmetic type of a problem type: 8 = double (the reference's, DDPProblem.h:20-35), 4 = float (the "*_f32" problem
+      types, BASELINE.json config 4).  The C-ABI exchanges doubles either way: inputs are rounded to the problem's type once
+      at ingest, results widened at nmpc_hip_ddp_get.  fp32 problem types: unconstrained solves with the shared problem
+      object only (no BoxQP, no set_model_params_batch, no mpc_run). */
+  int nmpc_hip_ddp_model_scalar_bytes(const char * model, int * bytes);
   /** Copy the default-constructed problem object (a trivially-copyable blob of param_bytes) to out. */
   int nmpc_hip_ddp_model_default_params(const char * model, void * out, size_t bytes);
 

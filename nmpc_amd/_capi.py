@@ -81,7 +81,7 @@ _lib = None
 # every symbol include/nmpc_hip_ddp.h declares
 EXPORTS = (
     "nmpc_hip_ddp_default_config", "nmpc_hip_ddp_model_count", "nmpc_hip_ddp_model_name",
-    "nmpc_hip_ddp_model_info", "nmpc_hip_ddp_model_default_params", "nmpc_hip_ddp_create",
+    "nmpc_hip_ddp_model_info", "nmpc_hip_ddp_model_scalar_bytes", "nmpc_hip_ddp_model_default_params", "nmpc_hip_ddp_create",
     "nmpc_hip_ddp_destroy", "nmpc_hip_ddp_set_config", "nmpc_hip_ddp_get_config",
     "nmpc_hip_ddp_set_model_params", "nmpc_hip_ddp_set_model_params_batch", "nmpc_hip_ddp_set_input_limits_batch",
     "nmpc_hip_ddp_input_dims", "nmpc_hip_ddp_set_input_limits", "nmpc_hip_ddp_solve",

@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-#include <nmpc_amd/hip/model_registry.hpp>
+#include <nmpc_amd/hip/model_ops.hpp>
 
 using nmpc_amd::hip::DeviceBuffers;
 using nmpc_amd::hip::ModelOps;
@@ -81,7 +81,8 @@ struct nmpc_hip_ddp_solver
   float last_total_ms = 0, last_kernel_ms = 0;
   hipStream_t last_stream = nullptr;
 
-  // device memory
+  int elem = 8; //!< sizeof(Problem::Scalar): element size of every Scalar array below (ModelOps::scalar_bytes)
+  // device memory (Scalar arrays are typed double here; an fp32 problem type stores floats in them, see elem)
   double * d_t0 = nullptr;
   double * d_x0 = nullptr;
   double * d_X = nullptr;
@@ -119,6 +120,14 @@ int devAlloc(T ** p, size_t count)
   return NMPC_HIP_OK;
 }
 
+/** A Scalar array of `count` elements of `elem` bytes behind a double pointer. */
+int devAllocScalar(double ** p, size_t count, int elem)
+{
+  NMPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), count * static_cast<size_t>(elem)));
+  NMPC_HIP_TRY(hipMemset(*p, 0, count * static_cast<size_t>(elem)));
+  return NMPC_HIP_OK;
+}
+
 int ensureStage(void ** p, size_t * have, size_t need)
 {
   if(*have >= need)
@@ -150,7 +159,7 @@ int allocTrace(nmpc_hip_ddp_solver * s)
     s->d_trace = nullptr;
   }
   s->trace_rows = rows;
-  return devAlloc(&s->d_trace, static_cast<size_t>(rows) * NMPC_HIP_NTRACE * s->Bp);
+  return devAllocScalar(&s->d_trace, static_cast<size_t>(rows) * NMPC_HIP_NTRACE * s->Bp, s->elem);
 }
 
 DeviceBuffers makeBuffers(const nmpc_hip_ddp_solver * s)
@@ -187,20 +196,43 @@ DeviceBuffers makeBuffers(const nmpc_hip_ddp_solver * s)
   return b;
 }
 
-template<class T>
-hipError_t toTile(const T * in, T * out, int B, int R, int Bp, int halves, int half, hipStream_t st)
+/** Reference layout [B][R] (T = double / int / unsigned as the C-ABI exchanges it) -> the handle's tile-major array, whose
+    element type is TDev. */
+template<class T, class TDev = T>
+hipError_t toTile(const T * in, TDev * out, int B, int R, int Bp, int halves, int half, hipStream_t st)
 {
   dim3 grid((R + 63) / 64, Bp / 64);
-  hipLaunchKernelGGL(nmpc_amd::hip::batch_major_to_tile_kernel<T>, grid, dim3(256), 0, st, in, out, B, R, halves, half);
+  hipLaunchKernelGGL((nmpc_amd::hip::batch_major_to_tile_kernel<T, TDev>), grid, dim3(256), 0, st, in, out, B, R, halves, half);
   return hipGetLastError();
 }
 
-template<class T>
-hipError_t toMajor(const T * in, T * out, const int * sel, int B, int R, int Bp, int halves, hipStream_t st)
+template<class TDev, class T = TDev>
+hipError_t toMajor(const TDev * in, T * out, const int * sel, int B, int R, int Bp, int halves, hipStream_t st,
+                   const int * row_limit = nullptr, int row_unit = 0)
 {
   dim3 grid((R + 63) / 64, Bp / 64);
-  hipLaunchKernelGGL(nmpc_amd::hip::tile_to_batch_major_kernel<T>, grid, dim3(256), 0, st, in, out, sel, B, R, halves);
+  hipLaunchKernelGGL((nmpc_amd::hip::tile_to_batch_major_kernel<TDev, T>), grid, dim3(256), 0, st, in, out, sel, B, R, halves,
+                     row_limit, row_unit);
   return hipGetLastError();
+}
+
+/** Scalar arrays: the device element type follows the problem's arithmetic, the C-ABI side is always double. */
+hipError_t scalarToTile(const nmpc_hip_ddp_solver * s, const double * in, double * out, int R, int halves, int half, hipStream_t st)
+{
+  if(s->elem == 4)
+  {
+    return toTile<double, float>(in, reinterpret_cast<float *>(out), s->B, R, s->Bp, halves, half, st);
+  }
+  return toTile<double, double>(in, out, s->B, R, s->Bp, halves, half, st);
+}
+hipError_t scalarToMajor(const nmpc_hip_ddp_solver * s, const double * in, double * out, const int * sel, int R, int halves,
+                         hipStream_t st, const int * row_limit = nullptr, int row_unit = 0)
+{
+  if(s->elem == 4)
+  {
+    return toMajor<float, double>(reinterpret_cast<const float *>(in), out, sel, s->B, R, s->Bp, halves, st, row_limit, row_unit);
+  }
+  return toMajor<double, double>(in, out, sel, s->B, R, s->Bp, halves, st, row_limit, row_unit);
 }
 
 struct FieldInfo
@@ -258,6 +290,7 @@ int fieldInfo(const nmpc_hip_ddp_solver * s, int field, FieldInfo * fi)
 int packField(nmpc_hip_ddp_solver * s, int field, void * d_out, hipStream_t st)
 {
   const int B = s->B, Bp = s->Bp;
+  (void)Bp;
   FieldInfo fi;
   int rc = fieldInfo(s, field, &fi);
   if(rc != NMPC_HIP_OK)
@@ -270,32 +303,45 @@ int packField(nmpc_hip_ddp_solver * s, int field, void * d_out, hipStream_t st)
   switch(field)
   {
     case NMPC_HIP_FIELD_X:
-      NMPC_HIP_TRY(toMajor<double>(s->d_X, dout, s->d_sel, B, R, Bp, 2, st));
+      NMPC_HIP_TRY(scalarToMajor(s, s->d_X, dout, s->d_sel, R, 2, st));
       break;
     case NMPC_HIP_FIELD_U:
-      NMPC_HIP_TRY(toMajor<double>(s->d_U, dout, s->d_sel, B, R, Bp, 2, st));
+      NMPC_HIP_TRY(scalarToMajor(s, s->d_U, dout, s->d_sel, R, 2, st));
       break;
     case NMPC_HIP_FIELD_COST:
-      NMPC_HIP_TRY(toMajor<double>(s->d_cost, dout, s->d_sel, B, R, Bp, 2, st));
+      NMPC_HIP_TRY(scalarToMajor(s, s->d_cost, dout, s->d_sel, R, 2, st));
       break;
     case NMPC_HIP_FIELD_KFF:
-      NMPC_HIP_TRY(toMajor<double>(s->d_kff, dout, nullptr, B, R, Bp, 1, st));
-      break;
     case NMPC_HIP_FIELD_KFB:
-      NMPC_HIP_TRY(toMajor<double>(s->d_Kfb, dout, nullptr, B, R, Bp, 1, st));
+      if(s->ops->gain_layout == 1)
+      {
+        // instance-major gain records [B][T][MM + MM N] in the workspace (fp32 tile kernel)
+        const int per_step = (field == NMPC_HIP_FIELD_KFF) ? s->MM : s->MM * s->N;
+        const int offset = (field == NMPC_HIP_FIELD_KFF) ? 0 : s->MM;
+        const size_t total = static_cast<size_t>(B) * s->T * per_step;
+        hipLaunchKernelGGL((nmpc_amd::hip::gain_records_to_batch_major_kernel<float>), dim3(static_cast<unsigned>((total + 255) / 256)),
+                           dim3(256), 0, st, reinterpret_cast<const float *>(s->d_wpi_ws), dout, total, s->MM + s->MM * s->N, per_step,
+                           offset);
+        NMPC_HIP_TRY(hipGetLastError());
+      }
+      else
+      {
+        NMPC_HIP_TRY(scalarToMajor(s, field == NMPC_HIP_FIELD_KFF ? s->d_kff : s->d_Kfb, dout, nullptr, R, 1, st));
+      }
       break;
     case NMPC_HIP_FIELD_TRACE:
       if(s->trace_rows != s->cfg.max_iter + 1)
       {
         return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "full trace was not recorded: set trace_level = 1 before solve");
       }
-      NMPC_HIP_TRY(toMajor<double>(s->d_trace, dout, nullptr, B, R, Bp, 1, st));
+      // rows beyond the last iteration of this solve are reported as zero (a reused handle keeps older rows on the device)
+      NMPC_HIP_TRY(scalarToMajor(s, s->d_trace, dout, nullptr, R, 1, st, s->d_iters, NMPC_HIP_NTRACE));
       break;
     case NMPC_HIP_FIELD_TRACE_LAST:
-      NMPC_HIP_TRY(toMajor<double>(s->d_trace_last, dout, nullptr, B, R, Bp, 1, st));
+      NMPC_HIP_TRY(scalarToMajor(s, s->d_trace_last, dout, nullptr, R, 1, st));
       break;
     case NMPC_HIP_FIELD_DV:
-      NMPC_HIP_TRY(toMajor<double>(s->d_dV, dout, nullptr, B, R, Bp, 1, st));
+      NMPC_HIP_TRY(scalarToMajor(s, s->d_dV, dout, nullptr, R, 1, st));
       break;
     case NMPC_HIP_FIELD_STATUS:
       NMPC_HIP_TRY(hipMemcpyAsync(iout, s->d_status, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
@@ -406,16 +452,21 @@ int launchRecorded(nmpc_hip_ddp_solver * s,
   if(ingest)
   {
     // reference layouts -> instance-minor device layout
-    if(d_t0)
+    if(d_t0 && s->elem == 8)
     {
       NMPC_HIP_TRY(hipMemcpyAsync(s->d_t0, d_t0, sizeof(double) * s->B, hipMemcpyDeviceToDevice, st));
     }
+    else if(d_t0)
+    {
+      // [B] doubles -> [Bp] floats: the tile-major layout of a one-row array is the array itself
+      NMPC_HIP_TRY(scalarToTile(s, d_t0, s->d_t0, 1, 1, 0, st));
+    }
     else
     {
-      NMPC_HIP_TRY(hipMemsetAsync(s->d_t0, 0, sizeof(double) * s->Bp, st));
+      NMPC_HIP_TRY(hipMemsetAsync(s->d_t0, 0, static_cast<size_t>(s->elem) * s->Bp, st));
     }
-    NMPC_HIP_TRY(toTile<double>(d_x0, s->d_x0, s->B, s->N, s->Bp, 1, 0, st));
-    NMPC_HIP_TRY(toTile<double>(d_u_init, s->d_U, s->B, s->T * s->MM, s->Bp, 2, 0, st));
+    NMPC_HIP_TRY(scalarToTile(s, d_x0, s->d_x0, s->N, 1, 0, st));
+    NMPC_HIP_TRY(scalarToTile(s, d_u_init, s->d_U, s->T * s->MM, 2, 0, st));
   }
   NMPC_HIP_TRY(hipEventRecord(s->ev_kernel[slot], st));
   const DeviceBuffers buf = makeBuffers(s);
@@ -423,8 +474,11 @@ int launchRecorded(nmpc_hip_ddp_solver * s,
     const hipError_t le = s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
     if(le == hipErrorNotSupported)
     {
-      return fail(NMPC_HIP_ERR_RUNTIME, "per-instance problem objects (set_model_params_batch) are served by the model's "
-                                        "default kernel only; this solve needs the single-wavefront kernel");
+      return fail(NMPC_HIP_ERR_RUNTIME,
+                  s->elem == 4 ? "the fp32 tile kernel serves unconstrained solves with one shared problem object (no BoxQP, no "
+                                 "set_model_params_batch): use the fp64 problem type for those"
+                               : "per-instance problem objects (set_model_params_batch) are served by the model's default kernel "
+                                 "only; this solve needs the single-wavefront kernel");
     }
     NMPC_HIP_TRY(le);
   }
@@ -542,6 +596,21 @@ extern "C"
     return NMPC_HIP_OK;
   }
 
+  int nmpc_hip_ddp_model_scalar_bytes(const char * model, int * bytes)
+  {
+    const ModelOps * m = findModel(model);
+    if(!m)
+    {
+      return fail(NMPC_HIP_ERR_UNKNOWN_MODEL, std::string("unknown model: ") + (model ? model : "(null)"));
+    }
+    if(!bytes)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "bytes is NULL");
+    }
+    *bytes = m->scalar_bytes;
+    return NMPC_HIP_OK;
+  }
+
   int nmpc_hip_ddp_model_default_params(const char * model, void * out, size_t bytes)
   {
     const ModelOps * m = findModel(model);
@@ -596,6 +665,7 @@ extern "C"
     s->N = m->state_dim;
     s->M = m->input_dim_max;
     s->MM = m->input_dim_max > 0 ? m->input_dim_max : 1;
+    s->elem = m->scalar_bytes;
     nmpc_hip_ddp_default_config(&s->cfg);
     s->cfg.horizon_steps = horizon_steps;
     s->params.resize(m->param_bytes);
@@ -615,15 +685,15 @@ extern "C"
         rc = r;
       }
     };
-    chk(devAlloc(&s->d_t0, Bp));
-    chk(devAlloc(&s->d_x0, N * Bp));
-    chk(devAlloc(&s->d_X, 2 * (T + 1) * N * Bp));
-    chk(devAlloc(&s->d_U, 2 * T * MM * Bp));
-    chk(devAlloc(&s->d_cost, 2 * (T + 1) * Bp));
-    chk(devAlloc(&s->d_kff, T * MM * Bp));
-    chk(devAlloc(&s->d_Kfb, T * N * MM * Bp));
-    chk(devAlloc(&s->d_trace_last, static_cast<size_t>(NMPC_HIP_NTRACE) * Bp));
-    chk(devAlloc(&s->d_dV, 2 * Bp));
+    chk(devAllocScalar(&s->d_t0, Bp, s->elem));
+    chk(devAllocScalar(&s->d_x0, N * Bp, s->elem));
+    chk(devAllocScalar(&s->d_X, 2 * (T + 1) * N * Bp, s->elem));
+    chk(devAllocScalar(&s->d_U, 2 * T * MM * Bp, s->elem));
+    chk(devAllocScalar(&s->d_cost, 2 * (T + 1) * Bp, s->elem));
+    chk(devAllocScalar(&s->d_kff, T * MM * Bp, s->elem));
+    chk(devAllocScalar(&s->d_Kfb, T * N * MM * Bp, s->elem));
+    chk(devAllocScalar(&s->d_trace_last, static_cast<size_t>(NMPC_HIP_NTRACE) * Bp, s->elem));
+    chk(devAllocScalar(&s->d_dV, 2 * Bp, s->elem));
     chk(devAlloc(&s->d_status, Bp));
     chk(devAlloc(&s->d_iters, Bp));
     chk(devAlloc(&s->d_sel, Bp));
@@ -635,7 +705,7 @@ extern "C"
       // wave-per-instance kernel (9 <= n <= 16): materialised derivatives, gains and one candidate trajectory per
       // step size, per instance.  No memset: the kernel writes everything it reads.
       if(hipMalloc(reinterpret_cast<void **>(&s->d_wpi_ws),
-                   m->wpi_workspace_doubles(s->T) * static_cast<size_t>(s->B) * sizeof(double))
+                   m->wpi_workspace_doubles(s->T) * static_cast<size_t>(s->B) * static_cast<size_t>(s->elem))
          != hipSuccess)
       {
         (void)hipGetLastError();
@@ -922,6 +992,10 @@ extern "C"
     if(opt->n_ticks < 1)
     {
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "n_ticks should be >= 1");
+    }
+    if(s->elem != 8)
+    {
+      return fail(NMPC_HIP_ERR_RUNTIME, "the receding-horizon driver is served by the fp64 problem types");
     }
     if(!opt->shift_warm_start)
     {

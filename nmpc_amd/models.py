@@ -45,6 +45,13 @@ class _Problem:
         return self.blob.dt
 
     @classmethod
+    def scalar_bytes(cls) -> int:
+        """8: the problem computes in double (the reference's arithmetic); 4: in float."""
+        out = C.c_int()
+        _capi.check(_capi.load().nmpc_hip_ddp_model_scalar_bytes(cls.name.encode(), C.byref(out)))
+        return out.value
+
+    @classmethod
     def dims(cls):
         n, m, dyn, nbytes = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
         _capi.check(_capi.load().nmpc_hip_ddp_model_info(cls.name.encode(), C.byref(n), C.byref(m), C.byref(dyn),
@@ -106,6 +113,19 @@ class DDPProblemQuadrotor(_Problem):
                     ("ref_pos", C.c_double * 3)]
 
 
+class DDPProblemQuadrotorF32(_Problem):
+    """The same problem type instantiated in float (DDPProblemQuadrotorT<float>): BASELINE.json config 4 as specified
+    ("fp32"), served by the fp32 tile kernel (include/nmpc_amd/hip/ddp_kernels_tile32.hpp)."""
+
+    name = "quadrotor_f32"
+
+    class _Blob(C.Structure):
+        _fields_ = [("dt", C.c_float), ("mass", C.c_float), ("inertia", C.c_float * 3), ("arm", C.c_float),
+                    ("yaw_coef", C.c_float), ("w_pos", C.c_float), ("w_rpy", C.c_float), ("w_vel", C.c_float),
+                    ("w_omega", C.c_float), ("w_u", C.c_float), ("wt_scale", C.c_float),
+                    ("ref_pos", C.c_float * 3)]
+
+
 class DDPProblemManipulator(_Problem):
     """include/nmpc_amd/models/Manipulator.hpp (builder-defined; BASELINE.json config 5)."""
 
@@ -118,7 +138,8 @@ class DDPProblemManipulator(_Problem):
 
 
 PROBLEMS = {c.name: c for c in (DDPProblemCartPole, DDPProblemBipedal, DDPProblemVerticalMotion,
-                                DDPProblemCentroidalMotion, DDPProblemQuadrotor, DDPProblemManipulator)}
+                                DDPProblemCentroidalMotion, DDPProblemQuadrotor, DDPProblemQuadrotorF32,
+                                DDPProblemManipulator)}
 
 
 def make_problem(name: str, **kw) -> _Problem:

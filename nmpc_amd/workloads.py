@@ -94,16 +94,17 @@ def _normal_from_uniform(u1: np.ndarray, u2: np.ndarray) -> np.ndarray:
     return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
 
 
-def quadrotor_batch(B: int = 8192, T: int = 50, seed: int = 1234, constrained: bool = False) -> Workload:
+def quadrotor_batch(B: int = 8192, T: int = 50, seed: int = 1234, constrained: bool = False,
+                    fp32: bool = False) -> Workload:
     """C4: hover perturbation x0 ~ N(0, 0.3^2) around (0,0,1) (Box-Muller on the splitmix stream), u_init = hover
-    thrust m g / 4, dt = 0.02."""
+    thrust m g / 4, dt = 0.02.  fp32: the problem type instantiated in float ("quadrotor_f32"), what BASELINE.json names."""
     u = splitmix64_uniform(seed, 24 * B).reshape(B, 24)
     x0 = 0.3 * _normal_from_uniform(u[:, :12], u[:, 12:])
     x0[:, 2] += 1.0
     hover = 1.0 * 9.80665 / 4
     limits = (np.full(4, 0.7 * hover), np.full(4, 1.3 * hover)) if constrained else None  # rotor thrust box
-    return Workload("quadrotor_batch", "quadrotor", 12, 4, T, B, 0.02, x0, np.full((B, T, 4), hover), np.zeros(B),
-                    limits=limits)
+    return Workload("quadrotor_batch", "quadrotor_f32" if fp32 else "quadrotor", 12, 4, T, B, 0.02, x0,
+                    np.full((B, T, 4), hover), np.zeros(B), limits=limits)
 
 
 def manipulator_batch(B: int = 8192, T: int = 30, seed: int = 1234, constrained: bool = False) -> Workload:

@@ -343,6 +343,7 @@ def mpc_run(model: str, cfg: OracleConfig, x0, n_ticks: int, t0: float = 0.0, pa
 
 # default parameter vectors (same order as each model's setParams in oracle/models*.hpp)
 def default_params(model: str, **over) -> np.ndarray:
+    model = model[:-4] if model.endswith("_f32") else model  # the fp32 instantiations take the same parameter vector
     if model == "cartpole":
         d = dict(dt=0.01, cart_mass=1.0, pole_mass=0.5, pole_length=2.0, running_x=(0.1, 1.0, 0.01, 0.1),
                  running_u=0.001, terminal_x=(0.1, 1.0, 0.01, 0.1), ref_pos=0.0)

@@ -28,7 +28,26 @@
 // pivot is <= 0 (NaN pivots pass), llt.solve = forward then backward substitution.  Reductions are
 // summed in ascending index order (Eigen's own order is implementation-defined, so bit parity with an
 // Eigen build is not a meaningful target; tolerance + exact indices is).
-#pragma once
+// Precision: the header is written against `Real`.  Included as is, Real = double in namespace `oracle` (the
+// reference's arithmetic, DDPProblem.h:20-35).  oracle_capi.cpp includes it a second time with ORACLE_F32 defined:
+// Real = float in namespace `oracle_f32` — the same statements instantiated in single precision, which is what the fp32
+// HIP path (BASELINE.json config 4) is compared with ("the oracle instantiated in fp32").
+#if defined(ORACLE_F32)
+#  ifdef ORACLE_DDP_ORACLE_F32_HPP
+#    error "ddp_oracle.hpp (fp32) included twice"
+#  endif
+#  define ORACLE_DDP_ORACLE_F32_HPP
+#  define ORACLE_NS oracle_f32
+#  define ORACLE_REAL float
+#else
+#  ifdef ORACLE_DDP_ORACLE_F64_HPP
+#    error "ddp_oracle.hpp (fp64) included twice"
+#  endif
+#  define ORACLE_DDP_ORACLE_F64_HPP
+#  define ORACLE_NS oracle
+#  define ORACLE_REAL double
+#endif
+
 
 #include <algorithm>
 #include <cmath>
@@ -37,20 +56,21 @@
 #include <string>
 #include <vector>
 
-namespace oracle
+namespace ORACLE_NS
 {
+using Real = ORACLE_REAL;
 // ---------------------------------------------------------------------------------------------------
 // small dense helpers, column-major, explicit leading dimension = row count
 // ---------------------------------------------------------------------------------------------------
 
 // C(r x c) = A^T * B  with A (k x r), B (k x c)
-inline void mulAtB(const double * A, const double * B, double * C, int r, int k, int c)
+inline void mulAtB(const Real * A, const Real * B, Real * C, int r, int k, int c)
 {
   for(int j = 0; j < c; j++)
   {
     for(int i = 0; i < r; i++)
     {
-      double s = 0;
+      Real s = 0;
       for(int p = 0; p < k; p++)
       {
         s += A[p + i * k] * B[p + j * k];
@@ -61,13 +81,13 @@ inline void mulAtB(const double * A, const double * B, double * C, int r, int k,
 }
 
 // C(r x c) = A * B  with A (r x k), B (k x c)
-inline void mulAB(const double * A, const double * B, double * C, int r, int k, int c)
+inline void mulAB(const Real * A, const Real * B, Real * C, int r, int k, int c)
 {
   for(int j = 0; j < c; j++)
   {
     for(int i = 0; i < r; i++)
     {
-      double s = 0;
+      Real s = 0;
       for(int p = 0; p < k; p++)
       {
         s += A[i + p * r] * B[p + j * k];
@@ -79,11 +99,11 @@ inline void mulAB(const double * A, const double * B, double * C, int r, int k, 
 
 /** Unblocked lower Cholesky in place (Eigen::internal::llt_inplace<Lower>::unblocked).
     \return -1 on success, otherwise the index of the failing pivot (pivot <= 0; NaN passes) */
-inline int lltInPlace(double * A, int n)
+inline int lltInPlace(Real * A, int n)
 {
   for(int k = 0; k < n; k++)
   {
-    double x = A[k + k * n];
+    Real x = A[k + k * n];
     for(int j = 0; j < k; j++)
     {
       x -= A[k + j * n] * A[k + j * n];
@@ -96,7 +116,7 @@ inline int lltInPlace(double * A, int n)
     A[k + k * n] = x;
     for(int i = k + 1; i < n; i++)
     {
-      double s = A[i + k * n];
+      Real s = A[i + k * n];
       for(int j = 0; j < k; j++)
       {
         s -= A[i + j * n] * A[k + j * n];
@@ -108,14 +128,14 @@ inline int lltInPlace(double * A, int n)
 }
 
 /** Solve L L^T X = B in place, B is (n x c) column-major, L the lower factor stored in A. */
-inline void lltSolveInPlace(const double * L, int n, double * B, int c)
+inline void lltSolveInPlace(const Real * L, int n, Real * B, int c)
 {
   for(int col = 0; col < c; col++)
   {
-    double * b = B + col * n;
+    Real * b = B + col * n;
     for(int i = 0; i < n; i++)
     {
-      double s = b[i];
+      Real s = b[i];
       for(int j = 0; j < i; j++)
       {
         s -= L[i + j * n] * b[j];
@@ -124,7 +144,7 @@ inline void lltSolveInPlace(const double * L, int n, double * B, int c)
     }
     for(int i = n - 1; i >= 0; i--)
     {
-      double s = b[i];
+      Real s = b[i];
       for(int j = i + 1; j < n; j++)
       {
         s -= L[j + i * n] * b[j];
@@ -140,11 +160,11 @@ inline void lltSolveInPlace(const double * L, int n, double * B, int c)
 struct BoxQPConfig
 {
   int max_iter = 500; // BoxQP.h:39
-  double grad_thre = 1e-8; // BoxQP.h:42
-  double rel_improve_thre = 1e-8; // BoxQP.h:45
-  double step_factor = 0.6; // BoxQP.h:48
-  double min_step = 1e-22; // BoxQP.h:51
-  double armijo_param = 0.1; // BoxQP.h:54
+  Real grad_thre = 1e-8; // BoxQP.h:42
+  Real rel_improve_thre = 1e-8; // BoxQP.h:45
+  Real step_factor = 0.6; // BoxQP.h:48
+  Real min_step = 1e-22; // BoxQP.h:51
+  Real armijo_param = 0.1; // BoxQP.h:54
 };
 
 /** Projected-Newton box QP.  After solve(): x, retval, free_idxs, llt_free (lower factor of H[free,free],
@@ -157,55 +177,55 @@ struct BoxQP
   int iter = 0;
   int factorization_num = 0;
   int total_step_num = 0;
-  std::vector<double> x;
+  std::vector<Real> x;
   std::vector<int> free_idxs;
-  std::vector<double> llt_free;
+  std::vector<Real> llt_free;
   int n_llt = 0;
 
-  static double objective(int m, const double * H, const double * g, const double * x)
+  static Real objective(int m, const Real * H, const Real * g, const Real * x)
   {
     // x.dot(g) + 0.5 * x.dot(H * x)      BoxQP.h:149,297,303
-    double xg = 0;
+    Real xg = 0;
     for(int i = 0; i < m; i++)
     {
       xg += x[i] * g[i];
     }
-    double xHx = 0;
+    Real xHx = 0;
     for(int i = 0; i < m; i++)
     {
-      double hx = 0;
+      Real hx = 0;
       for(int j = 0; j < m; j++)
       {
         hx += H[i + j * m] * x[j];
       }
       xHx += x[i] * hx;
     }
-    return xg + 0.5 * xHx;
+    return xg + Real(0.5) * xHx;
   }
 
   void solve(int m,
-             const double * H,
-             const double * g,
-             const double * lower,
-             const double * upper,
-             const double * initial_x)
+             const Real * H,
+             const Real * g,
+             const Real * lower,
+             const Real * upper,
+             const Real * initial_x)
   {
-    x.assign(m, 0.0);
+    x.assign(m, Real(0));
     for(int i = 0; i < m; i++)
     {
       // initial_x.cwiseMin(upper).cwiseMax(lower)    BoxQP.h:148
-      x[i] = std::max(std::min(initial_x ? initial_x[i] : 0.0, upper[i]), lower[i]);
+      x[i] = std::max(std::min(initial_x ? initial_x[i] : Real(0), upper[i]), lower[i]);
     }
-    double obj = objective(m, H, g, x.data());
-    double old_obj = obj;
+    Real obj = objective(m, H, g, x.data());
+    Real old_obj = obj;
 
     retval = 0;
     factorization_num = 0;
     total_step_num = 0;
-    std::vector<double> grad(m, 0.0);
+    std::vector<Real> grad(m, Real(0));
     std::vector<char> clamped(m, 0), old_clamped(m, 0);
     std::vector<int> clamped_idxs;
-    std::vector<double> search_dir(m), x_cand(m), rhs;
+    std::vector<Real> search_dir(m), x_cand(m), rhs;
     free_idxs.clear();
     for(iter = 1;; iter++)
     {
@@ -220,7 +240,7 @@ struct BoxQP
       // gradient    BoxQP.h:184
       for(int i = 0; i < m; i++)
       {
-        double hx = 0;
+        Real hx = 0;
         for(int j = 0; j < m; j++)
         {
           hx += H[i + j * m] * x[j];
@@ -257,7 +277,7 @@ struct BoxQP
       int nc = static_cast<int>(clamped_idxs.size());
       if(iter == 1 || clamped != old_clamped)
       {
-        llt_free.assign(static_cast<size_t>(nf) * nf, 0.0);
+        llt_free.assign(static_cast<size_t>(nf) * nf, Real(0));
         n_llt = nf;
         for(int i = 0; i < nf; i++)
         {
@@ -275,7 +295,7 @@ struct BoxQP
       }
 
       // free gradient norm    BoxQP.h:244-253
-      double grad_norm = 0;
+      Real grad_norm = 0;
       for(int i = 0; i < nf; i++)
       {
         grad_norm += grad[free_idxs[i]] * grad[free_idxs[i]];
@@ -287,10 +307,10 @@ struct BoxQP
       }
 
       // Newton direction on the free dims    BoxQP.h:256-279
-      rhs.assign(nf, 0.0);
+      rhs.assign(nf, Real(0));
       for(int i = 0; i < nf; i++)
       {
-        double s = 0;
+        Real s = 0;
         for(int j = 0; j < nc; j++)
         {
           s += H[free_idxs[i] + clamped_idxs[j] * m] * x[clamped_idxs[j]];
@@ -298,31 +318,31 @@ struct BoxQP
         rhs[i] = g[free_idxs[i]] + s;
       }
       lltSolveInPlace(llt_free.data(), nf, rhs.data(), 1);
-      std::fill(search_dir.begin(), search_dir.end(), 0.0);
+      std::fill(search_dir.begin(), search_dir.end(), Real(0));
       for(int i = 0; i < nf; i++)
       {
         search_dir[free_idxs[i]] = -1 * rhs[i] - x[free_idxs[i]];
       }
 
       // descent check    BoxQP.h:282-291
-      double sdg = 0;
+      Real sdg = 0;
       for(int i = 0; i < m; i++)
       {
         sdg += search_dir[i] * grad[i];
       }
-      if(sdg > 1e-10)
+      if(sdg > Real(1e-10))
       {
         retval = -2;
         break;
       }
 
       // Armijo line search with projection    BoxQP.h:294-309
-      double step = 1;
+      Real step = 1;
       for(int i = 0; i < m; i++)
       {
         x_cand[i] = std::max(std::min(x[i] + step * search_dir[i], upper[i]), lower[i]);
       }
-      double obj_cand = objective(m, H, g, x_cand.data());
+      Real obj_cand = objective(m, H, g, x_cand.data());
       while((obj_cand - old_obj) / (step * sdg) < config.armijo_param)
       {
         step = step * config.step_factor;
@@ -362,28 +382,28 @@ struct Config
   int max_iter = 500;
   int horizon_steps = 100;
   int reg_type = 1;
-  double initial_lambda = 1e-4;
-  double initial_dlambda = 1.0;
-  double lambda_factor = 1.6;
-  double lambda_min = 1e-6;
-  double lambda_max = 1e10;
-  double k_rel_norm_thre = 1e-4;
-  double lambda_thre = 1e-5;
-  std::vector<double> alpha_list;
-  double cost_update_ratio_thre = 0;
-  double cost_update_thre = 1e-7;
+  Real initial_lambda = 1e-4;
+  Real initial_dlambda = 1.0;
+  Real lambda_factor = 1.6;
+  Real lambda_min = 1e-6;
+  Real lambda_max = 1e10;
+  Real k_rel_norm_thre = 1e-4;
+  Real lambda_thre = 1e-5;
+  std::vector<Real> alpha_list;
+  Real cost_update_ratio_thre = 0;
+  Real cost_update_thre = 1e-7;
 
   Config()
   {
     // alpha_list[i] = std::pow(10, LinSpaced(11, 0, -3)[i])    DDPSolver.h:50-60
     // Eigen's LinSpaced (no flip since |high| >= |low|): low + i*step for i < size-1, exactly high at the end.
     const int list_size = 11;
-    const double low = 0, high = -3;
-    const double step = (high - low) / (list_size - 1);
+    const Real low = 0, high = -3;
+    const Real step = (high - low) / (list_size - 1);
     alpha_list.resize(list_size);
     for(int i = 0; i < list_size; i++)
     {
-      double e = (i == list_size - 1) ? high : (low + i * step);
+      Real e = (i == list_size - 1) ? high : (low + i * step);
       alpha_list[i] = std::pow(10, e);
     }
   }
@@ -393,14 +413,14 @@ struct Config
 struct TraceRow
 {
   int iter = 0;
-  double cost = 0;
-  double lambda = 0;
-  double dlambda = 0;
-  double alpha = 0;
-  double k_rel_norm = 0;
-  double cost_update_actual = 0;
-  double cost_update_expected = 0;
-  double cost_update_ratio = 0;
+  Real cost = 0;
+  Real lambda = 0;
+  Real dlambda = 0;
+  Real alpha = 0;
+  Real k_rel_norm = 0;
+  Real cost_update_actual = 0;
+  Real cost_update_expected = 0;
+  Real cost_update_ratio = 0;
   // extras (not in the reference struct): discrete decisions the GPU path must reproduce exactly
   int alpha_idx = -1; // index into alpha_list of the last trial (-1 if the line search was not reached)
   int n_backward = 0; // number of backwardPass() calls in this iteration
@@ -420,20 +440,20 @@ public:
   struct Deriv
   {
     int m = 0;
-    double Fx[N * N];
-    double Fu[N * (MMAX > 0 ? MMAX : 1)];
-    double Lx[N];
-    double Lu[MMAX > 0 ? MMAX : 1];
-    double Lxx[N * N];
-    double Luu[MMAX > 0 ? MMAX * MMAX : 1];
-    double Lxu[N * (MMAX > 0 ? MMAX : 1)];
+    Real Fx[N * N];
+    Real Fu[N * (MMAX > 0 ? MMAX : 1)];
+    Real Lx[N];
+    Real Lu[MMAX > 0 ? MMAX : 1];
+    Real Lxx[N * N];
+    Real Luu[MMAX > 0 ? MMAX * MMAX : 1];
+    Real Lxu[N * (MMAX > 0 ? MMAX : 1)];
   };
 
   struct ControlData
   {
-    std::vector<double> x; // (T+1) * N
-    std::vector<double> u; // T * MMAX (first m_i entries of each row valid)
-    std::vector<double> cost; // T+1
+    std::vector<Real> x; // (T+1) * N
+    std::vector<Real> u; // T * MMAX (first m_i entries of each row valid)
+    std::vector<Real> cost; // T+1
   };
 
   explicit DDPSolver(const Model & model) : model_(model) {}
@@ -446,7 +466,7 @@ public:
   /** Input limits, constant in time: lower[MMAX], upper[MMAX] (entries beyond inputDim(t) ignored).
       Mirrors setInputLimitsFunc for the only form the reference tests use (TestDDPCartPole.cpp:379-386,
       TestDDPVerticalMotion.cpp:262-270). */
-  void setInputLimits(const double * lower, const double * upper)
+  void setInputLimits(const Real * lower, const Real * upper)
   {
     lower_.assign(lower, lower + MMAX);
     upper_.assign(upper, upper + MMAX);
@@ -460,11 +480,11 @@ public:
   {
     return trace_;
   }
-  const std::vector<double> & kList() const
+  const std::vector<Real> & kList() const
   {
     return k_list_;
   }
-  const std::vector<double> & KList() const
+  const std::vector<Real> & KList() const
   {
     return K_list_;
   }
@@ -476,7 +496,7 @@ public:
   {
     return status_;
   }
-  const double * dV() const
+  const Real * dV() const
   {
     return dV_;
   }
@@ -490,9 +510,9 @@ public:
     return qp_free_mask_;
   }
 
-  /** DDPSolver::solve (DDPSolver.hpp:26-141).  u_init is T rows of MMAX doubles.
+  /** DDPSolver::solve (DDPSolver.hpp:26-141).  u_init is T rows of MMAX Reals.
       \return retval == 1 */
-  bool solve(double current_t, const double * current_x, const double * u_init)
+  bool solve(Real current_t, const Real * current_x, const Real * u_init)
   {
     const int T = config_.horizon_steps;
     current_t_ = current_t;
@@ -503,7 +523,7 @@ public:
     m_list_.resize(T);
     for(int i = 0; i < T; i++)
     {
-      double t = current_t_ + i * model_.dt;
+      Real t = current_t_ + i * model_.dt;
       m_list_[i] = model_.inputDim(t);
       if(m_list_[i] < 0 || m_list_[i] > MMAX)
       {
@@ -511,30 +531,30 @@ public:
       }
     }
 
-    cand_.x.assign(static_cast<size_t>(T + 1) * N, 0.0);
-    cand_.u.assign(static_cast<size_t>(T) * (MMAX > 0 ? MMAX : 1), 0.0);
-    cand_.cost.assign(T + 1, 0.0);
+    cand_.x.assign(static_cast<size_t>(T + 1) * N, Real(0));
+    cand_.u.assign(static_cast<size_t>(T) * (MMAX > 0 ? MMAX : 1), Real(0));
+    cand_.cost.assign(T + 1, Real(0));
     deriv_.resize(T);
-    k_list_.assign(static_cast<size_t>(T) * (MMAX > 0 ? MMAX : 1), 0.0);
-    K_list_.assign(static_cast<size_t>(T) * (MMAX > 0 ? MMAX : 1) * N, 0.0);
+    k_list_.assign(static_cast<size_t>(T) * (MMAX > 0 ? MMAX : 1), Real(0));
+    K_list_.assign(static_cast<size_t>(T) * (MMAX > 0 ? MMAX : 1) * N, Real(0));
     qp_retval_.assign(T, 0);
     qp_free_mask_.assign(T, 0u);
 
     // initial rollout    :83-95
     control_.u.assign(u_init, u_init + static_cast<size_t>(T) * (MMAX > 0 ? MMAX : 1));
-    control_.x.assign(static_cast<size_t>(T + 1) * N, 0.0);
-    control_.cost.assign(T + 1, 0.0);
+    control_.x.assign(static_cast<size_t>(T + 1) * N, Real(0));
+    control_.cost.assign(T + 1, Real(0));
     for(int j = 0; j < N; j++)
     {
       control_.x[j] = current_x[j];
     }
     for(int i = 0; i < T; i++)
     {
-      double t = current_t_ + i * model_.dt;
+      Real t = current_t_ + i * model_.dt;
       model_.stateEq(t, &control_.x[i * N], &control_.u[i * MM()], m_list_[i], &control_.x[(i + 1) * N]);
       control_.cost[i] = model_.runningCost(t, &control_.x[i * N], &control_.u[i * MM()], m_list_[i]);
     }
-    double terminal_t = current_t_ + T * model_.dt;
+    Real terminal_t = current_t_ + T * model_.dt;
     control_.cost[T] = model_.terminalCost(terminal_t, &control_.x[T * N]);
 
     // trace[0]    :98-104
@@ -566,10 +586,10 @@ protected:
     return MMAX > 0 ? MMAX : 1;
   }
 
-  static double sum(const std::vector<double> & v)
+  static Real sum(const std::vector<Real> & v)
   {
-    double s = 0;
-    for(double e : v)
+    Real s = 0;
+    for(Real e : v)
     {
       s += e;
     }
@@ -588,14 +608,14 @@ protected:
     for(int i = 0; i < T; i++)
     {
       Deriv & d = deriv_[i];
-      double t = current_t_ + i * model_.dt;
+      Real t = current_t_ + i * model_.dt;
       d.m = m_list_[i];
-      const double * x = &control_.x[i * N];
-      const double * u = &control_.u[i * MM()];
+      const Real * x = &control_.x[i * N];
+      const Real * u = &control_.u[i * MM()];
       model_.calcStateEqDeriv(t, x, u, d.m, d.Fx, d.Fu);
       model_.calcRunningCostDeriv(t, x, u, d.m, d.Lx, d.Lu, d.Lxx, d.Luu, d.Lxu);
     }
-    double terminal_t = current_t_ + T * model_.dt;
+    Real terminal_t = current_t_ + T * model_.dt;
     model_.calcTerminalCostDeriv(terminal_t, &control_.x[T * N], last_Vx_, last_Vxx_);
 
     // Step 2: backward pass with regularisation retries    :188-214
@@ -612,17 +632,17 @@ protected:
     }
 
     // small-gradient termination, evaluated before the line search    :217-231
-    double k_rel_norm = 0;
+    Real k_rel_norm = 0;
     for(int i = 0; i < T; i++)
     {
       int m = m_list_[i];
-      double kn = 0, un = 0;
+      Real kn = 0, un = 0;
       for(int a = 0; a < m; a++)
       {
         kn += k_list_[i * MM() + a] * k_list_[i * MM() + a];
         un += control_.u[i * MM() + a] * control_.u[i * MM() + a];
       }
-      k_rel_norm = std::max(k_rel_norm, std::sqrt(kn) / (std::sqrt(un) + 1.0));
+      k_rel_norm = std::max(k_rel_norm, std::sqrt(kn) / (std::sqrt(un) + Real(1)));
     }
     tr.k_rel_norm = k_rel_norm;
     if(k_rel_norm < config_.k_rel_norm_thre && lambda_ < config_.lambda_thre)
@@ -632,10 +652,10 @@ protected:
 
     // Step 3: backtracking line search    :234-274
     bool forward_pass_success = false;
-    double cost_update_actual = 0;
-    double alpha = 0;
-    double cost_update_expected = 0;
-    double cost_update_ratio = 0;
+    Real cost_update_actual = 0;
+    Real alpha = 0;
+    Real cost_update_expected = 0;
+    Real cost_update_ratio = 0;
     for(size_t ai = 0; ai < config_.alpha_list.size(); ai++)
     {
       alpha = config_.alpha_list[ai];
@@ -701,13 +721,13 @@ protected:
   bool backwardPass()
   {
     const int T = config_.horizon_steps;
-    double Vx[N], Vxx[N * N], Vxx_reg[N * N];
-    double Qu[MM()] = {0}, Qx[N], Qux[MM() * N] = {0}, Quu[MM() * MM()] = {0}, Qxx[N * N], Qux_reg[MM() * N] = {0},
+    Real Vx[N], Vxx[N * N], Vxx_reg[N * N];
+    Real Qu[MM()] = {0}, Qx[N], Qux[MM() * N] = {0}, Quu[MM() * MM()] = {0}, Qxx[N * N], Qux_reg[MM() * N] = {0},
            Quu_F[MM() * MM()] = {0};
     constexpr int PMAX = (N > MM() ? N : MM()) * (N > MM() ? N : MM());
-    double FuT_V[MM() * N], FxT_V[N * N], prod[PMAX];
-    double k[MM()] = {0}, K[MM() * N] = {0};
-    double tmp_m[MM()];
+    Real FuT_V[MM() * N], FxT_V[N * N], prod[PMAX];
+    Real k[MM()] = {0}, K[MM() * N] = {0};
+    Real tmp_m[MM()];
 
     for(int j = 0; j < N; j++)
     {
@@ -722,7 +742,7 @@ protected:
 
     for(int i = T - 1; i >= 0; i--)
     {
-      double t = current_t_ + i * model_.dt;
+      Real t = current_t_ + i * model_.dt;
       const Deriv & d = deriv_[i];
       const int m = d.m;
 
@@ -730,7 +750,7 @@ protected:
       // Qu = Lu + Fu^T Vx
       for(int a = 0; a < m; a++)
       {
-        double s = 0;
+        Real s = 0;
         for(int r = 0; r < N; r++)
         {
           s += d.Fu[r + a * N] * Vx[r];
@@ -740,7 +760,7 @@ protected:
       // Qx = Lx + Fx^T Vx
       for(int a = 0; a < N; a++)
       {
-        double s = 0;
+        Real s = 0;
         for(int r = 0; r < N; r++)
         {
           s += d.Fx[r + a * N] * Vx[r];
@@ -811,7 +831,7 @@ protected:
         if(config_.with_input_constraint)
         {
           // warm start from k[i+1] when the dimension matches    :452-467
-          double initial_k[MM()];
+          Real initial_k[MM()];
           for(int a = 0; a < m; a++)
           {
             initial_k[a] = 0;
@@ -823,7 +843,7 @@ protected:
               initial_k[a] = k_list_[(i + 1) * MM() + a];
             }
           }
-          double lo[MM()], up[MM()];
+          Real lo[MM()], up[MM()];
           (void)t; // limits are constant in time in this restatement
           for(int a = 0; a < m; a++)
           {
@@ -855,7 +875,7 @@ protected:
           int nf = static_cast<int>(qp.free_idxs.size());
           if(nf > 0)
           {
-            std::vector<double> Kf(static_cast<size_t>(nf) * N);
+            std::vector<Real> Kf(static_cast<size_t>(nf) * N);
             for(int c = 0; c < N; c++)
             {
               for(int j = 0; j < nf; j++)
@@ -876,7 +896,7 @@ protected:
         else
         {
           // LLT(Quu_F); k = -solve(Qu); K = -solve(Qux_reg)    :500-510
-          double L[MM() * MM()];
+          Real L[MM() * MM()];
           for(int e = 0; e < m * m; e++)
           {
             L[e] = Quu_F[e];
@@ -909,15 +929,15 @@ protected:
       // value update with the UNregularised Quu, Qux    :522-526
       // dV += [k.Qu, 0.5 k.(Quu k)]
       {
-        double kQu = 0;
+        Real kQu = 0;
         for(int a = 0; a < m; a++)
         {
           kQu += k[a] * Qu[a];
         }
-        double kQuuk = 0;
+        Real kQuuk = 0;
         for(int a = 0; a < m; a++)
         {
-          double s = 0;
+          Real s = 0;
           for(int b = 0; b < m; b++)
           {
             s += Quu[a + b * m] * k[b];
@@ -929,15 +949,15 @@ protected:
           kQuuk += k[a] * tmp_m[a];
         }
         dV_[0] += kQu;
-        dV_[1] += 0.5 * kQuuk;
+        dV_[1] += Real(0.5) * kQuuk;
       }
       // K^T Quu  (N x m), shared by both updates
-      double KtQuu[N * MM()];
+      Real KtQuu[N * MM()];
       mulAtB(K, Quu, KtQuu, N, m, m);
       // Vx = Qx + (K^T Quu) k + K^T Qu + Qux^T k
       for(int r = 0; r < N; r++)
       {
-        double s1 = 0, s2 = 0, s3 = 0;
+        Real s1 = 0, s2 = 0, s3 = 0;
         for(int a = 0; a < m; a++)
         {
           s1 += KtQuu[r + a * N] * k[a];
@@ -957,7 +977,7 @@ protected:
       {
         for(int r = 0; r < N; r++)
         {
-          double s1 = 0, s2 = 0, s3 = 0;
+          Real s1 = 0, s2 = 0, s3 = 0;
           for(int a = 0; a < m; a++)
           {
             s1 += KtQuu[r + a * N] * K[a + c * m];
@@ -977,7 +997,7 @@ protected:
       {
         for(int r = 0; r < N; r++)
         {
-          Vxx[r + c * N] = 0.5 * (prod[r + c * N] + prod[c + r * N]);
+          Vxx[r + c * N] = Real(0.5) * (prod[r + c * N] + prod[c + r * N]);
         }
       }
 
@@ -995,7 +1015,7 @@ protected:
       {
         for(int a = 0; a < MM(); a++)
         {
-          K_list_[(static_cast<size_t>(i) * N + c) * MM() + a] = (a < m) ? K[a + c * m] : 0.0;
+          K_list_[(static_cast<size_t>(i) * N + c) * MM() + a] = (a < m) ? K[a + c * m] : Real(0);
         }
       }
     }
@@ -1003,7 +1023,7 @@ protected:
   }
 
   /** DDPSolver::forwardPass (DDPSolver.hpp:536-560). */
-  void forwardPass(double alpha)
+  void forwardPass(Real alpha)
   {
     const int T = config_.horizon_steps;
     for(int j = 0; j < N; j++)
@@ -1014,25 +1034,25 @@ protected:
     {
       const int m = m_list_[i];
       // u' = u + alpha k + K (x' - x)    :545-546
-      double dx[N];
+      Real dx[N];
       for(int j = 0; j < N; j++)
       {
         dx[j] = cand_.x[i * N + j] - control_.x[i * N + j];
       }
       for(int a = 0; a < m; a++)
       {
-        double s = 0;
+        Real s = 0;
         for(int c = 0; c < N; c++)
         {
           s += K_list_[(static_cast<size_t>(i) * N + c) * MM() + a] * dx[c];
         }
         cand_.u[i * MM() + a] = (control_.u[i * MM() + a] + alpha * k_list_[i * MM() + a]) + s;
       }
-      double t = current_t_ + i * model_.dt;
+      Real t = current_t_ + i * model_.dt;
       model_.stateEq(t, &cand_.x[i * N], &cand_.u[i * MM()], m, &cand_.x[(i + 1) * N]);
       cand_.cost[i] = model_.runningCost(t, &cand_.x[i * N], &cand_.u[i * MM()], m);
     }
-    double terminal_t = current_t_ + T * model_.dt;
+    Real terminal_t = current_t_ + T * model_.dt;
     cand_.cost[T] = model_.terminalCost(terminal_t, &cand_.x[T * N]);
   }
 
@@ -1059,19 +1079,21 @@ protected:
   Model model_;
   Config config_;
   std::vector<TraceRow> trace_;
-  std::vector<double> lower_, upper_;
-  double current_t_ = 0;
-  double lambda_ = 0;
-  double dlambda_ = 0;
+  std::vector<Real> lower_, upper_;
+  Real current_t_ = 0;
+  Real lambda_ = 0;
+  Real dlambda_ = 0;
   ControlData control_, cand_;
-  std::vector<double> k_list_, K_list_;
+  std::vector<Real> k_list_, K_list_;
   std::vector<int> m_list_;
   std::vector<Deriv> deriv_;
-  double last_Vx_[N];
-  double last_Vxx_[N * N];
-  double dV_[2] = {0, 0};
+  Real last_Vx_[N];
+  Real last_Vxx_[N * N];
+  Real dV_[2] = {0, 0};
   int status_ = 0;
   std::vector<int> qp_retval_;
   std::vector<unsigned> qp_free_mask_;
 };
-} // namespace oracle
+} // namespace ORACLE_NS
+#undef ORACLE_NS
+#undef ORACLE_REAL

@@ -20,6 +20,7 @@ namespace oracle
 // ---------------------------------------------------------------------------------------------------
 struct CartPole
 {
+  using Real = double;
   static constexpr int N = 4;
   static constexpr int MMAX = 1;
   static constexpr int NPARAM = 14;
@@ -207,6 +208,7 @@ struct CartPole
 // ---------------------------------------------------------------------------------------------------
 struct Bipedal
 {
+  using Real = double;
   static constexpr int N = 2;
   static constexpr int MMAX = 1;
   static constexpr int NPARAM = 6;
@@ -367,6 +369,7 @@ struct Bipedal
 // ---------------------------------------------------------------------------------------------------
 struct VerticalMotion
 {
+  using Real = double;
   static constexpr int N = 2;
   static constexpr int MMAX = 2;
   static constexpr int NPARAM = 8;
@@ -505,6 +508,7 @@ struct VerticalMotion
 // ---------------------------------------------------------------------------------------------------
 struct CentroidalMotion
 {
+  using Real = double;
   static constexpr int N = 9;
   static constexpr int MMAX = 16;
   static constexpr int NPARAM = 12;

@@ -5,32 +5,51 @@
 // written twice, independently: here for the CPU oracle and in include/nmpc_amd/models/ for the HIP path.
 // Their Jacobians are pinned by finite-difference checks in tests/ (same method as the reference's
 // CheckDerivative tests, TestDDPCartPole.cpp:609-649).
-#pragma once
+// Precision: written against `Real` like ddp_oracle.hpp — Real = double in namespace `oracle`; with ORACLE_F32 defined
+// Real = float in namespace `oracle_f32` (the fp32 instantiation BASELINE.json config 4 is compared with).
+#if defined(ORACLE_F32)
+#  ifdef ORACLE_MODELS_BUILDER_F32_HPP
+#    error "models_builder.hpp (fp32) included twice"
+#  endif
+#  define ORACLE_MODELS_BUILDER_F32_HPP
+#  define ORACLE_NS oracle_f32
+#  define ORACLE_REAL float
+#else
+#  ifdef ORACLE_MODELS_BUILDER_F64_HPP
+#    error "models_builder.hpp (fp64) included twice"
+#  endif
+#  define ORACLE_MODELS_BUILDER_F64_HPP
+#  define ORACLE_NS oracle
+#  define ORACLE_REAL double
+#endif
+
 
 #include <cmath>
 
-namespace oracle
+namespace ORACLE_NS
 {
+using Real = ORACLE_REAL;
 // ---------------------------------------------------------------------------------------------------
 // Quadrotor: x = [p(3), rpy(3), v(3) world, w(3) body], u = 4 rotor thrusts, explicit Euler.
 // ---------------------------------------------------------------------------------------------------
 struct Quadrotor
 {
+  using Real = ORACLE_NS::Real;
   static constexpr int N = 12;
   static constexpr int MMAX = 4;
   static constexpr int NPARAM = 18;
 
-  double dt = 0.02;
-  double mass = 1.0;
-  double J[3] = {0.01, 0.01, 0.02};
-  double arm = 0.2;
-  double yaw_coef = 0.05;
-  double w_pos = 1.0, w_rpy = 0.5, w_vel = 0.1, w_omega = 0.05; // running state weights
-  double w_u = 0.01;
-  double wt_scale = 10.0; // terminal weights = wt_scale * running weights
-  double ref_pos[3] = {0, 0, 1.0};
-  double reserved[3] = {0, 0, 0};
-  static constexpr double g = 9.80665;
+  Real dt = 0.02;
+  Real mass = 1.0;
+  Real J[3] = {0.01, 0.01, 0.02};
+  Real arm = 0.2;
+  Real yaw_coef = 0.05;
+  Real w_pos = 1.0, w_rpy = 0.5, w_vel = 0.1, w_omega = 0.05; // running state weights
+  Real w_u = 0.01;
+  Real wt_scale = 10.0; // terminal weights = wt_scale * running weights
+  Real ref_pos[3] = {0, 0, 1.0};
+  Real reserved[3] = {0, 0, 0};
+  static constexpr Real g = 9.80665;
 
   void setParams(const double * p)
   {
@@ -52,17 +71,17 @@ struct Quadrotor
     ref_pos[2] = p[15];
   }
 
-  int inputDim(double) const
+  int inputDim(Real) const
   {
     return 4;
   }
 
-  double hoverThrust() const
+  Real hoverThrust() const
   {
     return mass * g / 4;
   }
 
-  void weights(double * w) const
+  void weights(Real * w) const
   {
     for(int i = 0; i < 3; i++)
     {
@@ -73,37 +92,37 @@ struct Quadrotor
     }
   }
 
-  void xdot(const double * x, const double * u, double * xd) const
+  void xdot(const Real * x, const Real * u, Real * xd) const
   {
-    const double sph = std::sin(x[3]), cph = std::cos(x[3]);
-    const double sth = std::sin(x[4]), cth = std::cos(x[4]);
-    const double sps = std::sin(x[5]), cps = std::cos(x[5]);
-    const double tth = sth / cth;
-    const double p = x[9], q = x[10], r = x[11];
-    const double F = ((u[0] + u[1]) + u[2]) + u[3];
+    const Real sph = std::sin(x[3]), cph = std::cos(x[3]);
+    const Real sth = std::sin(x[4]), cth = std::cos(x[4]);
+    const Real sps = std::sin(x[5]), cps = std::cos(x[5]);
+    const Real tth = sth / cth;
+    const Real p = x[9], q = x[10], r = x[11];
+    const Real F = ((u[0] + u[1]) + u[2]) + u[3];
     xd[0] = x[6];
     xd[1] = x[7];
     xd[2] = x[8];
     xd[3] = p + sph * tth * q + cph * tth * r;
     xd[4] = cph * q - sph * r;
     xd[5] = (sph * q + cph * r) / cth;
-    const double b0 = cph * sth * cps + sph * sps;
-    const double b1 = cph * sth * sps - sph * cps;
-    const double b2 = cph * cth;
+    const Real b0 = cph * sth * cps + sph * sps;
+    const Real b1 = cph * sth * sps - sph * cps;
+    const Real b2 = cph * cth;
     xd[6] = F / mass * b0;
     xd[7] = F / mass * b1;
     xd[8] = F / mass * b2 - g;
-    const double tx = arm * (u[1] - u[3]);
-    const double ty = arm * (u[2] - u[0]);
-    const double tz = yaw_coef * (((u[0] - u[1]) + u[2]) - u[3]);
+    const Real tx = arm * (u[1] - u[3]);
+    const Real ty = arm * (u[2] - u[0]);
+    const Real tz = yaw_coef * (((u[0] - u[1]) + u[2]) - u[3]);
     xd[9] = (tx - (J[2] - J[1]) * q * r) / J[0];
     xd[10] = (ty - (J[0] - J[2]) * p * r) / J[1];
     xd[11] = (tz - (J[1] - J[0]) * p * q) / J[2];
   }
 
-  void stateEq(double, const double * x, const double * u, int, double * xn) const
+  void stateEq(Real, const Real * x, const Real * u, int, Real * xn) const
   {
-    double xd[12];
+    Real xd[12];
     xdot(x, u, xd);
     for(int i = 0; i < 12; i++)
     {
@@ -111,53 +130,53 @@ struct Quadrotor
     }
   }
 
-  double runningCost(double, const double * x, const double * u, int) const
+  Real runningCost(Real, const Real * x, const Real * u, int) const
   {
-    double w[12];
+    Real w[12];
     weights(w);
-    double s = 0;
+    Real s = 0;
     for(int i = 0; i < 12; i++)
     {
-      double d = (i < 3) ? x[i] - ref_pos[i] : x[i];
+      Real d = (i < 3) ? x[i] - ref_pos[i] : x[i];
       s += w[i] * (d * d);
     }
-    double su = 0;
-    const double fh = hoverThrust();
+    Real su = 0;
+    const Real fh = hoverThrust();
     for(int a = 0; a < 4; a++)
     {
-      double d = u[a] - fh;
+      Real d = u[a] - fh;
       su += d * d;
     }
     return 0.5 * s + 0.5 * w_u * su;
   }
 
-  double terminalCost(double, const double * x) const
+  Real terminalCost(Real, const Real * x) const
   {
-    double w[12];
+    Real w[12];
     weights(w);
-    double s = 0;
+    Real s = 0;
     for(int i = 0; i < 12; i++)
     {
-      double d = (i < 3) ? x[i] - ref_pos[i] : x[i];
+      Real d = (i < 3) ? x[i] - ref_pos[i] : x[i];
       s += (wt_scale * w[i]) * (d * d);
     }
     return 0.5 * s;
   }
 
-  void calcStateEqDeriv(double, const double * x, const double * u, int, double * Fx, double * Fu) const
+  void calcStateEqDeriv(Real, const Real * x, const Real * u, int, Real * Fx, Real * Fu) const
   {
-    const double sph = std::sin(x[3]), cph = std::cos(x[3]);
-    const double sth = std::sin(x[4]), cth = std::cos(x[4]);
-    const double sps = std::sin(x[5]), cps = std::cos(x[5]);
-    const double tth = sth / cth;
-    const double p = x[9], q = x[10], r = x[11];
-    const double F = ((u[0] + u[1]) + u[2]) + u[3];
-    double A[144];
+    const Real sph = std::sin(x[3]), cph = std::cos(x[3]);
+    const Real sth = std::sin(x[4]), cth = std::cos(x[4]);
+    const Real sps = std::sin(x[5]), cps = std::cos(x[5]);
+    const Real tth = sth / cth;
+    const Real p = x[9], q = x[10], r = x[11];
+    const Real F = ((u[0] + u[1]) + u[2]) + u[3];
+    Real A[144];
     for(int e = 0; e < 144; e++)
     {
       A[e] = 0;
     }
-    auto a = [&](int row, int col) -> double & { return A[row + col * 12]; };
+    auto a = [&](int row, int col) -> Real & { return A[row + col * 12]; };
     a(0, 6) = 1;
     a(1, 7) = 1;
     a(2, 8) = 1;
@@ -175,7 +194,7 @@ struct Quadrotor
     a(5, 10) = sph / cth;
     a(5, 11) = cph / cth;
     // thrust direction
-    const double fm = F / mass;
+    const Real fm = F / mass;
     a(6, 3) = fm * (-sph * sth * cps + cph * sps);
     a(7, 3) = fm * (-sph * sth * sps - cph * cps);
     a(8, 3) = fm * (-sph * cth);
@@ -199,9 +218,9 @@ struct Quadrotor
     {
       Fx[i + i * 12] += 1.0;
     }
-    const double b0 = cph * sth * cps + sph * sps;
-    const double b1 = cph * sth * sps - sph * cps;
-    const double b2 = cph * cth;
+    const Real b0 = cph * sth * cps + sph * sps;
+    const Real b1 = cph * sth * sps - sph * cps;
+    const Real b2 = cph * cth;
     for(int e = 0; e < 48; e++)
     {
       Fu[e] = 0;
@@ -222,24 +241,24 @@ struct Quadrotor
     Fu[11 + 3 * 12] = dt * (-yaw_coef / J[2]);
   }
 
-  void calcRunningCostDeriv(double,
-                            const double * x,
-                            const double * u,
+  void calcRunningCostDeriv(Real,
+                            const Real * x,
+                            const Real * u,
                             int,
-                            double * Lx,
-                            double * Lu,
-                            double * Lxx,
-                            double * Luu,
-                            double * Lxu) const
+                            Real * Lx,
+                            Real * Lu,
+                            Real * Lxx,
+                            Real * Luu,
+                            Real * Lxu) const
   {
-    double w[12];
+    Real w[12];
     weights(w);
     for(int i = 0; i < 12; i++)
     {
-      double d = (i < 3) ? x[i] - ref_pos[i] : x[i];
+      Real d = (i < 3) ? x[i] - ref_pos[i] : x[i];
       Lx[i] = w[i] * d;
     }
-    const double fh = hoverThrust();
+    const Real fh = hoverThrust();
     for(int a = 0; a < 4; a++)
     {
       Lu[a] = w_u * (u[a] - fh);
@@ -266,13 +285,13 @@ struct Quadrotor
     }
   }
 
-  void calcTerminalCostDeriv(double, const double * x, double * Vx, double * Vxx) const
+  void calcTerminalCostDeriv(Real, const Real * x, Real * Vx, Real * Vxx) const
   {
-    double w[12];
+    Real w[12];
     weights(w);
     for(int i = 0; i < 12; i++)
     {
-      double d = (i < 3) ? x[i] - ref_pos[i] : x[i];
+      Real d = (i < 3) ? x[i] - ref_pos[i] : x[i];
       Vx[i] = (wt_scale * w[i]) * d;
     }
     for(int e = 0; e < 144; e++)
@@ -294,20 +313,21 @@ struct Quadrotor
 // ---------------------------------------------------------------------------------------------------
 struct Manipulator
 {
+  using Real = ORACLE_NS::Real;
   static constexpr int N = 14;
   static constexpr int MMAX = 7;
   static constexpr int NPARAM = 12;
   static constexpr int NJ = 7;
 
-  double dt = 0.01;
-  double w_diag = 2.0;
-  double w_off = 0.15;
-  double damping = 0.5;
-  double grav_scale = 4.0; // grav_j = grav_scale * (NJ - j) / NJ
-  double wq = 1.0, wv = 0.05, wu = 0.002;
-  double wt_scale = 20.0;
-  double q_ref_scale = 0.3; // q_ref_j = q_ref_scale * (j odd ? -1 : 1)
-  double reserved[2] = {0, 0};
+  Real dt = 0.01;
+  Real w_diag = 2.0;
+  Real w_off = 0.15;
+  Real damping = 0.5;
+  Real grav_scale = 4.0; // grav_j = grav_scale * (NJ - j) / NJ
+  Real wq = 1.0, wv = 0.05, wu = 0.002;
+  Real wt_scale = 20.0;
+  Real q_ref_scale = 0.3; // q_ref_j = q_ref_scale * (j odd ? -1 : 1)
+  Real reserved[2] = {0, 0};
 
   void setParams(const double * p)
   {
@@ -323,23 +343,23 @@ struct Manipulator
     q_ref_scale = p[9];
   }
 
-  int inputDim(double) const
+  int inputDim(Real) const
   {
     return 7;
   }
 
-  double grav(int j) const
+  Real grav(int j) const
   {
-    return grav_scale * static_cast<double>(NJ - j) / NJ;
+    return grav_scale * static_cast<Real>(NJ - j) / NJ;
   }
-  double qRef(int j) const
+  Real qRef(int j) const
   {
     return (j % 2 == 1) ? -q_ref_scale : q_ref_scale;
   }
 
-  void residual(const double * x, const double * u, double * r, double * S) const
+  void residual(const Real * x, const Real * u, Real * r, Real * S) const
   {
-    double acc = 0;
+    Real acc = 0;
     for(int j = 0; j < NJ; j++)
     {
       acc += x[j];
@@ -348,16 +368,16 @@ struct Manipulator
     }
   }
 
-  void stateEq(double, const double * x, const double * u, int, double * xn) const
+  void stateEq(Real, const Real * x, const Real * u, int, Real * xn) const
   {
-    double r[NJ], S[NJ];
+    Real r[NJ], S[NJ];
     residual(x, u, r, S);
     for(int i = 0; i < NJ; i++)
     {
-      double s = 0;
+      Real s = 0;
       for(int j = 0; j < NJ; j++)
       {
-        double W = (i == j ? w_diag : 0.0) + w_off * std::cos(x[i] - x[j]);
+        Real W = (i == j ? w_diag : 0.0) + w_off * std::cos(x[i] - x[j]);
         s += W * r[j];
       }
       xn[i] = x[i] + dt * x[NJ + i];
@@ -365,19 +385,19 @@ struct Manipulator
     }
   }
 
-  double runningCost(double, const double * x, const double * u, int) const
+  Real runningCost(Real, const Real * x, const Real * u, int) const
   {
-    double s = 0;
+    Real s = 0;
     for(int j = 0; j < NJ; j++)
     {
-      double d = x[j] - qRef(j);
+      Real d = x[j] - qRef(j);
       s += wq * (d * d);
     }
     for(int j = 0; j < NJ; j++)
     {
       s += wv * (x[NJ + j] * x[NJ + j]);
     }
-    double su = 0;
+    Real su = 0;
     for(int j = 0; j < NJ; j++)
     {
       su += u[j] * u[j];
@@ -385,12 +405,12 @@ struct Manipulator
     return 0.5 * s + 0.5 * wu * su;
   }
 
-  double terminalCost(double, const double * x) const
+  Real terminalCost(Real, const Real * x) const
   {
-    double s = 0;
+    Real s = 0;
     for(int j = 0; j < NJ; j++)
     {
-      double d = x[j] - qRef(j);
+      Real d = x[j] - qRef(j);
       s += (wt_scale * wq) * (d * d);
     }
     for(int j = 0; j < NJ; j++)
@@ -400,11 +420,11 @@ struct Manipulator
     return 0.5 * s;
   }
 
-  void calcStateEqDeriv(double, const double * x, const double * u, int, double * Fx, double * Fu) const
+  void calcStateEqDeriv(Real, const Real * x, const Real * u, int, Real * Fx, Real * Fu) const
   {
-    double r[NJ], S[NJ];
+    Real r[NJ], S[NJ];
     residual(x, u, r, S);
-    double W[NJ * NJ]; // W(i,j) at i + j*NJ
+    Real W[NJ * NJ]; // W(i,j) at i + j*NJ
     for(int i = 0; i < NJ; i++)
     {
       for(int j = 0; j < NJ; j++)
@@ -427,19 +447,19 @@ struct Manipulator
     for(int i = 0; i < NJ; i++)
     {
       // d qdd_i / d q_l
-      double self = 0;
+      Real self = 0;
       for(int j = 0; j < NJ; j++)
       {
         self += std::sin(x[i] - x[j]) * r[j];
       }
       for(int l = 0; l < NJ; l++)
       {
-        double dW = w_off * std::sin(x[i] - x[l]) * r[l];
+        Real dW = w_off * std::sin(x[i] - x[l]) * r[l];
         if(l == i)
         {
           dW += -w_off * self;
         }
-        double dG = 0;
+        Real dG = 0;
         for(int j = l; j < NJ; j++)
         {
           dG += W[i + j * NJ] * (grav(j) * std::cos(S[j]));
@@ -465,15 +485,15 @@ struct Manipulator
     }
   }
 
-  void calcRunningCostDeriv(double,
-                            const double * x,
-                            const double * u,
+  void calcRunningCostDeriv(Real,
+                            const Real * x,
+                            const Real * u,
                             int,
-                            double * Lx,
-                            double * Lu,
-                            double * Lxx,
-                            double * Luu,
-                            double * Lxu) const
+                            Real * Lx,
+                            Real * Lu,
+                            Real * Lxx,
+                            Real * Luu,
+                            Real * Lxu) const
   {
     for(int j = 0; j < NJ; j++)
     {
@@ -504,7 +524,7 @@ struct Manipulator
     }
   }
 
-  void calcTerminalCostDeriv(double, const double * x, double * Vx, double * Vxx) const
+  void calcTerminalCostDeriv(Real, const Real * x, Real * Vx, Real * Vxx) const
   {
     for(int j = 0; j < NJ; j++)
     {
@@ -522,4 +542,6 @@ struct Manipulator
     }
   }
 };
-} // namespace oracle
+} // namespace ORACLE_NS
+#undef ORACLE_NS
+#undef ORACLE_REAL

@@ -6,10 +6,16 @@
 #include "ddp_oracle.hpp"
 #include "models.hpp"
 #include "models_builder.hpp"
+// the same statements in single precision: namespace oracle_f32 (BASELINE.json config 4 is specified in fp32)
+#define ORACLE_F32
+#include "ddp_oracle.hpp"
+#include "models_builder.hpp"
+#undef ORACLE_F32
 
 #include <chrono>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 
 namespace
 {
@@ -43,7 +49,45 @@ int dispatch(const char * name, F && f)
   {
     return f(Manipulator());
   }
+  if(s == "quadrotor_f32")
+  {
+    return f(oracle_f32::Quadrotor());
+  }
+  if(s == "manipulator_f32")
+  {
+    return f(oracle_f32::Manipulator());
+  }
   return -100;
+}
+
+/** The solver instantiation that matches the model's arithmetic type. */
+template<class M>
+using SolverOf = std::conditional_t<std::is_same<typename M::Real, float>::value, oracle_f32::DDPSolver<M>, oracle::DDPSolver<M>>;
+
+/** The C entry points exchange doubles whatever the model computes in: inputs are rounded to the model's Real once,
+    outputs widened (exact). */
+template<class R>
+std::vector<R> toReal(const double * p, size_t n)
+{
+  std::vector<R> v(n);
+  for(size_t i = 0; i < n; i++)
+  {
+    v[i] = static_cast<R>(p[i]);
+  }
+  return v;
+}
+template<class R>
+void toDouble(double * dst, const R * src, size_t n)
+{
+  for(size_t i = 0; i < n; i++)
+  {
+    dst[i] = static_cast<double>(src[i]);
+  }
+}
+template<class R>
+void toDouble(double * dst, const std::vector<R> & v)
+{
+  toDouble(dst, v.data(), v.size());
 }
 } // namespace
 
@@ -97,7 +141,12 @@ extern "C"
     }
   }
 
-  static void toConfig(const oracle_config * c, Config & d)
+} // extern "C"
+
+namespace
+{
+  template<class Cfg>
+  void toConfig(const oracle_config * c, Cfg & d)
   {
     d.with_input_constraint = c->with_input_constraint != 0;
     d.max_iter = c->max_iter;
@@ -112,8 +161,16 @@ extern "C"
     d.lambda_thre = c->lambda_thre;
     d.cost_update_ratio_thre = c->cost_update_ratio_thre;
     d.cost_update_thre = c->cost_update_thre;
-    d.alpha_list.assign(c->alpha_list, c->alpha_list + c->n_alpha);
+    d.alpha_list.resize(c->n_alpha);
+    for(int i = 0; i < c->n_alpha; i++)
+    {
+      d.alpha_list[i] = static_cast<typename std::remove_reference<decltype(d.alpha_list[0])>::type>(c->alpha_list[i]);
+    }
   }
+} // namespace
+
+extern "C"
+{
 
   int oracle_model_dims(const char * model, int * n, int * mmax, int * nparam)
   {
@@ -174,34 +231,54 @@ extern "C"
                       {
                         m.setParams(params);
                       }
-                      int mi = m.inputDim(t);
+                      using R = typename M::Real;
+                      constexpr int N = M::N;
+                      constexpr int MM = M::MMAX > 0 ? M::MMAX : 1;
+                      const R tr = static_cast<R>(t);
+                      int mi = m.inputDim(tr);
                       if(m_out)
                       {
                         *m_out = mi;
                       }
+                      const std::vector<R> xr = toReal<R>(x, N);
+                      const std::vector<R> ur = u ? toReal<R>(u, MM) : std::vector<R>(MM, R(0));
                       if(xn)
                       {
-                        m.stateEq(t, x, u, mi, xn);
+                        R o[N];
+                        m.stateEq(tr, xr.data(), ur.data(), mi, o);
+                        toDouble(xn, o, N);
                       }
                       if(running_cost)
                       {
-                        *running_cost = m.runningCost(t, x, u, mi);
+                        *running_cost = m.runningCost(tr, xr.data(), ur.data(), mi);
                       }
                       if(terminal_cost)
                       {
-                        *terminal_cost = m.terminalCost(t, x);
+                        *terminal_cost = m.terminalCost(tr, xr.data());
                       }
                       if(Fx && Fu)
                       {
-                        m.calcStateEqDeriv(t, x, u, mi, Fx, Fu);
+                        R fx[N * N], fu[N * MM];
+                        m.calcStateEqDeriv(tr, xr.data(), ur.data(), mi, fx, fu);
+                        toDouble(Fx, fx, N * N);
+                        toDouble(Fu, fu, static_cast<size_t>(N) * mi);
                       }
                       if(Lx && Lu && Lxx && Luu && Lxu)
                       {
-                        m.calcRunningCostDeriv(t, x, u, mi, Lx, Lu, Lxx, Luu, Lxu);
+                        R lx[N], lu[MM], lxx[N * N], luu[MM * MM], lxu[N * MM];
+                        m.calcRunningCostDeriv(tr, xr.data(), ur.data(), mi, lx, lu, lxx, luu, lxu);
+                        toDouble(Lx, lx, N);
+                        toDouble(Lu, lu, mi);
+                        toDouble(Lxx, lxx, N * N);
+                        toDouble(Luu, luu, static_cast<size_t>(mi) * mi);
+                        toDouble(Lxu, lxu, static_cast<size_t>(N) * mi);
                       }
                       if(Vx && Vxx)
                       {
-                        m.calcTerminalCostDeriv(t, x, Vx, Vxx);
+                        R vx[N], vxx[N * N];
+                        m.calcTerminalCostDeriv(tr, xr.data(), vx, vxx);
+                        toDouble(Vx, vx, N);
+                        toDouble(Vxx, vxx, N * N);
                       }
                       (void)sizeof(M);
                       return 0;
@@ -278,7 +355,10 @@ extern "C"
                       {
                         m.setParams(params);
                       }
-                      DDPSolver<M> solver(m);
+                      using R = typename M::Real;
+                      constexpr int N = M::N;
+                      constexpr int MM = M::MMAX > 0 ? M::MMAX : 1;
+                      SolverOf<M> solver(m);
                       toConfig(cfg, solver.config());
                       if(cfg->with_input_constraint)
                       {
@@ -286,29 +366,30 @@ extern "C"
                         {
                           return -2;
                         }
-                        solver.setInputLimits(lower, upper);
+                        solver.setInputLimits(toReal<R>(lower, MM).data(), toReal<R>(upper, MM).data());
                       }
-                      solver.solve(t0, x0, u_init);
+                      solver.solve(static_cast<R>(t0), toReal<R>(x0, N).data(),
+                                   toReal<R>(u_init, static_cast<size_t>(cfg->horizon_steps) * MM).data());
                       const auto & cd = solver.controlData();
                       if(X)
                       {
-                        std::memcpy(X, cd.x.data(), cd.x.size() * sizeof(double));
+                        toDouble(X, cd.x);
                       }
                       if(U)
                       {
-                        std::memcpy(U, cd.u.data(), cd.u.size() * sizeof(double));
+                        toDouble(U, cd.u);
                       }
                       if(cost)
                       {
-                        std::memcpy(cost, cd.cost.data(), cd.cost.size() * sizeof(double));
+                        toDouble(cost, cd.cost);
                       }
                       if(k)
                       {
-                        std::memcpy(k, solver.kList().data(), solver.kList().size() * sizeof(double));
+                        toDouble(k, solver.kList());
                       }
                       if(K)
                       {
-                        std::memcpy(K, solver.KList().data(), solver.KList().size() * sizeof(double));
+                        toDouble(K, solver.KList());
                       }
                       const auto & tr = solver.traceDataList();
                       if(n_trace)
@@ -403,40 +484,48 @@ extern "C"
           {
             int b0 = static_cast<int>(static_cast<long long>(B) * tid / n_threads);
             int b1 = static_cast<int>(static_cast<long long>(B) * (tid + 1) / n_threads);
-            DDPSolver<M> solver(m);
+            using R = typename M::Real;
+            SolverOf<M> solver(m);
             toConfig(cfg, solver.config());
             if(cfg->with_input_constraint)
             {
-              solver.setInputLimits(lower, upper);
+              solver.setInputLimits(toReal<R>(lower, MM).data(), toReal<R>(upper, MM).data());
             }
+            std::vector<R> x0r(N), u0r(static_cast<size_t>(T) * MM);
             for(int b = b0; b < b1; b++)
             {
-              solver.solve(t0 ? t0[b] : 0.0, x0 + static_cast<size_t>(b) * N, u_init + static_cast<size_t>(b) * T * MM);
+              for(int j = 0; j < N; j++)
+              {
+                x0r[j] = static_cast<R>(x0[static_cast<size_t>(b) * N + j]);
+              }
+              for(size_t e = 0; e < u0r.size(); e++)
+              {
+                u0r[e] = static_cast<R>(u_init[static_cast<size_t>(b) * T * MM + e]);
+              }
+              solver.solve(static_cast<R>(t0 ? t0[b] : 0.0), x0r.data(), u0r.data());
               const auto & cd = solver.controlData();
               if(X)
               {
-                std::memcpy(X + static_cast<size_t>(b) * (T + 1) * N, cd.x.data(), cd.x.size() * sizeof(double));
+                toDouble(X + static_cast<size_t>(b) * (T + 1) * N, cd.x);
               }
               if(U)
               {
-                std::memcpy(U + static_cast<size_t>(b) * T * MM, cd.u.data(), cd.u.size() * sizeof(double));
+                toDouble(U + static_cast<size_t>(b) * T * MM, cd.u);
               }
               if(cost)
               {
-                std::memcpy(cost + static_cast<size_t>(b) * (T + 1), cd.cost.data(), cd.cost.size() * sizeof(double));
+                toDouble(cost + static_cast<size_t>(b) * (T + 1), cd.cost);
               }
               if(k)
               {
-                std::memcpy(k + static_cast<size_t>(b) * T * MM, solver.kList().data(),
-                            solver.kList().size() * sizeof(double));
+                toDouble(k + static_cast<size_t>(b) * T * MM, solver.kList());
               }
               if(K)
               {
-                std::memcpy(K + static_cast<size_t>(b) * T * MM * N, solver.KList().data(),
-                            solver.KList().size() * sizeof(double));
+                toDouble(K + static_cast<size_t>(b) * T * MM * N, solver.KList());
               }
               const auto & tr = solver.traceDataList();
-              const TraceRow & last = tr.back();
+              const auto & last = tr.back();
               it_count[tid] += last.iter;
               if(status)
               {
@@ -551,6 +640,12 @@ extern "C"
             m.setParams(params);
           }
           const int T = cfg->horizon_steps;
+          if constexpr(!std::is_same<typename M::Real, double>::value)
+          {
+            return -3; // the closed-loop restatements exist for the reference's own (fp64) models
+          }
+          else
+          {
           DDPSolver<M> solver(m);
           toConfig(cfg, solver.config());
           if(lower && upper)
@@ -671,6 +766,7 @@ extern "C"
             *t_final = current_t;
           }
           return 0;
+          }
         });
   }
 } // extern "C"

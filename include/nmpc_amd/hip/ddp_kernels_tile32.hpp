@@ -1,17 +1,16 @@
-// gfx950 device code of the batched DDP solver, fp32, LANE MAPPING "TILE32": one workgroup of eight wavefronts solves 32
+// gfx950 device code of the batched DDP solver, fp32, LANE MAPPING "TILE32": one workgroup of sixteen wavefronts solves 32
 // problem instances whose (n + m) x (n + m) augmented blocks are ONE 16 x 16 matrix-core tile — BASELINE.json config 4
 // (quadrotor n 12, m 4, T 50, batch 8192, fp32: 8192 / 32 = 256 workgroups = one per CU).
 //
 // What a lane means changes with the phase (reference: nmpc_ddp/include/nmpc_ddp/DDPSolver.hpp):
 //
 //   model code  — rollouts (:83-95, :536-560) and the linearisation sweep (:157-185): lane = INSTANCE (wave 0, "model
-//                 wave"), the line search (:234-274) additionally lane = (instance, step size) on waves 1..7, all step sizes
+//                 wave"), the line search (:234-274) additionally lane = (instance, step size) on waves 1..15, all step sizes
 //                 of alpha_list at once (the trials are independent: same nominal, same gains).
-//   backward    — (:342-534) lane = MATRIX ENTRY on waves 1..7, five instances per wave (two on the model wave's SIMD
-//                 partner), on v_mfma_f32_16x16x4_f32.
+//   backward    — (:342-534) lane = MATRIX ENTRY on waves 1..15, two or three instances per wave, on v_mfma_f32_16x16x4_f32.
 //
 // Derivatives never reach HBM and are never materialised for the whole horizon either: the model wave linearises timestep
-// i - 1 of all 32 instances into an LDS record while the seven matrix waves consume the record of timestep i (two record
+// i - 1 of all 32 instances into an LDS record while the fifteen matrix waves consume the record of timestep i (two record
 // slots, one barrier per timestep).  HBM sees (x, u) once per sweep, the gains once, and the rollouts' trajectories: the
 // fused lower bound of SURVEY.md §8(d).
 //
@@ -47,25 +46,36 @@ namespace hip
 {
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifndef NMPC_TILE32_WAVES
+#  define NMPC_TILE32_WAVES 12
+#endif
 constexpr int kTileInstances = 32; //!< instances per workgroup
-constexpr int kTileWaves = 8; //!< two per SIMD: 256 registers each
+//! wavefronts per workgroup: 8 (two per SIMD, 256 registers each), 12 (three, 168) or 16 (four, 128).  More waves hide
+//! more of the backward chains' latencies, fewer leave the model code (rollouts, linearisation) its registers.
+constexpr int kTileWaves = NMPC_TILE32_WAVES;
+static_assert(kTileWaves == 8 || kTileWaves == 12 || kTileWaves == 16, "8, 12 or 16 wavefronts per workgroup");
 constexpr int kTileThreads = kTileWaves * 64;
 constexpr int kTileModelWave = 0; //!< model code, lane = instance
-constexpr int kTileMatrixWaves = kTileWaves - 1; //!< waves 1..7: backward pass, line-search fan-out
-constexpr int kTileMaxPerWave = 5; //!< instances of one matrix wave
-/** Instances of matrix wave w (1..7).  Waves w and w + 4 share a SIMD: wave 4, the model wave's partner, takes two
-    instances (the linearisation of 32 instances costs about as many instructions per timestep as three to four backward
-    steps), the other six take five. */
+constexpr int kTileMatrixWaves = kTileWaves - 1; //!< waves 1 ..: backward pass, line-search fan-out
+/** Instances of matrix wave w >= 1.  Wave w runs on SIMD w % 4; the matrix waves that share SIMD 0 with the model wave
+    take fewer instances (the linearisation of 32 instances costs about as many instructions per timestep as three to four
+    backward steps):   8 waves: 5 5 5 | 2 | 5 5 5      12 waves: 3 3 3 | 3 | 3 3 3 | 2 | 3 3 3      16 waves: 2 each, 3 on waves 13, 14. */
 __host__ __device__ constexpr int tileWaveCount(int w)
 {
-  return w == 4 ? 2 : 5;
+  return kTileWaves == 8 ? (w == 4 ? 2 : 5) : (kTileWaves == 12 ? (w == 8 ? 2 : 3) : ((w == 13 || w == 14) ? 3 : 2));
 }
+constexpr int kTileMaxPerWave = kTileWaves == 8 ? 5 : 3;
+constexpr int kTileMinPerWave = 2;
 __host__ __device__ constexpr int tileWaveFirst(int w)
 {
-  return w <= 4 ? 5 * (w - 1) : 17 + 5 * (w - 5);
+  int first = 0;
+  for(int v = 1; v < w; v++)
+  {
+    first += tileWaveCount(v);
+  }
+  return first;
 }
-static_assert(tileWaveFirst(7) + tileWaveCount(7) == kTileInstances && tileWaveFirst(4) == 15 && tileWaveFirst(5) == 17,
-              "the matrix waves cover the 32 slots");
+static_assert(tileWaveFirst(kTileWaves) == kTileInstances, "the matrix waves cover the 32 slots");
 
 template<class Problem>
 struct TileSolver32
@@ -91,17 +101,21 @@ struct TileSolver32
 
   // ---- LDS record of one (instance, timestep): what the model wave hands to the matrix waves (floats)
   static constexpr int kOffF = 0; //!< [Fx Fu | 0]: 16 columns of n rows, column-major
-  static constexpr int kOffL = 16 * N; //!< [[Lxx Lxu],[Lxu^T Luu]] padded to 16 x 16, column-major
+  static constexpr int kOffL = 16 * N; //!< [[Lxx Lxu],[Lxu^T Luu]] padded to 16 x 16, column-major, 4-row groups rotated by column / 4
   static constexpr int kOffLv = kOffL + 256; //!< [Lx; Lu; 0]
   static constexpr int kOffInvU = kOffLv + 16; //!< 1 / (|u_i| + 1)    :217-221
-  static constexpr int kOffZero = kOffInvU + 4; //!< four zeros: what lanes outside an operand read
-  static constexpr int kRecRaw = kOffZero + 4;
+  static constexpr int kRecRaw = kOffInvU + 4;
   //! record stride: an odd number of 16-byte granules, so that the 32 lanes of the model wave (one record each) spread
   //! over the LDS banks when they write the same field
   static constexpr int kRec = ((kRecRaw / 4) % 2 == 1) ? kRecRaw : kRecRaw + 4;
   static constexpr int kRecAt = 0; //!< rec[2][32][kRec]
+  //! [Vxx | Vx] of the terminal cost per slot: n + 1 columns of n rows (its own area: the step records are then only ever
+  //! written by lineariseStep, which lets it skip what it knows to be constant)
+  static constexpr int kTermRaw = (N + 1) * N;
+  static constexpr int kTerm = ((kTermRaw / 4) % 2 == 1) ? kTermRaw : kTermRaw + 4;
+  static constexpr int kTermAt = kRecAt + 2 * kTileInstances * kRec;
   // ---- per-slot scalars and flags
-  static constexpr int kSlotAt = kRecAt + 2 * kTileInstances * kRec;
+  static constexpr int kSlotAt = kTermAt + kTileInstances * kTerm;
   enum SlotField
   {
     sB = 0, //!< int: instance index, -1 = empty slot
@@ -117,9 +131,14 @@ struct TileSolver32
     kNumSlotFields
   };
   static constexpr int kFlagAt = kSlotAt + kNumSlotFields * kTileInstances; //!< ints: any_bw, any_retry, any_ls
-  static constexpr int kScratchAt = kFlagAt + 8; //!< [32 slots][16]: q as a row -> q as a column
-  static constexpr int kLsAt = kScratchAt + kTileInstances * 16; //!< lsJ[NMPC_HIP_MAX_ALPHA][32]: cost of every trial
-  static constexpr int kLdsFloats = kLsAt + NMPC_HIP_MAX_ALPHA * kTileInstances;
+  static constexpr int kScratchAt = kFlagAt + 8; //!< [32 slots][16]: q as a row -> q as a column; then a 16-word dump
+  static constexpr int kLsAt = kScratchAt + kTileInstances * 16 + 16; //!< lsJ[NMPC_HIP_MAX_ALPHA][32]: cost of every trial
+  //! per wave: the new value function, written row by row (leading dimension 20: conflict-free both ways) and read back
+  //! transposed for Vxx <- (Vxx + Vxx^T) / 2; then 16 zeros for the lanes outside the block
+  static constexpr int kTrLd = 20;
+  static constexpr int kTrFloats = 16 * kTrLd + 16;
+  static constexpr int kTrAt = kLsAt + NMPC_HIP_MAX_ALPHA * kTileInstances;
+  static constexpr int kLdsFloats = kTrAt + kTileWaves * kTrFloats;
   static constexpr size_t kLdsBytes = static_cast<size_t>(kLdsFloats) * sizeof(float);
   static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 
@@ -147,6 +166,10 @@ struct TileSolver32
   {
     return lds + kRecAt + (parity * kTileInstances + slot) * kRec;
   }
+  NMPC_D float * term(int slot) const
+  {
+    return lds + kTermAt + slot * kTerm;
+  }
   NMPC_D float & slotF(int field, int slot) const
   {
     return lds[kSlotAt + field * kTileInstances + slot];
@@ -167,9 +190,11 @@ struct TileSolver32
   {
     __syncthreads();
   }
-  NMPC_D static float readLane(float v, int l)
+  /** Lane kSrc of this lane's 16-lane row in every lane of the row (DPP row_newbcast: one VALU move, no LDS, no SGPR). */
+  template<int kSrc>
+  NMPC_D static float rowBcast(float v)
   {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + kSrc, 0xf, 0xf, true));
   }
   NMPC_D static int uniform(int v)
   {
@@ -300,25 +325,56 @@ struct TileSolver32
     v4f v = {a, b, c, d};
     *reinterpret_cast<v4f *>(at) = v;
   }
+  /** One record entry.  kFull = false: entries the compiler knows to be constants (the literal zeros and ones of the model's
+      Jacobians, the padding) are not written again — the record slot already holds them from the sweep's first two (full)
+      timesteps.  Adjacent stores are merged by the compiler. */
+  template<bool kFull>
+  NMPC_D static void put(float * at, float v)
+  {
+    if(kFull || !__builtin_constant_p(v))
+    {
+      *at = v;
+    }
+  }
 
-  /** Derivatives at (x_i, u_i) of the slot's current trajectory -> rec(i & 1, slot). */
-  NMPC_D void lineariseStep(int slot, int b, int sel, float t0, int i) const
+  struct Point
+  {
+    float x[N], u[MM];
+  };
+  /** (x_i, u_i) of the slot's current trajectory: requested one timestep before lineariseStep consumes it. */
+  NMPC_D void loadPoint(Point & p, int b, int sel, int i) const
   {
     const size_t tile = static_cast<size_t>(b) / 64, ln = static_cast<size_t>(b) % 64;
     const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;
     const float * Xn = buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln;
     const float * Un = buf.U + ((tile * 2 + sel) * rows_u) * 64 + ln;
+#pragma unroll
+    for(int c = 0; c < N; c++)
+    {
+      p.x[c] = Xn[(static_cast<size_t>(i) * N + c) * 64];
+    }
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      p.u[a] = Un[(static_cast<size_t>(i) * MM + a) * 64];
+    }
+  }
+
+  /** Derivatives at (x_i, u_i) -> rec(i & 1, slot). */
+  template<bool kFull>
+  NMPC_D void lineariseStep(int slot, float t0, int i, const Point & p) const
+  {
     StateDimVector x;
     InputDimVector u;
 #pragma unroll
     for(int c = 0; c < N; c++)
     {
-      x[c] = Xn[(static_cast<size_t>(i) * N + c) * 64];
+      x[c] = p.x[c];
     }
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
-      u[a] = Un[(static_cast<size_t>(i) * MM + a) * 64];
+      u[a] = p.u[a];
     }
     const float t = t0 + i * problem.dt();
     StateStateDimMatrix Fx, Lxx;
@@ -334,15 +390,10 @@ struct TileSolver32
     for(int c = 0; c < 16; c++)
     {
 #pragma unroll
-      for(int r4 = 0; r4 < N; r4 += 4)
+      for(int rr = 0; rr < N; rr++)
       {
-        float v[4];
-#pragma unroll
-        for(int k = 0; k < 4; k++)
-        {
-          v[k] = (c < N) ? Fx(r4 + k, c < N ? c : 0) : ((c < NA) ? Fu(r4 + k, (c >= N && c < NA) ? c - N : 0) : 0.0f);
-        }
-        put4(r + kOffF + c * N + r4, v[0], v[1], v[2], v[3]);
+        const float v = (c < N) ? Fx(rr, c < N ? c : 0) : ((c < NA) ? Fu(rr, (c >= N && c < NA) ? c - N : 0) : 0.0f);
+        put<kFull>(r + kOffF + c * N + rr, v);
       }
     }
     // L = [[Lxx Lxu],[Lxu^T Luu]] padded with zeros
@@ -350,46 +401,33 @@ struct TileSolver32
     for(int c = 0; c < 16; c++)
     {
 #pragma unroll
-      for(int r4 = 0; r4 < 16; r4 += 4)
+      for(int rr = 0; rr < 16; rr++)
       {
-        float v[4];
-#pragma unroll
-        for(int k = 0; k < 4; k++)
+        float e = 0.0f;
+        if(rr < N && c < N)
         {
-          const int rr = r4 + k;
-          float e = 0.0f;
-          if(rr < N && c < N)
-          {
-            e = Lxx(rr < N ? rr : 0, c < N ? c : 0);
-          }
-          else if(rr < N && c < NA)
-          {
-            e = Lxu(rr < N ? rr : 0, (c >= N && c < NA) ? c - N : 0);
-          }
-          else if(rr < NA && c < N)
-          {
-            e = Lxu(c < N ? c : 0, (rr >= N && rr < NA) ? rr - N : 0);
-          }
-          else if(rr < NA && c < NA)
-          {
-            e = Luu((rr >= N && rr < NA) ? rr - N : 0, (c >= N && c < NA) ? c - N : 0);
-          }
-          v[k] = e;
+          e = Lxx(rr < N ? rr : 0, c < N ? c : 0);
         }
-        put4(r + kOffL + c * 16 + r4, v[0], v[1], v[2], v[3]);
+        else if(rr < N && c < NA)
+        {
+          e = Lxu(rr < N ? rr : 0, (c >= N && c < NA) ? c - N : 0);
+        }
+        else if(rr < NA && c < N)
+        {
+          e = Lxu(c < N ? c : 0, (rr >= N && rr < NA) ? rr - N : 0);
+        }
+        else if(rr < NA && c < NA)
+        {
+          e = Luu((rr >= N && rr < NA) ? rr - N : 0, (c >= N && c < NA) ? c - N : 0);
+        }
+        put<kFull>(r + kOffL + c * 16 + 4 * (((rr >> 2) + (c >> 2)) & 3) + (rr & 3), e);
       }
     }
 #pragma unroll
-    for(int r4 = 0; r4 < 16; r4 += 4)
+    for(int rr = 0; rr < 16; rr++)
     {
-      float v[4];
-#pragma unroll
-      for(int k = 0; k < 4; k++)
-      {
-        const int rr = r4 + k;
-        v[k] = (rr < N) ? Lx[rr < N ? rr : 0] : ((rr < NA) ? Lu[(rr >= N && rr < NA) ? rr - N : 0] : 0.0f);
-      }
-      put4(r + kOffLv + r4, v[0], v[1], v[2], v[3]);
+      const float v = (rr < N) ? Lx[rr < N ? rr : 0] : ((rr < NA) ? Lu[(rr >= N && rr < NA) ? rr - N : 0] : 0.0f);
+      put<kFull>(r + kOffLv + rr, v);
     }
     float un = 0;
 #pragma unroll
@@ -398,10 +436,10 @@ struct TileSolver32
       un += u[a] * u[a];
     }
     const float unorm = (M == 1) ? fabsf(u[0]) : sqrtf(un);
-    put4(r + kOffInvU, recipFast(unorm + 1.0f), 0.0f, 0.0f, 0.0f);
+    r[kOffInvU] = recipFast(unorm + 1.0f);
   }
 
-  /** [Vxx | Vx] of the terminal cost (:177-185, :346-365) in the F region of rec(T & 1, slot). */
+  /** [Vxx | Vx] of the terminal cost (:177-185, :346-365) -> term(slot). */
   NMPC_D void lineariseTerminal(int slot, int b, int sel, float t0) const
   {
     const size_t tile = static_cast<size_t>(b) / 64, ln = static_cast<size_t>(b) % 64;
@@ -415,7 +453,7 @@ struct TileSolver32
       xT[c] = Xn[(static_cast<size_t>(T) * N + c) * 64];
     }
     problem.calcTerminalCostDeriv(t0 + T * problem.dt(), xT, vx, vxx);
-    float * r = rec(T & 1, slot);
+    float * r = term(slot);
 #pragma unroll
     for(int c = 0; c <= N; c++)
     {
@@ -428,7 +466,7 @@ struct TileSolver32
         {
           v[k] = (c < N) ? vxx(r4 + k, c < N ? c : 0) : vx[r4 + k];
         }
-        put4(r + kOffF + c * N + r4, v[0], v[1], v[2], v[3]);
+        put4(r + c * N + r4, v[0], v[1], v[2], v[3]);
       }
     }
   }
@@ -502,24 +540,74 @@ struct TileSolver32
     }
   }
 
-  /** \param store_gains the slot takes part in this sweep */
+  /** Row broadcasts of the M x M block at rows / columns n .. n+m-1 of Q (and of Q_reg, reg_type 2) and of Qu. */
   template<int kRegType>
-  NMPC_D void backwardStep(BwState & st, int slot, int b, int i, float lambda, bool store_gains) const
+  NMPC_D static void bcastBlock(v4f Q, v4f Qr, float qrow, float lambda, std::integral_constant<int, kRegType>, float * Quu,
+                                float * QuuF, float * Qu)
+  {
+    bcastColumn<0, kRegType>(Q, Qr, qrow, lambda, Quu, QuuF, Qu);
+  }
+  template<int C, int kRegType>
+  NMPC_D static void bcastColumn(v4f Q, v4f Qr, float qrow, float lambda, float * Quu, float * QuuF, float * Qu)
+  {
+    if constexpr(C < MM)
+    {
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        Quu[a + C * MM] = rowBcast<N + C>(Q[a]);
+        QuuF[a + C * MM] = (kRegType == 2) ? rowBcast<N + C>(Qr[a]) : Quu[a + C * MM];
+      }
+      if(kRegType == 1)
+      {
+        QuuF[C + C * MM] += lambda;
+      }
+      Qu[C] = rowBcast<N + C>(qrow);
+      bcastColumn<C + 1, kRegType>(Q, Qr, qrow, lambda, Quu, QuuF, Qu);
+    }
+  }
+  NMPC_D static void bcastK(v4f A, float * kff)
+  {
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      kff[a] = rowBcast<N>(A[a]);
+    }
+  }
+
+  // The backward timestep of one instance in three branch-free stages.  The instances of a matrix wave run them staggered
+  // (software pipeline, see backwardSweepMatrix): while one instance is in the matrix-core heavy stage 1 or 3, another is in
+  // the VALU-only stage 2 (factorisation, substitutions) — its instructions fill the gaps between the other's MFMAs.
+  struct Stage1Out
+  {
+    v4f Q, Qr; //!< [[Qxx Qxu],[Qux Quu]] unregularised / with Vxx + lambda I (reg_type 2; else the same registers)
+    float qrow; //!< lane group qK: [Qx; Qu]_j
+    float inv_u; //!< 1 / (|u_i| + 1)
+  };
+  struct Stage2Out
+  {
+    v4f A; //!< [[I 0],[K k]]
+    v4f qcol; //!< [Qx; Qu] as column n of the accumulator of H
+  };
+
+  /** Stage 1: the record's operands, G = VV^T F, Q = F^T G + L (8 MFMAs; 12 with reg_type 2)    :386-441 */
+  template<int kRegType>
+  NMPC_D Stage1Out stage1(const BwState & st, int slot, int i, float lambda) const
   {
     const int q = lane >> 4, j = lane & 15;
     const float * r = rec(i & 1, slot);
     const v4f zero4 = {0, 0, 0, 0};
-    // operands of this timestep: rows >= n of F read the record's zero slot
-    const v4f F = *reinterpret_cast<const v4f *>(r + ((4 * q < N) ? kOffF + j * N + 4 * q : kOffZero));
-    const v4f L = *reinterpret_cast<const v4f *>(r + kOffL + j * 16 + 4 * q);
+    // rows >= n of F read the zeros behind the wave's transposition scratch
+    const v4f F = *reinterpret_cast<const v4f *>((4 * q < N) ? r + kOffF + j * N + 4 * q : lds + kTrAt + wave * kTrFloats + 16 * kTrLd);
+    // (the four-row groups of column j are rotated by j / 4: the 16 lanes of a group then read 16 different bank quadruples)
+    const v4f L = *reinterpret_cast<const v4f *>(r + kOffL + j * 16 + 4 * ((q + (j >> 2)) & 3));
     const float lv = r[kOffLv + j];
-    const float inv_u = r[kOffInvU];
-    // ---- Q terms    :386-408
+    Stage1Out o;
+    o.inv_u = r[kOffInvU];
     const v4f G = mma(st.VV, F, zero4);
-    const v4f Q = mma(F, G, L);
-    const float qrow = lv + G[0]; // lane group qK: q_j = l_j + (Vx^T F)_j  — row n of G is register 0 there (n % 4 == 0)
-    // ---- regularisation    :421-441
-    v4f Qr = Q;
+    o.Q = mma(F, G, L);
+    o.qrow = lv + G[0]; // lane group qK: q_j = l_j + (Vx^T F)_j  — row n of G is register 0 there (n % 4 == 0)
+    o.Qr = o.Q;
     if constexpr(kRegType == 2)
     {
       v4f G2;
@@ -528,50 +616,43 @@ struct TileSolver32
       {
         G2[rr] = (4 * q + rr < N) ? G[rr] + lambda * F[rr] : 0.0f; // (Vxx + lambda I) F, without the Vx row
       }
-      Qr = mma(F, G2, L);
+      o.Qr = mma(F, G2, L);
     }
-    // Quu (unregularised), Quu_F and Qu to every lane: columns n .. n+m-1 of rows n .. n+m-1 sit in lanes 16 qK + n + c
+    return o;
+  }
+
+  /** Stage 2: gains (:500-517), dV (:522-523), |k| / (|u| + 1) (:217-221) — VALU only. */
+  template<int kRegType>
+  NMPC_D Stage2Out stage2(BwState & st, const Stage1Out & in, int slot, float lambda) const
+  {
+    const int q = lane >> 4, j = lane & 15;
+    // q as a column (lane (q', n) register r <- q[4 q' + r]) through the slot's LDS scratch, written now and read at the end
+    // of the stage (one wave's LDS traffic is ordered); lanes outside group qK write to a dump behind the scratch: no branch
+    float * scratch = lds + kScratchAt + slot * 16;
+    lds[kScratchAt + ((q == qK) ? slot * 16 + j : kTileInstances * 16 + j)] = in.qrow;
+    // Quu (unregularised), Quu_F and Qu in every lane of lane group qK: entry (a, c) is register a of lane n + c of that row
     float Quu[MM * MM], QuuF[MM * MM], Qu[MM], inv_d[MM];
-#pragma unroll
-    for(int c = 0; c < MM; c++)
-    {
-#pragma unroll
-      for(int a = 0; a < MM; a++)
-      {
-        Quu[a + c * MM] = readLane(Q[a], 16 * qK + N + c);
-        QuuF[a + c * MM] = (kRegType == 2) ? readLane(Qr[a], 16 * qK + N + c) : Quu[a + c * MM];
-      }
-      if(kRegType == 1)
-      {
-        QuuF[c + c * MM] += lambda;
-      }
-      Qu[c] = readLane(qrow, 16 * qK + N + c);
-    }
-    // ---- gains    :500-517: every lane factorises Quu_F; lane (qK, j) solves column j of [Qux_reg | Qu]
+    bcastBlock(in.Q, in.Qr, in.qrow, lambda, std::integral_constant<int, kRegType>(), Quu, QuuF, Qu);
+    // every lane of the group factorises Quu_F; lane (qK, j) solves column j of [Qux_reg | Qu]
     const bool ok_now = ldlt(QuuF, inv_d);
-    st.ok = st.ok && ok_now; // wave-uniform; after a failure the slot keeps computing on garbage and stores nothing
+    st.ok = st.ok && ok_now; // (per lane, valid in lane group qK; after a failure the slot computes on garbage and stores nothing)
     float col[MM];
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
-      col[a] = (j == N) ? Qu[a] : Qr[a];
+      col[a] = (j == N) ? Qu[a] : in.Qr[a];
     }
     ldltSolve(QuuF, inv_d, col);
-    v4f A; // [[I 0],[K k]]
+    Stage2Out o;
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
       const float gain = (rr < MM && j <= N) ? -1.0f * col[rr < MM ? rr : 0] : 0.0f;
       const float ident = (4 * q + rr == j && j < N) ? 1.0f : 0.0f;
-      A[rr] = (q == qK) ? gain : ident;
+      o.A[rr] = (q == qK) ? gain : ident;
     }
     float kff[MM];
-#pragma unroll
-    for(int a = 0; a < MM; a++)
-    {
-      kff[a] = readLane(A[a], 16 * qK + N);
-    }
-    // ---- dV += [k.Qu, 0.5 k.(Quu k)], |k| / (|u| + 1)    :217-221, :522-523
+    bcastK(o.A, kff);
     {
       float kQu = 0, kQuuk = 0, kn = 0;
 #pragma unroll
@@ -590,34 +671,45 @@ struct TileSolver32
       st.dV0 += kQu;
       st.dV1 += 0.5f * kQuuk;
       const float knorm = (M == 1) ? fabsf(kff[0]) : sqrtf(kn);
-      st.krel = fmaxf(st.krel, knorm * inv_u);
+      st.krel = fmaxf(st.krel, knorm * in.inv_u);
     }
-    // ---- cost-to-go    :524-527
-    // q as a column (lane (q', n) register r <- q[4 q' + r]): through this wave's LDS scratch (one wave's LDS traffic is ordered)
-    float * scratch = lds + kScratchAt + slot * 16;
-    if(q == qK)
-    {
-      scratch[j] = qrow;
-    }
-    asm volatile("" ::: "memory");
-    v4f qcol = *reinterpret_cast<const v4f *>(scratch + 4 * q);
-    asm volatile("" ::: "memory");
+    // (lanes outside column n read the zeros behind the wave's transposition scratch)
+    o.qcol = *reinterpret_cast<const v4f *>((j == N) ? scratch + 4 * q : lds + kTrAt + wave * kTrFloats + 16 * kTrLd);
+    return o;
+  }
+
+  /** Stage 3: H = Q A + [0 | q], VV' = A^T H (8 MFMAs); Vxx <- (Vxx + Vxx^T) / 2 with the transpose taken through the wave's
+      LDS scratch (four row writes, one 16-byte read per lane)    :524-527 */
+  NMPC_D void stage3(BwState & st, const Stage1Out & s1, const Stage2Out & s2) const
+  {
+    const int q = lane >> 4, j = lane & 15;
+    const v4f zero4 = {0, 0, 0, 0};
+    const v4f H = mma(s1.Q, s2.A, s2.qcol);
+    const v4f Vn = mma(s2.A, H, zero4); // rows < n: [Vxx' | Vx']; row n: garbage (column n of A is [0; k]); the rest: zero
+    float * tr = lds + kTrAt + wave * kTrFloats;
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
-      qcol[rr] = (j == N) ? qcol[rr] : 0.0f;
+      tr[(4 * q + rr) * kTrLd + j] = Vn[rr];
     }
-    const v4f H = mma(Q, A, qcol);
-    const v4f Vn = mma(A, H, zero4);
-    const v4f Vt = mma(H, A, zero4);
+    // lane (q, j) takes Vn[j][4 q .. 4 q + 3]; lanes outside the n x n block read zeros
+    const v4f Vt = *reinterpret_cast<const v4f *>(tr + ((4 * q < N && j < N) ? j * kTrLd + 4 * q : 16 * kTrLd));
+    // weights per lane: (1/2, 1/2) inside the n x n block, (1, 0) in column n (Vx), (0, 0) elsewhere — exact
+    const float wn = (4 * q < N) ? ((j < N) ? 0.5f : ((j == N) ? 1.0f : 0.0f)) : 0.0f;
+    const float wt = (4 * q < N && j < N) ? 0.5f : 0.0f;
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
-      const float sym = (j < N) ? 0.5f * (Vn[rr] + Vt[rr]) : Vn[rr]; // column n is Vx
-      st.VV[rr] = (4 * q + rr < N && j <= N) ? sym : 0.0f;
+      st.VV[rr] = wn * Vn[rr] + wt * Vt[rr];
     }
-    // ---- save gains    :529-530 (not after a failed factorisation: backwardPass() returned before, :505-508)
-    if(store_gains && st.ok && q == qK && j <= N)
+  }
+
+  /** k_i, K_i -> the instance's gain record (:529-530); not after a failed factorisation: backwardPass() returned before
+      storing (:505-508). */
+  NMPC_D void storeGains(v4f A, int b, int i, bool ok) const
+  {
+    const int q = lane >> 4, j = lane & 15;
+    if(q == qK && j <= N && ok)
     {
       float * g = gainRecord(b, i) + ((j < N) ? MM + MM * j : 0);
       if constexpr(MM == 4)
@@ -635,48 +727,161 @@ struct TileSolver32
     }
   }
 
-  /** The sweep of the seven matrix waves (barriers are shared with the model wave's loop in solve()). */
-  template<int kRegType>
+  /** The sweep of the matrix waves (barriers are shared with the model wave's loop in solve()).  COUNT = instances of this
+      wave, a template parameter: the stages of a timestep are branch-free and the instances are staggered by one stage —
+      in every slot of the loop body one instance is in stage 1, one in stage 2, one in stage 3 (COUNT = 3), three independent
+      pieces of straight-line code in one scheduling region:
+          slot 0:  S1_0(i)   S3_1(i+1)  S2_2(i+1)
+          slot 1:  S2_0(i)   S1_1(i)    S3_2(i+1)
+          slot 2:  S3_0(i)   S2_1(i)    S1_2(i)         barrier (record i has been read by all, record i - 1 is complete)
+      Only stage 1 reads the record.  Waves with two instances run the stages back to back (the compiler interleaves the two). */
+  template<int kRegType, int COUNT>
   NMPC_D void backwardSweepMatrix() const
   {
     const int q = lane >> 4, j = lane & 15;
-    const int first = tileWaveFirst(wave), count = tileWaveCount(wave);
-    BwState st[kTileMaxPerWave];
-    int bs[kTileMaxPerWave];
-    bool act[kTileMaxPerWave];
-    float lam[kTileMaxPerWave];
+    const int first = tileWaveFirst(wave);
+    BwState st[COUNT];
+    int bs[COUNT];
+    bool act[COUNT];
+    float lam[COUNT];
     barrier(); // the terminal record and the record of timestep T - 1 are complete
 #pragma unroll
-    for(int e = 0; e < kTileMaxPerWave; e++)
+    for(int e = 0; e < COUNT; e++)
     {
-      const int slot = first + (e < count ? e : 0);
+      const int slot = first + e;
       bs[e] = uniform(slotI(sB, slot));
-      act[e] = e < count && uniform(slotI(sBw, slot)) != 0;
+      act[e] = uniform(slotI(sBw, slot)) != 0;
       lam[e] = uniformF(slotF(sLambda, slot));
-      const float * r = rec(T & 1, slot);
-      st[e].VV = *reinterpret_cast<const v4f *>(r + ((4 * q < N && j <= N) ? kOffF + j * N + 4 * q : kOffZero));
+      st[e].VV = (4 * q < N && j <= N) ? *reinterpret_cast<const v4f *>(term(slot) + j * N + 4 * q) : v4f{0, 0, 0, 0};
       st[e].dV0 = 0;
       st[e].dV1 = 0;
       st[e].krel = 0;
       st[e].ok = true;
     }
-    barrier(); // the terminal record has been read: the model wave may overwrite its slot with timestep T - 2
-    for(int i = T - 1; i >= 0; i--)
+    barrier(); // the terminal record has been read
+    if constexpr(COUNT == 3)
     {
-#pragma unroll
-      for(int e = 0; e < kTileMaxPerWave; e++)
+      Stage1Out s1[3];
+      Stage2Out s2[3];
+      // instance e finishes timestep i + 1 (stages 2 / 3) while the earlier instances start timestep i
+      auto body = [&](int i, auto first_step)
       {
-        if(e < count) // wave-uniform
+        constexpr bool kFirst = decltype(first_step)::value;
+        // (the gains are stored after the three slots: the conditional stores would otherwise cut the scheduling region)
+        v4f A1 = {0, 0, 0, 0}, A2 = {0, 0, 0, 0};
+        bool ok1 = false, ok2 = false;
+        // slot 0
+        if constexpr(!kFirst)
         {
-          backwardStep<kRegType>(st[e], first + e, bs[e], i, lam[e], act[e]);
+          stage3(st[1], s1[1], s2[1]);
+          A1 = s2[1].A;
+          ok1 = st[1].ok;
+          s2[2] = stage2<kRegType>(st[2], s1[2], first + 2, lam[2]);
         }
-      }
+        s1[0] = stage1<kRegType>(st[0], first + 0, i, lam[0]);
+        // slot 1
+        if constexpr(!kFirst)
+        {
+          stage3(st[2], s1[2], s2[2]);
+          A2 = s2[2].A;
+          ok2 = st[2].ok;
+        }
+        s2[0] = stage2<kRegType>(st[0], s1[0], first + 0, lam[0]);
+        s1[1] = stage1<kRegType>(st[1], first + 1, i, lam[1]);
+        // slot 2
+        stage3(st[0], s1[0], s2[0]);
+        s2[1] = stage2<kRegType>(st[1], s1[1], first + 1, lam[1]);
+        s1[2] = stage1<kRegType>(st[2], first + 2, i, lam[2]);
+        if constexpr(!kFirst)
+        {
+          if(act[1])
+          {
+            storeGains(A1, bs[1], i + 1, ok1);
+          }
+          if(act[2])
+          {
+            storeGains(A2, bs[2], i + 1, ok2);
+          }
+        }
+        if(act[0])
+        {
+          storeGains(s2[0].A, bs[0], i, st[0].ok);
+        }
+      };
+      body(T - 1, std::true_type());
       barrier();
+      for(int i = T - 2; i >= 0; i--)
+      {
+#ifdef NMPC_AMD_PROFILE_TILE32
+        const unsigned long long p0 = __builtin_readcyclecounter();
+#endif
+        body(i, std::false_type());
+#ifdef NMPC_AMD_PROFILE_TILE32
+        if(blockIdx.x == 0 && lane == 0)
+        {
+          buf.qp_free[static_cast<size_t>(8 + wave) * 64] += static_cast<unsigned>((__builtin_readcyclecounter() - p0) >> 4);
+        }
+#endif
+        barrier();
+      }
+      // drain: instances 1 and 2 finish timestep 0
+      stage3(st[1], s1[1], s2[1]);
+      if(act[1])
+      {
+        storeGains(s2[1].A, bs[1], 0, st[1].ok);
+      }
+      s2[2] = stage2<kRegType>(st[2], s1[2], first + 2, lam[2]);
+      stage3(st[2], s1[2], s2[2]);
+      if(act[2])
+      {
+        storeGains(s2[2].A, bs[2], 0, st[2].ok);
+      }
     }
-    if(lane == 0)
+    else
+    {
+      for(int i = T - 1; i >= 0; i--)
+      {
+#ifdef NMPC_AMD_PROFILE_TILE32
+        const unsigned long long p0 = __builtin_readcyclecounter();
+#endif
+        Stage1Out s1[COUNT];
+        Stage2Out s2[COUNT];
+#pragma unroll
+        for(int e = 0; e < COUNT; e++)
+        {
+          s1[e] = stage1<kRegType>(st[e], first + e, i, lam[e]);
+        }
+#pragma unroll
+        for(int e = 0; e < COUNT; e++)
+        {
+          s2[e] = stage2<kRegType>(st[e], s1[e], first + e, lam[e]);
+        }
+#pragma unroll
+        for(int e = 0; e < COUNT; e++)
+        {
+          stage3(st[e], s1[e], s2[e]);
+        }
+#pragma unroll
+        for(int e = 0; e < COUNT; e++)
+        {
+          if(act[e]) // wave-uniform
+          {
+            storeGains(s2[e].A, bs[e], i, st[e].ok);
+          }
+        }
+#ifdef NMPC_AMD_PROFILE_TILE32
+        if(blockIdx.x == 0 && lane == 0)
+        {
+          buf.qp_free[static_cast<size_t>(8 + wave) * 64] += static_cast<unsigned>((__builtin_readcyclecounter() - p0) >> 4);
+        }
+#endif
+        barrier();
+      }
+    }
+    if(lane == 16 * qK) // (dV, |k| / (|u| + 1) and the pivot tests are per-lane values of lane group qK)
     {
 #pragma unroll
-      for(int e = 0; e < kTileMaxPerWave; e++)
+      for(int e = 0; e < COUNT; e++)
       {
         if(act[e])
         {
@@ -689,23 +894,54 @@ struct TileSolver32
       }
     }
   }
+  template<int kRegType>
+  NMPC_D void backwardSweepMatrixWave() const
+  {
+    if(tileWaveCount(wave) == kTileMinPerWave)
+    {
+      backwardSweepMatrix<kRegType, kTileMinPerWave>();
+    }
+    else
+    {
+      backwardSweepMatrix<kRegType, kTileMaxPerWave>();
+    }
+  }
 
-  /** The model wave's half of the sweep: timestep i - 1 is linearised while the matrix waves consume timestep i. */
+  /** The model wave's half of the sweep: timestep i - 1 is linearised while the matrix waves consume timestep i; its
+      (x, u) were requested one timestep earlier. */
   NMPC_D void backwardSweepModel(bool mine, int slot, int b, int sel, float t0) const
   {
+    Point cur, next;
     if(mine)
     {
+      loadPoint(cur, b, sel, T - 1);
+      loadPoint(next, b, sel, T > 1 ? T - 2 : 0);
       lineariseTerminal(slot, b, sel, t0);
-      lineariseStep(slot, b, sel, t0, T - 1);
+      lineariseStep<true>(slot, t0, T - 1, cur);
     }
-    barrier(); // records T (terminal) and T - 1 are complete
-    barrier(); // the matrix waves have taken the terminal record
+    barrier(); // the terminal record and the record of timestep T - 1 are complete
+    barrier(); // (the matrix waves have taken the terminal record)
     for(int i = T - 1; i >= 0; i--)
     {
+#ifdef NMPC_AMD_PROFILE_TILE32
+      const unsigned long long p0 = __builtin_readcyclecounter();
+#endif
       if(mine && i > 0)
       {
-        lineariseStep(slot, b, sel, t0, i - 1);
+        cur = next;
+        loadPoint(next, b, sel, i > 1 ? i - 2 : 0);
+        if(i == T - 1)
+        {
+          lineariseStep<true>(slot, t0, i - 1, cur); // the first use of this record slot in the sweep: every entry
+        }
+        else
+        {
+          lineariseStep<false>(slot, t0, i - 1, cur);
+        }
       }
+#ifdef NMPC_AMD_PROFILE_TILE32
+      prof_acc[7] += __builtin_readcyclecounter() - p0; // the model wave's own work inside the sweep
+#endif
       barrier();
     }
   }
@@ -727,6 +963,41 @@ struct TileSolver32
     }
   }
 
+#ifdef NMPC_AMD_PROFILE_TILE32
+  // profiling build (scripts/profile_tile32.py): shader-clock ticks per phase seen by the model wave of workgroup 0,
+  // returned through qp_free (unused by this kernel family): 0 initial rollout, 1 backward sweeps, 2 line search, 3 re-rolls,
+  // 4 sweeps run, 5 re-rolls run, 6 iteration rounds
+  mutable unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  mutable unsigned long long prof_t0 = 0;
+  NMPC_D void profBegin() const
+  {
+    prof_t0 = __builtin_readcyclecounter();
+  }
+  NMPC_D void profEnd(int k) const
+  {
+    prof_acc[k] += __builtin_readcyclecounter() - prof_t0;
+  }
+  NMPC_D void profCount(int k) const
+  {
+    prof_acc[k] += 1;
+  }
+  NMPC_D void profFlush() const
+  {
+    if(blockIdx.x == 0 && wave == kTileModelWave && lane == 0)
+    {
+      for(int k = 0; k < 8; k++)
+      {
+        buf.qp_free[static_cast<size_t>(k) * 64] = static_cast<unsigned>((k < 4 || k == 7) ? prof_acc[k] >> 4 : prof_acc[k]);
+      }
+    }
+  }
+#else
+  NMPC_D void profBegin() const {}
+  NMPC_D void profEnd(int) const {}
+  NMPC_D void profCount(int) const {}
+  NMPC_D void profFlush() const {}
+#endif
+
   NMPC_D void solve()
   {
     const bool model_wave = (wave == kTileModelWave);
@@ -746,11 +1017,10 @@ struct TileSolver32
     {
       tr[f] = 0;
     }
-    // ---- zero slots of the records, slot table
-    for(int e = static_cast<int>(threadIdx.x); e < 2 * kTileInstances; e += kTileThreads)
+    // ---- zero areas, slot table
+    for(int e = static_cast<int>(threadIdx.x); e < kTileWaves * 16; e += kTileThreads)
     {
-      float * r = lds + kRecAt + e * kRec;
-      put4(r + kOffZero, 0.0f, 0.0f, 0.0f, 0.0f);
+      lds[kTrAt + (e >> 4) * kTrFloats + 16 * kTrLd + (e & 15)] = 0.0f;
     }
     if(model_wave && lane < kTileInstances)
     {
@@ -767,7 +1037,9 @@ struct TileSolver32
     }
     if(model_wave)
     {
+      profBegin();
       J_cur = rollout(owner, b, 0, 0, t0, 0.0f, true, true);
+      profEnd(0);
       if(owner)
       {
         tr[NMPC_HIP_TRACE_COST] = J_cur;
@@ -822,25 +1094,29 @@ struct TileSolver32
       }
       // ---- Steps 1 + 2: linearisation fused into the backward sweep, with the regularisation retries    :157-214
       bool need_bw = in_iter;
+      profCount(6);
       for(;;)
       {
+        profBegin();
+        profCount(4);
         if(model_wave)
         {
           backwardSweepModel(need_bw && lane < kTileInstances, slot, b, sel, t0);
         }
         else if(cfg.reg_type == 2)
         {
-          backwardSweepMatrix<2>();
+          backwardSweepMatrixWave<2>();
         }
         else if(cfg.reg_type == 1)
         {
-          backwardSweepMatrix<1>();
+          backwardSweepMatrixWave<1>();
         }
         else
         {
-          backwardSweepMatrix<0>();
+          backwardSweepMatrixWave<0>();
         }
         barrier(); // results of the sweep are in the slot table
+        profEnd(1);
         if(model_wave)
         {
           bool retry = false;
@@ -920,6 +1196,7 @@ struct TileSolver32
       if(uniform(flag(2)) != 0)
       {
         float J_first = 0;
+        profBegin();
         if(model_wave)
         {
           J_first = rollout(in_ls, b, sel, sel ^ 1, t0, static_cast<float>(cfg.alpha_list[0]), false, true);
@@ -941,6 +1218,7 @@ struct TileSolver32
           }
         }
         barrier();
+        profEnd(2);
         if(model_wave)
         {
           int ai_taken = cfg.n_alpha - 1;
@@ -972,7 +1250,10 @@ struct TileSolver32
           const bool reroll = in_ls && success && ai_taken > 0;
           if(__ballot(reroll) != 0)
           {
+            profBegin();
+            profCount(5);
             const float Jr = rollout(reroll, b, sel, sel ^ 1, t0, alpha, false, true);
+            profEnd(3);
             if(reroll)
             {
               J_cand = Jr; // (the same instruction stream on the same inputs: the same value)
@@ -1030,6 +1311,7 @@ struct TileSolver32
       }
     }
 
+    profFlush();
     // ---- results the host reads per instance
     if(owner)
     {
@@ -1052,7 +1334,7 @@ struct TileSolver32
   }
 };
 
-/** The fp32 tile kernel: grid = ceil(B / 32) workgroups of eight wavefronts. */
+/** The fp32 tile kernel: grid = ceil(B / 32) workgroups of sixteen wavefronts. */
 template<class Problem>
 __global__ __launch_bounds__(kTileThreads) void ddp_solve_tile32_kernel(const Problem problem,
                                                                         const nmpc_hip_ddp_config cfg,

@@ -1,0 +1,284 @@
+"""BASELINE.json config 4 as specified — quadrotor (nx 12, nu 4, T 50) in fp32 on the fp32 tile kernel
+(include/nmpc_amd/hip/ddp_kernels_tile32.hpp) — against the CPU oracle instantiated in float (namespace oracle_f32,
+oracle/ddp_oracle.hpp compiled with Real = float).
+
+Bar (SURVEY.md §8 c, fp32 config): X, U within 1e-3 relative, total cost within 1e-4 relative, discrete decisions (status,
+iteration count, step-size index of every iteration, backward / forward pass counts) EXACT on the margin-filtered set.
+The margin filter is the oracle's own decision stability at fp32 resolution: an instance is kept iff the fp32 oracle takes
+the same decisions when x0 is perturbed by a few float ulps.  Every masked comparison asserts a floor on the kept fraction
+and checks the dropped instances for the same optimum.
+"""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL_XU = 1e-3
+TOL_COST = 1e-4
+INT_COLS = (0, 9, 10, 11)
+#: a termination threshold fp32 can resolve (cost ~ 10, eps ~ 1e-7): with the reference's default 1e-7 the float algorithm
+#: keeps iterating on rounding noise and rejects steps at random
+FP32_COST_UPDATE_THRE = 1e-4
+
+
+def make(wl, **cfg):
+    import nmpc_amd
+
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model, **wl.params), wl.B)
+    c = s.config()
+    c.print_level = 0
+    c.horizon_steps = wl.T
+    for k, v in cfg.items():
+        setattr(c, k, v)
+    return s
+
+
+def ocfg_of(wl, **cfg):
+    return oracle.default_config(horizon_steps=wl.T, **{k: (list(v) if k == "alpha_list" else v) for k, v in cfg.items()})
+
+
+def oracle_f32(wl, x0=None, **cfg):
+    params = oracle.default_params(wl.model, **wl.params) if wl.params else None
+    return oracle.solve_batch(wl.model, ocfg_of(wl, **cfg), wl.x0 if x0 is None else x0, wl.u_init, t0=wl.t0, params=params,
+                              n_threads=8, want_alpha_hist=True)
+
+
+def margin_mask(wl, ref, **cfg):
+    """Instances whose decisions the fp32 oracle keeps under perturbations of x0 by 1 .. 8 float ulps."""
+    rng = np.random.default_rng(2024)
+    keep = np.ones(wl.B, bool)
+    for ulps in (1, 1, 2, 2, 4, 8):
+        x0p = wl.x0 * (1 + ulps * 2.0 ** -24 * rng.uniform(-1, 1, wl.x0.shape))
+        r = oracle_f32(wl, x0=x0p, **cfg)
+        keep &= (r.iters == ref.iters) & (r.status == ref.status) & (r.alpha_idx_hist == ref.alpha_idx_hist).all(axis=1)
+        keep &= np.all(r.trace_last[:, INT_COLS] == ref.trace_last[:, INT_COLS], axis=1)
+    return keep
+
+
+def rel(got, want):
+    return np.abs(got - want) / (1.0 + np.abs(want))
+
+
+def check(wl, s, ref, mask, floor, label):
+    frac = float(mask.mean())
+    print(f"[{label}] margin-filtered set: {int(mask.sum())} / {wl.B} instances ({frac:.3f}); floor {floor}")
+    assert frac >= floor, f"{label}: only {frac:.3f} of the instances are decision-stable in the fp32 oracle itself"
+    mk = mask
+    np.testing.assert_array_equal(s.status()[mk], ref.status[mk])
+    np.testing.assert_array_equal(s.iters()[mk], ref.iters[mk])
+    tr = s.trace()
+    hist = np.full_like(ref.alpha_idx_hist, -2)
+    for b in range(wl.B):
+        n = min(int(ref.iters[b]), int(s.iters()[b]))
+        hist[b, :n] = tr[b, 1:n + 1, 9].astype(np.int32)
+    np.testing.assert_array_equal(hist[mk], ref.alpha_idx_hist[mk])
+    np.testing.assert_array_equal(s.traceLast()[mk][:, INT_COLS], ref.trace_last[mk][:, INT_COLS])
+    ex, eu = rel(s.X(), ref.X).reshape(wl.B, -1).max(1), rel(s.U(), ref.U).reshape(wl.B, -1).max(1)
+    Jg, Jr = s.cost().sum(axis=1), ref.cost.sum(axis=1)
+    ej = np.abs(Jg - Jr) / np.abs(Jr)
+    print(f"[{label}] kept set: max X err {ex[mk].max():.2e}, U {eu[mk].max():.2e}, cost {ej[mk].max():.2e}")
+    assert ex[mk].max() <= TOL_XU and eu[mk].max() <= TOL_XU
+    assert ej[mk].max() <= TOL_COST
+    ok = mk & (ref.status >= 0)
+    if ok.any():
+        assert rel(s.kff()[ok], ref.k[ok]).max() <= 10 * TOL_XU
+        assert rel(s.Kfb()[ok], ref.K[ok]).max() <= 10 * TOL_XU
+    # the dropped instances: decisions may differ (the oracle's own do, a few ulps away), the optimum may not
+    if (~mk).any():
+        print(f"[{label}] dropped set: max cost err {ej[~mk].max():.2e}")
+        assert ej[~mk].max() <= 50 * TOL_COST
+
+
+def test_reports_fp32():
+    import nmpc_amd
+
+    assert nmpc_amd.make_problem("quadrotor_f32").scalar_bytes() == 4
+    assert nmpc_amd.make_problem("quadrotor").scalar_bytes() == 8
+
+
+def test_c4_first_iterations_ragged_batch():
+    """Default Configuration, the first four iterations (before fp32 rounding noise decides anything), 500 instances =
+    15 full workgroups of 32 + one of 20."""
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=500, T=50, seed=7, fp32=True)
+    s = make(wl, max_iter=4)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert s.kernelName() == "ddp_solve_tile32_kernel"
+    ref = oracle_f32(wl, max_iter=4)
+    check(wl, s, ref, margin_mask(wl, ref, max_iter=4), 0.93, "c4 4 iterations")  # the oracle keeps 0.946
+
+
+def test_c4_to_convergence_with_fp32_tolerance():
+    """Solve to convergence with a cost_update_thre float arithmetic can resolve: every instance converges."""
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=384, T=50, seed=11, fp32=True)
+    cfg = dict(max_iter=60, cost_update_thre=FP32_COST_UPDATE_THRE)
+    s = make(wl, **cfg)
+    ok = s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_f32(wl, **cfg)
+    assert (ref.status == 1).mean() > 0.99 and ok.mean() > 0.99
+    check(wl, s, ref, margin_mask(wl, ref, **cfg), 0.95, "c4 converged")  # the oracle keeps 0.974
+
+
+def test_c4_default_configuration_noise_regime_reaches_the_same_optimum():
+    """The reference's default thresholds in fp32: once the cost decrease is below the resolution of a float the accept test
+    (DDPSolver.hpp:251-264) is decided by rounding noise — in the fp32 ORACLE as well; most instances leave the
+    margin-filtered set.  What must hold for all of them: the same optimum."""
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=256, T=50, seed=3, fp32=True)
+    s = make(wl, max_iter=8)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_f32(wl, max_iter=8)
+    mask = margin_mask(wl, ref, max_iter=8)
+    check(wl, s, ref, mask, 0.30, "c4 default thresholds, 8 iterations")  # the oracle keeps 0.33
+    Jg, Jr = s.cost().sum(axis=1), ref.cost.sum(axis=1)
+    assert (np.abs(Jg - Jr) / np.abs(Jr)).max() <= 5e-4
+
+
+@pytest.mark.parametrize("B,T,max_iter", [(1, 50, 3), (31, 7, 2), (33, 2, 2), (64, 1, 1), (5, 3, 1), (96, 49, 3)])
+def test_shapes(B, T, max_iter):
+    """Batches that are not a multiple of 32, horizons of one and two timesteps, odd horizons.  (Short horizons converge in
+    one or two iterations; max_iter stops before the noise regime so that the whole batch stays in the kept set.)"""
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=B, T=T, seed=100 + B + T, fp32=True)
+    s = make(wl, max_iter=max_iter)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_f32(wl, max_iter=max_iter)
+    check(wl, s, ref, margin_mask(wl, ref, max_iter=max_iter), 0.95, f"B {B} T {T}")
+
+
+@pytest.mark.parametrize("cfg", [dict(reg_type=2), dict(reg_type=2, initial_lambda=1e-2),
+                                 dict(alpha_list=[1.0, 0.3, 0.1]),
+                                 dict(alpha_list=list(10.0 ** np.linspace(0, -3, 25))),  # 24 fan-out trials: two fan-out rounds
+                                 dict(initial_lambda=1.0, lambda_factor=2.5)])
+def test_configurations(cfg):
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=96, T=30, seed=21, fp32=True)
+    full = dict(max_iter=4, **cfg)
+    s = make(wl, **full)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_f32(wl, **full)
+    check(wl, s, ref, margin_mask(wl, ref, **full), 0.9, str(cfg)[:60])  # the oracle keeps 0.906 .. 1.0
+
+
+def test_line_search_failure_and_lambda_limit():
+    """No step size is ever accepted (ratio threshold 10): every iteration runs all 11 trials, lambda climbs past lambda_max
+    and the solve ends with status -1 (DDPSolver.hpp:318-328) in the same iteration as in the oracle."""
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=64, T=20, seed=5, fp32=True)
+    cfg = dict(max_iter=12, cost_update_ratio_thre=10.0, lambda_max=1.0)
+    s = make(wl, **cfg)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_f32(wl, **cfg)
+    assert (ref.status == -1).all()
+    np.testing.assert_array_equal(s.status(), ref.status)
+    np.testing.assert_array_equal(s.iters(), ref.iters)
+    np.testing.assert_array_equal(s.traceLast()[:, INT_COLS], ref.trace_last[:, INT_COLS])
+    # nothing was accepted: the trajectory is still the initial rollout
+    assert rel(s.X(), ref.X).max() <= 1e-5
+
+
+def test_backward_pass_retries():
+    """A negative input weight makes Quu indefinite: the factorisation fails, lambda is raised and the backward pass is
+    repeated (DDPSolver.hpp:188-214); the number of backward passes per iteration must match the oracle's."""
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=64, T=20, seed=9, fp32=True)
+    wl.params = dict(w_u=-0.05)
+    cfg = dict(max_iter=3)
+    s = make(wl, **cfg)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_f32(wl, **cfg)
+    assert ref.trace_last[:, 10].max() > 1 or (ref.status == -1).any(), "the case does not exercise the retry path"
+    mask = margin_mask(wl, ref, **cfg)
+    assert mask.mean() >= 0.8
+    np.testing.assert_array_equal(s.status()[mask], ref.status[mask])
+    np.testing.assert_array_equal(s.iters()[mask], ref.iters[mask])
+    tr = s.trace()
+    for b in np.flatnonzero(mask)[:16]:
+        r1 = oracle.solve(wl.model, ocfg_of(wl, **cfg), wl.x0[b], wl.u_init[b], params=oracle.default_params(wl.model, **wl.params))
+        n = r1.iters
+        np.testing.assert_array_equal(tr[b, 1:n + 1, 10], r1.trace[1:n + 1, 10])  # n_backward of every iteration
+
+
+def test_max_iter_zero_is_the_initial_rollout():
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=40, T=50, seed=2, fp32=True)
+    s = make(wl, max_iter=0)
+    ok = s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_f32(wl, max_iter=0)
+    assert not ok.any() and (s.iters() == 0).all()
+    assert rel(s.X(), ref.X).max() <= 1e-5 and rel(s.cost(), ref.cost).max() <= 1e-5
+    np.testing.assert_allclose(s.U(), wl.u_init.astype(np.float32), rtol=0, atol=0)
+
+
+def test_deterministic_and_handle_reuse():
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=200, T=50, seed=13, fp32=True)
+    s = make(wl, max_iter=6)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    X1, U1, it1, tr1 = s.X().copy(), s.U().copy(), s.iters().copy(), s.trace().copy()
+    wl2 = workloads.quadrotor_batch(B=200, T=50, seed=14, fp32=True)
+    s.solve(wl2.t0, wl2.x0, wl2.u_init)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    np.testing.assert_array_equal(s.X(), X1)
+    np.testing.assert_array_equal(s.U(), U1)
+    np.testing.assert_array_equal(s.iters(), it1)
+    np.testing.assert_array_equal(s.trace(), tr1)
+    # rows beyond the last iteration of an instance are zero (traceDataList() ends there)
+    tr = s.trace()
+    for b in range(wl.B):
+        assert not tr[b, int(it1[b]) + 1:].any()
+
+
+def test_unsupported_combinations_fail_loudly():
+    """The fp32 tile kernel serves unconstrained solves with one shared problem object; everything else raises instead of
+    silently running something different."""
+    import nmpc_amd
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=32, T=10, seed=1, fp32=True)
+    s = make(wl, max_iter=2, with_input_constraint=True)
+    s.setInputLimits(np.full(4, 1.0), np.full(4, 4.0))
+    with pytest.raises(RuntimeError):
+        s.solve(wl.t0, wl.x0, wl.u_init)
+    s2 = make(wl, max_iter=2)
+    with pytest.raises(RuntimeError):
+        s2.mpcRun(wl.t0, wl.x0, wl.u_init, n_ticks=2)
+    assert nmpc_amd.make_problem("quadrotor_f32").dims()[:2] == (12, 4)
+
+
+def test_full_size_c4_properties():
+    """BASELINE.json's size (8192 instances): size-independent properties instead of an oracle run — costs decrease
+    monotonically over accepted iterations, the stored trajectory is a rollout of the stored inputs (re-simulated by the fp32
+    oracle's model), and two solves agree bit for bit."""
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=8192, T=50, seed=1234, fp32=True)
+    s = make(wl, max_iter=8)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    X, U, tr, it = s.X(), s.U(), s.trace(), s.iters()
+    assert np.isfinite(X).all() and np.isfinite(U).all()
+    cost = tr[:, :, 1]
+    for b in range(0, wl.B, 37):
+        c = cost[b, :it[b] + 1]
+        c = c[c != 0]  # rows of iterations that terminated before the line search carry no cost
+        assert np.all(np.diff(c) <= 1e-5 * np.abs(c[:-1]))
+    # x_{i+1} = stateEq(x_i, u_i) along the stored solution, checked with the oracle's float model on a sample
+    for b in range(0, wl.B, 911):
+        for i in (0, 17, 49):
+            ev = oracle.model_eval(wl.model, None, 0.0, X[b, i], U[b, i])
+            assert rel(ev.xn, X[b, i + 1]).max() <= 2e-6
+    X1 = X.copy()
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    np.testing.assert_array_equal(s.X(), X1)

@@ -16,6 +16,10 @@ resident in HBM.  value = n_gpus * K * (executed instance-iterations per solve /
 wall time between two barrier + device-synchronise brackets.  Weak scaling: every rank owns its own 4096 instances; the
 only collective is ONE all_gather of the final trajectories (RCCL over xGMI) at the end of the timed job.
 
+After the timed job the default (c2, nominal) run also measures SURVEY.md 8(d)'s two timing modes with the same handle —
+m1 (termination tests disabled, N = 50 iterations forced) and m2 (solve to convergence, max_iter 500) — and reports them as
+config.m1_value / config.m2_value (batch-iterations/s): outside the timed region, a few solves each.
+
 The JSON line also carries
   roofline     HBM-roofline accounting of the solve kernel: algorithmic bytes (SURVEY.md §8 d formula with the
                measured backward / forward pass counts) / HIP-event kernel time measured on the launch stream;
@@ -44,6 +48,9 @@ LANE_MAPPINGS = {
     "ddp_solve_tpi2w_kernel": "one lane per instance, 64 instances per workgroup, master + helper wavefront",
     "ddp_solve_tpi_kernel": "one lane per instance, 64 instances per single-wavefront workgroup",
     "ddp_solve_wpi_kernel": "one wavefront per instance: lane = timestep / matrix entry (v_mfma_f64_16x16x4) / step size",
+    "ddp_solve_tile32_kernel": "fp32 tile: 32 instances per workgroup of 12 wavefronts; model code one lane per instance "
+                               "(linearisation into LDS records, rollouts; every step size of the line search at once on the "
+                               "other wavefronts), backward pass one 16x16 augmented block per instance on v_mfma_f32_16x16x4",
 }
 
 
@@ -56,8 +63,11 @@ WORKLOADS = {
            "C3 bipedal CoM-ZMP: nx=2, nu=1, T=%d, batch=%d per GPU, fp64, t0~U[0,17] s on the reference's ref_zmp / "
            "omega^2 schedule, splitmix64 seed %d, u_init=0"),
     "c4": ("quadrotor_batch", 8192, 50,
-           "C4-shape quadrotor: nx=12, nu=4, T=%d, batch=%d per GPU, fp64 (BASELINE names fp32), hover-perturbed x0 "
+           "C4 quadrotor: nx=12, nu=4, T=%d, batch=%d per GPU, fp32 (problem type quadrotor_f32), hover-perturbed x0 "
            "splitmix64 seed %d, u_init=hover"),
+    "c4f64": ("quadrotor_batch", 8192, 50,
+              "C4-shape quadrotor in the reference's arithmetic: nx=12, nu=4, T=%d, batch=%d per GPU, fp64, hover-perturbed "
+              "x0 splitmix64 seed %d, u_init=hover"),
     "c5": ("manipulator_batch", 8192, 30,
            "C5-shape manipulator: nx=14, nu=7, T=%d, batch=%d per GPU (65536 over 8 GPUs), fp64, splitmix64 seed %d"),
 }
@@ -66,8 +76,8 @@ WORKLOADS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 (default) is BASELINE.json's metric configuration; c3 / c4 / c5 are the other configs "
                          "(parity-test cases) measured with the same harness")
@@ -79,6 +89,10 @@ def parse_args():
                          "timing modes of SURVEY.md 8(d): m1 = termination tests disabled (k_rel_norm_thre = 0, "
                          "cost_update_thre = -inf), every instance executes exactly --iters-per-solve iterations unless "
                          "lambda exceeds lambda_max; m2 = solve to convergence with the reference defaults (max_iter 500)")
+    ap.add_argument("--cost-update-thre", type=float, default=None,
+                    help="override Configuration::cost_update_thre (the default 1e-7 is below the resolution of an fp32 cost: "
+                         "c4 also reports the rate with 1e-3 as config.fp32_tolerance_value)")
+    ap.add_argument("--no-extra-modes", action="store_true", help="skip the m1 / m2 (c2) and fp32-tolerance (c4) extra legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0,
                     help="sizing target of the CPU baseline sample (the sustained all-core rate is ~3x below the probe: ~20 s)")
@@ -86,21 +100,43 @@ def parse_args():
     return ap.parse_args()
 
 
-def mode_config(mode: str, iters_per_solve: int) -> dict:
+def mode_config(mode: str, iters_per_solve: int, cost_update_thre=None) -> dict:
     """Configuration overrides of the three timing modes (same for the GPU solver and the CPU oracle)."""
     if mode == "m1":
         return dict(max_iter=iters_per_solve, k_rel_norm_thre=0.0, cost_update_thre=-1e300)
-    if mode == "m2":
-        return dict(max_iter=500)
-    return dict(max_iter=iters_per_solve)
+    cfg = dict(max_iter=500 if mode == "m2" else iters_per_solve)
+    if cost_update_thre is not None:
+        cfg["cost_update_thre"] = cost_update_thre
+    return cfg
 
 
-def cpu_baseline(wl, mode: str, iters_per_solve: int, target_seconds: float):
-    """Time the CPU oracle (kind "port") on a bounded sample of the same workload, all host cores."""
+def host_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return n, quota
+
+
+def cpu_baseline(wl, mode: str, iters_per_solve: int, target_seconds: float, cost_update_thre=None):
+    """Time the CPU oracle (kind "port") on a bounded sample of the same workload: a thread sweep (1, 16, 64, all usable
+    cores; threads pinned, instances handed out dynamically), the best rate is the baseline."""
     import oracle
-    cores = os.cpu_count() or 1
+    affinity, quota = host_cores()
+    usable = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
     build_dir = tempfile.mkdtemp(prefix="oracle_native_")
-    cfg = oracle.default_config(horizon_steps=wl.T, **mode_config(mode, iters_per_solve))
+    cfg = oracle.default_config(horizon_steps=wl.T, **mode_config(mode, iters_per_solve, cost_update_thre))
 
     def run(nb, threads):
         # the sample is the workload's own instances, repeated cyclically when more than one batch is needed
@@ -109,23 +145,33 @@ def cpu_baseline(wl, mode: str, iters_per_solve: int, target_seconds: float):
                                want_gains=False, native=True, native_dir=build_dir)
         return r.total_iters, r.seconds
 
-    probe = 16 * cores
-    it, sec = run(probe, cores)
-    rate = it / max(sec, 1e-9)  # instance-iterations / s
-    nb = int(max(probe, rate * target_seconds / max(it / probe, 1.0)))  # iterations per solve as measured by the probe
-    it, sec = run(nb, cores)
-    nb1 = max(64, int(nb / cores / 4))
-    it1, sec1 = run(nb1, 1)
+    it1, sec1 = run(64, 1)  # probe: one core
+    rate1 = it1 / max(sec1, 1e-9)  # instance-iterations / s / core
+    per_solve = it1 / 64.0
+    sweep = {}
+    legs = sorted({1, min(16, usable), min(64, usable), usable})
+    budget = target_seconds / len(legs)
+    for th in legs:
+        guess = rate1 * th * (0.5 if th > 1 else 1.0)  # all-core rates are well below threads x one-core
+        nb = int(max(8 * th, 64, guess * budget / max(per_solve, 1.0)))
+        it, sec = run(nb, th)
+        sweep[th] = {"instance_iterations_per_s": it / sec, "solves": nb, "seconds": sec}
+    best = max(sweep, key=lambda k: sweep[k]["instance_iterations_per_s"])
     return {
-        "value": (it / sec) / wl.B,  # batch(4096)-iterations / s
+        "value": sweep[best]["instance_iterations_per_s"] / wl.B,  # batch-iterations / s
         "unit": "DDP iterations/s (batch=%d)" % wl.B,
-        "cores": cores,
+        "cores": best,
         "kind": "port",
-        "sample": "%d solves (the workload's %d instances, cycled), mode %s, max_iter %d: %d iterations, %d threads, %.1f s; "
-                  "1-core leg %d solves, %.1f s; oracle/ built -O3 -march=native"
-                  % (nb, wl.B, mode, cfg.max_iter, it, cores, sec, nb1, sec1),
-        "instance_iterations_per_s": it / sec,
-        "instance_iterations_per_s_1core": it1 / sec1,
+        "sample": "oracle/ (%s) built -O3 -march=native on this host; the workload's %d instances cycled, mode %s, max_iter %d; "
+                  "thread sweep %s, threads pinned, dynamic chunks; best: %d threads, %d solves in %.1f s.  Host: %d CPUs in the "
+                  "affinity mask, cgroup quota %s, os.cpu_count() %d"
+                  % (wl.model, wl.B, mode, cfg.max_iter, legs, best, sweep[best]["solves"], sweep[best]["seconds"], affinity,
+                     "none" if quota is None else "%.1f CPUs" % quota, os.cpu_count() or 0),
+        "instance_iterations_per_s": sweep[best]["instance_iterations_per_s"],
+        "instance_iterations_per_s_1core": sweep[1]["instance_iterations_per_s"],
+        "thread_sweep": {str(k): round(v["instance_iterations_per_s"], 1) for k, v in sweep.items()},
+        "host_cpus_affinity": affinity,
+        "host_cpu_quota": quota,
     }
 
 
@@ -140,25 +186,44 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    device_index = local_rank % n_dev  # (tests run two ranks on a one-GPU box: both on device 0)
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # RCCL needs one device per rank; two ranks sharing a GPU (the one-GPU test box) gather over gloo instead
+        backend = "nccl" if n_dev >= world else "gloo"
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
+    else:
+        backend = None
 
     import nmpc_amd
     from nmpc_amd import _capi, workloads
 
     # per-rank shard: rank r owns instances [r*B, (r+1)*B) of the global splitmix64 stream
     gen, wl_batch, wl_horizon, wl_text = WORKLOADS[args.workload]
-    wl = getattr(workloads, gen)(B=args.batch or wl_batch, T=args.horizon or wl_horizon, seed=args.seed + 7919 * rank)
-    solver = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B, device=local_rank)
-    cfg = solver.config()
-    cfg.print_level = 0
-    cfg.horizon_steps = wl.T
-    for key, val in mode_config(args.mode, args.iters_per_solve).items():
-        setattr(cfg, key, val)
-    cfg.trace_level = 1
+    gen_kw = dict(fp32=True) if args.workload == "c4" else {}
+    wl = getattr(workloads, gen)(B=args.batch or wl_batch, T=args.horizon or wl_horizon, seed=args.seed + 7919 * rank, **gen_kw)
+    problem = nmpc_amd.make_problem(wl.model)
+    elem = problem.scalar_bytes()
+    solver = nmpc_amd.DDPSolverBatch(problem, wl.B, device=device_index)
+
+    def configure(mode, iters, cost_update_thre=None):
+        cfg = solver.config()
+        dflt = nmpc_amd.Configuration()
+        for key in ("max_iter", "k_rel_norm_thre", "cost_update_thre"):
+            setattr(cfg, key, getattr(dflt, key))
+        cfg.print_level = 0
+        cfg.horizon_steps = wl.T
+        for key, val in mode_config(mode, iters, cost_update_thre).items():
+            setattr(cfg, key, val)
+        cfg.trace_level = 1
+
+    configure(args.mode, args.iters_per_solve, args.cost_update_thre)
 
     d_x0 = torch.from_numpy(wl.x0).to(dev)
     d_u0 = torch.from_numpy(wl.u_init).to(dev)
@@ -166,7 +231,8 @@ def main():
     n_x = wl.B * (wl.T + 1) * wl.n
     n_u = wl.B * wl.T * max(wl.m, 1)
     d_res = torch.empty(n_x + n_u, dtype=torch.float64, device=dev)  # packed [X | U] send buffer
-    d_all = torch.empty(world * (n_x + n_u), dtype=torch.float64, device=dev) if world > 1 else None
+    gather_dev = dev if backend == "nccl" else torch.device("cpu")
+    d_all = torch.empty(world * (n_x + n_u), dtype=torch.float64, device=gather_dev) if world > 1 else None
 
     def barrier():
         if world > 1:
@@ -192,17 +258,21 @@ def main():
     solver.getDevice(_capi.FIELD_U, d_res.data_ptr() + n_x * 8, n_u * 8)
     solver.synchronize()
     if world > 1:
-        dist.all_gather_into_tensor(d_all, d_res)
+        dist.all_gather_into_tensor(d_all, d_res if backend == "nccl" else d_res.cpu())
     barrier()
     t_end = time.perf_counter()
 
-    elapsed = torch.tensor([t_end - t_begin, t_end - t_solve], dtype=torch.float64, device=dev)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    mine = torch.tensor([t_end - t_begin, t_end - t_solve, t_solve - t_begin], dtype=torch.float64, device=red_dev)
+    per_rank = [mine.clone() for _ in range(world)]
+    elapsed_t = mine.clone()
     if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed, gather_s = float(elapsed[0]), float(elapsed[1])
+        dist.all_gather(per_rank, mine)
+        dist.all_reduce(elapsed_t, op=dist.ReduceOp.MAX)
+    elapsed, gather_s = float(elapsed_t[0]), float(elapsed_t[1])
 
     n_solves, total_ms, kernel_ms = solver.timingStats()
-    tr = solver.trace()  # (B, max_iter+1, 12) of the last solve
+    tr = solver.trace()  # (B, max_iter+1, 12) of the last solve; rows beyond an instance's last iteration are zero
     iters = solver.iters()
     rows = tr[:, 1:, :]
     executed = rows[:, :, 0] > 0
@@ -211,19 +281,77 @@ def main():
     n_fw = float(rows[:, :, _capi.TRACE_COLUMNS.index("n_forward")][executed].sum()) / max(n_it, 1)
     inst_it_per_solve = float(iters.sum())  # this rank's shard
     # whole-job count: every rank solves its own instances (different seeds), so sum the executed iterations over ranks
-    job_it = torch.tensor([inst_it_per_solve], dtype=torch.float64, device=dev)
+    job_it = torch.tensor([inst_it_per_solve], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(job_it, op=dist.ReduceOp.SUM)
     job_it_per_solve = float(job_it[0])
     status = solver.status()
+    kernel_name = solver.kernelName()
+    hist = {str(k): int(v) for k, v in zip(*np.unique(iters, return_counts=True))}
+    status_counts = {str(k): int(v) for k, v in zip(*np.unique(status, return_counts=True))}
+
+    # ---- extra legs, outside the timed job (every rank runs them; rank 0 reports its own)
+    def leg(mode, iters, n_steps, cost_update_thre=None):
+        configure(mode, iters, cost_update_thre)
+        for _ in range(2):
+            step()
+        solver.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        solver.synchronize()
+        dt = time.perf_counter() - t0
+        it = solver.iters()
+        st = solver.status()
+        return {"value": n_steps * (float(it.sum()) / wl.B) / dt, "ms_per_solve": 1e3 * dt / n_steps,
+                "solves_per_s": n_steps * wl.B / dt, "mean_iterations": float(it.mean()), "max_iterations": int(it.max()),
+                "status_counts": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))}}
+
+    extras = {}
+    if not args.no_extra_modes and args.mode == "nominal":
+        if args.workload == "c2":
+            extras["m1"] = leg("m1", 50, 10)
+            extras["m2"] = leg("m2", 500, 10)
+        if args.workload == "c4" and args.cost_update_thre is None:
+            extras["fp32_tolerance"] = leg("nominal", args.iters_per_solve, 20, cost_update_thre=1e-3)
+            extras["fp32_tolerance_m2"] = leg("m2", 500, 10, cost_update_thre=1e-3)
 
     if rank == 0:
         words = workloads.algorithmic_words_per_instance_iteration(wl.n, wl.m, wl.T, n_bw, n_fw)
         fused = workloads.fused_words_per_instance_iteration(wl.n, wl.m, wl.T, n_bw, n_fw)
         k_ms = kernel_ms / max(n_solves, 1)
-        bytes_per_launch = words * 8.0 * inst_it_per_solve
+        bytes_per_launch = words * float(elem) * inst_it_per_solve
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
         value = args.steps * (job_it_per_solve / wl.B) / elapsed
+        config = {
+            "workload": (wl_text % (wl.T, wl.B, args.seed))
+                        + ", default DDPSolver::Configuration with max_iter = iterations_per_step"
+                        + ("" if args.cost_update_thre is None else ", cost_update_thre = %g" % args.cost_update_thre),
+            "mode": args.mode,
+            "iterations_per_step": args.iters_per_solve if args.mode != "m2" else 500,
+            "solves_per_s": world * args.steps * wl.B / elapsed,
+            "iteration_histogram": hist,
+            "instance_iterations_per_step": job_it_per_solve,
+            "backward_passes_per_iteration": n_bw,
+            "forward_passes_per_iteration": n_fw,
+            "status_counts": status_counts,
+            "lane_mapping": LANE_MAPPINGS.get(kernel_name, kernel_name),
+            "final_gather_ms": 1e3 * gather_s,
+            "gather_backend": backend,
+            "per_rank_solve_ms": [1e3 * float(t[2]) / args.steps for t in per_rank],
+            "per_rank_gather_ms": [1e3 * float(t[1]) for t in per_rank],
+        }
+        if "m1" in extras:
+            config["m1_value"] = extras["m1"]["value"]
+            config["m1"] = dict(extras["m1"], note="SURVEY 8(d) M1: termination tests disabled, max_iter = N = 50; batch-iterations/s")
+            config["m2_value"] = extras["m2"]["value"]
+            config["m2"] = dict(extras["m2"], note="SURVEY 8(d) M2: default Configuration, solve to convergence (max_iter 500)")
+        if "fp32_tolerance" in extras:
+            config["fp32_tolerance_value"] = extras["fp32_tolerance"]["value"]
+            config["fp32_tolerance"] = dict(extras["fp32_tolerance"], note="same workload with cost_update_thre = 1e-3, a "
+                                            "threshold an fp32 cost can resolve (the default 1e-7 cannot: DESIGN.md 3a)")
+            config["fp32_tolerance_m2"] = dict(extras["fp32_tolerance_m2"], note="cost_update_thre = 1e-3, solve to convergence")
         out = {
             "metric": "DDP iterations/s (whole node), batch=%d, T=%d" % (wl.B, wl.T),
             "value": value,
@@ -235,41 +363,31 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if elem == 8 else "f32",
             "data": "synthetic",
-            "config": {
-                "workload": (wl_text % (wl.T, wl.B, args.seed))
-                            + ", default DDPSolver::Configuration with max_iter = iterations_per_step",
-                "mode": args.mode,
-                "iterations_per_step": args.iters_per_solve if args.mode != "m2" else 500,
-                "solves_per_s": world * args.steps * wl.B / elapsed,
-                "iteration_histogram": {str(k): int(v) for k, v in zip(*np.unique(iters, return_counts=True))},
-                "instance_iterations_per_step": job_it_per_solve,
-                "backward_passes_per_iteration": n_bw,
-                "forward_passes_per_iteration": n_fw,
-                "status_counts": {str(k): int(v) for k, v in zip(*np.unique(status, return_counts=True))},
-                "lane_mapping": LANE_MAPPINGS.get(solver.kernelName(), solver.kernelName()),
-                "final_gather_ms": 1e3 * gather_s,
-            },
+            "config": config,
             "instance_iterations_per_s": value * wl.B,
             "roofline": {
                 "bound": "hbm",
-                "kernel": solver.kernelName() + "<%s>" % wl.model,
+                "kernel": kernel_name + "<%s>" % wl.model,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
+                "accounting": "SURVEY.md 8(d) contract bytes (the reference's materialised dataflow), NOT measured traffic: the "
+                              "kernel keeps the derivatives on chip; `traffic` is the rocprofv3 PMC measurement",
                 "kernel_ms_avg": k_ms,
                 "launches_timed": int(n_solves),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "algorithmic_bytes_per_instance_iteration": words * 8.0,
-                "fused_lower_bound_bytes_per_instance_iteration": fused * 8.0,
+                "algorithmic_bytes_per_instance_iteration": words * float(elem),
+                "fused_lower_bound_bytes_per_instance_iteration": fused * float(elem),
+                "fused_lower_bound_bytes_per_launch": fused * float(elem) * inst_it_per_solve,
             },
         }
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(wl, args.mode, args.iters_per_solve, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(wl, args.mode, args.iters_per_solve, args.cpu_seconds, args.cost_update_thre)
             except Exception as e:  # the GPU number stands on its own; say why the baseline is missing
                 out["cpu_baseline"] = {"value": None, "unit": "DDP iterations/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": "failed: %r" % (e,)}
@@ -277,10 +395,15 @@ def main():
         if os.path.exists(traffic_file):
             try:
                 tf = json.load(open(traffic_file))
-                if (args.workload == "c2" and args.mode == "nominal" and tf.get("batch") == wl.B
-                        and tf.get("iterations_per_step") == args.iters_per_solve):
-                    out["roofline"]["traffic"] = tf.get("hbm_bytes_per_launch")
-                    out["roofline"]["traffic_source"] = tf.get("source")
+                entry = tf.get(args.workload) if isinstance(tf.get(args.workload), dict) else (tf if args.workload == "c2" else None)
+                if (entry and args.mode == "nominal" and args.cost_update_thre is None and entry.get("batch") == wl.B
+                        and entry.get("iterations_per_step") == args.iters_per_solve):
+                    out["roofline"]["traffic"] = entry.get("hbm_bytes_per_launch")
+                    out["roofline"]["traffic_source"] = entry.get("source")
+                    if out["roofline"]["traffic"]:
+                        out["roofline"]["traffic_over_fused_bound"] = (out["roofline"]["traffic"]
+                                                                       / out["roofline"]["fused_lower_bound_bytes_per_launch"])
+                        out["roofline"]["hbm_frac_measured"] = out["roofline"]["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             except Exception:
                 pass
         print(json.dumps(out), flush=True)

@@ -485,6 +485,10 @@ struct TileSolver32
       fails iff a pivot is <= 0, NaN passes.  Same operation order as the lane kernels' ldltInPlace. */
   NMPC_D static bool ldlt(float * A, float * inv_d)
   {
+#pragma clang fp contract(on) // fuse a * b + c only within a source expression: every instance gets the same instruction
+                              // sequence whichever slot of the stage pipeline it runs in (hipcc's default fuses across
+                              // statements, decided per inlined context) — sharded == unsharded, bit for bit
+
     bool ok = true;
 #pragma unroll
     for(int k = 0; k < MM; k++)
@@ -515,6 +519,10 @@ struct TileSolver32
   }
   NMPC_D static void ldltSolve(const float * A, const float * inv_d, float * x)
   {
+#pragma clang fp contract(on) // fuse a * b + c only within a source expression: every instance gets the same instruction
+                              // sequence whichever slot of the stage pipeline it runs in (hipcc's default fuses across
+                              // statements, decided per inlined context) — sharded == unsharded, bit for bit
+
 #pragma unroll
     for(int i = 0; i < MM; i++)
     {
@@ -594,6 +602,10 @@ struct TileSolver32
   template<int kRegType>
   NMPC_D Stage1Out stage1(const BwState & st, int slot, int i, float lambda) const
   {
+#pragma clang fp contract(on) // fuse a * b + c only within a source expression: every instance gets the same instruction
+                              // sequence whichever slot of the stage pipeline it runs in (hipcc's default fuses across
+                              // statements, decided per inlined context) — sharded == unsharded, bit for bit
+
     const int q = lane >> 4, j = lane & 15;
     const float * r = rec(i & 1, slot);
     const v4f zero4 = {0, 0, 0, 0};
@@ -625,6 +637,10 @@ struct TileSolver32
   template<int kRegType>
   NMPC_D Stage2Out stage2(BwState & st, const Stage1Out & in, int slot, float lambda) const
   {
+#pragma clang fp contract(on) // fuse a * b + c only within a source expression: every instance gets the same instruction
+                              // sequence whichever slot of the stage pipeline it runs in (hipcc's default fuses across
+                              // statements, decided per inlined context) — sharded == unsharded, bit for bit
+
     const int q = lane >> 4, j = lane & 15;
     // q as a column (lane (q', n) register r <- q[4 q' + r]) through the slot's LDS scratch, written now and read at the end
     // of the stage (one wave's LDS traffic is ordered); lanes outside group qK write to a dump behind the scratch: no branch
@@ -682,6 +698,10 @@ struct TileSolver32
       LDS scratch (four row writes, one 16-byte read per lane)    :524-527 */
   NMPC_D void stage3(BwState & st, const Stage1Out & s1, const Stage2Out & s2) const
   {
+#pragma clang fp contract(on) // fuse a * b + c only within a source expression: every instance gets the same instruction
+                              // sequence whichever slot of the stage pipeline it runs in (hipcc's default fuses across
+                              // statements, decided per inlined context) — sharded == unsharded, bit for bit
+
     const int q = lane >> 4, j = lane & 15;
     const v4f zero4 = {0, 0, 0, 0};
     const v4f H = mma(s1.Q, s2.A, s2.qcol);

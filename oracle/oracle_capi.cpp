@@ -12,10 +12,14 @@
 #include "models_builder.hpp"
 #undef ORACLE_F32
 
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <thread>
 #include <type_traits>
+
+#include <pthread.h>
+#include <sched.h>
 
 namespace
 {
@@ -437,8 +441,8 @@ extern "C"
                     });
   }
 
-  /** B independent solves, instances statically partitioned over n_threads std::threads (one solver object
-      per instance, as the reference would be used).  Batch layouts are the single-solve layouts with a
+  /** B independent solves on n_threads std::threads (one solver object per thread, re-used from instance to instance as
+      an MPC caller re-uses its DDPSolver), instances handed out dynamically in small chunks, threads pinned.  Batch layouts are the single-solve layouts with a
       leading [B].  trace_last[B][12] receives the last trace row; iters[B] its iter field.  Returns the
       wall time of the threaded region in seconds through *seconds. */
   int oracle_ddp_solve_batch(const char * model,
@@ -480,10 +484,34 @@ extern "C"
             n_threads = 1;
           }
           std::vector<long long> it_count(n_threads, 0);
+          // instances are handed out in chunks from a shared counter (solves differ in length: a static partition leaves
+          // threads idle at the end); threads are pinned to the CPUs this process may run on, one each, in order
+          std::atomic<int> next_chunk(0);
+          const int chunk = std::max(1, std::min(16, B / (n_threads * 8)));
+          std::vector<int> cpus;
+          {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            if(sched_getaffinity(0, sizeof(set), &set) == 0)
+            {
+              for(int c = 0; c < CPU_SETSIZE; c++)
+              {
+                if(CPU_ISSET(c, &set))
+                {
+                  cpus.push_back(c);
+                }
+              }
+            }
+          }
           auto worker = [&](int tid)
           {
-            int b0 = static_cast<int>(static_cast<long long>(B) * tid / n_threads);
-            int b1 = static_cast<int>(static_cast<long long>(B) * (tid + 1) / n_threads);
+            if(n_threads > 1 && !cpus.empty())
+            {
+              cpu_set_t one;
+              CPU_ZERO(&one);
+              CPU_SET(cpus[tid % cpus.size()], &one);
+              pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+            }
             using R = typename M::Real;
             SolverOf<M> solver(m);
             toConfig(cfg, solver.config());
@@ -492,6 +520,14 @@ extern "C"
               solver.setInputLimits(toReal<R>(lower, MM).data(), toReal<R>(upper, MM).data());
             }
             std::vector<R> x0r(N), u0r(static_cast<size_t>(T) * MM);
+            for(;;)
+            {
+            const int b0 = next_chunk.fetch_add(chunk);
+            if(b0 >= B)
+            {
+              break;
+            }
+            const int b1 = std::min(B, b0 + chunk);
             for(int b = b0; b < b1; b++)
             {
               for(int j = 0; j < N; j++)
@@ -563,6 +599,7 @@ extern "C"
                   h[r - 1] = tr[r].alpha_idx;
                 }
               }
+            }
             }
           };
           auto t_start = std::chrono::steady_clock::now();

@@ -40,6 +40,24 @@ def test_default_line_has_the_contract_keys():
     # value = executed iterations: consistent with the step time
     it_per_step = d["config"]["instance_iterations_per_step"] / 4096
     assert abs(d["value"] - it_per_step / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    # SURVEY 8(d)'s two timing modes ride in the default line
+    cfg = d["config"]
+    assert cfg["m1_value"] > 0 and cfg["m2_value"] > 0
+    assert cfg["m1"]["status_counts"].get("1", 0) == 0 and cfg["m1"]["max_iterations"] <= 50
+    assert cfg["m2"]["status_counts"].get("1", 0) >= 0.99 * 4096
+    assert cfg["per_rank_solve_ms"] and abs(cfg["per_rank_solve_ms"][0] - d["ms_per_step"]) < 0.5 * d["ms_per_step"]
+    assert cb["cores"] <= cb["host_cpus_affinity"] and "1" in cb["thread_sweep"]
+
+
+def test_c4_runs_in_fp32_on_the_tile_kernel():
+    d = run_bench("--workload", "c4", "--no-cpu-baseline")
+    assert d["dtype"] == "f32" and "batch=8192" in d["metric"]
+    assert d["roofline"]["kernel"] == "ddp_solve_tile32_kernel<quadrotor_f32>"
+    assert d["config"]["fp32_tolerance_value"] > 0
+    assert d["config"]["fp32_tolerance_m2"]["status_counts"].get("1", 0) >= 0.98 * 8192
+    d64 = run_bench("--workload", "c4f64", "--no-cpu-baseline")
+    assert d64["dtype"] == "f64" and d64["roofline"]["kernel"].startswith("ddp_solve_wpi_kernel")
+    assert d["value"] > 2.0 * d64["value"]
 
 
 def test_other_workload_and_modes_run():

@@ -82,6 +82,8 @@ public:
     double cost_update_thre = 1e-7;
     //! 1: keep the per-iteration trace of every instance on the device (traceDataList); 0: last row only
     int trace_level = 1;
+    //! line-search schedule (nmpc_hip_ddp_config::line_search_fan_out): 0 automatic, 1 step-size parallel, 2 sequential
+    int line_search_fan_out = 0;
   };
 
   /*! \brief Control data of one instance (DDPSolver::ControlData, DDPSolver.h:113-123). */
@@ -410,6 +412,7 @@ protected:
     c.cost_update_ratio_thre = config_.cost_update_ratio_thre;
     c.cost_update_thre = config_.cost_update_thre;
     c.trace_level = config_.trace_level;
+    c.line_search_fan_out = config_.line_search_fan_out;
     if(config_.alpha_list.empty() || config_.alpha_list.size() > NMPC_HIP_MAX_ALPHA)
     {
       throw std::invalid_argument("alpha_list size must be in [1, 32]");

@@ -33,14 +33,17 @@ namespace hip
 constexpr int kQuadInstances = 16; //!< instances per workgroup of the quad kernel
 constexpr int kQuadWaves = 4;
 
-template<class Problem, bool kConstrained>
-struct QuadSolver : PairSolver<Problem, kConstrained, true, kConstrained ? 4 : 1>
+/** \tparam kFanOut step-size-parallel line search: the four lane groups of 16 — mirrors of one another otherwise — try four
+    step sizes of alpha_list per forward pass once the first trial has failed (at most 1 + 3 + 3 passes instead of 11).
+    Box-constrained solves backtrack often (cart-pole with a +-15 N box: ~3 forward passes per iteration) and always use it.
+    Unconstrained solves have both instantiations: the sequential search is 1.5 % faster where the first step size is accepted
+    anyway (the extra code shifts the register allocation of the hot loops) — short solves, the MPC callers' max_iter = 3, the
+    nominal bench —, the fan-out is 2 - 3 x faster per iteration where instances backtrack: long solves that iterate into the
+    rounding-noise regime (SURVEY.md 8(d)'s M1 / M2 modes).  launchSolve picks by Configuration::line_search_fan_out. */
+template<class Problem, bool kConstrained, bool kFanOut = kConstrained>
+struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFanOut) ? 4 : 1>
 {
-  // Box-constrained solves backtrack often (cart-pole with a +-15 N box: ~3 forward passes per iteration): there the
-  // four lane groups of 16 — mirrors of one another otherwise — try four step sizes per forward pass once the first
-  // trial has failed.  The unconstrained kernel keeps the sequential search: the extra code costs 1.7 % on the nominal
-  // workload (register allocation in the hot loops), where the first step size is accepted anyway.
-  using Pair = PairSolver<Problem, kConstrained, true, kConstrained ? 4 : 1>;
+  using Pair = PairSolver<Problem, kConstrained, true, (kConstrained || kFanOut) ? 4 : 1>;
   using Base = typename Pair::Base;
   using Base::b;
   using Base::buf;
@@ -506,7 +509,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, kConstrained ? 4 : 1
 
   NMPC_D void solveMasterQuad(bool valid)
   {
-    if constexpr(kConstrained)
+    if constexpr(kConstrained || kFanOut)
     {
       Pair::solveMasterFanOut(valid, [this](bool need) { return backwardMasterQuad(need); });
     }
@@ -566,12 +569,12 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, kConstrained ? 4 : 1
     `-mllvm --amdgpu-mfma-vgpr-form` (nmpc_amd/build.py does): by default a kernel that may use 512 registers gets its
     matrix-core results in accumulation registers and spends ~30 v_accvgpr_read/write per timestep moving them to the
     VALU / DPP instructions that consume them (10.3k -> 10.6k iterations/s on the headline workload). */
-template<class Problem, bool kConstrained, bool kOwnProblem = false>
+template<class Problem, bool kConstrained, bool kOwnProblem = false, bool kFanOut = kConstrained>
 __global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const Problem problem,
                                                                          const nmpc_hip_ddp_config cfg,
                                                                          const DeviceBuffers buf)
 {
-  using Solver = QuadSolver<Problem, kConstrained>;
+  using Solver = QuadSolver<Problem, kConstrained, kFanOut>;
   extern __shared__ __attribute__((aligned(16))) double lds_quad[];
   const int wl = threadIdx.x % 64;
   // in the lane-per-instance roles (master, forward helper) every group of 16 lanes mirrors the workgroup's 16

@@ -65,6 +65,8 @@ struct ModelOpsFor
       whose 64-instance workgroups keep the latency flat up to 16384 instances.  NMPC_HIP_DDP_KERNEL=quad / 2w force. */
   static constexpr bool kQuadShape = QuadSolver<Problem, false>::kShape;
   static constexpr int kQuadMaxBatch = 4096;
+  //! Configuration::line_search_fan_out = 0 (automatic): solves with max_iter above this use the step-size-parallel search
+  static constexpr int kQuadFanOutAutoMaxIter = 16;
   static bool useQuad(int batch_padded, bool own)
   {
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
@@ -143,10 +145,12 @@ struct ModelOpsFor
         }
         if(!requested[dev])
         {
-          const void * variants[4] = {reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, false>),
+          const void * variants[6] = {reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, false>),
                                       reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true, false>),
                                       reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, true>),
-                                      reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true, true>)};
+                                      reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true, true>),
+                                      reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, false, true>),
+                                      reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, true, true>)};
           for(const void * fn : variants)
           {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -158,6 +162,8 @@ struct ModelOpsFor
           }
           requested[dev] = true;
         }
+        // step-size-parallel line search for unconstrained solves: on request, or (0 = automatic) for long solves
+        const bool fan = cfg.line_search_fan_out == 1 || (cfg.line_search_fan_out == 0 && cfg.max_iter > kQuadFanOutAutoMaxIter);
         if(con && own)
         {
           hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, true, true>), g, blk, quad_lds, stream, problem, cfg, buf);
@@ -165,6 +171,14 @@ struct ModelOpsFor
         else if(con)
         {
           hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, true, false>), g, blk, quad_lds, stream, problem, cfg, buf);
+        }
+        else if(fan && own)
+        {
+          hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, false, true, true>), g, blk, quad_lds, stream, problem, cfg, buf);
+        }
+        else if(fan)
+        {
+          hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, false, false, true>), g, blk, quad_lds, stream, problem, cfg, buf);
         }
         else if(own)
         {

@@ -76,6 +76,12 @@ extern "C"
     double qp_min_step; /* BoxQP.h:51 */
     double qp_armijo_param; /* BoxQP.h:54 */
     int trace_level; /* 0: keep only the last trace row per instance; 1: full per-iteration trace */
+    /* Line-search schedule of the kernels that can try several step sizes of alpha_list per forward pass (the quad kernel:
+       cart-pole / bipedal up to 4096 instances).  Results are identical either way (the trials of DDPSolver.hpp:234-274 are
+       independent and the first accepted one in list order is taken); only the time per iteration differs.
+       0: automatic (sequential search for max_iter <= 16, where the first step size is normally accepted; parallel beyond),
+       1: always parallel, 2: always sequential.  Box-constrained solves are always parallel. */
+    int line_search_fan_out;
   } nmpc_hip_ddp_config;
 
   /** Trace columns (TraceData, DDPSolver.h:179-216).  The three duration_* fields of the reference are

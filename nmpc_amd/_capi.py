@@ -60,6 +60,7 @@ class Config(C.Structure):
         ("qp_min_step", C.c_double),
         ("qp_armijo_param", C.c_double),
         ("trace_level", C.c_int),
+        ("line_search_fan_out", C.c_int),
     ]
 
 

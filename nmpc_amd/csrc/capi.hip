@@ -548,6 +548,7 @@ extern "C"
     c->qp_min_step = 1e-22;
     c->qp_armijo_param = 0.1;
     c->trace_level = 1;
+    c->line_search_fan_out = 0;
     return NMPC_HIP_OK;
   }
 

@@ -26,7 +26,7 @@ class Configuration:
               "initial_dlambda", "lambda_factor", "lambda_min", "lambda_max", "k_rel_norm_thre", "lambda_thre",
               "cost_update_ratio_thre", "cost_update_thre", "use_state_eq_second_derivative", "qp_max_iter",
               "qp_grad_thre", "qp_rel_improve_thre", "qp_step_factor", "qp_min_step", "qp_armijo_param",
-              "trace_level")
+              "trace_level", "line_search_fan_out")
 
     def __init__(self):
         c = _capi.Config()

@@ -163,17 +163,25 @@ public:
   }
 
   /** \brief Set function to return input limits (lower, upper), DDPSolver.h:282-285.
-      Only limits that are constant in time are supported on the device — the only form the reference's callers
-      use (TestDDPCartPole.cpp:379-386, TestDDPVerticalMotion.cpp:262-270): the function is sampled at t = 0. */
+      The reference evaluates it at every timestep of the backward pass, input_limits_func_(current_t + i * dt)
+      (DDPSolver.hpp:470-472).  solve() samples it there — for every instance's own current_t — and hands the device
+      the constant pair when the samples agree, the sampled table otherwise (nmpc_hip_ddp_set_input_limits_horizon).
+      Each returned vector must have the problem's input dimension (the capacity, when it is dynamic). */
   inline void setInputLimitsFunc(const std::function<std::array<InputDimVector, 2>(double)> & input_limits_func)
   {
-    const std::array<InputDimVector, 2> lim = input_limits_func(0.0);
+    input_limits_func_ = input_limits_func;
     has_limits_ = true;
-    for(int i = 0; i < MM; i++)
-    {
-      lower_[i] = i < lim[0].size() ? lim[0][i] : (lim[0].size() > 0 ? lim[0][lim[0].size() - 1] : -INFINITY);
-      upper_[i] = i < lim[1].size() ? lim[1][i] : (lim[1].size() > 0 ? lim[1][lim[1].size() - 1] : INFINITY);
-    }
+    limits_from_func_ = true;
+  }
+
+  /** \brief Input limits that are constant in time, without a function object. */
+  inline void setInputLimits(const InputDimVector & lower, const InputDimVector & upper)
+  {
+    limits_from_func_ = false;
+    has_limits_ = true;
+    storeConstantLimits(lower, upper);
+    horizon_limits_active_ = false;
+    horizon_limits_dirty_ = true;
   }
 
   /** \brief Per-instance input limits (constant in time): limits[b] = {lower, upper} of instance b — a batch of
@@ -224,6 +232,7 @@ public:
   {
     const size_t B = static_cast<size_t>(batch_size_);
     std::vector<double> x0, u0;
+    sampleInputLimits(current_t);
     packInputs(current_t, current_x, initial_u_list, x0, u0);
     check(nmpc_hip_ddp_solve(handle_, current_t.data(), x0.data(), u0.data()));
     fetched_ = false;
@@ -273,6 +282,7 @@ public:
   {
     const size_t B = static_cast<size_t>(batch_size_);
     std::vector<double> x0, u0;
+    sampleInputLimits(current_t);
     packInputs(current_t, current_x, initial_u_list, x0, u0);
     nmpc_hip_ddp_mpc_options opt;
     check(nmpc_hip_ddp_mpc_default_options(&opt));
@@ -423,10 +433,82 @@ protected:
       c.alpha_list[i] = config_.alpha_list[i];
     }
     check(nmpc_hip_ddp_set_config(handle_, &c));
-    if(has_limits_)
+    if(has_limits_ && !horizon_limits_active_)
     {
       check(nmpc_hip_ddp_set_input_limits(handle_, lower_, upper_));
     }
+    if(horizon_limits_dirty_)
+    {
+      if(horizon_limits_active_)
+      {
+        check(nmpc_hip_ddp_set_input_limits_horizon(handle_, horizon_lo_.data(), horizon_up_.data(), horizon_per_instance_ ? 1 : 0));
+      }
+      else
+      {
+        check(nmpc_hip_ddp_set_input_limits_horizon(handle_, nullptr, nullptr, 0));
+      }
+      horizon_limits_dirty_ = false;
+    }
+  }
+
+  inline void storeConstantLimits(const InputDimVector & lower, const InputDimVector & upper)
+  {
+    if(lower.size() != upper.size() || lower.size() > MM || (lower.size() == 0 && MM > 0 && Problem::kInputDimMax > 0))
+    {
+      throw std::invalid_argument("input limits should have the input dimension " + std::to_string(Problem::kInputDimMax)
+                                  + " but " + std::to_string(lower.size()) + ".");
+    }
+    for(int i = 0; i < MM; i++)
+    {
+      lower_[i] = i < lower.size() ? lower[i] : -INFINITY;
+      upper_[i] = i < upper.size() ? upper[i] : INFINITY;
+    }
+  }
+
+  /** Sample input_limits_func_ where the reference's backward pass evaluates it (DDPSolver.hpp:470-472). */
+  inline void sampleInputLimits(const std::vector<double> & current_t)
+  {
+    const size_t B = static_cast<size_t>(batch_size_);
+    if(!limits_from_func_ || current_t.size() != B) // (a wrong batch size is reported by packInputs)
+    {
+      return;
+    }
+    const int T = config_.horizon_steps;
+    const double dt = problem_->dt();
+    bool same_t0 = true;
+    for(size_t b = 1; b < B && b < current_t.size(); b++)
+    {
+      same_t0 = same_t0 && current_t[b] == current_t[0];
+    }
+    const size_t tables = same_t0 ? 1 : B;
+    horizon_lo_.assign(tables * T * MM, -INFINITY);
+    horizon_up_.assign(tables * T * MM, INFINITY);
+    bool constant = true;
+    for(size_t tb = 0; tb < tables; tb++)
+    {
+      for(int i = 0; i < T; i++)
+      {
+        const std::array<InputDimVector, 2> lim = input_limits_func_(current_t[tb] + i * dt);
+        if(lim[0].size() != lim[1].size() || lim[0].size() > MM)
+        {
+          throw std::invalid_argument("input_limits_func should return vectors of the input dimension.");
+        }
+        for(int a = 0; a < lim[0].size(); a++)
+        {
+          horizon_lo_[(tb * T + i) * MM + a] = lim[0][a];
+          horizon_up_[(tb * T + i) * MM + a] = lim[1][a];
+          constant = constant && lim[0][a] == horizon_lo_[a] && lim[1][a] == horizon_up_[a];
+        }
+        if(tb == 0 && i == 0)
+        {
+          storeConstantLimits(lim[0], lim[1]);
+        }
+      }
+    }
+    const bool was_active = horizon_limits_active_;
+    horizon_limits_active_ = !constant;
+    horizon_per_instance_ = !same_t0;
+    horizon_limits_dirty_ = horizon_limits_active_ || was_active;
   }
 
   void fetchResults()
@@ -574,6 +656,10 @@ protected:
   nmpc_hip_ddp_handle handle_ = nullptr;
   int handle_T_ = -1;
   bool has_limits_ = false;
+  bool limits_from_func_ = false;
+  std::function<std::array<InputDimVector, 2>(double)> input_limits_func_;
+  std::vector<double> horizon_lo_, horizon_up_; //!< sampled time-varying limits [1 or batch][T][MM]
+  bool horizon_limits_active_ = false, horizon_per_instance_ = false, horizon_limits_dirty_ = false;
   double lower_[MM];
   double upper_[MM];
   bool fetched_ = false;

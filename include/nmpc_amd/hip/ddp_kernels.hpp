@@ -64,6 +64,11 @@ struct DeviceBuffersT
              //!< (ddp_kernels_wpi.hpp: derivatives, gains, candidates), fp32 tile kernel (ddp_kernels_tile32.hpp: gains)
   const unsigned char * params_batch; //!< per-instance problem objects [Bp][sizeof(Problem)], or nullptr: one for all
   const double * lim_batch; //!< per-instance input limits [Bp][2][kMaxInputDim] (lower, upper), or nullptr: lim_lo / lim_hi
+  //! time-varying input limits, input_limits_func_(current_t + i dt) of DDPSolver.hpp:470-472 sampled per timestep:
+  //! [1 or Bp][T][2][lim_mm] (lower, upper), or nullptr.  Takes precedence over lim_batch / lim_lo / lim_hi.
+  const double * lim_steps;
+  int lim_steps_per_instance; //!< 1: one table per instance (instances start at different current_t), 0: one for all
+  int lim_mm; //!< row length of lim_steps (the handle's MM)
   double lim_lo[kMaxInputDim]; //!< input lower limits (constant in time)
   double lim_hi[kMaxInputDim]; //!< input upper limits
 };
@@ -87,14 +92,28 @@ struct Unroll
 };
 } // namespace detail
 
-/** Input limits of instance b (constant in time): its own if per-instance limits were given, else the shared ones. */
-NMPC_D double inputLimitLo(const DeviceBuffers & buf, int b, int a)
+/** Input limits of instance b at timestep i (input_limits_func_(current_t + i dt), DDPSolver.hpp:470-472): the sampled
+    table if time-varying limits were given, else the instance's own constant limits, else the shared ones. */
+NMPC_D double inputLimit(const DeviceBuffers & buf, int b, int i, int a, int side)
 {
-  return buf.lim_batch ? buf.lim_batch[(static_cast<size_t>(b) * 2 + 0) * kMaxInputDim + a] : buf.lim_lo[a];
+  if(buf.lim_steps != nullptr)
+  {
+    const size_t inst = buf.lim_steps_per_instance ? static_cast<size_t>(b) : 0;
+    return buf.lim_steps[((inst * buf.T + i) * 2 + side) * buf.lim_mm + a];
+  }
+  if(buf.lim_batch != nullptr)
+  {
+    return buf.lim_batch[(static_cast<size_t>(b) * 2 + side) * kMaxInputDim + a];
+  }
+  return side == 0 ? buf.lim_lo[a] : buf.lim_hi[a];
 }
-NMPC_D double inputLimitHi(const DeviceBuffers & buf, int b, int a)
+NMPC_D double inputLimitLo(const DeviceBuffers & buf, int b, int i, int a)
 {
-  return buf.lim_batch ? buf.lim_batch[(static_cast<size_t>(b) * 2 + 1) * kMaxInputDim + a] : buf.lim_hi[a];
+  return inputLimit(buf, b, i, a, 0);
+}
+NMPC_D double inputLimitHi(const DeviceBuffers & buf, int b, int i, int a)
+{
+  return inputLimit(buf, b, i, a, 1);
 }
 
 /** The problem object instance b solves: the handle's shared one, or its own when per-instance objects were given
@@ -982,8 +1001,8 @@ struct InstanceSolver
           {
             // warm start from k_list_[i+1] when its size matches    :452-467
             initial_k[a] = (i != T - 1 && m_next == m) ? k_next[a] : 0.0;
-            lo[a] = inputLimitLo(buf, b, a) - u[a]; // :470-472
-            up[a] = inputLimitHi(buf, b, a) - u[a];
+            lo[a] = inputLimitLo(buf, b, i, a) - u[a]; // :470-472
+            up[a] = inputLimitHi(buf, b, i, a) - u[a];
           }
           QPOut qp;
           boxQP(m, Quu_F, Qu, lo, up, initial_k, qp);

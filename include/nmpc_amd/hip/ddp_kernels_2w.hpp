@@ -629,8 +629,8 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
           for(int a = 0; a < MM; a++)
           {
             initial_k[a] = (i != T - 1 && m_next == m) ? k_next[a] : 0.0;
-            lo[a] = inputLimitLo(buf, b, a) - u[a];
-            up[a] = inputLimitHi(buf, b, a) - u[a];
+            lo[a] = inputLimitLo(buf, b, i, a) - u[a];
+            up[a] = inputLimitHi(buf, b, i, a) - u[a];
           }
           QPOut qp;
           Base::boxQP(m, Quu_F, Qu, lo, up, initial_k, qp);

@@ -333,8 +333,8 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       if constexpr(kConstrained)
       {
         const double initial_k = (i != T - 1 && have_next) ? k_next : 0.0;
-        const double lo = inputLimitLo(buf, b_q, 0) - o.u;
-        const double up = inputLimitHi(buf, b_q, 0) - o.u;
+        const double lo = inputLimitLo(buf, b_q, i, 0) - o.u;
+        const double up = inputLimitHi(buf, b_q, i, 0) - o.u;
         QPOut qp;
         Base::boxQP(1, &Quu_F, &Qu, &lo, &up, &initial_k, qp);
         if(need && ok && r0 && c0)

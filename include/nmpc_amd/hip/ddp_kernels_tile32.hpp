@@ -1412,6 +1412,9 @@ struct ModelOpsTile32
     buf.wpi_ws = reinterpret_cast<float *>(buf64.wpi_ws);
     buf.params_batch = nullptr;
     buf.lim_batch = nullptr;
+    buf.lim_steps = nullptr;
+    buf.lim_steps_per_instance = 0;
+    buf.lim_mm = Problem::kInputDimMax;
     for(int i = 0; i < kMaxInputDim; i++)
     {
       buf.lim_lo[i] = buf64.lim_lo[i];

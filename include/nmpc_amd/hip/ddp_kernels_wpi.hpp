@@ -726,8 +726,8 @@ struct WaveSolver
         for(int a = 0; a < MM; a++)
         {
           initial_k[a] = (i != T - 1) ? k_next[a] : 0.0; // warm start from k_{i+1} (same dimension), :452-467
-          lo[a] = inputLimitLo(buf, b, a) - vec(vU)[a]; // :470-472
-          up[a] = inputLimitHi(buf, b, a) - vec(vU)[a];
+          lo[a] = inputLimitLo(buf, b, i, a) - vec(vU)[a]; // :470-472
+          up[a] = inputLimitHi(buf, b, i, a) - vec(vU)[a];
         }
         const Lane lane_code(problem, cfg, buf, b);
         typename Lane::QPOut qp;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
     {
       if(a < m0)
       {
-        u0[a] = fmin(fmax(u0[a], inputLimitLo(buf, b, a)), inputLimitHi(buf, b, a)); // cwiseMax(lower).cwiseMin(upper), :394
+        u0[a] = fmin(fmax(u0[a], inputLimitLo(buf, b, 0, a)), inputLimitHi(buf, b, 0, a)); // cwiseMax(lower).cwiseMin(upper), :394
       }
     }
   }

@@ -153,7 +153,7 @@ extern "C"
   int nmpc_hip_ddp_set_model_params(nmpc_hip_ddp_handle h, const void * params, size_t bytes);
 
   /** Per-instance input limits (constant in time): lower[batch][MM], upper[batch][MM]; both NULL go back to the shared
-      limits of nmpc_hip_ddp_set_input_limits.  Reference equivalent: a batch of DDPSolver objects, each with its own
+      limits of nmpc_hip_ddp_set_input_limits (and to "no limits given" if that was never called).  Reference equivalent: a batch of DDPSolver objects, each with its own
       setInputLimitsFunc (DDPSolver.h:282-285). */
   int nmpc_hip_ddp_set_input_limits_batch(nmpc_hip_ddp_handle h, const double * lower, const double * upper);
 
@@ -169,10 +169,17 @@ extern "C"
       what DDPSolver::solve validates initial_u_list against (DDPSolver.hpp:46-58).  out has room for T ints. */
   int nmpc_hip_ddp_input_dims(nmpc_hip_ddp_handle h, double t0, int * out);
 
-  /** DDPSolver::setInputLimitsFunc (DDPSolver.h:282-285) for limits that are constant in time, the only form
-      the reference's callers use (TestDDPCartPole.cpp:379-386, TestDDPVerticalMotion.cpp:262-270):
-      lower[MM], upper[MM]; entries >= inputDim(t) are ignored. */
+  /** DDPSolver::setInputLimitsFunc (DDPSolver.h:282-285) for limits that are constant in time, the form the reference's
+      callers use (TestDDPCartPole.cpp:379-386, TestDDPVerticalMotion.cpp:262-270): lower[MM], upper[MM]; entries >=
+      inputDim(t) are ignored.  Time-varying limits: nmpc_hip_ddp_set_input_limits_horizon. */
   int nmpc_hip_ddp_set_input_limits(nmpc_hip_ddp_handle h, const double * lower, const double * upper);
+
+  /** DDPSolver::setInputLimitsFunc (DDPSolver.h:282-285) for limits that VARY in time: the reference evaluates
+      input_limits_func_(current_t + i * dt) at every timestep of the backward pass (DDPSolver.hpp:470-472); here the caller
+      samples the function for the next solve: lower / upper [T][MM] (per_instance = 0: every instance starts at the same
+      current_t) or [batch][T][MM] (per_instance = 1).  Takes precedence over the constant limits; both NULL removes it.
+      The table belongs to ONE solve's timesteps: nmpc_hip_ddp_mpc_run with more than one tick rejects it. */
+  int nmpc_hip_ddp_set_input_limits_horizon(nmpc_hip_ddp_handle h, const double * lower, const double * upper, int per_instance);
 
   /** DDPSolver::solve (DDPSolver.h:275, DDPSolver.hpp:26-141) for the whole batch, HOST pointers:
       H2D copy, device solve, synchronise.  Results stay on the device until nmpc_hip_ddp_get. */

@@ -68,6 +68,7 @@ struct nmpc_hip_ddp_solver
   double lim_lo[nmpc_amd::hip::kMaxInputDim];
   double lim_hi[nmpc_amd::hip::kMaxInputDim];
   bool has_limits = false;
+  bool has_shared_limits = false; // nmpc_hip_ddp_set_input_limits was called
   bool solved = false;
   hipStream_t stream = nullptr;
   // ring of HIP-event triples {begin, kernel start, end}: one per solve, harvested lazily so that timing a
@@ -102,6 +103,8 @@ struct nmpc_hip_ddp_solver
   double * d_wpi_ws = nullptr; // wave-per-instance kernel workspace (large models only)
   unsigned char * d_params_batch = nullptr; // [Bp][param_bytes] per-instance problem objects, or nullptr
   double * d_lim_batch = nullptr; // [Bp][2][kMaxInputDim] per-instance input limits, or nullptr
+  double * d_lim_steps = nullptr; // [1 or Bp][T][2][MM] time-varying input limits, or nullptr
+  int lim_steps_per_instance = 0;
   int trace_rows = 0;
   // staging in the reference layouts
   void * d_stage_in = nullptr; // x0 / u_init / t0 as handed over by the host entry point
@@ -188,6 +191,9 @@ DeviceBuffers makeBuffers(const nmpc_hip_ddp_solver * s)
   b.wpi_ws = s->d_wpi_ws;
   b.params_batch = s->d_params_batch;
   b.lim_batch = s->d_lim_batch;
+  b.lim_steps = s->d_lim_steps;
+  b.lim_steps_per_instance = s->lim_steps_per_instance;
+  b.lim_mm = s->MM;
   for(int i = 0; i < nmpc_amd::hip::kMaxInputDim; i++)
   {
     b.lim_lo[i] = s->lim_lo[i];
@@ -753,7 +759,8 @@ extern "C"
     }
     void * ptrs[] = {s->d_t0,     s->d_x0,     s->d_X,   s->d_U,      s->d_cost,    s->d_kff,       s->d_Kfb,
                      s->d_trace,  s->d_trace_last, s->d_dV, s->d_status, s->d_iters, s->d_sel,     s->d_qp_ret,
-                     s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_params_batch, s->d_lim_batch, s->d_stage_in, s->d_stage_out};
+                     s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_params_batch, s->d_lim_batch, s->d_lim_steps, s->d_stage_in,
+                     s->d_stage_out};
     for(void * p : ptrs)
     {
       if(p)
@@ -840,6 +847,7 @@ extern "C"
         NMPC_HIP_TRY(hipFree(s->d_lim_batch));
         s->d_lim_batch = nullptr;
       }
+      s->has_limits = s->has_shared_limits || s->d_lim_steps != nullptr; // back to what nmpc_hip_ddp_set_input_limits gave, if anything
       return NMPC_HIP_OK;
     }
     constexpr int kMax = nmpc_amd::hip::kMaxInputDim;
@@ -934,6 +942,55 @@ extern "C"
       s->lim_hi[i] = upper[i];
     }
     s->has_limits = true;
+    s->has_shared_limits = true;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_set_input_limits_horizon(nmpc_hip_ddp_handle s, const double * lower, const double * upper, int per_instance)
+  {
+    if(!s || (lower == nullptr) != (upper == nullptr))
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle, or only one of lower / upper given");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    NMPC_HIP_TRY(hipStreamSynchronize(s->stream));
+    if(!lower)
+    {
+      if(s->d_lim_steps)
+      {
+        NMPC_HIP_TRY(hipFree(s->d_lim_steps));
+        s->d_lim_steps = nullptr;
+      }
+      s->lim_steps_per_instance = 0;
+      s->has_limits = s->has_shared_limits || s->d_lim_batch != nullptr;
+      return NMPC_HIP_OK;
+    }
+    const size_t per_table = static_cast<size_t>(s->T) * s->MM;
+    const size_t n_tables = per_instance ? static_cast<size_t>(s->Bp) : 1;
+    // device layout [table][T][2][MM]; padding instances (b >= B) are unbounded
+    std::vector<double> host(n_tables * per_table * 2);
+    for(size_t tb = 0; tb < n_tables; tb++)
+    {
+      const bool valid = !per_instance || tb < static_cast<size_t>(s->B);
+      for(int i = 0; i < s->T; i++)
+      {
+        for(int a = 0; a < s->MM; a++)
+        {
+          const size_t src = (per_instance ? tb * per_table : 0) + static_cast<size_t>(i) * s->MM + a;
+          host[((tb * s->T + i) * 2 + 0) * s->MM + a] = valid ? lower[src] : -INFINITY;
+          host[((tb * s->T + i) * 2 + 1) * s->MM + a] = valid ? upper[src] : INFINITY;
+        }
+      }
+    }
+    if(s->d_lim_steps)
+    {
+      NMPC_HIP_TRY(hipFree(s->d_lim_steps));
+      s->d_lim_steps = nullptr;
+    }
+    NMPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_lim_steps), host.size() * sizeof(double)));
+    NMPC_HIP_TRY(hipMemcpy(s->d_lim_steps, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+    s->lim_steps_per_instance = per_instance ? 1 : 0;
+    s->has_limits = true;
     return NMPC_HIP_OK;
   }
 
@@ -997,6 +1054,12 @@ extern "C"
     if(s->elem != 8)
     {
       return fail(NMPC_HIP_ERR_RUNTIME, "the receding-horizon driver is served by the fp64 problem types");
+    }
+    if(s->d_lim_steps && opt->n_ticks > 1)
+    {
+      return fail(NMPC_HIP_ERR_RUNTIME, "time-varying input limits (set_input_limits_horizon) are sampled for ONE solve's "
+                                        "timesteps; the device-resident loop advances current_t, so it takes limits that "
+                                        "are constant in time");
     }
     if(!opt->shift_warm_start)
     {

@@ -129,10 +129,48 @@ class DDPSolverBatch:
 
     # ---- DDPSolver::setInputLimitsFunc  (DDPSolver.h:282-285) ----
     def setInputLimitsFunc(self, input_limits_func) -> None:
-        """input_limits_func(t) -> (lower, upper).  Only time-constant limits are supported on the device (the
-        only form the reference's callers use); the function is sampled once at t = 0."""
-        lo, up = input_limits_func(0.0)
-        self.setInputLimits(lo, up)
+        """input_limits_func(t) -> (lower, upper).  The reference evaluates it at every timestep of the backward pass,
+        input_limits_func_(current_t + i * dt) (DDPSolver.hpp:470-472); solve() samples it there, for every instance's own
+        current_t, and hands the device the constant pair when the samples agree and the sampled table otherwise
+        (nmpc_hip_ddp_set_input_limits_horizon)."""
+        self._limits_func = input_limits_func
+
+    def _sample_limits_func(self, t0: np.ndarray) -> None:
+        if getattr(self, "_limits_func", None) is None:
+            return
+        T = int(self._config.horizon_steps)
+        dt = float(self.problem.dt())
+        same_t0 = bool(np.all(t0 == t0[0]))
+        starts = t0[:1] if same_t0 else t0
+        lo = np.full((len(starts), T, self.mm), -np.inf)
+        up = np.full((len(starts), T, self.mm), np.inf)
+        for tb, ts in enumerate(starts):
+            for i in range(T):
+                l, u = self._limits_func(float(ts) + i * dt)
+                l = np.asarray(l, dtype=np.float64).ravel()
+                u = np.asarray(u, dtype=np.float64).ravel()
+                if l.size != u.size or l.size > self.mm:
+                    raise ValueError("input_limits_func should return vectors of the input dimension")
+                lo[tb, i, : l.size] = l
+                up[tb, i, : u.size] = u
+        self._limits = (lo[0, 0].copy(), up[0, 0].copy())
+        constant = bool(np.all(lo == lo[0, 0]) and np.all(up == up[0, 0]))
+        self._limits_horizon = None if constant else (np.ascontiguousarray(lo), np.ascontiguousarray(up), not same_t0)
+        self._limits_horizon_dirty = True
+
+    def setInputLimitsHorizon(self, lower, upper) -> None:
+        """Time-varying limits as tables: (T, MM) shared by every instance or (B, T, MM); None, None removes them."""
+        if lower is None and upper is None:
+            self._limits_horizon = None
+        else:
+            lo = np.ascontiguousarray(np.asarray(lower, dtype=np.float64))
+            up = np.ascontiguousarray(np.asarray(upper, dtype=np.float64))
+            T = int(self._config.horizon_steps)
+            if lo.shape != up.shape or lo.shape[-2:] != (T, self.mm) or lo.ndim not in (2, 3):
+                raise ValueError(f"limits tables should have shape ({T}, {self.mm}) or (B, {T}, {self.mm})")
+            self._limits_horizon = (lo, up, lo.ndim == 3)
+        self._limits_func = None
+        self._limits_horizon_dirty = True
 
     def setInputLimits(self, lower, upper) -> None:
         lo = np.full(self.mm, -np.inf)
@@ -199,6 +237,16 @@ class DDPSolverBatch:
             lo, up = self._limits
             _capi.check(self._L.nmpc_hip_ddp_set_input_limits(
                 self._h, lo.ctypes.data_as(C.POINTER(C.c_double)), up.ctypes.data_as(C.POINTER(C.c_double))))
+        if getattr(self, "_limits_horizon_dirty", False):
+            dp = C.POINTER(C.c_double)
+            hz = getattr(self, "_limits_horizon", None)
+            if hz is None:
+                _capi.check(self._L.nmpc_hip_ddp_set_input_limits_horizon(self._h, None, None, 0))
+            else:
+                lo, up, per_instance = hz
+                _capi.check(self._L.nmpc_hip_ddp_set_input_limits_horizon(self._h, lo.ctypes.data_as(dp), up.ctypes.data_as(dp),
+                                                                          1 if per_instance else 0))
+            self._limits_horizon_dirty = False
         if getattr(self, "_limits_batch_dirty", False):
             dp = C.POINTER(C.c_double)
             if self._limits_batch is None:
@@ -263,6 +311,7 @@ class DDPSolverBatch:
         B = self.batch_size
         t0 = np.broadcast_to(np.asarray(current_t, dtype=np.float64), (B,)).copy()
         x0 = np.ascontiguousarray(np.asarray(current_x, dtype=np.float64).reshape(B, self.n))
+        self._sample_limits_func(t0)
         self._push_state()
         u = self._pack_u(initial_u_list, t0)
         dp = C.POINTER(C.c_double)
@@ -286,6 +335,7 @@ class DDPSolverBatch:
         B = self.batch_size
         t0 = np.broadcast_to(np.asarray(current_t, dtype=np.float64), (B,)).copy()
         x0 = np.ascontiguousarray(np.asarray(current_x, dtype=np.float64).reshape(B, self.n))
+        self._sample_limits_func(t0)
         self._push_state()
         u = self._pack_u(initial_u_list, t0)
         opt = _capi.MpcOptions()

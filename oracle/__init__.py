@@ -221,6 +221,7 @@ class SolveResult:
 
 def solve(model: str, cfg: OracleConfig, x0, u_init, t0: float = 0.0, params=None,
           lower=None, upper=None) -> SolveResult:
+    """lower / upper: (MM,) constant limits, or (T, MM) tables of time-varying limits (input_limits_func_(t0 + i dt))."""
     n, mmax, _ = model_dims(model)
     mm = max(mmax, 1)
     T = cfg.horizon_steps
@@ -241,10 +242,11 @@ def solve(model: str, cfg: OracleConfig, x0, u_init, t0: float = 0.0, params=Non
     L = lib()
     L.oracle_ddp_solve.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(OracleConfig), C.c_double] + [
         C.POINTER(C.c_double)] * 10 + [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
-                                       C.POINTER(C.c_int), C.POINTER(C.c_uint)]
+                                       C.POINTER(C.c_int), C.POINTER(C.c_uint), C.c_int]
+    per_step = 1 if (lo is not None and lo.ndim == 2) else 0
     rc = L.oracle_ddp_solve(model.encode(), _dp(p), C.byref(cfg), t0, _dp(x0), _dp(u_init), _dp(lo), _dp(up),
                             _dp(X), _dp(U), _dp(cost), _dp(k), _dp(K), _dp(trace), C.byref(ntr), C.byref(status),
-                            _dp(dV), _ip(qret), qmask.ctypes.data_as(C.POINTER(C.c_uint)))
+                            _dp(dV), _ip(qret), qmask.ctypes.data_as(C.POINTER(C.c_uint)), per_step)
     if rc != 0:
         raise RuntimeError(f"oracle_ddp_solve failed: {rc}")
     return SolveResult(X, U, cost, k, K.transpose(0, 2, 1).copy(), trace[: ntr.value].copy(), status.value, dV,
@@ -292,10 +294,12 @@ def solve_batch(model: str, cfg: OracleConfig, x0, u_init, t0=None, params=None,
     L = lib(native, native_dir) if native else lib()
     L.oracle_ddp_solve_batch.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(OracleConfig), C.c_int] + [
         C.POINTER(C.c_double)] * 5 + [C.c_int] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_int)] * 2 + [
-        C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+        C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_int]
+    # limits: (MM,) constant, (T, MM) one time-varying table for all, (B, T, MM) one per instance
+    per_step = 0 if lo is None else {1: 0, 2: 1, 3: 2}[lo.ndim]
     rc = L.oracle_ddp_solve_batch(model.encode(), _dp(p), C.byref(cfg), B, _dp(t0), _dp(x0), _dp(u_init), _dp(lo),
                                   _dp(up), n_threads, _dp(X), _dp(U), _dp(cost), _dp(k), _dp(K), _ip(status),
-                                  _ip(iters), _dp(trl), _ip(hist), C.byref(tot), C.byref(sec))
+                                  _ip(iters), _dp(trl), _ip(hist), C.byref(tot), C.byref(sec), per_step)
     if rc != 0:
         raise RuntimeError(f"oracle_ddp_solve_batch failed: {rc}")
     return BatchResult(X, U, cost, k, None if K is None else K.transpose(0, 1, 3, 2).copy(), status, iters, trl,

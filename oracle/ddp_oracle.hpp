@@ -470,6 +470,17 @@ public:
   {
     lower_.assign(lower, lower + MMAX);
     upper_.assign(upper, upper + MMAX);
+    limits_per_step_ = false;
+  }
+
+  /** Input limits that vary in time: setInputLimitsFunc (DDPSolver.h:282-285) with the function sampled where the solver
+      evaluates it, input_limits_func_(current_t + i * dt) for i < horizon_steps (DDPSolver.hpp:470-472):
+      lower[T][MMAX], upper[T][MMAX]. */
+  void setInputLimitsPerStep(const Real * lower, const Real * upper, int T)
+  {
+    lower_.assign(lower, lower + static_cast<size_t>(T) * MMAX);
+    upper_.assign(upper, upper + static_cast<size_t>(T) * MMAX);
+    limits_per_step_ = true;
   }
 
   const ControlData & controlData() const
@@ -844,11 +855,12 @@ protected:
             }
           }
           Real lo[MM()], up[MM()];
-          (void)t; // limits are constant in time in this restatement
+          (void)t; // input_limits_func_(t): the constant pair, or row i of the table sampled at current_t + i dt    :470-472
+          const size_t lim_at = limits_per_step_ ? static_cast<size_t>(i) * MMAX : 0;
           for(int a = 0; a < m; a++)
           {
-            lo[a] = lower_.at(a) - control_.u[i * MM() + a];
-            up[a] = upper_.at(a) - control_.u[i * MM() + a];
+            lo[a] = lower_.at(lim_at + a) - control_.u[i * MM() + a];
+            up[a] = upper_.at(lim_at + a) - control_.u[i * MM() + a];
           }
           BoxQP qp;
           qp.solve(m, Quu_F, Qu, lo, up, initial_k);
@@ -1080,6 +1092,7 @@ protected:
   Config config_;
   std::vector<TraceRow> trace_;
   std::vector<Real> lower_, upper_;
+  bool limits_per_step_ = false;
   Real current_t_ = 0;
   Real lambda_ = 0;
   Real dlambda_ = 0;

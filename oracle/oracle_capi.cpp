@@ -349,7 +349,8 @@ extern "C"
                        int * status,
                        double * dV,
                        int * qp_retval,
-                       unsigned * qp_free_mask)
+                       unsigned * qp_free_mask,
+                       int limits_per_step /* 1: lower / upper are [T][MM] tables (time-varying limits), 0: [MM] */)
   {
     return dispatch(model,
                     [&](auto m)
@@ -370,7 +371,15 @@ extern "C"
                         {
                           return -2;
                         }
-                        solver.setInputLimits(toReal<R>(lower, MM).data(), toReal<R>(upper, MM).data());
+                        if(limits_per_step)
+                        {
+                          const size_t nl = static_cast<size_t>(cfg->horizon_steps) * MM;
+                          solver.setInputLimitsPerStep(toReal<R>(lower, nl).data(), toReal<R>(upper, nl).data(), cfg->horizon_steps);
+                        }
+                        else
+                        {
+                          solver.setInputLimits(toReal<R>(lower, MM).data(), toReal<R>(upper, MM).data());
+                        }
                       }
                       solver.solve(static_cast<R>(t0), toReal<R>(x0, N).data(),
                                    toReal<R>(u_init, static_cast<size_t>(cfg->horizon_steps) * MM).data());
@@ -465,7 +474,8 @@ extern "C"
                              double * trace_last,
                              int * alpha_idx_hist, /* [B][max_iter] or NULL */
                              long long * total_iters,
-                             double * seconds)
+                             double * seconds,
+                             int limits_per_step /* 0: [MM]; 1: one [T][MM] table for all; 2: [B][T][MM], one per instance */)
   {
     return dispatch(
         model,
@@ -515,9 +525,14 @@ extern "C"
             using R = typename M::Real;
             SolverOf<M> solver(m);
             toConfig(cfg, solver.config());
-            if(cfg->with_input_constraint)
+            const size_t nl = static_cast<size_t>(T) * MM;
+            if(cfg->with_input_constraint && limits_per_step == 0)
             {
               solver.setInputLimits(toReal<R>(lower, MM).data(), toReal<R>(upper, MM).data());
+            }
+            if(cfg->with_input_constraint && limits_per_step == 1)
+            {
+              solver.setInputLimitsPerStep(toReal<R>(lower, nl).data(), toReal<R>(upper, nl).data(), T);
             }
             std::vector<R> x0r(N), u0r(static_cast<size_t>(T) * MM);
             for(;;)
@@ -537,6 +552,11 @@ extern "C"
               for(size_t e = 0; e < u0r.size(); e++)
               {
                 u0r[e] = static_cast<R>(u_init[static_cast<size_t>(b) * T * MM + e]);
+              }
+              if(cfg->with_input_constraint && limits_per_step == 2)
+              {
+                solver.setInputLimitsPerStep(toReal<R>(lower + static_cast<size_t>(b) * nl, nl).data(),
+                                             toReal<R>(upper + static_cast<size_t>(b) * nl, nl).data(), T);
               }
               solver.solve(static_cast<R>(t0 ? t0[b] : 0.0), x0r.data(), u0r.data());
               const auto & cd = solver.controlData();

@@ -783,6 +783,103 @@ def test_per_instance_input_limits():
         assert np.array_equal(Xb, s.X()) and np.array_equal(itb, s.iters())
 
 
+@pytest.mark.parametrize("kernel", ["quad", "2w", "1w"])
+def test_time_varying_input_limits(kernel, monkeypatch):
+    """setInputLimitsFunc with limits that depend on t: the reference evaluates input_limits_func_(current_t + i dt) at every
+    timestep of the backward pass (DDPSolver.hpp:470-472).  A box that tightens along the horizon (+-18 N -> +-6 N, then a
+    step), every instance starting at its own current_t, on each lane mapping that serves box-constrained cart-poles;
+    compared with the oracle given the same per-timestep tables (BoxQP return codes and free sets of the last backward pass
+    included)."""
+    from nmpc_amd import workloads
+
+    monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", kernel)
+    wl = workloads.cartpole_batch(B=80, T=100, seed=31)
+    wl.t0 = np.linspace(0.0, 0.7, wl.B)  # a different current_t for every instance: one table per instance
+
+    def half_width(t):
+        return 6.0 + 12.0 * max(0.0, 1.0 - t / 1.2) - (2.0 if t > 0.9 else 0.0)
+
+    cfg = dict(with_input_constraint=True, max_iter=25)
+    s = make_solver(wl, **cfg)
+    s.setInputLimitsFunc(lambda t: (np.array([-half_width(t)]), np.array([half_width(t)])))
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert s.kernelName() == {"quad": "ddp_solve_quad_kernel", "2w": "ddp_solve_tpi2w_kernel", "1w": "ddp_solve_tpi_kernel"}[kernel]
+    lo = np.array([[[-half_width(t0 + i * wl.dt)] for i in range(wl.T)] for t0 in wl.t0])
+    ocfg = oracle.default_config(horizon_steps=wl.T, with_input_constraint=1, max_iter=25)
+    ref = oracle.solve_batch(wl.model, ocfg, wl.x0, wl.u_init, t0=wl.t0, lower=lo, upper=-lo, n_threads=8, want_alpha_hist=True)
+    # the limits bind and they differ from a constant box: the same solve with the loosest box ends elsewhere
+    loose = oracle.solve_batch(wl.model, ocfg, wl.x0, wl.u_init, t0=wl.t0, lower=np.array([-18.0]), upper=np.array([18.0]),
+                               n_threads=8)
+    assert np.abs(loose.U - ref.U).max() > 0.5
+    assert (np.abs(ref.U[:, :, 0]) >= np.abs(lo[:, :, 0]) - 1e-9).sum() > 20  # inputs sitting on the moving bound
+
+    def stable(eps_list):
+        keep = np.ones(wl.B, bool)
+        rng = np.random.default_rng(5)
+        for eps in eps_list:
+            r = oracle.solve_batch(wl.model, ocfg, wl.x0 * (1 + eps * rng.uniform(-1, 1, wl.x0.shape)), wl.u_init, t0=wl.t0,
+                                   lower=lo, upper=-lo, n_threads=8, want_alpha_hist=True)
+            keep &= (r.iters == ref.iters) & (r.status == ref.status) & (r.alpha_idx_hist == ref.alpha_idx_hist).all(axis=1)
+        return keep
+
+    mask = stable((1e-15, 3e-15, 1e-14, 3e-14, 1e-13, 1e-12))
+    print(f"[{kernel}] decision-stable: {int(mask.sum())} / {wl.B}")
+    assert mask.mean() >= 0.9
+    check_against_oracle(wl, s, ref, mask=mask)
+    qret, qfree = s.qpRetval(), s.qpFreeMask()
+    for b in np.flatnonzero(mask)[::9]:
+        r = oracle.solve(wl.model, ocfg, wl.x0[b], wl.u_init[b], t0=float(wl.t0[b]), lower=lo[b], upper=-lo[b])
+        if r.status >= 0:
+            np.testing.assert_array_equal(qret[b], r.qp_retval)
+            np.testing.assert_array_equal(qfree[b], r.qp_free_mask)
+    # the dropped instances still reach the same optimum
+    Jg, Jr = s.cost().sum(axis=1), ref.cost.sum(axis=1)
+    assert (np.abs(Jg - Jr) / np.abs(Jr)).max() <= 1e-3
+    # a function that happens to be constant takes the constant-limits path and equals setInputLimits bit for bit
+    s.setInputLimitsFunc(lambda t: (np.array([-15.0]), np.array([15.0])))
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    Xc = s.X().copy()
+    s2 = make_solver(wl, **cfg)
+    s2.setInputLimits(np.array([-15.0]), np.array([15.0]))
+    s2.solve(wl.t0, wl.x0, wl.u_init)
+    np.testing.assert_array_equal(Xc, s2.X())
+    # the device-resident loop advances current_t: it refuses a table sampled for one solve
+    s.setInputLimitsFunc(lambda t: (np.array([-half_width(t)]), np.array([half_width(t)])))
+    with pytest.raises(RuntimeError):
+        s.mpcRun(wl.t0, wl.x0, wl.u_init, n_ticks=3)
+
+
+def test_time_varying_input_limits_wave_per_instance_kernel():
+    """The same on the wave-per-instance kernel (quadrotor, rotor-thrust box that opens up along the horizon), one table for
+    the whole batch (every instance starts at t = 0)."""
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=48, T=50, seed=8)
+    hover = 9.80665 / 4
+    lo = np.array([[hover * (0.9 - 0.4 * i / wl.T)] * 4 for i in range(wl.T)])
+    up = np.array([[hover * (1.1 + 0.4 * i / wl.T)] * 4 for i in range(wl.T)])
+    cfg = dict(with_input_constraint=True, max_iter=6)
+    s = make_solver(wl, **cfg)
+    s.setInputLimitsHorizon(lo, up)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert s.kernelName() == "ddp_solve_wpi_kernel"
+    ocfg = oracle.default_config(horizon_steps=wl.T, with_input_constraint=1, max_iter=6)
+    ref = oracle.solve_batch(wl.model, ocfg, wl.x0, wl.u_init, t0=wl.t0, lower=lo, upper=up, n_threads=8, want_alpha_hist=True)
+    keep = np.ones(wl.B, bool)
+    rng = np.random.default_rng(6)
+    for eps in (1e-15, 3e-15, 1e-14, 3e-14, 1e-13, 1e-12):
+        r = oracle.solve_batch(wl.model, ocfg, wl.x0 * (1 + eps * rng.uniform(-1, 1, wl.x0.shape)), wl.u_init, t0=wl.t0,
+                               lower=lo, upper=up, n_threads=8, want_alpha_hist=True)
+        keep &= (r.iters == ref.iters) & (r.status == ref.status) & (r.alpha_idx_hist == ref.alpha_idx_hist).all(axis=1)
+        keep &= np.abs(r.U - ref.U).reshape(wl.B, -1).max(axis=1) <= 1e-7
+    print(f"decision-stable: {int(keep.sum())} / {wl.B}")
+    assert keep.mean() >= 0.6  # the oracle keeps 0.667: rotor-thrust box QPs are ill-conditioned (four near-identical actuators, DESIGN.md §3)
+    check_against_oracle(wl, s, ref, mask=keep)
+    # the dropped instances took a different branch somewhere in their six iterations (none has converged yet): same basin
+    Jg, Jr = s.cost().sum(axis=1), ref.cost.sum(axis=1)
+    assert (np.abs(Jg - Jr) / np.abs(Jr)).max() <= 1e-2
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """examples/c_api.c: the C-ABI used from C99 (gcc, no C++ on the caller's side) gives the Python mirror's numbers."""
     import os

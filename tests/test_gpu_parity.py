@@ -44,23 +44,64 @@ def scaled_err(got, want):
     return float((np.abs(got - want) / (1.0 + np.abs(want))).max())
 
 
-def decision_stable_mask(wl, ref, **cfg):
-    """Instances whose discrete decisions the ORACLE ITSELF keeps under 1e-15 .. 1e-13 relative perturbations of
+def decision_stable_mask(wl, ref, return_runs=False, **cfg):
+    """Instances whose discrete decisions the ORACLE ITSELF keeps under 1e-15 .. 1e-11 relative perturbations of
     x0.  The reference algorithm is not decision-stable everywhere: e.g. the box-constrained vertical-motion
     problem has two identical actuators (a degenerate QP), and a 1e-15 perturbation of the inputs flips BoxQP
     terminations and iteration counts of ~4 % of the instances in the Eigen-path restatement itself.  Bit-exact
-    index parity is only meaningful on the stable set (cf. the margin filter of SURVEY.md §8 c)."""
+    index parity is only meaningful on the stable set (cf. the margin filter of SURVEY.md §8 c).  return_runs: also the
+    perturbed oracle runs, for check_dropped()."""
     rng = np.random.default_rng(12345)
     stable = np.ones(wl.B, bool)
     ocfg = oracle.default_config(horizon_steps=wl.T, **{k: (int(v) if isinstance(v, bool) else v) for k, v in cfg.items()})
     lo, up = wl.limits if wl.limits is not None else (None, None)
+    runs = []
     for eps in (1e-15, 2e-15, 5e-15, 1e-14, 2e-14, 5e-14, 1e-13, 2e-13, 5e-13, 1e-12, 3e-12, 1e-11):
         x0p = wl.x0 * (1 + eps * rng.uniform(-1, 1, wl.x0.shape)) + 1e-300
         r = oracle.solve_batch(wl.model, ocfg, x0p, wl.u_init, t0=wl.t0, lower=lo, upper=up, n_threads=8,
                                want_alpha_hist=True)
+        runs.append(r)
         stable &= (r.iters == ref.iters) & (r.status == ref.status) & (r.alpha_idx_hist == ref.alpha_idx_hist).all(axis=1)
         stable &= np.abs(r.U - ref.U).reshape(wl.B, -1).max(axis=1) <= 1e-7 * (1 + np.abs(ref.U).reshape(wl.B, -1).max(axis=1))
-    return stable
+    return (stable, runs) if return_runs else stable
+
+
+def gpu_alpha_hist(s, ref):
+    tr = s.trace()
+    hist = np.full_like(ref.alpha_idx_hist, -2)
+    it = s.iters()
+    for b in range(hist.shape[0]):
+        n = min(int(it[b]), hist.shape[1])
+        hist[b, :n] = tr[b, 1:n + 1, 9].astype(np.int32)
+    return hist
+
+
+def check_dropped(label, wl, s, ref, mask, runs, floor, cost_tol=1e-6):
+    """What is asserted about the instances the stability mask drops, and about the mask itself: (1) the kept fraction is
+    printed and has a floor (a documented per-case number where the problem is ill-conditioned); (2) every dropped instance
+    either reproduces, decision for decision, one of the oracle's own runs from a rounding-level perturbation of x0 (the GPU
+    answer is one the reference algorithm gives), or it converged to the same optimum (relative cost <= cost_tol)."""
+    frac = float(mask.mean())
+    print(f"[{label}] decision-stable: {int(mask.sum())} / {wl.B} ({frac:.3f}); floor {floor}")
+    assert frac >= floor, f"{label}: the oracle itself keeps only {frac:.3f} of the instances"
+    dropped = np.flatnonzero(~mask)
+    if dropped.size == 0:
+        return
+    hist = gpu_alpha_hist(s, ref)
+    st, it, U = s.status(), s.iters(), s.U()
+    Jg, Jr = s.cost().sum(axis=1), ref.cost.sum(axis=1)
+    n_run, n_opt, bad = 0, 0, []
+    for b in dropped:
+        as_some_run = any(r.status[b] == st[b] and r.iters[b] == it[b] and np.array_equal(r.alpha_idx_hist[b], hist[b])
+                          and np.abs(r.U[b] - U[b]).max() <= 1e-6 * (1 + np.abs(U[b]).max()) for r in [ref] + runs)
+        same_opt = st[b] == 1 and ref.status[b] == 1 and abs(Jg[b] - Jr[b]) <= cost_tol * abs(Jr[b])
+        n_run += int(as_some_run)
+        n_opt += int(same_opt and not as_some_run)
+        if not (as_some_run or same_opt):
+            bad.append(int(b))
+    print(f"[{label}] dropped {dropped.size}: {n_run} reproduce one of the oracle's perturbed runs, {n_opt} more reach the same "
+          f"optimum, {len(bad)} neither {bad[:8]}")
+    return bad
 
 
 def check_against_oracle(wl, s, ref, check_gains=True, mask=None):
@@ -154,10 +195,11 @@ def test_vertical_motion_variable_input_dimension(constrained):
     for b in range(0, wl.B, 16):
         np.testing.assert_array_equal(dims[b], oracle.input_dims(wl.model, None, wl.t0[b], wl.T))
     # two identical actuators make the constrained QP degenerate: compare on the oracle's decision-stable set
-    mask = decision_stable_mask(wl, ref, initial_lambda=1e-6, with_input_constraint=constrained, max_iter=60)
-    assert mask.mean() > 0.75
-    if not constrained:
-        assert mask.all()
+    mask, runs = decision_stable_mask(wl, ref, return_runs=True, initial_lambda=1e-6, with_input_constraint=constrained,
+                                      max_iter=60)
+    # floors: the oracle keeps every unconstrained instance and 0.83 of the constrained ones (two identical actuators)
+    bad = check_dropped(f"vertical constrained={constrained}", wl, s, ref, mask, runs, 0.8 if constrained else 1.0, cost_tol=1e-6)
+    assert not bad
     check_against_oracle(wl, s, ref, mask=mask)
     # every converged instance, stable or not: same optimum to 1e-3 relative.  (Inputs may leave the box: like
     # the reference, the forward pass does not clamp u, DDPSolver.hpp:548 "todo"; callers clamp u[0].)
@@ -480,9 +522,9 @@ def test_quad_kernel_step_size_fan_out(monkeypatch):
     seen = set(np.unique(idx[idx >= 0]).tolist())
     assert {0, 1, 2, 10} <= seen and len(seen) >= 6, seen  # first trial, fan-out rounds, exhausted searches
     ref = oracle_batch(wl, **cfg)
-    mask = decision_stable_mask(wl, ref, **cfg)
-    print(f"decision-stable: {int(mask.sum())} / {wl.B}")
-    assert mask.mean() >= 0.9
+    mask, runs = decision_stable_mask(wl, ref, return_runs=True, **cfg)
+    bad = check_dropped("cart-pole +-15 N, fan-out", wl, s, ref, mask, runs, 0.9)
+    assert not bad
     check_against_oracle(wl, s, ref, mask=mask)
 
 
@@ -675,8 +717,10 @@ def test_wave_per_instance_kernel_box_constrained(model, monkeypatch):
     assert s.kernelName() == "ddp_solve_wpi_kernel"
     s.solve(wl.t0, wl.x0, wl.u_init)
     ref = oracle_batch(wl, **cfg)
-    stable = decision_stable_mask(wl, ref, **cfg)
-    assert stable.mean() >= 0.75
+    stable, runs = decision_stable_mask(wl, ref, return_runs=True, **cfg)
+    # floors: ill-conditioned box QPs — the oracle keeps 0.92 (rotor thrusts) / 0.84 (joint torques)
+    bad = check_dropped(f"{model} box", wl, s, ref, stable, runs, 0.75, cost_tol=1e-6)
+    assert len(bad) <= 2, bad  # (ten iterations: not converged yet, so an unsampled branch cannot show the same optimum)
     check_against_oracle(wl, s, ref, mask=stable)
     ocfg = oracle.default_config(horizon_steps=wl.T, with_input_constraint=1, max_iter=10)
     qret, qfree = s.qpRetval(), s.qpFreeMask()
@@ -772,7 +816,10 @@ def test_per_instance_input_limits():
                     flips |= rp.status != r.status or rp.iters != r.iters or np.abs(rp.U - r.U).max() > 1e-6
                 assert flips, f"{wl.model} instance {b}: GPU and oracle disagree on a decision-stable instance"
             agree += int(ok)
-        assert agree >= 0.6 * wl.B
+        # every disagreement above was shown to be an instance on which the oracle contradicts itself; the rest agree exactly.
+        # Documented fractions: cart-pole 0.9+, manipulator with per-instance torque boxes 0.67 (16 / 24: DESIGN.md §3)
+        print(f"[per-instance limits, {wl.model}] exact agreement on {agree} / {wl.B} instances")
+        assert agree >= (0.85 if wl.model == "cartpole" else 0.6) * wl.B
         # the same box for everyone through the batch entry point == the shared entry point, bit for bit
         s.setInputLimitsBatch(np.repeat(lo[:1], wl.B, 0), np.repeat(up[:1], wl.B, 0))
         s.solve(wl.t0, wl.x0, wl.u_init)

@@ -122,6 +122,9 @@ public:
     double solve = 0; //!< H2D + layout conversion + solve kernel (HIP events)
     double setup = 0; //!< solve - opt
     double opt = 0; //!< solve kernel alone
+    //! `opt` split by the shader-clock shares of the kernel's phases (nmpc_hip_ddp_last_solve_phases).  The linearisation is
+    //! fused into the backward sweep: derivative / Q / reg / gain of DDPSolver.h:219-247 are parts of `backward` and stay 0.
+    double derivative = 0, backward = 0, forward = 0, Q = 0, reg = 0, gain = 0;
   };
 
 public:
@@ -595,6 +598,8 @@ protected:
     computation_duration_.solve = total_ms;
     computation_duration_.opt = kernel_ms;
     computation_duration_.setup = total_ms - kernel_ms;
+    double other_ms = 0;
+    check(nmpc_hip_ddp_last_solve_phases(handle_, &computation_duration_.backward, &computation_duration_.forward, &other_ms));
     fetched_ = true;
   }
 

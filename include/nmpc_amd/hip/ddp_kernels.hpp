@@ -62,6 +62,10 @@ struct DeviceBuffersT
   int * input_dim; //!< [tile][T][64]
   S * wpi_ws; //!< per-instance workspace [B][ModelOps::wpi_workspace_doubles(T)] elements of S: wave-per-instance kernel
              //!< (ddp_kernels_wpi.hpp: derivatives, gains, candidates), fp32 tile kernel (ddp_kernels_tile32.hpp: gains)
+  //! [Bp][4] shader-clock ticks of the last solve as seen by the wave that drives instance b: backward passes (with the
+  //! linearisation fused into them), forward passes (rollouts of the line search), whole solve, reserved; or nullptr.
+  //! The split of computationDuration() (DDPSolver.h:219-247) is taken from these shares of the kernel's HIP-event time.
+  unsigned long long * phase_ticks;
   const unsigned char * params_batch; //!< per-instance problem objects [Bp][sizeof(Problem)], or nullptr: one for all
   const double * lim_batch; //!< per-instance input limits [Bp][2][kMaxInputDim] (lower, upper), or nullptr: lim_lo / lim_hi
   //! time-varying input limits, input_limits_func_(current_t + i dt) of DDPSolver.hpp:470-472 sampled per timestep:
@@ -1341,6 +1345,7 @@ struct InstanceSolver
 
   NMPC_D void solve()
   {
+    unsigned long long ph_start = __builtin_readcyclecounter(), ph_bw = 0, ph_fw = 0, ph_t0 = 0;
     current_t = buf.t0 ? buf.t0[b] : 0.0;
     lambda = cfg.initial_lambda; // :37
     dlambda = cfg.initial_dlambda; // :38
@@ -1379,6 +1384,7 @@ struct InstanceSolver
       // Step 2 (with Step 1 fused in): backward pass with regularisation retries    :188-214
       int n_backward = 1;
       bool bw_failed = false;
+      ph_t0 = __builtin_readcyclecounter();
       while(!backwardPass())
       {
         dlambda = fmax(dlambda * cfg.lambda_factor, cfg.lambda_factor);
@@ -1390,6 +1396,7 @@ struct InstanceSolver
         }
         n_backward++;
       }
+      ph_bw += __builtin_readcyclecounter() - ph_t0;
       tr[NMPC_HIP_TRACE_N_BACKWARD] = n_backward;
       if(bw_failed)
       {
@@ -1411,7 +1418,9 @@ struct InstanceSolver
           for(ai = 0; ai < cfg.n_alpha; ai++)
           {
             alpha = cfg.alpha_list[ai];
+            ph_t0 = __builtin_readcyclecounter();
             forwardPass(alpha);
+            ph_fw += __builtin_readcyclecounter() - ph_t0;
             cost_update_actual = J_cur - J_cand;
             cost_update_expected = -1 * alpha * (dV0 + alpha * dV1);
             cost_update_ratio = cost_update_actual / cost_update_expected;
@@ -1477,6 +1486,13 @@ struct InstanceSolver
     for(int f = 0; f < NMPC_HIP_NTRACE; f++)
     {
       elem(buf.trace_last, NMPC_HIP_NTRACE, f) = tr[f];
+    }
+    if(buf.phase_ticks != nullptr)
+    {
+      unsigned long long * p = buf.phase_ticks + static_cast<size_t>(b) * 4;
+      p[0] = ph_bw;
+      p[1] = ph_fw;
+      p[2] = __builtin_readcyclecounter() - ph_start;
     }
     buf.status[b] = retval;
     buf.iters[b] = static_cast<int>(tr[NMPC_HIP_TRACE_ITER]);

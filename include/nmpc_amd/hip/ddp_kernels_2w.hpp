@@ -181,9 +181,38 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  NMPC_D void profBegin() const {}
-  NMPC_D void profEnd(int) const {}
+  // product builds: two accumulators per wave (backward passes, forward passes), read by the master at the end of the solve
+  // (phaseFlush); the timestamps sit at pass boundaries, next to the workgroup barriers
+  mutable unsigned long long phase_t0 = 0, phase_start = 0;
+  mutable unsigned long long phase_acc[2] = {0, 0};
+  NMPC_D void profBegin() const
+  {
+    phase_t0 = __builtin_readcyclecounter();
+  }
+  NMPC_D void profEnd(int kind) const
+  {
+    phase_acc[kind] += __builtin_readcyclecounter() - phase_t0;
+  }
   NMPC_D void profFlush(int) const {}
+#endif
+#ifdef NMPC_AMD_PROFILE_2W
+  NMPC_D void phaseStart() const {}
+  NMPC_D void phaseFlush(bool) const {}
+#else
+  NMPC_D void phaseStart() const
+  {
+    phase_start = __builtin_readcyclecounter();
+  }
+  NMPC_D void phaseFlush(bool valid) const
+  {
+    if(valid && buf.phase_ticks != nullptr)
+    {
+      unsigned long long * p = buf.phase_ticks + static_cast<size_t>(b) * 4;
+      p[0] = phase_acc[0];
+      p[1] = phase_acc[1];
+      p[2] = __builtin_readcyclecounter() - phase_start;
+    }
+  }
 #endif
 
   // ===================================================================================================
@@ -1250,8 +1279,11 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     dV0 = dV1 = 0;
     k_rel_norm = 0;
     J_cand = 0;
+    phaseStart();
     post(kCmdRollout);
+    profBegin();
     rolloutMaster();
+    profEnd(1);
 
     double tr[NMPC_HIP_NTRACE];
 #pragma unroll
@@ -1424,6 +1456,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     }
     post(kCmdExit);
     profFlush(0);
+    phaseFlush(valid);
 
     if(valid)
     {
@@ -1453,8 +1486,11 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     dV0 = dV1 = 0;
     k_rel_norm = 0;
     J_cand = 0;
+    phaseStart();
     post(kCmdRollout);
+    profBegin();
     rolloutMaster();
+    profEnd(1);
 
     // The trace row of an iteration is assembled and written at its end; the last row of every lane waits in LDS for the
     // end of the solve (in registers it is 24 VGPRs that are live across every pass; written to HBM every iteration it is
@@ -1705,6 +1741,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     }
     post(kCmdExit);
     profFlush(0);
+    phaseFlush(valid);
 
     if(valid)
     {

@@ -1012,14 +1012,25 @@ struct TileSolver32
     }
   }
 #else
-  NMPC_D void profBegin() const {}
-  NMPC_D void profEnd(int) const {}
+  // product builds: ticks of the sweeps / rollouts seen by the model wave, per instance into DeviceBuffers::phase_ticks
+  mutable unsigned long long prof_acc[4] = {0, 0, 0, 0};
+  mutable unsigned long long prof_t0 = 0;
+  NMPC_D void profBegin() const
+  {
+    prof_t0 = __builtin_readcyclecounter();
+  }
+  NMPC_D void profEnd(int k) const
+  {
+    prof_acc[k] += __builtin_readcyclecounter() - prof_t0;
+  }
   NMPC_D void profCount(int) const {}
   NMPC_D void profFlush() const {}
 #endif
 
   NMPC_D void solve()
   {
+    const unsigned long long solve_start = __builtin_readcyclecounter();
+    (void)solve_start;
     const bool model_wave = (wave == kTileModelWave);
     const int slot = lane & (kTileInstances - 1);
     const int b = static_cast<int>(blockIdx.x) * kTileInstances + slot;
@@ -1339,6 +1350,15 @@ struct TileSolver32
       buf.status[b] = retval;
       buf.iters[b] = iter;
       buf.sel[b] = sel;
+#ifndef NMPC_AMD_PROFILE_TILE32
+      if(buf.phase_ticks != nullptr)
+      {
+        unsigned long long * p = buf.phase_ticks + static_cast<size_t>(b) * 4;
+        p[0] = prof_acc[1];
+        p[1] = prof_acc[0] + prof_acc[2] + prof_acc[3];
+        p[2] = __builtin_readcyclecounter() - solve_start;
+      }
+#endif
       buf.dV[(tile * 2 + 0) * 64 + ln] = dV0;
       buf.dV[(tile * 2 + 1) * 64 + ln] = dV1;
 #pragma unroll
@@ -1410,6 +1430,7 @@ struct ModelOpsTile32
     buf.qp_free = buf64.qp_free;
     buf.input_dim = buf64.input_dim;
     buf.wpi_ws = reinterpret_cast<float *>(buf64.wpi_ws);
+    buf.phase_ticks = buf64.phase_ticks;
     buf.params_batch = nullptr;
     buf.lim_batch = nullptr;
     buf.lim_steps = nullptr;

@@ -1489,9 +1489,28 @@ struct WaveSolver
     }
   }
 #else
-  NMPC_D void profBegin() const {}
-  NMPC_D void profEnd(int) const {}
-  NMPC_D void profFlush() const {}
+  // product builds: ticks per phase (0 initial rollout, 1 linearise, 2 backward, 3 line search, 4 adopt, 5 write-out), folded
+  // into DeviceBuffers::phase_ticks at the end of the solve
+  mutable unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
+  mutable unsigned long long prof_t0 = 0;
+  NMPC_D void profBegin() const
+  {
+    prof_t0 = __builtin_readcyclecounter();
+  }
+  NMPC_D void profEnd(int k) const
+  {
+    prof_acc[k] += __builtin_readcyclecounter() - prof_t0;
+  }
+  NMPC_D void profFlush() const
+  {
+    if(lane == 0 && buf.phase_ticks != nullptr)
+    {
+      unsigned long long * p = buf.phase_ticks + static_cast<size_t>(b) * 4;
+      p[0] = prof_acc[1] + prof_acc[2];
+      p[1] = prof_acc[0] + prof_acc[3] + prof_acc[4];
+      p[2] = prof_acc[0] + prof_acc[1] + prof_acc[2] + prof_acc[3] + prof_acc[4] + prof_acc[5];
+    }
+  }
 #endif
 
   NMPC_D BackwardResult runBackward(double lambda) const

@@ -191,10 +191,224 @@ struct Extents<true, true>
 };
 } // namespace detail
 
+template<class Scalar, int RMAX, int CMAX, bool DynRows = false, bool DynCols = false>
+class Matrix;
+
+// ---------------------------------------------------------------------------------------------------------------
+// The subset of Eigen's block / initialiser syntax the reference's problem classes are written in
+// (nmpc_ddp/tests/src/TestDDPCentroidalMotion.cpp:64-136, TestDDPCartPole.cpp:100-227): segment / head / tail / block /
+// middleRows / col / diagonal views, `m << a, b, c`, asDiagonal(), cross, transpose, products, cwiseMin / cwiseMax,
+// Constant / Zero / Identity — evaluated eagerly on the small fixed-capacity types above (no expression templates: every
+// operator returns a value, which after inlining is what Eigen's lazy products compile to for these sizes).  With it a
+// reference problem body carries over statement for statement (tests/cpp/CentroidalMotionEigenStyle.hpp).
+// ---------------------------------------------------------------------------------------------------------------
+/** Writable view of R x (up to CMAX) entries of a column-major matrix: Eigen's Block / Ref for fixed R. */
+template<class Scalar, int R, int CMAX>
+class Block
+{
+public:
+  NMPC_HD Block(Scalar * p, int ld, int cols = CMAX) : p_(p), ld_(ld), cols_(cols) {}
+  NMPC_HD int rows() const
+  {
+    return R;
+  }
+  NMPC_HD int cols() const
+  {
+    return cols_;
+  }
+  NMPC_HD int size() const
+  {
+    return R * cols_;
+  }
+  NMPC_HD Scalar & operator()(int r, int c) const
+  {
+    return p_[r + c * ld_];
+  }
+  NMPC_HD Scalar & operator[](int i) const // vectors: a column (CMAX == 1) or a row (R == 1)
+  {
+    return (CMAX == 1) ? p_[i] : p_[i * ld_];
+  }
+  template<bool DR, bool DC>
+  NMPC_HD const Block & operator=(const Matrix<Scalar, R, CMAX, DR, DC> & m) const
+  {
+    for(int c = 0; c < cols_; c++)
+    {
+      NMPC_UNROLL
+      for(int r = 0; r < R; r++)
+      {
+        (*this)(r, c) = m(r, c);
+      }
+    }
+    return *this;
+  }
+  NMPC_HD const Block & operator=(const Block & o) const
+  {
+    for(int c = 0; c < cols_; c++)
+    {
+      NMPC_UNROLL
+      for(int r = 0; r < R; r++)
+      {
+        (*this)(r, c) = o(r, c);
+      }
+    }
+    return *this;
+  }
+  template<bool DR, bool DC>
+  NMPC_HD const Block & operator+=(const Matrix<Scalar, R, CMAX, DR, DC> & m) const
+  {
+    for(int c = 0; c < cols_; c++)
+    {
+      NMPC_UNROLL
+      for(int r = 0; r < R; r++)
+      {
+        (*this)(r, c) += m(r, c);
+      }
+    }
+    return *this;
+  }
+  template<bool DR, bool DC>
+  NMPC_HD const Block & operator-=(const Matrix<Scalar, R, CMAX, DR, DC> & m) const
+  {
+    for(int c = 0; c < cols_; c++)
+    {
+      NMPC_UNROLL
+      for(int r = 0; r < R; r++)
+      {
+        (*this)(r, c) -= m(r, c);
+      }
+    }
+    return *this;
+  }
+  NMPC_HD const Block & setConstant(Scalar v) const
+  {
+    for(int c = 0; c < cols_; c++)
+    {
+      NMPC_UNROLL
+      for(int r = 0; r < R; r++)
+      {
+        (*this)(r, c) = v;
+      }
+    }
+    return *this;
+  }
+  NMPC_HD const Block & setZero() const
+  {
+    return setConstant(Scalar(0));
+  }
+  NMPC_HD Block<Scalar, R, 1> col(int c) const
+  {
+    return Block<Scalar, R, 1>(p_ + c * ld_, ld_);
+  }
+  /** The main diagonal as a strided vector view (setConstant, array() += v). */
+  struct Diagonal
+  {
+    Scalar * p;
+    int stride, n;
+    NMPC_HD const Diagonal & setConstant(Scalar v) const
+    {
+      for(int i = 0; i < n; i++)
+      {
+        p[i * stride] = v;
+      }
+      return *this;
+    }
+    NMPC_HD const Diagonal & array() const
+    {
+      return *this;
+    }
+    NMPC_HD const Diagonal & operator+=(Scalar v) const
+    {
+      for(int i = 0; i < n; i++)
+      {
+        p[i * stride] += v;
+      }
+      return *this;
+    }
+    NMPC_HD Scalar & operator[](int i) const
+    {
+      return p[i * stride];
+    }
+  };
+  NMPC_HD Diagonal diagonal() const
+  {
+    return Diagonal{p_, ld_ + 1, R < cols_ ? R : cols_};
+  }
+  /** The viewed entries as a value; arithmetic on a view goes through it. */
+  NMPC_HD Matrix<Scalar, R, CMAX, false, false> eval() const;
+  NMPC_HD operator Matrix<Scalar, R, CMAX, false, false>() const;
+  NMPC_HD Matrix<Scalar, R, CMAX, false, false> operator-(const Matrix<Scalar, R, CMAX, false, false> & o) const;
+  NMPC_HD Matrix<Scalar, R, CMAX, false, false> operator+(const Matrix<Scalar, R, CMAX, false, false> & o) const;
+  NMPC_HD Matrix<Scalar, R, CMAX, false, false> operator*(Scalar v) const;
+  NMPC_HD Matrix<Scalar, R, CMAX, false, false> operator/(Scalar v) const;
+  NMPC_HD Matrix<Scalar, R, CMAX, false, false> cross(const Matrix<Scalar, R, CMAX, false, false> & o) const;
+  NMPC_HD Scalar dot(const Matrix<Scalar, R, CMAX, false, false> & o) const;
+
+private:
+  Scalar * p_;
+  int ld_, cols_;
+};
+
+/** vec.asDiagonal(): assignable to a square matrix. */
+template<class Scalar, int N>
+struct DiagonalWrapper
+{
+  Scalar d[N > 0 ? N : 1];
+};
+
+/** `m << a, b, c;`  Scalars and vectors / matrices fill the target in Eigen's order: vectors entry by entry, matrices row by
+    row with blocks placed left to right (only what the reference's problem classes use: scalars into anything, vectors into
+    vectors). */
+template<class Target>
+class CommaInitializer
+{
+public:
+  using Scalar = typename Target::ScalarType;
+  NMPC_HD CommaInitializer(Target & t, int at) : t_(t), at_(at) {}
+  NMPC_HD CommaInitializer & operator,(Scalar v)
+  {
+    put(v);
+    return *this;
+  }
+  template<int RM, bool DR>
+  NMPC_HD CommaInitializer & operator,(const Matrix<Scalar, RM, 1, DR, false> & v)
+  {
+    for(int i = 0; i < v.rows(); i++)
+    {
+      put(v[i]);
+    }
+    return *this;
+  }
+  template<int K>
+  NMPC_HD CommaInitializer & operator,(const Block<Scalar, K, 1> & v)
+  {
+    for(int i = 0; i < K; i++)
+    {
+      put(v[i]);
+    }
+    return *this;
+  }
+  NMPC_HD void put(Scalar v)
+  {
+    if(Target::kColsMax == 1)
+    {
+      t_[at_] = v;
+    }
+    else
+    {
+      t_(at_ / t_.cols(), at_ % t_.cols()) = v; // row by row, as Eigen fills a matrix
+    }
+    at_++;
+  }
+
+private:
+  Target & t_;
+  int at_;
+};
+
 /** Column-major matrix with capacity RMAX x CMAX (leading dimension RMAX) and optional run-time extents.
     \tparam DynRows rows() is a run-time value <= RMAX
     \tparam DynCols cols() is a run-time value <= CMAX */
-template<class Scalar, int RMAX, int CMAX, bool DynRows = false, bool DynCols = false>
+template<class Scalar, int RMAX, int CMAX, bool DynRows, bool DynCols>
 class Matrix : private detail::Extents<DynRows, DynCols>
 {
   using Ext = detail::Extents<DynRows, DynCols>;
@@ -399,9 +613,321 @@ public:
     return cwiseProduct(*this);
   }
 
+  // ---- the Eigen subset (see Block above) ----
+  using ScalarType = Scalar;
+  //! Vector3(x, y, z)
+  NMPC_HD Matrix(Scalar a, Scalar b, Scalar c) : Ext(RMAX, CMAX)
+  {
+    static_assert(RMAX == 3 && CMAX == 1, "three coefficients: a 3-vector");
+    d_[0] = a;
+    d_[1] = b;
+    d_[2] = c;
+  }
+  NMPC_HD Scalar x() const
+  {
+    return d_[0];
+  }
+  NMPC_HD Scalar y() const
+  {
+    return d_[1];
+  }
+  NMPC_HD Scalar z() const
+  {
+    return d_[2];
+  }
+  NMPC_HD static Matrix Constant(Scalar v)
+  {
+    Matrix m;
+    m.setConstant(v);
+    return m;
+  }
+  NMPC_HD static Matrix Zero()
+  {
+    return Constant(Scalar(0));
+  }
+  NMPC_HD static Matrix Identity()
+  {
+    Matrix m;
+    m.setIdentity();
+    return m;
+  }
+  NMPC_HD CommaInitializer<Matrix> operator<<(Scalar v)
+  {
+    CommaInitializer<Matrix> ci(*this, 0);
+    ci.put(v);
+    return ci;
+  }
+  template<int RM, bool DR>
+  NMPC_HD CommaInitializer<Matrix> operator<<(const Matrix<Scalar, RM, 1, DR, false> & v)
+  {
+    CommaInitializer<Matrix> ci(*this, 0);
+    ci, v;
+    return ci;
+  }
+  template<int K>
+  NMPC_HD CommaInitializer<Matrix> operator<<(const Block<Scalar, K, 1> & v)
+  {
+    CommaInitializer<Matrix> ci(*this, 0);
+    ci, v;
+    return ci;
+  }
+  NMPC_HD Matrix & operator=(const DiagonalWrapper<Scalar, (RMAX < CMAX ? RMAX : CMAX)> & dw)
+  {
+    setZero();
+    constexpr int kDiag = RMAX < CMAX ? RMAX : CMAX;
+    NMPC_UNROLL
+    for(int i = 0; i < kDiag; i++)
+    {
+      d_[i + i * RMAX] = dw.d[i];
+    }
+    return *this;
+  }
+  NMPC_HD DiagonalWrapper<Scalar, RMAX> asDiagonal() const
+  {
+    static_assert(CMAX == 1, "asDiagonal() of a vector");
+    DiagonalWrapper<Scalar, RMAX> dw;
+    NMPC_UNROLL
+    for(int i = 0; i < RMAX; i++)
+    {
+      dw.d[i] = d_[i];
+    }
+    return dw;
+  }
+  // vector pieces: values from a const object, writable views from a mutable one
+  template<int K>
+  NMPC_HD Matrix<Scalar, K, 1> segment(int at) const
+  {
+    Matrix<Scalar, K, 1> r;
+    NMPC_UNROLL
+    for(int i = 0; i < K; i++)
+    {
+      r[i] = d_[at + i];
+    }
+    return r;
+  }
+  template<int K>
+  NMPC_HD Block<Scalar, K, 1> segment(int at)
+  {
+    return Block<Scalar, K, 1>(d_ + at, RMAX);
+  }
+  template<int K>
+  NMPC_HD Matrix<Scalar, K, 1> head() const
+  {
+    return this->template segment<K>(0);
+  }
+  template<int K>
+  NMPC_HD Block<Scalar, K, 1> head()
+  {
+    return this->template segment<K>(0);
+  }
+  template<int K>
+  NMPC_HD Matrix<Scalar, K, 1> tail() const
+  {
+    return this->template segment<K>(rows() - K);
+  }
+  template<int K>
+  NMPC_HD Block<Scalar, K, 1> tail()
+  {
+    return this->template segment<K>(rows() - K);
+  }
+  // matrix pieces
+  NMPC_HD Matrix<Scalar, RMAX, 1, DynRows, false> col(int c) const
+  {
+    Matrix<Scalar, RMAX, 1, DynRows, false> r(rows());
+    NMPC_UNROLL
+    for(int i = 0; i < RMAX; i++)
+    {
+      r[i] = d_[i + c * RMAX];
+    }
+    return r;
+  }
+  NMPC_HD Block<Scalar, RMAX, 1> col(int c)
+  {
+    static_assert(!DynRows, "column views of matrices with a fixed number of rows");
+    return Block<Scalar, RMAX, 1>(d_ + c * RMAX, RMAX);
+  }
+  template<int BR, int BC>
+  NMPC_HD Matrix<Scalar, BR, BC> block(int r0, int c0) const
+  {
+    Matrix<Scalar, BR, BC> r;
+    NMPC_UNROLL
+    for(int c = 0; c < BC; c++)
+    {
+      NMPC_UNROLL
+      for(int i = 0; i < BR; i++)
+      {
+        r(i, c) = (*this)(r0 + i, c0 + c);
+      }
+    }
+    return r;
+  }
+  template<int BR, int BC>
+  NMPC_HD Block<Scalar, BR, BC> block(int r0, int c0)
+  {
+    return Block<Scalar, BR, BC>(d_ + r0 + c0 * RMAX, RMAX);
+  }
+  template<int BR>
+  NMPC_HD Block<Scalar, BR, CMAX> middleRows(int r0)
+  {
+    return Block<Scalar, BR, CMAX>(d_ + r0, RMAX, cols());
+  }
+  NMPC_HD typename Block<Scalar, RMAX, CMAX>::Diagonal diagonal()
+  {
+    return Block<Scalar, RMAX, CMAX>(d_, RMAX, cols()).diagonal();
+  }
+  NMPC_HD Matrix<Scalar, CMAX, RMAX, DynCols, DynRows> transpose() const
+  {
+    Matrix<Scalar, CMAX, RMAX, DynCols, DynRows> r(cols(), rows());
+    NMPC_UNROLL
+    for(int c = 0; c < CMAX; c++)
+    {
+      NMPC_UNROLL
+      for(int i = 0; i < RMAX; i++)
+      {
+        r(c, i) = (*this)(i, c);
+      }
+    }
+    return r;
+  }
+  NMPC_HD Matrix cross(const Matrix & o) const
+  {
+    static_assert(RMAX == 3 && CMAX == 1, "cross product of 3-vectors");
+    Matrix r;
+    r[0] = d_[1] * o.d_[2] - d_[2] * o.d_[1];
+    r[1] = d_[2] * o.d_[0] - d_[0] * o.d_[2];
+    r[2] = d_[0] * o.d_[1] - d_[1] * o.d_[0];
+    return r;
+  }
+  NMPC_HD void normalize()
+  {
+    const Scalar n = norm();
+    NMPC_UNROLL
+    for(int i = 0; i < kCapacity; i++)
+    {
+      d_[i] = d_[i] / n;
+    }
+  }
+  NMPC_HD Matrix cwiseMin(const Matrix & o) const
+  {
+    Matrix r(*this);
+    NMPC_UNROLL
+    for(int i = 0; i < kCapacity; i++)
+    {
+      r.d_[i] = o.d_[i] < r.d_[i] ? o.d_[i] : r.d_[i];
+    }
+    return r;
+  }
+  NMPC_HD Matrix cwiseMax(const Matrix & o) const
+  {
+    Matrix r(*this);
+    NMPC_UNROLL
+    for(int i = 0; i < kCapacity; i++)
+    {
+      r.d_[i] = o.d_[i] > r.d_[i] ? o.d_[i] : r.d_[i];
+    }
+    return r;
+  }
+  NMPC_HD Matrix operator-() const
+  {
+    Matrix r(*this);
+    NMPC_UNROLL
+    for(int i = 0; i < kCapacity; i++)
+    {
+      r.d_[i] = -r.d_[i];
+    }
+    return r;
+  }
+  NMPC_HD Matrix operator*(Scalar s) const
+  {
+    Matrix r(*this);
+    r *= s;
+    return r;
+  }
+  NMPC_HD Matrix operator/(Scalar s) const
+  {
+    Matrix r(*this);
+    NMPC_UNROLL
+    for(int i = 0; i < kCapacity; i++)
+    {
+      r.d_[i] = r.d_[i] / s;
+    }
+    return r;
+  }
+  /** Matrix product, contraction in ascending index order over this->cols() (run-time when the inner dimension is). */
+  template<int C2, bool DR2, bool DC2>
+  NMPC_HD Matrix<Scalar, RMAX, C2, DynRows, DC2> operator*(const Matrix<Scalar, CMAX, C2, DR2, DC2> & o) const
+  {
+    Matrix<Scalar, RMAX, C2, DynRows, DC2> r(rows(), o.cols());
+    NMPC_UNROLL
+    for(int c = 0; c < C2; c++)
+    {
+      NMPC_UNROLL
+      for(int i = 0; i < RMAX; i++)
+      {
+        Scalar acc = 0;
+        for(int k = 0; k < cols(); k++)
+        {
+          acc += (*this)(i, k) * o(k, c);
+        }
+        r(i, c) = acc;
+      }
+    }
+    return r;
+  }
+
 private:
   Scalar d_[kCapacity];
 };
+
+template<class Scalar, int R, int CMAX>
+NMPC_HD Matrix<Scalar, R, CMAX, false, false> Block<Scalar, R, CMAX>::eval() const
+{
+  Matrix<Scalar, R, CMAX, false, false> m;
+  for(int c = 0; c < CMAX; c++)
+  {
+    NMPC_UNROLL
+    for(int r = 0; r < R; r++)
+    {
+      m(r, c) = (c < cols_) ? (*this)(r, c) : Scalar(0);
+    }
+  }
+  return m;
+}
+template<class Scalar, int R, int CMAX>
+NMPC_HD Block<Scalar, R, CMAX>::operator Matrix<Scalar, R, CMAX, false, false>() const
+{
+  return eval();
+}
+template<class Scalar, int R, int CMAX>
+NMPC_HD Matrix<Scalar, R, CMAX, false, false> Block<Scalar, R, CMAX>::operator-(const Matrix<Scalar, R, CMAX, false, false> & o) const
+{
+  return eval() - o;
+}
+template<class Scalar, int R, int CMAX>
+NMPC_HD Matrix<Scalar, R, CMAX, false, false> Block<Scalar, R, CMAX>::operator+(const Matrix<Scalar, R, CMAX, false, false> & o) const
+{
+  return eval() + o;
+}
+template<class Scalar, int R, int CMAX>
+NMPC_HD Matrix<Scalar, R, CMAX, false, false> Block<Scalar, R, CMAX>::operator*(Scalar v) const
+{
+  return eval() * v;
+}
+template<class Scalar, int R, int CMAX>
+NMPC_HD Matrix<Scalar, R, CMAX, false, false> Block<Scalar, R, CMAX>::operator/(Scalar v) const
+{
+  return eval() / v;
+}
+template<class Scalar, int R, int CMAX>
+NMPC_HD Matrix<Scalar, R, CMAX, false, false> Block<Scalar, R, CMAX>::cross(const Matrix<Scalar, R, CMAX, false, false> & o) const
+{
+  return eval().cross(o);
+}
+template<class Scalar, int R, int CMAX>
+NMPC_HD Scalar Block<Scalar, R, CMAX>::dot(const Matrix<Scalar, R, CMAX, false, false> & o) const
+{
+  return eval().dot(o);
+}
 
 template<class Scalar, int N>
 using Vector = Matrix<Scalar, N, 1>;

@@ -205,6 +205,12 @@ extern "C"
       (ingest + solve kernel), and of the solve kernel alone. */
   int nmpc_hip_ddp_last_solve_ms(nmpc_hip_ddp_handle h, float * total_ms, float * kernel_ms);
 
+  /** The split of computationDuration() (DDPSolver::ComputationDuration, DDPSolver.h:219-247: derivative / backward / forward):
+      the solve kernel's HIP-event time of the last solve divided by the shader-clock shares of its phases, as counted by the
+      wave that ran longest — backward passes (the linearisation is fused into them: derivative + backward + Q + reg + gain of
+      the reference), forward passes (initial rollout + line-search rollouts), the rest (accept / lambda logic, write-out). */
+  int nmpc_hip_ddp_last_solve_phases(nmpc_hip_ddp_handle h, double * backward_ms, double * forward_ms, double * other_ms);
+
   /** Accumulated HIP-event times over every device solve since create / the last reset: number of solves and
       the sums of (ingest + kernel) and of the solve kernel alone [ms].  Events are recorded on the launch stream
       and harvested lazily, so a sequence of asynchronous solves is timed without host synchronisation in

@@ -103,6 +103,7 @@ struct nmpc_hip_ddp_solver
   double * d_wpi_ws = nullptr; // wave-per-instance kernel workspace (large models only)
   unsigned char * d_params_batch = nullptr; // [Bp][param_bytes] per-instance problem objects, or nullptr
   double * d_lim_batch = nullptr; // [Bp][2][kMaxInputDim] per-instance input limits, or nullptr
+  unsigned long long * d_phase_ticks = nullptr; // [Bp][4] per-instance phase ticks of the last solve
   double * d_lim_steps = nullptr; // [1 or Bp][T][2][MM] time-varying input limits, or nullptr
   int lim_steps_per_instance = 0;
   int trace_rows = 0;
@@ -191,6 +192,7 @@ DeviceBuffers makeBuffers(const nmpc_hip_ddp_solver * s)
   b.wpi_ws = s->d_wpi_ws;
   b.params_batch = s->d_params_batch;
   b.lim_batch = s->d_lim_batch;
+  b.phase_ticks = s->d_phase_ticks;
   b.lim_steps = s->d_lim_steps;
   b.lim_steps_per_instance = s->lim_steps_per_instance;
   b.lim_mm = s->MM;
@@ -707,6 +709,7 @@ extern "C"
     chk(devAlloc(&s->d_qp_ret, T * Bp));
     chk(devAlloc(&s->d_qp_free, T * Bp));
     chk(devAlloc(&s->d_input_dim, T * Bp));
+    chk(devAlloc(&s->d_phase_ticks, 4 * Bp));
     if(m->wpi_workspace_doubles(s->T) > 0)
     {
       // wave-per-instance kernel (9 <= n <= 16): materialised derivatives, gains and one candidate trajectory per
@@ -759,7 +762,7 @@ extern "C"
     }
     void * ptrs[] = {s->d_t0,     s->d_x0,     s->d_X,   s->d_U,      s->d_cost,    s->d_kff,       s->d_Kfb,
                      s->d_trace,  s->d_trace_last, s->d_dV, s->d_status, s->d_iters, s->d_sel,     s->d_qp_ret,
-                     s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_params_batch, s->d_lim_batch, s->d_lim_steps, s->d_stage_in,
+                     s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_params_batch, s->d_lim_batch, s->d_lim_steps, s->d_phase_ticks, s->d_stage_in,
                      s->d_stage_out};
     for(void * p : ptrs)
     {
@@ -1316,6 +1319,48 @@ extern "C"
     if(kernel_ms)
     {
       *kernel_ms = s->last_kernel_ms;
+    }
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_last_solve_phases(nmpc_hip_ddp_handle s, double * backward_ms, double * forward_ms, double * other_ms)
+  {
+    if(!s)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle");
+    }
+    if(!s->solved)
+    {
+      return fail(NMPC_HIP_ERR_NOT_SOLVED, "solve() has not been called");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    int rc = harvestAll(s); // (waits for the last solve)
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    std::vector<unsigned long long> host(static_cast<size_t>(s->B) * 4);
+    NMPC_HIP_TRY(hipMemcpy(host.data(), s->d_phase_ticks, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    // The waves that drive the instances run side by side for the whole launch: the split of the kernel's time is the split of
+    // the longest-running wave's ticks (the one that sets the kernel's duration).
+    size_t worst = 0;
+    for(size_t b = 1; b < static_cast<size_t>(s->B); b++)
+    {
+      worst = host[b * 4 + 2] > host[worst * 4 + 2] ? b : worst;
+    }
+    const double total = static_cast<double>(host[worst * 4 + 2]);
+    const double bw = total > 0 ? host[worst * 4 + 0] / total : 0.0, fw = total > 0 ? host[worst * 4 + 1] / total : 0.0;
+    if(backward_ms)
+    {
+      *backward_ms = bw * s->last_kernel_ms;
+    }
+    if(forward_ms)
+    {
+      *forward_ms = fw * s->last_kernel_ms;
+    }
+    if(other_ms)
+    {
+      *other_ms = (1.0 - bw - fw) * s->last_kernel_ms;
     }
     return NMPC_HIP_OK;
   }

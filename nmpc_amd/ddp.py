@@ -91,16 +91,38 @@ class MpcLog:
     m0: np.ndarray  # (B, n_ticks) input dimension of the first timestep
     x_final: np.ndarray  # (B, n) state after the last advance
     t_final: np.ndarray  # (B,)
+    duration: "ComputationDuration" = None  # of the run's last solve (batch-wide)
+
+    def ticks(self, b: int):
+        """The rows of instance b as result_tables.Tick objects."""
+        from .result_tables import Tick
+        return [Tick(float(self.t[b, k]), self.x[b, k], self.u0[b, k], int(self.m0[b, k]), int(self.iters[b, k]), self.duration)
+                for k in range(self.t.shape[1])]
+
+    def dump(self, file_path: str, b: int, columns) -> None:
+        """Write instance b's closed-loop run as one of the reference's per-test result tables (TestDDPBipedal.cpp:242,259-262
+        and the three others; makers in nmpc_amd.result_tables): a header of column names, one line per tick — the format the
+        reference's plot scripts load with np.genfromtxt(path, names=True)."""
+        from .result_tables import write_table
+        write_table(file_path, self.ticks(b), columns)
 
 
 @dataclass
 class ComputationDuration:
     """DDPSolver::ComputationDuration (DDPSolver.h:219-247) for the whole batch [msec]: `solve` is the HIP-event
-    time of ingest + solve kernel, `opt` the solve kernel alone, `setup` their difference.  The per-phase
-    splits of the reference are not separable inside the fused kernel; profiles/ holds rocprofv3 data."""
+    time of ingest + solve kernel, `opt` the solve kernel alone, `setup` their difference.  `backward` and `forward`
+    split `opt` by the shader-clock shares of the kernel's phases (nmpc_hip_ddp_last_solve_phases).  The linearisation is
+    fused into the backward sweep and the sweep's sub-steps are not timed separately: `derivative`, `Q`, `reg`, `gain` (parts
+    of `backward` here) stay 0."""
     solve: float = 0.0
     setup: float = 0.0
     opt: float = 0.0
+    derivative: float = 0.0
+    backward: float = 0.0
+    forward: float = 0.0
+    Q: float = 0.0
+    reg: float = 0.0
+    gain: float = 0.0
 
 
 class DDPSolverBatch:
@@ -356,6 +378,7 @@ class DDPSolverBatch:
             log.status.ctypes.data_as(ip), log.m0.ctypes.data_as(ip), log.x_final.ctypes.data_as(dp),
             log.t_final.ctypes.data_as(dp)))
         self._cache = {}
+        log.duration = self.computationDuration()
         return log
 
     def solveDevice(self, d_t0: Optional[int], d_x0: int, d_u_init: int, stream: Optional[int] = None) -> None:
@@ -447,7 +470,10 @@ class DDPSolverBatch:
     def computationDuration(self) -> ComputationDuration:
         tot, ker = C.c_float(), C.c_float()
         _capi.check(self._L.nmpc_hip_ddp_last_solve_ms(self._h, C.byref(tot), C.byref(ker)))
-        return ComputationDuration(solve=tot.value, setup=tot.value - ker.value, opt=ker.value)
+        bw, fw, other = C.c_double(), C.c_double(), C.c_double()
+        _capi.check(self._L.nmpc_hip_ddp_last_solve_phases(self._h, C.byref(bw), C.byref(fw), C.byref(other)))
+        return ComputationDuration(solve=tot.value, setup=tot.value - ker.value, opt=ker.value, backward=bw.value,
+                                   forward=fw.value)
 
     def kernelName(self) -> str:
         """gfx950 kernel the next solve launches (lane mapping), as rocprofv3 lists it."""

@@ -250,3 +250,69 @@ def test_closed_loop_with_per_instance_problems():
         assert np.all(np.abs(log.u0[b]) <= up[b, 0] + 1e-12)
     # the instances really behave differently
     assert np.abs(log.x_final - log.x_final[0]).max() > 1e-2
+
+
+def test_result_table_dump_and_phase_durations(tmp_path):
+    """the reference's per-test result table (TestDDPBipedal.cpp:242,259-262: "time com_pos com_vel
+    planned_zmp ref_zmp omega^2 iter") written from a batched run, in the format its plot script loads
+    (tests/scripts/plotTestDDPBipedal.py:8: np.genfromtxt(path, names=True)); and computationDuration() with the backward /
+    forward split of DDPSolver.h:219-247."""
+    import nmpc_amd
+    from nmpc_amd import result_tables
+
+    B, T, n_ticks = 4, 300, 30
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem("bipedal"), B)
+    c = s.config()
+    c.print_level = 0
+    c.horizon_steps = T
+    c.max_iter = 20
+    t0 = np.array([0.0, 2.0, 7.4, 11.0])
+    x0 = np.zeros((B, 2))
+    log = s.mpcRun(t0, x0, np.zeros((B, T, 1)), n_ticks=n_ticks)
+
+    def ref_zmp(t):  # the harness schedule of TestDDPBipedal.cpp:171-185 (only the columns' plumbing is tested here)
+        return 0.1 * np.floor(t + 1e-6)
+
+    def omega2(t):
+        return 9.80665 / 1.0
+
+    path = str(tmp_path / "TestDDPBipedalResult.txt")
+    log.dump(path, 2, result_tables.bipedal_table(ref_zmp, omega2))
+    header = open(path).readline().split()
+    assert header == "time com_pos com_vel planned_zmp ref_zmp omega^2 iter".split()
+    data = np.genfromtxt(path, dtype=None, delimiter=None, names=True)  # as the reference's plot script does
+    assert data.shape == (n_ticks,)
+    np.testing.assert_allclose(data["time"], log.t[2], rtol=1e-5)
+    np.testing.assert_allclose(data["com_pos"], log.x[2, :, 0], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(data["planned_zmp"], log.u0[2, :, 0], rtol=1e-5, atol=1e-9)
+    np.testing.assert_array_equal(data["iter"], log.iters[2])
+    # the other three headers
+    assert [n for n, _ in result_tables.vertical_motion_table(lambda t: 1.0)] == "time pos vel force ref_pos num_contact iter".split()
+    assert [n for n, _ in result_tables.cart_pole_table(lambda t: 0.0)] == "time pos theta vel omega force ref_pos disturbance".split()
+    cen = [n for n, _ in result_tables.centroidal_motion_table(lambda t: np.zeros((3, 16)), lambda t: (0, 0, 1))]
+    assert cen[:4] == ["time", "pos_x", "pos_y", "pos_z"] and cen[-8:] == ["duration_" + f for f in (
+        "setup", "opt", "derivative", "backward", "forward", "Q", "reg", "gain")] and len(cen) == 25
+    # computationDuration(): the phases split the kernel time
+    d = s.computationDuration()
+    assert d.opt > 0 and d.backward > 0 and d.forward > 0
+    assert d.backward + d.forward <= d.opt * 1.0001 and d.backward + d.forward >= 0.5 * d.opt
+    assert log.duration is not None and log.duration.opt == d.opt
+
+
+@pytest.mark.parametrize("model,B,T", [("cartpole", 4096, 100), ("cartpole", 8192, 100), ("quadrotor", 256, 50), ("quadrotor_f32", 256, 50)])
+def test_phase_durations_on_every_kernel_family(model, B, T):
+    """quad, two-wave, wave-per-instance and fp32 tile kernels all report the backward / forward split."""
+    import nmpc_amd
+    from nmpc_amd import workloads
+
+    wl = (workloads.cartpole_batch(B=B, T=T, seed=2) if model == "cartpole" else
+          workloads.quadrotor_batch(B=B, T=T, seed=2, fp32=model.endswith("f32")))
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B)
+    c = s.config()
+    c.print_level = 0
+    c.horizon_steps = T
+    c.max_iter = 4
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    d = s.computationDuration()
+    print(f"{s.kernelName()}: opt {d.opt:.3f} ms = backward {d.backward:.3f} + forward {d.forward:.3f} + other {d.opt - d.backward - d.forward:.3f}")
+    assert d.backward > 0.15 * d.opt and d.forward > 0.1 * d.opt and d.backward + d.forward <= 1.0001 * d.opt

@@ -242,3 +242,21 @@ def test_sincos_fast_accuracy(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SINCOS_OK" in r.stdout, r.stdout
+
+
+def test_eigen_style_port_matches_the_shipped_model(tmp_path):
+    """the reference's problem classes are written in Eigen block / initialiser syntax.  linalg.hpp offers
+    that subset (segment / head / tail / block / middleRows / col / diagonal views, `<<` , asDiagonal, cross, products ...), so
+    tests/cpp/CentroidalMotionEigenStyle.hpp follows TestDDPCentroidalMotion.cpp:24-210 statement for statement.  It must
+    equal the shipped centroidal problem bit for bit on the host, and compile for gfx950."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_eigen_style_port.cpp")
+    exe = str(tmp_path / "port")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", f"-I{ROOT}/include", f"-I{ROOT}/tests/cpp", src, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "EIGEN_STYLE_PORT_OK" in r.stdout, r.stdout
+    from nmpc_amd import build as hip_build
+    r = subprocess.run([hip_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-DDEVICE_COMPILE_CHECK", f"-I{ROOT}/include",
+                        f"-I{ROOT}/tests/cpp", "-x", "hip", "-c", src, "-o", str(tmp_path / "port_dev.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

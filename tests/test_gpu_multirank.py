@@ -70,3 +70,25 @@ def test_bench_under_two_ranks():
     assert 7000 < cfg["instance_iterations_per_step"] / 8  # two shards of 4096 instances, ~7.3 iterations each
     it_per_step = cfg["instance_iterations_per_step"] / 4096
     assert abs(d["value"] - it_per_step / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_cpp_sharded_helper(tmp_path):
+    """include/nmpc_amd/DDPSolverSharded.hpp (one host process, one handle per shard, one gather): two and three shards on the
+    box's single device with the peer-copy gather, one shard through the RCCL all-gather (ncclCommInitAll needs distinct
+    devices); gathered results must equal the unsharded solve bit for bit — fp64 quad kernel and fp32 tile kernel."""
+    from nmpc_amd import build as hip_build
+
+    exe = str(tmp_path / "sharded")
+    libdir = os.path.dirname(hip_build.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-DNMPC_AMD_WITH_RCCL", f"-I{ROOT}/include", "-I/opt/rocm/include",
+           os.path.join(ROOT, "examples", "sharded_solve.cpp"), f"-L{libdir}", "-lnmpc_hip_ddp", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (bit-for-bit needs the same lane mapping on both sides: 4000 / 3 and 4000 both run the quad kernel, 8400 / 2 and 8400 both
+    # the two-wave kernel; across kernel families results agree to 1e-13 with identical decisions, test_gpu_parity.py)
+    for args in (["cartpole", "203", "40", "2"], ["cartpole", "4000", "30", "3"], ["cartpole", "8400", "30", "2"],
+                 ["quadrotor_f32", "75", "20", "2"], ["cartpole", "96", "30", "1", "rccl"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "SHARDED_OK" in r.stdout, (args, r.stdout[-2000:], r.stderr[-2000:])

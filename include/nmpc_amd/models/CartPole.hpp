@@ -37,15 +37,27 @@ public:
     return ref_pos_;
   }
 
-  NMPC_HD StateDimVector stateEq(double t, const StateDimVector & x, const InputDimVector & u) const
+  NMPC_HD StateDimVector stateEq(double, // t
+                                 const StateDimVector & x,
+                                 const InputDimVector & u) const
   {
-    return stateEq(t, x, u, dt_);
+    return step<false>(x, u, dt_);
   }
 
+  /** The plant step of the reference's test (TestDDPCartPole.cpp:63-98: stateEq with an explicit dt), used by the
+      receding-horizon driver's plant pattern.  Full-range sin / cos: a simulated pole may wind up arbitrarily far, where the
+      solver's restricted-range sincosFast would give NaN (its rollouts of diverging line-search candidates are rejected
+      either way, the plant's state is kept). */
   NMPC_HD StateDimVector stateEq(double, // t
                                  const StateDimVector & x,
                                  const InputDimVector & u,
                                  double dt) const
+  {
+    return step<true>(x, u, dt);
+  }
+
+  template<bool kFullRange>
+  NMPC_HD StateDimVector step(const StateDimVector & x, const InputDimVector & u, double dt) const
   {
     const double theta = x[1];
     const double vel = x[2];
@@ -56,7 +68,14 @@ public:
     const double l = param_.pole_length;
 
     double sin_theta, cos_theta;
-    sincosFast(theta, sin_theta, cos_theta); // |theta| < 2^27 rad, NaN beyond (linalg.hpp)
+    if constexpr(kFullRange)
+    {
+      sincos(theta, sin_theta, cos_theta);
+    }
+    else
+    {
+      sincosFast(theta, sin_theta, cos_theta); // |theta| < 2^27 rad, NaN beyond (linalg.hpp)
+    }
     const double omega2 = omega * omega;
     const double denom = m1 + m2 * (sin_theta * sin_theta);
     // one reciprocal instead of the two divisions of the textbook form (an fp64 divide costs ~10 FMAs on gfx950)

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Turn one scripts/profile_r02.sh session (gpurun_out/profile_<tag>/) into the tracked summaries under profiles/:
+
+  profiles/<tag>_kernel_stats_<wl>.csv     rocprofv3 --kernel-trace --stats of `python bench.py --workload <wl> --steps 10 --warmup 2`
+  profiles/<tag>_pmc_summary_<wl>.txt      per-launch means of the PMC passes (each set collected in its own run)
+  profiles/<tag>_counter_calibration.txt   FETCH_SIZE / WRITE_SIZE on a known 1 GiB read / write
+  profiles/<tag>_bench_<wl>.json           unprofiled bench line of the same session
+  profiles/hbm_traffic.json                corrected HBM bytes per launch PER WORKLOAD, read by bench.py for roofline.traffic
+"""
+import csv, collections, glob, json, os, shutil, sys
+
+tag, src = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+
+
+def means(pattern, kernel_pat):
+    out = collections.defaultdict(list)
+    for f in sorted(glob.glob(os.path.join(src, pattern))):
+        for r in csv.DictReader(open(f)):
+            if kernel_pat in r["Kernel_Name"]:
+                out[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+
+
+cal_r, _ = means("calF_counter_collection.csv", "read_k")
+cal_w, _ = means("calW_counter_collection.csv", "write_k")
+GiB_KB = 1024.0 * 1024.0
+fetch_scale = GiB_KB / cal_r["FETCH_SIZE"]
+write_scale = GiB_KB / cal_w["WRITE_SIZE"]
+with open(os.path.join(dst, f"{tag}_counter_calibration.txt"), "w") as f:
+    f.write("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on scripts/ubench_hbm_counters (1 GiB streamed), separate runs per counter:\n")
+    f.write(f"  read_k : FETCH_SIZE = {cal_r['FETCH_SIZE']:.1f} KB reported for 1048576 KB read  -> scale x{fetch_scale:.4f}\n")
+    f.write(f"  write_k: WRITE_SIZE = {cal_w['WRITE_SIZE']:.1f} KB reported for 1048576 KB written -> scale x{write_scale:.4f}\n")
+    f.write("(FETCH_SIZE under-reports a coalesced read by 2x on gfx950, as MI355X_MICROARCH.md §HBM states; WRITE_SIZE is 1:1.)\n")
+
+traffic = {}
+for wl in ("c2", "c4", "c3", "c5", "c4f64"):
+    stats = os.path.join(src, f"stats_{wl}_kernel_stats.csv")
+    if os.path.exists(stats):
+        shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats_{wl}.csv"))
+    bench_file = os.path.join(src, f"bench_{wl}.txt")
+    bench = None
+    if os.path.exists(bench_file):
+        lines = [l for l in open(bench_file) if l.startswith("{")]
+        if lines:
+            bench = json.loads(lines[-1])
+            json.dump(bench, open(os.path.join(dst, f"{tag}_bench_{wl}.json"), "w"), indent=1)
+    pm, cnt = means(f"pmc?_{wl}_counter_collection.csv", "ddp_solve")
+    if not pm:
+        continue
+    hbm_bytes = (pm.get("FETCH_SIZE", 0.0) * fetch_scale + pm.get("WRITE_SIZE", 0.0) * write_scale) * 1024.0
+    with open(os.path.join(dst, f"{tag}_pmc_summary_{wl}.txt"), "w") as f:
+        kname = bench["roofline"]["kernel"] if bench else "ddp_solve_*"
+        f.write(f"kernel: {kname} (bench.py --workload {wl} --steps 10 --warmup 2; one launch = one solve of the batch, max_iter 8)\n")
+        f.write("per-launch means; SQ_* cycle counters are in quad-cycles (x4 = shader cycles), summed over all waves of the launch\n")
+        for k in sorted(pm):
+            f.write(f"  {k:30s} n={cnt[k]:3d} mean={pm[k]:18.1f}\n")
+        f.write("\nderived:\n")
+        f.write(f"  HBM traffic per launch (FETCH x{fetch_scale:.2f} + WRITE x{write_scale:.2f})  {hbm_bytes / 1e6:10.1f} MB\n")
+        if "TCC_HIT" in pm:
+            f.write(f"  L2 hit rate                        {pm['TCC_HIT'] / (pm['TCC_HIT'] + pm['TCC_MISS']):6.3f}\n")
+        wc = pm.get("SQ_WAVE_CYCLES", 0.0)
+        if wc:
+            f.write(f"  VALU-active share of wave cycles   {pm['SQ_ACTIVE_INST_VALU'] / wc:6.3f}\n")
+            f.write(f"  s_waitcnt / barrier share          {pm['SQ_WAIT_ANY'] / wc:6.3f}\n")
+            f.write(f"  issue-stall share                  {pm['SQ_WAIT_INST_ANY'] / wc:6.3f}\n")
+            f.write(f"  VALU instructions per wave         {pm['SQ_INSTS_VALU'] / pm['SQ_WAVES']:10.0f}\n")
+            if pm.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                # busy cycles are per SIMD-pipe; 1024 SIMDs; wave cycles / waves = kernel duration in quad-cycles
+                dur_cycles = 4.0 * wc / pm["SQ_WAVES"]
+                f.write(f"  matrix-core busy share (1024 SIMDs) {pm['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / dur_cycles:6.3f}\n")
+                f.write(f"  VALU issue share (1024 SIMDs)       {4.0 * pm['SQ_ACTIVE_INST_VALU'] / 1024.0 / dur_cycles:6.3f}\n")
+        if bench:
+            rf = bench["roofline"]
+            f.write(f"  fused lower bound per launch       {rf['fused_lower_bound_bytes_per_launch'] / 1e6:10.1f} MB  -> traffic / bound = "
+                    f"{hbm_bytes / rf['fused_lower_bound_bytes_per_launch']:.2f}\n")
+            f.write(f"  contract (staged) bytes per launch {rf['algorithmic_bytes_per_launch'] / 1e6:10.1f} MB\n")
+    if bench:
+        traffic[wl] = {"hbm_bytes_per_launch": hbm_bytes, "batch": int(bench["metric"].split("batch=")[1].split(",")[0]),
+                       "iterations_per_step": bench["config"]["iterations_per_step"],
+                       "source": f"profiles/{tag}_pmc_summary_{wl}.txt (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; FETCH_SIZE "
+                                 f"x{fetch_scale:.2f} per profiles/{tag}_counter_calibration.txt)"}
+json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+for extra in ("fanout_ab.txt", "batch_scaling.txt", "ubench_mfma_f32.txt"):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
+print(json.dumps(traffic, indent=1))

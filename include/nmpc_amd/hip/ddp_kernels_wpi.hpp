@@ -126,7 +126,7 @@ struct WaveSolver
   }
   NMPC_HD static size_t workspaceDoubles(int T)
   {
-    return trajDoubles(T) * (1 + NMPC_HIP_MAX_ALPHA) + static_cast<size_t>(T) * (kDeriv + kGain);
+    return trajDoubles(T) * 2 + static_cast<size_t>(T) * (kDeriv + kGain); // control_data_ + ONE candidate
   }
 
   const Problem & problem;
@@ -137,6 +137,7 @@ struct WaveSolver
   const int lane;
   double * lds;
   double * ws; //!< this instance's workspace
+  int cur = 0; //!< which of the two trajectory buffers holds control_data_
   double current_t;
 
   NMPC_D WaveSolver(const Problem & p, const nmpc_hip_ddp_config & c, const DeviceBuffers & bf, int instance, double * lds_base)
@@ -146,9 +147,11 @@ struct WaveSolver
   }
 
   // workspace views
-  NMPC_D double * trajX(int which) const // which = 0: control_data_, 1 + j: candidate of alpha_list[j]
+  /** which = 0: control_data_, 1: candidate_control_data_.  Only ONE step size's rollout is ever stored: the one the line
+      search is expected to take (the first), or the taken one re-rolled; accepting flips `cur` (DDPSolver.hpp:285-287 copies). */
+  NMPC_D double * trajX(int which) const
   {
-    return ws + static_cast<size_t>(which) * trajDoubles(T);
+    return ws + static_cast<size_t>(which ^ cur) * trajDoubles(T);
   }
   NMPC_D double * trajU(int which) const
   {
@@ -160,11 +163,11 @@ struct WaveSolver
   }
   NMPC_D double * derivBlock(int i) const
   {
-    return ws + trajDoubles(T) * (1 + NMPC_HIP_MAX_ALPHA) + static_cast<size_t>(i) * kDeriv;
+    return ws + trajDoubles(T) * 2 + static_cast<size_t>(i) * kDeriv;
   }
   NMPC_D double * gainBlock(int i) const
   {
-    return ws + trajDoubles(T) * (1 + NMPC_HIP_MAX_ALPHA) + static_cast<size_t>(T) * kDeriv + static_cast<size_t>(i) * kGain;
+    return ws + trajDoubles(T) * 2 + static_cast<size_t>(T) * kDeriv + static_cast<size_t>(i) * kGain;
   }
   NMPC_D double * tile(int t) const
   {
@@ -1357,11 +1360,14 @@ struct WaveSolver
     return trajU(0)[static_cast<size_t>(i) * MM + (e - kGain - N)];
   }
 
-  NMPC_D double forwardCandidate(double alpha, bool active) const
+  /** \param store_lane the lane (= step-size index) whose rollout goes to the candidate buffer; the others only sum their
+      cost.  (Every candidate used to be written and the accepted one copied: 11 x 6.9 KB of stores per line search.) */
+  NMPC_D double forwardCandidate(double alpha, bool active_lane, int store_lane) const
   {
-    double * Xc = trajX(1 + lane);
-    double * Uc = trajU(1 + lane);
-    double * Cc = trajC(1 + lane);
+    const bool active = active_lane && lane == store_lane;
+    double * Xc = trajX(1);
+    double * Uc = trajU(1);
+    double * Cc = trajC(1);
     // The nominal record is the same for all lanes: the wave fetches it once (one or two doubles per lane, requested one
     // timestep ahead), passes it through LDS, and every lane reads it from there.
     double nf[kNomChunks];
@@ -1440,17 +1446,6 @@ struct WaveSolver
       Cc[T] = cT;
     }
     return J + cT;
-  }
-
-  NMPC_D void adoptCandidate(int j) const
-  {
-    const size_t n = trajDoubles(T);
-    const double * src = trajX(1 + j);
-    double * dst = trajX(0);
-    for(size_t e = lane; e < n; e += 64)
-    {
-      dst[e] = src[e];
-    }
   }
 
   // ===================================================================================================
@@ -1615,7 +1610,7 @@ struct WaveSolver
           const bool active = lane < cfg.n_alpha;
           const double alpha_l = cfg.alpha_list[active ? lane : 0];
           profBegin();
-          const double J_cand = forwardCandidate(alpha_l, active);
+          const double J_cand = forwardCandidate(alpha_l, active, 0);
           profEnd(3);
           const double actual_l = J_cur - J_cand;
           const double expected_l = -1 * alpha_l * (dV0 + alpha_l * dV1);
@@ -1642,8 +1637,14 @@ struct WaveSolver
           {
             profBegin();
             sync();
-            adoptCandidate(ai);
-            sync();
+            if(ai != 0)
+            {
+              // a later step size was taken: roll it out once more, this time into the candidate buffer (same instruction
+              // stream on the same inputs: the same trajectory its lane summed the cost of)
+              (void)forwardCandidate(alpha_l, active, ai);
+              sync();
+            }
+            cur ^= 1; // the candidate buffer becomes control_data_
             profEnd(4);
             J_cur = __shfl(J_cand, ai);
             if(cost_update_actual < cfg.cost_update_thre)

@@ -1,0 +1,1745 @@
+// gfx950 kernels of the batched FMPC solver: the reference's nmpc_fmpc::FmpcSolver
+// (nmpc_fmpc/include/nmpc_fmpc/FmpcSolver.hpp) for B independent instances at once.
+//
+// FMPC is a multiple-shooting method: every quantity of one iteration except the Riccati recursion is independent across the
+// T timesteps of the horizon.  The iteration is therefore split where the reference's procOnce (FmpcSolver.hpp:356-491) has
+// its steps, and each step is launched with the parallelism it has:
+//
+//   fmpc_barrier_kernel      (B x slices)   barrier parameter from mean(s . nu)                       :370-392
+//   fmpc_coeff_kernel        (B x (T+1))    linearisation, offsets x_bar / g_bar / Lx_bar / Lu_bar,
+//                                           the barrier-condensed Q~, L~ of the backward pass, per-step
+//                                           KKT-error terms                                            :394-441, :562-574, :493-520
+//   fmpc_riccati_kernel      (B)            KKT-error test, backward Riccati recursion, forward sweep  :443-449, :522-665, :667-687
+//   fmpc_delta_kernel        (B x T)        ds, dnu, per-step fraction-to-boundary step lengths        :689-697, :713-731
+//   fmpc_step_length_kernel  (B x slices)   min over the horizon, validity test                       :732-742
+//   fmpc_line_search_kernel  (B, optional)  l1 merit function backtracking                             :748-792, :840-981
+//   fmpc_update_kernel       (B x (T+1))    variables += step                                          :801-835
+//
+// Every array is laid out [timestep][element][instance] ("instance-minor"): consecutive lanes of a wavefront hold consecutive
+// instances, so every global access of every kernel above is a fully coalesced 512-byte row, whether the kernel's threads
+// enumerate (instance, timestep) pairs or instances only.  Per-instance state that decides control flow (status, iteration
+// count, barrier parameter, step lengths) lives in [instance] arrays; an instance that has terminated (Succeeded or an error
+// status) is skipped by every later kernel, the rest of the batch continues (masking, as in the DDP kernels).
+// Reductions over the horizon are done in a fixed order (per-slice ascending, then slices ascending): results do not depend
+// on scheduling, two runs of the same solve are bit-identical.
+#pragma once
+
+#include <cfloat>
+#include <cmath>
+
+#include <hip/hip_runtime.h>
+
+#include <nmpc_amd/FmpcProblem.hpp>
+#include <nmpc_hip_fmpc.h>
+
+namespace nmpc_amd
+{
+namespace hip
+{
+/** Device buffers and the scalar configuration of one handle; passed to every kernel by value. */
+struct FmpcBuffers
+{
+  int B = 0; // instances
+  int T = 0; // horizon_steps
+  int N = 0, M = 0, G = 0;
+  int coef_stride = 0; // doubles per timestep in `coef`
+  int gain_stride = 0; // doubles per timestep in `gain`
+  // Variable (FmpcSolver.h:117-158): x [T+1][N][B], u [T][M][B], lambda [T+1][N][B], s [T][G][B], nu [T][G][B]
+  double * x = nullptr;
+  double * u = nullptr;
+  double * lam = nullptr;
+  double * s = nullptr;
+  double * nu = nullptr;
+  // delta_variable_ (FmpcSolver.h:402), same shapes
+  double * dx = nullptr;
+  double * du = nullptr;
+  double * dlam = nullptr;
+  double * ds = nullptr;
+  double * dnu = nullptr;
+  // what the Riccati recursion reads per timestep: A, B, x_bar, Qxx~, Quu~, Qxu~, Lx~, Lu~  [T][coef_stride][B]
+  double * coef = nullptr;
+  // what it writes: k, K, s, P  [T+1][gain_stride][B] (Coefficient::k / K / s / P, FmpcSolver.h:214-224; the terminal entry
+  // holds s and P only)
+  double * gain = nullptr;
+  // per-timestep partial results [T+1][3][B]: KKT-error terms, alpha_s candidate, alpha_nu candidate
+  double * part = nullptr;
+  const double * t0 = nullptr; // [B] current_t
+  const double * x0 = nullptr; // [N][B] current_x
+  double * barrier_eps = nullptr; // [B] barrier_eps_ (FmpcSolver.h:414), kept across solves like the member it mirrors
+  double * alpha = nullptr; // [3][B]: alpha_s_max, alpha_nu_max, alpha_s of the current iteration
+  double * merit = nullptr; // [3][B]: merit_func_, merit_deriv_, merit_const_scale_ of the last line search
+  int * status = nullptr; // [B] FmpcSolver::Status, or NMPC_HIP_FMPC_STATUS_INVALID_VARIABLE
+  int * iters = nullptr; // [B] traceDataList().back().iter
+  int * flags = nullptr; // [B] bit 0: a coefficient is NaN / Inf, bit 1: delta_variable_ contains NaN / Inf
+  double * trace = nullptr; // [B][max_iter][NMPC_HIP_FMPC_NTRACE]
+  const void * problems = nullptr; // one problem object, or B of them
+  int own_problems = 0;
+  // Configuration (FmpcSolver.h:57-89)
+  int max_iter = 0;
+  double kkt_error_thre = 0;
+  int check_nan = 1;
+  int update_barrier_eps = 1;
+  int break_if_llt_fails = 0;
+  int enable_line_search = 0;
+  int merit_const_scale_from_lagrange_multipliers = 0;
+};
+
+namespace fmpc
+{
+constexpr int kStatusContinued = 6; // Status::IterationContinued (FmpcSolver.h:113)
+constexpr int kSlices = 8; // horizon slices of the per-instance reductions
+
+__device__ __forceinline__ size_t at(const FmpcBuffers & buf, int i, int e, int stride, int b)
+{
+  return (static_cast<size_t>(i) * stride + e) * buf.B + b;
+}
+
+__device__ __forceinline__ bool bad(double v)
+{
+  return !(fabs(v) <= DBL_MAX); // NaN or Inf (CHECK_NAN, FmpcSolver.hpp:10-18)
+}
+
+/** Offsets of the per-timestep coefficient record. */
+template<int N, int M>
+struct CoefLayout
+{
+  static constexpr int A = 0;
+  static constexpr int B = A + N * N;
+  static constexpr int XBAR = B + N * M;
+  static constexpr int QXX = XBAR + N;
+  static constexpr int QUU = QXX + N * N;
+  static constexpr int QXU = QUU + M * M;
+  static constexpr int LXT = QXU + N * M;
+  static constexpr int LUT = LXT + N;
+  static constexpr int kStride = LUT + M;
+};
+
+/** Offsets of the per-timestep gain record. */
+template<int N, int M>
+struct GainLayout
+{
+  static constexpr int k = 0;
+  static constexpr int K = k + M;
+  static constexpr int S = K + M * N;
+  static constexpr int P = S + N;
+  static constexpr int kStride = P + N * N;
+};
+
+/** Eigen::LDLT<Matrix, Lower> of an M x M matrix with symmetric diagonal pivoting and the pseudo-inverse of D in the solve
+    (what FmpcSolver.hpp:581-586 runs on G; Eigen 3.4 Cholesky/LDLT.h).  compute() returns false where info() would be
+    NumericalIssue. */
+template<int M>
+struct Ldlt
+{
+  double a[M * M > 0 ? M * M : 1];
+  int tr[M > 0 ? M : 1];
+
+  __device__ bool compute(const double * Gm)
+  {
+    NMPC_UNROLL
+    for(int i = 0; i < M * M; i++)
+    {
+      a[i] = Gm[i];
+    }
+    if constexpr(M <= 1)
+    {
+      if constexpr(M == 1)
+      {
+        tr[0] = 0;
+      }
+      return true;
+    }
+    else
+    {
+      bool found_zero_pivot = false;
+      bool ret = true;
+      for(int k = 0; k < M; k++)
+      {
+        int p = k;
+        double big = fabs(a[k + k * M]);
+        for(int i = k + 1; i < M; i++)
+        {
+          if(fabs(a[i + i * M]) > big)
+          {
+            big = fabs(a[i + i * M]);
+            p = i;
+          }
+        }
+        tr[k] = p;
+        if(p != k)
+        {
+          for(int j = 0; j < k; j++)
+          {
+            swap(a[k + j * M], a[p + j * M]);
+          }
+          for(int i = p + 1; i < M; i++)
+          {
+            swap(a[i + k * M], a[i + p * M]);
+          }
+          swap(a[k + k * M], a[p + p * M]);
+          for(int i = k + 1; i < p; i++)
+          {
+            swap(a[i + k * M], a[p + i * M]);
+          }
+        }
+        if(k > 0)
+        {
+          double temp[M];
+          double acc = 0;
+          for(int j = 0; j < k; j++)
+          {
+            temp[j] = a[j + j * M] * a[k + j * M];
+            acc += a[k + j * M] * temp[j];
+          }
+          a[k + k * M] -= acc;
+          for(int i = k + 1; i < M; i++)
+          {
+            double sum = 0;
+            for(int j = 0; j < k; j++)
+            {
+              sum += a[i + j * M] * temp[j];
+            }
+            a[i + k * M] -= sum;
+          }
+        }
+        const double akk = a[k + k * M];
+        const bool pivot_is_valid = fabs(akk) > 0.0;
+        if(k == 0 && !pivot_is_valid)
+        {
+          for(int j = 0; j < M; j++)
+          {
+            tr[j] = j;
+            for(int i = j + 1; i < M; i++)
+            {
+              ret = ret && (a[i + j * M] == 0.0);
+            }
+          }
+          return ret;
+        }
+        if(pivot_is_valid)
+        {
+          for(int i = k + 1; i < M; i++)
+          {
+            a[i + k * M] /= akk;
+          }
+        }
+        else
+        {
+          for(int i = k + 1; i < M; i++)
+          {
+            ret = ret && (a[i + k * M] == 0.0);
+          }
+        }
+        if(found_zero_pivot && pivot_is_valid)
+        {
+          ret = false;
+        }
+        else if(!pivot_is_valid)
+        {
+          found_zero_pivot = true;
+        }
+      }
+      return ret;
+    }
+  }
+
+  __device__ static void swap(double & p, double & q)
+  {
+    const double t = p;
+    p = q;
+    q = t;
+  }
+
+  /** x = G^-1 b, in place, for one right-hand side. */
+  __device__ void solveInPlace(double * x) const
+  {
+    if constexpr(M == 1)
+    {
+      x[0] = fabs(a[0]) > DBL_MIN ? x[0] / a[0] : 0.0;
+    }
+    else if constexpr(M > 1)
+    {
+      for(int k = 0; k < M; k++)
+      {
+        swap(x[k], x[tr[k]]);
+      }
+      for(int i = 0; i < M; i++)
+      {
+        for(int j = 0; j < i; j++)
+        {
+          x[i] -= a[i + j * M] * x[j];
+        }
+      }
+      for(int i = 0; i < M; i++)
+      {
+        x[i] = fabs(a[i + i * M]) > DBL_MIN ? x[i] / a[i + i * M] : 0.0;
+      }
+      for(int i = M - 1; i >= 0; i--)
+      {
+        for(int j = i + 1; j < M; j++)
+        {
+          x[i] -= a[j + i * M] * x[j];
+        }
+      }
+      for(int k = M - 1; k >= 0; k--)
+      {
+        swap(x[k], x[tr[k]]);
+      }
+    }
+  }
+};
+
+/** Full-pivot Gaussian elimination for one right-hand side: the role of Eigen::FullPivLU at FmpcSolver.hpp:599-601, reached
+    only when the LDLT reports NumericalIssue. */
+template<int M>
+__device__ void fullPivLuSolveInPlace(const double * Gm, double * b)
+{
+  if constexpr(M > 0)
+  {
+    double a[M * M];
+    int colperm[M];
+    for(int i = 0; i < M * M; i++)
+    {
+      a[i] = Gm[i];
+    }
+    for(int i = 0; i < M; i++)
+    {
+      colperm[i] = i;
+    }
+    int rank = 0;
+    for(int k = 0; k < M; k++)
+    {
+      int pr = k, pc = k;
+      double big = 0;
+      for(int j = k; j < M; j++)
+      {
+        for(int i = k; i < M; i++)
+        {
+          if(fabs(a[i + j * M]) > big)
+          {
+            big = fabs(a[i + j * M]);
+            pr = i;
+            pc = j;
+          }
+        }
+      }
+      if(big == 0.0)
+      {
+        break;
+      }
+      rank++;
+      for(int j = 0; j < M; j++)
+      {
+        Ldlt<M>::swap(a[k + j * M], a[pr + j * M]);
+      }
+      Ldlt<M>::swap(b[k], b[pr]);
+      for(int i = 0; i < M; i++)
+      {
+        Ldlt<M>::swap(a[i + k * M], a[i + pc * M]);
+      }
+      const int tmp = colperm[k];
+      colperm[k] = colperm[pc];
+      colperm[pc] = tmp;
+      for(int i = k + 1; i < M; i++)
+      {
+        const double f = a[i + k * M] / a[k + k * M];
+        for(int j = k + 1; j < M; j++)
+        {
+          a[i + j * M] -= f * a[k + j * M];
+        }
+        b[i] -= f * b[k];
+      }
+    }
+    double y[M];
+    for(int i = M - 1; i >= 0; i--)
+    {
+      if(i >= rank)
+      {
+        y[i] = 0;
+        continue;
+      }
+      double sum = b[i];
+      for(int j = i + 1; j < rank; j++)
+      {
+        sum -= a[i + j * M] * y[j];
+      }
+      y[i] = sum / a[i + i * M];
+    }
+    for(int i = 0; i < M; i++)
+    {
+      b[colperm[i]] = y[i];
+    }
+  }
+}
+
+template<class Problem>
+__device__ __forceinline__ Problem loadProblem(const FmpcBuffers & buf, int b)
+{
+  return static_cast<const Problem *>(buf.problems)[buf.own_problems ? b : 0];
+}
+
+template<int R, int C>
+__device__ __forceinline__ void loadVec(const double * base, const FmpcBuffers & buf, int i, int b, Matrix<double, R, C> & out)
+{
+  NMPC_UNROLL
+  for(int e = 0; e < R * C; e++)
+  {
+    out.data()[e] = base[at(buf, i, e, R * C, b)];
+  }
+}
+} // namespace fmpc
+
+// ---------------------------------------------------------------------------------------------------------------------
+// problem-independent kernels: compiled into ONE translation unit (nmpc_amd/csrc/fmpc_capi.hip defines
+// NMPC_AMD_FMPC_COMMON_KERNELS before including this header), the problem translation units see declarations only
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef NMPC_AMD_FMPC_COMMON_KERNELS
+
+/** Start of a solve (FmpcSolver.hpp:156-231): every instance is marked as running, trace cleared. */
+__global__ void fmpc_begin_kernel(FmpcBuffers buf)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if(b >= buf.B)
+  {
+    return;
+  }
+  buf.status[b] = fmpc::kStatusContinued;
+  buf.iters[b] = 0;
+  buf.flags[b] = 0;
+  for(int k = 0; k < buf.max_iter * NMPC_HIP_FMPC_NTRACE; k++)
+  {
+    buf.trace[static_cast<size_t>(b) * buf.max_iter * NMPC_HIP_FMPC_NTRACE + k] = 0.0;
+  }
+}
+
+/** checkVariable's non-negativity test (FmpcSolver.hpp:338-353): the reference throws std::runtime_error; here the instance
+    gets NMPC_HIP_FMPC_STATUS_INVALID_VARIABLE and is skipped, the C-ABI call reports NMPC_HIP_ERR_RUNTIME afterwards. */
+__global__ void fmpc_check_variable_kernel(FmpcBuffers buf)
+{
+  const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if(tid >= static_cast<size_t>(buf.B) * buf.T)
+  {
+    return;
+  }
+  const int b = static_cast<int>(tid % buf.B);
+  const int i = static_cast<int>(tid / buf.B);
+  bool negative = false;
+  for(int j = 0; j < buf.G; j++)
+  {
+    negative = negative || buf.s[fmpc::at(buf, i, j, buf.G, b)] < 0 || buf.nu[fmpc::at(buf, i, j, buf.G, b)] < 0;
+  }
+  if(negative)
+  {
+    buf.status[b] = NMPC_HIP_FMPC_STATUS_INVALID_VARIABLE; // every writer stores the same value
+  }
+}
+
+/** Barrier parameter of the iteration, (19.19) in Nocedal & Wright (FmpcSolver.hpp:370-392); also opens the iteration's trace
+    row (:363-366).  Block = 64 instances x kSlices horizon slices. */
+__global__ void __launch_bounds__(64 * fmpc::kSlices) fmpc_barrier_kernel(FmpcBuffers buf, int iter)
+{
+  __shared__ double sh[fmpc::kSlices][64];
+  const int lane = threadIdx.x & 63;
+  const int q = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + lane;
+  const bool act = b < buf.B && buf.status[b] == fmpc::kStatusContinued;
+  double acc = 0;
+  if(act && buf.update_barrier_eps)
+  {
+    const int chunk = (buf.T + fmpc::kSlices - 1) / fmpc::kSlices;
+    const int i1 = min(buf.T, (q + 1) * chunk);
+    for(int i = q * chunk; i < i1; i++)
+    {
+      double dot = 0;
+      for(int j = 0; j < buf.G; j++)
+      {
+        dot += buf.s[fmpc::at(buf, i, j, buf.G, b)] * buf.nu[fmpc::at(buf, i, j, buf.G, b)];
+      }
+      acc += dot;
+    }
+  }
+  sh[q][lane] = acc;
+  __syncthreads();
+  if(q == 0 && act)
+  {
+    double eps = buf.barrier_eps[b];
+    if(buf.update_barrier_eps)
+    {
+      double s_nu_ave = 0;
+      for(int k = 0; k < fmpc::kSlices; k++)
+      {
+        s_nu_ave += sh[k][lane];
+      }
+      s_nu_ave /= static_cast<double>(buf.T * buf.G);
+      constexpr double sigma = 0.5;
+      constexpr double barrier_eps_min = 1e-8;
+      constexpr double barrier_eps_max = 1e6;
+      // std::clamp(v, lo, hi) = (v < lo) ? lo : (hi < v) ? hi : v — a NaN passes through
+      const double v = sigma * s_nu_ave;
+      eps = (v < barrier_eps_min) ? barrier_eps_min : ((barrier_eps_max < v) ? barrier_eps_max : v);
+      buf.barrier_eps[b] = eps;
+    }
+    buf.iters[b] = iter;
+    buf.flags[b] = 0;
+    double * row = buf.trace + (static_cast<size_t>(b) * buf.max_iter + (iter - 1)) * NMPC_HIP_FMPC_NTRACE;
+    row[NMPC_HIP_FMPC_TRACE_ITER] = iter;
+    row[NMPC_HIP_FMPC_TRACE_BARRIER_EPS] = eps;
+  }
+}
+
+/** Fraction-to-boundary rule (FmpcSolver.hpp:713-742): minimum of the per-timestep candidates, validity test; and the verdict
+    on the forward pass's NaN check (:699-706), which the reference takes first. */
+__global__ void __launch_bounds__(64 * fmpc::kSlices) fmpc_step_length_kernel(FmpcBuffers buf, int iter)
+{
+  __shared__ double sh[2][fmpc::kSlices][64];
+  const int lane = threadIdx.x & 63;
+  const int q = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + lane;
+  const bool act = b < buf.B && buf.status[b] == fmpc::kStatusContinued;
+  double a_s = 1.0, a_nu = 1.0;
+  if(act)
+  {
+    const int chunk = (buf.T + fmpc::kSlices - 1) / fmpc::kSlices;
+    const int i1 = min(buf.T, (q + 1) * chunk);
+    for(int i = q * chunk; i < i1; i++)
+    {
+      // std::min(a, b) = (b < a) ? b : a — a NaN candidate is ignored exactly as the reference's loop ignores it
+      const double cs = buf.part[fmpc::at(buf, i, 1, 3, b)];
+      const double cn = buf.part[fmpc::at(buf, i, 2, 3, b)];
+      a_s = (cs < a_s) ? cs : a_s;
+      a_nu = (cn < a_nu) ? cn : a_nu;
+    }
+  }
+  sh[0][q][lane] = a_s;
+  sh[1][q][lane] = a_nu;
+  __syncthreads();
+  if(q == 0 && act)
+  {
+    for(int k = 1; k < fmpc::kSlices; k++)
+    {
+      a_s = (sh[0][k][lane] < a_s) ? sh[0][k][lane] : a_s;
+      a_nu = (sh[1][k][lane] < a_nu) ? sh[1][k][lane] : a_nu;
+    }
+    if(buf.check_nan && (buf.flags[b] & 2))
+    {
+      buf.status[b] = 2; // Status::ErrorInForward
+      return;
+    }
+    double * row = buf.trace + (static_cast<size_t>(b) * buf.max_iter + (iter - 1)) * NMPC_HIP_FMPC_NTRACE;
+    row[NMPC_HIP_FMPC_TRACE_ALPHA_S_MAX] = a_s;
+    row[NMPC_HIP_FMPC_TRACE_ALPHA_NU_MAX] = a_nu;
+    row[NMPC_HIP_FMPC_TRACE_ALPHA_S] = a_s;
+    buf.alpha[0 * buf.B + b] = a_s;
+    buf.alpha[1 * buf.B + b] = a_nu;
+    buf.alpha[2 * buf.B + b] = a_s;
+    if(!(a_s > 0.0 && a_s <= 1.0 && a_nu > 0.0 && a_nu <= 1.0))
+    {
+      buf.status[b] = 4; // Status::ErrorInUpdate
+    }
+  }
+}
+
+/** Variable update (FmpcSolver.hpp:801-835), one thread per (instance, timestep). */
+__global__ void fmpc_update_kernel(FmpcBuffers buf)
+{
+  const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if(tid >= static_cast<size_t>(buf.B) * (buf.T + 1))
+  {
+    return;
+  }
+  const int b = static_cast<int>(tid % buf.B);
+  const int i = static_cast<int>(tid / buf.B);
+  if(buf.status[b] != fmpc::kStatusContinued)
+  {
+    return;
+  }
+  const double alpha_s = buf.alpha[2 * buf.B + b];
+  const double alpha_nu = buf.alpha[1 * buf.B + b];
+  for(int e = 0; e < buf.N; e++)
+  {
+    const size_t k = fmpc::at(buf, i, e, buf.N, b);
+    buf.x[k] += alpha_s * buf.dx[k];
+    buf.lam[k] += alpha_nu * buf.dlam[k];
+  }
+  if(i < buf.T)
+  {
+    for(int e = 0; e < buf.M; e++)
+    {
+      const size_t k = fmpc::at(buf, i, e, buf.M, b);
+      buf.u[k] += alpha_s * buf.du[k];
+    }
+    // the reference clamps at numeric_limits<double>::lowest() (= -DBL_MAX, FmpcSolver.hpp:812) when an entry went negative:
+    // restated as written (array().max(c) = (a < c) ? c : a)
+    constexpr double min_positive_value = -DBL_MAX;
+    bool s_neg = false, nu_neg = false;
+    for(int e = 0; e < buf.G; e++)
+    {
+      const size_t k = fmpc::at(buf, i, e, buf.G, b);
+      const double sv = buf.s[k] + alpha_s * buf.ds[k];
+      const double nv = buf.nu[k] + alpha_nu * buf.dnu[k];
+      buf.s[k] = sv;
+      buf.nu[k] = nv;
+      s_neg = s_neg || sv < 0;
+      nu_neg = nu_neg || nv < 0;
+    }
+    if(s_neg || nu_neg)
+    {
+      for(int e = 0; e < buf.G; e++)
+      {
+        const size_t k = fmpc::at(buf, i, e, buf.G, b);
+        if(s_neg && buf.s[k] < min_positive_value)
+        {
+          buf.s[k] = min_positive_value;
+        }
+        if(nu_neg && buf.nu[k] < min_positive_value)
+        {
+          buf.nu[k] = min_positive_value;
+        }
+      }
+    }
+  }
+}
+
+/** End of solve (FmpcSolver.hpp:242-245): IterationContinued becomes MaxIterationReached. */
+__global__ void fmpc_finish_kernel(FmpcBuffers buf)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if(b < buf.B && buf.status[b] == fmpc::kStatusContinued)
+  {
+    buf.status[b] = 5; // Status::MaxIterationReached
+  }
+}
+
+/** Layout change between the C-ABI's arrays ([B][steps][E], the reference's per-instance std::vector of vectors) and the
+    device arrays ([steps][E][B]).  to_device = 1: dst is the device layout. */
+__global__ void fmpc_transpose_kernel(const double * src, double * dst, int B, int steps, int E, int to_device)
+{
+  const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t total = static_cast<size_t>(B) * steps * E;
+  if(tid >= total)
+  {
+    return;
+  }
+  const int b = static_cast<int>(tid % B);
+  const size_t ie = tid / B; // i * E + e
+  const size_t major = static_cast<size_t>(b) * steps * E + ie;
+  if(to_device)
+  {
+    dst[tid] = src[major];
+  }
+  else
+  {
+    dst[major] = src[tid];
+  }
+}
+#endif // NMPC_AMD_FMPC_COMMON_KERNELS
+
+// ---------------------------------------------------------------------------------------------------------------------
+// kernels instantiated per problem type
+// ---------------------------------------------------------------------------------------------------------------------
+
+/** init_complementary_variable (FmpcSolver.hpp:170-187). */
+template<class Problem>
+__global__ void fmpc_init_complementary_kernel(FmpcBuffers buf)
+{
+  constexpr int N = Problem::kStateDim, M = Problem::kInputDimMax, G = Problem::kIneqDim;
+  const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if(tid >= static_cast<size_t>(buf.B) * buf.T)
+  {
+    return;
+  }
+  const int b = static_cast<int>(tid % buf.B);
+  const int i = static_cast<int>(tid / buf.B);
+  constexpr double initial_barrier_eps = 1e-4;
+  constexpr double complementary_variable_margin_rate = 1e-2;
+  constexpr double complementary_variable_min = 1e-2;
+  const Problem prob = fmpc::loadProblem<Problem>(buf, b);
+  typename Problem::StateDimVector x;
+  typename Problem::InputDimVector u;
+  fmpc::loadVec(buf.x, buf, i, b, x);
+  fmpc::loadVec(buf.u, buf, i, b, u);
+  const double t = buf.t0[b] + i * prob.dt();
+  const typename Problem::IneqDimVector g = prob.ineqConst(t, x, u);
+  NMPC_UNROLL
+  for(int j = 0; j < G; j++)
+  {
+    const double neg_g = -1 * g[j];
+    const double sj = (1.0 + complementary_variable_margin_rate) * (neg_g < complementary_variable_min ? complementary_variable_min : neg_g);
+    const double r = initial_barrier_eps * (1.0 / sj);
+    buf.s[fmpc::at(buf, i, j, G, b)] = sj;
+    buf.nu[fmpc::at(buf, i, j, G, b)] =
+        (1.0 + complementary_variable_margin_rate) * (r < complementary_variable_min ? complementary_variable_min : r);
+  }
+  if(i == 0)
+  {
+    buf.barrier_eps[b] = initial_barrier_eps;
+  }
+  (void)N;
+  (void)M;
+}
+
+/** Step 1 of procOnce (FmpcSolver.hpp:394-441) for one (instance, timestep), fused with the pre-process of the backward pass
+    (:562-574: everything of it that does not depend on P) and with this timestep's terms of calcKktError (:493-520). */
+template<class Problem>
+__global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
+{
+  constexpr int N = Problem::kStateDim, M = Problem::kInputDimMax, G = Problem::kIneqDim;
+  using CL = fmpc::CoefLayout<N, M>;
+  using GL = fmpc::GainLayout<N, M>;
+  const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if(tid >= static_cast<size_t>(buf.B) * (buf.T + 1))
+  {
+    return;
+  }
+  const int b = static_cast<int>(tid % buf.B);
+  const int i = static_cast<int>(tid / buf.B);
+  if(buf.status[b] != fmpc::kStatusContinued)
+  {
+    return;
+  }
+  const Problem prob = fmpc::loadProblem<Problem>(buf, b);
+  const double dt = prob.dt();
+  const double t = buf.t0[b] + i * dt;
+  typename Problem::StateDimVector x, lambda;
+  fmpc::loadVec(buf.x, buf, i, b, x);
+  fmpc::loadVec(buf.lam, buf, i, b, lambda);
+  double kkt = 0;
+  bool nan = false;
+
+  if(i == buf.T)
+  {
+    // terminal coefficient (:429-436), start of the backward recursion (2.34) (:541-548)
+    typename Problem::StateDimVector Vx;
+    typename Problem::StateStateDimMatrix Vxx;
+    prob.calcTerminalCostDeriv(t, x, Vx, Vxx);
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      const double Lx_bar = Vx[a] - lambda[a]; // (2.25a)
+      kkt += Lx_bar * Lx_bar;
+      const double sT = -1 * Lx_bar;
+      nan = nan || fmpc::bad(Vx[a]) || fmpc::bad(Lx_bar);
+      buf.gain[fmpc::at(buf, i, GL::S + a, GL::kStride, b)] = sT;
+    }
+    NMPC_UNROLL
+    for(int e = 0; e < N * N; e++)
+    {
+      nan = nan || fmpc::bad(Vxx.data()[e]);
+      buf.gain[fmpc::at(buf, i, GL::P + e, GL::kStride, b)] = Vxx.data()[e];
+    }
+    buf.part[fmpc::at(buf, i, 0, 3, b)] = kkt;
+    if(nan)
+    {
+      atomicOr(&buf.flags[b], 1);
+    }
+    return;
+  }
+
+  typename Problem::InputDimVector u;
+  typename Problem::StateDimVector next_x, next_lambda;
+  typename Problem::IneqDimVector s, nu;
+  fmpc::loadVec(buf.u, buf, i, b, u);
+  fmpc::loadVec(buf.x, buf, i + 1, b, next_x);
+  fmpc::loadVec(buf.lam, buf, i + 1, b, next_lambda);
+  fmpc::loadVec(buf.s, buf, i, b, s);
+  fmpc::loadVec(buf.nu, buf, i, b, nu);
+
+  typename Problem::StateStateDimMatrix A, Lxx;
+  typename Problem::StateInputDimMatrix Bm, Lxu;
+  typename Problem::IneqStateDimMatrix C;
+  typename Problem::IneqInputDimMatrix D;
+  typename Problem::StateDimVector Lx;
+  typename Problem::InputDimVector Lu;
+  typename Problem::InputInputDimMatrix Luu;
+  prob.calcStateEqDeriv(t, x, u, A, Bm);
+  prob.calcIneqConstDeriv(t, x, u, C, D);
+  prob.calcRunningCostDeriv(t, x, u, Lx, Lu, Lxx, Luu, Lxu);
+  const typename Problem::StateDimVector f = prob.stateEq(t, x, u);
+  const typename Problem::IneqDimVector g = prob.ineqConst(t, x, u);
+
+  if(i == 0)
+  {
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      const double e = buf.x0[static_cast<size_t>(a) * buf.B + b] - x[a];
+      kkt += e * e;
+    }
+  }
+  double x_bar[N], g_bar[G > 0 ? G : 1], Lx_bar[N], Lu_bar[M > 0 ? M : 1];
+  double part = 0;
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    x_bar[a] = f[a] - next_x[a]; // (2.23c)
+    part += x_bar[a] * x_bar[a];
+    nan = nan || fmpc::bad(x_bar[a]);
+  }
+  kkt += part;
+  part = 0;
+  NMPC_UNROLL
+  for(int a = 0; a < G; a++)
+  {
+    g_bar[a] = g[a] + s[a]; // (2.23d)
+    part += g_bar[a] * g_bar[a];
+    nan = nan || fmpc::bad(g_bar[a]);
+  }
+  kkt += part;
+  part = 0;
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++) // (2.25b)
+  {
+    double at = 0, ct = 0;
+    NMPC_UNROLL
+    for(int r = 0; r < N; r++)
+    {
+      at += A(r, a) * next_lambda[r];
+    }
+    NMPC_UNROLL
+    for(int r = 0; r < G; r++)
+    {
+      ct += C(r, a) * nu[r];
+    }
+    Lx_bar[a] = ((-1 * lambda[a] + dt * Lx[a]) + at) + ct;
+    part += Lx_bar[a] * Lx_bar[a];
+    nan = nan || fmpc::bad(Lx_bar[a]) || fmpc::bad(Lx[a]);
+  }
+  kkt += part;
+  part = 0;
+  NMPC_UNROLL
+  for(int a = 0; a < M; a++) // (2.25c)
+  {
+    double bt = 0, dn = 0;
+    NMPC_UNROLL
+    for(int r = 0; r < N; r++)
+    {
+      bt += Bm(r, a) * next_lambda[r];
+    }
+    NMPC_UNROLL
+    for(int r = 0; r < G; r++)
+    {
+      dn += D(r, a) * nu[r];
+    }
+    Lu_bar[a] = (dt * Lu[a] + bt) + dn;
+    part += Lu_bar[a] * Lu_bar[a];
+    nan = nan || fmpc::bad(Lu_bar[a]) || fmpc::bad(Lu[a]);
+  }
+  kkt += part;
+  part = 0;
+  NMPC_UNROLL
+  for(int j = 0; j < G; j++) // complementarity term of calcKktError(0.0) (:509-510)
+  {
+    const double v = s[j] * nu[j];
+    const double e = v < 0.0 ? 0.0 : v; // array().max(0): (a < 0) ? 0 : a
+    part += e * e;
+  }
+  kkt += part;
+  buf.part[fmpc::at(buf, i, 0, 3, b)] = kkt;
+
+  // Coefficient::containsNaN (:136-154) on what is not stored below
+  NMPC_UNROLL
+  for(int e = 0; e < N * N; e++)
+  {
+    nan = nan || fmpc::bad(A.data()[e]) || fmpc::bad(Lxx.data()[e]);
+  }
+  NMPC_UNROLL
+  for(int e = 0; e < N * M; e++)
+  {
+    nan = nan || fmpc::bad(Bm.data()[e]) || fmpc::bad(Lxu.data()[e]);
+  }
+  NMPC_UNROLL
+  for(int e = 0; e < G * N; e++)
+  {
+    nan = nan || fmpc::bad(C.data()[e]);
+  }
+  NMPC_UNROLL
+  for(int e = 0; e < G * M; e++)
+  {
+    nan = nan || fmpc::bad(D.data()[e]);
+  }
+  NMPC_UNROLL
+  for(int e = 0; e < M * M; e++)
+  {
+    nan = nan || fmpc::bad(Luu.data()[e]);
+  }
+  if(nan)
+  {
+    atomicOr(&buf.flags[b], 1);
+  }
+
+  // pre-process of the backward pass (:562-574)
+  const double barrier_eps = buf.barrier_eps[b];
+  double nu_s[G > 0 ? G : 1], tilde_sub[G > 0 ? G : 1];
+  NMPC_UNROLL
+  for(int j = 0; j < G; j++)
+  {
+    nu_s[j] = nu[j] / s[j];
+    tilde_sub[j] = (nu_s[j] * g_bar[j] - nu[j]) + barrier_eps * (1.0 / s[j]);
+  }
+  NMPC_UNROLL
+  for(int e = 0; e < N * N; e++)
+  {
+    buf.coef[fmpc::at(buf, i, CL::A + e, CL::kStride, b)] = A.data()[e];
+  }
+  NMPC_UNROLL
+  for(int e = 0; e < N * M; e++)
+  {
+    buf.coef[fmpc::at(buf, i, CL::B + e, CL::kStride, b)] = Bm.data()[e];
+  }
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    buf.coef[fmpc::at(buf, i, CL::XBAR + a, CL::kStride, b)] = x_bar[a];
+  }
+  NMPC_UNROLL
+  for(int c = 0; c < N; c++)
+  {
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int j = 0; j < G; j++)
+      {
+        acc += (C(j, a) * nu_s[j]) * C(j, c);
+      }
+      buf.coef[fmpc::at(buf, i, CL::QXX + a + c * N, CL::kStride, b)] = dt * Lxx(a, c) + acc; // (2.28c)
+    }
+  }
+  NMPC_UNROLL
+  for(int c = 0; c < M; c++)
+  {
+    NMPC_UNROLL
+    for(int a = 0; a < M; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int j = 0; j < G; j++)
+      {
+        acc += (D(j, a) * nu_s[j]) * D(j, c);
+      }
+      buf.coef[fmpc::at(buf, i, CL::QUU + a + c * M, CL::kStride, b)] = dt * Luu(a, c) + acc; // (2.28e)
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int j = 0; j < G; j++)
+      {
+        acc += (C(j, a) * nu_s[j]) * D(j, c);
+      }
+      buf.coef[fmpc::at(buf, i, CL::QXU + a + c * N, CL::kStride, b)] = dt * Lxu(a, c) + acc; // (2.28d)
+    }
+  }
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    double acc = 0;
+    NMPC_UNROLL
+    for(int j = 0; j < G; j++)
+    {
+      acc += C(j, a) * tilde_sub[j];
+    }
+    buf.coef[fmpc::at(buf, i, CL::LXT + a, CL::kStride, b)] = Lx_bar[a] + acc; // (2.28f)
+  }
+  NMPC_UNROLL
+  for(int a = 0; a < M; a++)
+  {
+    double acc = 0;
+    NMPC_UNROLL
+    for(int j = 0; j < G; j++)
+    {
+      acc += D(j, a) * tilde_sub[j];
+    }
+    buf.coef[fmpc::at(buf, i, CL::LUT + a, CL::kStride, b)] = Lu_bar[a] + acc; // (2.28g)
+  }
+}
+
+/** KKT-error test (FmpcSolver.hpp:443-449), backward pass (:522-665) and the sequential part of the forward pass (:667-687) of
+    one instance per lane. */
+template<int N, int M>
+__global__ void __launch_bounds__(64) fmpc_riccati_kernel(FmpcBuffers buf, int iter)
+{
+  using CL = fmpc::CoefLayout<N, M>;
+  using GL = fmpc::GainLayout<N, M>;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if(b >= buf.B || buf.status[b] != fmpc::kStatusContinued)
+  {
+    return;
+  }
+  const int T = buf.T;
+  {
+    double kkt_error = 0;
+    for(int i = 0; i <= T; i++)
+    {
+      kkt_error += buf.part[fmpc::at(buf, i, 0, 3, b)];
+    }
+    kkt_error = sqrt(kkt_error);
+    buf.trace[(static_cast<size_t>(b) * buf.max_iter + (iter - 1)) * NMPC_HIP_FMPC_NTRACE + NMPC_HIP_FMPC_TRACE_KKT_ERROR] =
+        kkt_error;
+    if(kkt_error <= buf.kkt_error_thre)
+    {
+      buf.status[b] = 1; // Status::Succeeded
+      return;
+    }
+  }
+
+  // ---- backward pass
+  double s[N], P[N * N];
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    s[a] = buf.gain[fmpc::at(buf, T, GL::S + a, GL::kStride, b)];
+  }
+  NMPC_UNROLL
+  for(int e = 0; e < N * N; e++)
+  {
+    P[e] = buf.gain[fmpc::at(buf, T, GL::P + e, GL::kStride, b)];
+  }
+  bool nan = false;
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    nan = nan || fmpc::bad(s[a]);
+  }
+  bool llt_failed = false;
+  for(int i = T - 1; i >= 0; i--)
+  {
+    double A[N * N], Bm[N * M > 0 ? N * M : 1], x_bar[N];
+    double F[N * N], H[N * M > 0 ? N * M : 1], Gm[M * M > 0 ? M * M : 1], Lx_t[N], Lu_t[M > 0 ? M : 1];
+    NMPC_UNROLL
+    for(int e = 0; e < N * N; e++)
+    {
+      A[e] = buf.coef[fmpc::at(buf, i, CL::A + e, CL::kStride, b)];
+      F[e] = buf.coef[fmpc::at(buf, i, CL::QXX + e, CL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int e = 0; e < N * M; e++)
+    {
+      Bm[e] = buf.coef[fmpc::at(buf, i, CL::B + e, CL::kStride, b)];
+      H[e] = buf.coef[fmpc::at(buf, i, CL::QXU + e, CL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int e = 0; e < M * M; e++)
+    {
+      Gm[e] = buf.coef[fmpc::at(buf, i, CL::QUU + e, CL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      x_bar[a] = buf.coef[fmpc::at(buf, i, CL::XBAR + a, CL::kStride, b)];
+      Lx_t[a] = buf.coef[fmpc::at(buf, i, CL::LXT + a, CL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < M; a++)
+    {
+      Lu_t[a] = buf.coef[fmpc::at(buf, i, CL::LUT + a, CL::kStride, b)];
+    }
+
+    // F, H, G (2.35b-d) (:576-578): A^T P first, then times A / B; B^T P times B
+    double AtP[N * N], BtP[N * M > 0 ? N * M : 1];
+    NMPC_UNROLL
+    for(int c = 0; c < N; c++)
+    {
+      NMPC_UNROLL
+      for(int a = 0; a < N; a++)
+      {
+        double acc = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < N; r++)
+        {
+          acc += A[r + a * N] * P[r + c * N];
+        }
+        AtP[a + c * N] = acc;
+      }
+      NMPC_UNROLL
+      for(int a = 0; a < M; a++)
+      {
+        double acc = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < N; r++)
+        {
+          acc += Bm[r + a * N] * P[r + c * N];
+        }
+        BtP[a + c * M] = acc;
+      }
+    }
+    NMPC_UNROLL
+    for(int c = 0; c < N; c++)
+    {
+      NMPC_UNROLL
+      for(int a = 0; a < N; a++)
+      {
+        double acc = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < N; r++)
+        {
+          acc += AtP[a + r * N] * A[r + c * N];
+        }
+        F[a + c * N] += acc;
+      }
+    }
+    NMPC_UNROLL
+    for(int c = 0; c < M; c++)
+    {
+      NMPC_UNROLL
+      for(int a = 0; a < N; a++)
+      {
+        double acc = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < N; r++)
+        {
+          acc += AtP[a + r * N] * Bm[r + c * N];
+        }
+        H[a + c * N] += acc;
+      }
+      NMPC_UNROLL
+      for(int a = 0; a < M; a++)
+      {
+        double acc = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < N; r++)
+        {
+          acc += BtP[a + r * M] * Bm[r + c * N];
+        }
+        Gm[a + c * M] += acc;
+      }
+    }
+
+    // gains (2.35e) (:582-617)
+    double Px_s[N];
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int r = 0; r < N; r++)
+      {
+        acc += P[a + r * N] * x_bar[r];
+      }
+      Px_s[a] = acc - s[a];
+    }
+    double k[M > 0 ? M : 1], K[M * N > 0 ? M * N : 1];
+    if constexpr(M > 0)
+    {
+      NMPC_UNROLL
+      for(int a = 0; a < M; a++)
+      {
+        double acc = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < N; r++)
+        {
+          acc += Bm[r + a * N] * Px_s[r];
+        }
+        k[a] = acc + Lu_t[a];
+      }
+      NMPC_UNROLL
+      for(int c = 0; c < N; c++)
+      {
+        NMPC_UNROLL
+        for(int a = 0; a < M; a++)
+        {
+          K[a + c * M] = H[c + a * N];
+        }
+      }
+      fmpc::Ldlt<M> ldlt;
+      if(ldlt.compute(Gm))
+      {
+        ldlt.solveInPlace(k);
+        NMPC_UNROLL
+        for(int c = 0; c < N; c++)
+        {
+          ldlt.solveInPlace(K + c * M);
+        }
+      }
+      else
+      {
+        if(buf.break_if_llt_fails)
+        {
+          llt_failed = true;
+          break;
+        }
+        fmpc::fullPivLuSolveInPlace<M>(Gm, k);
+        for(int c = 0; c < N; c++)
+        {
+          fmpc::fullPivLuSolveInPlace<M>(Gm, K + c * M);
+        }
+      }
+      NMPC_UNROLL
+      for(int a = 0; a < M; a++)
+      {
+        k[a] = -1 * k[a];
+      }
+      NMPC_UNROLL
+      for(int e = 0; e < M * N; e++)
+      {
+        K[e] = -1 * K[e];
+      }
+    }
+
+    // post-process (2.35a) (:620-631)
+    double s_new[N], P_new[N * N];
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      double at = 0, hk = 0;
+      NMPC_UNROLL
+      for(int r = 0; r < N; r++)
+      {
+        at += A[r + a * N] * (-1 * Px_s[r]);
+      }
+      NMPC_UNROLL
+      for(int r = 0; r < M; r++)
+      {
+        hk += H[a + r * N] * k[r];
+      }
+      s_new[a] = (at - Lx_t[a]) - hk;
+    }
+    double KtG[N * M > 0 ? N * M : 1];
+    NMPC_UNROLL
+    for(int c = 0; c < M; c++)
+    {
+      NMPC_UNROLL
+      for(int a = 0; a < N; a++)
+      {
+        double acc = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < M; r++)
+        {
+          acc += K[r + a * M] * Gm[r + c * M];
+        }
+        KtG[a + c * N] = acc;
+      }
+    }
+    NMPC_UNROLL
+    for(int c = 0; c < N; c++)
+    {
+      NMPC_UNROLL
+      for(int a = 0; a < N; a++)
+      {
+        double acc = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < M; r++)
+        {
+          acc += KtG[a + r * N] * K[r + c * M];
+        }
+        P_new[a + c * N] = F[a + c * N] - acc;
+      }
+    }
+    NMPC_UNROLL
+    for(int c = 0; c < N; c++)
+    {
+      NMPC_UNROLL
+      for(int a = 0; a < N; a++)
+      {
+        P[a + c * N] = 0.5 * (P_new[a + c * N] + P_new[c + a * N]); // enforce symmetric (:627-629)
+      }
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      s[a] = s_new[a];
+    }
+
+    // save gains (:634-637)
+    NMPC_UNROLL
+    for(int a = 0; a < M; a++)
+    {
+      nan = nan || fmpc::bad(k[a]);
+      buf.gain[fmpc::at(buf, i, GL::k + a, GL::kStride, b)] = k[a];
+    }
+    NMPC_UNROLL
+    for(int e = 0; e < M * N; e++)
+    {
+      nan = nan || fmpc::bad(K[e]);
+      buf.gain[fmpc::at(buf, i, GL::K + e, GL::kStride, b)] = K[e];
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      nan = nan || fmpc::bad(s[a]);
+      buf.gain[fmpc::at(buf, i, GL::S + a, GL::kStride, b)] = s[a];
+    }
+    NMPC_UNROLL
+    for(int e = 0; e < N * N; e++)
+    {
+      nan = nan || fmpc::bad(P[e]);
+      buf.gain[fmpc::at(buf, i, GL::P + e, GL::kStride, b)] = P[e];
+    }
+  }
+  if(llt_failed || (buf.check_nan && (nan || (buf.flags[b] & 1)))) // :640-653
+  {
+    buf.status[b] = 3; // Status::ErrorInBackward
+    return;
+  }
+
+  // ---- forward pass, the recursion over the timesteps (:669-687)
+  double dx[N];
+  bool dnan = false;
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    dx[a] = buf.x0[static_cast<size_t>(a) * buf.B + b] - buf.x[fmpc::at(buf, 0, a, N, b)];
+  }
+  for(int i = 0; i <= T; i++)
+  {
+    double Pm[N * N], sv[N];
+    NMPC_UNROLL
+    for(int e = 0; e < N * N; e++)
+    {
+      Pm[e] = buf.gain[fmpc::at(buf, i, GL::P + e, GL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      sv[a] = buf.gain[fmpc::at(buf, i, GL::S + a, GL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int r = 0; r < N; r++)
+      {
+        acc += Pm[a + r * N] * dx[r];
+      }
+      const double dl = acc - sv[a]; // (2.33)
+      dnan = dnan || fmpc::bad(dl) || fmpc::bad(dx[a]);
+      buf.dlam[fmpc::at(buf, i, a, N, b)] = dl;
+      buf.dx[fmpc::at(buf, i, a, N, b)] = dx[a];
+    }
+    if(i < T)
+    {
+      double du[M > 0 ? M : 1];
+      NMPC_UNROLL
+      for(int a = 0; a < M; a++)
+      {
+        double acc = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < N; r++)
+        {
+          acc += buf.gain[fmpc::at(buf, i, GL::K + a + r * M, GL::kStride, b)] * dx[r];
+        }
+        du[a] = acc + buf.gain[fmpc::at(buf, i, GL::k + a, GL::kStride, b)]; // (2.36)
+        dnan = dnan || fmpc::bad(du[a]);
+        buf.du[fmpc::at(buf, i, a, M, b)] = du[a];
+      }
+      double nx[N];
+      NMPC_UNROLL
+      for(int a = 0; a < N; a++)
+      {
+        double ax = 0, bu = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < N; r++)
+        {
+          ax += buf.coef[fmpc::at(buf, i, CL::A + a + r * N, CL::kStride, b)] * dx[r];
+        }
+        NMPC_UNROLL
+        for(int r = 0; r < M; r++)
+        {
+          bu += buf.coef[fmpc::at(buf, i, CL::B + a + r * N, CL::kStride, b)] * du[r];
+        }
+        nx[a] = (ax + bu) + buf.coef[fmpc::at(buf, i, CL::XBAR + a, CL::kStride, b)]; // (2.26b)
+      }
+      NMPC_UNROLL
+      for(int a = 0; a < N; a++)
+      {
+        dx[a] = nx[a];
+      }
+    }
+  }
+  if(dnan)
+  {
+    buf.flags[b] |= 2; // single writer here; fmpc_delta_kernel ORs the same bit atomically in a later launch
+  }
+}
+
+/** The timestep-parallel part of the forward pass (FmpcSolver.hpp:689-697: ds, dnu), its share of the NaN check (:699) and the
+    per-timestep candidates of the fraction-to-boundary rule (:713-731).  C, D and g are re-evaluated instead of being kept
+    from the coefficient kernel (for the box-type rows of the reference's problems that is a handful of instructions against
+    (G N + G M + G) x 16 bytes of HBM traffic per timestep). */
+template<class Problem>
+__global__ void __launch_bounds__(256) fmpc_delta_kernel(FmpcBuffers buf)
+{
+  constexpr int N = Problem::kStateDim, M = Problem::kInputDimMax, G = Problem::kIneqDim;
+  const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if(tid >= static_cast<size_t>(buf.B) * buf.T)
+  {
+    return;
+  }
+  const int b = static_cast<int>(tid % buf.B);
+  const int i = static_cast<int>(tid / buf.B);
+  if(buf.status[b] != fmpc::kStatusContinued)
+  {
+    return;
+  }
+  const Problem prob = fmpc::loadProblem<Problem>(buf, b);
+  const double t = buf.t0[b] + i * prob.dt();
+  typename Problem::StateDimVector x, dx;
+  typename Problem::InputDimVector u, du;
+  typename Problem::IneqDimVector s, nu;
+  fmpc::loadVec(buf.x, buf, i, b, x);
+  fmpc::loadVec(buf.u, buf, i, b, u);
+  fmpc::loadVec(buf.dx, buf, i, b, dx);
+  fmpc::loadVec(buf.du, buf, i, b, du);
+  fmpc::loadVec(buf.s, buf, i, b, s);
+  fmpc::loadVec(buf.nu, buf, i, b, nu);
+  typename Problem::IneqStateDimMatrix C;
+  typename Problem::IneqInputDimMatrix D;
+  prob.calcIneqConstDeriv(t, x, u, C, D);
+  const typename Problem::IneqDimVector g = prob.ineqConst(t, x, u);
+  const double barrier_eps = buf.barrier_eps[b];
+  constexpr double margin_ratio = 0.995;
+  double alpha_s = 1.0, alpha_nu = 1.0;
+  bool nan = false;
+  NMPC_UNROLL
+  for(int j = 0; j < G; j++)
+  {
+    double cx = 0, dd = 0;
+    NMPC_UNROLL
+    for(int r = 0; r < N; r++)
+    {
+      cx += C(j, r) * dx[r];
+    }
+    NMPC_UNROLL
+    for(int r = 0; r < M; r++)
+    {
+      dd += D(j, r) * du[r];
+    }
+    const double g_bar = g[j] + s[j];
+    const double dsj = -1 * ((cx + dd) + g_bar); // (2.27a)
+    const double dnj = -1 * (nu[j] * (dsj + s[j]) - barrier_eps) / s[j]; // (2.27b)
+    buf.ds[fmpc::at(buf, i, j, G, b)] = dsj;
+    buf.dnu[fmpc::at(buf, i, j, G, b)] = dnj;
+    nan = nan || fmpc::bad(dsj) || fmpc::bad(dnj);
+    if(dsj < 0) // (19.9) in Nocedal & Wright
+    {
+      const double c = -1 * margin_ratio * s[j] / dsj;
+      alpha_s = (c < alpha_s) ? c : alpha_s;
+    }
+    if(dnj < 0)
+    {
+      const double c = -1 * margin_ratio * nu[j] / dnj;
+      alpha_nu = (c < alpha_nu) ? c : alpha_nu;
+    }
+  }
+  buf.part[fmpc::at(buf, i, 1, 3, b)] = alpha_s;
+  buf.part[fmpc::at(buf, i, 2, 3, b)] = alpha_nu;
+  if(nan)
+  {
+    atomicOr(&buf.flags[b], 2);
+  }
+}
+
+/** l1NormDirectionalDeriv (MathUtils.h:17-38) for one row: func_i, (jac row i) . dir. */
+__device__ __forceinline__ double fmpcL1RowDeriv(double func_i, double row_dot_dir)
+{
+  return func_i > 0 ? row_dot_dir : (func_i < 0 ? -1 * row_dot_dir : fabs(row_dot_dir));
+}
+
+/** Line search on the l1 merit function (FmpcSolver.hpp:748-792 with setupMeritFunc :840-936 and calcMeritFunc :938-981), one
+    instance per lane.  Off by default in the reference (FmpcSolver.h:85) and in both of its tests; kept sequential over the
+    horizon because the number of backtracking trials differs per instance. */
+template<class Problem>
+__global__ void __launch_bounds__(64) fmpc_line_search_kernel(FmpcBuffers buf, int iter)
+{
+  constexpr int N = Problem::kStateDim, M = Problem::kInputDimMax, G = Problem::kIneqDim;
+  using CL = fmpc::CoefLayout<N, M>;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if(b >= buf.B || buf.status[b] != fmpc::kStatusContinued)
+  {
+    return;
+  }
+  const int T = buf.T;
+  const Problem prob = fmpc::loadProblem<Problem>(buf, b);
+  const double dt = prob.dt();
+  const double t0 = buf.t0[b];
+  const double barrier_eps = buf.barrier_eps[b];
+
+  // merit function at a trial step length: FmpcSolver::calcMeritFunc on variable_ + alpha * delta_variable_ (alpha = 0: the
+  // function part of setupMeritFunc)
+  auto merit = [&](double alpha, double & obj, double & con) {
+    obj = 0;
+    con = 0;
+    typename Problem::StateDimVector x, next_x;
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      x[a] = buf.x[fmpc::at(buf, 0, a, N, b)] + alpha * buf.dx[fmpc::at(buf, 0, a, N, b)];
+      con += fabs(buf.x0[static_cast<size_t>(a) * buf.B + b] - x[a]);
+    }
+    for(int i = 0; i < T; i++)
+    {
+      const double t = t0 + i * dt;
+      typename Problem::InputDimVector u;
+      NMPC_UNROLL
+      for(int a = 0; a < M; a++)
+      {
+        u[a] = buf.u[fmpc::at(buf, i, a, M, b)] + alpha * buf.du[fmpc::at(buf, i, a, M, b)];
+      }
+      NMPC_UNROLL
+      for(int a = 0; a < N; a++)
+      {
+        next_x[a] = buf.x[fmpc::at(buf, i + 1, a, N, b)] + alpha * buf.dx[fmpc::at(buf, i + 1, a, N, b)];
+      }
+      obj += prob.runningCost(t, x, u) * dt;
+      const typename Problem::IneqDimVector g = prob.ineqConst(t, x, u);
+      double logsum = 0, c2 = 0;
+      NMPC_UNROLL
+      for(int j = 0; j < G; j++)
+      {
+        const double sj = buf.s[fmpc::at(buf, i, j, G, b)] + alpha * buf.ds[fmpc::at(buf, i, j, G, b)];
+        logsum += log(sj);
+        c2 += fabs(g[j] + sj);
+      }
+      obj += -1 * barrier_eps * logsum;
+      const typename Problem::StateDimVector f = prob.stateEq(t, x, u);
+      double c1 = 0;
+      NMPC_UNROLL
+      for(int a = 0; a < N; a++)
+      {
+        c1 += fabs(f[a] - next_x[a]);
+      }
+      con += c1;
+      con += c2;
+      x = next_x;
+    }
+    obj += prob.terminalCost(t0 + T * dt, x);
+  };
+
+  // setupMeritFunc: directional derivatives (:852-905)
+  double merit_func_obj, merit_func_const;
+  merit(0.0, merit_func_obj, merit_func_const);
+  double merit_deriv_obj = 0, merit_deriv_const = 0;
+  {
+    double acc = 0;
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      const double cf = buf.x0[static_cast<size_t>(a) * buf.B + b] - buf.x[fmpc::at(buf, 0, a, N, b)];
+      acc += fmpcL1RowDeriv(cf, -1 * buf.dx[fmpc::at(buf, 0, a, N, b)]);
+    }
+    merit_deriv_const += acc;
+  }
+  for(int i = 0; i < T; i++)
+  {
+    const double t = t0 + i * dt;
+    typename Problem::StateDimVector x, next_x, dx, dnx;
+    typename Problem::InputDimVector u, du;
+    typename Problem::IneqDimVector s, ds;
+    fmpc::loadVec(buf.x, buf, i, b, x);
+    fmpc::loadVec(buf.x, buf, i + 1, b, next_x);
+    fmpc::loadVec(buf.dx, buf, i, b, dx);
+    fmpc::loadVec(buf.dx, buf, i + 1, b, dnx);
+    fmpc::loadVec(buf.u, buf, i, b, u);
+    fmpc::loadVec(buf.du, buf, i, b, du);
+    fmpc::loadVec(buf.s, buf, i, b, s);
+    fmpc::loadVec(buf.ds, buf, i, b, ds);
+    typename Problem::StateDimVector Lx;
+    typename Problem::InputDimVector Lu;
+    typename Problem::StateStateDimMatrix Lxx;
+    typename Problem::InputInputDimMatrix Luu;
+    typename Problem::StateInputDimMatrix Lxu;
+    prob.calcRunningCostDeriv(t, x, u, Lx, Lu, Lxx, Luu, Lxu);
+    double lx = 0, lu = 0, invdot = 0;
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      lx += Lx[a] * dx[a];
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < M; a++)
+    {
+      lu += Lu[a] * du[a];
+    }
+    merit_deriv_obj += (lx + lu) * dt;
+    NMPC_UNROLL
+    for(int j = 0; j < G; j++)
+    {
+      invdot += (1.0 / s[j]) * ds[j];
+    }
+    merit_deriv_obj += -1 * barrier_eps * invdot;
+    {
+      const typename Problem::StateDimVector f = prob.stateEq(t, x, u);
+      double dA = 0, dB = 0, dI = 0;
+      NMPC_UNROLL
+      for(int a = 0; a < N; a++)
+      {
+        const double cf = f[a] - next_x[a];
+        double ra = 0, rb = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < N; r++)
+        {
+          ra += buf.coef[fmpc::at(buf, i, CL::A + a + r * N, CL::kStride, b)] * dx[r];
+        }
+        NMPC_UNROLL
+        for(int r = 0; r < M; r++)
+        {
+          rb += buf.coef[fmpc::at(buf, i, CL::B + a + r * N, CL::kStride, b)] * du[r];
+        }
+        dA += fmpcL1RowDeriv(cf, ra);
+        dB += fmpcL1RowDeriv(cf, rb);
+        dI += fmpcL1RowDeriv(cf, -1 * dnx[a]);
+      }
+      merit_deriv_const += dA;
+      merit_deriv_const += dB;
+      merit_deriv_const += dI;
+    }
+    {
+      typename Problem::IneqStateDimMatrix C;
+      typename Problem::IneqInputDimMatrix D;
+      prob.calcIneqConstDeriv(t, x, u, C, D);
+      const typename Problem::IneqDimVector g = prob.ineqConst(t, x, u);
+      double dC = 0, dD = 0, dI = 0;
+      NMPC_UNROLL
+      for(int j = 0; j < G; j++)
+      {
+        const double cf = g[j] + s[j];
+        double rc = 0, rd = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < N; r++)
+        {
+          rc += C(j, r) * dx[r];
+        }
+        NMPC_UNROLL
+        for(int r = 0; r < M; r++)
+        {
+          rd += D(j, r) * du[r];
+        }
+        dC += fmpcL1RowDeriv(cf, rc);
+        dD += fmpcL1RowDeriv(cf, rd);
+        dI += fmpcL1RowDeriv(cf, ds[j]);
+      }
+      merit_deriv_const += dC;
+      merit_deriv_const += dD;
+      merit_deriv_const += dI;
+    }
+  }
+  {
+    typename Problem::StateDimVector xT, Vx;
+    typename Problem::StateStateDimMatrix Vxx;
+    fmpc::loadVec(buf.x, buf, T, b, xT);
+    prob.calcTerminalCostDeriv(t0 + T * dt, xT, Vx, Vxx);
+    double acc = 0;
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      acc += Vx[a] * buf.dx[fmpc::at(buf, T, a, N, b)];
+    }
+    merit_deriv_obj += acc;
+  }
+
+  constexpr double merit_const_scale_min = 1e-3;
+  double merit_const_scale;
+  if(buf.merit_const_scale_from_lagrange_multipliers) // (18.32) in Nocedal & Wright
+  {
+    merit_const_scale = merit_const_scale_min;
+    for(int i = 0; i <= T; i++)
+    {
+      for(int a = 0; a < N; a++)
+      {
+        const double v = fabs(buf.lam[fmpc::at(buf, i, a, N, b)]);
+        merit_const_scale = (merit_const_scale < v) ? v : merit_const_scale;
+      }
+      if(i < T)
+      {
+        for(int j = 0; j < G; j++)
+        {
+          const double v = fabs(buf.nu[fmpc::at(buf, i, j, G, b)]);
+          merit_const_scale = (merit_const_scale < v) ? v : merit_const_scale;
+        }
+      }
+    }
+  }
+  else // (18.33)
+  {
+    constexpr double rho = 0.5;
+    const double v = merit_deriv_obj / ((1.0 - rho) * merit_func_const);
+    merit_const_scale = (v < merit_const_scale_min) ? merit_const_scale_min : v; // std::max(v, min)
+  }
+  const double merit_func = merit_func_obj + merit_const_scale * merit_func_const;
+  const double merit_deriv = merit_deriv_obj + merit_const_scale * merit_deriv_const;
+  buf.merit[0 * buf.B + b] = merit_func;
+  buf.merit[1 * buf.B + b] = merit_deriv;
+  buf.merit[2 * buf.B + b] = merit_const_scale;
+
+  constexpr double armijo_scale = 1e-3;
+  constexpr double alpha_s_update_ratio = 0.5;
+  constexpr double alpha_s_min = 1e-10;
+  double alpha_s = buf.alpha[0 * buf.B + b];
+  while(true)
+  {
+    if(alpha_s < alpha_s_min)
+    {
+      break;
+    }
+    double obj, con;
+    merit(alpha_s, obj, con);
+    const double merit_func_new = obj + merit_const_scale * con;
+    if(merit_func_new < merit_func + armijo_scale * alpha_s * merit_deriv)
+    {
+      break;
+    }
+    alpha_s *= alpha_s_update_ratio;
+  }
+  buf.alpha[2 * buf.B + b] = alpha_s;
+  buf.trace[(static_cast<size_t>(b) * buf.max_iter + (iter - 1)) * NMPC_HIP_FMPC_NTRACE + NMPC_HIP_FMPC_TRACE_ALPHA_S] = alpha_s;
+}
+
+/** The plant step of the reference's closed-loop tests (TestFmpcOscillator.cpp:191, TestFmpcCartPole.cpp:352):
+    x <- stateEq(t, x, u + K_0 (x_list[0] - x) * use_feedback, sim_dt), t += sim_dt, `substeps` times, on the handle's resident
+    arrays; u = u_list[0] of the last solve.  x_plant / t_plant: [N][B] / [B]. */
+template<class Problem>
+__global__ void fmpc_plant_kernel(FmpcBuffers buf, double * x_plant, double * t_plant, double sim_dt, int substeps, int use_feedback)
+{
+  constexpr int N = Problem::kStateDim, M = Problem::kInputDimMax;
+  using GL = fmpc::GainLayout<N, M>;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if(b >= buf.B)
+  {
+    return;
+  }
+  const Problem prob = fmpc::loadProblem<Problem>(buf, b);
+  typename Problem::StateDimVector x;
+  typename Problem::InputDimVector u0;
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    x[a] = x_plant[static_cast<size_t>(a) * buf.B + b];
+  }
+  NMPC_UNROLL
+  for(int a = 0; a < M; a++)
+  {
+    u0[a] = buf.u[fmpc::at(buf, 0, a, M, b)];
+  }
+  double t = t_plant[b];
+  for(int k = 0; k < substeps; k++)
+  {
+    typename Problem::InputDimVector u = u0;
+    if(use_feedback)
+    {
+      NMPC_UNROLL
+      for(int a = 0; a < M; a++)
+      {
+        double acc = 0;
+        NMPC_UNROLL
+        for(int r = 0; r < N; r++)
+        {
+          acc += buf.gain[fmpc::at(buf, 0, GL::K + a + r * M, GL::kStride, b)] * (buf.x[fmpc::at(buf, 0, r, N, b)] - x[r]);
+        }
+        u[a] += acc;
+      }
+    }
+    x = prob.stateEq(t, x, u, sim_dt);
+    t += sim_dt;
+  }
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    x_plant[static_cast<size_t>(a) * buf.B + b] = x[a];
+  }
+  t_plant[b] = t;
+}
+} // namespace hip
+} // namespace nmpc_amd

@@ -1,0 +1,123 @@
+// Type-erased description of one registered FMPC problem type: what the C-ABI (nmpc_amd/csrc/fmpc_capi.hip) knows about a
+// problem class compiled into gfx950 code (the FMPC counterpart of model_ops.hpp).
+#pragma once
+
+#include <cstddef>
+#include <new>
+#include <type_traits>
+
+#include <hip/hip_runtime.h>
+
+#include <nmpc_amd/hip/fmpc_kernels.hpp>
+
+namespace nmpc_amd
+{
+namespace hip
+{
+struct FmpcOps
+{
+  const char * name;
+  int state_dim;
+  int input_dim;
+  int ineq_dim;
+  size_t param_bytes;
+  int coef_stride; //!< doubles per timestep of FmpcBuffers::coef
+  int gain_stride; //!< doubles per timestep of FmpcBuffers::gain
+  int gain_offset_k, gain_offset_K, gain_offset_s, gain_offset_P;
+  //! placement-constructs a default problem object into out
+  void (*default_params)(void * out);
+  //! dt() of a problem object
+  double (*dt)(const void * params);
+  hipError_t (*launch_init_complementary)(const FmpcBuffers & buf, hipStream_t stream);
+  hipError_t (*launch_coeff)(const FmpcBuffers & buf, hipStream_t stream);
+  hipError_t (*launch_riccati)(const FmpcBuffers & buf, int iter, hipStream_t stream);
+  hipError_t (*launch_delta)(const FmpcBuffers & buf, hipStream_t stream);
+  hipError_t (*launch_line_search)(const FmpcBuffers & buf, int iter, hipStream_t stream);
+  hipError_t (*launch_plant)(const FmpcBuffers & buf,
+                             double * x_plant,
+                             double * t_plant,
+                             double sim_dt,
+                             int substeps,
+                             int use_feedback,
+                             hipStream_t stream);
+};
+
+template<class Problem>
+struct FmpcOpsOf
+{
+  static constexpr int N = Problem::kStateDim, M = Problem::kInputDimMax, G = Problem::kIneqDim;
+  static_assert(std::is_trivially_copyable<Problem>::value, "[FMPC] a problem object must be trivially copyable");
+  static_assert(!Problem::kDynamicInput, "[FMPC] dynamic input dimensions are not offered");
+
+  static unsigned blocks(size_t threads, unsigned block)
+  {
+    return static_cast<unsigned>((threads + block - 1) / block);
+  }
+
+  static FmpcOps make()
+  {
+    using GL = fmpc::GainLayout<N, M>;
+    FmpcOps o{};
+    o.name = Problem::kName;
+    o.state_dim = N;
+    o.input_dim = M;
+    o.ineq_dim = G;
+    o.param_bytes = sizeof(Problem);
+    o.coef_stride = fmpc::CoefLayout<N, M>::kStride;
+    o.gain_stride = GL::kStride;
+    o.gain_offset_k = GL::k;
+    o.gain_offset_K = GL::K;
+    o.gain_offset_s = GL::S;
+    o.gain_offset_P = GL::P;
+    o.default_params = [](void * out) { new(out) Problem(); };
+    o.dt = [](const void * params) { return static_cast<const Problem *>(params)->dt(); };
+    o.launch_init_complementary = [](const FmpcBuffers & buf, hipStream_t stream) {
+      hipLaunchKernelGGL(fmpc_init_complementary_kernel<Problem>, dim3(blocks(static_cast<size_t>(buf.B) * buf.T, 256)), dim3(256),
+                         0, stream, buf);
+      return hipGetLastError();
+    };
+    o.launch_coeff = [](const FmpcBuffers & buf, hipStream_t stream) {
+      hipLaunchKernelGGL(fmpc_coeff_kernel<Problem>, dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)), dim3(256), 0,
+                         stream, buf);
+      return hipGetLastError();
+    };
+    o.launch_riccati = [](const FmpcBuffers & buf, int iter, hipStream_t stream) {
+      hipLaunchKernelGGL((fmpc_riccati_kernel<N, M>), dim3(blocks(buf.B, 64)), dim3(64), 0, stream, buf, iter);
+      return hipGetLastError();
+    };
+    o.launch_delta = [](const FmpcBuffers & buf, hipStream_t stream) {
+      hipLaunchKernelGGL(fmpc_delta_kernel<Problem>, dim3(blocks(static_cast<size_t>(buf.B) * buf.T, 256)), dim3(256), 0, stream,
+                         buf);
+      return hipGetLastError();
+    };
+    o.launch_line_search = [](const FmpcBuffers & buf, int iter, hipStream_t stream) {
+      hipLaunchKernelGGL(fmpc_line_search_kernel<Problem>, dim3(blocks(buf.B, 64)), dim3(64), 0, stream, buf, iter);
+      return hipGetLastError();
+    };
+    o.launch_plant = [](const FmpcBuffers & buf, double * x_plant, double * t_plant, double sim_dt, int substeps, int use_feedback,
+                        hipStream_t stream) {
+      hipLaunchKernelGGL(fmpc_plant_kernel<Problem>, dim3(blocks(buf.B, 64)), dim3(64), 0, stream, buf, x_plant, t_plant, sim_dt,
+                         substeps, use_feedback);
+      return hipGetLastError();
+    };
+    return o;
+  }
+};
+} // namespace hip
+} // namespace nmpc_amd
+
+extern "C" int nmpc_hip_fmpc_register_model(const nmpc_amd::hip::FmpcOps * ops);
+
+/** Registers the FMPC problem type under ProblemType::kName. */
+#define NMPC_AMD_REGISTER_FMPC_PROBLEM(ProblemType)                                    \
+  namespace                                                                            \
+  {                                                                                    \
+  struct ProblemType##FmpcRegistrar                                                    \
+  {                                                                                    \
+    ProblemType##FmpcRegistrar()                                                       \
+    {                                                                                  \
+      static const nmpc_amd::hip::FmpcOps ops = nmpc_amd::hip::FmpcOpsOf<ProblemType>::make(); \
+      nmpc_hip_fmpc_register_model(&ops);                                              \
+    }                                                                                  \
+  } g_##ProblemType##_fmpc_registrar;                                                  \
+  }

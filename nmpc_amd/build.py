@@ -17,7 +17,7 @@ LIB_DIR = os.path.join(ROOT, "nmpc_amd", "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libnmpc_hip_ddp.so")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 SOURCES = ("capi.hip", "builtin_models.hip", "model_centroidal.hip", "model_quadrotor.hip", "model_manipulator.hip",
-           "model_quadrotor_f32.hip")
+           "model_quadrotor_f32.hip", "fmpc_capi.hip", "fmpc_models.hip")
 ARCH = "gfx950"
 # per-source flags.  builtin_models.hip holds the quad kernel (ddp_kernels_quad.hpp): its fp64 matrix-core results are
 # consumed by VALU / DPP instructions right away, so they have to live in ordinary VGPRs — by default a kernel that may
@@ -32,7 +32,7 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the MI355X path cannot be built (there is no CPU fallback)")
 
 
-HOST_ONLY_HEADERS = ("DDPSolverBatch.hpp",)  # mirrors over the C-ABI: no translation unit of the library includes them
+HOST_ONLY_HEADERS = ("DDPSolverBatch.hpp", "DDPSolverSharded.hpp", "FmpcSolverBatch.hpp")  # mirrors over the C-ABI: no translation unit of the library includes them
 
 
 def _headers():
@@ -42,10 +42,37 @@ def _headers():
     return out
 
 
+def _obj_deps(obj: str, src: str):
+    """Files the object was compiled from: the compiler's own dependency file (-MMD) when there is one from the last build,
+    every header of the tree otherwise."""
+    dep = obj[:-2] + ".d"
+    if os.path.exists(dep) and os.path.exists(obj):
+        tokens = open(dep).read().split(":", 1)[-1].split()
+        files = [f for f in tokens if f != "\\" and f.startswith(ROOT)]
+        if files:
+            return [f for f in files if os.path.exists(f)] + [src]
+    return [src] + _headers()
+
+
+def _stale_objects():
+    out = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        if not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _obj_deps(obj, src)):
+            out.append(s)
+    return out
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    if os.path.isdir(OBJ_DIR) and os.listdir(OBJ_DIR):
+        return bool(_stale_objects()) or any(
+            os.path.getmtime(os.path.join(OBJ_DIR, f)) > os.path.getmtime(LIB_PATH) for f in os.listdir(OBJ_DIR) if f.endswith(".o"))
+    t = os.path.getmtime(LIB_PATH)  # a shipped library without its objects (the GPU box): sources and headers decide
     deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
@@ -59,16 +86,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags += os.environ.get("NMPC_AMD_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DNMPC_AMD_PROFILE_2W
     objs = []
     procs = []
+    stale = set(SOURCES) if force else set(_stale_objects())
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         if not os.path.exists(src):
             continue
         obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
         objs.append(obj)
-        if (not force) and os.path.exists(obj) and all(
-                os.path.getmtime(obj) > os.path.getmtime(d) for d in [src] + _headers()):
+        if s not in stale:
             continue
-        cmd = [cc] + flags + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
+        cmd = [cc] + flags + EXTRA_FLAGS.get(s, []) + ["-MMD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

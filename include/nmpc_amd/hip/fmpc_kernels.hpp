@@ -956,12 +956,375 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
   }
 }
 
-/** KKT-error test (FmpcSolver.hpp:443-449), backward pass (:522-665) and the sequential part of the forward pass (:667-687) of
-    one instance per lane. */
+namespace fmpc
+{
+/** What one step of the backward recursion reads: loaded one step ahead of its use (the recursion is a chain of dependent
+    small-matrix products; with the loads issued a step early their latency overlaps the arithmetic of the current step). */
+template<int N, int M>
+struct BackwardRecord
+{
+  double A[N * N], Bm[N * M > 0 ? N * M : 1], x_bar[N];
+  double F[N * N], H[N * M > 0 ? N * M : 1], Gm[M * M > 0 ? M * M : 1], Lx_t[N], Lu_t[M > 0 ? M : 1];
+
+  __device__ __forceinline__ void load(const FmpcBuffers & buf, int i, int b)
+  {
+    using CL = CoefLayout<N, M>;
+    NMPC_UNROLL
+    for(int e = 0; e < N * N; e++)
+    {
+      A[e] = buf.coef[at(buf, i, CL::A + e, CL::kStride, b)];
+      F[e] = buf.coef[at(buf, i, CL::QXX + e, CL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int e = 0; e < N * M; e++)
+    {
+      Bm[e] = buf.coef[at(buf, i, CL::B + e, CL::kStride, b)];
+      H[e] = buf.coef[at(buf, i, CL::QXU + e, CL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int e = 0; e < M * M; e++)
+    {
+      Gm[e] = buf.coef[at(buf, i, CL::QUU + e, CL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      x_bar[a] = buf.coef[at(buf, i, CL::XBAR + a, CL::kStride, b)];
+      Lx_t[a] = buf.coef[at(buf, i, CL::LXT + a, CL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < M; a++)
+    {
+      Lu_t[a] = buf.coef[at(buf, i, CL::LUT + a, CL::kStride, b)];
+    }
+  }
+};
+
+/** What one step of the forward recursion reads. */
+template<int N, int M>
+struct ForwardRecord
+{
+  double A[N * N], Bm[N * M > 0 ? N * M : 1], x_bar[N], K[M * N > 0 ? M * N : 1], k[M > 0 ? M : 1];
+
+  __device__ __forceinline__ void load(const FmpcBuffers & buf, int i, int b)
+  {
+    using CL = CoefLayout<N, M>;
+    using GL = GainLayout<N, M>;
+    NMPC_UNROLL
+    for(int e = 0; e < N * N; e++)
+    {
+      A[e] = buf.coef[at(buf, i, CL::A + e, CL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int e = 0; e < N * M; e++)
+    {
+      Bm[e] = buf.coef[at(buf, i, CL::B + e, CL::kStride, b)];
+      K[e] = buf.gain[at(buf, i, GL::K + e, GL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      x_bar[a] = buf.coef[at(buf, i, CL::XBAR + a, CL::kStride, b)];
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < M; a++)
+    {
+      k[a] = buf.gain[at(buf, i, GL::k + a, GL::kStride, b)];
+    }
+  }
+};
+
+/** One step of backwardPass (FmpcSolver.hpp:550-637): (s, P) of step i + 1 in, of step i out; gains stored.  Returns false
+    where the reference returns false (LDLT failure with break_if_llt_fails). */
+template<int N, int M>
+__device__ __forceinline__ bool backwardStep(const FmpcBuffers & buf, int i, int b, BackwardRecord<N, M> & r, double * s, double * P, bool & nan)
+{
+  using GL = GainLayout<N, M>;
+  // F, H, G (2.35b-d) (:576-578): A^T P first, then times A / B; B^T P times B
+  double AtP[N * N], BtP[N * M > 0 ? N * M : 1];
+  NMPC_UNROLL
+  for(int c = 0; c < N; c++)
+  {
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int q = 0; q < N; q++)
+      {
+        acc += r.A[q + a * N] * P[q + c * N];
+      }
+      AtP[a + c * N] = acc;
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < M; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int q = 0; q < N; q++)
+      {
+        acc += r.Bm[q + a * N] * P[q + c * N];
+      }
+      BtP[a + c * M] = acc;
+    }
+  }
+  NMPC_UNROLL
+  for(int c = 0; c < N; c++)
+  {
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int q = 0; q < N; q++)
+      {
+        acc += AtP[a + q * N] * r.A[q + c * N];
+      }
+      r.F[a + c * N] += acc;
+    }
+  }
+  NMPC_UNROLL
+  for(int c = 0; c < M; c++)
+  {
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int q = 0; q < N; q++)
+      {
+        acc += AtP[a + q * N] * r.Bm[q + c * N];
+      }
+      r.H[a + c * N] += acc;
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < M; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int q = 0; q < N; q++)
+      {
+        acc += BtP[a + q * M] * r.Bm[q + c * N];
+      }
+      r.Gm[a + c * M] += acc;
+    }
+  }
+
+  // gains (2.35e) (:582-617)
+  double Px_s[N];
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    double acc = 0;
+    NMPC_UNROLL
+    for(int q = 0; q < N; q++)
+    {
+      acc += P[a + q * N] * r.x_bar[q];
+    }
+    Px_s[a] = acc - s[a];
+  }
+  double k[M > 0 ? M : 1], K[M * N > 0 ? M * N : 1];
+  if constexpr(M > 0)
+  {
+    NMPC_UNROLL
+    for(int a = 0; a < M; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int q = 0; q < N; q++)
+      {
+        acc += r.Bm[q + a * N] * Px_s[q];
+      }
+      k[a] = acc + r.Lu_t[a];
+    }
+    NMPC_UNROLL
+    for(int c = 0; c < N; c++)
+    {
+      NMPC_UNROLL
+      for(int a = 0; a < M; a++)
+      {
+        K[a + c * M] = r.H[c + a * N];
+      }
+    }
+    Ldlt<M> ldlt;
+    if(ldlt.compute(r.Gm))
+    {
+      ldlt.solveInPlace(k);
+      NMPC_UNROLL
+      for(int c = 0; c < N; c++)
+      {
+        ldlt.solveInPlace(K + c * M);
+      }
+    }
+    else
+    {
+      if(buf.break_if_llt_fails)
+      {
+        return false;
+      }
+      fullPivLuSolveInPlace<M>(r.Gm, k);
+      for(int c = 0; c < N; c++)
+      {
+        fullPivLuSolveInPlace<M>(r.Gm, K + c * M);
+      }
+    }
+    NMPC_UNROLL
+    for(int a = 0; a < M; a++)
+    {
+      k[a] = -1 * k[a];
+    }
+    NMPC_UNROLL
+    for(int e = 0; e < M * N; e++)
+    {
+      K[e] = -1 * K[e];
+    }
+  }
+
+  // post-process (2.35a) (:620-631)
+  double s_new[N], P_new[N * N];
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    double at_ = 0, hk = 0;
+    NMPC_UNROLL
+    for(int q = 0; q < N; q++)
+    {
+      at_ += r.A[q + a * N] * (-1 * Px_s[q]);
+    }
+    NMPC_UNROLL
+    for(int q = 0; q < M; q++)
+    {
+      hk += r.H[a + q * N] * k[q];
+    }
+    s_new[a] = (at_ - r.Lx_t[a]) - hk;
+  }
+  double KtG[N * M > 0 ? N * M : 1];
+  NMPC_UNROLL
+  for(int c = 0; c < M; c++)
+  {
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int q = 0; q < M; q++)
+      {
+        acc += K[q + a * M] * r.Gm[q + c * M];
+      }
+      KtG[a + c * N] = acc;
+    }
+  }
+  NMPC_UNROLL
+  for(int c = 0; c < N; c++)
+  {
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      double acc = 0;
+      NMPC_UNROLL
+      for(int q = 0; q < M; q++)
+      {
+        acc += KtG[a + q * N] * K[q + c * M];
+      }
+      P_new[a + c * N] = r.F[a + c * N] - acc;
+    }
+  }
+  NMPC_UNROLL
+  for(int c = 0; c < N; c++)
+  {
+    NMPC_UNROLL
+    for(int a = 0; a < N; a++)
+    {
+      P[a + c * N] = 0.5 * (P_new[a + c * N] + P_new[c + a * N]); // enforce symmetric (:627-629)
+    }
+  }
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    s[a] = s_new[a];
+  }
+
+  // save gains (:634-637)
+  NMPC_UNROLL
+  for(int a = 0; a < M; a++)
+  {
+    nan = nan || bad(k[a]);
+    buf.gain[at(buf, i, GL::k + a, GL::kStride, b)] = k[a];
+  }
+  NMPC_UNROLL
+  for(int e = 0; e < M * N; e++)
+  {
+    nan = nan || bad(K[e]);
+    buf.gain[at(buf, i, GL::K + e, GL::kStride, b)] = K[e];
+  }
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    nan = nan || bad(s[a]);
+    buf.gain[at(buf, i, GL::S + a, GL::kStride, b)] = s[a];
+  }
+  NMPC_UNROLL
+  for(int e = 0; e < N * N; e++)
+  {
+    nan = nan || bad(P[e]);
+    buf.gain[at(buf, i, GL::P + e, GL::kStride, b)] = P[e];
+  }
+  return true;
+}
+
+/** One step of the forward recursion (FmpcSolver.hpp:676-685): du_i (2.36) and dx_{i+1} (2.26b) from dx_i. */
+template<int N, int M>
+__device__ __forceinline__ void forwardStep(const FmpcBuffers & buf, int i, int b, const ForwardRecord<N, M> & r, double * dx)
+{
+  double du[M > 0 ? M : 1];
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    buf.dx[at(buf, i, a, N, b)] = dx[a];
+  }
+  NMPC_UNROLL
+  for(int a = 0; a < M; a++)
+  {
+    double acc = 0;
+    NMPC_UNROLL
+    for(int q = 0; q < N; q++)
+    {
+      acc += r.K[a + q * M] * dx[q];
+    }
+    du[a] = acc + r.k[a];
+    buf.du[at(buf, i, a, M, b)] = du[a];
+  }
+  double nx[N];
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    double ax = 0, bu = 0;
+    NMPC_UNROLL
+    for(int q = 0; q < N; q++)
+    {
+      ax += r.A[a + q * N] * dx[q];
+    }
+    NMPC_UNROLL
+    for(int q = 0; q < M; q++)
+    {
+      bu += r.Bm[a + q * N] * du[q];
+    }
+    nx[a] = (ax + bu) + r.x_bar[a];
+  }
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
+  {
+    dx[a] = nx[a];
+  }
+}
+} // namespace fmpc
+
+/** KKT-error test (FmpcSolver.hpp:443-449), backward pass (:522-665) and the recursion of the forward pass (:667-687: dx, du;
+    dlambda of (2.33) depends on dx_i only and is left to fmpc_delta_kernel) of one instance per lane.  Both recursions run two
+    steps per loop trip on two register sets, each loaded one step before it is used. */
 template<int N, int M>
 __global__ void __launch_bounds__(64) fmpc_riccati_kernel(FmpcBuffers buf, int iter)
 {
-  using CL = fmpc::CoefLayout<N, M>;
   using GL = fmpc::GainLayout<N, M>;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if(b >= buf.B || buf.status[b] != fmpc::kStatusContinued)
@@ -1004,268 +1367,40 @@ __global__ void __launch_bounds__(64) fmpc_riccati_kernel(FmpcBuffers buf, int i
     nan = nan || fmpc::bad(s[a]);
   }
   bool llt_failed = false;
-  for(int i = T - 1; i >= 0; i--)
   {
-    double A[N * N], Bm[N * M > 0 ? N * M : 1], x_bar[N];
-    double F[N * N], H[N * M > 0 ? N * M : 1], Gm[M * M > 0 ? M * M : 1], Lx_t[N], Lu_t[M > 0 ? M : 1];
-    NMPC_UNROLL
-    for(int e = 0; e < N * N; e++)
+    fmpc::BackwardRecord<N, M> r0, r1;
+    int i = T - 1;
+    r0.load(buf, i, b);
+    while(true)
     {
-      A[e] = buf.coef[fmpc::at(buf, i, CL::A + e, CL::kStride, b)];
-      F[e] = buf.coef[fmpc::at(buf, i, CL::QXX + e, CL::kStride, b)];
-    }
-    NMPC_UNROLL
-    for(int e = 0; e < N * M; e++)
-    {
-      Bm[e] = buf.coef[fmpc::at(buf, i, CL::B + e, CL::kStride, b)];
-      H[e] = buf.coef[fmpc::at(buf, i, CL::QXU + e, CL::kStride, b)];
-    }
-    NMPC_UNROLL
-    for(int e = 0; e < M * M; e++)
-    {
-      Gm[e] = buf.coef[fmpc::at(buf, i, CL::QUU + e, CL::kStride, b)];
-    }
-    NMPC_UNROLL
-    for(int a = 0; a < N; a++)
-    {
-      x_bar[a] = buf.coef[fmpc::at(buf, i, CL::XBAR + a, CL::kStride, b)];
-      Lx_t[a] = buf.coef[fmpc::at(buf, i, CL::LXT + a, CL::kStride, b)];
-    }
-    NMPC_UNROLL
-    for(int a = 0; a < M; a++)
-    {
-      Lu_t[a] = buf.coef[fmpc::at(buf, i, CL::LUT + a, CL::kStride, b)];
-    }
-
-    // F, H, G (2.35b-d) (:576-578): A^T P first, then times A / B; B^T P times B
-    double AtP[N * N], BtP[N * M > 0 ? N * M : 1];
-    NMPC_UNROLL
-    for(int c = 0; c < N; c++)
-    {
-      NMPC_UNROLL
-      for(int a = 0; a < N; a++)
+      if(i > 0)
       {
-        double acc = 0;
-        NMPC_UNROLL
-        for(int r = 0; r < N; r++)
-        {
-          acc += A[r + a * N] * P[r + c * N];
-        }
-        AtP[a + c * N] = acc;
+        r1.load(buf, i - 1, b);
       }
-      NMPC_UNROLL
-      for(int a = 0; a < M; a++)
+      if(!fmpc::backwardStep<N, M>(buf, i, b, r0, s, P, nan))
       {
-        double acc = 0;
-        NMPC_UNROLL
-        for(int r = 0; r < N; r++)
-        {
-          acc += Bm[r + a * N] * P[r + c * N];
-        }
-        BtP[a + c * M] = acc;
+        llt_failed = true;
+        break;
       }
-    }
-    NMPC_UNROLL
-    for(int c = 0; c < N; c++)
-    {
-      NMPC_UNROLL
-      for(int a = 0; a < N; a++)
+      if(i == 0)
       {
-        double acc = 0;
-        NMPC_UNROLL
-        for(int r = 0; r < N; r++)
-        {
-          acc += AtP[a + r * N] * A[r + c * N];
-        }
-        F[a + c * N] += acc;
+        break;
       }
-    }
-    NMPC_UNROLL
-    for(int c = 0; c < M; c++)
-    {
-      NMPC_UNROLL
-      for(int a = 0; a < N; a++)
+      i--;
+      if(i > 0)
       {
-        double acc = 0;
-        NMPC_UNROLL
-        for(int r = 0; r < N; r++)
-        {
-          acc += AtP[a + r * N] * Bm[r + c * N];
-        }
-        H[a + c * N] += acc;
+        r0.load(buf, i - 1, b);
       }
-      NMPC_UNROLL
-      for(int a = 0; a < M; a++)
+      if(!fmpc::backwardStep<N, M>(buf, i, b, r1, s, P, nan))
       {
-        double acc = 0;
-        NMPC_UNROLL
-        for(int r = 0; r < N; r++)
-        {
-          acc += BtP[a + r * M] * Bm[r + c * N];
-        }
-        Gm[a + c * M] += acc;
+        llt_failed = true;
+        break;
       }
-    }
-
-    // gains (2.35e) (:582-617)
-    double Px_s[N];
-    NMPC_UNROLL
-    for(int a = 0; a < N; a++)
-    {
-      double acc = 0;
-      NMPC_UNROLL
-      for(int r = 0; r < N; r++)
+      if(i == 0)
       {
-        acc += P[a + r * N] * x_bar[r];
+        break;
       }
-      Px_s[a] = acc - s[a];
-    }
-    double k[M > 0 ? M : 1], K[M * N > 0 ? M * N : 1];
-    if constexpr(M > 0)
-    {
-      NMPC_UNROLL
-      for(int a = 0; a < M; a++)
-      {
-        double acc = 0;
-        NMPC_UNROLL
-        for(int r = 0; r < N; r++)
-        {
-          acc += Bm[r + a * N] * Px_s[r];
-        }
-        k[a] = acc + Lu_t[a];
-      }
-      NMPC_UNROLL
-      for(int c = 0; c < N; c++)
-      {
-        NMPC_UNROLL
-        for(int a = 0; a < M; a++)
-        {
-          K[a + c * M] = H[c + a * N];
-        }
-      }
-      fmpc::Ldlt<M> ldlt;
-      if(ldlt.compute(Gm))
-      {
-        ldlt.solveInPlace(k);
-        NMPC_UNROLL
-        for(int c = 0; c < N; c++)
-        {
-          ldlt.solveInPlace(K + c * M);
-        }
-      }
-      else
-      {
-        if(buf.break_if_llt_fails)
-        {
-          llt_failed = true;
-          break;
-        }
-        fmpc::fullPivLuSolveInPlace<M>(Gm, k);
-        for(int c = 0; c < N; c++)
-        {
-          fmpc::fullPivLuSolveInPlace<M>(Gm, K + c * M);
-        }
-      }
-      NMPC_UNROLL
-      for(int a = 0; a < M; a++)
-      {
-        k[a] = -1 * k[a];
-      }
-      NMPC_UNROLL
-      for(int e = 0; e < M * N; e++)
-      {
-        K[e] = -1 * K[e];
-      }
-    }
-
-    // post-process (2.35a) (:620-631)
-    double s_new[N], P_new[N * N];
-    NMPC_UNROLL
-    for(int a = 0; a < N; a++)
-    {
-      double at = 0, hk = 0;
-      NMPC_UNROLL
-      for(int r = 0; r < N; r++)
-      {
-        at += A[r + a * N] * (-1 * Px_s[r]);
-      }
-      NMPC_UNROLL
-      for(int r = 0; r < M; r++)
-      {
-        hk += H[a + r * N] * k[r];
-      }
-      s_new[a] = (at - Lx_t[a]) - hk;
-    }
-    double KtG[N * M > 0 ? N * M : 1];
-    NMPC_UNROLL
-    for(int c = 0; c < M; c++)
-    {
-      NMPC_UNROLL
-      for(int a = 0; a < N; a++)
-      {
-        double acc = 0;
-        NMPC_UNROLL
-        for(int r = 0; r < M; r++)
-        {
-          acc += K[r + a * M] * Gm[r + c * M];
-        }
-        KtG[a + c * N] = acc;
-      }
-    }
-    NMPC_UNROLL
-    for(int c = 0; c < N; c++)
-    {
-      NMPC_UNROLL
-      for(int a = 0; a < N; a++)
-      {
-        double acc = 0;
-        NMPC_UNROLL
-        for(int r = 0; r < M; r++)
-        {
-          acc += KtG[a + r * N] * K[r + c * M];
-        }
-        P_new[a + c * N] = F[a + c * N] - acc;
-      }
-    }
-    NMPC_UNROLL
-    for(int c = 0; c < N; c++)
-    {
-      NMPC_UNROLL
-      for(int a = 0; a < N; a++)
-      {
-        P[a + c * N] = 0.5 * (P_new[a + c * N] + P_new[c + a * N]); // enforce symmetric (:627-629)
-      }
-    }
-    NMPC_UNROLL
-    for(int a = 0; a < N; a++)
-    {
-      s[a] = s_new[a];
-    }
-
-    // save gains (:634-637)
-    NMPC_UNROLL
-    for(int a = 0; a < M; a++)
-    {
-      nan = nan || fmpc::bad(k[a]);
-      buf.gain[fmpc::at(buf, i, GL::k + a, GL::kStride, b)] = k[a];
-    }
-    NMPC_UNROLL
-    for(int e = 0; e < M * N; e++)
-    {
-      nan = nan || fmpc::bad(K[e]);
-      buf.gain[fmpc::at(buf, i, GL::K + e, GL::kStride, b)] = K[e];
-    }
-    NMPC_UNROLL
-    for(int a = 0; a < N; a++)
-    {
-      nan = nan || fmpc::bad(s[a]);
-      buf.gain[fmpc::at(buf, i, GL::S + a, GL::kStride, b)] = s[a];
-    }
-    NMPC_UNROLL
-    for(int e = 0; e < N * N; e++)
-    {
-      nan = nan || fmpc::bad(P[e]);
-      buf.gain[fmpc::at(buf, i, GL::P + e, GL::kStride, b)] = P[e];
+      i--;
     }
   }
   if(llt_failed || (buf.check_nan && (nan || (buf.flags[b] & 1)))) // :640-653
@@ -1276,86 +1411,48 @@ __global__ void __launch_bounds__(64) fmpc_riccati_kernel(FmpcBuffers buf, int i
 
   // ---- forward pass, the recursion over the timesteps (:669-687)
   double dx[N];
-  bool dnan = false;
   NMPC_UNROLL
   for(int a = 0; a < N; a++)
   {
     dx[a] = buf.x0[static_cast<size_t>(a) * buf.B + b] - buf.x[fmpc::at(buf, 0, a, N, b)];
   }
-  for(int i = 0; i <= T; i++)
   {
-    double Pm[N * N], sv[N];
-    NMPC_UNROLL
-    for(int e = 0; e < N * N; e++)
+    fmpc::ForwardRecord<N, M> r0, r1;
+    int i = 0;
+    r0.load(buf, 0, b);
+    while(true)
     {
-      Pm[e] = buf.gain[fmpc::at(buf, i, GL::P + e, GL::kStride, b)];
-    }
-    NMPC_UNROLL
-    for(int a = 0; a < N; a++)
-    {
-      sv[a] = buf.gain[fmpc::at(buf, i, GL::S + a, GL::kStride, b)];
-    }
-    NMPC_UNROLL
-    for(int a = 0; a < N; a++)
-    {
-      double acc = 0;
-      NMPC_UNROLL
-      for(int r = 0; r < N; r++)
+      if(i + 1 < T)
       {
-        acc += Pm[a + r * N] * dx[r];
+        r1.load(buf, i + 1, b);
       }
-      const double dl = acc - sv[a]; // (2.33)
-      dnan = dnan || fmpc::bad(dl) || fmpc::bad(dx[a]);
-      buf.dlam[fmpc::at(buf, i, a, N, b)] = dl;
-      buf.dx[fmpc::at(buf, i, a, N, b)] = dx[a];
-    }
-    if(i < T)
-    {
-      double du[M > 0 ? M : 1];
-      NMPC_UNROLL
-      for(int a = 0; a < M; a++)
+      fmpc::forwardStep<N, M>(buf, i, b, r0, dx);
+      i++;
+      if(i == T)
       {
-        double acc = 0;
-        NMPC_UNROLL
-        for(int r = 0; r < N; r++)
-        {
-          acc += buf.gain[fmpc::at(buf, i, GL::K + a + r * M, GL::kStride, b)] * dx[r];
-        }
-        du[a] = acc + buf.gain[fmpc::at(buf, i, GL::k + a, GL::kStride, b)]; // (2.36)
-        dnan = dnan || fmpc::bad(du[a]);
-        buf.du[fmpc::at(buf, i, a, M, b)] = du[a];
+        break;
       }
-      double nx[N];
-      NMPC_UNROLL
-      for(int a = 0; a < N; a++)
+      if(i + 1 < T)
       {
-        double ax = 0, bu = 0;
-        NMPC_UNROLL
-        for(int r = 0; r < N; r++)
-        {
-          ax += buf.coef[fmpc::at(buf, i, CL::A + a + r * N, CL::kStride, b)] * dx[r];
-        }
-        NMPC_UNROLL
-        for(int r = 0; r < M; r++)
-        {
-          bu += buf.coef[fmpc::at(buf, i, CL::B + a + r * N, CL::kStride, b)] * du[r];
-        }
-        nx[a] = (ax + bu) + buf.coef[fmpc::at(buf, i, CL::XBAR + a, CL::kStride, b)]; // (2.26b)
+        r0.load(buf, i + 1, b);
       }
-      NMPC_UNROLL
-      for(int a = 0; a < N; a++)
+      fmpc::forwardStep<N, M>(buf, i, b, r1, dx);
+      i++;
+      if(i == T)
       {
-        dx[a] = nx[a];
+        break;
       }
     }
   }
-  if(dnan)
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++)
   {
-    buf.flags[b] |= 2; // single writer here; fmpc_delta_kernel ORs the same bit atomically in a later launch
+    buf.dx[fmpc::at(buf, T, a, N, b)] = dx[a];
   }
 }
 
-/** The timestep-parallel part of the forward pass (FmpcSolver.hpp:689-697: ds, dnu), its share of the NaN check (:699) and the
+/** The timestep-parallel part of the forward pass (FmpcSolver.hpp:673: dlambda (2.33); :689-697: ds, dnu), the NaN check of
+    delta_variable_ (:699) and the
     per-timestep candidates of the fraction-to-boundary rule (:713-731).  C, D and g are re-evaluated instead of being kept
     from the coefficient kernel (for the box-type rows of the reference's problems that is a handful of instructions against
     (G N + G M + G) x 16 bytes of HBM traffic per timestep). */
@@ -1364,7 +1461,8 @@ __global__ void __launch_bounds__(256) fmpc_delta_kernel(FmpcBuffers buf)
 {
   constexpr int N = Problem::kStateDim, M = Problem::kInputDimMax, G = Problem::kIneqDim;
   const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if(tid >= static_cast<size_t>(buf.B) * buf.T)
+  using GL = fmpc::GainLayout<N, M>;
+  if(tid >= static_cast<size_t>(buf.B) * (buf.T + 1))
   {
     return;
   }
@@ -1374,15 +1472,42 @@ __global__ void __launch_bounds__(256) fmpc_delta_kernel(FmpcBuffers buf)
   {
     return;
   }
+  typename Problem::StateDimVector x, dx;
+  fmpc::loadVec(buf.dx, buf, i, b, dx);
+  bool nan = false;
+  NMPC_UNROLL
+  for(int a = 0; a < N; a++) // (2.33)
+  {
+    double acc = 0;
+    NMPC_UNROLL
+    for(int r = 0; r < N; r++)
+    {
+      acc += buf.gain[fmpc::at(buf, i, GL::P + a + r * N, GL::kStride, b)] * dx[r];
+    }
+    const double dl = acc - buf.gain[fmpc::at(buf, i, GL::S + a, GL::kStride, b)];
+    buf.dlam[fmpc::at(buf, i, a, N, b)] = dl;
+    nan = nan || fmpc::bad(dl) || fmpc::bad(dx[a]);
+  }
+  if(i == buf.T)
+  {
+    if(nan)
+    {
+      atomicOr(&buf.flags[b], 2);
+    }
+    return;
+  }
   const Problem prob = fmpc::loadProblem<Problem>(buf, b);
   const double t = buf.t0[b] + i * prob.dt();
-  typename Problem::StateDimVector x, dx;
   typename Problem::InputDimVector u, du;
   typename Problem::IneqDimVector s, nu;
   fmpc::loadVec(buf.x, buf, i, b, x);
   fmpc::loadVec(buf.u, buf, i, b, u);
-  fmpc::loadVec(buf.dx, buf, i, b, dx);
   fmpc::loadVec(buf.du, buf, i, b, du);
+  NMPC_UNROLL
+  for(int a = 0; a < M; a++)
+  {
+    nan = nan || fmpc::bad(du[a]);
+  }
   fmpc::loadVec(buf.s, buf, i, b, s);
   fmpc::loadVec(buf.nu, buf, i, b, nu);
   typename Problem::IneqStateDimMatrix C;
@@ -1392,7 +1517,6 @@ __global__ void __launch_bounds__(256) fmpc_delta_kernel(FmpcBuffers buf)
   const double barrier_eps = buf.barrier_eps[b];
   constexpr double margin_ratio = 0.995;
   double alpha_s = 1.0, alpha_nu = 1.0;
-  bool nan = false;
   NMPC_UNROLL
   for(int j = 0; j < G; j++)
   {

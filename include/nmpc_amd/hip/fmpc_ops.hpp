@@ -86,8 +86,8 @@ struct FmpcOpsOf
       return hipGetLastError();
     };
     o.launch_delta = [](const FmpcBuffers & buf, hipStream_t stream) {
-      hipLaunchKernelGGL(fmpc_delta_kernel<Problem>, dim3(blocks(static_cast<size_t>(buf.B) * buf.T, 256)), dim3(256), 0, stream,
-                         buf);
+      hipLaunchKernelGGL(fmpc_delta_kernel<Problem>, dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)), dim3(256), 0,
+                         stream, buf);
       return hipGetLastError();
     };
     o.launch_line_search = [](const FmpcBuffers & buf, int iter, hipStream_t stream) {

@@ -1,0 +1,34 @@
+"""Times the batched FMPC solve (cart-pole problem of the reference's TestFmpcCartPole) and prints the mean solve time; under
+rocprofv3 --kernel-trace --stats this gives the per-kernel split.  usage: fmpc_run.py [B] [T] [max_iter] [reps] [model]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nmpc_amd import fmpc as F  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+max_iter = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+model = sys.argv[5] if len(sys.argv) > 5 else "fmpc_cartpole"
+prob = {"fmpc_cartpole": F.FmpcProblemCartPole, "fmpc_oscillator": F.FmpcProblemOscillator,
+        "fmpc_pointmass": F.FmpcProblemPointMass}[model](0.01)
+rng = np.random.default_rng(0)
+n = prob.state_dim
+x0 = np.zeros((B, n))
+x0[:, 0] = rng.uniform(-1, 1, B)
+x0[:, 1] = rng.uniform(-0.3, 0.3, B) + (np.pi if os.environ.get("SWINGUP") else 0.0)
+s = F.FmpcSolverBatch(prob, B, T)
+s.config().max_iter = max_iter
+s.config().use_graph = not os.environ.get("NOGRAPH")
+var = F.Variable.make(prob, T, B)
+var.reset(0.0, 0.0, 0.0, 1.0, 1.0)
+ms = []
+for r in range(reps):
+    s.solve(0.0, x0, var)
+    ms.append(s.computationDuration().solve)
+it = s.iters()
+print(f"B={B} T={T} max_iter={max_iter} model={model}: solve {np.mean(ms[1:]):.3f} ms (first {ms[0]:.3f}), iterations mean {it.mean():.2f}, "
+      f"status {np.bincount(s.status())}, {it.sum() / B / (np.mean(ms[1:]) * 1e-3):.1f} batch-iterations/s")

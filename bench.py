@@ -78,7 +78,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["fmpc"], default="c2",
                     help="c2 (default) is BASELINE.json's metric configuration; c3 / c4 / c5 are the other configs "
                          "(parity-test cases) measured with the same harness")
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (0: the workload's own)")
@@ -177,6 +177,9 @@ def cpu_baseline(wl, mode: str, iters_per_solve: int, target_seconds: float, cos
 
 def main():
     args = parse_args()
+    if args.workload == "fmpc":  # the FMPC path has its own script behind the same contract
+        import bench_fmpc
+        return bench_fmpc.main(args, host_cores)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

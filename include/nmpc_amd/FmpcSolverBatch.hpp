@@ -427,6 +427,7 @@ protected:
     c.enable_line_search = config_.enable_line_search;
     c.merit_const_scale_from_lagrange_multipliers = config_.merit_const_scale_from_lagrange_multipliers;
     c.use_graph = config_.use_graph;
+    c.time_kernels = 0;
     nmpc_hip_fmpc_config cur;
     check(nmpc_hip_fmpc_get_config(handle_, &cur));
     if(cur.max_iter != c.max_iter || cur.kkt_error_thre != c.kkt_error_thre || cur.check_nan != c.check_nan

@@ -88,6 +88,18 @@ namespace fmpc
 {
 constexpr int kStatusContinued = 6; // Status::IterationContinued (FmpcSolver.h:113)
 constexpr int kSlices = 8; // horizon slices of the per-instance reductions
+// Register sets of the two recursions of fmpc_riccati_kernel: a step's record is requested (depth - 1) steps before its use.
+// Deeper rings do not pay on gfx950 (measured, 4096 x 200 cart-pole: depth 2 / 3 / 4 backward 297 / 322 / 583 us): a step
+// issues ~75 vector memory instructions and a wavefront can have at most 64 in flight (6-bit vmcnt), so requests further ahead
+// than one step only queue.  Parking the stores in LDS to keep the steady state load-only was measured too (428 us): slower.
+#ifndef NMPC_AMD_FMPC_BACKWARD_DEPTH
+#  define NMPC_AMD_FMPC_BACKWARD_DEPTH 2
+#endif
+#ifndef NMPC_AMD_FMPC_FORWARD_DEPTH
+#  define NMPC_AMD_FMPC_FORWARD_DEPTH 2
+#endif
+constexpr int kBackwardDepth = NMPC_AMD_FMPC_BACKWARD_DEPTH;
+constexpr int kForwardDepth = NMPC_AMD_FMPC_FORWARD_DEPTH;
 
 __device__ __forceinline__ size_t at(const FmpcBuffers & buf, int i, int e, int stride, int b)
 {
@@ -1320,8 +1332,8 @@ __device__ __forceinline__ void forwardStep(const FmpcBuffers & buf, int i, int 
 } // namespace fmpc
 
 /** KKT-error test (FmpcSolver.hpp:443-449), backward pass (:522-665) and the recursion of the forward pass (:667-687: dx, du;
-    dlambda of (2.33) depends on dx_i only and is left to fmpc_delta_kernel) of one instance per lane.  Both recursions run two
-    steps per loop trip on two register sets, each loaded one step before it is used. */
+    dlambda of (2.33) depends on dx_i only and is left to fmpc_delta_kernel) of one instance per lane.  Both recursions run on a
+    ring of register sets, each loaded a step before it is used. */
 template<int N, int M>
 __global__ void __launch_bounds__(64) fmpc_riccati_kernel(FmpcBuffers buf, int iter)
 {
@@ -1368,39 +1380,33 @@ __global__ void __launch_bounds__(64) fmpc_riccati_kernel(FmpcBuffers buf, int i
   }
   bool llt_failed = false;
   {
-    fmpc::BackwardRecord<N, M> r0, r1;
+    // ring of kBackwardDepth register sets: the record of step i - (kBackwardDepth - 1) is requested while step i is computed
+    constexpr int D = fmpc::kBackwardDepth;
+    fmpc::BackwardRecord<N, M> r[D];
     int i = T - 1;
-    r0.load(buf, i, b);
-    while(true)
+    NMPC_UNROLL
+    for(int d = 0; d < D - 1; d++)
     {
-      if(i > 0)
+      if(i - d >= 0)
       {
-        r1.load(buf, i - 1, b);
+        r[d].load(buf, i - d, b);
       }
-      if(!fmpc::backwardStep<N, M>(buf, i, b, r0, s, P, nan))
+    }
+    while(i >= 0 && !llt_failed)
+    {
+      NMPC_UNROLL
+      for(int d = 0; d < D; d++)
       {
-        llt_failed = true;
-        break;
+        if(i >= 0 && !llt_failed)
+        {
+          if(i - (D - 1) >= 0)
+          {
+            r[(d + D - 1) % D].load(buf, i - (D - 1), b);
+          }
+          llt_failed = !fmpc::backwardStep<N, M>(buf, i, b, r[d], s, P, nan);
+          i--;
+        }
       }
-      if(i == 0)
-      {
-        break;
-      }
-      i--;
-      if(i > 0)
-      {
-        r0.load(buf, i - 1, b);
-      }
-      if(!fmpc::backwardStep<N, M>(buf, i, b, r1, s, P, nan))
-      {
-        llt_failed = true;
-        break;
-      }
-      if(i == 0)
-      {
-        break;
-      }
-      i--;
     }
   }
   if(llt_failed || (buf.check_nan && (nan || (buf.flags[b] & 1)))) // :640-653
@@ -1417,30 +1423,31 @@ __global__ void __launch_bounds__(64) fmpc_riccati_kernel(FmpcBuffers buf, int i
     dx[a] = buf.x0[static_cast<size_t>(a) * buf.B + b] - buf.x[fmpc::at(buf, 0, a, N, b)];
   }
   {
-    fmpc::ForwardRecord<N, M> r0, r1;
+    constexpr int D = fmpc::kForwardDepth;
+    fmpc::ForwardRecord<N, M> r[D];
     int i = 0;
-    r0.load(buf, 0, b);
-    while(true)
+    NMPC_UNROLL
+    for(int d = 0; d < D - 1; d++)
     {
-      if(i + 1 < T)
+      if(d < T)
       {
-        r1.load(buf, i + 1, b);
+        r[d].load(buf, d, b);
       }
-      fmpc::forwardStep<N, M>(buf, i, b, r0, dx);
-      i++;
-      if(i == T)
+    }
+    while(i < T)
+    {
+      NMPC_UNROLL
+      for(int d = 0; d < D; d++)
       {
-        break;
-      }
-      if(i + 1 < T)
-      {
-        r0.load(buf, i + 1, b);
-      }
-      fmpc::forwardStep<N, M>(buf, i, b, r1, dx);
-      i++;
-      if(i == T)
-      {
-        break;
+        if(i < T)
+        {
+          if(i + (D - 1) < T)
+          {
+            r[(d + D - 1) % D].load(buf, i + (D - 1), b);
+          }
+          fmpc::forwardStep<N, M>(buf, i, b, r[d], dx);
+          i++;
+        }
       }
     }
   }

@@ -70,6 +70,9 @@ extern "C"
     /** 1 (default): the kernel sequence of one solve is captured in a hipGraph at the first solve and replayed afterwards
         (one host launch per solve instead of ~6 per iteration); 0: plain stream launches. */
     int use_graph;
+    /** 1: plain stream launches with a HIP-event pair around every kernel of the solve, summed per kernel class and read back
+        with nmpc_hip_fmpc_last_solve_kernel_ms (bench.py's roofline leg).  Overrides use_graph.  0 (default): off. */
+    int time_kernels;
   } nmpc_hip_fmpc_config;
 
   /** Trace columns.  TraceData (FmpcSolver.h:230-249) holds iter, kkt_error and four CPU timers; the timer slots carry the
@@ -136,7 +139,8 @@ extern "C"
 
   /** The `initial_variable` argument of solve (FmpcSolver.h:283) for every instance: HOST arrays in the layouts above, or
       DEVICE arrays of the same layouts when on_device != 0.  A NULL pointer leaves that part of the resident variable as
-      it is.  barrier_eps [B] (may be NULL) sets barrier_eps_ (FmpcSolver.h:414; 1e-4 at create). */
+      it is.  barrier_eps [B] (may be NULL) sets barrier_eps_ (FmpcSolver.h:414; 1e-4 at create).  Host sources: synchronous.
+      Device sources: asynchronous on the solver's own stream (ordered before the next solve on that stream). */
   int nmpc_hip_fmpc_set_variable(nmpc_hip_fmpc_handle h,
                                  const double * x,
                                  const double * u,
@@ -165,6 +169,25 @@ extern "C"
 
   /** computationDuration() (FmpcSolver.h:304-307): HIP-event time of the last solve [ms] (ingest of t / x0 + all kernels). */
   int nmpc_hip_fmpc_last_solve_ms(nmpc_hip_fmpc_handle h, float * ms);
+
+  /** Kernel classes of nmpc_hip_fmpc_last_solve_kernel_ms, in this order. */
+  typedef enum
+  {
+    NMPC_HIP_FMPC_KERNEL_BARRIER = 0,
+    NMPC_HIP_FMPC_KERNEL_COEFF = 1,
+    NMPC_HIP_FMPC_KERNEL_RICCATI = 2,
+    NMPC_HIP_FMPC_KERNEL_DELTA = 3,
+    NMPC_HIP_FMPC_KERNEL_STEP_LENGTH = 4,
+    NMPC_HIP_FMPC_KERNEL_LINE_SEARCH = 5,
+    NMPC_HIP_FMPC_KERNEL_UPDATE = 6,
+    NMPC_HIP_FMPC_KERNEL_OTHER = 7, /* begin / init / check / finish */
+    NMPC_HIP_FMPC_NKERNELS = 8
+  } nmpc_hip_fmpc_kernel_class;
+
+  /** The split of computationDuration() (FmpcSolver::ComputationDuration, FmpcSolver.h:252-287: coeff / backward / forward /
+      update): HIP-event time [ms] and number of launches of each kernel class in the last solve.  Needs
+      config.time_kernels = 1 (else NMPC_HIP_ERR_NOT_SOLVED).  ms / launches: arrays of NMPC_HIP_FMPC_NKERNELS. */
+  int nmpc_hip_fmpc_last_solve_kernel_ms(nmpc_hip_fmpc_handle h, double * ms, int * launches);
 
   /** The reference's closed-loop caller patterns (TestFmpcOscillator.cpp:164-194, TestFmpcCartPole.cpp:340-366,408-414),
       batched and device-resident: n_ticks times { solve(t, x, resident variable); log; plant: `sim_substeps` steps of

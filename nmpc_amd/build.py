@@ -47,8 +47,15 @@ def _obj_deps(obj: str, src: str):
     every header of the tree otherwise."""
     dep = obj[:-2] + ".d"
     if os.path.exists(dep) and os.path.exists(obj):
+        # written on the machine that compiled the object; the tree may live elsewhere now (the GPU box): re-root the paths
         tokens = open(dep).read().split(":", 1)[-1].split()
-        files = [f for f in tokens if f != "\\" and f.startswith(ROOT)]
+        files = []
+        for f in tokens:
+            for marker in ("/include/nmpc", "/nmpc_amd/csrc/"):
+                k = f.find(marker)
+                if k >= 0:
+                    files.append(ROOT + f[k:])
+                    break
         if files:
             return [f for f in files if os.path.exists(f)] + [src]
     return [src] + _headers()

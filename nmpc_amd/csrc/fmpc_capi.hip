@@ -142,6 +142,11 @@ struct nmpc_hip_fmpc_solver
   hipGraphExec_t graph_exec = nullptr;
   bool solved = false;
   std::string kernel_names;
+  // config.time_kernels: one event pair per launch of the last solve, with its kernel class
+  std::vector<hipEvent_t> kev;
+  std::vector<int> kev_class;
+  size_t kev_used = 0;
+  bool kev_valid = false;
 };
 
 namespace
@@ -205,41 +210,73 @@ void applyConfig(nmpc_hip_fmpc_solver * h)
   b.merit_const_scale_from_lagrange_multipliers = h->cfg.merit_const_scale_from_lagrange_multipliers;
 }
 
+/** config.time_kernels: an event on `stream` that opens (begin) or closes the timing bracket of one launch. */
+int timeMark(nmpc_hip_fmpc_solver * h, hipStream_t stream, int kernel_class, bool begin)
+{
+  if(!h->cfg.time_kernels)
+  {
+    return NMPC_HIP_OK;
+  }
+  if(h->kev_used == h->kev.size())
+  {
+    hipEvent_t e = nullptr;
+    FMPC_TRY(hipEventCreate(&e));
+    h->kev.push_back(e);
+    h->kev_class.push_back(0);
+  }
+  h->kev_class[h->kev_used] = begin ? kernel_class : -1;
+  FMPC_TRY(hipEventRecord(h->kev[h->kev_used], stream));
+  h->kev_used++;
+  return NMPC_HIP_OK;
+}
+
+#define FMPC_TIMED(h, stream, kernel_class, launch)           \
+  do                                                          \
+  {                                                           \
+    FMPC_CHECK(timeMark(h, stream, kernel_class, true));      \
+    launch;                                                   \
+    FMPC_TRY(hipGetLastError());                              \
+    FMPC_CHECK(timeMark(h, stream, kernel_class, false));     \
+  } while(0)
+
 /** The kernel sequence of FmpcSolver::solve (FmpcSolver.hpp:156-255) on `stream`. */
 int enqueueSolve(nmpc_hip_fmpc_solver * h, hipStream_t stream)
 {
   const FmpcBuffers & buf = h->buf;
   const FmpcOps * ops = h->ops;
   const unsigned nb = blocks(buf.B, 64);
-  hipLaunchKernelGGL(nmpc_amd::hip::fmpc_begin_kernel, dim3(nb), dim3(64), 0, stream, buf);
-  FMPC_TRY(hipGetLastError());
+  h->kev_used = 0;
+  h->kev_valid = h->cfg.time_kernels != 0;
+  FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_OTHER,
+             hipLaunchKernelGGL(nmpc_amd::hip::fmpc_begin_kernel, dim3(nb), dim3(64), 0, stream, buf));
   if(h->cfg.init_complementary_variable)
   {
-    FMPC_TRY(ops->launch_init_complementary(buf, stream));
+    FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_OTHER, FMPC_TRY(ops->launch_init_complementary(buf, stream)));
   }
-  hipLaunchKernelGGL(nmpc_amd::hip::fmpc_check_variable_kernel, dim3(blocks(static_cast<size_t>(buf.B) * buf.T, 256)), dim3(256), 0,
-                     stream, buf);
-  FMPC_TRY(hipGetLastError());
+  FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_OTHER,
+             hipLaunchKernelGGL(nmpc_amd::hip::fmpc_check_variable_kernel, dim3(blocks(static_cast<size_t>(buf.B) * buf.T, 256)),
+                                dim3(256), 0, stream, buf));
   for(int iter = 1; iter <= h->cfg.max_iter; iter++)
   {
-    hipLaunchKernelGGL(nmpc_amd::hip::fmpc_barrier_kernel, dim3(nb), dim3(64 * nmpc_amd::hip::fmpc::kSlices), 0, stream, buf, iter);
-    FMPC_TRY(hipGetLastError());
-    FMPC_TRY(ops->launch_coeff(buf, stream));
-    FMPC_TRY(ops->launch_riccati(buf, iter, stream));
-    FMPC_TRY(ops->launch_delta(buf, stream));
-    hipLaunchKernelGGL(nmpc_amd::hip::fmpc_step_length_kernel, dim3(nb), dim3(64 * nmpc_amd::hip::fmpc::kSlices), 0, stream, buf,
-                       iter);
-    FMPC_TRY(hipGetLastError());
+    FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_BARRIER,
+               hipLaunchKernelGGL(nmpc_amd::hip::fmpc_barrier_kernel, dim3(nb), dim3(64 * nmpc_amd::hip::fmpc::kSlices), 0, stream, buf,
+                                  iter));
+    FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_COEFF, FMPC_TRY(ops->launch_coeff(buf, stream)));
+    FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_RICCATI, FMPC_TRY(ops->launch_riccati(buf, iter, stream)));
+    FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_DELTA, FMPC_TRY(ops->launch_delta(buf, stream)));
+    FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_STEP_LENGTH,
+               hipLaunchKernelGGL(nmpc_amd::hip::fmpc_step_length_kernel, dim3(nb), dim3(64 * nmpc_amd::hip::fmpc::kSlices), 0, stream,
+                                  buf, iter));
     if(h->cfg.enable_line_search)
     {
-      FMPC_TRY(ops->launch_line_search(buf, iter, stream));
+      FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_LINE_SEARCH, FMPC_TRY(ops->launch_line_search(buf, iter, stream)));
     }
-    hipLaunchKernelGGL(nmpc_amd::hip::fmpc_update_kernel, dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)), dim3(256), 0,
-                       stream, buf);
-    FMPC_TRY(hipGetLastError());
+    FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_UPDATE,
+               hipLaunchKernelGGL(nmpc_amd::hip::fmpc_update_kernel, dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)),
+                                  dim3(256), 0, stream, buf));
   }
-  hipLaunchKernelGGL(nmpc_amd::hip::fmpc_finish_kernel, dim3(nb), dim3(64), 0, stream, buf);
-  FMPC_TRY(hipGetLastError());
+  FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_OTHER,
+             hipLaunchKernelGGL(nmpc_amd::hip::fmpc_finish_kernel, dim3(nb), dim3(64), 0, stream, buf));
   return NMPC_HIP_OK;
 }
 
@@ -250,7 +287,7 @@ int launchSolve(nmpc_hip_fmpc_solver * h, hipStream_t stream)
   {
     return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "[FMPC] max_iter exceeds the trace buffer; call set_config");
   }
-  if(!h->cfg.use_graph)
+  if(!h->cfg.use_graph || h->cfg.time_kernels)
   {
     return enqueueSolve(h, stream);
   }
@@ -401,6 +438,7 @@ extern "C"
     cfg->enable_line_search = 0;
     cfg->merit_const_scale_from_lagrange_multipliers = 0;
     cfg->use_graph = 1;
+    cfg->time_kernels = 0;
     return NMPC_HIP_OK;
   }
 
@@ -475,6 +513,10 @@ extern "C"
     for(void * p : h->allocs)
     {
       (void)hipFree(p);
+    }
+    for(hipEvent_t e : h->kev)
+    {
+      (void)hipEventDestroy(e);
     }
     if(h->d_problems)
     {
@@ -727,7 +769,10 @@ extern "C"
       FMPC_TRY(hipMemcpyAsync(b.barrier_eps, barrier_eps, static_cast<size_t>(b.B) * sizeof(double),
                               on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     }
-    FMPC_TRY(hipStreamSynchronize(h->stream));
+    if(!on_device) // device sources: asynchronous on the solver's stream, ordered before the next solve on it
+    {
+      FMPC_TRY(hipStreamSynchronize(h->stream));
+    }
     return NMPC_HIP_OK;
   }
 
@@ -900,6 +945,36 @@ extern "C"
       h->timed = false;
     }
     *ms = h->last_ms;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_fmpc_last_solve_kernel_ms(nmpc_hip_fmpc_handle h, double * ms, int * launches)
+  {
+    if(!h || !ms || !launches)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    }
+    if(!h->solved || !h->kev_valid)
+    {
+      return fail(NMPC_HIP_ERR_NOT_SOLVED, "[FMPC] the last solve was not run with config.time_kernels = 1");
+    }
+    FMPC_TRY(hipSetDevice(h->device));
+    for(int k = 0; k < NMPC_HIP_FMPC_NKERNELS; k++)
+    {
+      ms[k] = 0;
+      launches[k] = 0;
+    }
+    if(h->kev_used > 0)
+    {
+      FMPC_TRY(hipEventSynchronize(h->kev[h->kev_used - 1]));
+    }
+    for(size_t k = 0; k + 1 < h->kev_used; k += 2)
+    {
+      float t = 0;
+      FMPC_TRY(hipEventElapsedTime(&t, h->kev[k], h->kev[k + 1]));
+      ms[h->kev_class[k]] += t;
+      launches[h->kev_class[k]]++;
+    }
     return NMPC_HIP_OK;
   }
 

@@ -49,6 +49,7 @@ class CConfig(C.Structure):
         ("enable_line_search", C.c_int),
         ("merit_const_scale_from_lagrange_multipliers", C.c_int),
         ("use_graph", C.c_int),
+        ("time_kernels", C.c_int),
     ]
 
 
@@ -58,7 +59,7 @@ EXPORTS = (
     "nmpc_hip_fmpc_model_default_params", "nmpc_hip_fmpc_create", "nmpc_hip_fmpc_destroy", "nmpc_hip_fmpc_set_config",
     "nmpc_hip_fmpc_get_config", "nmpc_hip_fmpc_set_problem", "nmpc_hip_fmpc_set_variable", "nmpc_hip_fmpc_reset_variable",
     "nmpc_hip_fmpc_solve", "nmpc_hip_fmpc_solve_device", "nmpc_hip_fmpc_synchronize", "nmpc_hip_fmpc_get",
-    "nmpc_hip_fmpc_field_bytes", "nmpc_hip_fmpc_last_solve_ms", "nmpc_hip_fmpc_mpc_run", "nmpc_hip_fmpc_kernel_names",
+    "nmpc_hip_fmpc_field_bytes", "nmpc_hip_fmpc_last_solve_ms", "nmpc_hip_fmpc_last_solve_kernel_ms", "nmpc_hip_fmpc_mpc_run", "nmpc_hip_fmpc_kernel_names",
     "nmpc_hip_fmpc_last_error",
 )
 
@@ -90,6 +91,7 @@ def load():
     L.nmpc_hip_fmpc_get.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int]
     L.nmpc_hip_fmpc_field_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
     L.nmpc_hip_fmpc_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.nmpc_hip_fmpc_last_solve_kernel_ms.argtypes = [vp, dp, ip]
     L.nmpc_hip_fmpc_mpc_run.argtypes = [vp, dp, dp, C.c_int, C.c_double, C.c_int, C.c_int, dp, dp, ip, ip, dp, dp, dp]
     L.nmpc_hip_fmpc_kernel_names.argtypes = [vp, C.POINTER(C.c_char_p)]
     L.nmpc_hip_fmpc_last_error.argtypes = []
@@ -191,9 +193,10 @@ class Configuration:
     """FmpcSolver::Configuration (FmpcSolver.h:57-89).  Defaults come from the library."""
 
     _FIELDS = ("horizon_steps", "max_iter", "kkt_error_thre", "check_nan", "init_complementary_variable", "update_barrier_eps",
-               "break_if_llt_fails", "enable_line_search", "merit_const_scale_from_lagrange_multipliers", "use_graph")
+               "break_if_llt_fails", "enable_line_search", "merit_const_scale_from_lagrange_multipliers", "use_graph",
+               "time_kernels")
     _BOOL = ("check_nan", "init_complementary_variable", "update_barrier_eps", "break_if_llt_fails", "enable_line_search",
-             "merit_const_scale_from_lagrange_multipliers", "use_graph")
+             "merit_const_scale_from_lagrange_multipliers", "use_graph", "time_kernels")
 
     def __init__(self):
         c = CConfig()
@@ -244,11 +247,22 @@ class Variable:
         return self.x_list, self.u_list, self.lambda_list, self.s_list, self.nu_list
 
 
+KERNEL_CLASSES = ("barrier", "coeff", "riccati", "delta", "step_length", "line_search", "update", "other")
+
+
 @dataclass
 class ComputationDuration:
-    """FmpcSolver::ComputationDuration (FmpcSolver.h:252-287): `solve` is the HIP-event time of the whole batch [ms]; the
-    reference's finer split is per CPU phase of one instance and has no batched counterpart (see rocprofv3 per-kernel times)."""
+    """FmpcSolver::ComputationDuration (FmpcSolver.h:252-287) for the whole batch [ms]: `solve` is the HIP-event time of the
+    last solve; with config().time_kernels the per-kernel times fill the reference's split — coeff (coefficient kernel),
+    backward + forward (the Riccati kernel runs both recursions: reported under backward), update (delta + step-length +
+    line-search + update kernels) — and `kernels` / `launches` hold every kernel class (KERNEL_CLASSES)."""
     solve: float = 0.0
+    coeff: float = 0.0
+    backward: float = 0.0
+    forward: float = 0.0
+    update: float = 0.0
+    kernels: Optional[dict] = None
+    launches: Optional[dict] = None
 
 
 class FmpcSolverBatch:
@@ -372,7 +386,18 @@ class FmpcSolverBatch:
     def computationDuration(self) -> ComputationDuration:
         ms = C.c_float()
         check(self._L.nmpc_hip_fmpc_last_solve_ms(self._h, C.byref(ms)))
-        return ComputationDuration(solve=float(ms.value))
+        d = ComputationDuration(solve=float(ms.value))
+        if self._config.time_kernels:
+            k = np.zeros(len(KERNEL_CLASSES))
+            n = np.zeros(len(KERNEL_CLASSES), dtype=np.int32)
+            check(self._L.nmpc_hip_fmpc_last_solve_kernel_ms(self._h, k.ctypes.data_as(C.POINTER(C.c_double)),
+                                                             n.ctypes.data_as(C.POINTER(C.c_int))))
+            d.kernels = dict(zip(KERNEL_CLASSES, (float(v) for v in k)))
+            d.launches = dict(zip(KERNEL_CLASSES, (int(v) for v in n)))
+            d.coeff = d.kernels["coeff"] + d.kernels["barrier"]
+            d.backward = d.kernels["riccati"]
+            d.update = d.kernels["delta"] + d.kernels["step_length"] + d.kernels["line_search"] + d.kernels["update"]
+        return d
 
     def dumpTraceDataList(self, file_path: str, instance: int = 0) -> None:
         """FmpcSolver::dumpTraceDataList (FmpcSolver.hpp:257-283) for one instance; the four duration columns of the reference

@@ -32,3 +32,6 @@ for r in range(reps):
 it = s.iters()
 print(f"B={B} T={T} max_iter={max_iter} model={model}: solve {np.mean(ms[1:]):.3f} ms (first {ms[0]:.3f}), iterations mean {it.mean():.2f}, "
       f"status {np.bincount(s.status())}, {it.sum() / B / (np.mean(ms[1:]) * 1e-3):.1f} batch-iterations/s")
+if os.environ.get("NMPC_AMD_EXTRA_HIPCC_FLAGS", "").find("NMPC_AMD_FMPC_PROFILE") >= 0:
+    m = s.meritFunc()
+    print(f"riccati kernel, 100 MHz ticks: backward {m[:, 0].mean() / 100:.1f} us, forward {m[:, 1].mean() / 100:.1f} us")

@@ -28,7 +28,7 @@ def make_case(model, B, T, seed, spread=0.3):
 
 
 def oracle_cfg(cfg: F.Configuration):
-    return O.default_config(**{k: getattr(cfg, k) for k in F.Configuration._FIELDS if k != "use_graph"})
+    return O.default_config(**{k: getattr(cfg, k) for k in F.Configuration._FIELDS if k not in ("use_graph", "time_kernels")})
 
 
 def oracle_batch(model, cfg, params, t0, x0, var, barrier_eps=None):
@@ -321,6 +321,13 @@ def test_full_size_batch_properties():
     for a, c in zip(s2.variable().arrays(), v.arrays()):
         assert np.array_equal(a, c[sub])
     assert s.computationDuration().solve > 0
+    # the split of computationDuration(): one event pair per kernel launch
+    s.config().time_kernels = True
+    s.solve(0.0, x0, var)
+    d = s.computationDuration()
+    assert d.launches["riccati"] == 8 and d.launches["coeff"] == 8 and d.launches["line_search"] == 0
+    assert 0 < d.backward < d.solve and d.coeff > 0 and d.update > 0
+    assert abs(sum(d.kernels.values()) - d.solve) < 0.5 * d.solve
 
 
 def test_cpp_mirror_runs_the_reference_oscillator_loop(tmp_path):

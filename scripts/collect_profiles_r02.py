@@ -81,7 +81,57 @@ for wl in ("c2", "c4", "c3", "c5", "c4f64"):
                        "iterations_per_step": bench["config"]["iterations_per_step"],
                        "source": f"profiles/{tag}_pmc_summary_{wl}.txt (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; FETCH_SIZE "
                                  f"x{fetch_scale:.2f} per profiles/{tag}_counter_calibration.txt)"}
+# FMPC: several kernels per iteration -> one table, per kernel: launches, HBM bytes per launch, SQ shares
+stats = os.path.join(src, "stats_fmpc_kernel_stats.csv")
+if os.path.exists(stats):
+    shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats_fmpc.csv"))
+    bench = None
+    bench_file = os.path.join(src, "bench_fmpc.txt")
+    if os.path.exists(bench_file):
+        lines = [l for l in open(bench_file) if l.startswith("{")]
+        if lines:
+            bench = json.loads(lines[-1])
+            json.dump(bench, open(os.path.join(dst, f"{tag}_bench_fmpc.json"), "w"), indent=1)
+    avg_us = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(stats))}
+    with open(os.path.join(dst, f"{tag}_pmc_summary_fmpc.txt"), "w") as f:
+        f.write("bench.py --workload fmpc --steps 10 --warmup 2 (4096 cart-pole FMPC instances, T = 200, max_iter 5); per-launch means,\n")
+        f.write("each counter set collected in its own run; SQ_* cycle counters in quad-cycles summed over the waves of a launch\n\n")
+        f.write("%-28s %9s %11s %11s %8s %9s %9s %9s\n" % ("kernel", "avg_us", "fetch_MB", "write_MB", "L2_hit", "GB/s", "VALU_act", "waitcnt"))
+        for short in ("fmpc_barrier_kernel", "fmpc_coeff_kernel", "fmpc_riccati_kernel", "fmpc_delta_kernel", "fmpc_step_length_kernel",
+                      "fmpc_update_kernel", "fmpc_transpose_kernel"):
+            pm, cnt = means("pmc?_fmpc_counter_collection.csv", short)
+            if not pm:
+                continue
+            fetch = pm.get("FETCH_SIZE", 0.0) * fetch_scale * 1024.0
+            write = pm.get("WRITE_SIZE", 0.0) * write_scale * 1024.0
+            us = next((v for k, v in avg_us.items() if short in k), float("nan"))
+            hit = pm["TCC_HIT"] / (pm["TCC_HIT"] + pm["TCC_MISS"]) if pm.get("TCC_HIT") else float("nan")
+            wc = pm.get("SQ_WAVE_CYCLES", 0.0)
+            f.write("%-28s %9.1f %11.1f %11.1f %8.3f %9.0f %9.3f %9.3f\n" % (
+                short, us, fetch / 1e6, write / 1e6, hit, (fetch + write) / (us * 1e-6) / 1e9,
+                pm["SQ_ACTIVE_INST_VALU"] / wc if wc else float("nan"), pm["SQ_WAIT_ANY"] / wc if wc else float("nan")))
+            if short == "fmpc_riccati_kernel" and bench:
+                traffic["fmpc"] = {"hbm_bytes_per_launch": fetch + write, "batch": int(bench["metric"].split("batch=")[1].split(",")[0]),
+                                   "horizon": int(bench["metric"].split("T=")[1]),
+                                   "source": f"profiles/{tag}_pmc_summary_fmpc.txt (fmpc_riccati_kernel; FETCH_SIZE x{fetch_scale:.2f}, "
+                                             "WRITE_SIZE 1:1, separate passes)"}
+        if bench:
+            f.write("\nalgorithmic bytes per launch of fmpc_riccati_kernel (bench accounting): %.1f MB\n"
+                    % (bench["roofline"]["algorithmic_bytes_per_launch"] / 1e6))
 json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+# the bench lines of this session were printed before this file existed in its new state: give them the session's own traffic
+for wl, entry in traffic.items():
+    path = os.path.join(dst, f"{tag}_bench_{wl}.json")
+    if not os.path.exists(path):
+        continue
+    b = json.load(open(path))
+    rf = b["roofline"]
+    rf["traffic"] = entry["hbm_bytes_per_launch"]
+    rf["traffic_source"] = entry["source"]
+    if rf.get("fused_lower_bound_bytes_per_launch"):
+        rf["traffic_over_fused_bound"] = rf["traffic"] / rf["fused_lower_bound_bytes_per_launch"]
+    rf["hbm_frac_measured"] = rf["traffic"] / (rf["kernel_ms_avg"] * 1e-3) / 1e9 / rf["peak"]
+    json.dump(b, open(path, "w"), indent=1)
 for extra in ("fanout_ab.txt", "batch_scaling.txt", "ubench_mfma_f32.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))

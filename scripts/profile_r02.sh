@@ -25,6 +25,14 @@ for WL in c2 c4; do
   rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $OUT -o pmcB_$WL -- $BENCH > $OUT/pmcB_$WL.log 2>&1
   rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_INT32 --output-format csv -d $OUT -o pmcC_$WL -- $BENCH > $OUT/pmcC_$WL.log 2>&1
 done
+# FMPC: the same passes on bench.py --workload fmpc (several kernels per iteration: summarised per kernel)
+BENCH="python bench.py --workload fmpc --steps 10 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats_fmpc -- $BENCH > $OUT/stats_fmpc.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o pmcD_fmpc -- $BENCH > $OUT/pmcD_fmpc.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT TCC_MISS --output-format csv -d $OUT -o pmcE_fmpc -- $BENCH > $OUT/pmcE_fmpc.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT -o pmcA_fmpc -- $BENCH > $OUT/pmcA_fmpc.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $OUT -o pmcB_fmpc -- $BENCH > $OUT/pmcB_fmpc.log 2>&1
+python bench.py --workload fmpc > $OUT/bench_fmpc.txt 2>&1
 echo "== bench c2 (unprofiled, default arguments)" > $OUT/bench_c2.txt
 python bench.py >> $OUT/bench_c2.txt 2>&1
 echo "== bench c4 (unprofiled)" > $OUT/bench_c4.txt

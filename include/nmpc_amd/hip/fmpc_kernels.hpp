@@ -56,10 +56,9 @@ struct FmpcBuffers
   double * dlam = nullptr;
   double * ds = nullptr;
   double * dnu = nullptr;
-  // what the Riccati recursion reads per timestep: A, B, x_bar, Qxx~, Quu~, Qxu~, Lx~, Lu~  [T][ceil(coef_stride / 2)][B][2]
-  // (pairs of elements adjacent, fmpc::atp)
+  // what the Riccati recursion reads per timestep: A, B, x_bar, Qxx~, Quu~, Qxu~, Lx~, Lu~  [T][coef_stride][B]
   double * coef = nullptr;
-  // what it writes: k, K, s, P  [T+1][ceil(gain_stride / 2)][B][2] (Coefficient::k / K / s / P, FmpcSolver.h:214-224; the terminal entry
+  // what it writes: k, K, s, P  [T+1][gain_stride][B] (Coefficient::k / K / s / P, FmpcSolver.h:214-224; the terminal entry
   // holds s and P only)
   double * gain = nullptr;
   // per-timestep partial results [T+1][3][B]: KKT-error terms, alpha_s candidate, alpha_nu candidate
@@ -90,9 +89,13 @@ namespace fmpc
 constexpr int kStatusContinued = 6; // Status::IterationContinued (FmpcSolver.h:113)
 constexpr int kSlices = 8; // horizon slices of the per-instance reductions
 // Register sets of the two recursions of fmpc_riccati_kernel: a step's record is requested (depth - 1) steps before its use.
-// Deeper rings do not pay on gfx950 (measured, 4096 x 200 cart-pole: depth 2 / 3 / 4 backward 297 / 322 / 583 us): a step
-// issues ~75 vector memory instructions and a wavefront can have at most 64 in flight (6-bit vmcnt), so requests further ahead
-// than one step only queue.  Parking the stores in LDS to keep the steady state load-only was measured too (428 us): slower.
+// What was measured on MI355X around this choice (4096 x 200 cart-pole, backward recursion alone 297 us at depth 2): deeper
+// rings 322 (3) / 583 us (4); all records of 2-4 steps requested at the top of a loop trip instead of a ring: 10 % slower;
+// stores parked in LDS and written in bursts (steady state load-only): 428 us; records as adjacent element pairs (16-byte
+// accesses, half the memory instructions): +5 %.  The recursion is not waiting for memory it could have asked for earlier: per
+// step it issues ~500 instructions on one wavefront per SIMD (the VALU is busy 40 % of the kernel's time, profiles/
+// r02_pmc_summary_fmpc.txt), and part of the requested data reaches its loop-carried registers through compiler-inserted copies
+// that wait for the loads.  Fewer instructions per lane (several lanes per instance) is the lever, not prefetch depth.
 #ifndef NMPC_AMD_FMPC_BACKWARD_DEPTH
 #  define NMPC_AMD_FMPC_BACKWARD_DEPTH 2
 #endif
@@ -105,15 +108,6 @@ constexpr int kForwardDepth = NMPC_AMD_FMPC_FORWARD_DEPTH;
 __device__ __forceinline__ size_t at(const FmpcBuffers & buf, int i, int e, int stride, int b)
 {
   return (static_cast<size_t>(i) * stride + e) * buf.B + b;
-}
-
-/** Index into the coefficient / gain records, which are kept [timestep][element pair][instance][2]: the two doubles of a pair
-    are adjacent, so one 16-byte memory instruction moves both.  The Riccati recursion is bounded by the number of vector memory
-    instructions a wavefront can have in flight (64) against the ~75 a step would need with 8-byte accesses; pairs halve that. */
-__device__ __forceinline__ size_t atp(const FmpcBuffers & buf, int i, int e, int stride, int b)
-{
-  const int pairs = (stride + 1) / 2;
-  return ((static_cast<size_t>(i) * pairs + (e >> 1)) * buf.B + b) * 2 + (e & 1);
 }
 
 __device__ __forceinline__ bool bad(double v)
@@ -741,13 +735,13 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
       kkt += Lx_bar * Lx_bar;
       const double sT = -1 * Lx_bar;
       nan = nan || fmpc::bad(Vx[a]) || fmpc::bad(Lx_bar);
-      buf.gain[fmpc::atp(buf, i, GL::S + a, GL::kStride, b)] = sT;
+      buf.gain[fmpc::at(buf, i, GL::S + a, GL::kStride, b)] = sT;
     }
     NMPC_UNROLL
     for(int e = 0; e < N * N; e++)
     {
       nan = nan || fmpc::bad(Vxx.data()[e]);
-      buf.gain[fmpc::atp(buf, i, GL::P + e, GL::kStride, b)] = Vxx.data()[e];
+      buf.gain[fmpc::at(buf, i, GL::P + e, GL::kStride, b)] = Vxx.data()[e];
     }
     buf.part[fmpc::at(buf, i, 0, 3, b)] = kkt;
     if(nan)
@@ -901,17 +895,17 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
   NMPC_UNROLL
   for(int e = 0; e < N * N; e++)
   {
-    buf.coef[fmpc::atp(buf, i, CL::A + e, CL::kStride, b)] = A.data()[e];
+    buf.coef[fmpc::at(buf, i, CL::A + e, CL::kStride, b)] = A.data()[e];
   }
   NMPC_UNROLL
   for(int e = 0; e < N * M; e++)
   {
-    buf.coef[fmpc::atp(buf, i, CL::B + e, CL::kStride, b)] = Bm.data()[e];
+    buf.coef[fmpc::at(buf, i, CL::B + e, CL::kStride, b)] = Bm.data()[e];
   }
   NMPC_UNROLL
   for(int a = 0; a < N; a++)
   {
-    buf.coef[fmpc::atp(buf, i, CL::XBAR + a, CL::kStride, b)] = x_bar[a];
+    buf.coef[fmpc::at(buf, i, CL::XBAR + a, CL::kStride, b)] = x_bar[a];
   }
   NMPC_UNROLL
   for(int c = 0; c < N; c++)
@@ -925,7 +919,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
       {
         acc += (C(j, a) * nu_s[j]) * C(j, c);
       }
-      buf.coef[fmpc::atp(buf, i, CL::QXX + a + c * N, CL::kStride, b)] = dt * Lxx(a, c) + acc; // (2.28c)
+      buf.coef[fmpc::at(buf, i, CL::QXX + a + c * N, CL::kStride, b)] = dt * Lxx(a, c) + acc; // (2.28c)
     }
   }
   NMPC_UNROLL
@@ -940,7 +934,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
       {
         acc += (D(j, a) * nu_s[j]) * D(j, c);
       }
-      buf.coef[fmpc::atp(buf, i, CL::QUU + a + c * M, CL::kStride, b)] = dt * Luu(a, c) + acc; // (2.28e)
+      buf.coef[fmpc::at(buf, i, CL::QUU + a + c * M, CL::kStride, b)] = dt * Luu(a, c) + acc; // (2.28e)
     }
     NMPC_UNROLL
     for(int a = 0; a < N; a++)
@@ -951,7 +945,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
       {
         acc += (C(j, a) * nu_s[j]) * D(j, c);
       }
-      buf.coef[fmpc::atp(buf, i, CL::QXU + a + c * N, CL::kStride, b)] = dt * Lxu(a, c) + acc; // (2.28d)
+      buf.coef[fmpc::at(buf, i, CL::QXU + a + c * N, CL::kStride, b)] = dt * Lxu(a, c) + acc; // (2.28d)
     }
   }
   NMPC_UNROLL
@@ -963,7 +957,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
     {
       acc += C(j, a) * tilde_sub[j];
     }
-    buf.coef[fmpc::atp(buf, i, CL::LXT + a, CL::kStride, b)] = Lx_bar[a] + acc; // (2.28f)
+    buf.coef[fmpc::at(buf, i, CL::LXT + a, CL::kStride, b)] = Lx_bar[a] + acc; // (2.28f)
   }
   NMPC_UNROLL
   for(int a = 0; a < M; a++)
@@ -974,7 +968,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
     {
       acc += D(j, a) * tilde_sub[j];
     }
-    buf.coef[fmpc::atp(buf, i, CL::LUT + a, CL::kStride, b)] = Lu_bar[a] + acc; // (2.28g)
+    buf.coef[fmpc::at(buf, i, CL::LUT + a, CL::kStride, b)] = Lu_bar[a] + acc; // (2.28g)
   }
 }
 
@@ -994,30 +988,30 @@ struct BackwardRecord
     NMPC_UNROLL
     for(int e = 0; e < N * N; e++)
     {
-      A[e] = buf.coef[atp(buf, i, CL::A + e, CL::kStride, b)];
-      F[e] = buf.coef[atp(buf, i, CL::QXX + e, CL::kStride, b)];
+      A[e] = buf.coef[at(buf, i, CL::A + e, CL::kStride, b)];
+      F[e] = buf.coef[at(buf, i, CL::QXX + e, CL::kStride, b)];
     }
     NMPC_UNROLL
     for(int e = 0; e < N * M; e++)
     {
-      Bm[e] = buf.coef[atp(buf, i, CL::B + e, CL::kStride, b)];
-      H[e] = buf.coef[atp(buf, i, CL::QXU + e, CL::kStride, b)];
+      Bm[e] = buf.coef[at(buf, i, CL::B + e, CL::kStride, b)];
+      H[e] = buf.coef[at(buf, i, CL::QXU + e, CL::kStride, b)];
     }
     NMPC_UNROLL
     for(int e = 0; e < M * M; e++)
     {
-      Gm[e] = buf.coef[atp(buf, i, CL::QUU + e, CL::kStride, b)];
+      Gm[e] = buf.coef[at(buf, i, CL::QUU + e, CL::kStride, b)];
     }
     NMPC_UNROLL
     for(int a = 0; a < N; a++)
     {
-      x_bar[a] = buf.coef[atp(buf, i, CL::XBAR + a, CL::kStride, b)];
-      Lx_t[a] = buf.coef[atp(buf, i, CL::LXT + a, CL::kStride, b)];
+      x_bar[a] = buf.coef[at(buf, i, CL::XBAR + a, CL::kStride, b)];
+      Lx_t[a] = buf.coef[at(buf, i, CL::LXT + a, CL::kStride, b)];
     }
     NMPC_UNROLL
     for(int a = 0; a < M; a++)
     {
-      Lu_t[a] = buf.coef[atp(buf, i, CL::LUT + a, CL::kStride, b)];
+      Lu_t[a] = buf.coef[at(buf, i, CL::LUT + a, CL::kStride, b)];
     }
   }
 };
@@ -1035,23 +1029,23 @@ struct ForwardRecord
     NMPC_UNROLL
     for(int e = 0; e < N * N; e++)
     {
-      A[e] = buf.coef[atp(buf, i, CL::A + e, CL::kStride, b)];
+      A[e] = buf.coef[at(buf, i, CL::A + e, CL::kStride, b)];
     }
     NMPC_UNROLL
     for(int e = 0; e < N * M; e++)
     {
-      Bm[e] = buf.coef[atp(buf, i, CL::B + e, CL::kStride, b)];
-      K[e] = buf.gain[atp(buf, i, GL::K + e, GL::kStride, b)];
+      Bm[e] = buf.coef[at(buf, i, CL::B + e, CL::kStride, b)];
+      K[e] = buf.gain[at(buf, i, GL::K + e, GL::kStride, b)];
     }
     NMPC_UNROLL
     for(int a = 0; a < N; a++)
     {
-      x_bar[a] = buf.coef[atp(buf, i, CL::XBAR + a, CL::kStride, b)];
+      x_bar[a] = buf.coef[at(buf, i, CL::XBAR + a, CL::kStride, b)];
     }
     NMPC_UNROLL
     for(int a = 0; a < M; a++)
     {
-      k[a] = buf.gain[atp(buf, i, GL::k + a, GL::kStride, b)];
+      k[a] = buf.gain[at(buf, i, GL::k + a, GL::kStride, b)];
     }
   }
 };
@@ -1271,25 +1265,25 @@ __device__ __forceinline__ bool backwardStep(const FmpcBuffers & buf, int i, int
   for(int a = 0; a < M; a++)
   {
     nan = nan || bad(k[a]);
-    buf.gain[atp(buf, i, GL::k + a, GL::kStride, b)] = k[a];
+    buf.gain[at(buf, i, GL::k + a, GL::kStride, b)] = k[a];
   }
   NMPC_UNROLL
   for(int e = 0; e < M * N; e++)
   {
     nan = nan || bad(K[e]);
-    buf.gain[atp(buf, i, GL::K + e, GL::kStride, b)] = K[e];
+    buf.gain[at(buf, i, GL::K + e, GL::kStride, b)] = K[e];
   }
   NMPC_UNROLL
   for(int a = 0; a < N; a++)
   {
     nan = nan || bad(s[a]);
-    buf.gain[atp(buf, i, GL::S + a, GL::kStride, b)] = s[a];
+    buf.gain[at(buf, i, GL::S + a, GL::kStride, b)] = s[a];
   }
   NMPC_UNROLL
   for(int e = 0; e < N * N; e++)
   {
     nan = nan || bad(P[e]);
-    buf.gain[atp(buf, i, GL::P + e, GL::kStride, b)] = P[e];
+    buf.gain[at(buf, i, GL::P + e, GL::kStride, b)] = P[e];
   }
   return true;
 }
@@ -1375,12 +1369,12 @@ __global__ void __launch_bounds__(64) fmpc_riccati_kernel(FmpcBuffers buf, int i
   NMPC_UNROLL
   for(int a = 0; a < N; a++)
   {
-    s[a] = buf.gain[fmpc::atp(buf, T, GL::S + a, GL::kStride, b)];
+    s[a] = buf.gain[fmpc::at(buf, T, GL::S + a, GL::kStride, b)];
   }
   NMPC_UNROLL
   for(int e = 0; e < N * N; e++)
   {
-    P[e] = buf.gain[fmpc::atp(buf, T, GL::P + e, GL::kStride, b)];
+    P[e] = buf.gain[fmpc::at(buf, T, GL::P + e, GL::kStride, b)];
   }
   bool nan = false;
   NMPC_UNROLL
@@ -1499,9 +1493,9 @@ __global__ void __launch_bounds__(256) fmpc_delta_kernel(FmpcBuffers buf)
     NMPC_UNROLL
     for(int r = 0; r < N; r++)
     {
-      acc += buf.gain[fmpc::atp(buf, i, GL::P + a + r * N, GL::kStride, b)] * dx[r];
+      acc += buf.gain[fmpc::at(buf, i, GL::P + a + r * N, GL::kStride, b)] * dx[r];
     }
-    const double dl = acc - buf.gain[fmpc::atp(buf, i, GL::S + a, GL::kStride, b)];
+    const double dl = acc - buf.gain[fmpc::at(buf, i, GL::S + a, GL::kStride, b)];
     buf.dlam[fmpc::at(buf, i, a, N, b)] = dl;
     nan = nan || fmpc::bad(dl) || fmpc::bad(dx[a]);
   }
@@ -1712,12 +1706,12 @@ __global__ void __launch_bounds__(64) fmpc_line_search_kernel(FmpcBuffers buf, i
         NMPC_UNROLL
         for(int r = 0; r < N; r++)
         {
-          ra += buf.coef[fmpc::atp(buf, i, CL::A + a + r * N, CL::kStride, b)] * dx[r];
+          ra += buf.coef[fmpc::at(buf, i, CL::A + a + r * N, CL::kStride, b)] * dx[r];
         }
         NMPC_UNROLL
         for(int r = 0; r < M; r++)
         {
-          rb += buf.coef[fmpc::atp(buf, i, CL::B + a + r * N, CL::kStride, b)] * du[r];
+          rb += buf.coef[fmpc::at(buf, i, CL::B + a + r * N, CL::kStride, b)] * du[r];
         }
         dA += fmpcL1RowDeriv(cf, ra);
         dB += fmpcL1RowDeriv(cf, rb);
@@ -1867,7 +1861,7 @@ __global__ void fmpc_plant_kernel(FmpcBuffers buf, double * x_plant, double * t_
         NMPC_UNROLL
         for(int r = 0; r < N; r++)
         {
-          acc += buf.gain[fmpc::atp(buf, 0, GL::K + a + r * M, GL::kStride, b)] * (buf.x[fmpc::at(buf, 0, r, N, b)] - x[r]);
+          acc += buf.gain[fmpc::at(buf, 0, GL::K + a + r * M, GL::kStride, b)] * (buf.x[fmpc::at(buf, 0, r, N, b)] - x[r]);
         }
         u[a] += acc;
       }

@@ -115,8 +115,7 @@ __global__ void fmpc_gather_gain_kernel(const double * gain, double * dst, int B
   const int b = static_cast<int>(tid % B);
   const size_t ie = tid / B;
   const int i = static_cast<int>(ie / E), e = static_cast<int>(ie % E);
-  const int el = offset + e; // records are [step][element pair][instance][2] (fmpc::atp)
-  dst[tid] = gain[((static_cast<size_t>(i) * ((stride + 1) / 2) + (el >> 1)) * B + b) * 2 + (el & 1)];
+  dst[tid] = gain[(static_cast<size_t>(i) * stride + offset + e) * B + b];
 }
 } // namespace
 
@@ -602,8 +601,8 @@ extern "C"
     A(&b.dlam, (T + 1) * N * B);
     A(&b.ds, T * G * B);
     A(&b.dnu, T * G * B);
-    A(&b.coef, T * (2 * ((b.coef_stride + 1) / 2)) * B);
-    A(&b.gain, (T + 1) * (2 * ((b.gain_stride + 1) / 2)) * B);
+    A(&b.coef, T * b.coef_stride * B);
+    A(&b.gain, (T + 1) * b.gain_stride * B);
     A(&b.part, (T + 1) * 3 * B);
     A(&h->d_t0, B);
     A(&h->d_x0, N * B);

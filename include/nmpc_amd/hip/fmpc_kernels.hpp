@@ -1462,6 +1462,244 @@ __global__ void __launch_bounds__(64) fmpc_riccati_kernel(FmpcBuffers buf, int i
   }
 }
 
+/** The Riccati kernel for N <= 4 states and one input on the fp64 matrix cores, SIXTEEN lanes per instance.
+    A workgroup is 16 instances x 4 wavefronts, a wavefront owns four instances; lane l holds entry (row l / 16, column l % 4)
+    of the 4 x 4 matrices of instance (l / 4) % 4 — the C / D operand layout of v_mfma_f64_4x4x4_4b_f64, in which the
+    instruction computes mma(X, Y, C) = X^T Y + C on matrices held one entry per lane (ddp_kernels_quad.hpp; measured in
+    scripts/ubench_mfma_f64_4x4.hip), summing k ascending as an FMA chain from C.  One backward step (FmpcSolver.hpp:576-637) is
+    seven such instructions:
+
+        PA = mma(P, A, 0)                 (A^T P)^T                                   R  = mma(P, [B | x_bar], [0 | -s])  [P B | P x_bar - s]
+        F  = mma(PA, A, Qxx~)             (2.35b)                                     S  = mma(A, R, [Qxu~ | Lx~])        [H | A^T (P x_bar - s) + Lx~]
+        FT = mma(A, PA, Qxx~^T)           the same entries transposed                 Wq = mma([B B B B], R, [Quu~ Lu~])  every row [G, B^T (P x_bar - s) + Lu~]
+        HA = mma(bcast(P B), A, Qxu~^T)   H[col] in every row
+
+    then, per lane, k = -k_rhs / G, K[row] = -H[row] / G, K[col] = -H[col] / G (the pseudo-inverse rule of Eigen's LDLT solve
+    for the 1 x 1 block), s' = -(A^T (P x_bar - s) + Lx~) - H k and P' = 1/2 ((F - (K[row] G) K[col]) + (FT - (K[col] G)
+    K[row])) — entry (row, col) and entry (col, row) of F - K^T G K exactly as the reference's two triangles (:620-629).  The
+    forward recursion (:676-685) is two more: A dx and K dx.  Against the one-lane-per-instance kernel a step issues ~12 loads
+    and ~60 instructions per lane instead of ~75 and ~500, and 4096 instances are 1024 wavefronts (every SIMD of the chip)
+    instead of 64.  Sums that the lane kernel starts from zero and adds to a coefficient afterwards start from the coefficient
+    here (MFMA accumulates from C); H is formed as A^T (P B) + Qxu~ rather than (A^T P) B + Qxu~: results agree with the lane
+    kernel and the oracle to rounding, not bit for bit (tests/test_gpu_fmpc.py compares both against the oracle). */
+template<int N>
+__global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf, int iter)
+{
+  static_assert(N >= 1 && N <= 4, "[FMPC] the quad Riccati kernel handles up to four states");
+  constexpr int M = 1;
+  using CL = fmpc::CoefLayout<N, M>;
+  using GL = fmpc::GainLayout<N, M>;
+  __shared__ double sh_kkt[16];
+  const int wl = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row = wl >> 4, blk = (wl >> 2) & 3, col = wl & 3;
+  const int inst = wave * 4 + blk;
+  const int b_raw = blockIdx.x * 16 + inst;
+  const int b = b_raw < buf.B ? b_raw : buf.B - 1; // lanes beyond the batch mirror the last instance and store nothing
+  const bool head = row == 0 && col == 0; // the lane that speaks for the instance
+  const bool c0 = col == 0, c1 = col == 1, r0 = row == 0;
+  const bool rv = row < N, cv = col < N, valid = rv && cv;
+  const int rc = rv ? row : N - 1, cc = cv ? col : N - 1;
+  const int T = buf.T;
+  bool live = b_raw < buf.B && buf.status[b] == fmpc::kStatusContinued;
+
+  auto mma = [](double x, double y, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, c, 0, 0, 0); };
+  auto bcast0 = [](double v) { // entry of column 0 of this lane's row (same quad) in all four lanes of the quad
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x00, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x00, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  auto bcast1 = [](double v) { // quad_perm:[1,1,1,1]
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x55, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x55, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  auto coef = [&](int i, int e) { return buf.coef[fmpc::at(buf, i, e, CL::kStride, b)]; };
+  auto gain = [&](int i, int e) -> double & { return buf.gain[fmpc::at(buf, i, e, GL::kStride, b)]; };
+
+  // ---- KKT-error test (FmpcSolver.hpp:443-449): summed by the head lane in the order of the lane kernel
+  if(head)
+  {
+    double kkt_error = 0;
+    if(live)
+    {
+      for(int i = 0; i <= T; i++)
+      {
+        kkt_error += buf.part[fmpc::at(buf, i, 0, 3, b)];
+      }
+      kkt_error = sqrt(kkt_error);
+      buf.trace[(static_cast<size_t>(b) * buf.max_iter + (iter - 1)) * NMPC_HIP_FMPC_NTRACE + NMPC_HIP_FMPC_TRACE_KKT_ERROR] =
+          kkt_error;
+      if(kkt_error <= buf.kkt_error_thre)
+      {
+        buf.status[b] = 1; // Status::Succeeded
+      }
+    }
+    sh_kkt[inst] = kkt_error;
+  }
+  __syncthreads();
+  live = live && !(sh_kkt[inst] <= buf.kkt_error_thre);
+  if(!__any(live))
+  {
+    return; // wavefront-uniform: nothing to do for these four instances
+  }
+
+  // ---- backward pass
+  double P = valid ? static_cast<double>(gain(T, GL::P + rc + cc * N)) : 0.0;
+  double s_row = rv ? static_cast<double>(gain(T, GL::S + rc)) : 0.0; // s[row], kept by every lane of the row
+  bool nan = fmpc::bad(s_row);
+
+  struct Operands
+  {
+    double A, Qxx, QxxT, Bv, Y, CM, LM, QxuRow;
+  };
+  auto loadOperands = [&](int i, Operands & o) {
+    const double a = coef(i, CL::A + rc + cc * N), q = coef(i, CL::QXX + rc + cc * N), qt = coef(i, CL::QXX + cc + rc * N);
+    const double bv = coef(i, CL::B + rc), xb = coef(i, CL::XBAR + rc);
+    const double cm = coef(i, c0 ? CL::QUU : CL::LUT);
+    const double lm = coef(i, c0 ? CL::QXU + rc : CL::LXT + rc);
+    const double qr = coef(i, CL::QXU + cc);
+    o.A = valid ? a : 0.0;
+    o.Qxx = valid ? q : 0.0;
+    o.QxxT = valid ? qt : 0.0;
+    o.Bv = rv ? bv : 0.0; // B[row] in every column
+    o.Y = rv ? (c0 ? bv : (c1 ? xb : 0.0)) : 0.0; // [B | x_bar | 0 | 0]
+    o.CM = (c0 || c1) ? cm : 0.0; // [Quu~, Lu~, 0, 0] in every row
+    o.LM = (rv && (c0 || c1)) ? lm : 0.0; // [Qxu~ | Lx~ | 0 | 0]
+    o.QxuRow = cv ? qr : 0.0; // Qxu~^T in every row
+  };
+  auto backwardStep = [&](int i, const Operands & o) {
+    const double PA = mma(P, o.A, 0.0);
+    const double R = mma(P, o.Y, c1 ? -1 * s_row : 0.0);
+    const double F = mma(PA, o.A, o.Qxx);
+    const double FT = mma(o.A, PA, o.QxxT);
+    const double S = mma(o.A, R, o.LM);
+    const double Wq = mma(o.Bv, R, o.CM);
+    const double HA = mma(bcast0(R), o.A, o.QxuRow);
+    const double G = bcast0(Wq), k_rhs = bcast1(Wq);
+    const double Hr = bcast0(S), Qxl = bcast1(S);
+    // Eigen's LDLT solve of the 1 x 1 system (pseudo-inverse of D), then (2.35e)
+    const bool pivot = fabs(G) > DBL_MIN;
+    const double k = -1 * (pivot ? k_rhs / G : 0.0);
+    const double Kc = -1 * (pivot ? HA / G : 0.0);
+    const double Kr = -1 * (pivot ? Hr / G : 0.0);
+    const double s_new = (-1 * Qxl) - Hr * k; // (2.35a)
+    const double Pn = F - (Kr * G) * Kc;
+    const double PnT = FT - (Kc * G) * Kr;
+    P = 0.5 * (Pn + PnT); // enforce symmetric (:627-629)
+    s_row = s_new;
+    nan = nan || fmpc::bad(k) || fmpc::bad(Kc) || fmpc::bad(s_new) || fmpc::bad(P);
+    if(live)
+    {
+      if(valid)
+      {
+        gain(i, GL::P + rc + cc * N) = P;
+      }
+      if(c0 && rv)
+      {
+        gain(i, GL::S + rc) = s_new;
+      }
+      if(r0 && cv)
+      {
+        gain(i, GL::K + cc) = Kc;
+      }
+      if(head)
+      {
+        gain(i, GL::k) = k;
+      }
+    }
+  };
+  {
+    Operands oa, ob; // two operand sets, loop unrolled by two: no register copies between timesteps
+    loadOperands(T - 1, oa);
+    int i = T - 1;
+    for(; i - 1 >= 0; i -= 2)
+    {
+      loadOperands(i - 1, ob);
+      backwardStep(i, oa);
+      loadOperands(i - 2 >= 0 ? i - 2 : 0, oa);
+      backwardStep(i - 1, ob);
+    }
+    if(i >= 0)
+    {
+      backwardStep(i, oa);
+    }
+  }
+  // verdict of the backward pass per instance (:640-653): OR over the sixteen lanes of the instance
+  {
+    int bad_any = nan ? 1 : 0;
+    bad_any |= __shfl_xor(bad_any, 1);
+    bad_any |= __shfl_xor(bad_any, 2);
+    bad_any |= __shfl_xor(bad_any, 16);
+    bad_any |= __shfl_xor(bad_any, 32);
+    const bool failed = buf.check_nan && (bad_any != 0 || (buf.flags[b] & 1));
+    if(live && failed && head)
+    {
+      buf.status[b] = 3; // Status::ErrorInBackward
+    }
+    live = live && !failed;
+    if(!__any(live))
+    {
+      return;
+    }
+  }
+
+  // ---- forward pass, the recursion over the timesteps (:669-687); dx[row] is kept by every lane of the row
+  double dx_row = rv ? buf.x0[static_cast<size_t>(rc) * buf.B + b] - buf.x[fmpc::at(buf, 0, rc, N, b)] : 0.0;
+  struct ForwardOperands
+  {
+    double AT, Kx, k, Bv, xb;
+  };
+  auto loadForward = [&](int i, ForwardOperands & o) {
+    const double at_ = coef(i, CL::A + cc + rc * N); // entry (col, row): the A operand of mma is used transposed
+    const double kx = gain(i, GL::K + rc);
+    o.k = gain(i, GL::k);
+    const double bv = coef(i, CL::B + rc), xb = coef(i, CL::XBAR + rc);
+    o.AT = valid ? at_ : 0.0;
+    o.Kx = rv ? kx : 0.0; // K[row] in every column
+    o.Bv = rv ? bv : 0.0;
+    o.xb = rv ? xb : 0.0;
+  };
+  auto forwardStep = [&](int i, const ForwardOperands & o) {
+    const double Y = c0 ? dx_row : 0.0;
+    const double ax = bcast0(mma(o.AT, Y, 0.0)); // (A dx)[row]
+    const double du = bcast0(mma(o.Kx, Y, 0.0)) + o.k; // (2.36), the same in every row
+    if(live)
+    {
+      if(c0 && rv)
+      {
+        buf.dx[fmpc::at(buf, i, rc, N, b)] = dx_row;
+      }
+      if(head)
+      {
+        buf.du[fmpc::at(buf, i, 0, M, b)] = du;
+      }
+    }
+    const double nx = (ax + o.Bv * du) + o.xb; // (2.26b)
+    dx_row = rv ? nx : 0.0;
+  };
+  {
+    ForwardOperands oa, ob;
+    loadForward(0, oa);
+    int i = 0;
+    for(; i + 1 < T; i += 2)
+    {
+      loadForward(i + 1, ob);
+      forwardStep(i, oa);
+      loadForward(i + 2 < T ? i + 2 : T - 1, oa);
+      forwardStep(i + 1, ob);
+    }
+    if(i < T)
+    {
+      forwardStep(i, oa);
+    }
+  }
+  if(live && c0 && rv)
+  {
+    buf.dx[fmpc::at(buf, T, rc, N, b)] = dx_row;
+  }
+}
+
 /** The timestep-parallel part of the forward pass (FmpcSolver.hpp:673: dlambda (2.33); :689-697: ds, dnu), the NaN check of
     delta_variable_ (:699) and the
     per-timestep candidates of the fraction-to-boundary rule (:713-731).  C, D and g are re-evaluated instead of being kept

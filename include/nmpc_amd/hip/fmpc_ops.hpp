@@ -3,6 +3,7 @@
 #pragma once
 
 #include <cstddef>
+#include <cstdlib>
 #include <new>
 #include <type_traits>
 
@@ -82,6 +83,17 @@ struct FmpcOpsOf
       return hipGetLastError();
     };
     o.launch_riccati = [](const FmpcBuffers & buf, int iter, hipStream_t stream) {
+      // N <= 4 states and one input: sixteen lanes per instance on the fp64 matrix cores (fmpc_riccati_quad_kernel); the
+      // environment variable NMPC_HIP_FMPC_RICCATI=lane forces the one-lane-per-instance kernel (A/B measurements, tests)
+      if constexpr(N <= 4 && M == 1)
+      {
+        const char * force = getenv("NMPC_HIP_FMPC_RICCATI");
+        if(!(force && force[0] == 'l'))
+        {
+          hipLaunchKernelGGL((fmpc_riccati_quad_kernel<N>), dim3(blocks(buf.B, 16)), dim3(256), 0, stream, buf, iter);
+          return hipGetLastError();
+        }
+      }
       hipLaunchKernelGGL((fmpc_riccati_kernel<N, M>), dim3(blocks(buf.B, 64)), dim3(64), 0, stream, buf, iter);
       return hipGetLastError();
     };

@@ -22,7 +22,8 @@ ARCH = "gfx950"
 # per-source flags.  builtin_models.hip holds the quad kernel (ddp_kernels_quad.hpp): its fp64 matrix-core results are
 # consumed by VALU / DPP instructions right away, so they have to live in ordinary VGPRs — by default a kernel that may
 # use 512 registers gets them in accumulation registers plus ~30 v_accvgpr moves per timestep (-5 % on the headline).
-EXTRA_FLAGS = {"builtin_models.hip": ["-mllvm", "--amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"builtin_models.hip": ["-mllvm", "--amdgpu-mfma-vgpr-form"],
+               "fmpc_models.hip": ["-mllvm", "--amdgpu-mfma-vgpr-form"]}  # fmpc_riccati_quad_kernel: same reason
 
 
 def hipcc() -> str:

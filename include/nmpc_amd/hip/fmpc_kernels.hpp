@@ -26,6 +26,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -88,6 +89,10 @@ namespace fmpc
 {
 constexpr int kStatusContinued = 6; // Status::IterationContinued (FmpcSolver.h:113)
 constexpr int kSlices = 8; // horizon slices of the per-instance reductions
+#ifndef NMPC_AMD_FMPC_STAGE_STEPS
+#  define NMPC_AMD_FMPC_STAGE_STEPS 4
+#endif
+constexpr int kStageSteps = NMPC_AMD_FMPC_STAGE_STEPS; // timesteps per cooperative fetch of fmpc_riccati_quad_kernel
 // Register sets of the two recursions of fmpc_riccati_kernel: a step's record is requested (depth - 1) steps before its use.
 // What was measured on MI355X around this choice (4096 x 200 cart-pole, backward recursion alone 297 us at depth 2): deeper
 // rings 322 (3) / 583 us (4); all records of 2-4 steps requested at the top of a loop trip instead of a ring: 10 % slower;
@@ -1489,7 +1494,15 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
   constexpr int M = 1;
   using CL = fmpc::CoefLayout<N, M>;
   using GL = fmpc::GainLayout<N, M>;
-  __shared__ double sh_kkt[16];
+  constexpr int kS = fmpc::kStageSteps;
+  constexpr int kRecB = CL::kStride | 1; // odd record widths: the 16 instances of a row slot hit 16 different banks
+  constexpr int kFwdCoef = CL::XBAR + N; // A, B, x_bar: elements [0, kFwdCoef) of the coefficient record
+  constexpr int kFwdGain = GL::K + M * N; // k, K: elements [0, kFwdGain) of the gain record
+  constexpr int kRecF = (kFwdCoef + kFwdGain) | 1;
+  constexpr int kSlotDoubles = kS * 16 * (kRecB > kRecF ? kRecB : kRecF);
+  __shared__ double stage_lds[2 * kSlotDoubles];
+  __shared__ double sh_kkt[16][17];
+
   const int wl = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int row = wl >> 4, blk = (wl >> 2) & 3, col = wl & 3;
@@ -1497,11 +1510,17 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
   const int b_raw = blockIdx.x * 16 + inst;
   const int b = b_raw < buf.B ? b_raw : buf.B - 1; // lanes beyond the batch mirror the last instance and store nothing
   const bool head = row == 0 && col == 0; // the lane that speaks for the instance
-  const bool c0 = col == 0, c1 = col == 1, r0 = row == 0;
+  const bool c0 = col == 0, c1 = col == 1;
   const bool rv = row < N, cv = col < N, valid = rv && cv;
   const int rc = rv ? row : N - 1, cc = cv ? col : N - 1;
   const int T = buf.T;
+  const size_t Bz = static_cast<size_t>(buf.B);
   bool live = b_raw < buf.B && buf.status[b] == fmpc::kStatusContinued;
+  // staging role of this thread: element slot t_slot (+ 16 q) of instance t_inst of the workgroup
+  const int t_inst = threadIdx.x & 15, t_slot = threadIdx.x >> 4;
+  const int b_stage_raw = blockIdx.x * 16 + t_inst;
+  const int b_stage = b_stage_raw < buf.B ? b_stage_raw : buf.B - 1;
+  const size_t lane_stage = static_cast<size_t>(t_slot) * Bz + b_stage; // + (row index) * B = element index of this thread's load
 
   auto mma = [](double x, double y, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, c, 0, 0, 0); };
   auto bcast0 = [](double v) { // entry of column 0 of this lane's row (same quad) in all four lanes of the quad
@@ -1514,20 +1533,29 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x55, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
   };
-  auto coef = [&](int i, int e) { return buf.coef[fmpc::at(buf, i, e, CL::kStride, b)]; };
-  auto gain = [&](int i, int e) -> double & { return buf.gain[fmpc::at(buf, i, e, GL::kStride, b)]; };
 
-  // ---- KKT-error test (FmpcSolver.hpp:443-449): summed by the head lane in the order of the lane kernel
+  // ---- KKT-error test (FmpcSolver.hpp:443-449): sixteen partial sums per instance (timesteps t_slot, t_slot + 16, ...; every
+  // 16-lane group reads one full line per row), added up by the head lane in slot order
+  {
+    double acc = 0;
+    for(int i = t_slot; i <= T; i += 16)
+    {
+      acc += buf.part[fmpc::at(buf, i, 0, 3, b_stage)];
+    }
+    sh_kkt[t_inst][t_slot] = acc;
+  }
+  __syncthreads();
   if(head)
   {
     double kkt_error = 0;
+    NMPC_UNROLL
+    for(int q = 0; q < 16; q++)
+    {
+      kkt_error += sh_kkt[inst][q];
+    }
+    kkt_error = sqrt(kkt_error);
     if(live)
     {
-      for(int i = 0; i <= T; i++)
-      {
-        kkt_error += buf.part[fmpc::at(buf, i, 0, 3, b)];
-      }
-      kkt_error = sqrt(kkt_error);
       buf.trace[(static_cast<size_t>(b) * buf.max_iter + (iter - 1)) * NMPC_HIP_FMPC_NTRACE + NMPC_HIP_FMPC_TRACE_KKT_ERROR] =
           kkt_error;
       if(kkt_error <= buf.kkt_error_thre)
@@ -1535,30 +1563,92 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
         buf.status[b] = 1; // Status::Succeeded
       }
     }
-    sh_kkt[inst] = kkt_error;
+    sh_kkt[inst][16] = kkt_error;
   }
   __syncthreads();
-  live = live && !(sh_kkt[inst] <= buf.kkt_error_thre);
-  if(!__any(live))
+  live = live && !(sh_kkt[inst][16] <= buf.kkt_error_thre);
+  if(__syncthreads_or(live ? 1 : 0) == 0)
   {
-    return; // wavefront-uniform: nothing to do for these four instances
+    return; // workgroup-uniform: none of the sixteen instances is live
   }
 
+  // ---- operand staging.  In the [timestep][element][instance] arrays the four instances of a wavefront are 32 bytes of every
+  // row: operands fetched per lane would touch sixteen cache lines per load and use a quarter of each (measured: the kernel is
+  // then bound by the line rate of the vector L1, 0.95 us per step).  Instead the sixteen instances of the WORKGROUP — one full
+  // 128-byte line per row — are fetched cooperatively for kStageSteps timesteps at a time (thread = (element slot, instance):
+  // every 16-lane group reads one whole line), parked in registers while the previous chunk is being consumed, written to LDS
+  // as per-(timestep, instance) records and read from there by the lanes that need them.
+  /** Elements [0, NR) of timesteps i0, i0 + dir, ..., i0 + (kS - 1) dir of this thread's instance: request into v. */
+  auto request = [&](auto nr_tag, const double * src, int stride, int i0, int dir, double * v) {
+    constexpr int NR = decltype(nr_tag)::value;
+    constexpr int kQ = (NR + 15) / 16;
+    NMPC_UNROLL
+    for(int st = 0; st < kS; st++)
+    {
+      const int step = i0 + dir * st; // wavefront-uniform
+      if(step >= 0 && step < T)
+      {
+        const double * rowp = src + (static_cast<size_t>(step) * stride) * Bz + lane_stage;
+        NMPC_UNROLL
+        for(int q = 0; q < kQ; q++)
+        {
+          if(16 * q + 15 < NR || t_slot < NR - 16 * q)
+          {
+            v[st * kQ + q] = rowp[static_cast<size_t>(16 * q) * Bz];
+          }
+        }
+      }
+    }
+  };
+  /** ... and park them in LDS slot `slot` as records of width W, at offset `off` of each record. */
+  auto commit = [&](auto nr_tag, int slot, int W, int off, const double * v) {
+    constexpr int NR = decltype(nr_tag)::value;
+    constexpr int kQ = (NR + 15) / 16;
+    double * base = stage_lds + static_cast<size_t>(slot) * kSlotDoubles + t_inst * W + off + t_slot;
+    NMPC_UNROLL
+    for(int st = 0; st < kS; st++)
+    {
+      NMPC_UNROLL
+      for(int q = 0; q < kQ; q++)
+      {
+        if(16 * q + 15 < NR || t_slot < NR - 16 * q)
+        {
+          base[st * 16 * W + 16 * q] = v[st * kQ + q];
+        }
+      }
+    }
+  };
+  using TagB = std::integral_constant<int, CL::kStride>;
+  using TagFc = std::integral_constant<int, kFwdCoef>;
+  using TagFg = std::integral_constant<int, kFwdGain>;
+
   // ---- backward pass
-  double P = valid ? static_cast<double>(gain(T, GL::P + rc + cc * N)) : 0.0;
-  double s_row = rv ? static_cast<double>(gain(T, GL::S + rc)) : 0.0; // s[row], kept by every lane of the row
+#ifdef NMPC_AMD_FMPC_PROFILE
+  const unsigned long long tick0 = wall_clock64();
+#endif
+  double P = valid ? buf.gain[fmpc::at(buf, T, GL::P + rc + cc * N, GL::kStride, b)] : 0.0;
+  double s_row = rv ? buf.gain[fmpc::at(buf, T, GL::S + rc, GL::kStride, b)] : 0.0; // s[row], kept by every lane of the row
   bool nan = fmpc::bad(s_row);
 
+  // What a lane writes per step: its entry of P, and one more value by role — s[row] on the diagonal lanes, K[col] on the
+  // lanes one row below the diagonal (cyclically), k on lane (2, 0) — every value is present on every lane of its row / column,
+  // so any lane of the right row / column can write it.  Two stores per step and no branch inside the recursion loop.
+  const bool role_s = (row == col) && rv, role_K = (row == ((col + 1) & 3)) && cv, role_k = (row == 2 && col == 0);
+  const int e2 = role_s ? GL::S + rc : (role_K ? GL::K + cc : (role_k ? GL::k : GL::P + rc + cc * N));
+  const size_t gain_step = static_cast<size_t>(GL::kStride) * Bz;
+  double * gP = buf.gain + (static_cast<size_t>(T - 1) * GL::kStride + GL::P + rc + cc * N) * Bz + b; // entry of step T - 1
+  double * g2 = buf.gain + (static_cast<size_t>(T - 1) * GL::kStride + e2) * Bz + b;
+  const bool store1 = live && valid, store2 = live && (role_s || role_K || role_k || valid);
+
+  // per-lane offsets into a staged record
+  const int oA = CL::A + rc + cc * N, oQ = CL::QXX + rc + cc * N, oQT = CL::QXX + cc + rc * N, oB = CL::B + rc, oX = CL::XBAR + rc;
+  const int oCM = c0 ? CL::QUU : CL::LUT, oLM = c0 ? CL::QXU + rc : CL::LXT + rc, oQR = CL::QXU + cc;
   struct Operands
   {
     double A, Qxx, QxxT, Bv, Y, CM, LM, QxuRow;
   };
-  auto loadOperands = [&](int i, Operands & o) {
-    const double a = coef(i, CL::A + rc + cc * N), q = coef(i, CL::QXX + rc + cc * N), qt = coef(i, CL::QXX + cc + rc * N);
-    const double bv = coef(i, CL::B + rc), xb = coef(i, CL::XBAR + rc);
-    const double cm = coef(i, c0 ? CL::QUU : CL::LUT);
-    const double lm = coef(i, c0 ? CL::QXU + rc : CL::LXT + rc);
-    const double qr = coef(i, CL::QXU + cc);
+  auto loadOperands = [&](const double * rec, Operands & o) {
+    const double a = rec[oA], q = rec[oQ], qt = rec[oQT], bv = rec[oB], xb = rec[oX], cm = rec[oCM], lm = rec[oLM], qr = rec[oQR];
     o.A = valid ? a : 0.0;
     o.Qxx = valid ? q : 0.0;
     o.QxxT = valid ? qt : 0.0;
@@ -1568,7 +1658,7 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     o.LM = (rv && (c0 || c1)) ? lm : 0.0; // [Qxu~ | Lx~ | 0 | 0]
     o.QxuRow = cv ? qr : 0.0; // Qxu~^T in every row
   };
-  auto backwardStep = [&](int i, const Operands & o) {
+  auto backwardStep = [&](const Operands & o) {
     const double PA = mma(P, o.A, 0.0);
     const double R = mma(P, o.Y, c1 ? -1 * s_row : 0.0);
     const double F = mma(PA, o.A, o.Qxx);
@@ -1589,40 +1679,52 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     P = 0.5 * (Pn + PnT); // enforce symmetric (:627-629)
     s_row = s_new;
     nan = nan || fmpc::bad(k) || fmpc::bad(Kc) || fmpc::bad(s_new) || fmpc::bad(P);
-    if(live)
+    const double v2 = role_s ? s_new : (role_K ? Kc : (role_k ? k : P));
+    if(store1)
     {
-      if(valid)
-      {
-        gain(i, GL::P + rc + cc * N) = P;
-      }
-      if(c0 && rv)
-      {
-        gain(i, GL::S + rc) = s_new;
-      }
-      if(r0 && cv)
-      {
-        gain(i, GL::K + cc) = Kc;
-      }
-      if(head)
-      {
-        gain(i, GL::k) = k;
-      }
+      *gP = P;
     }
+    if(store2)
+    {
+      *g2 = v2;
+    }
+    gP -= gain_step;
+    g2 -= gain_step;
   };
   {
-    Operands oa, ob; // two operand sets, loop unrolled by two: no register copies between timesteps
-    loadOperands(T - 1, oa);
-    int i = T - 1;
-    for(; i - 1 >= 0; i -= 2)
+    constexpr int kQB = (CL::kStride + 15) / 16;
+    double vb[kS * kQB];
+    request(TagB(), buf.coef, CL::kStride, T - 1, -1, vb);
+    commit(TagB(), 0, kRecB, 0, vb);
+    __syncthreads();
+    int slot = 0;
+    for(int i0 = T - 1; i0 >= 0; i0 -= kS)
     {
-      loadOperands(i - 1, ob);
-      backwardStep(i, oa);
-      loadOperands(i - 2 >= 0 ? i - 2 : 0, oa);
-      backwardStep(i - 1, ob);
-    }
-    if(i >= 0)
-    {
-      backwardStep(i, oa);
+      if(i0 - kS >= 0)
+      {
+        request(TagB(), buf.coef, CL::kStride, i0 - kS, -1, vb); // the next chunk travels while this one is consumed
+      }
+      const double * recs = stage_lds + static_cast<size_t>(slot) * kSlotDoubles + inst * kRecB;
+      Operands o[2];
+      loadOperands(recs, o[0]);
+      NMPC_UNROLL
+      for(int st = 0; st < kS; st++)
+      {
+        if(i0 - st >= 0)
+        {
+          if(st + 1 < kS)
+          {
+            loadOperands(recs + (st + 1) * 16 * kRecB, o[(st + 1) & 1]);
+          }
+          backwardStep(o[st & 1]);
+        }
+      }
+      if(i0 - kS >= 0)
+      {
+        commit(TagB(), slot ^ 1, kRecB, 0, vb);
+      }
+      __syncthreads();
+      slot ^= 1;
     }
   }
   // verdict of the backward pass per instance (:640-653): OR over the sixteen lanes of the instance
@@ -1638,66 +1740,99 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
       buf.status[b] = 3; // Status::ErrorInBackward
     }
     live = live && !failed;
-    if(!__any(live))
-    {
-      return;
-    }
   }
+  // (no early exit from here on: every wavefront of the workgroup takes part in the staging barriers of the forward pass,
+  // and the gains the other wavefronts wrote above are read below: make them visible first)
+  __threadfence();
+  __syncthreads();
 
   // ---- forward pass, the recursion over the timesteps (:669-687); dx[row] is kept by every lane of the row
-  double dx_row = rv ? buf.x0[static_cast<size_t>(rc) * buf.B + b] - buf.x[fmpc::at(buf, 0, rc, N, b)] : 0.0;
+#ifdef NMPC_AMD_FMPC_PROFILE
+  const unsigned long long tick1 = wall_clock64();
+#endif
+  double dx_row = rv ? buf.x0[static_cast<size_t>(rc) * Bz + b] - buf.x[fmpc::at(buf, 0, rc, N, b)] : 0.0;
+  // one store per lane and step by role: dx[row] on the diagonal lanes, du on lane (1, 0)
+  const bool role_dx = (row == col) && rv, role_du = (row == 1 && col == 0);
+  double * fP = role_du ? buf.du + b : buf.dx + static_cast<size_t>(rc) * Bz + b;
+  const size_t f_step = (role_du ? static_cast<size_t>(M) : static_cast<size_t>(N)) * Bz;
+  const bool store_f = live && (role_dx || role_du);
+  const int oAT = CL::A + cc + rc * N; // entry (col, row): the A operand of mma is used transposed
+  const int oKx = kFwdCoef + GL::K + rc, ok = kFwdCoef + GL::k;
   struct ForwardOperands
   {
     double AT, Kx, k, Bv, xb;
   };
-  auto loadForward = [&](int i, ForwardOperands & o) {
-    const double at_ = coef(i, CL::A + cc + rc * N); // entry (col, row): the A operand of mma is used transposed
-    const double kx = gain(i, GL::K + rc);
-    o.k = gain(i, GL::k);
-    const double bv = coef(i, CL::B + rc), xb = coef(i, CL::XBAR + rc);
+  auto loadForward = [&](const double * rec, ForwardOperands & o) {
+    const double at_ = rec[oAT], kx = rec[oKx], bv = rec[oB], xb = rec[oX];
+    o.k = rec[ok];
     o.AT = valid ? at_ : 0.0;
     o.Kx = rv ? kx : 0.0; // K[row] in every column
     o.Bv = rv ? bv : 0.0;
     o.xb = rv ? xb : 0.0;
   };
-  auto forwardStep = [&](int i, const ForwardOperands & o) {
+  auto forwardStep = [&](const ForwardOperands & o) {
     const double Y = c0 ? dx_row : 0.0;
     const double ax = bcast0(mma(o.AT, Y, 0.0)); // (A dx)[row]
     const double du = bcast0(mma(o.Kx, Y, 0.0)) + o.k; // (2.36), the same in every row
-    if(live)
+    if(store_f)
     {
-      if(c0 && rv)
-      {
-        buf.dx[fmpc::at(buf, i, rc, N, b)] = dx_row;
-      }
-      if(head)
-      {
-        buf.du[fmpc::at(buf, i, 0, M, b)] = du;
-      }
+      *fP = role_du ? du : dx_row;
     }
+    fP += f_step;
     const double nx = (ax + o.Bv * du) + o.xb; // (2.26b)
     dx_row = rv ? nx : 0.0;
   };
   {
-    ForwardOperands oa, ob;
-    loadForward(0, oa);
-    int i = 0;
-    for(; i + 1 < T; i += 2)
+    constexpr int kQC = (kFwdCoef + 15) / 16, kQG = (kFwdGain + 15) / 16;
+    double vc[kS * kQC], vg[kS * kQG];
+    request(TagFc(), buf.coef, CL::kStride, 0, 1, vc);
+    request(TagFg(), buf.gain, GL::kStride, 0, 1, vg);
+    commit(TagFc(), 0, kRecF, 0, vc);
+    commit(TagFg(), 0, kRecF, kFwdCoef, vg);
+    __syncthreads();
+    int slot = 0;
+    for(int i0 = 0; i0 < T; i0 += kS)
     {
-      loadForward(i + 1, ob);
-      forwardStep(i, oa);
-      loadForward(i + 2 < T ? i + 2 : T - 1, oa);
-      forwardStep(i + 1, ob);
-    }
-    if(i < T)
-    {
-      forwardStep(i, oa);
+      if(i0 + kS < T)
+      {
+        request(TagFc(), buf.coef, CL::kStride, i0 + kS, 1, vc);
+        request(TagFg(), buf.gain, GL::kStride, i0 + kS, 1, vg);
+      }
+      const double * recs = stage_lds + static_cast<size_t>(slot) * kSlotDoubles + inst * kRecF;
+      ForwardOperands o[2];
+      loadForward(recs, o[0]);
+      NMPC_UNROLL
+      for(int st = 0; st < kS; st++)
+      {
+        if(i0 + st < T)
+        {
+          if(st + 1 < kS)
+          {
+            loadForward(recs + (st + 1) * 16 * kRecF, o[(st + 1) & 1]);
+          }
+          forwardStep(o[st & 1]);
+        }
+      }
+      if(i0 + kS < T)
+      {
+        commit(TagFc(), slot ^ 1, kRecF, 0, vc);
+        commit(TagFg(), slot ^ 1, kRecF, kFwdCoef, vg);
+      }
+      __syncthreads();
+      slot ^= 1;
     }
   }
   if(live && c0 && rv)
   {
     buf.dx[fmpc::at(buf, T, rc, N, b)] = dx_row;
   }
+#ifdef NMPC_AMD_FMPC_PROFILE
+  if(head && b_raw < buf.B) // developer build only: 100 MHz wall-clock ticks of the two recursions in the merit slots
+  {
+    buf.merit[0 * buf.B + b] = static_cast<double>(tick1 - tick0);
+    buf.merit[1 * buf.B + b] = static_cast<double>(wall_clock64() - tick1);
+  }
+#endif
 }
 
 /** The timestep-parallel part of the forward pass (FmpcSolver.hpp:673: dlambda (2.33); :689-697: ds, dnu), the NaN check of

@@ -62,7 +62,7 @@ struct FmpcBuffers
   // what it writes: k, K, s, P  [T+1][gain_stride][B] (Coefficient::k / K / s / P, FmpcSolver.h:214-224; the terminal entry
   // holds s and P only)
   double * gain = nullptr;
-  // per-timestep partial results [T+1][3][B]: KKT-error terms, alpha_s candidate, alpha_nu candidate
+  // per-timestep partial results [T+1][kPartSlots][B]: KKT-error terms, alpha_s candidate, alpha_nu candidate, s . nu
   double * part = nullptr;
   const double * t0 = nullptr; // [B] current_t
   const double * x0 = nullptr; // [N][B] current_x
@@ -89,6 +89,7 @@ namespace fmpc
 {
 constexpr int kStatusContinued = 6; // Status::IterationContinued (FmpcSolver.h:113)
 constexpr int kSlices = 8; // horizon slices of the per-instance reductions
+constexpr int kPartSlots = 4; // per-timestep partials: 0 KKT-error terms, 1 / 2 step-length candidates, 3 s . nu of the timestep
 #ifndef NMPC_AMD_FMPC_STAGE_STEPS
 #  define NMPC_AMD_FMPC_STAGE_STEPS 4
 #endif
@@ -445,10 +446,14 @@ __global__ void fmpc_check_variable_kernel(FmpcBuffers buf)
   const int b = static_cast<int>(tid % buf.B);
   const int i = static_cast<int>(tid / buf.B);
   bool negative = false;
+  double dot = 0; // s_list[i] . nu_list[i]: what the first iteration's barrier update sums (later ones: fmpc_update_kernel)
   for(int j = 0; j < buf.G; j++)
   {
-    negative = negative || buf.s[fmpc::at(buf, i, j, buf.G, b)] < 0 || buf.nu[fmpc::at(buf, i, j, buf.G, b)] < 0;
+    const double sv = buf.s[fmpc::at(buf, i, j, buf.G, b)], nv = buf.nu[fmpc::at(buf, i, j, buf.G, b)];
+    negative = negative || sv < 0 || nv < 0;
+    dot += sv * nv;
   }
+  buf.part[fmpc::at(buf, i, 3, fmpc::kPartSlots, b)] = dot;
   if(negative)
   {
     buf.status[b] = NMPC_HIP_FMPC_STATUS_INVALID_VARIABLE; // every writer stores the same value
@@ -471,12 +476,7 @@ __global__ void __launch_bounds__(64 * fmpc::kSlices) fmpc_barrier_kernel(FmpcBu
     const int i1 = min(buf.T, (q + 1) * chunk);
     for(int i = q * chunk; i < i1; i++)
     {
-      double dot = 0;
-      for(int j = 0; j < buf.G; j++)
-      {
-        dot += buf.s[fmpc::at(buf, i, j, buf.G, b)] * buf.nu[fmpc::at(buf, i, j, buf.G, b)];
-      }
-      acc += dot;
+      acc += buf.part[fmpc::at(buf, i, 3, fmpc::kPartSlots, b)]; // s_list[i] . nu_list[i], left by the kernel that wrote s, nu
     }
   }
   sh[q][lane] = acc;
@@ -525,8 +525,8 @@ __global__ void __launch_bounds__(64 * fmpc::kSlices) fmpc_step_length_kernel(Fm
     for(int i = q * chunk; i < i1; i++)
     {
       // std::min(a, b) = (b < a) ? b : a — a NaN candidate is ignored exactly as the reference's loop ignores it
-      const double cs = buf.part[fmpc::at(buf, i, 1, 3, b)];
-      const double cn = buf.part[fmpc::at(buf, i, 2, 3, b)];
+      const double cs = buf.part[fmpc::at(buf, i, 1, fmpc::kPartSlots, b)];
+      const double cn = buf.part[fmpc::at(buf, i, 2, fmpc::kPartSlots, b)];
       a_s = (cs < a_s) ? cs : a_s;
       a_nu = (cn < a_nu) ? cn : a_nu;
     }
@@ -593,6 +593,7 @@ __global__ void fmpc_update_kernel(FmpcBuffers buf)
     // restated as written (array().max(c) = (a < c) ? c : a)
     constexpr double min_positive_value = -DBL_MAX;
     bool s_neg = false, nu_neg = false;
+    double dot = 0; // s . nu of the updated timestep, for the next iteration's barrier update (FmpcSolver.hpp:376-380)
     for(int e = 0; e < buf.G; e++)
     {
       const size_t k = fmpc::at(buf, i, e, buf.G, b);
@@ -600,24 +601,31 @@ __global__ void fmpc_update_kernel(FmpcBuffers buf)
       const double nv = buf.nu[k] + alpha_nu * buf.dnu[k];
       buf.s[k] = sv;
       buf.nu[k] = nv;
+      dot += sv * nv;
       s_neg = s_neg || sv < 0;
       nu_neg = nu_neg || nv < 0;
     }
     if(s_neg || nu_neg)
     {
+      dot = 0;
       for(int e = 0; e < buf.G; e++)
       {
         const size_t k = fmpc::at(buf, i, e, buf.G, b);
-        if(s_neg && buf.s[k] < min_positive_value)
+        double sv = buf.s[k], nv = buf.nu[k];
+        if(s_neg && sv < min_positive_value)
         {
-          buf.s[k] = min_positive_value;
+          sv = min_positive_value;
+          buf.s[k] = sv;
         }
-        if(nu_neg && buf.nu[k] < min_positive_value)
+        if(nu_neg && nv < min_positive_value)
         {
-          buf.nu[k] = min_positive_value;
+          nv = min_positive_value;
+          buf.nu[k] = nv;
         }
+        dot += sv * nv;
       }
     }
+    buf.part[fmpc::at(buf, i, 3, fmpc::kPartSlots, b)] = dot;
   }
 }
 
@@ -748,7 +756,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
       nan = nan || fmpc::bad(Vxx.data()[e]);
       buf.gain[fmpc::at(buf, i, GL::P + e, GL::kStride, b)] = Vxx.data()[e];
     }
-    buf.part[fmpc::at(buf, i, 0, 3, b)] = kkt;
+    buf.part[fmpc::at(buf, i, 0, fmpc::kPartSlots, b)] = kkt;
     if(nan)
     {
       atomicOr(&buf.flags[b], 1);
@@ -855,7 +863,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
     part += e * e;
   }
   kkt += part;
-  buf.part[fmpc::at(buf, i, 0, 3, b)] = kkt;
+  buf.part[fmpc::at(buf, i, 0, fmpc::kPartSlots, b)] = kkt;
 
   // Coefficient::containsNaN (:136-154) on what is not stored below
   NMPC_UNROLL
@@ -1357,7 +1365,7 @@ __global__ void __launch_bounds__(64) fmpc_riccati_kernel(FmpcBuffers buf, int i
     double kkt_error = 0;
     for(int i = 0; i <= T; i++)
     {
-      kkt_error += buf.part[fmpc::at(buf, i, 0, 3, b)];
+      kkt_error += buf.part[fmpc::at(buf, i, 0, fmpc::kPartSlots, b)];
     }
     kkt_error = sqrt(kkt_error);
     buf.trace[(static_cast<size_t>(b) * buf.max_iter + (iter - 1)) * NMPC_HIP_FMPC_NTRACE + NMPC_HIP_FMPC_TRACE_KKT_ERROR] =
@@ -1540,7 +1548,7 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     double acc = 0;
     for(int i = t_slot; i <= T; i += 16)
     {
-      acc += buf.part[fmpc::at(buf, i, 0, 3, b_stage)];
+      acc += buf.part[fmpc::at(buf, i, 0, fmpc::kPartSlots, b_stage)];
     }
     sh_kkt[t_inst][t_slot] = acc;
   }
@@ -1932,8 +1940,8 @@ __global__ void __launch_bounds__(256) fmpc_delta_kernel(FmpcBuffers buf)
       alpha_nu = (c < alpha_nu) ? c : alpha_nu;
     }
   }
-  buf.part[fmpc::at(buf, i, 1, 3, b)] = alpha_s;
-  buf.part[fmpc::at(buf, i, 2, 3, b)] = alpha_nu;
+  buf.part[fmpc::at(buf, i, 1, fmpc::kPartSlots, b)] = alpha_s;
+  buf.part[fmpc::at(buf, i, 2, fmpc::kPartSlots, b)] = alpha_nu;
   if(nan)
   {
     atomicOr(&buf.flags[b], 2);

@@ -603,7 +603,7 @@ extern "C"
     A(&b.dnu, T * G * B);
     A(&b.coef, T * b.coef_stride * B);
     A(&b.gain, (T + 1) * b.gain_stride * B);
-    A(&b.part, (T + 1) * 3 * B);
+    A(&b.part, (T + 1) * nmpc_amd::hip::fmpc::kPartSlots * B);
     A(&h->d_t0, B);
     A(&h->d_x0, N * B);
     A(&b.barrier_eps, B);

@@ -71,10 +71,9 @@ def compare(solver, ref, rtol=1e-8, atol=1e-10, min_stable=0.9):
 def test_solve_matches_oracle(model, B, T, max_iter, riccati, monkeypatch):
     """Both Riccati kernels: sixteen lanes per instance on the matrix cores (n <= 4, one input: the default for the oscillator and
     the cart-pole) and one lane per instance (everything else; forced here through NMPC_HIP_FMPC_RICCATI, which is read at launch)."""
-    if riccati == "lane":
-        if model == "fmpc_pointmass":
-            pytest.skip("two inputs: the lane kernel is what runs anyway")
-        monkeypatch.setenv("NMPC_HIP_FMPC_RICCATI", "lane")
+    if model == "fmpc_pointmass" and riccati == "lane":
+        pytest.skip("two inputs: the lane kernel is what runs anyway")
+    monkeypatch.setenv("NMPC_HIP_FMPC_RICCATI", riccati)
     prob = MODELS[model]()
     var, x0, t0 = make_case(model, B, T, seed=B + T)
     s = F.FmpcSolverBatch(prob, B, T)

@@ -12,7 +12,7 @@ iteration is one FmpcSolver::procOnce (FmpcSolver.hpp:356-491); executed iterati
 value = n_gpus * K * (executed instance-iterations per solve / batch) / t.  Weak scaling, no collective in the data path; the
 final variables of every rank are gathered once after the timed job (as in bench.py).
 
-roofline: the dominant kernel is fmpc_riccati_kernel.  Its algorithmic bytes per launch = batch x T x (coefficient record read
+roofline: the dominant kernel is the Riccati kernel (fmpc_riccati_quad_kernel at this batch size).  Its algorithmic bytes per launch = batch x T x (coefficient record read
 by the backward recursion + gain record written by it + A, B, x_bar, K, k read by the forward recursion + dx, du written) x 8;
 its average duration comes from HIP events around every launch (config.time_kernels) in a second pass of K steps outside the
 timed region (the timed region replays the hipGraph of the solve, where single kernels cannot be bracketed).
@@ -231,7 +231,8 @@ def main(args, host_cores):
                 "kernels": solver.kernelNames(),
                 "kernel_ms_per_iteration": per_iter_ms,
                 "lane_mapping": "timestep-parallel kernels: one thread per (instance, timestep), arrays [timestep][element][instance]; "
-                                "Riccati recursion: one lane per instance, 64 instances per wavefront",
+                                "Riccati recursion: sixteen lanes per instance on v_mfma_f64_4x4x4 (16-instance workgroups, operands "
+                                "staged through LDS) up to two workgroups per CU, one lane per instance beyond",
                 "final_gather_ms": 1e3 * gather_s,
                 "gather_backend": backend,
                 "per_rank_solve_ms": [1e3 * float(s[2]) / args.steps for s in per_rank],
@@ -239,7 +240,7 @@ def main(args, host_cores):
             "instance_iterations_per_s": value * B,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fmpc_riccati_kernel<%d, %d>" % (n, m),
+                "kernel": next(k for k in solver.kernelNames() if "riccati" in k),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -15,6 +15,36 @@ namespace nmpc_amd
 {
 namespace hip
 {
+/** Which Riccati kernel a batch of B instances of an (N states, M inputs) problem type runs: fmpc_riccati_quad_kernel (sixteen
+    lanes per instance on the fp64 matrix cores) for N <= 4, M = 1 while its 16-instance workgroups are at most two per CU — the
+    regime in which the chip is otherwise empty; fmpc_riccati_kernel (one lane per instance) otherwise: it issues half as many
+    instructions per instance and wins once the batch fills the chip by itself (measured on MI355X, cart-pole, T = 200, quad /
+    lane ms per 5-iteration solve: 1.5 / 2.8 at 2048 instances, 2.2 / 3.6 at 4096, 4.5 / 4.7 at 8192, 8.9 / 7.2 at 16384,
+    37.8 / 29.0 at 65536).  The environment variable NMPC_HIP_FMPC_RICCATI=quad|lane forces one (A/B measurements, tests). */
+inline bool fmpcUseQuadRiccati(int N, int M, int B)
+{
+  if(!(N <= 4 && M == 1))
+  {
+    return false;
+  }
+  const char * force = getenv("NMPC_HIP_FMPC_RICCATI");
+  if(force && (force[0] == 'l' || force[0] == 'q'))
+  {
+    return force[0] == 'q';
+  }
+  static int n_cu = 0; // of the current device at first use (the handles of one process sit on like devices)
+  if(n_cu == 0)
+  {
+    int device = 0;
+    if(hipGetDevice(&device) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess
+       || n_cu <= 0)
+    {
+      n_cu = 256;
+    }
+  }
+  return (B + 15) / 16 <= 2 * n_cu;
+}
+
 struct FmpcOps
 {
   const char * name;
@@ -83,34 +113,9 @@ struct FmpcOpsOf
       return hipGetLastError();
     };
     o.launch_riccati = [](const FmpcBuffers & buf, int iter, hipStream_t stream) {
-      // N <= 4 states and one input: sixteen lanes per instance on the fp64 matrix cores (fmpc_riccati_quad_kernel) while its
-      // 16-instance workgroups are at most two per CU — the regime in which the chip is otherwise empty; the one-lane-per-
-      // instance kernel issues half as many instructions per instance and wins once the batch fills the chip by itself
-      // (measured on MI355X, cart-pole, T = 200: quad / lane 1.5 / 2.8 ms per 5-iteration solve at 2048 instances, 2.2 / 3.6 at
-      // 4096, 4.5 / 4.7 at 8192, 8.9 / 7.2 at 16384, 37.8 / 29.0 at 65536).  NMPC_HIP_FMPC_RICCATI=quad|lane forces one.
       if constexpr(N <= 4 && M == 1)
       {
-        const char * force = getenv("NMPC_HIP_FMPC_RICCATI");
-        bool quad;
-        if(force && (force[0] == 'l' || force[0] == 'q'))
-        {
-          quad = force[0] == 'q';
-        }
-        else
-        {
-          static int n_cu = 0; // of the current device at first use (the handles of one process sit on like devices)
-          if(n_cu == 0)
-          {
-            int device = 0;
-            if(hipGetDevice(&device) != hipSuccess
-               || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n_cu <= 0)
-            {
-              n_cu = 256;
-            }
-          }
-          quad = blocks(buf.B, 16) <= 2u * static_cast<unsigned>(n_cu);
-        }
-        if(quad)
+        if(fmpcUseQuadRiccati(N, M, buf.B))
         {
           hipLaunchKernelGGL((fmpc_riccati_quad_kernel<N>), dim3(blocks(buf.B, 16)), dim3(256), 0, stream, buf, iter);
           return hipGetLastError();

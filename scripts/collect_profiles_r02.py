@@ -97,8 +97,8 @@ if os.path.exists(stats):
         f.write("bench.py --workload fmpc --steps 10 --warmup 2 (4096 cart-pole FMPC instances, T = 200, max_iter 5); per-launch means,\n")
         f.write("each counter set collected in its own run; SQ_* cycle counters in quad-cycles summed over the waves of a launch\n\n")
         f.write("%-28s %9s %11s %11s %8s %9s %9s %9s\n" % ("kernel", "avg_us", "fetch_MB", "write_MB", "L2_hit", "GB/s", "VALU_act", "waitcnt"))
-        for short in ("fmpc_barrier_kernel", "fmpc_coeff_kernel", "fmpc_riccati_kernel", "fmpc_delta_kernel", "fmpc_step_length_kernel",
-                      "fmpc_update_kernel", "fmpc_transpose_kernel"):
+        for short in ("fmpc_barrier_kernel", "fmpc_coeff_kernel", "fmpc_riccati_quad_kernel", "fmpc_riccati_kernel", "fmpc_delta_kernel",
+                      "fmpc_step_length_kernel", "fmpc_update_kernel", "fmpc_transpose_kernel"):
             pm, cnt = means("pmc?_fmpc_counter_collection.csv", short)
             if not pm:
                 continue
@@ -110,13 +110,13 @@ if os.path.exists(stats):
             f.write("%-28s %9.1f %11.1f %11.1f %8.3f %9.0f %9.3f %9.3f\n" % (
                 short, us, fetch / 1e6, write / 1e6, hit, (fetch + write) / (us * 1e-6) / 1e9,
                 pm["SQ_ACTIVE_INST_VALU"] / wc if wc else float("nan"), pm["SQ_WAIT_ANY"] / wc if wc else float("nan")))
-            if short == "fmpc_riccati_kernel" and bench:
+            if short in ("fmpc_riccati_quad_kernel", "fmpc_riccati_kernel") and bench and short in bench["roofline"]["kernel"]:
                 traffic["fmpc"] = {"hbm_bytes_per_launch": fetch + write, "batch": int(bench["metric"].split("batch=")[1].split(",")[0]),
                                    "horizon": int(bench["metric"].split("T=")[1]),
-                                   "source": f"profiles/{tag}_pmc_summary_fmpc.txt (fmpc_riccati_kernel; FETCH_SIZE x{fetch_scale:.2f}, "
+                                   "source": f"profiles/{tag}_pmc_summary_fmpc.txt ({short}; FETCH_SIZE x{fetch_scale:.2f}, "
                                              "WRITE_SIZE 1:1, separate passes)"}
         if bench:
-            f.write("\nalgorithmic bytes per launch of fmpc_riccati_kernel (bench accounting): %.1f MB\n"
+            f.write("\nalgorithmic bytes per launch of the Riccati kernel (bench accounting): %.1f MB\n"
                     % (bench["roofline"]["algorithmic_bytes_per_launch"] / 1e6))
 json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 # the bench lines of this session were printed before this file existed in its new state: give them the session's own traffic

@@ -65,3 +65,18 @@ def test_other_workload_and_modes_run():
     assert "batch=1024" in d["metric"] and "cpu_baseline" not in d
     d = run_bench("--mode", "m1", "--no-cpu-baseline")
     assert d["config"]["mode"] == "m1" and d["config"]["status_counts"].get("1", 0) == 0  # nobody may terminate early
+
+
+def test_fmpc_workload_keeps_the_contract():
+    d = run_bench("--workload", "fmpc")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data",
+                "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert "FMPC iterations/s" in d["metric"] and "batch=4096" in d["metric"] and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["config"]["status_counts"] == {"5": 4096} and d["config"]["iterations_per_step"] == 5
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel"] == "fmpc_riccati_quad_kernel" and rf["launches_timed"] == 4 * 5
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.5
+    assert abs(d["value"] - 5 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and d["value"] > cb["value"]

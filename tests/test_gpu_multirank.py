@@ -72,6 +72,22 @@ def test_bench_under_two_ranks():
     assert abs(d["value"] - it_per_step / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
 
+def test_fmpc_bench_under_two_ranks():
+    """bench.py --workload fmpc under two ranks (both on device 0): FMPC shards like DDP — independent instances, no collective in
+    the data path; the job's value counts both ranks' iterations."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--workload", "fmpc", "--gpus", "2", "--steps", "4", "--warmup", "1",
+                   "--no-cpu-baseline", "--batch", "1024"], 29647)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64" and "FMPC" in d["metric"]
+    assert len(d["config"]["per_rank_solve_ms"]) == 2
+    # 5 iterations per instance per solve on each of the two ranks
+    assert abs(d["value"] - 2 * 5 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["roofline"]["kernel"] == "fmpc_riccati_quad_kernel" and 0 < d["roofline"]["frac"] < 1.5
+
+
 def test_cpp_sharded_helper(tmp_path):
     """include/nmpc_amd/DDPSolverSharded.hpp (one host process, one handle per shard, one gather): two and three shards on the
     box's single device with the peer-copy gather, one shard through the RCCL all-gather (ncclCommInitAll needs distinct

@@ -354,3 +354,42 @@ def test_cpp_mirror_runs_the_reference_oscillator_loop(tmp_path):
     r = subprocess.run([exe, "4", "10.0"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "failures 0" in r.stdout
+
+
+def test_large_batch_closed_loop_fails_where_the_oracle_fails():
+    """4096 perturbed cart-pole swing-ups: the interior-point iteration diverges for a handful of starts (KKT error -> inf, NaN in
+    the backward pass: Status::ErrorInBackward; the reference's cart-pole test ignores solve()'s return value,
+    TestFmpcCartPole.cpp:411).  Those instances must fail at the same tick with the same status in the oracle's loop, after
+    tracking it until then; a sample of healthy instances is followed as well."""
+    model = "fmpc_cartpole"
+    B, T, n_ticks = 4096, 200, 24
+    rng = np.random.default_rng(0)
+    prob = F.FmpcProblemCartPole(0.01)
+    x0 = np.tile([0.0, np.pi, 0.0, 0.0], (B, 1)) + 0.05 * rng.standard_normal((B, 4))
+    s = F.FmpcSolverBatch(prob, B, T)
+    s.config().max_iter = 5
+    var = F.Variable.make(prob, T, B)
+    var.reset(0.0, 0.0, 0.0, 1.0, 1.0)
+    s.setVariable(var)
+    log = s.mpcRun(0.0, x0, n_ticks, 0.002, sim_substeps=2, use_feedback=True)
+    st = log["status"]
+    failed = np.unique(np.argwhere(~np.isin(st, (1, 5)))[:, 0])
+    assert 1 <= len(failed) <= 40, len(failed)  # 10 with this seed
+    cfg = O.default_config(horizon_steps=T, max_iter=5)
+    for b in list(failed[:6]) + [0, 1234, 4095]:
+        v, x, t, be = O.Variable.reset(model, T), x0[b].copy(), 0.0, 1e-4
+        kkt_prev = 0.0
+        for k in range(n_ticks):
+            r = O.solve(model, cfg, prob.p, t, x, v, be)
+            assert r.status == st[b, k] and r.iters == log["iters"][b, k], (b, k, r.status, st[b, k])
+            if r.status not in (1, 5):
+                break  # the device loop keeps ticking on the broken variable; nothing to compare beyond the failure
+            # an iteration on its way to divergence amplifies rounding: the state is tracked tightly while the KKT error is sane
+            assert np.allclose(x, log["x"][b, k], rtol=0, atol=1e-6 if kkt_prev < 1e3 else 1e-2), (b, k)
+            kkt_prev = max(kkt_prev, r.trace[:r.iters, 1].max())
+            be, v = r.barrier_eps, r.variable
+            for _ in range(2):
+                u = r.variable.u[0] + r.K[0] @ (r.variable.x[0] - x)
+                x = O.evaluate(model, prob.p, t, x, u, step_dt=0.002)["f"]
+                t += 0.002
+        assert (b in failed) == (r.status not in (1, 5))

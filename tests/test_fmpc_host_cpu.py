@@ -77,3 +77,6 @@ def test_cpp_mirror_and_example_compile_on_the_host():
     r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", f"-I{ROOT}/include", "-fsyntax-only",
                         os.path.join(ROOT, "examples", "fmpc_oscillator_mpc.cpp")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", f"-I{ROOT}/include", "-fsyntax-only",
+                        os.path.join(ROOT, "examples", "fmpc_c_api.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]  # include/nmpc_hip_fmpc.h is a C header

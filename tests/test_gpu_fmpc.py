@@ -393,3 +393,40 @@ def test_large_batch_closed_loop_fails_where_the_oracle_fails():
                 x = O.evaluate(model, prob.p, t, x, u, step_dt=0.002)["f"]
                 t += 0.002
         assert (b in failed) == (r.status not in (1, 5))
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/fmpc_c_api.c: the FMPC C-ABI used from C99 (gcc, no C++ on the caller's side) gives the Python mirror's numbers."""
+    import os
+    import subprocess
+
+    from nmpc_amd import _capi
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_capi.lib_path())
+    F.load()
+    exe = str(tmp_path / "fmpc_c_api")
+    cmd = ["gcc", "-std=c99", "-O2", f"-I{root}/include", f"{root}/examples/fmpc_c_api.c", f"-L{libdir}", "-lnmpc_hip_ddp",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    rows = [l.split() for l in r.stdout.splitlines() if l.startswith("solve")]
+    assert len(rows) == 8
+    prob = F.FmpcProblemOscillator()
+    s = F.FmpcSolverBatch(prob, 4, 100)
+    s.config().max_iter = 3
+    var = F.Variable.make(prob, 100, 4)
+    var.reset(0.0, 0.0, 0.0, 1.0, 1.0)
+    x0 = np.array([[0.1 * b, 1.0] for b in range(4)])
+    s.setVariable(var)
+    for p in range(2):
+        st = s.solve(np.zeros(4), x0)
+        it, tr, u = s.iters(), s.traceDataList(), s.variable().u_list
+        for b in range(4):
+            row = rows[4 * p + b]
+            assert [int(row[5]), int(row[6]), int(row[7])] == [2, 1, 3]  # dims
+            assert int(row[9]) == st[b] and int(row[11]) == it[b]
+            assert np.isclose(float(row[13]), tr[b, it[b] - 1, 1], rtol=1e-11, atol=0)  # printed with 13 digits
+            assert np.isclose(float(row[15]), u[b, 0, 0], rtol=1e-11, atol=1e-300)

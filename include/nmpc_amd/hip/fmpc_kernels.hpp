@@ -1508,8 +1508,12 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
   constexpr int kFwdGain = GL::K + M * N; // k, K: elements [0, kFwdGain) of the gain record
   constexpr int kRecF = (kFwdCoef + kFwdGain) | 1;
   constexpr int kSlotDoubles = kS * 16 * (kRecB > kRecF ? kRecB : kRecF);
+  constexpr int kRecG = (GL::kStride + 2) | 1; // gain record + two spare slots
+  constexpr int kRecX = (N + M + 2) | 1; // dx, du + two spare slots
   __shared__ double stage_lds[2 * kSlotDoubles];
+  __shared__ double gain_lds[kS * 16 * kRecG]; // what the chunk's steps produce (backward: gains, forward: dx, du), before it goes to HBM
   __shared__ double sh_kkt[16][17];
+  __shared__ int sh_live[16];
 
   const int wl = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -1575,6 +1579,10 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
   }
   __syncthreads();
   live = live && !(sh_kkt[inst][16] <= buf.kkt_error_thre);
+  if(head)
+  {
+    sh_live[inst] = live ? 1 : 0;
+  }
   if(__syncthreads_or(live ? 1 : 0) == 0)
   {
     return; // workgroup-uniform: none of the sixteen instances is live
@@ -1642,11 +1650,11 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
   // lanes one row below the diagonal (cyclically), k on lane (2, 0) — every value is present on every lane of its row / column,
   // so any lane of the right row / column can write it.  Two stores per step and no branch inside the recursion loop.
   const bool role_s = (row == col) && rv, role_K = (row == ((col + 1) & 3)) && cv, role_k = (row == 2 && col == 0);
-  const int e2 = role_s ? GL::S + rc : (role_K ? GL::K + cc : (role_k ? GL::k : GL::P + rc + cc * N));
-  const size_t gain_step = static_cast<size_t>(GL::kStride) * Bz;
-  double * gP = buf.gain + (static_cast<size_t>(T - 1) * GL::kStride + GL::P + rc + cc * N) * Bz + b; // entry of step T - 1
-  double * g2 = buf.gain + (static_cast<size_t>(T - 1) * GL::kStride + e2) * Bz + b;
-  const bool store1 = live && valid, store2 = live && (role_s || role_K || role_k || valid);
+  // (lanes without a value of their own write the record's spare slots)
+  const int e1 = valid ? GL::P + rc + cc * N : GL::kStride;
+  const int e2 = role_s ? GL::S + rc : (role_K ? GL::K + cc : (role_k ? GL::k : GL::kStride + 1));
+  double * const gP = gain_lds + inst * kRecG + e1;
+  double * const g2 = gain_lds + inst * kRecG + e2;
 
   // per-lane offsets into a staged record
   const int oA = CL::A + rc + cc * N, oQ = CL::QXX + rc + cc * N, oQT = CL::QXX + cc + rc * N, oB = CL::B + rc, oX = CL::XBAR + rc;
@@ -1666,7 +1674,7 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     o.LM = (rv && (c0 || c1)) ? lm : 0.0; // [Qxu~ | Lx~ | 0 | 0]
     o.QxuRow = cv ? qr : 0.0; // Qxu~^T in every row
   };
-  auto backwardStep = [&](const Operands & o) {
+  auto backwardStep = [&](int st, const Operands & o) {
     const double PA = mma(P, o.A, 0.0);
     const double R = mma(P, o.Y, c1 ? -1 * s_row : 0.0);
     const double F = mma(PA, o.A, o.Qxx);
@@ -1688,16 +1696,31 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     s_row = s_new;
     nan = nan || fmpc::bad(k) || fmpc::bad(Kc) || fmpc::bad(s_new) || fmpc::bad(P);
     const double v2 = role_s ? s_new : (role_K ? Kc : (role_k ? k : P));
-    if(store1)
+    gP[st * 16 * kRecG] = P; // parked in LDS; flushGains writes the chunk out in whole cache lines
+    g2[st * 16 * kRecG] = v2;
+  };
+  /** The gains of the chunk that started at timestep i0: LDS -> HBM, thread = (element slot, instance), a full line per row. */
+  auto flushGains = [&](int i0) {
+    if(sh_live[t_inst] != 0)
     {
-      *gP = P;
+      NMPC_UNROLL
+      for(int st = 0; st < kS; st++)
+      {
+        const int step = i0 - st;
+        if(step >= 0)
+        {
+          double * rowp = buf.gain + (static_cast<size_t>(step) * GL::kStride) * Bz + lane_stage;
+          NMPC_UNROLL
+          for(int q = 0; q < (GL::kStride + 15) / 16; q++)
+          {
+            if(16 * q + 15 < GL::kStride || t_slot < GL::kStride - 16 * q)
+            {
+              rowp[static_cast<size_t>(16 * q) * Bz] = gain_lds[(st * 16 + t_inst) * kRecG + 16 * q + t_slot];
+            }
+          }
+        }
+      }
     }
-    if(store2)
-    {
-      *g2 = v2;
-    }
-    gP -= gain_step;
-    g2 -= gain_step;
   };
   {
     constexpr int kQB = (CL::kStride + 15) / 16;
@@ -1706,12 +1729,21 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     commit(TagB(), 0, kRecB, 0, vb);
     __syncthreads();
     int slot = 0;
+#ifdef NMPC_AMD_FMPC_PROFILE2
+    unsigned long long pa = 0, pb = 0, pc = 0, pd = 0, t0_, t1_, t2_, t3_, t4_;
+#endif
     for(int i0 = T - 1; i0 >= 0; i0 -= kS)
     {
+#ifdef NMPC_AMD_FMPC_PROFILE2
+      t0_ = wall_clock64();
+#endif
       if(i0 - kS >= 0)
       {
         request(TagB(), buf.coef, CL::kStride, i0 - kS, -1, vb); // the next chunk travels while this one is consumed
       }
+#ifdef NMPC_AMD_FMPC_PROFILE2
+      t1_ = wall_clock64();
+#endif
       const double * recs = stage_lds + static_cast<size_t>(slot) * kSlotDoubles + inst * kRecB;
       Operands o[2];
       loadOperands(recs, o[0]);
@@ -1724,16 +1756,41 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
           {
             loadOperands(recs + (st + 1) * 16 * kRecB, o[(st + 1) & 1]);
           }
-          backwardStep(o[st & 1]);
+          backwardStep(st, o[st & 1]);
         }
       }
+#ifdef NMPC_AMD_FMPC_PROFILE2
+      t2_ = wall_clock64();
+#endif
+      __syncthreads(); // every wavefront's gains of this chunk are in LDS
       if(i0 - kS >= 0)
       {
         commit(TagB(), slot ^ 1, kRecB, 0, vb);
       }
+#ifdef NMPC_AMD_FMPC_PROFILE2
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      t3_ = wall_clock64();
+#endif
+      flushGains(i0);
       __syncthreads();
+#ifdef NMPC_AMD_FMPC_PROFILE2
+      t4_ = wall_clock64();
+      pa += t1_ - t0_;
+      pb += t2_ - t1_;
+      pc += t3_ - t2_;
+      pd += t4_ - t3_;
+#endif
       slot ^= 1;
     }
+#ifdef NMPC_AMD_FMPC_PROFILE2
+    if(head && b_raw < buf.B)
+    {
+      buf.trace[(static_cast<size_t>(b) * buf.max_iter + (iter - 1)) * NMPC_HIP_FMPC_NTRACE + 2] = static_cast<double>(pa);
+      buf.merit[0 * buf.B + b] = static_cast<double>(pb);
+      buf.merit[1 * buf.B + b] = static_cast<double>(pc);
+      buf.merit[2 * buf.B + b] = static_cast<double>(pd);
+    }
+#endif
   }
   // verdict of the backward pass per instance (:640-653): OR over the sixteen lanes of the instance
   {
@@ -1748,6 +1805,10 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
       buf.status[b] = 3; // Status::ErrorInBackward
     }
     live = live && !failed;
+    if(head)
+    {
+      sh_live[inst] = live ? 1 : 0;
+    }
   }
   // (no early exit from here on: every wavefront of the workgroup takes part in the staging barriers of the forward pass,
   // and the gains the other wavefronts wrote above are read below: make them visible first)
@@ -1759,11 +1820,9 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
   const unsigned long long tick1 = wall_clock64();
 #endif
   double dx_row = rv ? buf.x0[static_cast<size_t>(rc) * Bz + b] - buf.x[fmpc::at(buf, 0, rc, N, b)] : 0.0;
-  // one store per lane and step by role: dx[row] on the diagonal lanes, du on lane (1, 0)
+  // one value per lane and step by role, parked in LDS: dx[row] on the diagonal lanes, du on lane (1, 0)
   const bool role_dx = (row == col) && rv, role_du = (row == 1 && col == 0);
-  double * fP = role_du ? buf.du + b : buf.dx + static_cast<size_t>(rc) * Bz + b;
-  const size_t f_step = (role_du ? static_cast<size_t>(M) : static_cast<size_t>(N)) * Bz;
-  const bool store_f = live && (role_dx || role_du);
+  double * const fP = gain_lds + inst * kRecX + (role_dx ? rc : (role_du ? N : N + M));
   const int oAT = CL::A + cc + rc * N; // entry (col, row): the A operand of mma is used transposed
   const int oKx = kFwdCoef + GL::K + rc, ok = kFwdCoef + GL::k;
   struct ForwardOperands
@@ -1778,15 +1837,11 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     o.Bv = rv ? bv : 0.0;
     o.xb = rv ? xb : 0.0;
   };
-  auto forwardStep = [&](const ForwardOperands & o) {
+  auto forwardStep = [&](int st, const ForwardOperands & o) {
     const double Y = c0 ? dx_row : 0.0;
     const double ax = bcast0(mma(o.AT, Y, 0.0)); // (A dx)[row]
     const double du = bcast0(mma(o.Kx, Y, 0.0)) + o.k; // (2.36), the same in every row
-    if(store_f)
-    {
-      *fP = role_du ? du : dx_row;
-    }
-    fP += f_step;
+    fP[st * 16 * kRecX] = role_du ? du : dx_row;
     const double nx = (ax + o.Bv * du) + o.xb; // (2.26b)
     dx_row = rv ? nx : 0.0;
   };
@@ -1818,13 +1873,34 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
           {
             loadForward(recs + (st + 1) * 16 * kRecF, o[(st + 1) & 1]);
           }
-          forwardStep(o[st & 1]);
+          forwardStep(st, o[st & 1]);
         }
       }
+      __syncthreads();
       if(i0 + kS < T)
       {
         commit(TagFc(), slot ^ 1, kRecF, 0, vc);
         commit(TagFg(), slot ^ 1, kRecF, kFwdCoef, vg);
+      }
+      if(sh_live[t_inst] != 0 && t_slot < N + M) // dx, du of the chunk: LDS -> HBM in whole lines
+      {
+        NMPC_UNROLL
+        for(int st = 0; st < kS; st++)
+        {
+          const int step = i0 + st;
+          if(step < T)
+          {
+            const double v = gain_lds[(st * 16 + t_inst) * kRecX + t_slot];
+            if(t_slot < N)
+            {
+              buf.dx[(static_cast<size_t>(step) * N + t_slot) * Bz + b_stage] = v;
+            }
+            else
+            {
+              buf.du[(static_cast<size_t>(step) * M + (t_slot - N)) * Bz + b_stage] = v;
+            }
+          }
+        }
       }
       __syncthreads();
       slot ^= 1;

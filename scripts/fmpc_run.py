@@ -35,3 +35,8 @@ print(f"B={B} T={T} max_iter={max_iter} model={model}: solve {np.mean(ms[1:]):.3
 if os.environ.get("NMPC_AMD_EXTRA_HIPCC_FLAGS", "").find("NMPC_AMD_FMPC_PROFILE") >= 0:
     m = s.meritFunc()
     print(f"riccati kernel, 100 MHz ticks: backward {m[:, 0].mean() / 100:.1f} us, forward {m[:, 1].mean() / 100:.1f} us")
+if os.environ.get("FMPC_PROFILE2"):
+    tr = s.traceDataList()
+    m = s.meritFunc()
+    print("backward per launch, 100 MHz ticks -> us: request %.1f, compute %.1f, barrier+commit %.1f, flush+barrier %.1f"
+          % (tr[:, 0, 2].mean() / 100, m[:, 0].mean() / 100, m[:, 1].mean() / 100, m[:, 2].mean() / 100))

@@ -629,13 +629,14 @@ __global__ void fmpc_update_kernel(FmpcBuffers buf)
   }
 }
 
-/** End of solve (FmpcSolver.hpp:242-245): IterationContinued becomes MaxIterationReached. */
+/** End of solve (FmpcSolver.hpp:233-246): IterationContinued becomes MaxIterationReached; with max_iter = 0 the loop never
+    ran and solve() returns the initial Status::Uninitialized. */
 __global__ void fmpc_finish_kernel(FmpcBuffers buf)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if(b < buf.B && buf.status[b] == fmpc::kStatusContinued)
   {
-    buf.status[b] = 5; // Status::MaxIterationReached
+    buf.status[b] = buf.max_iter > 0 ? 5 : 0; // Status::MaxIterationReached : Status::Uninitialized
   }
 }
 

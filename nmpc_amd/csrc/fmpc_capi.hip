@@ -1006,11 +1006,6 @@ extern "C"
     const size_t nt = n_ticks;
     double *d_xlog = nullptr, *d_ulog = nullptr, *d_klog = nullptr;
     int *d_slog = nullptr, *d_ilog = nullptr;
-    FMPC_TRY(hipMalloc(reinterpret_cast<void **>(&d_xlog), nt * N * B * sizeof(double)));
-    FMPC_TRY(hipMalloc(reinterpret_cast<void **>(&d_ulog), std::max<size_t>(nt * M * B, 1) * sizeof(double)));
-    FMPC_TRY(hipMalloc(reinterpret_cast<void **>(&d_klog), nt * B * sizeof(double)));
-    FMPC_TRY(hipMalloc(reinterpret_cast<void **>(&d_slog), nt * B * sizeof(int)));
-    FMPC_TRY(hipMalloc(reinterpret_cast<void **>(&d_ilog), nt * B * sizeof(int)));
     auto release = [&]() {
       (void)hipFree(d_xlog);
       (void)hipFree(d_ulog);
@@ -1018,8 +1013,17 @@ extern "C"
       (void)hipFree(d_slog);
       (void)hipFree(d_ilog);
     };
+    if(hipMalloc(reinterpret_cast<void **>(&d_xlog), nt * N * B * sizeof(double)) != hipSuccess
+       || hipMalloc(reinterpret_cast<void **>(&d_ulog), std::max<size_t>(nt * M * B, 1) * sizeof(double)) != hipSuccess
+       || hipMalloc(reinterpret_cast<void **>(&d_klog), nt * B * sizeof(double)) != hipSuccess
+       || hipMalloc(reinterpret_cast<void **>(&d_slog), nt * B * sizeof(int)) != hipSuccess
+       || hipMalloc(reinterpret_cast<void **>(&d_ilog), nt * B * sizeof(int)) != hipSuccess)
+    {
+      release();
+      return fail(NMPC_HIP_ERR_HIP, "[FMPC] log buffers: hipMalloc failed");
+    }
     int rc = ingest(h, t, x0, false, h->stream);
-    FMPC_TRY(hipEventRecord(h->ev0, h->stream));
+    (void)hipEventRecord(h->ev0, h->stream);
     for(int k = 0; k < n_ticks && rc == NMPC_HIP_OK; k++)
     {
       rc = launchSolve(h, h->stream);

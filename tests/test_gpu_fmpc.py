@@ -430,3 +430,18 @@ def test_c_abi_from_plain_c(tmp_path):
             assert int(row[9]) == st[b] and int(row[11]) == it[b]
             assert np.isclose(float(row[13]), tr[b, it[b] - 1, 1], rtol=1e-11, atol=0)  # printed with 13 digits
             assert np.isclose(float(row[15]), u[b, 0, 0], rtol=1e-11, atol=1e-300)
+
+
+def test_max_iter_zero_returns_uninitialized():
+    """solve() with max_iter = 0 never enters the loop (FmpcSolver.hpp:233-246): Status::Uninitialized, variable untouched."""
+    model = "fmpc_oscillator"
+    prob = MODELS[model]()
+    B, T = 20, 12
+    var, x0, t0 = make_case(model, B, T, seed=3)
+    s = F.FmpcSolverBatch(prob, B, T)
+    s.config().max_iter = 0
+    st = s.solve(t0, x0, var)
+    ref = oracle_batch(model, s.config(), prob.p, t0, x0, var)
+    assert (st == 0).all() and np.array_equal(st, ref.status) and (s.iters() == 0).all() and (ref.iters == 0).all()
+    for a, c in zip(s.variable().arrays(), var.arrays()):
+        assert np.array_equal(a, c)

@@ -72,6 +72,26 @@ def cart_pole_table(ref_pos_func: Callable[[float], float]) -> List[Column]:
             ("disturbance", lambda k: 0.0)]
 
 
+def fmpc_oscillator_table() -> List[Column]:
+    """TestFmpcOscillator.cpp:168,186-188: time x[0] x[1] u[0] mpc_iter computation_time kkt_error (from an FMPC mpcRun log:
+    Tick.duration carries (solve ms of the run, kkt_error of the tick))."""
+    return [("time", lambda k: k.t), ("x[0]", lambda k: k.x[0]), ("x[1]", lambda k: k.x[1]), ("u[0]", lambda k: k.u0[0]),
+            ("mpc_iter", lambda k: k.iter), ("computation_time", lambda k: k.duration[0]), ("kkt_error", lambda k: k.duration[1])]
+
+
+def fmpc_cart_pole_table(ref_pos_func: Callable[[float], float]) -> List[Column]:
+    """TestFmpcCartPole.cpp:337,364-365: time pos theta vel omega force ref_pos disturbance (one line per MPC tick)."""
+    return cart_pole_table(ref_pos_func)
+
+
+def fmpc_ticks(log: dict, instance: int, t0: float, tick_dt: float, solve_ms: float = 0.0) -> List[Tick]:
+    """Rows of instance `instance` of an nmpc_amd.fmpc.FmpcSolverBatch.mpcRun log (x, u0, iters, kkt_error per tick)."""
+    n_ticks = log["x"].shape[1]
+    return [Tick(t=t0 + k * tick_dt, x=log["x"][instance, k], u0=log["u0"][instance, k], m0=log["u0"].shape[2],
+                 iter=int(log["iters"][instance, k]), duration=(solve_ms, float(log["kkt_error"][instance, k])))
+            for k in range(n_ticks)]
+
+
 def write_table(file_path: str, ticks: Sequence[Tick], columns: Sequence[Column]) -> None:
     with open(file_path, "w") as f:
         f.write(" ".join(name for name, _ in columns) + "\n")

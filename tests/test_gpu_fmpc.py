@@ -241,6 +241,16 @@ def test_oscillator_closed_loop_reference_bounds_and_oracle_trajectory():
     assert (g[:, 100:] <= 1e-9).all() and (g[:, :, 1:] <= 1e-9).all()  # perturbed starts may begin outside x1 >= -0.05
     assert (np.abs(log["x_final"]) < 1e-2).all()  # :197-198
     assert np.allclose(log["t_final"], n_ticks * sim_dt)
+    # the test's result table (TestFmpcOscillator.cpp:168,186-188), readable the way the reference's users read theirs
+    import os
+    import tempfile
+
+    from nmpc_amd import result_tables as RT
+    path = os.path.join(tempfile.mkdtemp(), "TestFmpcOscillatorResult.txt")
+    RT.write_table(path, RT.fmpc_ticks(log, 0, 0.0, sim_dt), RT.fmpc_oscillator_table())
+    tab = np.genfromtxt(path, names=True)
+    assert tab.dtype.names == ("time", "x0", "x1", "u0", "mpc_iter", "computation_time", "kkt_error")  # genfromtxt drops [ ]
+    assert len(tab) == n_ticks and np.allclose(tab["x1"], log["x"][0, :, 1], rtol=1e-5, atol=1e-9) and tab["mpc_iter"].max() <= 3
     # the same loop through the oracle for two instances
     for b in (0, 17):
         cfg = O.default_config(horizon_steps=T, max_iter=3)

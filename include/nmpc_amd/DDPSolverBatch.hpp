@@ -285,7 +285,7 @@ public:
   {
     const size_t B = static_cast<size_t>(batch_size_);
     std::vector<double> x0, u0;
-    sampleInputLimits(current_t);
+    sampleInputLimits(current_t, shift_warm_start ? n_ticks - 1 : 0);
     packInputs(current_t, current_x, initial_u_list, x0, u0);
     nmpc_hip_ddp_mpc_options opt;
     check(nmpc_hip_ddp_mpc_default_options(&opt));
@@ -444,7 +444,8 @@ protected:
     {
       if(horizon_limits_active_)
       {
-        check(nmpc_hip_ddp_set_input_limits_horizon(handle_, horizon_lo_.data(), horizon_up_.data(), horizon_per_instance_ ? 1 : 0));
+        check(nmpc_hip_ddp_set_input_limits_schedule(handle_, horizon_lo_.data(), horizon_up_.data(), horizon_rows_,
+                                                     horizon_per_instance_ ? 1 : 0));
       }
       else
       {
@@ -469,14 +470,17 @@ protected:
   }
 
   /** Sample input_limits_func_ where the reference's backward pass evaluates it (DDPSolver.hpp:470-472). */
-  inline void sampleInputLimits(const std::vector<double> & current_t)
+  /** \param extra_rows further timesteps to sample beyond the horizon: a device-resident shift loop of extra_rows + 1 ticks
+      starts every tick one timestep later (nmpc_hip_ddp_set_input_limits_schedule) */
+  inline void sampleInputLimits(const std::vector<double> & current_t, int extra_rows = 0)
   {
     const size_t B = static_cast<size_t>(batch_size_);
     if(!limits_from_func_ || current_t.size() != B) // (a wrong batch size is reported by packInputs)
     {
       return;
     }
-    const int T = config_.horizon_steps;
+    const int T = config_.horizon_steps + (extra_rows > 0 ? extra_rows : 0);
+    horizon_rows_ = T;
     const double dt = problem_->dt();
     bool same_t0 = true;
     for(size_t b = 1; b < B && b < current_t.size(); b++)
@@ -663,7 +667,8 @@ protected:
   bool has_limits_ = false;
   bool limits_from_func_ = false;
   std::function<std::array<InputDimVector, 2>(double)> input_limits_func_;
-  std::vector<double> horizon_lo_, horizon_up_; //!< sampled time-varying limits [1 or batch][T][MM]
+  std::vector<double> horizon_lo_, horizon_up_; //!< sampled time-varying limits [1 or batch][horizon_rows_][MM]
+  int horizon_rows_ = 0;
   bool horizon_limits_active_ = false, horizon_per_instance_ = false, horizon_limits_dirty_ = false;
   double lower_[MM];
   double upper_[MM];

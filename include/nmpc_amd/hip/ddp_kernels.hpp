@@ -73,6 +73,8 @@ struct DeviceBuffersT
   const double * lim_steps;
   int lim_steps_per_instance; //!< 1: one table per instance (instances start at different current_t), 0: one for all
   int lim_mm; //!< row length of lim_steps (the handle's MM)
+  int lim_rows; //!< rows per table (>= T): row j = limits at current_t + j dt of the FIRST solve
+  int lim_offset; //!< row of timestep 0 of this solve (the tick number in the device-resident shift loop, else 0)
   double lim_lo[kMaxInputDim]; //!< input lower limits (constant in time)
   double lim_hi[kMaxInputDim]; //!< input upper limits
 };
@@ -103,7 +105,8 @@ NMPC_D double inputLimit(const DeviceBuffers & buf, int b, int i, int a, int sid
   if(buf.lim_steps != nullptr)
   {
     const size_t inst = buf.lim_steps_per_instance ? static_cast<size_t>(b) : 0;
-    return buf.lim_steps[((inst * buf.T + i) * 2 + side) * buf.lim_mm + a];
+    const int r = (i + buf.lim_offset < buf.lim_rows) ? i + buf.lim_offset : buf.lim_rows - 1;
+    return buf.lim_steps[((inst * buf.lim_rows + r) * 2 + side) * buf.lim_mm + a];
   }
   if(buf.lim_batch != nullptr)
   {

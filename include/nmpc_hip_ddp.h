@@ -178,8 +178,15 @@ extern "C"
       input_limits_func_(current_t + i * dt) at every timestep of the backward pass (DDPSolver.hpp:470-472); here the caller
       samples the function for the next solve: lower / upper [T][MM] (per_instance = 0: every instance starts at the same
       current_t) or [batch][T][MM] (per_instance = 1).  Takes precedence over the constant limits; both NULL removes it.
-      The table belongs to ONE solve's timesteps: nmpc_hip_ddp_mpc_run with more than one tick rejects it. */
+      The table belongs to ONE solve's timesteps: nmpc_hip_ddp_mpc_run with more than one tick needs the longer table of
+      nmpc_hip_ddp_set_input_limits_schedule. */
   int nmpc_hip_ddp_set_input_limits_horizon(nmpc_hip_ddp_handle h, const double * lower, const double * upper, int per_instance);
+
+  /** The same for a run of solves that advance by one timestep each (nmpc_hip_ddp_mpc_run with the shift pattern, where the
+      device advances current_t by dt per tick): `rows` >= T samples of the limits function, row j at current_t + j dt of the
+      FIRST solve; tick k uses rows [k, k + T).  lower / upper [rows][MM] or [batch][rows][MM].  A run of n_ticks needs
+      rows >= T + n_ticks - 1.  nmpc_hip_ddp_set_input_limits_horizon is this call with rows = T. */
+  int nmpc_hip_ddp_set_input_limits_schedule(nmpc_hip_ddp_handle h, const double * lower, const double * upper, int rows, int per_instance);
 
   /** DDPSolver::solve (DDPSolver.h:275, DDPSolver.hpp:26-141) for the whole batch, HOST pointers:
       H2D copy, device solve, synchronise.  Results stay on the device until nmpc_hip_ddp_get. */

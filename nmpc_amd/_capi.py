@@ -85,7 +85,8 @@ EXPORTS = (
     "nmpc_hip_ddp_model_info", "nmpc_hip_ddp_model_scalar_bytes", "nmpc_hip_ddp_model_default_params", "nmpc_hip_ddp_create",
     "nmpc_hip_ddp_destroy", "nmpc_hip_ddp_set_config", "nmpc_hip_ddp_get_config",
     "nmpc_hip_ddp_set_model_params", "nmpc_hip_ddp_set_model_params_batch", "nmpc_hip_ddp_set_input_limits_batch",
-    "nmpc_hip_ddp_input_dims", "nmpc_hip_ddp_set_input_limits", "nmpc_hip_ddp_set_input_limits_horizon", "nmpc_hip_ddp_solve",
+    "nmpc_hip_ddp_input_dims", "nmpc_hip_ddp_set_input_limits", "nmpc_hip_ddp_set_input_limits_horizon",
+    "nmpc_hip_ddp_set_input_limits_schedule", "nmpc_hip_ddp_solve",
     "nmpc_hip_ddp_solve_device", "nmpc_hip_ddp_synchronize", "nmpc_hip_ddp_get", "nmpc_hip_ddp_get_device",
     "nmpc_hip_ddp_field_bytes", "nmpc_hip_ddp_last_solve_ms", "nmpc_hip_ddp_last_solve_phases", "nmpc_hip_ddp_timing_stats",
     "nmpc_hip_ddp_kernel_name", "nmpc_hip_ddp_mpc_default_options", "nmpc_hip_ddp_mpc_run",
@@ -126,6 +127,7 @@ def load():
     L.nmpc_hip_ddp_input_dims.argtypes = [vp, C.c_double, ip]
     L.nmpc_hip_ddp_set_input_limits.argtypes = [vp, dp, dp]
     L.nmpc_hip_ddp_set_input_limits_horizon.argtypes = [vp, dp, dp, C.c_int]
+    L.nmpc_hip_ddp_set_input_limits_schedule.argtypes = [vp, dp, dp, C.c_int, C.c_int]
     L.nmpc_hip_ddp_solve.argtypes = [vp, dp, dp, dp]
     L.nmpc_hip_ddp_solve_device.argtypes = [vp, vp, vp, vp, vp]
     L.nmpc_hip_ddp_synchronize.argtypes = [vp]

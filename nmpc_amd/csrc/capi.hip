@@ -106,6 +106,8 @@ struct nmpc_hip_ddp_solver
   unsigned long long * d_phase_ticks = nullptr; // [Bp][4] per-instance phase ticks of the last solve
   double * d_lim_steps = nullptr; // [1 or Bp][T][2][MM] time-varying input limits, or nullptr
   int lim_steps_per_instance = 0;
+  int lim_rows = 0; // rows per table of d_lim_steps
+  int lim_offset = 0; // row of timestep 0 of the next launch (mpc_run's tick)
   int trace_rows = 0;
   // staging in the reference layouts
   void * d_stage_in = nullptr; // x0 / u_init / t0 as handed over by the host entry point
@@ -196,6 +198,8 @@ DeviceBuffers makeBuffers(const nmpc_hip_ddp_solver * s)
   b.lim_steps = s->d_lim_steps;
   b.lim_steps_per_instance = s->lim_steps_per_instance;
   b.lim_mm = s->MM;
+  b.lim_rows = s->lim_rows;
+  b.lim_offset = s->lim_offset;
   for(int i = 0; i < nmpc_amd::hip::kMaxInputDim; i++)
   {
     b.lim_lo[i] = s->lim_lo[i];
@@ -949,11 +953,15 @@ extern "C"
     return NMPC_HIP_OK;
   }
 
-  int nmpc_hip_ddp_set_input_limits_horizon(nmpc_hip_ddp_handle s, const double * lower, const double * upper, int per_instance)
+  int nmpc_hip_ddp_set_input_limits_schedule(nmpc_hip_ddp_handle s, const double * lower, const double * upper, int rows, int per_instance)
   {
     if(!s || (lower == nullptr) != (upper == nullptr))
     {
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle, or only one of lower / upper given");
+    }
+    if(lower && rows < s->T)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "a limits table needs at least horizon_steps rows");
     }
     NMPC_HIP_TRY(hipSetDevice(s->device));
     NMPC_HIP_TRY(hipStreamSynchronize(s->stream));
@@ -965,23 +973,24 @@ extern "C"
         s->d_lim_steps = nullptr;
       }
       s->lim_steps_per_instance = 0;
+      s->lim_rows = 0;
       s->has_limits = s->has_shared_limits || s->d_lim_batch != nullptr;
       return NMPC_HIP_OK;
     }
-    const size_t per_table = static_cast<size_t>(s->T) * s->MM;
+    const size_t per_table = static_cast<size_t>(rows) * s->MM;
     const size_t n_tables = per_instance ? static_cast<size_t>(s->Bp) : 1;
-    // device layout [table][T][2][MM]; padding instances (b >= B) are unbounded
+    // device layout [table][rows][2][MM]; padding instances (b >= B) are unbounded
     std::vector<double> host(n_tables * per_table * 2);
     for(size_t tb = 0; tb < n_tables; tb++)
     {
       const bool valid = !per_instance || tb < static_cast<size_t>(s->B);
-      for(int i = 0; i < s->T; i++)
+      for(int i = 0; i < rows; i++)
       {
         for(int a = 0; a < s->MM; a++)
         {
           const size_t src = (per_instance ? tb * per_table : 0) + static_cast<size_t>(i) * s->MM + a;
-          host[((tb * s->T + i) * 2 + 0) * s->MM + a] = valid ? lower[src] : -INFINITY;
-          host[((tb * s->T + i) * 2 + 1) * s->MM + a] = valid ? upper[src] : INFINITY;
+          host[((tb * rows + i) * 2 + 0) * s->MM + a] = valid ? lower[src] : -INFINITY;
+          host[((tb * rows + i) * 2 + 1) * s->MM + a] = valid ? upper[src] : INFINITY;
         }
       }
     }
@@ -993,8 +1002,15 @@ extern "C"
     NMPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_lim_steps), host.size() * sizeof(double)));
     NMPC_HIP_TRY(hipMemcpy(s->d_lim_steps, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
     s->lim_steps_per_instance = per_instance ? 1 : 0;
+    s->lim_rows = rows;
+    s->lim_offset = 0;
     s->has_limits = true;
     return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_set_input_limits_horizon(nmpc_hip_ddp_handle s, const double * lower, const double * upper, int per_instance)
+  {
+    return nmpc_hip_ddp_set_input_limits_schedule(s, lower, upper, s ? s->T : 0, per_instance);
   }
 
   int nmpc_hip_ddp_solve_device(nmpc_hip_ddp_handle s,
@@ -1058,11 +1074,11 @@ extern "C"
     {
       return fail(NMPC_HIP_ERR_RUNTIME, "the receding-horizon driver is served by the fp64 problem types");
     }
-    if(s->d_lim_steps && opt->n_ticks > 1)
+    if(s->d_lim_steps && opt->n_ticks > 1 && !(opt->shift_warm_start && s->lim_rows >= s->T + opt->n_ticks - 1))
     {
-      return fail(NMPC_HIP_ERR_RUNTIME, "time-varying input limits (set_input_limits_horizon) are sampled for ONE solve's "
-                                        "timesteps; the device-resident loop advances current_t, so it takes limits that "
-                                        "are constant in time");
+      return fail(NMPC_HIP_ERR_RUNTIME, "time-varying input limits in the device-resident loop: the shift pattern with a table of "
+                                        "horizon_steps + n_ticks - 1 rows (nmpc_hip_ddp_set_input_limits_schedule); the plant "
+                                        "pattern advances current_t by sim_dt and takes limits that are constant in time");
     }
     if(!opt->shift_warm_start)
     {
@@ -1130,6 +1146,7 @@ extern "C"
     const int max_iter_saved = s->cfg.max_iter;
     for(int tick = 0; tick < opt->n_ticks && rc == NMPC_HIP_OK; tick++)
     {
+      s->lim_offset = s->d_lim_steps ? tick : 0; // row of this tick's timestep 0 in the limits schedule
       rc = launchRecorded(s, st, t0 ? dt : nullptr, dx, du, tick == 0);
       if(rc != NMPC_HIP_OK)
       {
@@ -1148,6 +1165,7 @@ extern "C"
       }
     }
     s->cfg.max_iter = max_iter_saved;
+    s->lim_offset = 0;
     if(rc != NMPC_HIP_OK)
     {
       return rc;

@@ -157,10 +157,12 @@ class DDPSolverBatch:
         (nmpc_hip_ddp_set_input_limits_horizon)."""
         self._limits_func = input_limits_func
 
-    def _sample_limits_func(self, t0: np.ndarray) -> None:
+    def _sample_limits_func(self, t0: np.ndarray, extra_rows: int = 0) -> None:
+        """Samples the limits function at current_t + i dt for the timesteps of the next solve (+ extra_rows further ones: a
+        device-resident shift loop of extra_rows + 1 ticks, each of which starts one timestep later)."""
         if getattr(self, "_limits_func", None) is None:
             return
-        T = int(self._config.horizon_steps)
+        T = int(self._config.horizon_steps) + int(extra_rows)
         dt = float(self.problem.dt())
         same_t0 = bool(np.all(t0 == t0[0]))
         starts = t0[:1] if same_t0 else t0
@@ -266,8 +268,8 @@ class DDPSolverBatch:
                 _capi.check(self._L.nmpc_hip_ddp_set_input_limits_horizon(self._h, None, None, 0))
             else:
                 lo, up, per_instance = hz
-                _capi.check(self._L.nmpc_hip_ddp_set_input_limits_horizon(self._h, lo.ctypes.data_as(dp), up.ctypes.data_as(dp),
-                                                                          1 if per_instance else 0))
+                _capi.check(self._L.nmpc_hip_ddp_set_input_limits_schedule(self._h, lo.ctypes.data_as(dp), up.ctypes.data_as(dp),
+                                                                           lo.shape[-2], 1 if per_instance else 0))
             self._limits_horizon_dirty = False
         if getattr(self, "_limits_batch_dirty", False):
             dp = C.POINTER(C.c_double)
@@ -357,7 +359,8 @@ class DDPSolverBatch:
         B = self.batch_size
         t0 = np.broadcast_to(np.asarray(current_t, dtype=np.float64), (B,)).copy()
         x0 = np.ascontiguousarray(np.asarray(current_x, dtype=np.float64).reshape(B, self.n))
-        self._sample_limits_func(t0)
+        # the shift loop starts every tick one timestep later: a limits function is sampled over horizon + n_ticks - 1 steps
+        self._sample_limits_func(t0, extra_rows=(int(n_ticks) - 1) if shift_warm_start else 0)
         self._push_state()
         u = self._pack_u(initial_u_list, t0)
         opt = _capi.MpcOptions()

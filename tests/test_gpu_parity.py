@@ -890,10 +890,63 @@ def test_time_varying_input_limits(kernel, monkeypatch):
     s2.setInputLimits(np.array([-15.0]), np.array([15.0]))
     s2.solve(wl.t0, wl.x0, wl.u_init)
     np.testing.assert_array_equal(Xc, s2.X())
-    # the device-resident loop advances current_t: it refuses a table sampled for one solve
+    # the plant loop advances current_t by sim_substeps * sim_dt per tick, which is no multiple of dt: it refuses a table
+    # sampled on the dt grid (the shift loop, which advances by dt, takes one — test_shift_loop_with_time_varying_limits)
     s.setInputLimitsFunc(lambda t: (np.array([-half_width(t)]), np.array([half_width(t)])))
     with pytest.raises(RuntimeError):
-        s.mpcRun(wl.t0, wl.x0, wl.u_init, n_ticks=3)
+        s.mpcRun(wl.t0, wl.x0, wl.u_init, n_ticks=3, shift_warm_start=False, sim_substeps=2, sim_dt=0.002)
+
+
+@pytest.mark.parametrize("kernel", ["quad", "2w"])
+def test_shift_loop_with_time_varying_limits(kernel, monkeypatch):
+    """The device-resident shift loop (solve; x <- state_list[1]; u_list shifted; current_t += dt) with limits that depend
+    on t: tick k's backward pass sees input_limits_func_(current_t + (k + i) dt) (DDPSolver.hpp:470-472 under the loop of
+    TestDDPVerticalMotion.cpp:290-326).  The host samples the function once over horizon + n_ticks - 1 timesteps and the
+    kernels read the table from row k on; compared tick by tick with the oracle solving each tick with its own table."""
+    from nmpc_amd import workloads
+
+    monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", kernel)
+    ticks = 12
+    wl = workloads.cartpole_batch(B=48, T=60, seed=77)
+    wl.t0 = np.linspace(0.0, 0.5, wl.B)
+
+    def half_width(t):
+        return 5.0 + 11.0 * max(0.0, 1.0 - t / 0.9) + (3.0 if t > 0.6 else 0.0)
+
+    s = make_solver(wl, with_input_constraint=True, max_iter=20)
+    s.setInputLimitsFunc(lambda t: (np.array([-half_width(t)]), np.array([half_width(t)])))
+    log = s.mpcRun(wl.t0, wl.x0, wl.u_init, n_ticks=ticks, shift_warm_start=True, max_iter_after_first=4)
+    # a later solve() samples the horizon again (the schedule of the loop is not left behind)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    X_after = s.X().copy()
+    s_fresh = make_solver(wl, with_input_constraint=True, max_iter=20)
+    s_fresh.setInputLimitsFunc(lambda t: (np.array([-half_width(t)]), np.array([half_width(t)])))
+    s_fresh.solve(wl.t0, wl.x0, wl.u_init)
+    np.testing.assert_array_equal(X_after, s_fresh.X())
+
+    bound_hits, compared = 0, 0
+    for b in range(0, wl.B, 5):
+        x, u, t = wl.x0[b].copy(), wl.u_init[b].copy(), float(wl.t0[b])
+        ok = True
+        for k in range(ticks):
+            ocfg = oracle.default_config(horizon_steps=wl.T, with_input_constraint=1, max_iter=20 if k == 0 else 4)
+            lo = np.array([[-half_width(t + i * wl.dt)] for i in range(wl.T)])
+            r = oracle.solve(wl.model, ocfg, x, u, t0=t, lower=lo, upper=-lo)
+            assert abs(log.t[b, k] - t) < 1e-12
+            if ok:
+                # the loop is compared while it has not branched (a flipped line-search decision sends both sides to
+                # nearby but different iterates from there on; see DESIGN.md §3)
+                ok = int(log.iters[b, k]) == r.iters and np.abs(log.u0[b, k] - r.U[0]).max() <= 1e-6 * max(1.0, np.abs(r.U).max())
+                if ok:
+                    assert np.abs(log.x[b, k] - x).max() <= 1e-7 * max(1.0, np.abs(x).max())
+                    compared += 1
+            bound_hits += int(abs(abs(r.U[0, 0]) - half_width(t)) < 1e-9)
+            assert abs(log.u0[b, k, 0]) <= half_width(t) + 1e-9  # the first input respects this tick's own bound
+            x, u, t = r.X[1].copy(), np.concatenate([r.U[1:], r.U[-1:]]), t + wl.dt
+        assert abs(log.t_final[b] - t) < 1e-12
+    print(f"[{kernel}] ticks compared before any branch: {compared} / {len(range(0, wl.B, 5)) * ticks}, bound hits {bound_hits}")
+    assert compared >= 0.8 * len(range(0, wl.B, 5)) * ticks
+    assert bound_hits > 10  # the moving bound is active at the first input of many ticks
 
 
 def test_time_varying_input_limits_wave_per_instance_kernel():

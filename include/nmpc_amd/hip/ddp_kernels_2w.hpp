@@ -147,6 +147,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   // scripts/profile_2w.py): shader cycles per pass kind and the share spent waiting in the per-timestep barriers,
   // per role; written over qp_free of instances 0 (master) / 1 (helper) of tile 0.  Never enabled in product builds.
   mutable unsigned long long prof_wait = 0, prof_t0 = 0;
+  mutable unsigned prof_count = 0, prof_passes[2] = {0, 0}; // stamped sections (quad kernel: NMPC_QPROF_END), passes per kind
   mutable unsigned long long prof_acc[4] = {0, 0, 0, 0}; // [2 * pass_kind + 0] = total, [+ 1] = barrier wait
   NMPC_D void wgBarrier() const
   {
@@ -163,6 +164,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   {
     prof_acc[2 * kind] += __builtin_readcyclecounter() - prof_t0;
     prof_acc[2 * kind + 1] += prof_wait;
+    prof_passes[kind]++;
   }
   NMPC_D void profFlush(int instance) const
   {
@@ -174,6 +176,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       }
       // HW_REG_HW_ID (id 4): [3:0] wave slot, [5:4] SIMD, [11:8] CU, [15:13] SE -> which SIMD each role runs on
       buf.qp_free[static_cast<size_t>(4) * LW + instance] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+      buf.qp_free[static_cast<size_t>(9) * LW + instance] = prof_count;
+      buf.qp_free[static_cast<size_t>(10) * LW + instance] = prof_passes[0];
+      buf.qp_free[static_cast<size_t>(11) * LW + instance] = prof_passes[1];
     }
   }
 #else

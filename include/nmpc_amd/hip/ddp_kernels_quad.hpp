@@ -80,7 +80,6 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
   static constexpr int oLu = 45;
   static constexpr int oU = 46;
   static constexpr int oZero = 47; // 0.0: what the lanes outside a masked operand read
-  static constexpr int oUinv = 48; // 1 / (|u| + 1) for the running max of |k| / (|u| + 1)
   static constexpr int kRecQ = 49; // odd: the 64 lanes of the linearisation write conflict-free
   static constexpr int kChunkSteps = 16;
   // gains of the chunk's 64 (instance, timestep) pairs, staged in LDS and written to HBM at the chunk boundary
@@ -160,7 +159,8 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     }
     p.u = pu[static_cast<size_t>(i) * LW];
   }
-  NMPC_D void lineariseStep(int i, double t0_l, const PointQ & p, double * rec) const
+  /** \return 1 / (|u_i| + 1), the weight of |k_i| in the running max of DDPSolver.hpp:217-221 */
+  NMPC_D double lineariseStep(int i, double t0_l, const PointQ & p, double * rec) const
   {
     const double t = t0_l + i * lin_problem.dt();
     StateDimVector x;
@@ -200,7 +200,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     rec[oLu] = Lu[0];
     rec[oU] = u[0];
     rec[oZero] = 0.0;
-    rec[oUinv] = recipFast(fabs(u[0]) + 1.0);
+    return recipFast(fabs(u[0]) + 1.0);
   }
 
   /** One backward pass (DDPSolver::backwardPass, DDPSolver.hpp:342-534) of the four instances of this wave.  Entered by
@@ -227,6 +227,11 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     // (rows 2 and 3 write the record's dummy slot: no branch in the recursion loop)
     double * gain_q = gains + static_cast<size_t>(blk * 16) * kGainRec
                       + (row == 0 ? gKfb + col : ((row == 1 && col == 0) ? gK : ((row == 1 && col == 1) ? gLive : gDummy)));
+    // the same without the flag (unguarded chunks set the 16 flags of an instance with one store when they are done: the
+    // 16 lanes of a block are then the 16 timesteps)
+    double * gain_u = gains + static_cast<size_t>(blk * 16) * kGainRec
+                      + (row == 0 ? gKfb + col : ((row == 1 && col == 0) ? gK : gDummy));
+    double * live_q = gains + static_cast<size_t>(blk * 16 + 4 * row + col) * kGainRec + gLive;
     const double * rec_q = chunk + static_cast<size_t>(blk * 16) * kRecQ;
 
     // lane predicates of the natural layout
@@ -241,7 +246,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     const int aLxuRow = oLxu + col; // Lxu^T in every row
     struct Operands
     {
-      double Fx, Lxx, LxxT, FuM, FuB, LM, CM, LxuRow, u, uinv;
+      double Fx, Lxx, LxxT, FuM, FuB, LM, CM, LxuRow, u;
     };
     auto loadOperands = [&](int ts, Operands & o)
     {
@@ -258,7 +263,6 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       {
         o.u = R[oU];
       }
-      o.uinv = R[oUinv];
     };
 
     // ---- terminal value function    DDPSolver.hpp:349-352
@@ -286,7 +290,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     double Vxx = rec_q[aE];
     double VxM = pick(c1, rec_q[16 + row]); // Vx in column 1, zero elsewhere
 
-    double dV0_l = 0, dV1_l = 0, krn = 0;
+    double dV0_l = 0, dV1_l = 0;
     bool ok = true;
     double k_next = 0;
     bool have_next = false;
@@ -295,9 +299,12 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
 
     /** One timestep of the recursion on the operands `o`; requests the operands of record `ts_next` into `o_next`
         first (they do not depend on the recursion: their LDS latency hides behind this timestep). */
-    auto step = [&](auto reg_tag, int i, int ts, const Operands & o, int ts_next, Operands & o_next)
+    auto step = [&](auto reg_tag, auto guarded_tag, int i, int ts, const Operands & o, int ts_next, Operands & o_next)
     {
       constexpr int kReg = decltype(reg_tag)::value; // Configuration::reg_type, a compile-time constant in here
+      // guarded: the reference's semantics for a pass that fails at this timestep or has failed before (nothing is
+      // accumulated or saved from then on); unguarded: the caller looks at `ok` when the chunk is done and repeats it
+      constexpr bool kGuarded = decltype(guarded_tag)::value;
       loadOperands(ts_next, o_next);
       // ---- Q terms    DDPSolver.hpp:386-408   (mma(X, Y, C) = X^T Y + C)
       const double P = mma(Vxx, o.Fx, 0.0); // Vxx^T Fx = (Fx^T Vxx)^T
@@ -349,7 +356,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       else
       {
         step_ok = !(Quu_F <= 0);
-        inv = step_ok ? recipFast(Quu_F) : 0.0;
+        inv = (!kGuarded || step_ok) ? recipFast(Quu_F) : 0.0;
         k = -1 * (Qu * inv);
       }
       const double Kc = -1 * (QAr * inv); // K[col]
@@ -358,7 +365,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       ok = ok && step_ok;
 
       // ---- cost-to-go update    :522-527
-      if(live)
+      if(!kGuarded || live)
       {
         dV0_l += k * Qu;
         dV1_l += 0.5 * (k * (Quu * k));
@@ -371,27 +378,38 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       // Qx + K^T Quu k + K^T Qu + Qux^T k
       VxM = pick(c1, fma(Qr, k, fma(Kr, Qu, fma(KQr, k, Qxr))));
 
-      // ---- save gains    :529-530 (staged, see flushGains), running max of |k_i| / (|u_i| + 1)    :217-221
-      gain_q[static_cast<size_t>(ts) * kGainRec] = r0 ? Kc : (c0 ? k : (live ? 1.0 : 0.0));
+      // ---- save gains    :529-530 (staged, see flushGains)
+      if constexpr(kGuarded)
+      {
+        gain_q[static_cast<size_t>(ts) * kGainRec] = r0 ? Kc : (c0 ? k : (live ? 1.0 : 0.0));
+      }
+      else
+      {
+        gain_u[static_cast<size_t>(ts) * kGainRec] = r0 ? Kc : k;
+      }
       // (what a lane computes after it stopped being live is never read: a failed pass is retried or ends the solve)
       k_next = k;
       have_next = true;
-      krn = fmax(krn, fabs(k) * o.uinv);
     };
 
     /** Gains of the chunk starting at timestep i_first: LDS -> k_list_ / K_list_ in HBM, by the lane of each (instance,
-        timestep) pair in the linearisation mapping. */
-    auto flushGains = [&](int i_first)
+        timestep) pair in the linearisation mapping, which also takes the running max of |k_i| / (|u_i| + 1)
+        (DDPSolver.hpp:217-221; uinv = this lane's 1 / (|u_i| + 1) from the chunk's linearisation): two instructions per
+        chunk here instead of an LDS read and two instructions per timestep in the recursion. */
+    double krn_l = 0;
+    auto flushGains = [&](int i_first, double uinv)
     {
       const int i = i_first + ts_l;
       if(i < T && gain_l[gLive] != 0.0)
       {
-        Base::kt[static_cast<size_t>(i) * LW + lane_l] = gain_l[gK];
+        const double kv = gain_l[gK];
+        Base::kt[static_cast<size_t>(i) * LW + lane_l] = kv;
 #pragma unroll
         for(int c = 0; c < N; c++)
         {
           Base::Kt[(static_cast<size_t>(i) * N + c) * LW + lane_l] = gain_l[gKfb + c];
         }
+        krn_l = fmax(krn_l, fabs(kv) * uinv);
       }
     };
     auto runChunks = [&](auto reg_tag)
@@ -402,26 +420,30 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
         const int i = ((n_chunks - 1) * kChunkSteps + ts_l < T) ? (n_chunks - 1) * kChunkSteps + ts_l : T - 1;
         loadPointQ(i, px, pu, pt);
       }
+      double uinv_prev = 0; // 1 / (|u| + 1) of this lane's timestep in the chunk whose gains are staged
       for(int ch = n_chunks - 1; ch >= 0; ch--)
       {
         const int i0 = ch * kChunkSteps;
+        double uinv_now;
         {
 #ifdef NMPC_AMD_PROFILE_2W
           const unsigned long long tl = __builtin_readcyclecounter();
 #endif
           const int i = (i0 + ts_l < T) ? i0 + ts_l : T - 1;
-          lineariseStep(i, t0_l, pt, rec_l);
+          uinv_now = lineariseStep(i, t0_l, pt, rec_l);
 #ifdef NMPC_AMD_PROFILE_2W
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           Pair::prof_wait += __builtin_readcyclecounter() - tl; // reported as "barrier wait": the linearisation share
+          Pair::prof_count++;
 #endif
         }
         // HBM traffic of this wave happens here, one chunk behind / ahead of the recursion: the previous chunk's gains
         // go out, then the next chunk's (x, u) are requested — both have the 16 recursion steps below to complete
         if(ch + 1 < n_chunks)
         {
-          flushGains(i0 + kChunkSteps);
+          flushGains(i0 + kChunkSteps, uinv_prev);
         }
+        uinv_prev = uinv_now;
         {
           const int in = i0 - kChunkSteps + ts_l; // (unconditional, clamped: the last request is never used)
           loadPointQ(in > 0 ? in : 0, px, pu, pt);
@@ -429,19 +451,33 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
         const int hi = (i0 + kChunkSteps - 1 < T) ? i0 + kChunkSteps - 1 : T - 1;
         if constexpr(!kConstrained)
         {
-          if(hi - i0 + 1 == kChunkSteps)
+          if(hi - i0 + 1 == kChunkSteps && __all(ok))
           {
             // a full chunk as straight-line code: one scheduling region for the 16 timesteps (the compiler fills the
-            // recursion's dependency stalls across timesteps) and immediate LDS offsets.  (The BoxQP variant would not
-            // fit the instruction cache.)
+            // recursion's dependency stalls across timesteps), immediate LDS offsets, and NO guards: a lone wave issues
+            // one instruction every ~4.3 cycles whatever its kind (scripts/ubench_issue_cost.hip), so the selects that
+            // freeze a failed pass (`inv`, the two dV sums, the live flag: ~16 instructions of ~80 per timestep) cost
+            // what arithmetic costs.  A pivot that fails (rare) is noticed when the chunk is done, and the chunk is
+            // then repeated from its saved state by the guarded loop below.  (The BoxQP variant would not fit the
+            // instruction cache.)
+            const double Vxx_s = Vxx, VxM_s = VxM, dV0_s = dV0_l, dV1_s = dV1_l;
             Operands o2[2];
             loadOperands(kChunkSteps - 1, o2[(kChunkSteps - 1) & 1]);
 #pragma unroll
             for(int ts = kChunkSteps - 1; ts >= 0; ts--)
             {
-              step(reg_tag, i0 + ts, ts, o2[ts & 1], ts > 0 ? ts - 1 : 0, o2[(ts & 1) ^ 1]);
+              step(reg_tag, std::false_type(), i0 + ts, ts, o2[ts & 1], ts > 0 ? ts - 1 : 0, o2[(ts & 1) ^ 1]);
             }
-            continue;
+            if(__all(ok))
+            {
+              *live_q = need ? 1.0 : 0.0; // the 16 lanes of a block: the flags of the chunk's 16 timesteps
+              continue;
+            }
+            Vxx = Vxx_s;
+            VxM = VxM_s;
+            dV0_l = dV0_s;
+            dV1_l = dV1_s;
+            ok = true;
           }
         }
         // two operand sets, loop unrolled by two: no register copies between timesteps
@@ -450,15 +486,15 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
         int i = hi;
         for(; i - 1 >= i0; i -= 2)
         {
-          step(reg_tag, i, i - i0, oa, i - 1 - i0, ob);
-          step(reg_tag, i - 1, i - 1 - i0, ob, (i - 2 >= i0) ? i - 2 - i0 : 0, oa);
+          step(reg_tag, std::true_type(), i, i - i0, oa, i - 1 - i0, ob);
+          step(reg_tag, std::true_type(), i - 1, i - 1 - i0, ob, (i - 2 >= i0) ? i - 2 - i0 : 0, oa);
         }
         if(i >= i0)
         {
-          step(reg_tag, i, i - i0, oa, 0, ob);
+          step(reg_tag, std::true_type(), i, i - i0, oa, 0, ob);
         }
       }
-      flushGains(0);
+      flushGains(0, uinv_prev);
     };
     if(cfg.reg_type == 2)
     {
@@ -472,12 +508,21 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     {
       runChunks(std::integral_constant<int, 0>());
     }
+    // max over the 16 timestep lanes of an instance (the lanes of one DPP row)
+#pragma unroll
+    for(int m = 8; m >= 1; m >>= 1)
+    {
+      krn_l = fmax(krn_l, __shfl_xor(krn_l, m, 16));
+    }
+    if(ts_l == 0)
+    {
+      mailOut(inst_l, 3) = krn_l;
+    }
     if(r0 && c0)
     {
       mailOut(inst, 0) = ok ? 1.0 : 0.0;
       mailOut(inst, 1) = dV0_l;
       mailOut(inst, 2) = dV1_l;
-      mailOut(inst, 3) = krn;
     }
     __syncthreads(); // closes the pass: results in the mailboxes, gains in HBM
   }

@@ -11,6 +11,10 @@ q = s.qpFreeMask().astype(np.float64) * 16.0
 print("kernel ms", s.computationDuration().opt, s.kernelName())
 bt, bw, ft, fw = q[0, 0], q[0, 1], q[0, 2], q[0, 3]
 print(f"master: backward total {bt:.0f} cyc, linearise {bw:.0f} ({bw / max(bt, 1):.2%}) | forward total {ft:.0f}, wait {fw:.0f} ({fw / max(ft, 1):.2%})")
+qi = s.qpFreeMask()
+n_sec, n_bw, n_fw = int(qi[0, 9]), int(qi[0, 10]), int(qi[0, 11])
+print(f"        {n_bw} backward passes ({bt / max(n_bw, 1):.0f} cyc each), {n_fw} forward passes ({ft / max(n_fw, 1):.0f} each), "
+      f"{n_sec} stamped sections ({bw / max(n_sec, 1):.0f} cyc each; NMPC_AMD_PROFILE_WHAT picks the section)")
 for w in range(0, 4):
     hw = int(s.qpFreeMask()[0, 4 + w])
     print(f"   wave {w}: HW_ID wave slot {hw & 15}, SIMD {(hw >> 4) & 3}, CU {(hw >> 8) & 15}, SE {(hw >> 13) & 7}")

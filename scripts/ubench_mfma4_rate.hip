@@ -93,6 +93,50 @@ __global__ void k_fma_dep(double * out)
   }
   out[threadIdx.x] = d;
 }
+/** Does a lone wave issue independent VALU work while its MFMA occupies the matrix core?  Per unrolled element: one MFMA of a
+    dependent chain (24 cycles alone) + NV FMAs of chains that do not touch it. */
+template<int NV>
+__global__ void k_mfma_dep_plus_valu(double * out)
+{
+  double a = 1e-3, d = 1.0 + threadIdx.x * 1e-4;
+  double f[6] = {1.0, 1.1, 1.2, 1.3, 1.4, 1.5};
+  for(int i = 0; i < kIters; i++)
+  {
+#pragma unroll
+    for(int r = 0; r < 8; r++)
+    {
+      d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, d, 0.5, 0, 0, 0);
+#pragma unroll
+      for(int v = 0; v < NV; v++)
+      {
+        f[v % 6] = fma(f[v % 6], 0.999, 0.001);
+      }
+    }
+  }
+  out[threadIdx.x] = d + f[0] + f[1] + f[2] + f[3] + f[4] + f[5];
+}
+/** The same with independent MFMAs (issue-limited, 13.5 cycles alone). */
+template<int NV>
+__global__ void k_mfma_indep_plus_valu(double * out)
+{
+  double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+  double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double f[6] = {1.0, 1.1, 1.2, 1.3, 1.4, 1.5};
+  for(int i = 0; i < kIters; i++)
+  {
+#pragma unroll
+    for(int r = 0; r < 8; r++)
+    {
+      c[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c[r], 0, 0, 0);
+#pragma unroll
+      for(int v = 0; v < NV; v++)
+      {
+        f[v % 6] = fma(f[v % 6], 0.999, 0.001);
+      }
+    }
+  }
+  out[threadIdx.x] = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] + f[0] + f[1] + f[2] + f[3] + f[4] + f[5];
+}
 template<class K>
 double timeIt(K kernel, double * out)
 {
@@ -126,5 +170,17 @@ int main()
   std::printf("2 x v_mov_b32_dpp quad_perm + dependent v_fma_f64: %.2f ns = %.1f cycles per group\n", dp, dp / ns_per_cycle);
   const double bp = timeIt(k_bperm_dep, out);
   std::printf("2 x ds_bpermute_b32 + dependent v_fma_f64: %.2f ns = %.1f cycles per group\n", bp, bp / ns_per_cycle);
+  std::printf("MFMA of a dependent chain + NV independent v_fma_f64 per MFMA (cycles per element):");
+  std::printf(" NV=0 %.1f", timeIt(k_mfma_dep_plus_valu<0>, out) / ns_per_cycle);
+  std::printf(" NV=2 %.1f", timeIt(k_mfma_dep_plus_valu<2>, out) / ns_per_cycle);
+  std::printf(" NV=4 %.1f", timeIt(k_mfma_dep_plus_valu<4>, out) / ns_per_cycle);
+  std::printf(" NV=6 %.1f", timeIt(k_mfma_dep_plus_valu<6>, out) / ns_per_cycle);
+  std::printf(" NV=8 %.1f\n", timeIt(k_mfma_dep_plus_valu<8>, out) / ns_per_cycle);
+  std::printf("independent MFMAs + NV independent v_fma_f64 per MFMA (cycles per element):");
+  std::printf(" NV=0 %.1f", timeIt(k_mfma_indep_plus_valu<0>, out) / ns_per_cycle);
+  std::printf(" NV=1 %.1f", timeIt(k_mfma_indep_plus_valu<1>, out) / ns_per_cycle);
+  std::printf(" NV=2 %.1f", timeIt(k_mfma_indep_plus_valu<2>, out) / ns_per_cycle);
+  std::printf(" NV=3 %.1f", timeIt(k_mfma_indep_plus_valu<3>, out) / ns_per_cycle);
+  std::printf(" NV=4 %.1f\n", timeIt(k_mfma_indep_plus_valu<4>, out) / ns_per_cycle);
   return 0;
 }

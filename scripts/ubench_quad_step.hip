@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void step_lab(double * out, long long * cyc, i
   const bool need = lam >= 0; // runtime-true
 
   // ---- variant 0 / 3
+  double * gain_u = gains + (blk * 16) * kGainRec + (row == 0 ? gKfb + col : ((row == 1 && col == 0) ? gK : gDummy));
   auto step0 = [&](int ts, const Operands & o, int ts_next, Operands & o_next)
   {
     if(FEAT & 1)
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void step_lab(double * out, long long * cyc, i
     const double Qxr = quadBroadcast<1>(S);
     const double Quu_F = Quu + lam;
     const bool step_ok = !(Quu_F <= 0);
-    const double inv = step_ok ? recipFast(Quu_F) : 0.0;
+    const double inv = (VARIANT == 16 || step_ok) ? recipFast(Quu_F) : 0.0;
     const double k = -1 * (Qu * inv);
     const double Kc = -1 * (QA * inv);
     const double Kr = -1 * (Qr * inv);
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void step_lab(double * out, long long * cyc, i
     ok = ok && step_ok;
     if(VARIANT != 3 && (FEAT & 2))
     {
-      if(live)
+      if(VARIANT == 16 || live)
       {
         dV0_l += k * Qu;
         dV1_l += 0.5 * (k * (Quu * k));
@@ -149,11 +150,15 @@ __global__ __launch_bounds__(256) void step_lab(double * out, long long * cyc, i
     const double VnT = fma(QA, Kr, fma(Kc, Qr, fma(KQc, Kr, QxxT)));
     Vxx = 0.5 * (Vn + VnT);
     VxM = pick(c1, fma(Qr, k, fma(Kr, Qu, fma(KQr, k, Qxr))));
-    if(VARIANT != 3 && (FEAT & 4))
+    if(VARIANT == 16)
+    {
+      gain_u[ts * kGainRec] = r0 ? Kc : k;
+    }
+    else if(VARIANT != 3 && (FEAT & 4))
     {
       gain_q[ts * kGainRec] = r0 ? Kc : (c0 ? k : (live ? 1.0 : 0.0));
     }
-    if(VARIANT != 3 && (FEAT & 8))
+    if(VARIANT != 3 && VARIANT != 16 && (FEAT & 8))
     {
       krn = fmax(krn, fabs(k) * o.uinv);
     }
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256) void step_lab(double * out, long long * cyc, i
   asm volatile("" : "+v"(qFx), "+v"(qLxx), "+v"(qLxxT), "+v"(qFu), "+v"(qLxu), "+v"(qLx), "+v"(qLxuRow), "+v"(qLuu), "+v"(qLu), "+v"(qUinv));
   auto loadOperandsB = [&](int ts, OperandsB & o)
   {
-    if constexpr(VARIANT >= 8 && VARIANT != 12 && VARIANT != 13 && VARIANT != 14)
+    if constexpr(VARIANT >= 8 && VARIANT != 12 && VARIANT != 13 && VARIANT != 14 && VARIANT != 15)
     {
       // one ds_read_b64 each (a ds_read2_b64 costs three): every operand has its own opaque base offset
       const double * R = chunk + ts * kRecQ;
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(256) void step_lab(double * out, long long * cyc, i
   int n_live = 0;
   struct DeferredB
   {
-    double Fx, FuB, LxB, Lu, uinv, ninv, Kr, KQr, Qr, Quu;
+    double Fx, FuB, LxB, Lu, uinv, ninv, Kr, KQr, Qr, Quu, Kc;
     int ts;
   };
   DeferredB dB;
@@ -310,6 +315,11 @@ __global__ __launch_bounds__(256) void step_lab(double * out, long long * cyc, i
     dV0_l += k * Qu;
     dV1_l += 0.5 * (k * (d.Quu * k));
     VxB = fma(d.Qr, k, fma(d.Kr, Qu, fma(d.KQr, k, Qxr)));
+    if constexpr(VARIANT == 15)
+    {
+      gain_u[d.ts * kGainRec] = r0 ? d.Kc : k;
+      return;
+    }
     if constexpr(VARIANT >= 8)
     {
       hk[d.ts] = k;
@@ -352,7 +362,10 @@ __global__ __launch_bounds__(256) void step_lab(double * out, long long * cyc, i
     const double Vn = fma(Qr, Kc, fma(Kr, QA, fma(KQr, Kc, Qxx)));
     const double VnT = fma(QA, Kr, fma(Kc, Qr, fma(KQc, Kr, QxxT)));
     Vxx = 0.5 * (Vn + VnT);
-    if constexpr(VARIANT >= 8)
+    if constexpr(VARIANT == 15)
+    {
+    }
+    else if constexpr(VARIANT >= 8)
     {
       hK[ts] = Kc;
     }
@@ -370,6 +383,7 @@ __global__ __launch_bounds__(256) void step_lab(double * out, long long * cyc, i
     dB.KQr = KQr;
     dB.Qr = Qr;
     dB.Quu = Quu;
+    dB.Kc = Kc;
     dB.ts = ts;
     have_df = true;
     if(VARIANT != 5 && VARIANT != 10)
@@ -458,6 +472,9 @@ __global__ __launch_bounds__(256) void step_lab(double * out, long long * cyc, i
           }
         }
       }
+      else if constexpr(VARIANT == 15)
+      {
+      }
       else if constexpr(VARIANT == 9 || VARIANT == 13)
       {
 #pragma unroll
@@ -486,7 +503,7 @@ __global__ __launch_bounds__(256) void step_lab(double * out, long long * cyc, i
 #pragma unroll
     for(int ts = kChunkSteps - 1; ts >= 0; ts--)
     {
-      if constexpr(VARIANT == 0 || VARIANT == 3)
+      if constexpr(VARIANT == 0 || VARIANT == 3 || VARIANT == 16)
       {
         step0(ts, o2[ts & 1], ts > 0 ? ts - 1 : 0, o2[(ts & 1) ^ 1]);
       }
@@ -537,6 +554,10 @@ void run(const char * name, int waves, int blocks = 1)
 
 int main()
 {
+  run<16>("16: the kernel after round 2 (0 unguarded, krn in the flush)", 4, 1);
+  run<15>("15: broadcast-free, one select + LDS store per step, unguarded", 4, 1);
+  run<16>("16: the kernel after round 2 (0 unguarded, krn in the flush)", 1, 1);
+  run<15>("15: broadcast-free, one select + LDS store per step, unguarded", 1, 1);
   for(int blocks : {1, 64, 256})
   {
     run<0>("0: the kernel's order", 4, blocks);

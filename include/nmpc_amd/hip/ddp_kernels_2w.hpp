@@ -35,8 +35,13 @@ namespace hip
 /** \tparam kForwardRecordsOnly the LDS records carry only the forward hand-off (x', u'): for solvers that replace the
     backward pass of this class (ddp_kernels_quad.hpp)
     \tparam kAlphaGroups lane groups of the master / helper wave that hold the SAME instances (ddp_kernels_quad.hpp: 4
-    groups of 16): the line search then tries kAlphaGroups step sizes per forward pass, one per group */
-template<class Problem, bool kConstrained, bool kForwardRecordsOnly = false, int kAlphaGroups = 1>
+    groups of 16): the line search then tries kAlphaGroups step sizes per forward pass, one per group
+    \tparam kLdsNominal the forward master takes the nominal (x, u, k, K) of a timestep from LDS records that a THIRD wave
+    of the workgroup (forwardPrefetch) keeps two groups of timesteps ahead of it, instead of loading it itself: a lone
+    wave pays ~20 cycles per global_load whatever its width (scripts/ubench_issue_cost.hip) and the master issues
+    N + 2 m + m N of them per timestep (a fifth of its time on the cart-pole); from LDS the same data is
+    (N + 2 m + m N) / 2 ds_read_b128.  For workgroups of 16 instances (ddp_kernels_quad.hpp). */
+template<class Problem, bool kConstrained, bool kForwardRecordsOnly = false, int kAlphaGroups = 1, bool kLdsNominal = false>
 struct PairSolver : InstanceSolver<Problem, kConstrained>
 {
   using Base = InstanceSolver<Problem, kConstrained>;
@@ -88,8 +93,15 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   static constexpr int kFwdGroup = 4;
   static constexpr int kFwdSlots = 2 * kFwdGroup + 1;
   static constexpr int kRecArea = (2 * kRec > kFwdSlots * kFwdRec) ? 2 * kRec : kFwdSlots * kFwdRec;
+  //! nominal records (kLdsNominal): [slot = group of kFwdGroup timesteps % 3][timestep of the group][instance][x, u, k, K]
+  static constexpr bool kLdsNominalPath = kLdsNominal;
+  static constexpr int kNomRec = (N + 2 * MM + MM * N + 1) / 2 * 2; // even: records are read as 16-byte pairs
+  static constexpr int kNomSlots = 3;
+  static constexpr int kNomInst = 16;
+  static constexpr int kNomDoubles = kLdsNominal ? kNomSlots * kFwdGroup * kNomInst * kNomRec : 0;
+  static constexpr int kNomBase = (kRecArea + 2 + NMPC_HIP_NTRACE) * static_cast<int>(LW);
   //! + per-lane mailboxes (flags, J_cand) + the last trace row of every lane (kept in LDS until the solve ends)
-  static constexpr int kLdsDoubles = (kRecArea + 2 + NMPC_HIP_NTRACE) * static_cast<int>(LW);
+  static constexpr int kLdsDoubles = kNomBase + kNomDoubles;
   static constexpr size_t kLdsBytes = static_cast<size_t>(kLdsDoubles) * sizeof(double);
   static constexpr bool kFits = kLdsBytes <= 64 * 1024;
 
@@ -117,6 +129,10 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   NMPC_D double & frec(int slot, int idx) const
   {
     return lds[(static_cast<size_t>(slot) * kFwdRec + idx) * LW + waveLane()];
+  }
+  NMPC_D double * nomRec(int slot, int r, unsigned inst) const
+  {
+    return lds + kNomBase + ((static_cast<size_t>(slot) * kFwdGroup + r) * kNomInst + inst) * kNomRec;
   }
   NMPC_D double & mailFlags() const
   {
@@ -942,6 +958,13 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     const unsigned cx = Base::offX(cs), cu = Base::offU(cs), cc = Base::offC(cs);
     double J = 0;
     const int n_full = T / kFwdGroup;
+    if constexpr(kLdsNominal)
+    {
+      if(!initial)
+      {
+        wgBarrier(); // barrier S of forwardMasterLds / forwardPrefetch
+      }
+    }
     for(int g = 0; g < n_full; g++)
     {
       wgBarrier(); // barrier g: the master wrote the records of timesteps 4 g .. 4 g + 3
@@ -1156,8 +1179,203 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     J_cur = mailCost();
   }
 
+  // ---- kLdsNominal: the nominal comes through LDS --------------------------------------------------------------------
+  NMPC_D void readNominalLds(int slot, int r, Nominal & n) const
+  {
+    typedef double Pair2 __attribute__((ext_vector_type(2)));
+    const Pair2 * rec = reinterpret_cast<const Pair2 *>(nomRec(slot, r, waveLane() % kNomInst));
+    double v[kNomRec];
+#pragma unroll
+    for(int p = 0; p < kNomRec / 2; p++)
+    {
+      const Pair2 w = rec[p];
+      v[2 * p] = w[0];
+      v[2 * p + 1] = w[1];
+    }
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      n.x[j] = v[j];
+    }
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      n.u[a] = v[N + a];
+      n.k[a] = v[N + MM + a];
+    }
+#pragma unroll kU
+    for(int e = 0; e < MM * N; e++)
+    {
+      n.K[e] = v[N + 2 * MM + e];
+    }
+  }
+  /** forwardStep on a nominal that is already in registers (no request of its own). */
+  NMPC_D void forwardStepLds(int i, double alpha, const Nominal & nom, StateDimVector & xc) const
+  {
+    const int slot = i % (2 * kFwdGroup);
+    const double t = current_t + i * problem.dt();
+    const int m = Base::inputDimAt(t);
+    InputDimVector uc;
+    uc.resize(m);
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      if(a < m)
+      {
+        double s = 0;
+#pragma unroll kU
+        for(int c = 0; c < N; c++)
+        {
+          s += nom.K[a + c * MM] * (xc[c] - nom.x[c]);
+        }
+        uc[a] = (nom.u[a] + alpha * nom.k[a]) + s;
+      }
+      else
+      {
+        uc[a] = 0;
+      }
+    }
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      frec(slot, oXc + j) = xc[j];
+    }
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      frec(slot, oUc + a) = uc[a];
+    }
+    xc = problem.stateEq(t, xc, uc);
+  }
+  /** The wave that keeps the nominal records ahead of the master (wave 2 of the quad kernel): lane = (timestep of the
+      group, instance), so one request fetches an entry of the record for the four timesteps of a group at once —
+      kNomRec requests per group instead of the master's 4 kNomRec.  Group g + 2 is written while the master works on
+      group g (its slot was read during group g - 1) and published by the barrier that ends group g; the requests for
+      group g + 3 then have a whole group of timesteps to arrive. */
+  NMPC_D void forwardPrefetch(int sel_h) const
+  {
+    typedef double Pair2 __attribute__((ext_vector_type(2)));
+    const unsigned inst = waveLane() % kNomInst;
+    const int q = static_cast<int>(waveLane() / kNomInst); // timestep within the group
+    const unsigned ox = Base::offX(sel_h), ou = Base::offU(sel_h), ob = Base::offB();
+    auto loadGroup = [&](int g, double (&v)[kNomRec])
+    {
+      const int ii = g * kFwdGroup + q;
+      const int i = ii < T ? ii : T - 1; // (beyond the horizon: re-reads the last timestep, never used)
+#pragma unroll kU
+      for(int j = 0; j < N; j++)
+      {
+        v[j] = Base::ld(Base::xRow(i) + j * LW, ox);
+      }
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        v[N + a] = Base::ld(Base::uRow(i) + a * LW, ou);
+        v[N + MM + a] = Base::ld(Base::kRow(i) + a * LW, ob);
+      }
+#pragma unroll kU
+      for(int e = 0; e < MM * N; e++)
+      {
+        v[N + 2 * MM + e] = Base::ld(Base::KRow(i) + e * LW, ob);
+      }
+      if constexpr(kNomRec > N + 2 * MM + MM * N)
+      {
+        v[kNomRec - 1] = 0;
+      }
+    };
+    auto writeGroup = [&](int slot, const double (&v)[kNomRec])
+    {
+      Pair2 * rec = reinterpret_cast<Pair2 *>(nomRec(slot, q, inst));
+#pragma unroll
+      for(int p = 0; p < kNomRec / 2; p++)
+      {
+        Pair2 w;
+        w[0] = v[2 * p];
+        w[1] = v[2 * p + 1];
+        rec[p] = w;
+      }
+    };
+    double v0[kNomRec], v1[kNomRec], v2[kNomRec];
+    loadGroup(0, v0);
+    loadGroup(1, v1);
+    loadGroup(2, v2);
+    writeGroup(0, v0);
+    writeGroup(1, v1);
+    wgBarrier(); // barrier S: groups 0 and 1 are in LDS
+    const int n_full = T / kFwdGroup;
+    int slot2 = 2; // slot of group g + 2
+    for(int g = 0; g < n_full; g++)
+    {
+      writeGroup(slot2, v2);
+      loadGroup(g + 3, v2);
+      wgBarrier(); // barrier of this group of kFwdGroup timesteps
+      slot2 = (slot2 == kNomSlots - 1) ? 0 : slot2 + 1;
+    }
+    wgBarrier(); // barrier E
+    wgBarrier(); // barrier F
+  }
+  NMPC_D void forwardMasterLds(double alpha)
+  {
+    static_assert(kFwdGroup == 4, "forwardMasterLds is written for groups of four timesteps");
+    wgBarrier(); // barrier S: the records of groups 0 and 1 are in LDS
+    Nominal na, nb;
+    int slot = 0; // slot of the group the master works on
+    readNominalLds(slot, 0, na);
+    StateDimVector xc;
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      xc[j] = na.x[j]; // x'_0 = x_0
+    }
+    const int n_full = T / kFwdGroup;
+    for(int g = 0; g < n_full; g++)
+    {
+      const int slot1 = (slot == kNomSlots - 1) ? 0 : slot + 1;
+      // a record is requested one timestep before its use; the first record of the next group was published by the
+      // barrier before last
+      readNominalLds(slot, 1, nb);
+      forwardStepLds(g * kFwdGroup, alpha, na, xc);
+      readNominalLds(slot, 2, na);
+      forwardStepLds(g * kFwdGroup + 1, alpha, nb, xc);
+      readNominalLds(slot, 3, nb);
+      forwardStepLds(g * kFwdGroup + 2, alpha, na, xc);
+      readNominalLds(slot1, 0, na);
+      forwardStepLds(g * kFwdGroup + 3, alpha, nb, xc);
+      wgBarrier(); // barrier of this group of kFwdGroup timesteps
+      slot = slot1;
+    }
+    const int i = n_full * kFwdGroup;
+    if(i < T)
+    {
+      readNominalLds(slot, 1, nb);
+      forwardStepLds(i, alpha, na, xc);
+    }
+    if(i + 1 < T)
+    {
+      readNominalLds(slot, 2, na);
+      forwardStepLds(i + 1, alpha, nb, xc);
+    }
+    if(i + 2 < T)
+    {
+      forwardStepLds(i + 2, alpha, na, xc);
+    }
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      frec(2 * kFwdGroup, oXc + j) = xc[j];
+    }
+    wgBarrier(); // barrier E
+    wgBarrier(); // barrier F
+    J_cand = mailCost();
+  }
+
   NMPC_D void forwardMaster(double alpha)
   {
+    if constexpr(kLdsNominal)
+    {
+      forwardMasterLds(alpha);
+      return;
+    }
     // kFwdAhead register sets form a ring: set r holds timestep i with i % kFwdAhead == r, the loop is unrolled by
     // kFwdAhead so that every set keeps its registers (no copies) and the compiler can count the requests in flight
     Nominal n0, n1, n2, n3;

@@ -39,6 +39,11 @@ enum Kind
   kGlobalLoad,
   kGlobalLoadX4,
   kGlobalStore,
+  kDsWrite16,
+  kDsWriteMirror,
+  kGlobalLoad16,
+  kGlobalLoadMirror,
+  kDsRead16,
   kFmaDep,
   kCndDep,
   kDppDep,
@@ -235,6 +240,46 @@ __global__ void issue_k(double * out, long long * cyc, double seed, double * gbu
                         : "memory");)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    else if constexpr(KIND == kDsWrite16 || KIND == kDsWriteMirror)
+    {
+      // the forward master: 16 instances in lanes 0..15, lanes 16..63 mirror them (same addresses, same values) or are off
+      const unsigned ad = wave_base + (threadIdx.x % 16) * 8;
+      if(KIND == kDsWriteMirror || threadIdx.x % 64 < 16)
+      {
+        REP4(asm volatile("ds_write_b64 %8, %0\n ds_write_b64 %8, %1 offset:512\n ds_write_b64 %8, %2 offset:1024\n ds_write_b64 %8, %3 offset:1536\n"
+                          "ds_write_b64 %8, %4 offset:2048\n ds_write_b64 %8, %5 offset:2560\n ds_write_b64 %8, %6 offset:3072\n ds_write_b64 %8, %7 offset:3584\n"
+                          :
+                          : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(ad)
+                          : "memory");)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    else if constexpr(KIND == kDsRead16)
+    {
+      const unsigned ad = wave_base + (threadIdx.x % 16) * 8;
+      if(threadIdx.x % 64 < 16)
+      {
+        REP4(asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %8 offset:512\n ds_read_b64 %2, %8 offset:1024\n ds_read_b64 %3, %8 offset:1536\n"
+                          "ds_read_b64 %4, %8 offset:2048\n ds_read_b64 %5, %8 offset:2560\n ds_read_b64 %6, %8 offset:3072\n ds_read_b64 %7, %8 offset:3584\n"
+                          : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7])
+                          : "v"(ad)
+                          : "memory");)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    else if constexpr(KIND == kGlobalLoad16 || KIND == kGlobalLoadMirror)
+    {
+      double * gp = gbuf + (threadIdx.x / 64) * 4096 + (threadIdx.x % 16);
+      if(KIND == kGlobalLoadMirror || threadIdx.x % 64 < 16)
+      {
+        REP4(asm volatile("global_load_dwordx2 %0, %8, off\n global_load_dwordx2 %1, %8, off offset:512\n global_load_dwordx2 %2, %8, off offset:1024\n global_load_dwordx2 %3, %8, off offset:1536\n"
+                          "global_load_dwordx2 %4, %8, off offset:2048\n global_load_dwordx2 %5, %8, off offset:2560\n global_load_dwordx2 %6, %8, off offset:3072\n global_load_dwordx2 %7, %8, off offset:3584\n"
+                          : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7])
+                          : "v"(gp)
+                          : "memory");)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
     else if constexpr(KIND == kDsWriteSame)
     {
       REP4(asm volatile("ds_write_b64 %8, %0\n ds_write_b64 %8, %1 offset:512\n ds_write_b64 %8, %2 offset:1024\n ds_write_b64 %8, %3 offset:1536\n"
@@ -392,6 +437,11 @@ int main()
   run<kGlobalLoad>("global_load_dwordx2, coalesced, L2 hit (+ one vmcnt(0) per 32)", 0);
   run<kGlobalLoadX4>("global_load_dwordx4, coalesced, L2 hit", 0);
   run<kGlobalStore>("global_store_dwordx2, coalesced", 0);
+  run<kDsWriteMirror>("ds_write_b64, lanes 16..63 mirror lanes 0..15 (same address, same value)", 0);
+  run<kDsWrite16>("ds_write_b64, lanes 0..15 only (exec mask)", 0);
+  run<kDsRead16>("ds_read_b64, lanes 0..15 only", 0);
+  run<kGlobalLoadMirror>("global_load_dwordx2, lanes 16..63 mirror lanes 0..15", 0);
+  run<kGlobalLoad16>("global_load_dwordx2, lanes 0..15 only", 0);
   std::printf("--- two waves of one workgroup (the forward pass: master + helper)\n");
   run<kDsWrite>("ds_write_b64", 0, 2);
   run<kDsWrite2st64>("ds_write2st64_b64", 0, 2);

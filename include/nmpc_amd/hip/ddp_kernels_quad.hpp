@@ -41,9 +41,9 @@ constexpr int kQuadWaves = 4;
     nominal bench —, the fan-out is 2 - 3 x faster per iteration where instances backtrack: long solves that iterate into the
     rounding-noise regime (SURVEY.md 8(d)'s M1 / M2 modes).  launchSolve picks by Configuration::line_search_fan_out. */
 template<class Problem, bool kConstrained, bool kFanOut = kConstrained>
-struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFanOut) ? 4 : 1, !(kConstrained || kFanOut)>
+struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFanOut) ? 4 : 1, true>
 {
-  using Pair = PairSolver<Problem, kConstrained, true, (kConstrained || kFanOut) ? 4 : 1, !(kConstrained || kFanOut)>;
+  using Pair = PairSolver<Problem, kConstrained, true, (kConstrained || kFanOut) ? 4 : 1, true>;
   using Base = typename Pair::Base;
   using Base::b;
   using Base::buf;
@@ -599,14 +599,15 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
           Pair::forwardHelper(sel_h, cmd == Pair::kCmdRollout);
         }
       }
-      else if(Pair::kLdsNominalPath && cmd == Pair::kCmdForward && wave == 2)
+      else if(Pair::kLdsNominalPath && (cmd == Pair::kCmdForward || cmd == Pair::kCmdForwardFanOut) && wave == 2)
       {
         Pair::forwardPrefetch(sel_h);
       }
       else
       {
         // one barrier per group of timesteps, then E and F (+ barrier S where wave 2 feeds the master from LDS)
-        const int n_bar = T / Pair::kFwdGroup + 2 + ((Pair::kLdsNominalPath && cmd == Pair::kCmdForward) ? 1 : 0);
+        const int n_bar = T / Pair::kFwdGroup + 2
+                          + ((Pair::kLdsNominalPath && (cmd == Pair::kCmdForward || cmd == Pair::kCmdForwardFanOut)) ? 1 : 0);
         for(int i = 0; i < n_bar; i++)
         {
           Pair::wgBarrier();

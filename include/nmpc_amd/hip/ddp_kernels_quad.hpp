@@ -159,7 +159,20 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     }
     p.u = pu[static_cast<size_t>(i) * LW];
   }
+  /** One record entry.  kFull = false: entries the compiler knows to be constants (the literal zeros and ones of the
+      model's Jacobians and Hessians, the padding beyond n) are not written again — the record already holds them from
+      the pass's first (full) chunk.  An LDS store costs a lone wave 14 cycles, 25 when the four waves of the workgroup
+      write (scripts/ubench_issue_cost.hip): the 49 stores of a record were most of the linearisation's time. */
+  template<bool kFull>
+  NMPC_D static void put(double * at, double v)
+  {
+    if(kFull || !__builtin_constant_p(v))
+    {
+      *at = v;
+    }
+  }
   /** \return 1 / (|u_i| + 1), the weight of |k_i| in the running max of DDPSolver.hpp:217-221 */
+  template<bool kFull>
   NMPC_D double lineariseStep(int i, double t0_l, const PointQ & p, double * rec) const
   {
     const double t = t0_l + i * lin_problem.dt();
@@ -189,17 +202,17 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
 #pragma unroll
       for(int c = 0; c < 4; c++)
       {
-        rec[oFx + 4 * r + c] = (r < N && c < N) ? Fx(r < N ? r : 0, c < N ? c : 0) : 0.0;
-        rec[oLxx + 4 * r + c] = (r < N && c < N) ? Lxx(r < N ? r : 0, c < N ? c : 0) : 0.0;
+        put<kFull>(rec + oFx + 4 * r + c, (r < N && c < N) ? Fx(r < N ? r : 0, c < N ? c : 0) : 0.0);
+        put<kFull>(rec + oLxx + 4 * r + c, (r < N && c < N) ? Lxx(r < N ? r : 0, c < N ? c : 0) : 0.0);
       }
-      rec[oFu + r] = (r < N) ? Fu(r < N ? r : 0, 0) : 0.0;
-      rec[oLxu + r] = (r < N) ? Lxu(r < N ? r : 0, 0) : 0.0;
-      rec[oLx + r] = (r < N) ? Lx[r < N ? r : 0] : 0.0;
+      put<kFull>(rec + oFu + r, (r < N) ? Fu(r < N ? r : 0, 0) : 0.0);
+      put<kFull>(rec + oLxu + r, (r < N) ? Lxu(r < N ? r : 0, 0) : 0.0);
+      put<kFull>(rec + oLx + r, (r < N) ? Lx[r < N ? r : 0] : 0.0);
     }
-    rec[oLuu] = Luu(0, 0);
-    rec[oLu] = Lu[0];
+    put<kFull>(rec + oLuu, Luu(0, 0));
+    put<kFull>(rec + oLu, Lu[0]);
     rec[oU] = u[0];
-    rec[oZero] = 0.0;
+    put<kFull>(rec + oZero, 0.0);
     return recipFast(fabs(u[0]) + 1.0);
   }
 
@@ -430,7 +443,8 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
           const unsigned long long tl = __builtin_readcyclecounter();
 #endif
           const int i = (i0 + ts_l < T) ? i0 + ts_l : T - 1;
-          uinv_now = lineariseStep(i, t0_l, pt, rec_l);
+          // (the terminal blocks above were parked in the records of the lanes with ts_l = 0: the first chunk rewrites all)
+          uinv_now = (ch == n_chunks - 1) ? lineariseStep<true>(i, t0_l, pt, rec_l) : lineariseStep<false>(i, t0_l, pt, rec_l);
 #ifdef NMPC_AMD_PROFILE_2W
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           Pair::prof_wait += __builtin_readcyclecounter() - tl; // reported as "barrier wait": the linearisation share

@@ -1555,6 +1555,54 @@ __global__ __launch_bounds__(256) void batch_major_to_tile_kernel(const TIn * __
   }
 }
 
+/** The three input conversions of a solve in ONE launch (a kernel boundary on a stream costs a few microseconds, and a
+    solve of the headline batch takes ~470): current_t [B] -> [Bp] (nullptr: zeros), current_x [B][N] -> tile-major,
+    initial_u_list [B][RU] -> half 0 of the two tile-major input halves.  grid = (ceil(RU / 64) + ceil(N / 64) + 1, Bp / 64). */
+template<class TIn, class TOut = TIn>
+__global__ __launch_bounds__(256) void ingest_kernel(const TIn * __restrict__ t0_in,
+                                                      TOut * __restrict__ t0_out,
+                                                      const TIn * __restrict__ x_in,
+                                                      TOut * __restrict__ x_out,
+                                                      int N,
+                                                      const TIn * __restrict__ u_in,
+                                                      TOut * __restrict__ u_out,
+                                                      int RU,
+                                                      int B)
+{
+  __shared__ TOut blk[64][65];
+  const int nu = (RU + 63) / 64, nx = (N + 63) / 64;
+  const int tile = blockIdx.y;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 64 x 4
+  if(static_cast<int>(blockIdx.x) == nu + nx)
+  {
+    if(ty == 0)
+    {
+      const int bb = tile * 64 + tx;
+      t0_out[bb] = (t0_in && bb < B) ? static_cast<TOut>(t0_in[bb]) : TOut(0);
+    }
+    return;
+  }
+  const bool is_u = static_cast<int>(blockIdx.x) < nu;
+  const TIn * in = is_u ? u_in : x_in;
+  const int R = is_u ? RU : N, halves = is_u ? 2 : 1;
+  const int r0 = (is_u ? blockIdx.x : blockIdx.x - nu) * 64;
+  for(int k = ty; k < 64; k += 4)
+  {
+    const int bb = tile * 64 + k, r = r0 + tx;
+    blk[k][tx] = (bb < B && r < R) ? static_cast<TOut>(in[static_cast<size_t>(bb) * R + r]) : TOut(0);
+  }
+  __syncthreads();
+  TOut * o = (is_u ? u_out : x_out) + static_cast<size_t>(tile) * halves * R * 64;
+  for(int k = ty; k < 64; k += 4)
+  {
+    const int r = r0 + k;
+    if(r < R)
+    {
+      o[static_cast<size_t>(r) * 64 + tx] = blk[tx][k];
+    }
+  }
+}
+
 /** in [tile][halves][R][64], half selected per instance by sel (sel == nullptr: half 0) -> out [B][R].
     row_limit != nullptr: rows >= (row_limit[b] + 1) * row_unit of instance b are written as 0 — the trace of a reused
     handle keeps rows of earlier solves beyond iters[b]; traceDataList() ends at the last iteration (DDPSolver.h:294). */

@@ -463,22 +463,20 @@ int launchRecorded(nmpc_hip_ddp_solver * s,
   NMPC_HIP_TRY(hipEventRecord(s->ev_begin[slot], st));
   if(ingest)
   {
-    // reference layouts -> instance-minor device layout
-    if(d_t0 && s->elem == 8)
+    // reference layouts -> instance-minor device layout, one launch
+    const int RU = s->T * s->MM;
+    const dim3 grid((RU + 63) / 64 + (s->N + 63) / 64 + 1, s->Bp / 64);
+    if(s->elem == 4)
     {
-      NMPC_HIP_TRY(hipMemcpyAsync(s->d_t0, d_t0, sizeof(double) * s->B, hipMemcpyDeviceToDevice, st));
-    }
-    else if(d_t0)
-    {
-      // [B] doubles -> [Bp] floats: the tile-major layout of a one-row array is the array itself
-      NMPC_HIP_TRY(scalarToTile(s, d_t0, s->d_t0, 1, 1, 0, st));
+      hipLaunchKernelGGL((nmpc_amd::hip::ingest_kernel<double, float>), grid, dim3(256), 0, st, d_t0, reinterpret_cast<float *>(s->d_t0),
+                         d_x0, reinterpret_cast<float *>(s->d_x0), s->N, d_u_init, reinterpret_cast<float *>(s->d_U), RU, s->B);
     }
     else
     {
-      NMPC_HIP_TRY(hipMemsetAsync(s->d_t0, 0, static_cast<size_t>(s->elem) * s->Bp, st));
+      hipLaunchKernelGGL((nmpc_amd::hip::ingest_kernel<double, double>), grid, dim3(256), 0, st, d_t0, s->d_t0, d_x0, s->d_x0, s->N,
+                         d_u_init, s->d_U, RU, s->B);
     }
-    NMPC_HIP_TRY(scalarToTile(s, d_x0, s->d_x0, s->N, 1, 0, st));
-    NMPC_HIP_TRY(scalarToTile(s, d_u_init, s->d_U, s->T * s->MM, 2, 0, st));
+    NMPC_HIP_TRY(hipGetLastError());
   }
   NMPC_HIP_TRY(hipEventRecord(s->ev_kernel[slot], st));
   const DeviceBuffers buf = makeBuffers(s);

@@ -18,6 +18,11 @@ TOL_COST = 1e-10
 INT_COLS = (0, 9, 10, 11)
 
 
+def _capi_trace_col(trace_rows, name):
+    from nmpc_amd import _capi
+    return trace_rows[:, _capi.TRACE_COLUMNS.index(name)]
+
+
 def make_solver(wl, **cfg):
     import nmpc_amd
 
@@ -261,6 +266,81 @@ def test_failure_status_matches():
     s2 = make_solver(wl2, max_iter=2)
     assert not s2.solve(wl2.t0, wl2.x0, wl2.u_init).any()
     assert (s2.status() == 0).all() and (s2.iters() == 2).all()
+
+
+@pytest.mark.parametrize("running_u, T", [(-0.001, 96), (-0.01, 96), (-0.05, 100), (-0.05, 64)])
+def test_quad_kernel_pivot_failures_inside_full_chunks(running_u, T, monkeypatch):
+    """The quad kernel runs full 16-timestep chunks of the recursion unguarded and repeats a chunk in which a pivot failed
+    with the guarded loop (ddp_kernels_quad.hpp).  A slightly negative input weight makes Quu_F non-positive until lambda
+    has grown: backward passes fail — at the first timestep of a chunk or in its middle, for some instances of a wave and
+    not for others — and are retried several times per iteration (DDPSolver.hpp:196-204); T = 96 / 64 have no ragged chunk,
+    so every failure happens inside the unguarded code.  Compared with the oracle: lambda schedule and retry counts (trace),
+    gains of the last pass, dV, trajectories.  (Three iterations: the problem is not convex, later iterations are
+    decision-unstable in the oracle itself.)"""
+    import nmpc_amd
+    from nmpc_amd import workloads
+
+    monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", "quad")
+    wl = workloads.cartpole_batch(B=80, T=T, seed=11)
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.DDPProblemCartPole(running_u=[running_u]), wl.B)
+    c = s.config()
+    c.print_level = 0
+    c.horizon_steps = wl.T
+    c.max_iter = 3
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert s.kernelName() == "ddp_solve_quad_kernel"
+    ocfg = oracle.default_config(horizon_steps=wl.T, max_iter=3)
+    params = oracle.default_params("cartpole", running_u=running_u)
+    ref = oracle.solve_batch("cartpole", ocfg, wl.x0, wl.u_init, params=params, n_threads=8, want_alpha_hist=True)
+    n_bw = _capi_trace_col(ref.trace_last, "n_backward")
+    keep = np.ones(wl.B, bool)
+    rng = np.random.default_rng(3)
+    for eps in (1e-15, 1e-14, 1e-13, 1e-12):
+        r = oracle.solve_batch("cartpole", ocfg, wl.x0 * (1 + eps * rng.uniform(-1, 1, wl.x0.shape)), wl.u_init, params=params,
+                               n_threads=8, want_alpha_hist=True)
+        keep &= (r.iters == ref.iters) & (r.status == ref.status) & (r.alpha_idx_hist == ref.alpha_idx_hist).all(axis=1)
+        keep &= (r.trace_last[:, INT_COLS] == ref.trace_last[:, INT_COLS]).all(axis=1)
+    print(f"[running_u {running_u}, T {T}] decision-stable: {int(keep.sum())} / {wl.B}; backward passes in the last iteration: "
+          f"{dict(zip(*np.unique(n_bw.astype(int), return_counts=True)))}")
+    assert n_bw.max() >= 2, "the workload no longer makes backward passes fail"
+    assert keep.mean() >= 0.8
+    check_against_oracle(wl, s, ref, mask=keep)
+    np.testing.assert_array_equal(s.traceLast()[keep][:, INT_COLS], ref.trace_last[keep][:, INT_COLS])
+    dv_g = s.dV()
+    for b in np.flatnonzero(keep)[::9]:
+        r1 = oracle.solve("cartpole", ocfg, wl.x0[b], wl.u_init[b], params=params)
+        assert np.abs(dv_g[b] - r1.dV).max() <= 1e-8 * max(1.0, np.abs(r1.dV).max())
+
+
+def test_quad_kernel_pivot_failures_of_some_instances_of_a_wave(monkeypatch):
+    """The same with per-instance problem objects whose input weights differ in sign and size: within one wavefront (four
+    instances share a matrix-core instruction) some instances fail a pivot — at different timesteps — while their
+    neighbours do not; the chunk is then repeated guarded for all four, and the instances that were fine must come out as if
+    nothing had happened.  Per instance against the oracle (status, iterations, retry counts, trajectories)."""
+    import nmpc_amd
+    from nmpc_amd import workloads, _capi
+
+    monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", "quad")
+    wl = workloads.cartpole_batch(B=64, T=96, seed=12)
+    weights = [(-0.05, -0.01, 0.01, 0.003, -0.001, 0.02, -0.02, 0.005)[b % 8] for b in range(wl.B)]
+    probs = [nmpc_amd.DDPProblemCartPole(running_u=[w]) for w in weights]
+    s = make_solver(wl, max_iter=3)
+    s.setProblemBatch(probs)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert s.kernelName() == "ddp_solve_quad_kernel"
+    ocfg = oracle.default_config(horizon_steps=wl.T, max_iter=3)
+    X, U, st, it, tl = s.X(), s.U(), s.status(), s.iters(), s.traceLast()
+    nb_col = _capi.TRACE_COLUMNS.index("n_backward")
+    retried, clean = 0, 0
+    for b in range(wl.B):
+        r = oracle.solve(wl.model, ocfg, wl.x0[b], wl.u_init[b], params=oracle.default_params("cartpole", running_u=weights[b]))
+        assert st[b] == r.status and it[b] == r.iters
+        np.testing.assert_array_equal(tl[b, list(INT_COLS)], r.trace[-1, list(INT_COLS)])
+        assert scaled_err(X[b], r.X) <= TOL and scaled_err(U[b], r.U) <= TOL
+        retried += int(r.trace[-1, nb_col] > 1)
+        clean += int(r.trace[-1, nb_col] == 1)
+    print(f"instances whose last iteration retried the backward pass: {retried}, that did not: {clean}")
+    assert retried >= 16 and clean >= 16
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ print(f"master: backward total {bt:.0f} cyc, linearise {bw:.0f} ({bw / max(bt, 1
 qi = s.qpFreeMask()
 n_sec, n_bw, n_fw = int(qi[0, 9]), int(qi[0, 10]), int(qi[0, 11])
 print(f"        {n_bw} backward passes ({bt / max(n_bw, 1):.0f} cyc each), {n_fw} forward passes ({ft / max(n_fw, 1):.0f} each), "
-      f"{n_sec} stamped sections ({bw / max(n_sec, 1):.0f} cyc each; NMPC_AMD_PROFILE_WHAT picks the section)")
+      f"{n_sec} stamped sections ({bw / max(n_sec, 1):.0f} cyc each: the linearisation of one chunk)")
 for w in range(0, 4):
     hw = int(s.qpFreeMask()[0, 4 + w])
     print(f"   wave {w}: HW_ID wave slot {hw & 15}, SIMD {(hw >> 4) & 3}, CU {(hw >> 8) & 15}, SE {(hw >> 13) & 7}")

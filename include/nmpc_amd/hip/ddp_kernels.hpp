@@ -534,6 +534,106 @@ struct InstanceSolver
     return xg + 0.5 * xHx;
   }
 
+  /** The same algorithm for ONE input (MM = 1, m = 1), statement for statement, on scalars: the general code below keeps
+      its iterates in the arrays of QPOut and indexes them through free_idx, which for one input is private-memory traffic
+      and ~700 instructions per timestep where a few dozen do.  Every comparison, return code and rounding of the general
+      code is kept (the factor of a 1 x 1 block is the pivot, its solve one product with the reciprocal).  Box-constrained
+      cart-pole solve on the quad kernel: backward pass 277 k -> 251 k cycles (scripts/profile_quad_box.py); what remains is
+      the algorithm's own: two to three projected-Newton iterations per timestep with an IEEE division per Armijo trial,
+      the trials themselves (40 k cycles per pass) and trip counts that differ between the four instances of a wave. */
+  NMPC_D void boxQP1(double H, double g, double lower, double upper, double initial_x, QPOut & out) const
+  {
+    auto clampToBox = [&](double v) { return fmax(fmin(v, upper), lower); };
+    auto objective = [&](double v)
+    {
+      const double xg = v * g;
+      const double hx = H * v;
+      const double xHx = v * hx;
+      return xg + 0.5 * xHx;
+    };
+    double x = clampToBox(initial_x); // BoxQP.h:148
+    double obj = objective(x);
+    double old_obj = obj;
+    int retval = 0, n_free = 0;
+    double inv_d = 0;
+    for(int iter = 1;; iter++)
+    {
+      // relative improvement    BoxQP.h:176-181
+      if(iter > 1 && (old_obj - obj) < cfg.qp_rel_improve_thre * fabs(old_obj))
+      {
+        retval = 4;
+        break;
+      }
+      old_obj = obj;
+      const double grad = g + H * x; // BoxQP.h:184
+      // clamped / free sets (exact == compare)    BoxQP.h:187-213
+      const bool clamped = (x == lower && grad > 0) || (x == upper && grad < 0);
+      n_free = clamped ? 0 : 1;
+      if(clamped)
+      {
+        retval = 6;
+        break;
+      }
+      // factorise the free block iff the clamped set changed    BoxQP.h:216-241   (a clamped input ends the iteration above,
+      // so the set is {free} from the first iteration on)
+      if(iter == 1)
+      {
+        if(H <= 0)
+        {
+          retval = -1;
+          break;
+        }
+        inv_d = recipFast(H);
+      }
+      // free gradient norm    BoxQP.h:244-253
+      const double grad_norm = grad * grad;
+      if(grad_norm < cfg.qp_grad_thre * cfg.qp_grad_thre)
+      {
+        retval = 5;
+        break;
+      }
+      // Newton direction    BoxQP.h:256-279
+      const double rhs = g * inv_d;
+      const double search_dir = -1 * rhs - x;
+      // descent check    BoxQP.h:282-291
+      const double sdg = search_dir * grad;
+      if(sdg > 1e-10)
+      {
+        retval = -2;
+        break;
+      }
+      // Armijo line search with projection    BoxQP.h:294-309
+      double step = 1;
+      double x_cand = clampToBox(x + step * search_dir);
+      double obj_cand = objective(x_cand);
+      while((obj_cand - old_obj) / (step * sdg) < cfg.qp_armijo_param)
+      {
+        step = step * cfg.qp_step_factor;
+        x_cand = clampToBox(x + step * search_dir);
+        obj_cand = objective(x_cand);
+        if(step < cfg.qp_min_step)
+        {
+          retval = 2; // leaves only the inner loop (BoxQP.h:304-308)
+          break;
+        }
+      }
+      // accept    BoxQP.h:328-329
+      x = x_cand;
+      obj = obj_cand;
+      if(iter == cfg.qp_max_iter)
+      {
+        retval = 1; // BoxQP.h:332-336
+        break;
+      }
+    }
+    out.x[0] = x;
+    out.fac[0] = H;
+    out.inv_d[0] = inv_d;
+    out.free_idx[0] = 0;
+    out.n_free = n_free;
+    out.retval = retval;
+  }
+
   NMPC_D void boxQP(int m,
                     const double * H,
                     const double * g,
@@ -542,6 +642,14 @@ struct InstanceSolver
                     const double * initial_x,
                     QPOut & out) const
   {
+    if constexpr(MM == 1)
+    {
+      if(m == 1)
+      {
+        boxQP1(H[0], g[0], lower[0], upper[0], initial_x[0], out);
+        return;
+      }
+    }
     double * x = out.x;
 #pragma unroll kU
     for(int i = 0; i < MM; i++)

@@ -151,6 +151,12 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     return lds[(static_cast<size_t>(kRecArea) + 2 + field) * LW + waveLane()];
   }
   static constexpr unsigned kGroupLanes = kLanesPerBlock / kAlphaGroups;
+#ifndef NMPC_FANOUT_FIRST_PASS
+#  define NMPC_FANOUT_FIRST_PASS 1
+#endif
+  //! step sizes tried by the FIRST forward pass of a line search (solveMasterFanOut): all lane groups at once, or 1
+  //! (A/B builds: the groups mirror the first trial and fan out only after it failed)
+  static constexpr int kFanOutFirstPass = NMPC_FANOUT_FIRST_PASS ? kAlphaGroups : 1;
   //! lane group of this lane (0 when there are none); only group 0 writes trajectories to HBM
   NMPC_D static unsigned laneGroup()
   {
@@ -1813,9 +1819,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       double alpha = 0, cost_update_actual = 0, cost_update_expected = 0, cost_update_ratio = 0;
       int ai_used = 0;
       const int last_ai = cfg.n_alpha - 1;
-      // The first trial (the one the nominal regime accepts) is rolled out by every group alike; only when it fails do
-      // the groups fan out over the next kAlphaGroups step sizes per pass.
-      for(int ai0 = 0, n_par = 1; ai0 < cfg.n_alpha; ai0 += n_par, n_par = kAlphaGroups)
+      // The groups fan out from the first pass on: group 0 rolls out (and stores) the first step size — the one the
+      // nominal regime accepts, at the cost of a mirrored pass — while the other groups already try the next ones.
+      for(int ai0 = 0, n_par = kFanOutFirstPass; ai0 < cfg.n_alpha; ai0 += n_par, n_par = kAlphaGroups)
       {
         if(!__any(need_fw))
         {

@@ -954,14 +954,108 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       candidate trajectory (the helper issues ONLY stores during this pass, the master ONLY loads: a wave with both
       kinds in flight has to drain them all at every wait), returns the candidate total cost through
       LDS. */
-  /** \tparam kFanOut the lane groups roll out DIFFERENT step sizes (line search after a failed first trial): only group
-      0 writes its trajectory; otherwise the groups are mirrors and all of them write (the same values) */
+  /** Where the helper's lanes store the rollout of a fan-out pass: group 0 into the candidate half of X / U / cost, group
+      g > 0 into slot g - 1 of the handle's fan-out scratch [tile][kAlphaGroups - 1][rows of X, U, cost][64] (buf.wpi_ws:
+      shapes of the lane-group kernels have no other use for it), from where adoptFanOut() copies the trajectory of an
+      accepted step size into the candidate half.  Without the scratch (allocation failed) only group 0 stores and an
+      accepted step size of another group is rolled out once more. */
+  struct FanDest
+  {
+    char * x;
+    char * u;
+    char * c;
+    bool on;
+  };
+  NMPC_D bool fanScratch() const
+  {
+    return kAlphaGroups > 1 && buf.wpi_ws != nullptr;
+  }
+  NMPC_D size_t fanRows() const
+  {
+    return Base::rowsX() + Base::rowsU() + static_cast<size_t>(T + 1);
+  }
+  //! rows of X, U, cost of scratch slot g - 1 (g >= 1) for this lane's instance
+  NMPC_D FanDest fanSlot(unsigned g) const
+  {
+    FanDest d;
+    char * f = reinterpret_cast<char *>(Base::tileBase(buf.wpi_ws, fanRows(), kAlphaGroups - 1))
+               + (static_cast<size_t>(g - 1) * fanRows() * LW + Base::lane) * sizeof(double);
+    d.x = f;
+    d.u = f + Base::rowsX() * LW * sizeof(double);
+    d.c = d.u + Base::rowsU() * LW * sizeof(double);
+    d.on = true;
+    return d;
+  }
+  NMPC_D FanDest fanDest(unsigned cx, unsigned cu, unsigned cc) const
+  {
+    const unsigned g = laneGroup();
+    if(g > 0 && fanScratch())
+    {
+      return fanSlot(g);
+    }
+    FanDest d;
+    d.x = reinterpret_cast<char *>(Base::Xt) + cx;
+    d.u = reinterpret_cast<char *>(Base::Ut) + cu;
+    d.c = reinterpret_cast<char *>(Base::Ct) + cc;
+    d.on = (g == 0);
+    return d;
+  }
+  NMPC_D static void stAt(char * base, size_t row, double v)
+  {
+    *reinterpret_cast<double *>(base + row * (LW * sizeof(double))) = v;
+  }
+  NMPC_D static double ldAt(const char * base, size_t row)
+  {
+    return *reinterpret_cast<const double *>(base + row * (LW * sizeof(double)));
+  }
+  /** Every wave of the workgroup, after a fan-out pass in which instances accepted the step size of a group g > 0 (the
+      master left g in the instance's cost mailbox, 0 otherwise): the trajectory of slot g - 1 of the scratch becomes the
+      candidate (rows are shared out over the workgroup's threads: thread = (instance, part)).  The pass boundaries on
+      either side are full barriers (post()): the helper's stores have landed, these land before the next pass reads. */
+  NMPC_D void adoptFanOut(int sel_lane) const
+  {
+    const unsigned inst = waveLane() % kGroupLanes;
+    const unsigned part = threadIdx.x / kGroupLanes, parts = blockDim.x / kGroupLanes;
+    const int g = static_cast<int>(mailCostAt(inst));
+    if(g > 0)
+    {
+      const FanDest src = fanSlot(static_cast<unsigned>(g));
+      const int cs = 1 - sel_lane;
+      char * dx = reinterpret_cast<char *>(Base::Xt) + Base::offX(cs);
+      char * du = reinterpret_cast<char *>(Base::Ut) + Base::offU(cs);
+      char * dc = reinterpret_cast<char *>(Base::Ct) + Base::offC(cs);
+      const size_t nx = Base::rowsX(), nu = Base::rowsU(), nc = static_cast<size_t>(T + 1);
+#pragma unroll 4
+      for(size_t r = part; r < nx; r += parts)
+      {
+        stAt(dx, r, ldAt(src.x, r));
+      }
+#pragma unroll 4
+      for(size_t r = part; r < nu; r += parts)
+      {
+        stAt(du, r, ldAt(src.u, r));
+      }
+#pragma unroll 4
+      for(size_t r = part; r < nc; r += parts)
+      {
+        stAt(dc, r, ldAt(src.c, r));
+      }
+    }
+  }
+  /** \tparam kFanOut the lane groups roll out DIFFERENT step sizes (line search after a failed first trial): group 0
+      writes its trajectory into the candidate half, the others into the fan-out scratch (fanDest()); otherwise the groups
+      are mirrors and all of them write (the same values) */
   template<bool kFanOut = false>
   NMPC_D void forwardHelper(int sel_h, bool initial = false) const
   {
     // forward pass: the candidate half; initial rollout (rolloutMaster): the trajectory half itself
     const int cs = initial ? sel_h : 1 - sel_h;
     const unsigned cx = Base::offX(cs), cu = Base::offU(cs), cc = Base::offC(cs);
+    FanDest fd = {nullptr, nullptr, nullptr, false};
+    if constexpr(kFanOut)
+    {
+      fd = fanDest(cx, cu, cc);
+    }
     double J = 0;
     const int n_full = T / kFwdGroup;
     if constexpr(kLdsNominal)
@@ -982,7 +1076,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
         {
           Base::elem(buf.input_dim, T, i) = Base::inputDimAt(current_t + i * problem.dt());
         }
-        J += consumeStep<kFanOut>(i, cx, cu, cc);
+        J += consumeStep<kFanOut>(i, cx, cu, cc, fd);
       }
     }
     wgBarrier(); // barrier E: the remaining timesteps and x'_T (slot 2 * kFwdGroup) are available
@@ -992,7 +1086,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       {
         Base::elem(buf.input_dim, T, i) = Base::inputDimAt(current_t + i * problem.dt());
       }
-      J += consumeStep<kFanOut>(i, cx, cu, cc);
+      J += consumeStep<kFanOut>(i, cx, cu, cc, fd);
     }
     {
       StateDimVector xT;
@@ -1002,7 +1096,19 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
         xT[j] = frec(2 * kFwdGroup, oXc + j);
       }
       const double cT = problem.terminalCost(current_t + T * problem.dt(), xT);
-      if(!kFanOut || laneGroup() == 0)
+      if constexpr(kFanOut)
+      {
+        if(fd.on)
+        {
+#pragma unroll kU
+          for(int j = 0; j < N; j++)
+          {
+            stAt(fd.x, static_cast<size_t>(T) * N + j, xT[j]);
+          }
+          stAt(fd.c, static_cast<size_t>(T), cT);
+        }
+      }
+      else
       {
         Base::storeX(Base::xRow(T), cx, xT);
         Base::st(Base::costRow(T), cc, cT);
@@ -1015,7 +1121,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 
   /** Helper: cost + stores of step i from the "out" record the master wrote. */
   template<bool kFanOut>
-  NMPC_D double consumeStep(int i, unsigned cx, unsigned cu, unsigned cc) const
+  NMPC_D double consumeStep(int i, unsigned cx, unsigned cu, unsigned cc, const FanDest & fd) const
   {
     const int slot = i % (2 * kFwdGroup);
     const double t = current_t + i * problem.dt();
@@ -1034,7 +1140,24 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       u[a] = frec(slot, oUc + a);
     }
     const double c = problem.runningCost(t, x, u);
-    if(!kFanOut || laneGroup() == 0)
+    if constexpr(kFanOut)
+    {
+      if(fd.on)
+      {
+#pragma unroll kU
+        for(int j = 0; j < N; j++)
+        {
+          stAt(fd.x, static_cast<size_t>(i) * N + j, x[j]);
+        }
+#pragma unroll kU
+        for(int a = 0; a < MM; a++)
+        {
+          stAt(fd.u, static_cast<size_t>(i) * MM + a, (a < m) ? u[a] : 0.0);
+        }
+        stAt(fd.c, static_cast<size_t>(i), c);
+      }
+    }
+    else
     {
       Base::storeX(Base::xRow(i), cx, x);
       Base::storeU(Base::uRow(i), cu, u, m);
@@ -1436,7 +1559,8 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     kCmdBackward = 1,
     kCmdForward = 2,
     kCmdRollout = 3,
-    kCmdForwardFanOut = 4 //!< forward pass in which every lane group rolls out its own step size
+    kCmdForwardFanOut = 4, //!< forward pass in which every lane group rolls out its own step size
+    kCmdAdoptFanOut = 5 //!< adoptFanOut(): lane-group kernels only (ddp_kernels_quad.hpp)
   };
 
   NMPC_D void post(int cmd) const
@@ -1812,8 +1936,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 
       // ---- Step 3: backtracking line search    :234-274.  Every forward pass tries kAlphaGroups consecutive step sizes,
       // one per lane group (the trials of the reference's loop are independent: same nominal, same gains); the
-      // instance takes the FIRST one that passes, as the sequential loop does.  Only group 0's rollout is written to
-      // HBM, so a step size accepted from another group is rolled out once more, then by every group.
+      // instance takes the FIRST one that passes, as the sequential loop does.  Group 0's rollout goes to the candidate
+      // half, the others' to the fan-out scratch, from where an accepted one is adopted (without the scratch: rolled out
+      // once more, then by every group).
       const bool searched = need_fw;
       bool forward_pass_success = false;
       double alpha = 0, cost_update_actual = 0, cost_update_expected = 0, cost_update_ratio = 0;
@@ -1887,11 +2012,23 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
         {
           if(__any(need_fw && g_acc > 0))
           {
-            // (instances that accepted group 0's step size re-create the same candidate, the others do not care)
-            post(kCmdForward);
-            profBegin();
-            forwardMaster((need_fw && g_acc > 0) ? alpha : cfg.alpha_list[ai0]);
-            profEnd(1);
+            if(fanScratch())
+            {
+              // the accepted rollout waits in the fan-out scratch: the whole workgroup copies it into the candidate half
+              mailCost() = (need_fw && g_acc > 0) ? static_cast<double>(g_acc) : 0.0;
+              post(kCmdAdoptFanOut);
+              profBegin();
+              adoptFanOut(sel);
+              profEnd(1);
+            }
+            else
+            {
+              // (instances that accepted group 0's step size re-create the same candidate, the others do not care)
+              post(kCmdForward);
+              profBegin();
+              forwardMaster((need_fw && g_acc > 0) ? alpha : cfg.alpha_list[ai0]);
+              profEnd(1);
+            }
           }
         }
         if(need_fw && g_acc >= 0)

@@ -34,12 +34,13 @@ constexpr int kQuadInstances = 16; //!< instances per workgroup of the quad kern
 constexpr int kQuadWaves = 4;
 
 /** \tparam kFanOut step-size-parallel line search: the four lane groups of 16 — mirrors of one another otherwise — try four
-    step sizes of alpha_list per forward pass once the first trial has failed (at most 1 + 3 + 3 passes instead of 11).
-    Box-constrained solves backtrack often (cart-pole with a +-15 N box: ~3 forward passes per iteration) and always use it.
-    Unconstrained solves have both instantiations: the sequential search is 1.5 % faster where the first step size is accepted
-    anyway (the extra code shifts the register allocation of the hot loops) — short solves, the MPC callers' max_iter = 3, the
-    nominal bench —, the fan-out is 2 - 3 x faster per iteration where instances backtrack: long solves that iterate into the
-    rounding-noise regime (SURVEY.md 8(d)'s M1 / M2 modes).  launchSolve picks by Configuration::line_search_fan_out. */
+    step sizes of alpha_list per forward pass, from the first pass on (at most 3 passes instead of 11).  Group 0 stores its
+    rollout into the candidate half, groups 1 - 3 into the handle's fan-out scratch, and the rollout of the accepted step
+    size is copied from there by the whole workgroup (PairSolver::adoptFanOut: ~2 k cycles instead of another pass).
+    Box-constrained solves backtrack often (cart-pole with a +-15 N box: ~3 trials per iteration) and always use it.
+    Unconstrained solves have both instantiations; Configuration::line_search_fan_out = 0 picks this one (nominal bench:
+    +4 %, the few instances whose first step size fails no longer cost their workgroup a pass each; M1: 2.4 x), 2 the
+    sequential search (A/B, bit-identical results: tests/test_gpu_parity.py). */
 template<class Problem, bool kConstrained, bool kFanOut = kConstrained>
 struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFanOut) ? 4 : 1, true>
 {
@@ -601,6 +602,10 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       if(cmd == Pair::kCmdBackward)
       {
         backwardQuad();
+      }
+      else if(cmd == Pair::kCmdAdoptFanOut)
+      {
+        Pair::adoptFanOut(sel_h);
       }
       else if(wave == 1)
       {

@@ -55,6 +55,17 @@ struct ModelOpsFor
     {
       return WaveSolver<Problem>::workspaceDoubles(T);
     }
+    else if constexpr(QuadSolver<Problem, false>::kShape)
+    {
+      // fan-out scratch of the quad kernel's line search (PairSolver::FanDest): three more candidate trajectories.
+      // NMPC_HIP_DDP_FAN_SCRATCH=0: none (A/B measurements, tests of the path taken when the allocation fails)
+      const char * off = std::getenv("NMPC_HIP_DDP_FAN_SCRATCH");
+      if(off && std::strcmp(off, "0") == 0)
+      {
+        return 0;
+      }
+      return 3 * (static_cast<size_t>(T + 1) * (Problem::kStateDim + 1) + static_cast<size_t>(T) * Problem::kInputDimMax);
+    }
     else
     {
       return 0;
@@ -65,8 +76,16 @@ struct ModelOpsFor
       whose 64-instance workgroups keep the latency flat up to 16384 instances.  NMPC_HIP_DDP_KERNEL=quad / 2w force. */
   static constexpr bool kQuadShape = QuadSolver<Problem, false>::kShape;
   static constexpr int kQuadMaxBatch = 4096;
-  //! Configuration::line_search_fan_out = 0 (automatic): solves with max_iter above this use the step-size-parallel search
-  static constexpr int kQuadFanOutAutoMaxIter = 16;
+  //! Configuration::line_search_fan_out = 0 (automatic): solves with max_iter above this use the step-size-parallel search.
+  //! -1 = always: since the lane groups fan out from the first pass on and an accepted rollout is adopted from the fan-out
+  //! scratch (PairSolver::adoptFanOut), the parallel search is the faster one in the nominal regime too.
+  //! NMPC_HIP_DDP_FAN_AUTO=<max_iter> overrides (A/B measurements).
+  static constexpr int kQuadFanOutAutoMaxIter = -1;
+  static int fanOutAutoMaxIter()
+  {
+    const char * e = std::getenv("NMPC_HIP_DDP_FAN_AUTO");
+    return e ? std::atoi(e) : kQuadFanOutAutoMaxIter;
+  }
   static bool useQuad(int batch_padded, bool own)
   {
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
@@ -163,7 +182,7 @@ struct ModelOpsFor
           requested[dev] = true;
         }
         // step-size-parallel line search for unconstrained solves: on request, or (0 = automatic) for long solves
-        const bool fan = cfg.line_search_fan_out == 1 || (cfg.line_search_fan_out == 0 && cfg.max_iter > kQuadFanOutAutoMaxIter);
+        const bool fan = cfg.line_search_fan_out == 1 || (cfg.line_search_fan_out == 0 && cfg.max_iter > fanOutAutoMaxIter());
         if(con && own)
         {
           hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, true, true>), g, blk, quad_lds, stream, problem, cfg, buf);

@@ -79,8 +79,8 @@ extern "C"
     /* Line-search schedule of the kernels that can try several step sizes of alpha_list per forward pass (the quad kernel:
        cart-pole / bipedal up to 4096 instances).  Results are identical either way (the trials of DDPSolver.hpp:234-274 are
        independent and the first accepted one in list order is taken); only the time per iteration differs.
-       0: automatic (sequential search for max_iter <= 16, where the first step size is normally accepted; parallel beyond),
-       1: always parallel, 2: always sequential.  Box-constrained solves are always parallel. */
+       0: automatic (parallel: the lane groups try the first four step sizes in the first pass, and the rollout of whichever
+       is accepted is kept), 1: always parallel, 2: always sequential.  Box-constrained solves are always parallel. */
     int line_search_fan_out;
   } nmpc_hip_ddp_config;
 

@@ -717,7 +717,7 @@ extern "C"
       // wave-per-instance kernel (9 <= n <= 16): materialised derivatives, gains and one candidate trajectory per
       // step size, per instance.  No memset: the kernel writes everything it reads.
       if(hipMalloc(reinterpret_cast<void **>(&s->d_wpi_ws),
-                   m->wpi_workspace_doubles(s->T) * static_cast<size_t>(s->B) * static_cast<size_t>(s->elem))
+                   m->wpi_workspace_doubles(s->T) * static_cast<size_t>(s->Bp) * static_cast<size_t>(s->elem))
          != hipSuccess)
       {
         (void)hipGetLastError();

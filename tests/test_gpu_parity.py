@@ -619,17 +619,26 @@ def test_unconstrained_fan_out_equals_sequential_line_search(monkeypatch):
     wl = workloads.cartpole_batch(B=512, T=100, seed=3)
     for cfg in (dict(max_iter=500), dict(max_iter=50, k_rel_norm_thre=0.0, cost_update_thre=-1e300)):
         out = []
-        for fan in (2, 1):
+        # (fan-out, fan-out scratch): sequential; parallel with the accepted rollout adopted from the scratch
+        # (PairSolver::adoptFanOut); parallel without the scratch (what a failed allocation leaves: the accepted step size
+        # of another lane group is rolled out once more)
+        for fan, scratch in ((2, None), (1, None), (1, "0")):
+            if scratch is None:
+                monkeypatch.delenv("NMPC_HIP_DDP_FAN_SCRATCH", raising=False)
+            else:
+                monkeypatch.setenv("NMPC_HIP_DDP_FAN_SCRATCH", scratch)  # read when the handle is created
             s = make_solver(wl, line_search_fan_out=fan, **cfg)
+            monkeypatch.delenv("NMPC_HIP_DDP_FAN_SCRATCH", raising=False)
             s.solve(wl.t0, wl.x0, wl.u_init)
             assert s.kernelName() == "ddp_solve_quad_kernel"
             out.append((s.X(), s.U(), s.cost(), s.kff(), s.Kfb(), s.trace(), s.status(), s.iters(), s.dV()))
-        for a, b in zip(*out):
-            np.testing.assert_array_equal(a, b)
+        for other in out[1:]:
+            for a, b in zip(out[0], other):
+                np.testing.assert_array_equal(a, b)
         if "k_rel_norm_thre" in cfg:  # M1 keeps iterating on converged trajectories: searches end at every index of the list
             idx = out[0][5][:, 1:, 9].astype(int)
             assert (idx > 0).sum() > 1000 and (idx == 10).sum() > 100, "the workload never backtracks: the fan-out was not exercised"
-    # and the automatic choice follows max_iter
+    # and the automatic choice (the parallel search) against the oracle
     ref = oracle_batch(wl, max_iter=30)
     s = make_solver(wl, max_iter=30)
     s.solve(wl.t0, wl.x0, wl.u_init)

@@ -43,3 +43,5 @@ done
 python scripts/fanout_ab.py > $OUT/fanout_ab.txt 2>&1
 python scripts/batch_scaling.py > $OUT/batch_scaling.txt 2>&1
 ls $OUT | head -80
+python scripts/constrained_ab.py > $OUT/constrained_ab.txt 2>&1
+python scripts/mpc_throughput.py > $OUT/mpc_throughput.txt 2>&1

@@ -61,7 +61,9 @@ struct DeviceBuffersT
   unsigned * qp_free; //!< [tile][T][64]
   int * input_dim; //!< [tile][T][64]
   S * wpi_ws; //!< per-instance workspace [B][ModelOps::wpi_workspace_doubles(T)] elements of S: wave-per-instance kernel
-             //!< (ddp_kernels_wpi.hpp: derivatives, gains, candidates), fp32 tile kernel (ddp_kernels_tile32.hpp: gains)
+             //!< (ddp_kernels_wpi.hpp: derivatives, gains, candidates), fp32 tile kernel (ddp_kernels_tile32.hpp: gains);
+             //!< quad-kernel shapes (n <= 4, one input): the line search's fan-out scratch [tile][3][rows of X, U, cost][64]
+             //!< (PairSolver::FanDest in ddp_kernels_2w.hpp); nullptr: none (the kernels that can do without check)
   //! [Bp][4] shader-clock ticks of the last solve as seen by the wave that drives instance b: backward passes (with the
   //! linearisation fused into them), forward passes (rollouts of the line search), whole solve, reserved; or nullptr.
   //! The split of computationDuration() (DDPSolver.h:219-247) is taken from these shares of the kernel's HIP-event time.

@@ -100,7 +100,7 @@ struct nmpc_hip_ddp_solver
   int * d_qp_ret = nullptr;
   unsigned * d_qp_free = nullptr;
   int * d_input_dim = nullptr;
-  double * d_wpi_ws = nullptr; // wave-per-instance kernel workspace (large models only)
+  double * d_wpi_ws = nullptr; // per-instance workspace: wave-per-instance / fp32 tile kernels, fan-out scratch of the quad kernel
   unsigned char * d_params_batch = nullptr; // [Bp][param_bytes] per-instance problem objects, or nullptr
   double * d_lim_batch = nullptr; // [Bp][2][kMaxInputDim] per-instance input limits, or nullptr
   unsigned long long * d_phase_ticks = nullptr; // [Bp][4] per-instance phase ticks of the last solve
@@ -715,7 +715,8 @@ extern "C"
     if(m->wpi_workspace_doubles(s->T) > 0)
     {
       // wave-per-instance kernel (9 <= n <= 16): materialised derivatives, gains and one candidate trajectory per
-      // step size, per instance.  No memset: the kernel writes everything it reads.
+      // step size, per instance; quad-kernel shapes: three candidate trajectories per instance, tile-major (the line
+      // search's fan-out scratch).  No memset: the kernels write everything they read.
       if(hipMalloc(reinterpret_cast<void **>(&s->d_wpi_ws),
                    m->wpi_workspace_doubles(s->T) * static_cast<size_t>(s->Bp) * static_cast<size_t>(s->elem))
          != hipSuccess)

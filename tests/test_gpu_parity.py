@@ -268,13 +268,14 @@ def test_failure_status_matches():
     assert (s2.status() == 0).all() and (s2.iters() == 2).all()
 
 
-@pytest.mark.parametrize("running_u, T", [(-0.001, 96), (-0.01, 96), (-0.05, 100), (-0.05, 64)])
+@pytest.mark.parametrize("running_u, T", [(-0.001, 96), (-0.01, 96), (-0.05, 100), (-0.05, 64), (-0.001, 100), (-0.01, 68), (-0.05, 36)])
 def test_quad_kernel_pivot_failures_inside_full_chunks(running_u, T, monkeypatch):
     """The quad kernel runs full 16-timestep chunks of the recursion unguarded and repeats a chunk in which a pivot failed
     with the guarded loop (ddp_kernels_quad.hpp).  A slightly negative input weight makes Quu_F non-positive until lambda
     has grown: backward passes fail — at the first timestep of a chunk or in its middle, for some instances of a wave and
     not for others — and are retried several times per iteration (DDPSolver.hpp:196-204); T = 96 / 64 have no ragged chunk,
-    so every failure happens inside the unguarded code.  Compared with the oracle: lambda schedule and retry counts (trace),
+    so every failure happens inside the unguarded code; T = 100 / 68 / 36 end in a ragged chunk of four timesteps (the one
+    with the terminal step), which runs unguarded as well and is repeated the same way.  Compared with the oracle: lambda schedule and retry counts (trace),
     gains of the last pass, dV, trajectories.  (Three iterations: the problem is not convex, later iterations are
     decision-unstable in the oracle itself.)"""
     import nmpc_amd

@@ -1,0 +1,1718 @@
+// gfx950 device code of the batched DDP solver, fp64, LANE MAPPING "TILE64": one workgroup of eight wavefronts solves a GROUP
+// of up to 32 problem instances whose blocks fill 16 x 16 matrix-core tiles (5 <= n <= 15, static 1 <= m <= 8: BASELINE.json's
+// manipulator n 14 m 7 — config 5 — and the quadrotor n 12 m 4 in the reference's arithmetic), derivatives never in HBM.
+//
+// What a lane means changes with the phase (reference: nmpc_ddp/include/nmpc_ddp/DDPSolver.hpp):
+//
+//   model code  — initial rollout (:83-95), the linearisation sweep (:157-185), the first step size of every line search
+//                 (:234-274): lane = INSTANCE on wave 0 ("model wave"); the later step sizes of alpha_list: lane =
+//                 (instance, step size) on the other waves, all at once (the trials are independent: same nominal, same gains).
+//   backward    — (:342-534) lane = MATRIX ENTRY on waves 1..7 ("matrix waves"), one instance at a time per wave, on
+//                 v_mfma_f64_16x16x4_f64; the instances of a group are dealt round-robin to the seven matrix waves.
+//
+// Derivative records.  The model wave linearises timestep i - 1 of every instance of the group into an LDS record while the
+// matrix waves consume the records of timestep i (two record slots per instance, one barrier per timestep).  A record holds
+// only the entries of Fx, Fu, Lxx, Lxu, Luu, Lx, Lu that are NOT structural zeros of the problem's functors: an entry the
+// compiler proves to be the constant 0 after inlining (__builtin_constant_p, the same mechanism as macc() in ddp_kernels.hpp)
+// is never stored, its position in the offset table points at the record's zero word.  The table is produced at kernel start by
+// the very code that writes the records (emitRecord with a different sink), so writer and readers cannot disagree.  For the
+// manipulator that is 204 instead of 752 doubles per record, which is what lets 32 instances share the 160 KB of a CU: a dense
+// fp64 record set would cap the group at 8 instances and leave 56 of the model wave's 64 lanes idle.
+// The group size follows from the table at run time: G = min(32, what the LDS holds, ceil(B / workgroups)); workgroups are
+// persistent (grid = number of CUs) and loop over groups, so there is no batch-size cliff.
+//
+// The backward step in "natural layout".  A 16 x 16 fp64 matrix X lives in four registers: register r of lane (q = lane / 16,
+// j = lane % 16) holds X[4 r + q][j] — the matrix core's C / D layout (measured: scripts/ubench_mfma_f64_16.hip).  The same four
+// registers passed as the A operands of four MFMAs, with another matrix's registers as B operands, contract over the row index
+// in ascending order: mma(X, Y) = X^T Y, an fma chain per entry, with no LDS round trip or cross-lane move between chained
+// products.  With VV = [Vxx | Vx] (n x (n + 1), one tile since n <= 15) and A = [K | k] (m x (n + 1)):
+//     Pa  = mma(VV, Fx)            rows < n: Vxx Fx = (Fx^T Vxx)^T,  row n: Vx^T Fx            :386-408 in the reference's
+//     Pb  = mma(VV, Fu)            rows < n: Vxx Fu,                 row n: Vx^T Fu            left-to-right association
+//     Qxx = Lxx + mma(Pa, Fx)      Qux = Lxu^T + mma(Pb, Fx)        Quu = Luu + mma(Pb, Fu)    Qx, Qu: L + row n of Pa, Pb
+//     Quu_F (= Quu + lambda I, or rebuilt from Vxx + lambda I: :421-441) and [Qux_reg | Qu] pass through the wave's LDS scratch:
+//     every lane factorises Quu_F (the lane kernels' ldltInPlace: same bits), lane (., j) solves column j            :500-517
+//     Z   = mma(Quu, A)            C1 = mma(Z, A)                   T2 = mma(A, [Qux | Qu])    T3 = mma(Qux, A)
+//     VV' = (([Qxx | Qx] + C1) + T2) + T3;   entry (n, n) of C1 is k^T Quu k, of T2 is k^T Qu: dV for free        :522-526
+//     Vxx <- (Vxx + Vxx^T) / 2 with the transpose taken through the wave's LDS scratch                              :527
+// 5 ceil(n/4) + 4 ceil(m/4) MFMAs per instance and timestep (manipulator 28, quadrotor 19) of 64 cycles each, and ~350 other
+// instructions, most of them the m x m factorisation.  fp64 MFMAs of two waves on one SIMD serialise, an fp64 VALU wave beside
+// a matrix wave still gets about a third of its issue slots (profiles/r03_ubench_mfma_f64_16.txt): two waves per SIMD.
+//
+// Gains go straight to the handle's tile-major kff / Kfb arrays (the rollouts read them lane = instance: coalesced), X / U /
+// cost live in the two halves of the handle's arrays with a per-instance `sel` flip on acceptance, exactly like the lane kernels.
+#pragma once
+
+#include <cstring>
+#include <new>
+#include <type_traits>
+
+#include <nmpc_amd/hip/ddp_kernels.hpp>
+
+namespace nmpc_amd
+{
+namespace hip
+{
+typedef double v4d64 __attribute__((ext_vector_type(4)));
+
+constexpr int kT64Waves = 8; //!< wavefronts per workgroup: two per SIMD, 256 registers each
+constexpr int kT64Threads = kT64Waves * 64;
+constexpr int kT64MatrixWaves = kT64Waves - 1;
+constexpr int kT64MaxGroup = 32; //!< instances per group at most (lanes 0..31 of the model wave)
+constexpr int kT64MaxPerWave = (kT64MaxGroup + kT64MatrixWaves - 1) / kT64MatrixWaves; //!< 5
+constexpr size_t kT64LdsBytes = 160 * 1024; //!< the whole LDS of a CU: one workgroup per CU
+
+template<class Problem, bool kConstrained = false, bool kOwnProblem = false>
+struct TileSolver64
+{
+  static_assert(std::is_same<typename Problem::Scalar, double>::value, "the fp64 tile kernel computes in double");
+  static constexpr int N = Problem::kStateDim;
+  static constexpr int M = Problem::kInputDimMax;
+  static constexpr int MM = M;
+  static_assert(!Problem::kDynamicInput, "static input dimension only");
+  static_assert(N >= 1 && N <= 15, "[Vxx | Vx] is one 16-column tile");
+  static_assert(M >= 1 && M <= 8, "the m x m factorisation runs in registers");
+  static constexpr bool kShape = true;
+  static constexpr int KN = (N + 3) / 4; //!< k-slices of a contraction over state rows
+  static constexpr int KM = (MM + 3) / 4; //!< ... over input rows; also the registers of an m-row tile that hold anything
+  static constexpr int rN = N / 4, qN = N % 4; //!< row n of a natural-layout tile: register rN of lane group qN
+  static constexpr int kStarLane = 16 * qN + N; //!< the lane whose register rN is entry (n, n)
+  using Lane = InstanceSolver<Problem, kConstrained>; //!< the lane kernels' scalar helpers (ldltInPlace, boxQP): same bits
+
+  using StateDimVector = typename Problem::StateDimVector;
+  using InputDimVector = typename Problem::InputDimVector;
+  using StateStateDimMatrix = typename Problem::StateStateDimMatrix;
+  using InputInputDimMatrix = typename Problem::InputInputDimMatrix;
+  using StateInputDimMatrix = typename Problem::StateInputDimMatrix;
+
+  // ---- record entries in canonical order (the order emitRecord() visits them)
+  static constexpr int idFx = 0; //!< Fx(r, c) at idFx + c N + r
+  static constexpr int idFu = idFx + N * N; //!< Fu(r, a) at idFu + a N + r
+  static constexpr int idLxx = idFu + N * MM;
+  static constexpr int idLxuT = idLxx + N * N; //!< Lxu(c, a) = Lxu^T[a][c] at idLxuT + c M + a
+  static constexpr int idLuu = idLxuT + N * MM; //!< Luu(a, c) at idLuu + c M + a
+  static constexpr int idLx = idLuu + MM * MM;
+  static constexpr int idLu = idLx + N;
+  static constexpr int idInvU = idLu + MM; //!< 1 / (|u_i| + 1)    :217-221
+  static constexpr int idU = idInvU + 1; //!< u_i (box-constrained solves: the QP's bounds are limits - u_i, :470-472)
+  static constexpr int kNumIds = idU + (kConstrained ? MM : 0);
+
+  // ---- LDS layout, in doubles.  Fixed part first, the record area takes the rest.
+  static constexpr int kTblAt = 0; //!< unsigned short tbl[kNumIds]: entry -> offset in a record (0 = the zero word)
+  static constexpr int kMetaAt = kTblAt + (kNumIds + 3) / 4; //!< ints: 0 record stride, 1 group size, 2.. flags
+  enum MetaField
+  {
+    mStride = 0,
+    mGroup,
+    mAnyIter,
+    mAnyRetry,
+    mAnyLs,
+    mAnyMore, //!< a slot's first step size was rejected: the later ones are tried
+    mAnyReroll, //!< a later step size was taken: its trajectory has to be stored
+    kNumMeta = 8
+  };
+  static constexpr int kSlotAt = kMetaAt + kNumMeta / 2;
+  enum SlotField
+  {
+    // what the roles tell each other, and the per-instance solver state of the model wave between its phases (nothing of it
+    // is live in registers across a sweep or a rollout)
+    sB = 0, //!< int: instance index, -1 = empty slot
+    sBw, //!< int: this sweep computes gains for the slot
+    sLs, //!< int: the slot takes part in the running line-search pass
+    sSel, //!< int: half of X / U / cost that holds control_data_
+    sOk, //!< int: backwardPass() returned true
+    sIter, //!< int: iterations started
+    sRet, //!< int: procOnce's return value
+    sFlags, //!< int: bit 0 running, 1 inside a procOnce, 2 backward pass pending, 3 in the line search, 4 step size found
+    sNBw, //!< int: backward passes of this iteration
+    sAi, //!< int: index of the last step size judged
+    sLambda,
+    sDlambda,
+    sT0, //!< current_t
+    sJcur, //!< control_data_.cost_list.sum()
+    sJcand,
+    sAlpha, //!< last step size judged (the one to re-roll)
+    sActual,
+    sExpected,
+    sRatio,
+    sDV0,
+    sDV1,
+    sKrel,
+    sTicksBw, //!< unsigned long long
+    sTicksFw,
+    kNumSlotFields
+  };
+  enum SlotFlag
+  {
+    fRunning = 1,
+    fInIter = 2,
+    fNeedBw = 4,
+    fInLs = 8,
+    fSuccess = 16
+  };
+  static constexpr int kKnextAt = kSlotAt + kNumSlotFields * kT64MaxGroup; //!< [32][8]: k_{i+1}, the BoxQP warm start (:452-467)
+  static constexpr int kWaveAt = kKnextAt + (kConstrained ? kT64MaxGroup * 8 : 0);
+  // per matrix wave: the column exchange of the gain computation, then (aliased: one wave's LDS traffic is ordered) the transposition
+  static constexpr int wQQ = 0; //!< [Qux_reg | Qu]: column j at 8 j, rows a < m
+  static constexpr int wF = wQQ + 8 * 16; //!< Quu_F: column c at wF + 8 c
+  static constexpr int wX = wF + 8 * 8; //!< Qx, row 4 r + q at wX + 4 q + r
+  static constexpr int wExchange = wX + 16;
+  static constexpr int kTrLd = 17; //!< leading dimension of the transposition scratch: conflict-free both ways
+  static constexpr int wT = 0;
+  static constexpr int wZero = (wExchange > 16 * kTrLd ? wExchange : 16 * kTrLd); //!< two zeros, read by lanes outside a block
+  static constexpr int wDump = wZero + 2; //!< written by lanes outside a block
+  static constexpr int kWaveDoubles = wDump + 2;
+  static constexpr int kLsAt = kWaveAt + kT64MatrixWaves * kWaveDoubles; //!< lsJ[NMPC_HIP_MAX_ALPHA][32]: cost of every trial
+  static constexpr int kTraceAt = kLsAt + NMPC_HIP_MAX_ALPHA * kT64MaxGroup; //!< trace row of the running iteration, [field][32]
+  static constexpr int kFixedRaw = kTraceAt + NMPC_HIP_NTRACE * kT64MaxGroup;
+  static constexpr int kRecAt = (kFixedRaw + 1) & ~1; //!< records: rec[2][G][stride]; before a sweep: [Vxx | Vx] per slot
+  static constexpr int kTerm = (N + 1) * N; //!< terminal record: n + 1 columns of n rows
+  // line search: ring of nominal records [depth][row][G] in the record area; rows of a timestep: k_i (m), K_i (m n, column-major),
+  // x_i (n), u_i (m)
+  static constexpr int kGainRows = MM + MM * N;
+  static constexpr int kRingRows = kGainRows + N + MM;
+  static constexpr int kRingDepth = 3;
+  static constexpr int kLdsDoubles = static_cast<int>(kT64LdsBytes / sizeof(double));
+  static_assert(kRecAt + 2 * (kNumIds + 2) <= kLdsDoubles && kRecAt + kTerm <= kLdsDoubles, "one instance must fit");
+
+  const Problem & problem;
+  const nmpc_hip_ddp_config & cfg;
+  const DeviceBuffers & buf;
+  const int T;
+  const int wave;
+  const int lane;
+  double * lds;
+  int stride = 0; //!< doubles per record (odd: the model wave's lanes spread over the banks)
+  int G = 1; //!< instances per group
+  int group_cap;
+
+  NMPC_D TileSolver64(const Problem & p, const nmpc_hip_ddp_config & c, const DeviceBuffers & bf, double * lds_base, int cap)
+  : problem(p), cfg(c), buf(bf), T(bf.T), wave(static_cast<int>(threadIdx.x) >> 6), lane(static_cast<int>(threadIdx.x) & 63),
+    lds(lds_base), group_cap(cap)
+  {
+  }
+
+  // ---- LDS views
+  NMPC_D unsigned short * tbl() const
+  {
+    return reinterpret_cast<unsigned short *>(lds + kTblAt);
+  }
+  NMPC_D int & meta(int k) const
+  {
+    return reinterpret_cast<int *>(lds + kMetaAt)[k];
+  }
+  NMPC_D double & slotF(int field, int slot) const
+  {
+    return lds[kSlotAt + field * kT64MaxGroup + slot];
+  }
+  NMPC_D int & slotI(int field, int slot) const
+  {
+    return reinterpret_cast<int *>(lds + kSlotAt + field * kT64MaxGroup + slot)[0];
+  }
+  NMPC_D unsigned long long & slotT(int field, int slot) const
+  {
+    return reinterpret_cast<unsigned long long *>(lds + kSlotAt + field * kT64MaxGroup + slot)[0];
+  }
+  NMPC_D double * rec(int parity, int slot) const
+  {
+    return lds + kRecAt + (parity * G + slot) * stride;
+  }
+  NMPC_D double * term(int slot) const
+  {
+    return lds + kRecAt + slot * kTerm;
+  }
+  NMPC_D double * waveScratch() const
+  {
+    return lds + kWaveAt + (wave - 1) * kWaveDoubles;
+  }
+  NMPC_D static void barrier()
+  {
+    __syncthreads();
+  }
+  /** A barrier that PUBLISHES global memory written by this wave (gains, candidate trajectories) to the other waves of the
+      workgroup.  __syncthreads() waits for LDS traffic only (workgroup scope: the compiler relies on the CU's shared L1 keeping
+      the waves' global accesses in order); the stores are drained explicitly so that nothing depends on that. */
+  NMPC_D static void publishBarrier()
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  /** Lanes of ONE wave exchange data through LDS without a barrier (the LDS executes a wave's instructions in order); the
+      compiler, which reasons per thread, must be kept from moving a lane's reads above the other lanes' writes. */
+  NMPC_D static void fence()
+  {
+    asm volatile("" ::: "memory");
+  }
+  NMPC_D static int uniform(int v)
+  {
+    return __builtin_amdgcn_readfirstlane(v);
+  }
+  NMPC_D static double uniformD(double v)
+  {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+  }
+
+  /** X^T Y over the first 4 S rows of X and Y, formed from zero (k ascending: an fma chain per entry). */
+  template<int S>
+  NMPC_D static v4d64 mma(v4d64 X, v4d64 Y)
+  {
+    v4d64 acc = {0, 0, 0, 0};
+#pragma unroll
+    for(int s = 0; s < S; s++)
+    {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[s], Y[s], acc, 0, 0, 0);
+    }
+    return acc;
+  }
+
+  // tile-major addressing of the handle's arrays (ddp_kernels.hpp): element (half s, row r) of instance b
+  NMPC_D static size_t tileOf(int b)
+  {
+    return static_cast<size_t>(b) / 64;
+  }
+  NMPC_D static size_t lnOf(int b)
+  {
+    return static_cast<size_t>(b) % 64;
+  }
+  NMPC_D Problem problemOf(int b) const
+  {
+    if constexpr(kOwnProblem)
+    {
+      return instanceProblem(problem, buf, b);
+    }
+    else
+    {
+      return problem;
+    }
+  }
+
+  // ===================================================================================================
+  // records: one visitor for the table and for the stores
+  // ===================================================================================================
+  /** Visits the record entries of the linearisation at (t, x, u) in canonical order. */
+  template<class Sink>
+  NMPC_D static void emitRecord(const Problem & p, double t, const StateDimVector & x, const InputDimVector & u, Sink & sink)
+  {
+    StateStateDimMatrix Fx, Lxx;
+    StateInputDimMatrix Fu, Lxu;
+    StateDimVector Lx;
+    InputDimVector Lu;
+    InputInputDimMatrix Luu;
+    p.calcStateEqDeriv(t, x, u, Fx, Fu);
+    p.calcRunningCostDeriv(t, x, u, Lx, Lu, Lxx, Luu, Lxu);
+#pragma unroll
+    for(int c = 0; c < N; c++)
+    {
+#pragma unroll
+      for(int r = 0; r < N; r++)
+      {
+        sink.put(Fx(r, c));
+      }
+    }
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+#pragma unroll
+      for(int r = 0; r < N; r++)
+      {
+        sink.put(Fu(r, a));
+      }
+    }
+#pragma unroll
+    for(int c = 0; c < N; c++)
+    {
+#pragma unroll
+      for(int r = 0; r < N; r++)
+      {
+        sink.put(Lxx(r, c));
+      }
+    }
+#pragma unroll
+    for(int c = 0; c < N; c++)
+    {
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        sink.put(Lxu(c, a));
+      }
+    }
+#pragma unroll
+    for(int c = 0; c < MM; c++)
+    {
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        sink.put(Luu(a, c));
+      }
+    }
+#pragma unroll
+    for(int r = 0; r < N; r++)
+    {
+      sink.put(Lx[r]);
+    }
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      sink.put(Lu[a]);
+    }
+    double un = 0;
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      un += u[a] * u[a];
+    }
+    const double unorm = (M == 1) ? fabs(u[0]) : sqrt(un);
+    sink.putVar(recipFast(unorm + 1.0));
+    if constexpr(kConstrained)
+    {
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        sink.putVar(u[a]);
+      }
+    }
+  }
+  /** A structural zero: the compiler knows the value, and it is zero. */
+  NMPC_D static bool structuralZero(double v)
+  {
+    return __builtin_constant_p(v) && v == 0.0;
+  }
+  struct TableSink
+  {
+    unsigned short * tbl;
+    int id = 0, cnt = 0;
+    NMPC_D void put(double v)
+    {
+      if(structuralZero(v))
+      {
+        tbl[id++] = 0;
+      }
+      else
+      {
+        tbl[id++] = static_cast<unsigned short>(++cnt);
+      }
+    }
+    NMPC_D void putVar(double)
+    {
+      tbl[id++] = static_cast<unsigned short>(++cnt);
+    }
+  };
+  /** kFull = false: entries the compiler knows to be constants (the literal ones of the Jacobians, weights of a shared
+      problem object) are not written again — the record slot holds them from the sweep's first two (full) timesteps. */
+  template<bool kFull>
+  struct StoreSink
+  {
+    double * rec;
+    int cnt = 0;
+    NMPC_D void put(double v)
+    {
+      if(!structuralZero(v))
+      {
+        ++cnt;
+        if(kFull || !__builtin_constant_p(v))
+        {
+          rec[cnt] = v;
+        }
+      }
+    }
+    NMPC_D void putVar(double v)
+    {
+      rec[++cnt] = v;
+    }
+  };
+
+  struct Point
+  {
+    double x[N], u[MM];
+  };
+  /** (x_i, u_i) of the slot's current trajectory: requested one timestep before lineariseStep consumes it. */
+  NMPC_D void loadPoint(Point & p, int b, int sel, int i) const
+  {
+    const size_t tile = tileOf(b), ln = lnOf(b);
+    const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;
+    const double * Xn = buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln;
+    const double * Un = buf.U + ((tile * 2 + sel) * rows_u) * 64 + ln;
+#pragma unroll
+    for(int c = 0; c < N; c++)
+    {
+      p.x[c] = Xn[(static_cast<size_t>(i) * N + c) * 64];
+    }
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      p.u[a] = Un[(static_cast<size_t>(i) * MM + a) * 64];
+    }
+  }
+  template<bool kFull>
+  NMPC_D void lineariseStep(const Problem & mine, int slot, double t0, int i, const Point & p) const
+  {
+    StateDimVector x;
+    InputDimVector u;
+#pragma unroll
+    for(int c = 0; c < N; c++)
+    {
+      x[c] = p.x[c];
+    }
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      u[a] = p.u[a];
+    }
+    StoreSink<kFull> sink{rec(i & 1, slot)};
+    if(kFull)
+    {
+      sink.rec[0] = 0.0; // the zero word
+    }
+    emitRecord(mine, t0 + i * mine.dt(), x, u, sink);
+  }
+  /** [Vxx | Vx] of the terminal cost (:177-185, :346-365) -> term(slot), column-major n x (n + 1). */
+  NMPC_D void lineariseTerminal(const Problem & mine, int slot, int b, int sel, double t0) const
+  {
+    const size_t tile = tileOf(b), ln = lnOf(b);
+    const size_t rows_x = static_cast<size_t>(T + 1) * N;
+    const double * Xn = buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln;
+    StateDimVector xT, vx;
+    StateStateDimMatrix vxx;
+#pragma unroll
+    for(int c = 0; c < N; c++)
+    {
+      xT[c] = Xn[(static_cast<size_t>(T) * N + c) * 64];
+    }
+    mine.calcTerminalCostDeriv(t0 + T * mine.dt(), xT, vx, vxx);
+    double * r = term(slot);
+#pragma unroll
+    for(int c = 0; c <= N; c++)
+    {
+#pragma unroll
+      for(int k = 0; k < N; k++)
+      {
+        r[c * N + k] = (c < N) ? vxx(k, c < N ? c : 0) : vx[k];
+      }
+    }
+  }
+
+  // ===================================================================================================
+  // line search: rollouts fed from an LDS ring of nominal records    DDPSolver.hpp:234-274, forwardPass :536-560
+  // ===================================================================================================
+  // A forward pass needs k_i, K_i, x_i, u_i of its instance per timestep: n + 2 m + m n doubles (126 for the manipulator).
+  // Loaded by the rolling lane itself they do not fit its registers next to the model code (measured: every load spilled behind
+  // a vmcnt(0), 80 k cycles per timestep against 8 k for the initial rollout).  So the waves that do not roll out in a pass
+  // fetch the nominal of timestep i + 2 into a ring in LDS (the record area, idle during the line search) — coalesced rows of
+  // the tile-major arrays, element (row, slot) — while the rolling waves read timestep i from it, one column of K at a time.
+  // One barrier per timestep; both roles run stagedPass() with the same barrier count.
+  NMPC_D double * ring(int i) const
+  {
+    return lds + kRecAt + (i % kRingDepth) * (kRingRows * G);
+  }
+  /** Prefetch role: rows of timestep i of every slot that takes part in the pass -> ring(i).  p_lane of p_count lanes. */
+  NMPC_D void prefetchNominal(int group, int i, int p_lane, int p_count) const
+  {
+    double * dst = ring(i);
+    const int total = kRingRows * G;
+    const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;
+    constexpr int kBatch = 8; // loads in flight per lane
+    for(int e0 = p_lane; e0 < total; e0 += p_count * kBatch)
+    {
+      double v[kBatch];
+      int at[kBatch];
+#pragma unroll
+      for(int k = 0; k < kBatch; k++)
+      {
+        const int e = e0 + k * p_count;
+        const int ec = e < total ? e : 0;
+        const int row = ec / G, slot = ec - row * G;
+        const bool want = e < total && slotI(sLs, slot) != 0;
+        const int b = group * G + slot;
+        const int sel = slotI(sSel, slot);
+        const size_t tile = tileOf(b), ln = lnOf(b);
+        // row < m: k_i | < m + m n: K_i | < m + m n + n: x_i | else u_i — one address expression, selected piecewise
+        const bool is_k = row < MM, is_K = !is_k && row < kGainRows, is_x = !is_k && !is_K && row < kGainRows + N;
+        const double * base = is_k ? buf.kff : (is_K ? buf.Kfb : (is_x ? buf.X : buf.U));
+        const size_t per_tile = is_k ? rows_u : (is_K ? rows_u * N : (is_x ? 2 * rows_x : 2 * rows_u));
+        const size_t half_off = (is_k || is_K) ? 0 : (is_x ? sel * rows_x : sel * rows_u);
+        const size_t per_step = is_k ? MM : (is_K ? N * MM : (is_x ? N : MM));
+        const size_t r = is_k ? row : (is_K ? row - MM : (is_x ? row - kGainRows : row - kGainRows - N));
+        const double * src = base + (tile * per_tile + half_off + static_cast<size_t>(i) * per_step + r) * 64 + ln;
+        at[k] = want ? e : -1;
+        v[k] = 0;
+        if(want)
+        {
+          v[k] = *src;
+        }
+      }
+#pragma unroll
+      for(int k = 0; k < kBatch; k++)
+      {
+        if(at[k] >= 0)
+        {
+          dst[at[k]] = v[k];
+        }
+      }
+    }
+  }
+  /** One pass over the horizon, every wave of the workgroup together (T + 2 barriers).
+      compute = false: this lane prefetches for the ring (p_lane of p_count; nothing to do in an initial pass).
+      compute = true:  every active lane rolls out one trajectory of slot `inst` (instance b) and sums the cost in list order:
+        initial  — u_i = initial_u_list[i] (half 0 of U), x_0 = current_x    :83-95
+        else     — u'_i = (u_i + alpha k_i) + K_i (x'_i - x_i) around the nominal in the ring    :536-560
+      store: the trajectory goes to half out_half of X / U / cost (an initial pass leaves U as it is).
+      Trip j of the loop: the prefetchers fetch timestep j, the rolling lanes compute timestep j - 2 (ring depth 3). */
+  NMPC_D double stagedPass(bool compute, bool initial, const Problem & mine, bool active, int group, int b, int inst, int out_half,
+                           double t0, double alpha, bool store, int p_lane, int p_count) const
+  {
+    double J = 0;
+    StateDimVector x;
+    double *Xo = nullptr, *Uo = nullptr, *Co = nullptr;
+    const double * Uin = nullptr;
+    const bool rolling = compute && active;
+    if(rolling)
+    {
+      const size_t tile = tileOf(b), ln = lnOf(b);
+      const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM, rows_c = static_cast<size_t>(T + 1);
+      Xo = buf.X + ((tile * 2 + out_half) * rows_x) * 64 + ln;
+      Uo = buf.U + ((tile * 2 + out_half) * rows_u) * 64 + ln;
+      Co = buf.cost + ((tile * 2 + out_half) * rows_c) * 64 + ln;
+      Uin = buf.U + ((tile * 2 + 0) * rows_u) * 64 + ln;
+      if(initial)
+      {
+#pragma unroll
+        for(int c = 0; c < N; c++)
+        {
+          x[c] = buf.x0[(tile * N + c) * 64 + ln];
+        }
+      }
+    }
+#pragma nounroll
+    for(int j = 0; j < T + 2; j++)
+    {
+      if(!compute)
+      {
+        if(!initial && j < T)
+        {
+          prefetchNominal(group, j, p_lane, p_count);
+        }
+      }
+      else if(active && j >= 2)
+      {
+        const int i = j - 2;
+        const double t = t0 + i * mine.dt();
+        InputDimVector u;
+        if(initial)
+        {
+#pragma unroll
+          for(int a = 0; a < MM; a++)
+          {
+            u[a] = Uin[(static_cast<size_t>(i) * MM + a) * 64];
+          }
+        }
+        else
+        {
+          const double * R = ring(i) + inst;
+          if(i == 0)
+          {
+#pragma unroll
+            for(int c = 0; c < N; c++)
+            {
+              x[c] = R[(kGainRows + c) * G]; // x'_0 = x_0    :541
+            }
+          }
+          double s[MM];
+#pragma unroll
+          for(int a = 0; a < MM; a++)
+          {
+            u[a] = R[(kGainRows + N + a) * G] + alpha * R[a * G]; // u_i + alpha k_i    :545
+            s[a] = 0;
+          }
+#pragma unroll
+          for(int c = 0; c < N; c++)
+          {
+            const double dxc = x[c] - R[(kGainRows + c) * G];
+#pragma unroll
+            for(int a = 0; a < MM; a++)
+            {
+              s[a] += R[(MM + a + c * MM) * G] * dxc;
+            }
+            if((c & 1) == 1)
+            {
+              __builtin_amdgcn_sched_barrier(0); // two columns of K in registers at a time, not all of it
+            }
+          }
+#pragma unroll
+          for(int a = 0; a < MM; a++)
+          {
+            u[a] = u[a] + s[a]; // ... + K_i (x'_i - x_i)    :546
+          }
+        }
+        const double c = mine.runningCost(t, x, u);
+        if(store)
+        {
+#pragma unroll
+          for(int cc = 0; cc < N; cc++)
+          {
+            Xo[(static_cast<size_t>(i) * N + cc) * 64] = x[cc];
+          }
+          if(!initial)
+          {
+#pragma unroll
+            for(int a = 0; a < MM; a++)
+            {
+              Uo[(static_cast<size_t>(i) * MM + a) * 64] = u[a];
+            }
+          }
+          Co[static_cast<size_t>(i) * 64] = c;
+        }
+        J += c;
+        x = mine.stateEq(t, x, u);
+      }
+      barrier();
+    }
+    if(rolling)
+    {
+      const double cT = mine.terminalCost(t0 + T * mine.dt(), x);
+      if(store)
+      {
+#pragma unroll
+        for(int cc = 0; cc < N; cc++)
+        {
+          Xo[(static_cast<size_t>(T) * N + cc) * 64] = x[cc];
+        }
+        Co[static_cast<size_t>(T) * 64] = cT;
+      }
+      J += cT;
+    }
+    return J;
+  }
+  /** Trips of the second pass (later step sizes, lane = (slot, step size) on the matrix waves): slots covered per trip. */
+  NMPC_D int laterPerWave() const
+  {
+    const int n_later = cfg.n_alpha - 1;
+    return n_later > 0 ? 64 / n_later : 64; // >= 2 (NMPC_HIP_MAX_ALPHA = 32)
+  }
+
+  // ===================================================================================================
+  // matrix waves: one backward timestep of one instance    DDPSolver.hpp:381-530
+  // ===================================================================================================
+  /** What a matrix lane knows for the whole kernel: where its entries of a record are (offsets in doubles). */
+  struct LaneMap
+  {
+    int oFx[4], oFu[4], oLxx[4], oLxuT[KM], oLuu[KM], oLx, oLu, oInvU, oU[kConstrained ? MM : 1];
+    double wn, wt; //!< weights of (Vn, Vn^T) in the new [Vxx | Vx]: (1/2, 1/2) inside the n x n block, (1, 0) in column n
+  };
+  NMPC_D LaneMap makeLaneMap() const
+  {
+    const int q = lane >> 4, j = lane & 15;
+    const unsigned short * t = tbl();
+    LaneMap mp;
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+      const int row = 4 * r + q;
+      mp.oFx[r] = (row < N && j < N) ? t[idFx + j * N + row] : 0;
+      mp.oFu[r] = (row < N && j < MM) ? t[idFu + j * N + row] : 0;
+      mp.oLxx[r] = (row < N && j < N) ? t[idLxx + j * N + row] : 0;
+    }
+#pragma unroll
+    for(int r = 0; r < KM; r++)
+    {
+      const int a = 4 * r + q;
+      mp.oLxuT[r] = (a < MM && j < N) ? t[idLxuT + j * MM + a] : 0;
+      mp.oLuu[r] = (a < MM && j < MM) ? t[idLuu + j * MM + a] : 0;
+    }
+    mp.oLx = (j < N) ? t[idLx + j] : 0;
+    mp.oLu = (j < MM) ? t[idLu + j] : 0;
+    mp.oInvU = t[idInvU];
+    if constexpr(kConstrained)
+    {
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        mp.oU[a] = t[idU + a];
+      }
+    }
+    else
+    {
+      mp.oU[0] = 0;
+    }
+    mp.wn = (j < N) ? 0.5 : ((j == N) ? 1.0 : 0.0);
+    mp.wt = (j < N) ? 0.5 : 0.0;
+    return mp;
+  }
+
+  /** Row `sel` (0..3) of four values. */
+  NMPC_D static double pick4(int sel, double a0, double a1, double a2, double a3)
+  {
+    const double lo = (sel & 1) ? a1 : a0;
+    const double hi = (sel & 1) ? a3 : a2;
+    return (sel & 2) ? hi : lo;
+  }
+
+  /** One timestep of one instance.  VV = [Vxx | Vx] in natural layout (in / out), r = the instance's record of this timestep,
+      ok = no factorisation of this sweep has failed yet (in / out); dV and the running max of |k| / (|u| + 1) accumulate in the
+      slot table (lane kStarLane).  Everything but the lane id is wave-uniform. */
+  NMPC_D void backwardStep(v4d64 & VV, bool & ok, const LaneMap & mp, const double * r, int slot, int b, int i, double lambda) const
+  {
+    const int q = lane >> 4, j = lane & 15;
+    double * W = waveScratch();
+    // ---- operands from the record
+    v4d64 Fx, Fu, Lxx, LxuT = {0, 0, 0, 0}, Luu = {0, 0, 0, 0};
+#pragma unroll
+    for(int rr = 0; rr < 4; rr++)
+    {
+      Fx[rr] = r[mp.oFx[rr]];
+      Fu[rr] = r[mp.oFu[rr]];
+      Lxx[rr] = r[mp.oLxx[rr]];
+    }
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      LxuT[rr] = r[mp.oLxuT[rr]];
+      Luu[rr] = r[mp.oLuu[rr]];
+    }
+    const double lx = r[mp.oLx], lu = r[mp.oLu], inv_u = r[mp.oInvU];
+
+    // ---- Q terms    :386-408
+    const v4d64 Pa = mma<KN>(VV, Fx);
+    const v4d64 Pb = mma<KN>(VV, Fu);
+    v4d64 Qxx = mma<KN>(Pa, Fx);
+    v4d64 Qux = mma<KN>(Pb, Fx);
+    v4d64 Quu = mma<KN>(Pb, Fu);
+#pragma unroll
+    for(int rr = 0; rr < 4; rr++)
+    {
+      Qxx[rr] = Lxx[rr] + Qxx[rr];
+      Qux[rr] = LxuT[rr] + Qux[rr];
+      Quu[rr] = Luu[rr] + Quu[rr];
+    }
+    const double qxrow = lx + Pa[rN]; // lane group qN: Qx[j]
+    const double qurow = lu + Pb[rN]; // lane group qN: Qu[j]
+
+    // ---- regularisation    :421-441
+    v4d64 QuxR = Qux, QuuF = Quu;
+    if(cfg.reg_type == 2)
+    {
+      v4d64 VVr = VV;
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        VVr[rr] = (4 * rr + q == j && j < N) ? VV[rr] + lambda : VV[rr];
+      }
+      const v4d64 Pbr = mma<KN>(VVr, Fu);
+      QuxR = mma<KN>(Pbr, Fx);
+      QuuF = mma<KN>(Pbr, Fu);
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        QuxR[rr] = LxuT[rr] + QuxR[rr];
+        QuuF[rr] = Luu[rr] + QuuF[rr];
+      }
+    }
+    else if(cfg.reg_type == 1)
+    {
+#pragma unroll
+      for(int rr = 0; rr < KM; rr++)
+      {
+        QuuF[rr] = (4 * rr + q == j) ? Quu[rr] + lambda : Quu[rr];
+      }
+    }
+
+    // ---- column exchange through the wave's scratch: lane (., c) gets column c of [Qux_reg | Qu], every lane gets Quu_F
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      const int a = 4 * rr + q;
+      W[(a < MM && j < N) ? wQQ + 8 * j + a : wDump] = QuxR[rr];
+      W[(a < MM && j < MM) ? wF + 8 * j + a : wDump] = QuuF[rr];
+    }
+    W[(q == qN && j < MM) ? wQQ + 8 * N + j : wDump] = qurow;
+    W[(q == qN && j < N) ? wX + 4 * (j & 3) + (j >> 2) : wDump] = qxrow;
+    fence();
+    double fac[MM * MM], inv_d[MM], col[MM], colQ[MM];
+#pragma unroll
+    for(int c = 0; c < MM; c++)
+    {
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        fac[a + c * MM] = (kConstrained || a >= c) ? W[wF + 8 * c + a] : 0.0; // (the factorisation reads the lower triangle)
+      }
+    }
+    const int jc = (j < N) ? j : N;
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      colQ[a] = W[wQQ + 8 * jc + a];
+      inv_d[a] = 0;
+    }
+    // Qx as column n of the accumulator of the value update: lane (q, n) register r <- Qx[4 r + q]
+    v4d64 qxcol;
+#pragma unroll
+    for(int rr = 0; rr < 4; rr++)
+    {
+      qxcol[rr] = W[(j == N) ? wX + 4 * q + rr : wZero];
+    }
+    fence();
+
+    // ---- gains    :500-517
+    bool ok_now = true;
+    if constexpr(kConstrained)
+    {
+      // every lane solves the same small QP (BoxQP.h:141-347, the lane kernel's implementation)    :450-497
+      double initial_k[MM], lo[MM], up[MM], Qu[MM];
+      double * knext = lds + kKnextAt + slot * 8;
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        const double ua = r[mp.oU[a]];
+        initial_k[a] = (i != T - 1) ? knext[a] : 0.0; // warm start from k_{i+1}    :452-467
+        lo[a] = inputLimitLo(buf, b, i, a) - ua; // :470-472
+        up[a] = inputLimitHi(buf, b, i, a) - ua;
+        Qu[a] = W[wQQ + 8 * N + a];
+      }
+      const Lane lane_code(problem, cfg, buf, b);
+      typename Lane::QPOut qp;
+      lane_code.boxQP(M, fac, Qu, lo, up, initial_k, qp);
+      unsigned free_mask = 0;
+      for(int f = 0; f < qp.n_free; f++)
+      {
+        free_mask |= (1u << qp.free_idx[f]);
+      }
+      if(lane == 0)
+      {
+        const size_t tl = tileOf(b), ln = lnOf(b);
+        buf.qp_ret[(tl * T + i) * 64 + ln] = qp.retval;
+        buf.qp_free[(tl * T + i) * 64 + ln] = free_mask;
+      }
+      ok_now = !(qp.retval < 0); // :473-480
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        col[a] = 0;
+      }
+      if(j == N)
+      {
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          col[a] = qp.x[a];
+        }
+      }
+      else if(qp.n_free > 0)
+      {
+        double sub[MM];
+        for(int f = 0; f < qp.n_free; f++)
+        {
+          sub[f] = colQ[qp.free_idx[f]];
+        }
+        Lane::template ldltSolveInPlace<MM, 1>(qp.fac, qp.inv_d, qp.n_free, sub);
+        for(int f = 0; f < qp.n_free; f++)
+        {
+          col[qp.free_idx[f]] = -1 * sub[f]; // clamped rows of K stay zero    :482-496
+        }
+      }
+      fence();
+      if(lane == 0)
+      {
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          knext[a] = qp.x[a];
+        }
+      }
+      fence();
+    }
+    else
+    {
+      ok_now = Lane::template ldltInPlace<MM>(fac, inv_d, M);
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        col[a] = colQ[a];
+      }
+      Lane::template ldltSolveInPlace<MM, 1>(fac, inv_d, M, col);
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        col[a] = -1 * col[a];
+      }
+    }
+    ok = ok && ok_now; // (after a failure the slot computes on garbage and stores nothing)
+
+    // ---- A = [K | k] and QQ = [Qux | Qu] in natural layout
+    v4d64 A = {0, 0, 0, 0}, QQ = {0, 0, 0, 0};
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      double g[4], c4[4];
+#pragma unroll
+      for(int e = 0; e < 4; e++)
+      {
+        g[e] = (4 * rr + e < MM) ? col[(4 * rr + e < MM) ? 4 * rr + e : 0] : 0.0;
+        c4[e] = (4 * rr + e < MM) ? colQ[(4 * rr + e < MM) ? 4 * rr + e : 0] : 0.0;
+      }
+      const double gq = pick4(q, g[0], g[1], g[2], g[3]);
+      const double cq = pick4(q, c4[0], c4[1], c4[2], c4[3]);
+      A[rr] = (j <= N) ? gq : 0.0;
+      QQ[rr] = (j < N) ? Qux[rr] : ((j == N) ? cq : 0.0); // (column n of colQ is Qu; unregularised Qux elsewhere)
+    }
+
+    // ---- cost-to-go    :522-527
+    const v4d64 Z = mma<KM>(Quu, A);
+    const v4d64 C1 = mma<KM>(Z, A);
+    const v4d64 T2 = mma<KM>(A, QQ);
+    const v4d64 T3 = mma<KM>(Qux, A);
+    v4d64 Vn;
+#pragma unroll
+    for(int rr = 0; rr < 4; rr++)
+    {
+      const double c0 = (j < N) ? Qxx[rr] : qxcol[rr];
+      Vn[rr] = ((c0 + C1[rr]) + T2[rr]) + T3[rr];
+    }
+    Vn[rN] = (q == qN) ? 0.0 : Vn[rN]; // row n: k^T (...), not part of the value function
+    // Vxx <- (Vxx + Vxx^T) / 2: rows to the scratch, columns back
+#pragma unroll
+    for(int rr = 0; rr < 4; rr++)
+    {
+      W[wT + (4 * rr + q) * kTrLd + j] = Vn[rr];
+    }
+    fence();
+#pragma unroll
+    for(int rr = 0; rr < 4; rr++)
+    {
+      const double vt = W[(4 * rr + q < N && j < N) ? wT + j * kTrLd + 4 * rr + q : wZero];
+      VV[rr] = mp.wn * Vn[rr] + mp.wt * vt;
+    }
+    fence();
+
+    // ---- |k| / (|u| + 1)    :217-221   (lanes of column n hold k)
+    {
+      double kn = 0;
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        kn += col[a] * col[a];
+      }
+      const double knorm = (M == 1) ? fabs(col[0]) : sqrt(kn);
+      if(lane == kStarLane) // entry (n, n) of T2 is k^T Qu, of C1 k^T Quu k    :522-523
+      {
+        slotF(sDV0, slot) += T2[rN];
+        slotF(sDV1, slot) += 0.5 * C1[rN];
+        slotF(sKrel, slot) = fmax(slotF(sKrel, slot), knorm * inv_u);
+      }
+    }
+
+    // ---- k_i, K_i -> kff / Kfb (:529-530); not after a failed factorisation: backwardPass() returned before storing (:505-508)
+    if(ok && j <= N)
+    {
+      const size_t tile = tileOf(b), ln = lnOf(b);
+      const size_t rows_u = static_cast<size_t>(T) * MM;
+#pragma unroll
+      for(int rr = 0; rr < KM; rr++)
+      {
+        const int a = 4 * rr + q;
+        if(a < MM)
+        {
+          if(j == N)
+          {
+            buf.kff[(tile * rows_u + static_cast<size_t>(i) * MM + a) * 64 + ln] = A[rr];
+          }
+          else
+          {
+            buf.Kfb[(tile * rows_u * N + static_cast<size_t>(i) * N * MM + a + j * MM) * 64 + ln] = A[rr];
+          }
+        }
+      }
+    }
+  }
+
+  /** The sweep of the matrix waves (barriers are shared with the model wave's loop, backwardSweepModel).
+      The value functions of the wave's (up to five) slots stay in registers for the whole sweep.  The slot loop is a real loop
+      — one copy of the step in the instruction cache — that always works on V0 and then rotates V0 <- V1 <- ... <- V4 <- V0
+      (register moves; an array indexed by the trip count would live in scratch memory): after five trips every value function
+      is back in its place. */
+  NMPC_D void backwardSweepMatrix() const
+  {
+    static_assert(kT64MaxPerWave == 5, "the rotation below is written for five slots per wave");
+    const LaneMap mp = makeLaneMap();
+    const int q = lane >> 4, j = lane & 15;
+    const int mw = wave - 1;
+    v4d64 V0, V1, V2, V3, V4;
+    unsigned ok_mask = ~0u;
+    barrier(); // the terminal records are complete
+    auto loadTerminal = [&](int e) -> v4d64
+    {
+      const int slot = mw + kT64MatrixWaves * e;
+      v4d64 v = {0, 0, 0, 0};
+      if(slot < G && uniform(slotI(sBw, slot)) != 0)
+      {
+        const double * tr = term(slot);
+#pragma unroll
+        for(int rr = 0; rr < 4; rr++)
+        {
+          const int row = 4 * rr + q;
+          const double t = tr[(row < N && j <= N) ? j * N + row : 0];
+          v[rr] = (row < N && j <= N) ? t : 0.0;
+        }
+        if(lane == kStarLane)
+        {
+          slotF(sDV0, slot) = 0;
+          slotF(sDV1, slot) = 0;
+          slotF(sKrel, slot) = 0;
+        }
+      }
+      return v;
+    };
+    V0 = loadTerminal(0);
+    V1 = loadTerminal(1);
+    V2 = loadTerminal(2);
+    V3 = loadTerminal(3);
+    V4 = loadTerminal(4);
+    barrier(); // the terminal records have been read
+    barrier(); // the records of timestep T - 1 are complete
+    for(int i = T - 1; i >= 0; i--)
+    {
+#pragma nounroll
+      for(int e = 0; e < kT64MaxPerWave; e++)
+      {
+        const int slot = mw + kT64MatrixWaves * e;
+        if(slot < G && uniform(slotI(sBw, slot)) != 0)
+        {
+          bool ok = ((ok_mask >> e) & 1u) != 0;
+          backwardStep(V0, ok, mp, rec(i & 1, slot), slot, uniform(slotI(sB, slot)), i, uniformD(slotF(sLambda, slot)));
+          ok_mask = ok ? ok_mask : (ok_mask & ~(1u << e));
+        }
+        const v4d64 t = V0;
+        V0 = V1;
+        V1 = V2;
+        V2 = V3;
+        V3 = V4;
+        V4 = t;
+      }
+      barrier(); // record i has been read by all, record i - 1 is complete
+    }
+    if(lane == kStarLane)
+    {
+#pragma unroll
+      for(int e = 0; e < kT64MaxPerWave; e++)
+      {
+        const int slot = mw + kT64MatrixWaves * e;
+        if(slot < G && slotI(sBw, slot) != 0)
+        {
+          slotI(sOk, slot) = static_cast<int>((ok_mask >> e) & 1u);
+        }
+      }
+    }
+  }
+
+  /** The model wave's half of the sweep: record i - 1 is written while the matrix waves consume record i; (x, u) of a timestep
+      are requested one timestep before they are linearised.  T + 3 barriers, as backwardSweepMatrix. */
+  NMPC_D void backwardSweepModel(const Problem & mine_p, bool mine, int slot, int b, int sel, double t0) const
+  {
+    Point cur, next;
+    if(mine)
+    {
+      loadPoint(next, b, sel, T - 1);
+      lineariseTerminal(mine_p, slot, b, sel, t0);
+    }
+    barrier(); // the terminal records are complete
+    barrier(); // (the matrix waves have taken them: the record area is free)
+    for(int step = T - 1; step >= 0; step--)
+    {
+      if(mine)
+      {
+        cur = next;
+        loadPoint(next, b, sel, step > 0 ? step - 1 : 0);
+        if(step >= T - 2)
+        {
+          lineariseStep<true>(mine_p, slot, t0, step, cur); // the first use of a record slot in the sweep: every entry
+        }
+        else
+        {
+          lineariseStep<false>(mine_p, slot, t0, step, cur);
+        }
+      }
+      barrier(); // record `step` is complete (and record step + 1 has been read by all)
+    }
+    barrier(); // record 0 has been read
+  }
+
+  // ===================================================================================================
+  // solve    DDPSolver.hpp:26-141, procOnce :143-340
+  // ===================================================================================================
+  /** Kernel start: the offset table (lane 0 of the model wave), the record stride and the group size that follow from it. */
+  NMPC_D void setup()
+  {
+    if(wave == 0 && lane == 0)
+    {
+      // the point is irrelevant (only what the compiler knows about each entry matters) but must not be a constant
+      Point p;
+      loadPoint(p, 0, 0, 0);
+      StateDimVector x;
+      InputDimVector u;
+#pragma unroll
+      for(int c = 0; c < N; c++)
+      {
+        x[c] = p.x[c];
+      }
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        u[a] = p.u[a];
+      }
+      const Problem mine = problemOf(0);
+      TableSink sink{tbl()};
+      emitRecord(mine, buf.t0 ? buf.t0[0] : 0.0, x, u, sink);
+      int s = sink.cnt + 1; // + the zero word
+      s |= 1; // odd: the model wave's lanes (one record each) spread over the LDS banks
+      const int room = kLdsDoubles - kRecAt;
+      int per_instance = (2 * s > kTerm) ? 2 * s : kTerm;
+      per_instance = (per_instance > kRingDepth * kRingRows) ? per_instance : kRingDepth * kRingRows; // (line search: nominal ring)
+      int g = room / per_instance;
+      g = g > kT64MaxGroup ? kT64MaxGroup : g;
+      const int spread = (buf.B + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x); // every workgroup gets work
+      g = g > spread ? spread : g;
+      if(group_cap > 0 && g > group_cap)
+      {
+        g = group_cap;
+      }
+      meta(mStride) = s;
+      meta(mGroup) = g < 1 ? 1 : g;
+    }
+    barrier();
+    stride = uniform(meta(mStride));
+    G = uniform(meta(mGroup));
+  }
+
+  /** The trace row of the iteration in progress lives in LDS (field-major: the owner lanes spread over the banks), not in
+      twelve registers that would be live across every rollout and linearisation. */
+  NMPC_D double & trF(int f, int slot) const
+  {
+    return lds[kTraceAt + f * kT64MaxGroup + slot];
+  }
+  NMPC_D void clearTrace(int slot) const
+  {
+#pragma unroll
+    for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+    {
+      trF(f, slot) = 0;
+    }
+  }
+  NMPC_D void writeTraceRow(int b, int row, int slot) const
+  {
+    if(cfg.trace_level >= 1 && row < buf.trace_rows)
+    {
+      const size_t tile = tileOf(b), ln = lnOf(b);
+      double * p = buf.trace + (tile * (static_cast<size_t>(buf.trace_rows) * NMPC_HIP_NTRACE)) * 64 + ln;
+#pragma unroll
+      for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+      {
+        p[(static_cast<size_t>(row) * NMPC_HIP_NTRACE + f) * 64] = trF(f, slot);
+      }
+    }
+  }
+
+  /** One group of instances, all eight waves.  The phases are separated by barriers; wave 0 ("model wave", lane = slot) runs the
+      solver state machine of DDPSolver::solve / procOnce for its slot in short blocks between them — its state lives in the
+      slot table — and the model code; waves 1 .. 7 run the backward sweeps and help in the line search. */
+  NMPC_D void solveGroup(int group)
+  {
+    const unsigned long long solve_start = __builtin_readcyclecounter();
+    const bool model_wave = (wave == 0);
+    const int slot = lane & (kT64MaxGroup - 1);
+    const int b = group * G + slot;
+    const bool owner = model_wave && lane < G && b < buf.B; // this lane drives an instance
+    const bool slot_lane = model_wave && lane < kT64MaxGroup;
+    const int p_lane_matrix = (wave - 1) * 64 + lane, p_count_matrix = kT64MatrixWaves * 64;
+    double * lsJ = lds + kLsAt;
+
+    // ---- solve(): reset, initial rollout    :36-38, :83-104
+    if(slot_lane)
+    {
+      slotI(sB, slot) = owner ? b : -1;
+      slotI(sBw, slot) = 0;
+      slotI(sLs, slot) = 0;
+      slotI(sSel, slot) = 0;
+      slotI(sOk, slot) = 1;
+      slotI(sIter, slot) = 0;
+      slotI(sRet, slot) = 0;
+      slotI(sFlags, slot) = owner ? fRunning : 0;
+      slotF(sLambda, slot) = cfg.initial_lambda;
+      slotF(sDlambda, slot) = cfg.initial_dlambda;
+      slotF(sT0, slot) = (owner && buf.t0) ? buf.t0[b] : 0.0;
+      slotF(sDV0, slot) = 0;
+      slotF(sDV1, slot) = 0;
+      slotT(sTicksBw, slot) = 0;
+      slotT(sTicksFw, slot) = 0;
+      clearTrace(slot);
+    }
+    barrier();
+
+    // Every trip of this loop ends with the rollouts of one procOnce (the line search); the first trip has nothing before them
+    // and rolls out initial_u_list instead (pass 0) — so that the kernel holds ONE copy of the rollout code.
+    bool first_trip = true;
+    for(;;)
+    {
+      bool rollouts = true; // (first trip: the initial rollout)
+      if(!first_trip)
+      {
+      // ---- which slots start procOnce number iter + 1    :115-123
+      if(slot_lane)
+      {
+        int flags = slotI(sFlags, slot);
+        const int iter = slotI(sIter, slot);
+        const bool in_iter = (flags & fRunning) != 0 && iter < cfg.max_iter;
+        flags = in_iter ? (fRunning | fInIter | fNeedBw) : 0;
+        if(in_iter)
+        {
+          slotI(sIter, slot) = iter + 1;
+          slotI(sRet, slot) = 0;
+          slotI(sNBw, slot) = 0;
+          clearTrace(slot);
+          trF(NMPC_HIP_TRACE_ITER, slot) = static_cast<double>(iter + 1);
+          trF(NMPC_HIP_TRACE_ALPHA_IDX, slot) = -1;
+        }
+        slotI(sFlags, slot) = flags;
+        slotI(sBw, slot) = in_iter ? 1 : 0;
+        const unsigned long long any = __ballot(in_iter);
+        if(lane == 0)
+        {
+          meta(mAnyIter) = (any != 0) ? 1 : 0;
+        }
+      }
+      publishBarrier(); // B1 (the initial rollout's / a re-rolled step size's trajectory is in X / U)
+      if(uniform(meta(mAnyIter)) == 0)
+      {
+        break;
+      }
+      // ---- Steps 1 + 2: linearisation fused into the backward sweep, with the regularisation retries    :157-214
+      for(;;)
+      {
+        const unsigned long long p0 = __builtin_readcyclecounter();
+        if(model_wave)
+        {
+          const bool mine = slot_lane && (slotI(sFlags, slot) & fNeedBw) != 0;
+          const Problem mine_p = problemOf(mine ? b : 0);
+          backwardSweepModel(mine_p, mine, slot, b, slotI(sSel, slot), slotF(sT0, slot));
+        }
+        else
+        {
+          backwardSweepMatrix();
+        }
+        publishBarrier(); // B2: results of the sweep are in the slot table, the gains in kff / Kfb
+        if(slot_lane)
+        {
+          int flags = slotI(sFlags, slot);
+          bool retry = false;
+          if((flags & fNeedBw) != 0)
+          {
+            slotI(sNBw, slot) += 1;
+            slotT(sTicksBw, slot) += __builtin_readcyclecounter() - p0;
+            if(slotI(sOk, slot) == 0)
+            {
+              const double dlambda = fmax(slotF(sDlambda, slot) * cfg.lambda_factor, cfg.lambda_factor); // :191-209
+              const double lambda = fmax(slotF(sLambda, slot) * dlambda, cfg.lambda_min);
+              slotF(sDlambda, slot) = dlambda;
+              slotF(sLambda, slot) = lambda;
+              if(lambda > cfg.lambda_max)
+              {
+                slotI(sRet, slot) = -1;
+                flags &= ~fNeedBw;
+              }
+              else
+              {
+                retry = true;
+              }
+            }
+            else
+            {
+              flags &= ~fNeedBw;
+            }
+            slotI(sFlags, slot) = flags;
+          }
+          slotI(sBw, slot) = retry ? 1 : 0;
+          const unsigned long long any = __ballot(retry);
+          if(lane == 0)
+          {
+            meta(mAnyRetry) = (any != 0) ? 1 : 0;
+          }
+        }
+        barrier(); // B3
+        if(uniform(meta(mAnyRetry)) == 0)
+        {
+          break;
+        }
+      }
+      // ---- small-gradient termination (:217-231); who searches    :234-274
+      if(slot_lane)
+      {
+        int flags = slotI(sFlags, slot);
+        bool in_ls = false;
+        if((flags & fInIter) != 0)
+        {
+          trF(NMPC_HIP_TRACE_N_BACKWARD, slot) = static_cast<double>(slotI(sNBw, slot));
+          if(slotI(sRet, slot) == 0)
+          {
+            const double krel = slotF(sKrel, slot);
+            trF(NMPC_HIP_TRACE_K_REL_NORM, slot) = krel;
+            if(krel < cfg.k_rel_norm_thre && slotF(sLambda, slot) < cfg.lambda_thre)
+            {
+              slotI(sRet, slot) = 1;
+            }
+            else
+            {
+              in_ls = true;
+            }
+          }
+        }
+        flags = in_ls ? (flags | fInLs) : (flags & ~fInLs);
+        slotI(sFlags, slot) = flags & ~fSuccess;
+        slotI(sLs, slot) = in_ls ? 1 : 0;
+        slotI(sAi, slot) = cfg.n_alpha - 1;
+        const unsigned long long any = __ballot(in_ls);
+        if(lane == 0)
+        {
+          meta(mAnyLs) = (any != 0) ? 1 : 0;
+        }
+      }
+      barrier(); // B4
+      rollouts = uniform(meta(mAnyLs)) != 0;
+      }
+      if(rollouts)
+      {
+        // Step 3, the line search.  Pass 1: the first step size — the one normally taken — lane = slot on the model wave, stored;
+        // the matrix waves feed the ring.  Pass 2 (only if a slot rejected it): the later step sizes of those slots all at once
+        // on the matrix waves, lane = (slot, step size), cost only; the model wave feeds the ring.  Pass 3 (only if a later
+        // step size was taken): its trajectory, stored.  The first accepted step size in list order is the sequential loop's
+        // choice (:242-265).  One call site of stagedPass: one copy of the model's rollout code in the kernel.
+        const unsigned long long p0 = __builtin_readcyclecounter();
+        /** judge step size ai of this lane's slot with cost Jc    :247-264 */
+        auto judge = [&](int ai, double Jc) -> bool
+        {
+          const double alpha = cfg.alpha_list[ai];
+          const double actual = slotF(sJcur, slot) - Jc;
+          const double expected = -1 * alpha * (slotF(sDV0, slot) + alpha * slotF(sDV1, slot));
+          double ratio = actual / expected;
+          if(expected < 0)
+          {
+            ratio = (actual >= 0 ? 1 : -1); // :251-259
+          }
+          slotF(sAlpha, slot) = alpha;
+          slotF(sActual, slot) = actual;
+          slotF(sExpected, slot) = expected;
+          slotF(sRatio, slot) = ratio;
+          slotF(sJcand, slot) = Jc;
+          slotI(sAi, slot) = ai;
+          return ratio > cfg.cost_update_ratio_thre;
+        };
+        const int later_per_wave = laterPerWave();
+        const int covered = later_per_wave * kT64MatrixWaves;
+        int pass = first_trip ? 0 : 1, trip_base = 0;
+#pragma nounroll
+        for(;;)
+        {
+          // ---- what this lane does in this pass
+          bool compute, active = false, store = true;
+          int pb = 0, pinst = 0, phalf = 0, pai = 0;
+          double pt0 = 0, palpha = 0;
+          if(pass == 0)
+          {
+            compute = model_wave;
+            active = owner;
+            pb = owner ? b : 0;
+            pinst = slot;
+            pt0 = slotF(sT0, slot);
+          }
+          else if(pass != 2)
+          {
+            compute = model_wave;
+            if(slot_lane && slotI(sLs, slot) != 0)
+            {
+              active = true;
+              pb = b;
+              pinst = slot;
+              phalf = slotI(sSel, slot) ^ 1;
+              pt0 = slotF(sT0, slot);
+              palpha = (pass == 1) ? cfg.alpha_list[0] : slotF(sAlpha, slot);
+            }
+          }
+          else
+          {
+            compute = !model_wave;
+            store = false;
+            if(compute)
+            {
+              const int n_later = cfg.n_alpha - 1;
+              const int inst = lane / n_later;
+              pai = 1 + lane - inst * n_later;
+              const int fslot = trip_base + (wave - 1) * later_per_wave + inst;
+              if(inst < later_per_wave && fslot < G && slotI(sB, fslot) >= 0 && slotI(sLs, fslot) != 0)
+              {
+                active = true;
+                pb = slotI(sB, fslot);
+                pinst = fslot;
+                phalf = slotI(sSel, fslot) ^ 1;
+                pt0 = slotF(sT0, fslot);
+                palpha = cfg.alpha_list[pai];
+              }
+            }
+          }
+          const Problem theirs = active ? problemOf(pb) : problem;
+          const double Jc = stagedPass(compute, pass == 0, theirs, active, group, pb, pinst, phalf, pt0, palpha, store,
+                                       model_wave ? lane : p_lane_matrix, model_wave ? 64 : p_count_matrix);
+          // ---- what follows from it
+          if(pass == 0)
+          {
+            if(owner) // :98-104
+            {
+              slotF(sJcur, slot) = Jc;
+              slotT(sTicksFw, slot) += __builtin_readcyclecounter() - p0;
+              trF(NMPC_HIP_TRACE_COST, slot) = Jc;
+              trF(NMPC_HIP_TRACE_LAMBDA, slot) = cfg.initial_lambda;
+              trF(NMPC_HIP_TRACE_DLAMBDA, slot) = cfg.initial_dlambda;
+              trF(NMPC_HIP_TRACE_ALPHA_IDX, slot) = -1;
+              writeTraceRow(b, 0, slot);
+            }
+            break;
+          }
+          else if(pass == 1)
+          {
+            if(slot_lane)
+            {
+              int flags = slotI(sFlags, slot);
+              bool more = false;
+              if((flags & fInLs) != 0)
+              {
+                const bool success = judge(0, Jc);
+                flags = success ? (flags | fSuccess) : flags;
+                more = !success && cfg.n_alpha > 1;
+                slotI(sFlags, slot) = flags;
+              }
+              slotI(sLs, slot) = more ? 1 : 0;
+              const unsigned long long any = __ballot(more);
+              if(lane == 0)
+              {
+                meta(mAnyMore) = (any != 0) ? 1 : 0;
+              }
+            }
+            publishBarrier(); // B5: the candidate trajectory is in the other half of X / U / cost
+            if(uniform(meta(mAnyMore)) == 0)
+            {
+              break;
+            }
+            pass = 2;
+            trip_base = 0;
+          }
+          else if(pass == 2)
+          {
+            if(active)
+            {
+              lsJ[pai * kT64MaxGroup + pinst] = Jc;
+            }
+            trip_base += covered;
+            if(trip_base < G)
+            {
+              continue;
+            }
+            barrier(); // B5b: the later step sizes' costs are in lsJ
+            if(slot_lane)
+            {
+              bool reroll = false;
+              if(slotI(sLs, slot) != 0)
+              {
+                bool success = false;
+                for(int ai = 1; ai < cfg.n_alpha && !success; ai++)
+                {
+                  success = judge(ai, lsJ[ai * kT64MaxGroup + slot]);
+                }
+                if(success)
+                {
+                  slotI(sFlags, slot) |= fSuccess;
+                  reroll = true; // its trajectory has not been stored yet
+                }
+              }
+              slotI(sLs, slot) = reroll ? 1 : 0;
+              const unsigned long long any = __ballot(reroll);
+              if(lane == 0)
+              {
+                meta(mAnyReroll) = (any != 0) ? 1 : 0;
+              }
+            }
+            barrier(); // B5c
+            if(uniform(meta(mAnyReroll)) == 0)
+            {
+              break;
+            }
+            pass = 3;
+          }
+          else
+          {
+            if(active)
+            {
+              slotF(sJcand, slot) = Jc; // (the same arithmetic on the same inputs as the lane that summed its cost)
+            }
+            break;
+          }
+        }
+        // ---- Step 4    :280-333
+        if(!first_trip && slot_lane && (slotI(sFlags, slot) & fInLs) != 0)
+        {
+          const bool success = (slotI(sFlags, slot) & fSuccess) != 0;
+          const int ai_taken = slotI(sAi, slot);
+          double lambda = slotF(sLambda, slot), dlambda = slotF(sDlambda, slot);
+          slotT(sTicksFw, slot) += __builtin_readcyclecounter() - p0;
+          trF(NMPC_HIP_TRACE_ALPHA, slot) = slotF(sAlpha, slot);
+          trF(NMPC_HIP_TRACE_COST_UPDATE_ACTUAL, slot) = slotF(sActual, slot);
+          trF(NMPC_HIP_TRACE_COST_UPDATE_EXPECTED, slot) = slotF(sExpected, slot);
+          trF(NMPC_HIP_TRACE_COST_UPDATE_RATIO, slot) = slotF(sRatio, slot);
+          trF(NMPC_HIP_TRACE_ALPHA_IDX, slot) = static_cast<double>(ai_taken);
+          trF(NMPC_HIP_TRACE_N_FORWARD, slot) = static_cast<double>(success ? ai_taken + 1 : cfg.n_alpha);
+          if(success)
+          {
+            slotI(sSel, slot) ^= 1;
+            slotF(sJcur, slot) = slotF(sJcand, slot);
+            if(slotF(sActual, slot) < cfg.cost_update_thre)
+            {
+              slotI(sRet, slot) = 1;
+            }
+            dlambda = fmin(dlambda / cfg.lambda_factor, 1 / cfg.lambda_factor);
+            if(lambda >= cfg.lambda_min)
+            {
+              lambda *= dlambda;
+            }
+            else
+            {
+              lambda = 0;
+            }
+          }
+          else
+          {
+            dlambda = fmax(dlambda * cfg.lambda_factor, cfg.lambda_factor);
+            lambda = fmax(lambda * dlambda, cfg.lambda_min);
+            if(lambda > cfg.lambda_max)
+            {
+              slotI(sRet, slot) = -1;
+            }
+          }
+          slotF(sLambda, slot) = lambda;
+          slotF(sDlambda, slot) = dlambda;
+          trF(NMPC_HIP_TRACE_COST, slot) = slotF(sJcur, slot);
+          trF(NMPC_HIP_TRACE_LAMBDA, slot) = lambda;
+          trF(NMPC_HIP_TRACE_DLAMBDA, slot) = dlambda;
+        }
+      }
+      if(!first_trip && slot_lane && (slotI(sFlags, slot) & fInIter) != 0)
+      {
+        if(owner)
+        {
+          writeTraceRow(b, slotI(sIter, slot), slot);
+        }
+        if(slotI(sRet, slot) != 0)
+        {
+          slotI(sFlags, slot) &= ~fRunning; // :118-122
+        }
+      }
+      first_trip = false;
+    }
+
+    // ---- results the host reads per instance
+    if(owner)
+    {
+      const size_t tile = tileOf(b), ln = lnOf(b);
+      buf.status[b] = slotI(sRet, slot);
+      buf.iters[b] = slotI(sIter, slot);
+      buf.sel[b] = slotI(sSel, slot);
+      if(buf.phase_ticks != nullptr)
+      {
+        unsigned long long * p = buf.phase_ticks + static_cast<size_t>(b) * 4;
+        p[0] = slotT(sTicksBw, slot);
+        p[1] = slotT(sTicksFw, slot);
+        p[2] = __builtin_readcyclecounter() - solve_start;
+      }
+      buf.dV[(tile * 2 + 0) * 64 + ln] = slotF(sDV0, slot);
+      buf.dV[(tile * 2 + 1) * 64 + ln] = slotF(sDV1, slot);
+#pragma unroll
+      for(int f = 0; f < NMPC_HIP_NTRACE; f++)
+      {
+        buf.trace_last[(tile * NMPC_HIP_NTRACE + f) * 64 + ln] = trF(f, slot);
+      }
+      for(int i = 0; i < T; i++)
+      {
+        buf.input_dim[(tile * T + i) * 64 + ln] = M;
+      }
+    }
+    barrier(); // the next group reuses the slot table and the record area
+  }
+
+  NMPC_D void run()
+  {
+    if(wave != 0 && lane < 4)
+    {
+      waveScratch()[wZero + lane] = 0.0; // zero words (read by lanes outside a block) and dump words (written by them)
+    }
+    setup();
+    const int n_groups = (buf.B + G - 1) / G;
+    for(int group = static_cast<int>(blockIdx.x); group < n_groups; group += static_cast<int>(gridDim.x))
+    {
+      solveGroup(group);
+    }
+  }
+};
+
+/** The fp64 tile kernel: persistent workgroups of eight wavefronts, grid = number of CUs (or fewer for small batches). */
+template<class Problem, bool kConstrained, bool kOwnProblem>
+__global__ __launch_bounds__(kT64Threads) void ddp_solve_tile64_kernel(const Problem problem,
+                                                                        const nmpc_hip_ddp_config cfg,
+                                                                        const DeviceBuffers buf,
+                                                                        const int group_cap)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds_tile64[];
+  TileSolver64<Problem, kConstrained, kOwnProblem> solver(problem, cfg, buf, lds_tile64, group_cap);
+  solver.run();
+}
+
+/** Launch helper for model_registry.hpp. */
+template<class Problem, bool kConstrained, bool kOwnProblem>
+inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_config & cfg, const DeviceBuffers & buf, hipStream_t stream)
+{
+  static bool requested[64] = {};
+  static int n_cu[64] = {};
+  int dev = 0;
+  if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+  {
+    return hipErrorInvalidDevice;
+  }
+  const void * fn = reinterpret_cast<const void *>(&ddp_solve_tile64_kernel<Problem, kConstrained, kOwnProblem>);
+  if(!requested[dev])
+  {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kT64LdsBytes));
+    if(e != hipSuccess)
+    {
+      return e;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if(e != hipSuccess)
+    {
+      return e;
+    }
+    n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    requested[dev] = true;
+  }
+  int cap = 0; // NMPC_HIP_DDP_TILE64_GROUP=<g>: at most g instances per group (tests: full groups on small batches)
+  if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_GROUP"))
+  {
+    cap = std::atoi(e);
+  }
+  int grid = n_cu[dev];
+  if(cap > 0)
+  {
+    const int groups = (buf.B + cap - 1) / cap; // (the kernel may still choose smaller groups: idle workgroups exit)
+    grid = groups < grid ? (groups < 1 ? 1 : groups) : grid;
+  }
+  grid = buf.B < grid ? buf.B : grid;
+  hipLaunchKernelGGL((ddp_solve_tile64_kernel<Problem, kConstrained, kOwnProblem>), dim3(grid), dim3(kT64Threads), kT64LdsBytes,
+                     stream, problem, cfg, buf, cap);
+  return hipGetLastError();
+}
+} // namespace hip
+} // namespace nmpc_amd

@@ -18,6 +18,7 @@
 #include <nmpc_amd/hip/ddp_kernels_2w.hpp>
 #include <nmpc_amd/hip/ddp_kernels_quad.hpp>
 #include <nmpc_amd/hip/ddp_kernels_wpi.hpp>
+#include <nmpc_amd/hip/ddp_kernels_tile64.hpp>
 #include <nmpc_amd/hip/mpc_kernels.hpp>
 
 namespace nmpc_amd
@@ -48,6 +49,16 @@ struct ModelOpsFor
   {
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
     return kWpiShape && (!constrained || kWpiBoxQP) && !(force && std::strcmp(force, "1w") == 0);
+  }
+  /** fp64 tile kernel (ddp_kernels_tile64.hpp: groups of up to 32 instances per workgroup, derivatives LDS-resident, backward
+      pass on v_mfma_f64_16x16x4 in natural layout, BoxQP included): 5 <= n <= 15 with a static input dimension m <= 8.  It
+      replaces the wave-per-instance kernel on these shapes; NMPC_HIP_DDP_KERNEL=wpi / 1w select the older kernels (A/B). */
+  static constexpr bool kTile64Shape = !Problem::kDynamicInput && Problem::kStateDim >= 5 && Problem::kStateDim <= 15
+                                       && Problem::kInputDimMax >= 1 && Problem::kInputDimMax <= 8;
+  static bool useTile64()
+  {
+    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
+    return kTile64Shape && !(force && (std::strcmp(force, "1w") == 0 || std::strcmp(force, "wpi") == 0));
   }
   static size_t wpiWorkspaceDoubles(int T)
   {
@@ -103,6 +114,10 @@ struct ModelOpsFor
     {
       return "ddp_solve_quad_kernel";
     }
+    if(useTile64())
+    {
+      return "ddp_solve_tile64_kernel";
+    }
     if(useWpi(false)) // (a box-constrained solve of an LDS-gains shape still goes to the lane kernel, see launchSolve)
     {
       return "ddp_solve_wpi_kernel";
@@ -119,6 +134,25 @@ struct ModelOpsFor
     const int grid = buf.Bp / kLanesPerBlock;
     const bool own = buf.params_batch != nullptr; // per-instance problem objects: separate instantiations (kOwnProblem)
     const bool con = cfg.with_input_constraint != 0;
+    if constexpr(kTile64Shape)
+    {
+      if(useTile64())
+      {
+        if(con && own)
+        {
+          return launchTile64<Problem, true, true>(problem, cfg, buf, stream);
+        }
+        if(con)
+        {
+          return launchTile64<Problem, true, false>(problem, cfg, buf, stream);
+        }
+        if(own)
+        {
+          return launchTile64<Problem, false, true>(problem, cfg, buf, stream);
+        }
+        return launchTile64<Problem, false, false>(problem, cfg, buf, stream);
+      }
+    }
     if constexpr(kWpiShape)
     {
       if(useWpi(con) && buf.wpi_ws != nullptr)

@@ -30,7 +30,7 @@
 //     Pb  = mma(VV, Fu)            rows < n: Vxx Fu,                 row n: Vx^T Fu            left-to-right association
 //     Qxx = Lxx + mma(Pa, Fx)      Qux = Lxu^T + mma(Pb, Fx)        Quu = Luu + mma(Pb, Fu)    Qx, Qu: L + row n of Pa, Pb
 //     Quu_F (= Quu + lambda I, or rebuilt from Vxx + lambda I: :421-441) and [Qux_reg | Qu] pass through the wave's LDS scratch:
-//     every lane factorises Quu_F (the lane kernels' ldltInPlace: same bits), lane (., j) solves column j            :500-517
+//     every lane factorises Quu_F (L D L^T, one reciprocal per pivot), lane (., j) solves column j                  :500-517
 //     Z   = mma(Quu, A)            C1 = mma(Z, A)                   T2 = mma(A, [Qux | Qu])    T3 = mma(Qux, A)
 //     VV' = (([Qxx | Qx] + C1) + T2) + T3;   entry (n, n) of C1 is k^T Quu k, of T2 is k^T Qu: dV for free        :522-526
 //     Vxx <- (Vxx + Vxx^T) / 2 with the transpose taken through the wave's LDS scratch                              :527
@@ -163,7 +163,8 @@ struct TileSolver64
   static constexpr int kWaveDoubles = wDump + 2;
   static constexpr int kLsAt = kWaveAt + kT64MatrixWaves * kWaveDoubles; //!< lsJ[NMPC_HIP_MAX_ALPHA][32]: cost of every trial
   static constexpr int kTraceAt = kLsAt + NMPC_HIP_MAX_ALPHA * kT64MaxGroup; //!< trace row of the running iteration, [field][32]
-  static constexpr int kFixedRaw = kTraceAt + NMPC_HIP_NTRACE * kT64MaxGroup;
+  static constexpr int kProfAt = kTraceAt + NMPC_HIP_NTRACE * kT64MaxGroup; //!< profiling builds: 16 tick counters of workgroup 0
+  static constexpr int kFixedRaw = kProfAt + 16;
   static constexpr int kRecAt = (kFixedRaw + 1) & ~1; //!< records: rec[2][G][stride]; before a sweep: [Vxx | Vx] per slot
   static constexpr int kTerm = (N + 1) * N; //!< terminal record: n + 1 columns of n rows
   // line search: ring of nominal records [depth][row][G] in the record area; rows of a timestep: k_i (m), K_i (m n, column-major),
@@ -252,6 +253,31 @@ struct TileSolver64
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
   }
+
+#ifdef NMPC_AMD_PROFILE_TILE64
+  // profiling build (scripts/profile_tile64.py): shader-clock ticks of workgroup 0, by role, returned through qp_free.
+  //  0 model wave: linearisation (its own work inside the sweeps)   1 model wave: waiting at the sweeps' barriers
+  //  2 matrix wave 1: backward steps   3 matrix wave 1: waiting at the sweeps' barriers   4 matrix wave 1: steps run
+  //  5 rolling lanes (wave 0, passes 0 / 1 / 3): compute   6 the same: waiting   7 matrix wave 1 as prefetcher: prefetch
+  //  8 the same: waiting   9 sweeps   10 passes   11 matrix wave 5 (shares SIMD 0 with the model wave): backward steps
+  NMPC_D void profAdd(int k, unsigned long long ticks, int who_wave) const
+  {
+    if(blockIdx.x == 0 && wave == who_wave && lane == 0)
+    {
+      reinterpret_cast<unsigned long long *>(lds + kProfAt)[k] += ticks;
+    }
+  }
+  NMPC_D static unsigned long long profNow()
+  {
+    return __builtin_readcyclecounter();
+  }
+#else
+  NMPC_D void profAdd(int, unsigned long long, int) const {}
+  NMPC_D static unsigned long long profNow()
+  {
+    return 0;
+  }
+#endif
 
   /** X^T Y over the first 4 S rows of X and Y, formed from zero (k ascending: an fma chain per entry). */
   template<int S>
@@ -505,40 +531,57 @@ struct TileSolver64
   {
     return lds + kRecAt + (i % kRingDepth) * (kRingRows * G);
   }
-  /** Prefetch role: rows of timestep i of every slot that takes part in the pass -> ring(i).  p_lane of p_count lanes. */
-  NMPC_D void prefetchNominal(int group, int i, int p_lane, int p_count) const
+  /** What a prefetching lane keeps for a whole pass: it serves ONE slot (p_lane % G) and every (p_count / G)-th row of it, so
+      everything that depends on the slot is computed once. */
+  struct PrefetchLane
   {
-    double * dst = ring(i);
-    const int total = kRingRows * G;
+    bool want; //!< the slot takes part in the pass and this lane has rows to fetch
+    int row0, row_step, slot;
+    const double *pk, *pK, *pX, *pU; //!< row 0 of timestep 0 of k_list_, K_list_, x_list, u_list of the slot's instance
+  };
+  NMPC_D PrefetchLane makePrefetchLane(int group, int p_lane, int p_count) const
+  {
+    PrefetchLane pl;
+    const int lanes_per_row_set = p_count / G; // (>= 1: p_count >= 64 >= G)
+    pl.slot = p_lane % G;
+    pl.row0 = p_lane / G;
+    pl.row_step = lanes_per_row_set;
+    pl.want = pl.row0 < lanes_per_row_set && slotI(sLs, pl.slot) != 0;
+    const int b = group * G + pl.slot;
+    const int sel = slotI(sSel, pl.slot);
+    const size_t tile = pl.want ? tileOf(b) : 0, ln = pl.want ? lnOf(b) : 0;
     const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;
-    constexpr int kBatch = 8; // loads in flight per lane
-    for(int e0 = p_lane; e0 < total; e0 += p_count * kBatch)
+    pl.pk = buf.kff + (tile * rows_u) * 64 + ln;
+    pl.pK = buf.Kfb + (tile * rows_u * N) * 64 + ln;
+    pl.pX = buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln;
+    pl.pU = buf.U + ((tile * 2 + sel) * rows_u) * 64 + ln;
+    return pl;
+  }
+  /** Prefetch role: this lane's rows of timestep i -> ring(i): element (row, slot) at row * G + slot. */
+  NMPC_D void prefetchNominal(const PrefetchLane & pl, int i) const
+  {
+    double * dst = ring(i) + pl.slot;
+    constexpr int kBatch = (kRingRows + 13) / 14 < 10 ? (kRingRows + 13) / 14 : 10; // loads in flight per lane: a whole timestep's
+                                                                                    // share when seven waves prefetch 32 slots
+    for(int r0 = pl.row0; r0 < kRingRows; r0 += pl.row_step * kBatch)
     {
       double v[kBatch];
       int at[kBatch];
 #pragma unroll
       for(int k = 0; k < kBatch; k++)
       {
-        const int e = e0 + k * p_count;
-        const int ec = e < total ? e : 0;
-        const int row = ec / G, slot = ec - row * G;
-        const bool want = e < total && slotI(sLs, slot) != 0;
-        const int b = group * G + slot;
-        const int sel = slotI(sSel, slot);
-        const size_t tile = tileOf(b), ln = lnOf(b);
-        // row < m: k_i | < m + m n: K_i | < m + m n + n: x_i | else u_i — one address expression, selected piecewise
+        const int row = r0 + k * pl.row_step;
+        const bool ok = pl.want && row < kRingRows;
+        // row < m: k_i | < m + m n: K_i | < m + m n + n: x_i | else u_i
         const bool is_k = row < MM, is_K = !is_k && row < kGainRows, is_x = !is_k && !is_K && row < kGainRows + N;
-        const double * base = is_k ? buf.kff : (is_K ? buf.Kfb : (is_x ? buf.X : buf.U));
-        const size_t per_tile = is_k ? rows_u : (is_K ? rows_u * N : (is_x ? 2 * rows_x : 2 * rows_u));
-        const size_t half_off = (is_k || is_K) ? 0 : (is_x ? sel * rows_x : sel * rows_u);
-        const size_t per_step = is_k ? MM : (is_K ? N * MM : (is_x ? N : MM));
-        const size_t r = is_k ? row : (is_K ? row - MM : (is_x ? row - kGainRows : row - kGainRows - N));
-        const double * src = base + (tile * per_tile + half_off + static_cast<size_t>(i) * per_step + r) * 64 + ln;
-        at[k] = want ? e : -1;
+        const double * base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
+        const int per_step = is_k ? MM : (is_K ? N * MM : (is_x ? N : MM));
+        const int r = is_k ? row : (is_K ? row - MM : (is_x ? row - kGainRows : row - kGainRows - N));
+        at[k] = ok ? row * G : -1;
         v[k] = 0;
-        if(want)
+        if(ok)
         {
-          v[k] = *src;
+          v[k] = base[static_cast<size_t>(i * per_step + r) * 64];
         }
       }
 #pragma unroll
@@ -566,6 +609,7 @@ struct TileSolver64
     double *Xo = nullptr, *Uo = nullptr, *Co = nullptr;
     const double * Uin = nullptr;
     const bool rolling = compute && active;
+    const PrefetchLane pl = makePrefetchLane(group, p_lane, p_count);
     if(rolling)
     {
       const size_t tile = tileOf(b), ln = lnOf(b);
@@ -583,14 +627,16 @@ struct TileSolver64
         }
       }
     }
+    profAdd(10, 1, 0);
 #pragma nounroll
     for(int j = 0; j < T + 2; j++)
     {
+      const unsigned long long pa = profNow();
       if(!compute)
       {
         if(!initial && j < T)
         {
-          prefetchNominal(group, j, p_lane, p_count);
+          prefetchNominal(pl, j);
         }
       }
       else if(active && j >= 2)
@@ -665,7 +711,10 @@ struct TileSolver64
         J += c;
         x = mine.stateEq(t, x, u);
       }
+      const unsigned long long pb = profNow();
+      profAdd(compute ? 5 : 7, pb - pa, compute ? 0 : 1);
       barrier();
+      profAdd(compute ? 6 : 8, profNow() - pb, compute ? 0 : 1);
     }
     if(rolling)
     {
@@ -737,6 +786,74 @@ struct TileSolver64
     mp.wn = (j < N) ? 0.5 : ((j == N) ? 1.0 : 0.0);
     mp.wt = (j < N) ? 0.5 : 0.0;
     return mp;
+  }
+
+  /** In-place L D L^T of the m x m matrix A (column-major, leading dimension MM, lower triangle) with the pivot rule of Eigen's
+      LLT: fails iff a pivot is <= 0, NaN passes.  The products L_kj d_j of a pivot row are formed once
+      (m^3 / 6 multiply-adds instead of the m^3 / 3 of the lane kernels' ldltInPlace, whose (L L) d association this differs from
+      by rounding); branch-free: after a failed pivot the factor is garbage and the caller stores nothing. */
+  NMPC_D static bool ldlt(double * A, double * inv_d)
+  {
+    bool ok = true;
+#pragma unroll
+    for(int k = 0; k < MM; k++)
+    {
+      double v[MM];
+      double d = A[k + k * MM];
+#pragma unroll
+      for(int j = 0; j < k; j++)
+      {
+        v[j] = A[k + j * MM] * A[j + j * MM];
+      }
+#pragma unroll
+      for(int j = 0; j < k; j++)
+      {
+        d -= A[k + j * MM] * v[j];
+      }
+      ok = ok && !(d <= 0.0);
+      A[k + k * MM] = d;
+      const double r = recipFast(d);
+      inv_d[k] = r;
+#pragma unroll
+      for(int i = k + 1; i < MM; i++)
+      {
+        double s = A[i + k * MM];
+#pragma unroll
+        for(int j = 0; j < k; j++)
+        {
+          s -= A[i + j * MM] * v[j];
+        }
+        A[i + k * MM] = s * r;
+      }
+    }
+    return ok;
+  }
+  /** (L D L^T) x = rhs in place. */
+  NMPC_D static void ldltSolve(const double * A, const double * inv_d, double * x)
+  {
+#pragma unroll
+    for(int i = 0; i < MM; i++)
+    {
+      double s = x[i];
+#pragma unroll
+      for(int j = 0; j < i; j++)
+      {
+        s -= A[i + j * MM] * x[j];
+      }
+      x[i] = s;
+    }
+#pragma unroll
+    for(int ii = 0; ii < MM; ii++)
+    {
+      const int i = MM - 1 - ii;
+      double s = x[i] * inv_d[i];
+#pragma unroll
+      for(int j = i + 1; j < MM; j++)
+      {
+        s -= A[j + i * MM] * x[j];
+      }
+      x[i] = s;
+    }
   }
 
   /** Row `sel` (0..3) of four values. */
@@ -923,13 +1040,13 @@ struct TileSolver64
     }
     else
     {
-      ok_now = Lane::template ldltInPlace<MM>(fac, inv_d, M);
+      ok_now = ldlt(fac, inv_d);
 #pragma unroll
       for(int a = 0; a < MM; a++)
       {
         col[a] = colQ[a];
       }
-      Lane::template ldltSolveInPlace<MM, 1>(fac, inv_d, M, col);
+      ldltSolve(fac, inv_d, col);
 #pragma unroll
       for(int a = 0; a < MM; a++)
       {
@@ -1071,6 +1188,7 @@ struct TileSolver64
     barrier(); // the records of timestep T - 1 are complete
     for(int i = T - 1; i >= 0; i--)
     {
+      const unsigned long long pa = profNow();
 #pragma nounroll
       for(int e = 0; e < kT64MaxPerWave; e++)
       {
@@ -1080,6 +1198,7 @@ struct TileSolver64
           bool ok = ((ok_mask >> e) & 1u) != 0;
           backwardStep(V0, ok, mp, rec(i & 1, slot), slot, uniform(slotI(sB, slot)), i, uniformD(slotF(sLambda, slot)));
           ok_mask = ok ? ok_mask : (ok_mask & ~(1u << e));
+          profAdd(4, 1, 1);
         }
         const v4d64 t = V0;
         V0 = V1;
@@ -1088,7 +1207,11 @@ struct TileSolver64
         V3 = V4;
         V4 = t;
       }
+      const unsigned long long pb = profNow();
+      profAdd(2, pb - pa, 1);
+      profAdd(11, pb - pa, 5);
       barrier(); // record i has been read by all, record i - 1 is complete
+      profAdd(3, profNow() - pb, 1);
     }
     if(lane == kStarLane)
     {
@@ -1116,8 +1239,10 @@ struct TileSolver64
     }
     barrier(); // the terminal records are complete
     barrier(); // (the matrix waves have taken them: the record area is free)
+    profAdd(9, 1, 0);
     for(int step = T - 1; step >= 0; step--)
     {
+      const unsigned long long pa = profNow();
       if(mine)
       {
         cur = next;
@@ -1131,7 +1256,10 @@ struct TileSolver64
           lineariseStep<false>(mine_p, slot, t0, step, cur);
         }
       }
+      const unsigned long long pb = profNow();
+      profAdd(0, pb - pa, 0);
       barrier(); // record `step` is complete (and record step + 1 has been read by all)
+      profAdd(1, profNow() - pb, 0);
     }
     barrier(); // record 0 has been read
   }
@@ -1649,12 +1777,25 @@ struct TileSolver64
     {
       waveScratch()[wZero + lane] = 0.0; // zero words (read by lanes outside a block) and dump words (written by them)
     }
+#ifdef NMPC_AMD_PROFILE_TILE64
+    if(threadIdx.x < 16)
+    {
+      reinterpret_cast<unsigned long long *>(lds + kProfAt)[threadIdx.x] = 0;
+    }
+#endif
     setup();
     const int n_groups = (buf.B + G - 1) / G;
     for(int group = static_cast<int>(blockIdx.x); group < n_groups; group += static_cast<int>(gridDim.x))
     {
       solveGroup(group);
     }
+#ifdef NMPC_AMD_PROFILE_TILE64
+    if(blockIdx.x == 0 && threadIdx.x < 16)
+    {
+      buf.qp_free[static_cast<size_t>(threadIdx.x) * 64] =
+          static_cast<unsigned>(reinterpret_cast<unsigned long long *>(lds + kProfAt)[threadIdx.x] >> 4);
+    }
+#endif
   }
 };
 

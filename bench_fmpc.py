@@ -265,10 +265,16 @@ def main(args, host_cores):
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(traffic_file):
             try:
+                from nmpc_amd import build as hip_build
+                src_hash = hip_build.source_hash()
                 entry = json.load(open(traffic_file)).get("fmpc")
-                if entry and entry.get("batch") == B and entry.get("horizon") == T:
+                if entry and entry.get("batch") == B and entry.get("horizon") == T and entry.get("source_hash") != src_hash:
+                    out["roofline"]["traffic_note"] = ("profiles/hbm_traffic.json holds a measurement of other device sources (hash %s, "
+                                                       "now %s): not used" % (entry.get("source_hash"), src_hash))
+                elif entry and entry.get("batch") == B and entry.get("horizon") == T:
                     out["roofline"]["traffic"] = entry.get("hbm_bytes_per_launch")
                     out["roofline"]["traffic_source"] = entry.get("source")
+                    out["roofline"]["traffic_source_hash"] = src_hash
                     if out["roofline"]["traffic"]:
                         out["roofline"]["hbm_frac_measured"] = out["roofline"]["traffic"] / (ric_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             except Exception:

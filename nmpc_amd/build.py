@@ -74,6 +74,19 @@ def _stale_objects():
     return out
 
 
+def source_hash() -> str:
+    """Hash of everything the device code is compiled from (translation units + headers, by relative path and content).
+    profiles/hbm_traffic.json keys its measured HBM traffic on it: bench.py refuses an entry measured on other sources."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))] + _headers()
+    for f in sorted(files, key=lambda f: os.path.relpath(f, ROOT)):
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

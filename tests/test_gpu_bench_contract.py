@@ -47,22 +47,45 @@ def test_default_line_has_the_contract_keys():
     assert cfg["m2"]["status_counts"].get("1", 0) >= 0.99 * 4096
     assert cfg["per_rank_solve_ms"] and abs(cfg["per_rank_solve_ms"][0] - d["ms_per_step"]) < 0.5 * d["ms_per_step"]
     assert cb["cores"] <= cb["host_cpus_affinity"] and "1" in cb["thread_sweep"]
+    # the timed job lasts at least half a second whatever --steps says: blocks of --steps steps
+    assert cfg["timed_seconds"] >= 0.5 and cfg["timed_steps_total"] == cfg["timed_blocks"] * 4 and cfg["timed_blocks"] >= 2
+    assert cfg["first_block_ms_per_step"] > 0
+    # both timing modes carry their own roofline (measured pass counts, kernel time, contract fraction)
+    for key in ("roofline_m1", "roofline_m2"):
+        r = d[key]
+        assert r["bound"] == "hbm" and r["kernel_ms_avg"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        assert r["backward_passes_per_iteration"] >= 1.0 and r["forward_passes_per_iteration"] > 0
+    # measured HBM traffic is only taken from profiles/hbm_traffic.json if it was measured on these device sources
+    from nmpc_amd import build as hip_build
+    if rf["traffic"] is not None:
+        assert rf["traffic_source_hash"] == hip_build.source_hash()
 
 
 def test_c4_runs_in_fp32_on_the_tile_kernel():
     d = run_bench("--workload", "c4", "--no-cpu-baseline")
     assert d["dtype"] == "f32" and "batch=8192" in d["metric"]
     assert d["roofline"]["kernel"] == "ddp_solve_tile32_kernel<quadrotor_f32>"
-    assert d["config"]["fp32_tolerance_value"] > 0
+    # the headline is the threshold an fp32 cost can resolve; the reference's default rides along as the secondary number
+    assert d["config"]["cost_update_thre"] == 1e-3 and "cost_update_thre = 0.001" in d["config"]["workload"]
+    assert d["config"]["default_threshold_value"] > 0 and d["config"]["default_threshold"]["roofline"]["frac"] > 0
     assert d["config"]["fp32_tolerance_m2"]["status_counts"].get("1", 0) >= 0.98 * 8192
-    d64 = run_bench("--workload", "c4f64", "--no-cpu-baseline")
-    assert d64["dtype"] == "f64" and d64["roofline"]["kernel"].startswith("ddp_solve_wpi_kernel")
-    assert d["value"] > 2.0 * d64["value"]
+    d64 = run_bench("--workload", "c4f64", "--cpu-seconds", "0.5")
+    assert d64["dtype"] == "f64" and d64["roofline"]["kernel"].startswith("ddp_solve_tile64_kernel")
+    assert d64["cpu_baseline"]["value"] > 0 and d64["value"] > d64["cpu_baseline"]["value"]
+    assert d["value"] > 0 and d64["value"] > 0
+
+
+def test_c5_runs_on_the_fp64_tile_kernel_with_a_cpu_baseline():
+    d = run_bench("--workload", "c5", "--cpu-seconds", "0.5")
+    assert d["dtype"] == "f64" and "batch=8192" in d["metric"] and "T=30" in d["metric"]
+    assert d["roofline"]["kernel"] == "ddp_solve_tile64_kernel<manipulator>"
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["value"] > d["cpu_baseline"]["value"]
+    assert d["config"]["timed_seconds"] >= 0.5
 
 
 def test_other_workload_and_modes_run():
-    d = run_bench("--workload", "c3", "--no-cpu-baseline")
-    assert "batch=1024" in d["metric"] and "cpu_baseline" not in d
+    d = run_bench("--workload", "c3", "--cpu-seconds", "0.5")
+    assert "batch=1024" in d["metric"] and d["cpu_baseline"]["value"] > 0
     d = run_bench("--mode", "m1", "--no-cpu-baseline")
     assert d["config"]["mode"] == "m1" and d["config"]["status_counts"].get("1", 0) == 0  # nobody may terminate early
 

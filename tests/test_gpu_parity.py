@@ -685,24 +685,44 @@ def test_quad_kernel_batch_threshold(monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------------
-# wave-per-instance kernel (ddp_kernels_wpi.hpp): quadrotor n = 12 m = 4, manipulator n = 14 m = 7
+# matrix-core kernels for 5 <= n <= 15: quadrotor n = 12 m = 4, manipulator n = 14 m = 7.  "tile64" = the fp64 tile kernel
+# (ddp_kernels_tile64.hpp, the default: groups of instances per workgroup, derivatives LDS-resident), "wpi" = the
+# wave-per-instance kernel it replaces on these shapes (ddp_kernels_wpi.hpp, NMPC_HIP_DDP_KERNEL=wpi: kept as A/B partner)
 # ---------------------------------------------------------------------------------------------------
+MATRIX_KERNELS = {"tile64": "ddp_solve_tile64_kernel", "wpi": "ddp_solve_wpi_kernel"}
+
+
+def _select_matrix_kernel(monkeypatch, kernel, group=None):
+    """kernel: "tile64" (default dispatch) or "wpi" (forced).  group: NMPC_HIP_DDP_TILE64_GROUP — at most that many instances
+    per workgroup (small test batches otherwise spread out to one instance per workgroup)."""
+    if kernel == "wpi":
+        monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", "wpi")
+    else:
+        monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    if group:
+        monkeypatch.setenv("NMPC_HIP_DDP_TILE64_GROUP", str(group))
+    else:
+        monkeypatch.delenv("NMPC_HIP_DDP_TILE64_GROUP", raising=False)
+
+
 def _large(model, B, seed):
     from nmpc_amd import workloads
     return workloads.quadrotor_batch(B=B, T=50, seed=seed) if model == "quadrotor" else \
         workloads.manipulator_batch(B=B, T=30, seed=seed)
 
 
+@pytest.mark.parametrize("kernel,group", [("tile64", 32), ("tile64", 5), ("tile64", None), ("wpi", None)])
 @pytest.mark.parametrize("model", ["quadrotor", "manipulator"])
 @pytest.mark.parametrize("cfg", [dict(max_iter=10), dict(max_iter=10, reg_type=2),
                                  dict(max_iter=6, alpha_list=np.array([1.0, 0.3, 0.1, 0.03]))])
-def test_wave_per_instance_kernel_vs_oracle_and_lane_kernel(model, cfg, monkeypatch):
-    """The matrix-core kernel against the oracle (bar of this file) and against the lane-per-instance kernel, which
-    evaluates the same arithmetic in the same order: identical discrete decisions, values to rounding."""
+def test_wave_per_instance_kernel_vs_oracle_and_lane_kernel(model, cfg, kernel, group, monkeypatch):
+    """The matrix-core kernels against the oracle (bar of this file) and against the lane-per-instance kernel, which
+    evaluates the same arithmetic up to the association of a few sums: identical discrete decisions, values to rounding.
+    tile64 with full groups (32 slots: five per matrix wave), ragged groups (5) and one instance per workgroup."""
     wl = _large(model, 96, 77)
-    monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    _select_matrix_kernel(monkeypatch, kernel, group)
     s = make_solver(wl, **cfg)
-    assert s.kernelName() == "ddp_solve_wpi_kernel"
+    assert s.kernelName() == MATRIX_KERNELS[kernel]
     s.solve(wl.t0, wl.x0, wl.u_init)
     ref = oracle_batch(wl, **cfg)
     check_against_oracle(wl, s, ref)
@@ -717,13 +737,16 @@ def test_wave_per_instance_kernel_vs_oracle_and_lane_kernel(model, cfg, monkeypa
         assert scaled_err(a, b) <= TOL
 
 
+@pytest.mark.parametrize("kernel", ["tile64", "wpi"])
 @pytest.mark.parametrize("model,B", [("quadrotor", 8192), ("manipulator", 8192)])
-def test_wave_per_instance_kernel_full_size(model, B):
+def test_wave_per_instance_kernel_full_size(model, B, kernel, monkeypatch):
     """BASELINE.json configs 4 / 5 at their per-GPU batch (fp64): a sample of instances against the oracle, and
     size-independent properties on all of them — the solve is a fixed point (re-solving from its own solution with
     max_iter = 1 changes nothing beyond rounding), costs are monotone along the trace."""
     wl = _large(model, B, 1234)
+    _select_matrix_kernel(monkeypatch, kernel)
     s = make_solver(wl, max_iter=6)
+    assert s.kernelName() == MATRIX_KERNELS[kernel]
     s.solve(wl.t0, wl.x0, wl.u_init)
     status, iters, tr = s.status(), s.iters(), s.trace()
     assert status.min() >= 0
@@ -742,11 +765,13 @@ def test_wave_per_instance_kernel_full_size(model, B):
     assert np.array_equal(X1, s.X())
 
 
-def test_wave_per_instance_kernel_mpc_loop():
-    """The receding-horizon driver on top of the wave-per-instance kernel (shift pattern), against the oracle's loop."""
+@pytest.mark.parametrize("kernel,group", [("tile64", 32), ("tile64", None), ("wpi", None)])
+def test_wave_per_instance_kernel_mpc_loop(kernel, group, monkeypatch):
+    """The receding-horizon driver on top of the matrix-core kernels (shift pattern), against the oracle's loop."""
     import nmpc_amd
     from nmpc_amd import workloads
 
+    _select_matrix_kernel(monkeypatch, kernel, group)
     wl = workloads.quadrotor_batch(B=16, T=50, seed=5)
     s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B)
     c = s.config()
@@ -760,29 +785,33 @@ def test_wave_per_instance_kernel_mpc_loop():
         assert scaled_err(log.x[b], r.x) <= 1e-7 and scaled_err(log.u0[b], r.u0) <= 1e-7
 
 
-@pytest.mark.parametrize("B,T,max_iter", [(1, 50, 5), (65, 70, 4), (7, 3, 6), (3, 50, 0)])
-def test_wave_per_instance_kernel_edge_shapes(B, T, max_iter):
-    """Ragged batches (grid = B wavefronts, tile-major results of the other 63 lanes untouched), horizons longer than one
-    wavefront of timesteps (the linearisation then runs in chunks of 64), tiny horizons, zero iterations."""
+@pytest.mark.parametrize("kernel,group", [("tile64", 32), ("tile64", 3), ("wpi", None)])
+@pytest.mark.parametrize("B,T,max_iter", [(1, 50, 5), (65, 70, 4), (7, 3, 6), (3, 50, 0), (33, 1, 3), (40, 2, 3)])
+def test_wave_per_instance_kernel_edge_shapes(B, T, max_iter, kernel, group, monkeypatch):
+    """Ragged batches (a last group / tile that is not full, results of the other lanes untouched), horizons longer than one
+    wavefront of timesteps, tiny horizons (T = 1, 2: shorter than the line search's prefetch ring), zero iterations."""
     from nmpc_amd import workloads
+    _select_matrix_kernel(monkeypatch, kernel, group)
     wl = workloads.quadrotor_batch(B=B, T=T, seed=100 + B)
     s = make_solver(wl, max_iter=max_iter)
     s.solve(wl.t0, wl.x0, wl.u_init)
     check_against_oracle(wl, s, oracle_batch(wl, max_iter=max_iter), check_gains=max_iter > 0)
 
 
-def test_wave_per_instance_kernel_failure_status():
+@pytest.mark.parametrize("kernel,group", [("tile64", 32), ("tile64", None), ("wpi", None)])
+def test_wave_per_instance_kernel_failure_status(kernel, group, monkeypatch):
     """Quu_F never positive definite (negative input weight): every backward pass fails, lambda climbs past lambda_max,
     status -1 with the same trace as the oracle (DDPSolver.hpp:196-204)."""
     import nmpc_amd
     from nmpc_amd import workloads
+    _select_matrix_kernel(monkeypatch, kernel, group)
     wl = workloads.manipulator_batch(B=24, T=30, seed=9)
     s = nmpc_amd.DDPSolverBatch(nmpc_amd.DDPProblemManipulator(wu=-1.0), wl.B)
     c = s.config()
     c.print_level = 0
     c.horizon_steps = wl.T
     c.lambda_max = 1e-3
-    assert s.kernelName() == "ddp_solve_wpi_kernel"
+    assert s.kernelName() == MATRIX_KERNELS[kernel]
     ok = s.solve(wl.t0, wl.x0, wl.u_init)
     ocfg = oracle.default_config(horizon_steps=wl.T, lambda_max=1e-3)
     ref = oracle.solve_batch("manipulator", ocfg, wl.x0, wl.u_init, params=oracle.default_params("manipulator", wu=-1.0))
@@ -792,9 +821,10 @@ def test_wave_per_instance_kernel_failure_status():
     np.testing.assert_array_equal(s.traceLast()[:, INT_COLS], ref.trace_last[:, INT_COLS])
 
 
+@pytest.mark.parametrize("kernel,group", [("tile64", 32), ("tile64", None), ("wpi", None)])
 @pytest.mark.parametrize("model", ["quadrotor", "manipulator"])
-def test_wave_per_instance_kernel_box_constrained(model, monkeypatch):
-    """with_input_constraint on the matrix-core kernel (every lane runs the same BoxQP, lane c solves column c of K on the
+def test_wave_per_instance_kernel_box_constrained(model, kernel, group, monkeypatch):
+    """with_input_constraint on the matrix-core kernels (every lane runs the same BoxQP, lane c solves column c of K on the
     free rows), against the oracle and the lane kernel.  Tightly boxed problems spend iterations in rejected line
     searches, where the reference algorithm is not decision-stable: indices are compared on the oracle's
     decision-stable set, as for the box-constrained vertical-motion problem."""
@@ -802,9 +832,9 @@ def test_wave_per_instance_kernel_box_constrained(model, monkeypatch):
     wl = (workloads.quadrotor_batch(B=64, T=50, seed=31, constrained=True) if model == "quadrotor" else
           workloads.manipulator_batch(B=64, T=30, seed=32, constrained=True))
     cfg = dict(with_input_constraint=True, max_iter=10)
-    monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    _select_matrix_kernel(monkeypatch, kernel, group)
     s = make_solver(wl, **cfg)
-    assert s.kernelName() == "ddp_solve_wpi_kernel"
+    assert s.kernelName() == MATRIX_KERNELS[kernel]
     s.solve(wl.t0, wl.x0, wl.u_init)
     ref = oracle_batch(wl, **cfg)
     stable, runs = decision_stable_mask(wl, ref, return_runs=True, **cfg)
@@ -1039,11 +1069,13 @@ def test_shift_loop_with_time_varying_limits(kernel, monkeypatch):
     assert bound_hits > 10  # the moving bound is active at the first input of many ticks
 
 
-def test_time_varying_input_limits_wave_per_instance_kernel():
-    """The same on the wave-per-instance kernel (quadrotor, rotor-thrust box that opens up along the horizon), one table for
+@pytest.mark.parametrize("kernel,group", [("tile64", 32), ("wpi", None)])
+def test_time_varying_input_limits_wave_per_instance_kernel(kernel, group, monkeypatch):
+    """The same on the matrix-core kernels (quadrotor, rotor-thrust box that opens up along the horizon), one table for
     the whole batch (every instance starts at t = 0)."""
     from nmpc_amd import workloads
 
+    _select_matrix_kernel(monkeypatch, kernel, group)
     wl = workloads.quadrotor_batch(B=48, T=50, seed=8)
     hover = 9.80665 / 4
     lo = np.array([[hover * (0.9 - 0.4 * i / wl.T)] * 4 for i in range(wl.T)])
@@ -1052,7 +1084,7 @@ def test_time_varying_input_limits_wave_per_instance_kernel():
     s = make_solver(wl, **cfg)
     s.setInputLimitsHorizon(lo, up)
     s.solve(wl.t0, wl.x0, wl.u_init)
-    assert s.kernelName() == "ddp_solve_wpi_kernel"
+    assert s.kernelName() == MATRIX_KERNELS[kernel]
     ocfg = oracle.default_config(horizon_steps=wl.T, with_input_constraint=1, max_iter=6)
     ref = oracle.solve_batch(wl.model, ocfg, wl.x0, wl.u_init, t0=wl.t0, lower=lo, upper=up, n_threads=8, want_alpha_hist=True)
     keep = np.ones(wl.B, bool)

@@ -76,6 +76,11 @@ struct TileSolver64
   static constexpr int KM = (MM + 3) / 4; //!< ... over input rows; also the registers of an m-row tile that hold anything
   static constexpr int rN = N / 4, qN = N % 4; //!< row n of a natural-layout tile: register rN of lane group qN
   static constexpr int kStarLane = 16 * qN + N; //!< the lane whose register rN is entry (n, n)
+  //! n + m <= 16 with n a multiple of 4 (the quadrotor): [Fx Fu] and [[Lxx Lxu],[Lxu^T Luu]] are ONE tile each, and all five
+  //! Q blocks come out of two products (G = VV^T F, Q = G^T F + L: 2 ceil(n/4) MFMAs instead of 5 ceil(n/4)); rows n .. n+m-1 of
+  //! Q are then whole registers of the lane groups (n % 4 == 0), i.e. Qux / Quu without any cross-lane-group move
+  static constexpr bool kAug = (N % 4 == 0) && (N + MM <= 16);
+  static constexpr int NA = N + MM;
   using Lane = InstanceSolver<Problem, kConstrained>; //!< the lane kernels' scalar helpers (ldltInPlace, boxQP): same bits
 
   using StateDimVector = typename Problem::StateDimVector;
@@ -757,9 +762,37 @@ struct TileSolver64
     for(int r = 0; r < 4; r++)
     {
       const int row = 4 * r + q;
-      mp.oFx[r] = (row < N && j < N) ? t[idFx + j * N + row] : 0;
-      mp.oFu[r] = (row < N && j < MM) ? t[idFu + j * N + row] : 0;
-      mp.oLxx[r] = (row < N && j < N) ? t[idLxx + j * N + row] : 0;
+      if constexpr(kAug)
+      {
+        // oFx: the augmented F = [Fx Fu]; oLxx: the augmented L = [[Lxx Lxu],[Lxu^T Luu]]
+        const int ju = (j >= N && j < NA) ? j - N : 0, ru = (row >= N && row < NA) ? row - N : 0, jx = j < N ? j : 0, rx = row < N ? row : 0;
+        mp.oFx[r] = (row < N) ? ((j < N) ? t[idFx + jx * N + rx] : ((j < NA) ? t[idFu + ju * N + rx] : 0)) : 0;
+        int l = 0;
+        if(row < N && j < N)
+        {
+          l = t[idLxx + jx * N + rx];
+        }
+        else if(row < N && j < NA)
+        {
+          l = t[idLxuT + rx * MM + ju]; // Lxu(row, j - n)
+        }
+        else if(row < NA && j < N)
+        {
+          l = t[idLxuT + jx * MM + ru]; // Lxu(j, row - n)
+        }
+        else if(row < NA && j < NA)
+        {
+          l = t[idLuu + ju * MM + ru];
+        }
+        mp.oLxx[r] = l;
+        mp.oFu[r] = 0;
+      }
+      else
+      {
+        mp.oFx[r] = (row < N && j < N) ? t[idFx + j * N + row] : 0;
+        mp.oFu[r] = (row < N && j < MM) ? t[idFu + j * N + row] : 0;
+        mp.oLxx[r] = (row < N && j < N) ? t[idLxx + j * N + row] : 0;
+      }
     }
 #pragma unroll
     for(int r = 0; r < KM; r++)
@@ -768,7 +801,7 @@ struct TileSolver64
       mp.oLxuT[r] = (a < MM && j < N) ? t[idLxuT + j * MM + a] : 0;
       mp.oLuu[r] = (a < MM && j < MM) ? t[idLuu + j * MM + a] : 0;
     }
-    mp.oLx = (j < N) ? t[idLx + j] : 0;
+    mp.oLx = (j < N) ? t[idLx + j] : ((kAug && j < NA) ? t[idLu + ((j >= N && j < NA) ? j - N : 0)] : 0); // (augmented: [Lx; Lu])
     mp.oLu = (j < MM) ? t[idLu + j] : 0;
     mp.oInvU = t[idInvU];
     if constexpr(kConstrained)
@@ -856,6 +889,15 @@ struct TileSolver64
     }
   }
 
+  /** The value of lane j + n of this lane's 16-lane row (whatever another lane holds when j + n >= 16: callers mask). */
+  NMPC_D double fromColumnPlusN(double v) const
+  {
+    const int src = ((lane & 48) | ((lane + N) & 15)) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+  }
+
   /** Row `sel` (0..3) of four values. */
   NMPC_D static double pick4(int sel, double a0, double a1, double a2, double a3)
   {
@@ -871,7 +913,81 @@ struct TileSolver64
   {
     const int q = lane >> 4, j = lane & 15;
     double * W = waveScratch();
-    // ---- operands from the record
+    // ---- operands from the record, Q terms (:386-408), regularisation (:421-441)
+    v4d64 Qxx, Qux = {0, 0, 0, 0}, Quu = {0, 0, 0, 0}, QuxR, QuuF;
+    double qxrow, qurow, inv_u;
+    if constexpr(kAug)
+    {
+      v4d64 F, L;
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        F[rr] = r[mp.oFx[rr]];
+        L[rr] = r[mp.oLxx[rr]];
+      }
+      const double lv = r[mp.oLx];
+      inv_u = r[mp.oInvU];
+      // G = VV^T F: rows < n: Vxx [Fx Fu], row n: Vx^T [Fx Fu];  Q = G^T F + L = [[Qxx Qxu],[Qux Quu]] (row n of G meets the
+      // zero row n of F).  Same products in the same order as the block form below: (Fu^T Vxx) Fx etc., left to right.
+      const v4d64 Gm = mma<KN>(VV, F);
+      v4d64 Q = mma<KN>(Gm, F);
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        Q[rr] = L[rr] + Q[rr];
+      }
+      const double qrow = lv + Gm[rN]; // lane group 0: Qx[j] (j < n), Qu[j - n] (n <= j < n + m)
+      qxrow = qrow;
+      qurow = fromColumnPlusN(qrow);
+      auto split = [&](const v4d64 & Qa, v4d64 & qux, v4d64 & quu)
+      {
+#pragma unroll
+        for(int rr = 0; rr < KM; rr++)
+        {
+          const double e = Qa[rN + rr]; // rows n + 4 rr + q: Qux in columns < n, Quu in columns n .. n+m-1
+          const double shifted = fromColumnPlusN(e);
+          qux[rr] = (j < N) ? e : 0.0;
+          quu[rr] = (j < MM) ? shifted : 0.0;
+        }
+      };
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        Qxx[rr] = (rr < rN) ? Q[rr] : 0.0; // (columns >= n hold Qxu: every use below selects columns < n)
+      }
+      split(Q, Qux, Quu);
+      QuxR = Qux;
+      QuuF = Quu;
+      if(cfg.reg_type == 2)
+      {
+        v4d64 VVr = VV;
+#pragma unroll
+        for(int rr = 0; rr < 4; rr++)
+        {
+          VVr[rr] = (4 * rr + q == j && j < N) ? VV[rr] + lambda : VV[rr];
+        }
+        const v4d64 G2 = mma<KN>(VVr, F);
+        v4d64 Q2 = mma<KN>(G2, F);
+#pragma unroll
+        for(int rr = 0; rr < 4; rr++)
+        {
+          Q2[rr] = L[rr] + Q2[rr];
+        }
+        QuxR = v4d64{0, 0, 0, 0};
+        QuuF = v4d64{0, 0, 0, 0};
+        split(Q2, QuxR, QuuF);
+      }
+      else if(cfg.reg_type == 1)
+      {
+#pragma unroll
+        for(int rr = 0; rr < KM; rr++)
+        {
+          QuuF[rr] = (4 * rr + q == j) ? Quu[rr] + lambda : Quu[rr];
+        }
+      }
+    }
+    else
+    {
     v4d64 Fx, Fu, Lxx, LxuT = {0, 0, 0, 0}, Luu = {0, 0, 0, 0};
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
@@ -886,14 +1002,14 @@ struct TileSolver64
       LxuT[rr] = r[mp.oLxuT[rr]];
       Luu[rr] = r[mp.oLuu[rr]];
     }
-    const double lx = r[mp.oLx], lu = r[mp.oLu], inv_u = r[mp.oInvU];
+    const double lx = r[mp.oLx], lu = r[mp.oLu];
+    inv_u = r[mp.oInvU];
 
-    // ---- Q terms    :386-408
     const v4d64 Pa = mma<KN>(VV, Fx);
     const v4d64 Pb = mma<KN>(VV, Fu);
-    v4d64 Qxx = mma<KN>(Pa, Fx);
-    v4d64 Qux = mma<KN>(Pb, Fx);
-    v4d64 Quu = mma<KN>(Pb, Fu);
+    Qxx = mma<KN>(Pa, Fx);
+    Qux = mma<KN>(Pb, Fx);
+    Quu = mma<KN>(Pb, Fu);
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
@@ -901,11 +1017,11 @@ struct TileSolver64
       Qux[rr] = LxuT[rr] + Qux[rr];
       Quu[rr] = Luu[rr] + Quu[rr];
     }
-    const double qxrow = lx + Pa[rN]; // lane group qN: Qx[j]
-    const double qurow = lu + Pb[rN]; // lane group qN: Qu[j]
+    qxrow = lx + Pa[rN]; // lane group qN: Qx[j]
+    qurow = lu + Pb[rN]; // lane group qN: Qu[j]
 
-    // ---- regularisation    :421-441
-    v4d64 QuxR = Qux, QuuF = Quu;
+    QuxR = Qux;
+    QuuF = Quu;
     if(cfg.reg_type == 2)
     {
       v4d64 VVr = VV;
@@ -931,6 +1047,7 @@ struct TileSolver64
       {
         QuuF[rr] = (4 * rr + q == j) ? Quu[rr] + lambda : Quu[rr];
       }
+    }
     }
 
     // ---- column exchange through the wave's scratch: lane (., c) gets column c of [Qux_reg | Qu], every lane gets Quu_F

@@ -17,6 +17,7 @@
 #pragma once
 
 #include <cstring>
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -55,6 +56,20 @@ public:
     {
       throw std::invalid_argument("need at least one device and one instance per shard");
     }
+    try
+    {
+      construct(model, batch, devices);
+    }
+    catch(...)
+    {
+      release(); // the destructor of a half-built object never runs: give back what was created so far
+      throw;
+    }
+  }
+
+private:
+  void construct(const std::string & model, int batch, const std::vector<int> & devices)
+  {
     size_t param_bytes = 0;
     int dyn = 0;
     check(nmpc_hip_ddp_model_info(model.c_str(), &n_, &m_, &dyn, &param_bytes));
@@ -102,13 +117,18 @@ public:
     }
   }
 
-  ~DDPSolverSharded()
+  /** Gives back every handle, stream, buffer and communicator (idempotent). */
+  void release()
   {
 #ifdef NMPC_AMD_WITH_RCCL
     for(ncclComm_t c : comms_)
     {
-      ncclCommDestroy(c);
+      if(c)
+      {
+        ncclCommDestroy(c);
+      }
     }
+    comms_.clear();
 #endif
     for(Shard & sh : shards_)
     {
@@ -122,8 +142,18 @@ public:
       (void)hipFree(sh.d_rec);
       (void)hipFree(sh.d_all);
       (void)hipFree(sh.scratch);
-      nmpc_hip_ddp_destroy(sh.handle);
+      if(sh.handle)
+      {
+        nmpc_hip_ddp_destroy(sh.handle);
+      }
     }
+    shards_.clear();
+  }
+
+public:
+  ~DDPSolverSharded()
+  {
+    release();
   }
   DDPSolverSharded(const DDPSolverSharded &) = delete;
   DDPSolverSharded & operator=(const DDPSolverSharded &) = delete;

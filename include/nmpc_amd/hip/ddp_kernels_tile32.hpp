@@ -1407,7 +1407,7 @@ struct ModelOpsTile32
   {
     new(out) Problem();
   }
-  static const char * kernelName(int)
+  static const char * kernelName(int, int)
   {
     return "ddp_solve_tile32_kernel";
   }

@@ -166,7 +166,8 @@ struct TileSolver64
   static constexpr int wZero = (wExchange > 16 * kTrLd ? wExchange : 16 * kTrLd); //!< two zeros, read by lanes outside a block
   static constexpr int wDump = wZero + 2; //!< written by lanes outside a block
   static constexpr int kWaveDoubles = wDump + 2;
-  static constexpr int kLsAt = kWaveAt + kT64MatrixWaves * kWaveDoubles; //!< lsJ[NMPC_HIP_MAX_ALPHA][32]: cost of every trial
+  static constexpr int kScratchPerWave = 1;
+  static constexpr int kLsAt = kWaveAt + kT64MatrixWaves * kScratchPerWave * kWaveDoubles; //!< lsJ[NMPC_HIP_MAX_ALPHA][32]: cost of every trial
   static constexpr int kTraceAt = kLsAt + NMPC_HIP_MAX_ALPHA * kT64MaxGroup; //!< trace row of the running iteration, [field][32]
   static constexpr int kProfAt = kTraceAt + NMPC_HIP_NTRACE * kT64MaxGroup; //!< profiling builds: 16 tick counters of workgroup 0
   static constexpr int kFixedRaw = kProfAt + 16;
@@ -226,9 +227,9 @@ struct TileSolver64
   {
     return lds + kRecAt + slot * kTerm;
   }
-  NMPC_D double * waveScratch() const
+  NMPC_D double * waveScratch(int which = 0) const
   {
-    return lds + kWaveAt + (wave - 1) * kWaveDoubles;
+    return lds + kWaveAt + ((wave - 1) * kScratchPerWave + which) * kWaveDoubles;
   }
   NMPC_D static void barrier()
   {
@@ -684,9 +685,9 @@ struct TileSolver64
             {
               s[a] += R[(MM + a + c * MM) * G] * dxc;
             }
-            if((c & 1) == 1)
+            if(MM * N > 64 && (c & 1) == 1)
             {
-              __builtin_amdgcn_sched_barrier(0); // two columns of K in registers at a time, not all of it
+              __builtin_amdgcn_sched_barrier(0); // large gain blocks: two columns of K in registers at a time, not all of it
             }
           }
 #pragma unroll
@@ -906,16 +907,25 @@ struct TileSolver64
     return (sel & 2) ? hi : lo;
   }
 
-  /** One timestep of one instance.  VV = [Vxx | Vx] in natural layout (in / out), r = the instance's record of this timestep,
-      ok = no factorisation of this sweep has failed yet (in / out); dV and the running max of |k| / (|u| + 1) accumulate in the
-      slot table (lane kStarLane).  Everything but the lane id is wave-uniform. */
-  NMPC_D void backwardStep(v4d64 & VV, bool & ok, const LaneMap & mp, const double * r, int slot, int b, int i, double lambda) const
+  /** Registers of one instance while its timestep is processed.  The step is written as PHASES (below) so that a wave can
+      run the phases of two instances back to back: between two fences the compiler sees two independent chains. */
+  struct StepCtx
   {
-    const int q = lane >> 4, j = lane & 15;
-    double * W = waveScratch();
-    // ---- operands from the record, Q terms (:386-408), regularisation (:421-441)
-    v4d64 Qxx, Qux = {0, 0, 0, 0}, Quu = {0, 0, 0, 0}, QuxR, QuuF;
+    v4d64 VV; //!< [Vxx | Vx] in natural layout (in / out)
+    v4d64 Qxx, Qux, Quu, QuxR, QuuF, qxcol, A, Vn;
     double qxrow, qurow, inv_u;
+    double fac[MM * MM], inv_d[MM], col[MM], colQ[MM];
+    double c1nn, t2nn, krel_i; //!< k^T Quu k, k^T Qu, |k| / (|u| + 1) of this timestep (lane kStarLane)
+    bool ok; //!< no factorisation of this sweep has failed yet (in / out)
+  };
+
+  /** Phase 1a: the record's operands, the Q terms (:386-408), Quu_F / Qux_reg as if unregularised.  Branch-free. */
+  NMPC_D void stepQTerms(StepCtx & c, const LaneMap & mp, const double * r, v4d64 & F0, v4d64 & F1, v4d64 & L0, v4d64 & L1, v4d64 & L2) const
+  {
+    const int j = lane & 15;
+    (void)j;
+    c.Qux = v4d64{0, 0, 0, 0};
+    c.Quu = v4d64{0, 0, 0, 0};
     if constexpr(kAug)
     {
       v4d64 F, L;
@@ -926,10 +936,10 @@ struct TileSolver64
         L[rr] = r[mp.oLxx[rr]];
       }
       const double lv = r[mp.oLx];
-      inv_u = r[mp.oInvU];
+      c.inv_u = r[mp.oInvU];
       // G = VV^T F: rows < n: Vxx [Fx Fu], row n: Vx^T [Fx Fu];  Q = G^T F + L = [[Qxx Qxu],[Qux Quu]] (row n of G meets the
       // zero row n of F).  Same products in the same order as the block form below: (Fu^T Vxx) Fx etc., left to right.
-      const v4d64 Gm = mma<KN>(VV, F);
+      const v4d64 Gm = mma<KN>(c.VV, F);
       v4d64 Q = mma<KN>(Gm, F);
 #pragma unroll
       for(int rr = 0; rr < 4; rr++)
@@ -937,159 +947,185 @@ struct TileSolver64
         Q[rr] = L[rr] + Q[rr];
       }
       const double qrow = lv + Gm[rN]; // lane group 0: Qx[j] (j < n), Qu[j - n] (n <= j < n + m)
-      qxrow = qrow;
-      qurow = fromColumnPlusN(qrow);
-      auto split = [&](const v4d64 & Qa, v4d64 & qux, v4d64 & quu)
-      {
-#pragma unroll
-        for(int rr = 0; rr < KM; rr++)
-        {
-          const double e = Qa[rN + rr]; // rows n + 4 rr + q: Qux in columns < n, Quu in columns n .. n+m-1
-          const double shifted = fromColumnPlusN(e);
-          qux[rr] = (j < N) ? e : 0.0;
-          quu[rr] = (j < MM) ? shifted : 0.0;
-        }
-      };
+      c.qxrow = qrow;
+      c.qurow = fromColumnPlusN(qrow);
 #pragma unroll
       for(int rr = 0; rr < 4; rr++)
       {
-        Qxx[rr] = (rr < rN) ? Q[rr] : 0.0; // (columns >= n hold Qxu: every use below selects columns < n)
+        c.Qxx[rr] = (rr < rN) ? Q[rr] : 0.0; // (columns >= n hold Qxu: every use below selects columns < n)
       }
-      split(Q, Qux, Quu);
-      QuxR = Qux;
-      QuuF = Quu;
-      if(cfg.reg_type == 2)
-      {
-        v4d64 VVr = VV;
-#pragma unroll
-        for(int rr = 0; rr < 4; rr++)
-        {
-          VVr[rr] = (4 * rr + q == j && j < N) ? VV[rr] + lambda : VV[rr];
-        }
-        const v4d64 G2 = mma<KN>(VVr, F);
-        v4d64 Q2 = mma<KN>(G2, F);
-#pragma unroll
-        for(int rr = 0; rr < 4; rr++)
-        {
-          Q2[rr] = L[rr] + Q2[rr];
-        }
-        QuxR = v4d64{0, 0, 0, 0};
-        QuuF = v4d64{0, 0, 0, 0};
-        split(Q2, QuxR, QuuF);
-      }
-      else if(cfg.reg_type == 1)
-      {
-#pragma unroll
-        for(int rr = 0; rr < KM; rr++)
-        {
-          QuuF[rr] = (4 * rr + q == j) ? Quu[rr] + lambda : Quu[rr];
-        }
-      }
+      splitAug(Q, c.Qux, c.Quu);
+      F0 = F;
+      L0 = L;
     }
     else
     {
-    v4d64 Fx, Fu, Lxx, LxuT = {0, 0, 0, 0}, Luu = {0, 0, 0, 0};
-#pragma unroll
-    for(int rr = 0; rr < 4; rr++)
-    {
-      Fx[rr] = r[mp.oFx[rr]];
-      Fu[rr] = r[mp.oFu[rr]];
-      Lxx[rr] = r[mp.oLxx[rr]];
-    }
-#pragma unroll
-    for(int rr = 0; rr < KM; rr++)
-    {
-      LxuT[rr] = r[mp.oLxuT[rr]];
-      Luu[rr] = r[mp.oLuu[rr]];
-    }
-    const double lx = r[mp.oLx], lu = r[mp.oLu];
-    inv_u = r[mp.oInvU];
-
-    const v4d64 Pa = mma<KN>(VV, Fx);
-    const v4d64 Pb = mma<KN>(VV, Fu);
-    Qxx = mma<KN>(Pa, Fx);
-    Qux = mma<KN>(Pb, Fx);
-    Quu = mma<KN>(Pb, Fu);
-#pragma unroll
-    for(int rr = 0; rr < 4; rr++)
-    {
-      Qxx[rr] = Lxx[rr] + Qxx[rr];
-      Qux[rr] = LxuT[rr] + Qux[rr];
-      Quu[rr] = Luu[rr] + Quu[rr];
-    }
-    qxrow = lx + Pa[rN]; // lane group qN: Qx[j]
-    qurow = lu + Pb[rN]; // lane group qN: Qu[j]
-
-    QuxR = Qux;
-    QuuF = Quu;
-    if(cfg.reg_type == 2)
-    {
-      v4d64 VVr = VV;
+      v4d64 Fx, Fu, Lxx, LxuT = {0, 0, 0, 0}, Luu = {0, 0, 0, 0};
 #pragma unroll
       for(int rr = 0; rr < 4; rr++)
       {
-        VVr[rr] = (4 * rr + q == j && j < N) ? VV[rr] + lambda : VV[rr];
+        Fx[rr] = r[mp.oFx[rr]];
+        Fu[rr] = r[mp.oFu[rr]];
+        Lxx[rr] = r[mp.oLxx[rr]];
       }
-      const v4d64 Pbr = mma<KN>(VVr, Fu);
-      QuxR = mma<KN>(Pbr, Fx);
-      QuuF = mma<KN>(Pbr, Fu);
-#pragma unroll
-      for(int rr = 0; rr < 4; rr++)
-      {
-        QuxR[rr] = LxuT[rr] + QuxR[rr];
-        QuuF[rr] = Luu[rr] + QuuF[rr];
-      }
-    }
-    else if(cfg.reg_type == 1)
-    {
 #pragma unroll
       for(int rr = 0; rr < KM; rr++)
       {
-        QuuF[rr] = (4 * rr + q == j) ? Quu[rr] + lambda : Quu[rr];
+        LxuT[rr] = r[mp.oLxuT[rr]];
+        Luu[rr] = r[mp.oLuu[rr]];
+      }
+      const double lx = r[mp.oLx], lu = r[mp.oLu];
+      c.inv_u = r[mp.oInvU];
+      const v4d64 Pa = mma<KN>(c.VV, Fx);
+      const v4d64 Pb = mma<KN>(c.VV, Fu);
+      c.Qxx = mma<KN>(Pa, Fx);
+      c.Qux = mma<KN>(Pb, Fx);
+      c.Quu = mma<KN>(Pb, Fu);
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        c.Qxx[rr] = Lxx[rr] + c.Qxx[rr];
+        c.Qux[rr] = LxuT[rr] + c.Qux[rr];
+        c.Quu[rr] = Luu[rr] + c.Quu[rr];
+      }
+      c.qxrow = lx + Pa[rN]; // lane group qN: Qx[j]
+      c.qurow = lu + Pb[rN]; // lane group qN: Qu[j]
+      F0 = Fx;
+      F1 = Fu;
+      L0 = Lxx;
+      L1 = LxuT;
+      L2 = Luu;
+    }
+    c.QuxR = c.Qux;
+    c.QuuF = c.Quu;
+  }
+  /** Rows n .. n+m-1 of the augmented Q: Qux in columns < n, Quu in columns n .. n+m-1 (moved to columns 0 .. m-1). */
+  NMPC_D void splitAug(const v4d64 & Qa, v4d64 & qux, v4d64 & quu) const
+  {
+    const int j = lane & 15;
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      const double e = Qa[(rN + rr) < 4 ? rN + rr : 0];
+      const double shifted = fromColumnPlusN(e);
+      qux[rr] = (j < N) ? e : 0.0;
+      quu[rr] = (j < MM) ? shifted : 0.0;
+    }
+  }
+  /** Phase 1b: regularisation, reg_type 2: Quu_F and Qux_reg rebuilt from Vxx + lambda I    :421-441 */
+  NMPC_D void stepRegType2(StepCtx & c, double lambda, const v4d64 & F0, const v4d64 & F1, const v4d64 & L0, const v4d64 & L1,
+                           const v4d64 & L2) const
+  {
+    const int q = lane >> 4, j = lane & 15;
+    v4d64 VVr = c.VV;
+#pragma unroll
+    for(int rr = 0; rr < 4; rr++)
+    {
+      VVr[rr] = (4 * rr + q == j && j < N) ? c.VV[rr] + lambda : c.VV[rr];
+    }
+    if constexpr(kAug)
+    {
+      const v4d64 G2 = mma<KN>(VVr, F0);
+      v4d64 Q2 = mma<KN>(G2, F0);
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        Q2[rr] = L0[rr] + Q2[rr];
+      }
+      c.QuxR = v4d64{0, 0, 0, 0};
+      c.QuuF = v4d64{0, 0, 0, 0};
+      splitAug(Q2, c.QuxR, c.QuuF);
+    }
+    else
+    {
+      const v4d64 Pbr = mma<KN>(VVr, F1);
+      c.QuxR = mma<KN>(Pbr, F0);
+      c.QuuF = mma<KN>(Pbr, F1);
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        c.QuxR[rr] = L1[rr] + c.QuxR[rr];
+        c.QuuF[rr] = L2[rr] + c.QuuF[rr];
       }
     }
+  }
+  /** ... reg_type 1: Quu_F = Quu + lambda I */
+  NMPC_D void stepRegType1(StepCtx & c, double lambda) const
+  {
+    const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      c.QuuF[rr] = (4 * rr + q == j) ? c.Quu[rr] + lambda : c.Quu[rr];
     }
-
-    // ---- column exchange through the wave's scratch: lane (., c) gets column c of [Qux_reg | Qu], every lane gets Quu_F
+  }
+  /** Phase 1c: column exchange through the wave's scratch W, write side: lane (., c) will get column c of [Qux_reg | Qu],
+      every lane Quu_F; Qx goes from a row of lanes to a column. */
+  NMPC_D void stepExchangeWrite(const StepCtx & c, double * W) const
+  {
+    const int q = lane >> 4, j = lane & 15;
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
       const int a = 4 * rr + q;
-      W[(a < MM && j < N) ? wQQ + 8 * j + a : wDump] = QuxR[rr];
-      W[(a < MM && j < MM) ? wF + 8 * j + a : wDump] = QuuF[rr];
+      W[(a < MM && j < N) ? wQQ + 8 * j + a : wDump] = c.QuxR[rr];
+      W[(a < MM && j < MM) ? wF + 8 * j + a : wDump] = c.QuuF[rr];
     }
-    W[(q == qN && j < MM) ? wQQ + 8 * N + j : wDump] = qurow;
-    W[(q == qN && j < N) ? wX + 4 * (j & 3) + (j >> 2) : wDump] = qxrow;
-    fence();
-    double fac[MM * MM], inv_d[MM], col[MM], colQ[MM];
+    W[(q == qN && j < MM) ? wQQ + 8 * N + j : wDump] = c.qurow;
+    W[(q == qN && j < N) ? wX + 4 * (j & 3) + (j >> 2) : wDump] = c.qxrow;
+  }
+  /** Phase 2: ... read side. */
+  NMPC_D void stepExchangeRead(StepCtx & c, const double * W) const
+  {
+    const int q = lane >> 4, j = lane & 15;
 #pragma unroll
-    for(int c = 0; c < MM; c++)
+    for(int cc = 0; cc < MM; cc++)
     {
 #pragma unroll
       for(int a = 0; a < MM; a++)
       {
-        fac[a + c * MM] = (kConstrained || a >= c) ? W[wF + 8 * c + a] : 0.0; // (the factorisation reads the lower triangle)
+        c.fac[a + cc * MM] = (kConstrained || a >= cc) ? W[wF + 8 * cc + a] : 0.0; // (the factorisation reads the lower triangle)
       }
     }
     const int jc = (j < N) ? j : N;
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
-      colQ[a] = W[wQQ + 8 * jc + a];
-      inv_d[a] = 0;
+      c.colQ[a] = W[wQQ + 8 * jc + a];
+      c.inv_d[a] = 0;
     }
     // Qx as column n of the accumulator of the value update: lane (q, n) register r <- Qx[4 r + q]
-    v4d64 qxcol;
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
-      qxcol[rr] = W[(j == N) ? wX + 4 * q + rr : wZero];
+      c.qxcol[rr] = W[(j == N) ? wX + 4 * q + rr : wZero];
     }
-    fence();
-
-    // ---- gains    :500-517
+  }
+  /** Phase 3a, unconstrained: every lane factorises Quu_F, lane (., c) solves column c    :500-517.  Branch-free. */
+  NMPC_D void stepGains(StepCtx & c) const
+  {
+    const bool ok_now = ldlt(c.fac, c.inv_d);
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      c.col[a] = c.colQ[a];
+    }
+    ldltSolve(c.fac, c.inv_d, c.col);
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      c.col[a] = -1 * c.col[a];
+    }
+    c.ok = c.ok && ok_now; // (after a failure the slot computes on garbage and stores nothing)
+  }
+  /** Phase 3a, box-constrained (:450-497). */
+  NMPC_D void stepGainsBoxQP(StepCtx & c, const LaneMap & mp, const double * r, double * W, int slot, int b, int i) const
+  {
+    const int j = lane & 15;
+    double (&fac)[MM * MM] = c.fac;
+    double (&col)[MM] = c.col;
+    double (&colQ)[MM] = c.colQ;
     bool ok_now = true;
-    if constexpr(kConstrained)
     {
       // every lane solves the same small QP (BoxQP.h:141-347, the lane kernel's implementation)    :450-497
       double initial_k[MM], lo[MM], up[MM], Qu[MM];
@@ -1155,25 +1191,15 @@ struct TileSolver64
       }
       fence();
     }
-    else
-    {
-      ok_now = ldlt(fac, inv_d);
-#pragma unroll
-      for(int a = 0; a < MM; a++)
-      {
-        col[a] = colQ[a];
-      }
-      ldltSolve(fac, inv_d, col);
-#pragma unroll
-      for(int a = 0; a < MM; a++)
-      {
-        col[a] = -1 * col[a];
-      }
-    }
-    ok = ok && ok_now; // (after a failure the slot computes on garbage and stores nothing)
-
-    // ---- A = [K | k] and QQ = [Qux | Qu] in natural layout
-    v4d64 A = {0, 0, 0, 0}, QQ = {0, 0, 0, 0};
+    c.ok = c.ok && ok_now;
+  }
+  /** Phase 3b: A = [K | k], QQ = [Qux | Qu] in natural layout; the cost-to-go (:522-527) up to the symmetrisation; rows of the new
+      value function to the scratch.  Branch-free. */
+  NMPC_D void stepValueUpdate(StepCtx & c, double * W) const
+  {
+    const int q = lane >> 4, j = lane & 15;
+    v4d64 QQ = {0, 0, 0, 0};
+    c.A = v4d64{0, 0, 0, 0};
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
@@ -1181,62 +1207,66 @@ struct TileSolver64
 #pragma unroll
       for(int e = 0; e < 4; e++)
       {
-        g[e] = (4 * rr + e < MM) ? col[(4 * rr + e < MM) ? 4 * rr + e : 0] : 0.0;
-        c4[e] = (4 * rr + e < MM) ? colQ[(4 * rr + e < MM) ? 4 * rr + e : 0] : 0.0;
+        g[e] = (4 * rr + e < MM) ? c.col[(4 * rr + e < MM) ? 4 * rr + e : 0] : 0.0;
+        c4[e] = (4 * rr + e < MM) ? c.colQ[(4 * rr + e < MM) ? 4 * rr + e : 0] : 0.0;
       }
       const double gq = pick4(q, g[0], g[1], g[2], g[3]);
       const double cq = pick4(q, c4[0], c4[1], c4[2], c4[3]);
-      A[rr] = (j <= N) ? gq : 0.0;
-      QQ[rr] = (j < N) ? Qux[rr] : ((j == N) ? cq : 0.0); // (column n of colQ is Qu; unregularised Qux elsewhere)
+      c.A[rr] = (j <= N) ? gq : 0.0;
+      QQ[rr] = (j < N) ? c.Qux[rr] : ((j == N) ? cq : 0.0); // (column n of colQ is Qu; unregularised Qux elsewhere)
     }
-
-    // ---- cost-to-go    :522-527
-    const v4d64 Z = mma<KM>(Quu, A);
-    const v4d64 C1 = mma<KM>(Z, A);
-    const v4d64 T2 = mma<KM>(A, QQ);
-    const v4d64 T3 = mma<KM>(Qux, A);
-    v4d64 Vn;
+    const v4d64 Z = mma<KM>(c.Quu, c.A);
+    const v4d64 C1 = mma<KM>(Z, c.A);
+    const v4d64 T2 = mma<KM>(c.A, QQ);
+    const v4d64 T3 = mma<KM>(c.Qux, c.A);
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
-      const double c0 = (j < N) ? Qxx[rr] : qxcol[rr];
-      Vn[rr] = ((c0 + C1[rr]) + T2[rr]) + T3[rr];
+      const double c0 = (j < N) ? c.Qxx[rr] : c.qxcol[rr];
+      c.Vn[rr] = ((c0 + C1[rr]) + T2[rr]) + T3[rr];
     }
-    Vn[rN] = (q == qN) ? 0.0 : Vn[rN]; // row n: k^T (...), not part of the value function
-    // Vxx <- (Vxx + Vxx^T) / 2: rows to the scratch, columns back
+    c.Vn[rN] = (q == qN) ? 0.0 : c.Vn[rN]; // row n: k^T (...), not part of the value function
+    c.c1nn = C1[rN]; // lane kStarLane: k^T Quu k, k^T Qu    :522-523
+    c.t2nn = T2[rN];
+    double kn = 0; // |k| / (|u| + 1)    :217-221   (lanes of column n hold k)
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      kn += c.col[a] * c.col[a];
+    }
+    const double knorm = (M == 1) ? fabs(c.col[0]) : sqrt(kn);
+    c.krel_i = knorm * c.inv_u;
+    // Vxx <- (Vxx + Vxx^T) / 2: rows to the scratch, columns back (phase 4)
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
-      W[wT + (4 * rr + q) * kTrLd + j] = Vn[rr];
+      W[wT + (4 * rr + q) * kTrLd + j] = c.Vn[rr];
     }
-    fence();
+  }
+  /** Phase 4: the symmetrised value function; dV and the running max of |k| / (|u| + 1) in the slot table (lane kStarLane; the
+      other lanes update a dump word: no branch). */
+  NMPC_D void stepFinish(StepCtx & c, const LaneMap & mp, double * W, int slot) const
+  {
+    const int q = lane >> 4, j = lane & 15;
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
       const double vt = W[(4 * rr + q < N && j < N) ? wT + j * kTrLd + 4 * rr + q : wZero];
-      VV[rr] = mp.wn * Vn[rr] + mp.wt * vt;
+      c.VV[rr] = mp.wn * c.Vn[rr] + mp.wt * vt;
     }
-    fence();
-
-    // ---- |k| / (|u| + 1)    :217-221   (lanes of column n hold k)
-    {
-      double kn = 0;
-#pragma unroll
-      for(int a = 0; a < MM; a++)
-      {
-        kn += col[a] * col[a];
-      }
-      const double knorm = (M == 1) ? fabs(col[0]) : sqrt(kn);
-      if(lane == kStarLane) // entry (n, n) of T2 is k^T Qu, of C1 k^T Quu k    :522-523
-      {
-        slotF(sDV0, slot) += T2[rN];
-        slotF(sDV1, slot) += 0.5 * C1[rN];
-        slotF(sKrel, slot) = fmax(slotF(sKrel, slot), knorm * inv_u);
-      }
-    }
-
-    // ---- k_i, K_i -> kff / Kfb (:529-530); not after a failed factorisation: backwardPass() returned before storing (:505-508)
-    if(ok && j <= N)
+    const bool star = lane == kStarLane;
+    double * dv0 = star ? &slotF(sDV0, slot) : W + wDump;
+    double * dv1 = star ? &slotF(sDV1, slot) : W + wDump + 1;
+    double * kr = star ? &slotF(sKrel, slot) : W + wDump;
+    *dv0 += c.t2nn;
+    *dv1 += 0.5 * c.c1nn;
+    *kr = fmax(*kr, c.krel_i);
+  }
+  /** k_i, K_i -> kff / Kfb (:529-530); not after a failed factorisation: backwardPass() returned before storing (:505-508). */
+  NMPC_D void stepStoreGains(const StepCtx & c, int b, int i) const
+  {
+    const int q = lane >> 4, j = lane & 15;
+    if(c.ok && j <= N)
     {
       const size_t tile = tileOf(b), ln = lnOf(b);
       const size_t rows_u = static_cast<size_t>(T) * MM;
@@ -1248,25 +1278,64 @@ struct TileSolver64
         {
           if(j == N)
           {
-            buf.kff[(tile * rows_u + static_cast<size_t>(i) * MM + a) * 64 + ln] = A[rr];
+            buf.kff[(tile * rows_u + static_cast<size_t>(i) * MM + a) * 64 + ln] = c.A[rr];
           }
           else
           {
-            buf.Kfb[(tile * rows_u * N + static_cast<size_t>(i) * N * MM + a + j * MM) * 64 + ln] = A[rr];
+            buf.Kfb[(tile * rows_u * N + static_cast<size_t>(i) * N * MM + a + j * MM) * 64 + ln] = c.A[rr];
           }
         }
       }
     }
   }
 
+  /** One timestep of one instance.  VV = [Vxx | Vx] in natural layout (in / out), r = the instance's record of this timestep,
+      ok = no factorisation of this sweep has failed yet (in / out).  Everything but the lane id is wave-uniform. */
+  NMPC_D void backwardStep(v4d64 & VV, bool & ok, const LaneMap & mp, const double * r, int slot, int b, int i, double lambda) const
+  {
+    double * W = waveScratch(0);
+    StepCtx c;
+    c.VV = VV;
+    c.ok = ok;
+    v4d64 F0, F1, L0, L1, L2;
+    stepQTerms(c, mp, r, F0, F1, L0, L1, L2);
+    if(cfg.reg_type == 2)
+    {
+      stepRegType2(c, lambda, F0, F1, L0, L1, L2);
+    }
+    else if(cfg.reg_type == 1)
+    {
+      stepRegType1(c, lambda);
+    }
+    stepExchangeWrite(c, W);
+    fence();
+    stepExchangeRead(c, W);
+    fence();
+    if constexpr(kConstrained)
+    {
+      stepGainsBoxQP(c, mp, r, W, slot, b, i);
+    }
+    else
+    {
+      stepGains(c);
+    }
+    stepValueUpdate(c, W);
+    fence();
+    stepFinish(c, mp, W, slot);
+    fence();
+    stepStoreGains(c, b, i);
+    VV = c.VV;
+    ok = c.ok;
+  }
   /** The sweep of the matrix waves (barriers are shared with the model wave's loop, backwardSweepModel).
       The value functions of the wave's (up to five) slots stay in registers for the whole sweep.  The slot loop is a real loop
-      — one copy of the step in the instruction cache — that always works on V0 and then rotates V0 <- V1 <- ... <- V4 <- V0
-      (register moves; an array indexed by the trip count would live in scratch memory): after five trips every value function
-      is back in its place. */
+      — one copy of the step in the instruction cache — that always works on the first register(s) and then rotates them
+      (register moves; an array indexed by the trip count would live in scratch memory): after the last trip every value
+      function is back in its place.  (Two slots per trip with their steps interleaved phase by phase was measured for the
+      quadrotor: no gain — the SIMDs are busy, not waiting.) */
   NMPC_D void backwardSweepMatrix() const
   {
-    static_assert(kT64MaxPerWave == 5, "the rotation below is written for five slots per wave");
+    static_assert(kT64MaxPerWave == 5, "the rotations below are written for five slots per wave");
     const LaneMap mp = makeLaneMap();
     const int q = lane >> 4, j = lane & 15;
     const int mw = wave - 1;
@@ -1306,23 +1375,25 @@ struct TileSolver64
     for(int i = T - 1; i >= 0; i--)
     {
       const unsigned long long pa = profNow();
-#pragma nounroll
-      for(int e = 0; e < kT64MaxPerWave; e++)
       {
-        const int slot = mw + kT64MatrixWaves * e;
-        if(slot < G && uniform(slotI(sBw, slot)) != 0)
+#pragma nounroll
+        for(int e = 0; e < kT64MaxPerWave; e++)
         {
-          bool ok = ((ok_mask >> e) & 1u) != 0;
-          backwardStep(V0, ok, mp, rec(i & 1, slot), slot, uniform(slotI(sB, slot)), i, uniformD(slotF(sLambda, slot)));
-          ok_mask = ok ? ok_mask : (ok_mask & ~(1u << e));
-          profAdd(4, 1, 1);
+          const int slot = mw + kT64MatrixWaves * e;
+          if(slot < G && uniform(slotI(sBw, slot)) != 0)
+          {
+            bool ok = ((ok_mask >> e) & 1u) != 0;
+            backwardStep(V0, ok, mp, rec(i & 1, slot), slot, uniform(slotI(sB, slot)), i, uniformD(slotF(sLambda, slot)));
+            ok_mask = ok ? ok_mask : (ok_mask & ~(1u << e));
+            profAdd(4, 1, 1);
+          }
+          const v4d64 t = V0;
+          V0 = V1;
+          V1 = V2;
+          V2 = V3;
+          V3 = V4;
+          V4 = t;
         }
-        const v4d64 t = V0;
-        V0 = V1;
-        V1 = V2;
-        V2 = V3;
-        V3 = V4;
-        V4 = t;
       }
       const unsigned long long pb = profNow();
       profAdd(2, pb - pa, 1);
@@ -1892,7 +1963,7 @@ struct TileSolver64
   {
     if(wave != 0 && lane < 4)
     {
-      waveScratch()[wZero + lane] = 0.0; // zero words (read by lanes outside a block) and dump words (written by them)
+      waveScratch(0)[wZero + lane] = 0.0; // zero words (read by lanes outside a block) and dump words (written by them)
     }
 #ifdef NMPC_AMD_PROFILE_TILE64
     if(threadIdx.x < 16)

@@ -33,8 +33,9 @@ struct ModelOps
   void (*input_dims)(const void * params, double t0, int T, int * out);
   //! dt() of the problem object
   double (*dt)(const void * params);
-  //! name of the kernel launch_solve launches for a batch of `batch` instances (lane mapping, see launchSolve)
-  const char * (*kernel_name)(int batch);
+  //! name of the kernel launch_solve launches for a batch of `batch` instances with / without input constraints (lane
+  //! mapping, see launchSolve)
+  const char * (*kernel_name)(int batch, int constrained);
   //! launches the receding-horizon advance step (mpc_kernels.hpp) between two solves
   hipError_t (*launch_mpc_advance)(const void * params,
                                    const DeviceBuffers & buf,

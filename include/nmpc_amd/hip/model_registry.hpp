@@ -55,10 +55,21 @@ struct ModelOpsFor
       replaces the wave-per-instance kernel on these shapes; NMPC_HIP_DDP_KERNEL=wpi / 1w select the older kernels (A/B). */
   static constexpr bool kTile64Shape = !Problem::kDynamicInput && Problem::kStateDim >= 5 && Problem::kStateDim <= 15
                                        && Problem::kInputDimMax >= 1 && Problem::kInputDimMax <= 8;
-  static bool useTile64()
+  static bool useTile64(bool constrained)
   {
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
-    return kTile64Shape && !(force && (std::strcmp(force, "1w") == 0 || std::strcmp(force, "wpi") == 0));
+    if(!kTile64Shape || (force && (std::strcmp(force, "1w") == 0 || std::strcmp(force, "wpi") == 0)))
+    {
+      return false;
+    }
+    if(force && std::strcmp(force, "tile64") == 0)
+    {
+      return true;
+    }
+    // Box-constrained solves: every lane of a wave runs the BoxQP of its instance, which dominates the step and does not
+    // care how the waves are grouped — measured (scripts/constrained_tile64_ab.py, 8192 instances) the wave-per-instance
+    // kernel is 20 % faster there, so it keeps them where it exists (n >= 9); the tile kernel takes them for 5 <= n <= 8.
+    return !(constrained && kWpiBoxQP);
   }
   static size_t wpiWorkspaceDoubles(int T)
   {
@@ -107,18 +118,18 @@ struct ModelOpsFor
     }
     return batch_padded <= kQuadMaxBatch || (force && std::strcmp(force, "quad") == 0);
   }
-  static const char * kernelName(int batch)
+  static const char * kernelName(int batch, int constrained)
   {
     const int padded = (batch + kLanesPerBlock - 1) / kLanesPerBlock * kLanesPerBlock;
     if(useQuad(padded, false))
     {
       return "ddp_solve_quad_kernel";
     }
-    if(useTile64())
+    if(useTile64(constrained != 0))
     {
       return "ddp_solve_tile64_kernel";
     }
-    if(useWpi(false)) // (a box-constrained solve of an LDS-gains shape still goes to the lane kernel, see launchSolve)
+    if(useWpi(constrained != 0))
     {
       return "ddp_solve_wpi_kernel";
     }
@@ -136,7 +147,7 @@ struct ModelOpsFor
     const bool con = cfg.with_input_constraint != 0;
     if constexpr(kTile64Shape)
     {
-      if(useTile64())
+      if(useTile64(con))
       {
         if(con && own)
         {

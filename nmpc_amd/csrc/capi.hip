@@ -1388,7 +1388,7 @@ extern "C"
     {
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output pointer");
     }
-    *name = s->ops->kernel_name(s->B);
+    *name = s->ops->kernel_name(s->B, s->cfg.with_input_constraint != 0 ? 1 : 0);
     return NMPC_HIP_OK;
   }
 

@@ -141,6 +141,8 @@ struct nmpc_hip_fmpc_solver
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   bool solved = false;
+  int solved_max_iter = 0; // row stride of the trace the last solve wrote (set_config may change cfg.max_iter afterwards)
+  double * solved_trace = nullptr; // ... and the buffer it wrote it to (a larger max_iter allocates a new one)
   std::string kernel_names;
   // config.time_kernels: one event pair per launch of the last solve, with its kernel class
   std::vector<hipEvent_t> kev;
@@ -343,7 +345,9 @@ int fieldInfo(nmpc_hip_fmpc_solver * h, int field, FieldInfo * fi)
     case NMPC_HIP_FMPC_FIELD_GAIN_P: *fi = {nullptr, T + 1, N * N, h->ops->gain_offset_P}; break;
     case NMPC_HIP_FMPC_FIELD_MERIT: *fi = {b.merit, 1, 3}; break;
     case NMPC_HIP_FMPC_FIELD_BARRIER_EPS: *fi = {b.barrier_eps, 1, 1}; break;
-    case NMPC_HIP_FMPC_FIELD_TRACE: *fi = {b.trace, h->cfg.max_iter, NMPC_HIP_FMPC_NTRACE}; break; // already [B][..]
+    case NMPC_HIP_FMPC_FIELD_TRACE: // already [B][..]; rows and stride of the solve that wrote it
+      *fi = {h->solved ? h->solved_trace : b.trace, h->solved ? h->solved_max_iter : h->cfg.max_iter, NMPC_HIP_FMPC_NTRACE};
+      break;
     case NMPC_HIP_FMPC_FIELD_STATUS: *fi = {nullptr, 1, 1, -1, true}; break;
     case NMPC_HIP_FMPC_FIELD_ITERS: *fi = {nullptr, 1, 1, -1, true}; break;
     default: return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "[FMPC] unknown field");
@@ -744,6 +748,13 @@ extern "C"
     return NMPC_HIP_OK;
   }
 
+  /** The last solve may have been queued on a caller's stream (solve_device): whatever reads or rewrites the handle's
+      buffers on the handle's own stream waits for it first (ev1 is recorded behind every solve). */
+  static hipError_t waitLastSolve(nmpc_hip_fmpc_handle h)
+  {
+    return (h->solved && h->ev1) ? hipStreamWaitEvent(h->stream, h->ev1, 0) : hipSuccess;
+  }
+
   int nmpc_hip_fmpc_set_variable(nmpc_hip_fmpc_handle h,
                                  const double * x,
                                  const double * u,
@@ -758,6 +769,7 @@ extern "C"
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle");
     }
     FMPC_TRY(hipSetDevice(h->device));
+    FMPC_TRY(waitLastSolve(h));
     const FmpcBuffers & b = h->buf;
     FMPC_CHECK(uploadField(h, x, b.x, b.T + 1, b.N, on_device));
     FMPC_CHECK(uploadField(h, u, b.u, b.T, b.M, on_device));
@@ -818,6 +830,8 @@ extern "C"
     FMPC_TRY(hipEventRecord(h->ev1, st));
     h->timed = true;
     h->solved = true;
+    h->solved_max_iter = h->buf.max_iter;
+    h->solved_trace = h->buf.trace;
     return NMPC_HIP_OK;
   }
 
@@ -845,6 +859,8 @@ extern "C"
     FMPC_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     h->solved = true;
+    h->solved_max_iter = h->buf.max_iter;
+    h->solved_trace = h->buf.trace;
     std::vector<int> status(h->buf.B);
     FMPC_TRY(hipMemcpyAsync(status.data(), h->buf.status, status.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     FMPC_TRY(hipStreamSynchronize(h->stream));
@@ -884,6 +900,7 @@ extern "C"
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "[FMPC] field size mismatch");
     }
     FMPC_TRY(hipSetDevice(h->device));
+    FMPC_TRY(waitLastSolve(h));
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if(count == 0)
     {
@@ -1046,6 +1063,8 @@ extern "C"
     (void)hipEventRecord(h->ev1, h->stream);
     h->timed = true;
     h->solved = true;
+    h->solved_max_iter = h->buf.max_iter;
+    h->solved_trace = h->buf.trace;
     // logs: [tick][E][B] -> [B][tick][E]
     auto fetch = [&](const double * d_src, double * host, int steps, int E) -> int {
       if(!host || static_cast<size_t>(steps) * E == 0)

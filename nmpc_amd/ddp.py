@@ -207,6 +207,11 @@ class DDPSolverBatch:
             lo[:] = lower[0]
             up[:] = upper[0]
         self._limits = (lo, up)
+        # constant limits replace a limits function / table given earlier (DDPSolverBatch.hpp setInputLimits does the same)
+        self._limits_func = None
+        if getattr(self, "_limits_horizon", None) is not None:
+            self._limits_horizon = None
+            self._limits_horizon_dirty = True
 
     def setInputLimitsBatch(self, lower, upper) -> None:
         """Per-instance limits: lower, upper of shape (B, MM) (constant in time), or None, None to go back to the shared
@@ -230,6 +235,7 @@ class DDPSolverBatch:
         self._h_T = T
         self._problem_batch_dirty = getattr(self, "_problem_batch", None) is not None  # a new handle starts shared
         self._limits_batch_dirty = getattr(self, "_limits_batch", None) is not None
+        self._limits_horizon_dirty = getattr(self, "_limits_horizon", None) is not None  # a table given to the old handle
 
     def close(self):
         if getattr(self, "_h", None):
@@ -268,6 +274,8 @@ class DDPSolverBatch:
                 _capi.check(self._L.nmpc_hip_ddp_set_input_limits_horizon(self._h, None, None, 0))
             else:
                 lo, up, per_instance = hz
+                if lo.shape[-2] < self._h_T:  # (validated against the horizon_steps of the time it was given)
+                    raise ValueError(f"limits tables have {lo.shape[-2]} rows but horizon_steps is {self._h_T}")
                 _capi.check(self._L.nmpc_hip_ddp_set_input_limits_schedule(self._h, lo.ctypes.data_as(dp), up.ctypes.data_as(dp),
                                                                            lo.shape[-2], 1 if per_instance else 0))
             self._limits_horizon_dirty = False

@@ -689,7 +689,7 @@ def test_quad_kernel_batch_threshold(monkeypatch):
 # (ddp_kernels_tile64.hpp, the default: groups of instances per workgroup, derivatives LDS-resident), "wpi" = the
 # wave-per-instance kernel it replaces on these shapes (ddp_kernels_wpi.hpp, NMPC_HIP_DDP_KERNEL=wpi: kept as A/B partner)
 # ---------------------------------------------------------------------------------------------------
-MATRIX_KERNELS = {"tile64": "ddp_solve_tile64_kernel", "wpi": "ddp_solve_wpi_kernel"}
+MATRIX_KERNELS = {"tile64": "ddp_solve_tile64_kernel", "tile64!": "ddp_solve_tile64_kernel", "wpi": "ddp_solve_wpi_kernel"}
 
 
 def _select_matrix_kernel(monkeypatch, kernel, group=None):
@@ -697,6 +697,8 @@ def _select_matrix_kernel(monkeypatch, kernel, group=None):
     per workgroup (small test batches otherwise spread out to one instance per workgroup)."""
     if kernel == "wpi":
         monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", "wpi")
+    elif kernel == "tile64!":  # forced: box-constrained solves of the n >= 9 shapes default to the wave-per-instance kernel
+        monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", "tile64")
     else:
         monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
     if group:
@@ -821,7 +823,7 @@ def test_wave_per_instance_kernel_failure_status(kernel, group, monkeypatch):
     np.testing.assert_array_equal(s.traceLast()[:, INT_COLS], ref.trace_last[:, INT_COLS])
 
 
-@pytest.mark.parametrize("kernel,group", [("tile64", 32), ("tile64", None), ("wpi", None)])
+@pytest.mark.parametrize("kernel,group", [("tile64!", 32), ("tile64!", None), ("wpi", None)])
 @pytest.mark.parametrize("model", ["quadrotor", "manipulator"])
 def test_wave_per_instance_kernel_box_constrained(model, kernel, group, monkeypatch):
     """with_input_constraint on the matrix-core kernels (every lane runs the same BoxQP, lane c solves column c of K on the
@@ -1069,7 +1071,7 @@ def test_shift_loop_with_time_varying_limits(kernel, monkeypatch):
     assert bound_hits > 10  # the moving bound is active at the first input of many ticks
 
 
-@pytest.mark.parametrize("kernel,group", [("tile64", 32), ("wpi", None)])
+@pytest.mark.parametrize("kernel,group", [("tile64!", 32), ("wpi", None)])
 def test_time_varying_input_limits_wave_per_instance_kernel(kernel, group, monkeypatch):
     """The same on the matrix-core kernels (quadrotor, rotor-thrust box that opens up along the horizon), one table for
     the whole batch (every instance starts at t = 0)."""

@@ -260,3 +260,20 @@ def test_eigen_style_port_matches_the_shipped_model(tmp_path):
     r = subprocess.run([hip_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-DDEVICE_COMPILE_CHECK", f"-I{ROOT}/include",
                         f"-I{ROOT}/tests/cpp", "-x", "hip", "-c", src, "-o", str(tmp_path / "port_dev.o")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_constant_limits_replace_a_limits_function_or_table():
+    """setInputLimits after setInputLimitsFunc / setInputLimitsHorizon: the constant pair is what the next solve uses (the
+    C++ mirror, DDPSolverBatch::setInputLimits, resets both as well); a table survives a change of horizon_steps as "to be
+    pushed again" and is re-validated against the new horizon."""
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.DDPProblemCartPole(), 2)
+    s.setInputLimitsFunc(lambda t: (np.array([-1.0 - t]), np.array([1.0 + t])))
+    assert s._limits_func is not None
+    s.setInputLimits(np.array([-15.0]), np.array([15.0]))
+    assert s._limits_func is None and s._limits[0][0] == -15.0 and s._limits[1][0] == 15.0
+    T = int(s.config().horizon_steps)
+    s.setInputLimitsHorizon(np.full((T, 1), -2.0), np.full((T, 1), 2.0))
+    assert s._limits_horizon is not None and s._limits_horizon_dirty
+    s._limits_horizon_dirty = False  # (as if pushed to a handle)
+    s.setInputLimits(np.array([-3.0]), np.array([3.0]))
+    assert s._limits_horizon is None and s._limits_horizon_dirty  # the device table has to be removed on the next push

@@ -38,8 +38,9 @@
 // instructions, most of them the m x m factorisation.  fp64 MFMAs of two waves on one SIMD serialise, an fp64 VALU wave beside
 // a matrix wave still gets about a third of its issue slots (profiles/r03_ubench_mfma_f64_16.txt): two waves per SIMD.
 //
-// Gains go straight to the handle's tile-major kff / Kfb arrays (the rollouts read them lane = instance: coalesced), X / U /
-// cost live in the two halves of the handle's arrays with a per-instance `sel` flip on acceptance, exactly like the lane kernels.
+// Gains are kept as instance-major records in the handle's workspace (ModelOps::gain_layout 1: one contiguous run per instance
+// and timestep), X / U / cost live in the two halves of the handle's tile-major arrays with a per-instance `sel` flip on acceptance,
+// exactly like the lane kernels.
 #pragma once
 
 #include <cstring>
@@ -178,6 +179,13 @@ struct TileSolver64
   static constexpr int kGainRows = MM + MM * N;
   static constexpr int kRingRows = kGainRows + N + MM;
   static constexpr int kRingDepth = 3;
+  /** Per-instance workspace: the gains as records [T][k_i (m) | K_i (m n, column-major)] — a matrix wave writes the 105 doubles of
+      an (instance, timestep) as one contiguous run; into the handle's tile-major kff / Kfb arrays the same stores would be 8 bytes
+      each, 512 bytes apart (measured: 7 x the written bytes reach HBM). */
+  NMPC_HD static size_t workspaceDoubles(int T)
+  {
+    return static_cast<size_t>(T) * kGainRows;
+  }
   static constexpr int kLdsDoubles = static_cast<int>(kT64LdsBytes / sizeof(double));
   static_assert(kRecAt + 2 * (kNumIds + 2) <= kLdsDoubles && kRecAt + kTerm <= kLdsDoubles, "one instance must fit");
 
@@ -557,8 +565,8 @@ struct TileSolver64
     const int sel = slotI(sSel, pl.slot);
     const size_t tile = pl.want ? tileOf(b) : 0, ln = pl.want ? lnOf(b) : 0;
     const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;
-    pl.pk = buf.kff + (tile * rows_u) * 64 + ln;
-    pl.pK = buf.Kfb + (tile * rows_u * N) * 64 + ln;
+    pl.pk = buf.wpi_ws + static_cast<size_t>(pl.want ? b : 0) * workspaceDoubles(T); // gain record of timestep 0
+    pl.pK = pl.pk + MM;
     pl.pX = buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln;
     pl.pU = buf.U + ((tile * 2 + sel) * rows_u) * 64 + ln;
     return pl;
@@ -581,13 +589,13 @@ struct TileSolver64
         // row < m: k_i | < m + m n: K_i | < m + m n + n: x_i | else u_i
         const bool is_k = row < MM, is_K = !is_k && row < kGainRows, is_x = !is_k && !is_K && row < kGainRows + N;
         const double * base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
-        const int per_step = is_k ? MM : (is_K ? N * MM : (is_x ? N : MM));
-        const int r = is_k ? row : (is_K ? row - MM : (is_x ? row - kGainRows : row - kGainRows - N));
+        const int per_step = (is_k || is_K) ? kGainRows : (is_x ? N * 64 : MM * 64); // gains: records; x, u: tile-major rows
+        const int r = is_k ? row : (is_K ? row - MM : (is_x ? (row - kGainRows) * 64 : (row - kGainRows - N) * 64));
         at[k] = ok ? row * G : -1;
         v[k] = 0;
         if(ok)
         {
-          v[k] = base[static_cast<size_t>(i * per_step + r) * 64];
+          v[k] = base[static_cast<size_t>(i) * per_step + r];
         }
       }
 #pragma unroll
@@ -1262,28 +1270,20 @@ struct TileSolver64
     *dv1 += 0.5 * c.c1nn;
     *kr = fmax(*kr, c.krel_i);
   }
-  /** k_i, K_i -> kff / Kfb (:529-530); not after a failed factorisation: backwardPass() returned before storing (:505-508). */
+  /** k_i, K_i -> the instance's gain record (:529-530); not after a failed factorisation: backwardPass() returned before storing (:505-508). */
   NMPC_D void stepStoreGains(const StepCtx & c, int b, int i) const
   {
     const int q = lane >> 4, j = lane & 15;
     if(c.ok && j <= N)
     {
-      const size_t tile = tileOf(b), ln = lnOf(b);
-      const size_t rows_u = static_cast<size_t>(T) * MM;
+      double * rec_g = buf.wpi_ws + (static_cast<size_t>(b) * T + i) * kGainRows;
 #pragma unroll
       for(int rr = 0; rr < KM; rr++)
       {
         const int a = 4 * rr + q;
         if(a < MM)
         {
-          if(j == N)
-          {
-            buf.kff[(tile * rows_u + static_cast<size_t>(i) * MM + a) * 64 + ln] = c.A[rr];
-          }
-          else
-          {
-            buf.Kfb[(tile * rows_u * N + static_cast<size_t>(i) * N * MM + a + j * MM) * 64 + ln] = c.A[rr];
-          }
+          rec_g[(j == N) ? a : MM + a + j * MM] = c.A[rr];
         }
       }
     }

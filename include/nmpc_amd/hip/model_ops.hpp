@@ -51,6 +51,9 @@ struct ModelOps
   //! 0: k_list_ / K_list_ live in the handle's tile-major kff / Kfb arrays; 1: in the workspace, instance-major records
   //! [B][T][MM + MM * N] (k_i, then K_i column-major) as the fp32 tile kernel writes them
   int gain_layout;
+  //! the same per launch, for problem types whose kernel families differ in it (nullptr: gain_layout): what a solve of `batch`
+  //! instances with / without input constraints leaves behind
+  int (*gain_layout_of)(int batch, int constrained) = nullptr;
 };
 
 } // namespace hip

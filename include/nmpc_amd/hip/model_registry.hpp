@@ -71,11 +71,20 @@ struct ModelOpsFor
     // kernel is 20 % faster there, so it keeps them where it exists (n >= 9); the tile kernel takes them for 5 <= n <= 8.
     return !(constrained && kWpiBoxQP);
   }
+  /** Where k_list_ / K_list_ are after a solve: the tile kernel leaves instance-major records in the workspace. */
+  static int gainLayoutOf(int, int constrained)
+  {
+    return useTile64(constrained != 0) ? 1 : 0;
+  }
   static size_t wpiWorkspaceDoubles(int T)
   {
     if constexpr(kWpiShape)
     {
-      return WaveSolver<Problem>::workspaceDoubles(T);
+      return WaveSolver<Problem>::workspaceDoubles(T); // (>= the tile kernel's gain records)
+    }
+    else if constexpr(kTile64Shape)
+    {
+      return TileSolver64<Problem>::workspaceDoubles(T);
     }
     else if constexpr(QuadSolver<Problem, false>::kShape)
     {
@@ -149,6 +158,10 @@ struct ModelOpsFor
     {
       if(useTile64(con))
       {
+        if(buf.wpi_ws == nullptr)
+        {
+          return hipErrorOutOfMemory; // the gain records live in the workspace (ModelOps::wpi_workspace_doubles)
+        }
         if(con && own)
         {
           return launchTile64<Problem, true, true>(problem, cfg, buf, stream);
@@ -353,6 +366,7 @@ struct ModelOpsFor
     ops.wpi_workspace_doubles = &wpiWorkspaceDoubles;
     ops.scalar_bytes = static_cast<int>(sizeof(typename Problem::Scalar));
     ops.gain_layout = 0;
+    ops.gain_layout_of = &gainLayoutOf;
     static_assert(sizeof(typename Problem::Scalar) == 8, "these kernel families compute in double; fp32 problem types register "
                                                          "through ddp_kernels_tile32.hpp");
     return ops;

@@ -70,6 +70,7 @@ struct nmpc_hip_ddp_solver
   bool has_limits = false;
   bool has_shared_limits = false; // nmpc_hip_ddp_set_input_limits was called
   bool solved = false;
+  int last_gain_layout = 0; // ModelOps::gain_layout of the kernel the last solve ran on
   hipStream_t stream = nullptr;
   // ring of HIP-event triples {begin, kernel start, end}: one per solve, harvested lazily so that timing a
   // sequence of asynchronous solves never inserts a host synchronisation between them
@@ -325,15 +326,23 @@ int packField(nmpc_hip_ddp_solver * s, int field, void * d_out, hipStream_t st)
       break;
     case NMPC_HIP_FIELD_KFF:
     case NMPC_HIP_FIELD_KFB:
-      if(s->ops->gain_layout == 1)
+      if(s->last_gain_layout == 1)
       {
-        // instance-major gain records [B][T][MM + MM N] in the workspace (fp32 tile kernel)
+        // instance-major gain records [B][T][MM + MM N] in the workspace (the tile kernels)
         const int per_step = (field == NMPC_HIP_FIELD_KFF) ? s->MM : s->MM * s->N;
         const int offset = (field == NMPC_HIP_FIELD_KFF) ? 0 : s->MM;
         const size_t total = static_cast<size_t>(B) * s->T * per_step;
-        hipLaunchKernelGGL((nmpc_amd::hip::gain_records_to_batch_major_kernel<float>), dim3(static_cast<unsigned>((total + 255) / 256)),
-                           dim3(256), 0, st, reinterpret_cast<const float *>(s->d_wpi_ws), dout, total, s->MM + s->MM * s->N, per_step,
-                           offset);
+        const dim3 grid(static_cast<unsigned>((total + 255) / 256)), blk(256);
+        if(s->ops->scalar_bytes == 4)
+        {
+          hipLaunchKernelGGL((nmpc_amd::hip::gain_records_to_batch_major_kernel<float>), grid, blk, 0, st,
+                             reinterpret_cast<const float *>(s->d_wpi_ws), dout, total, s->MM + s->MM * s->N, per_step, offset);
+        }
+        else
+        {
+          hipLaunchKernelGGL((nmpc_amd::hip::gain_records_to_batch_major_kernel<double>), grid, blk, 0, st,
+                             reinterpret_cast<const double *>(s->d_wpi_ws), dout, total, s->MM + s->MM * s->N, per_step, offset);
+        }
         NMPC_HIP_TRY(hipGetLastError());
       }
       else
@@ -481,6 +490,7 @@ int launchRecorded(nmpc_hip_ddp_solver * s,
   NMPC_HIP_TRY(hipEventRecord(s->ev_kernel[slot], st));
   const DeviceBuffers buf = makeBuffers(s);
   {
+    s->last_gain_layout = s->ops->gain_layout_of ? s->ops->gain_layout_of(s->B, s->cfg.with_input_constraint != 0 ? 1 : 0) : s->ops->gain_layout;
     const hipError_t le = s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
     if(le == hipErrorNotSupported)
     {

@@ -137,9 +137,20 @@ class DDPProblemManipulator(_Problem):
                     ("wt_scale", C.c_double), ("q_ref_scale", C.c_double)]
 
 
+class DDPProblemPlanarVtol(_Problem):
+    """include/nmpc_amd/models/PlanarVtol.hpp (builder-defined n = 6, m = 2: the 5 <= n <= 8 shapes on the fp64 tile kernel)."""
+
+    name = "planar_vtol"
+
+    class _Blob(C.Structure):
+        _fields_ = [("dt", C.c_double), ("mass", C.c_double), ("inertia", C.c_double), ("arm", C.c_double),
+                    ("w_pos", C.c_double), ("w_ang", C.c_double), ("w_vel", C.c_double), ("w_omega", C.c_double),
+                    ("w_u", C.c_double), ("wt_scale", C.c_double), ("ref_pos", C.c_double * 2)]
+
+
 PROBLEMS = {c.name: c for c in (DDPProblemCartPole, DDPProblemBipedal, DDPProblemVerticalMotion,
                                 DDPProblemCentroidalMotion, DDPProblemQuadrotor, DDPProblemQuadrotorF32,
-                                DDPProblemManipulator)}
+                                DDPProblemManipulator, DDPProblemPlanarVtol)}
 
 
 def make_problem(name: str, **kw) -> _Problem:

@@ -107,6 +107,18 @@ def quadrotor_batch(B: int = 8192, T: int = 50, seed: int = 1234, constrained: b
                     np.full((B, T, 4), hover), np.zeros(B), limits=limits)
 
 
+def planar_vtol_batch(B: int = 4096, T: int = 60, seed: int = 1234, constrained: bool = False) -> Workload:
+    """Builder-defined n = 6, m = 2 shape (planar VTOL): hover perturbation x0 ~ N(0, 0.3^2) around (0, 1), attitude
+    ~ N(0, 0.2^2), u_init = hover thrust m g / 2, dt = 0.02."""
+    u = splitmix64_uniform(seed, 12 * B).reshape(B, 12)
+    x0 = 0.3 * _normal_from_uniform(u[:, :6], u[:, 6:])
+    x0[:, 2] *= 2.0 / 3.0
+    x0[:, 1] += 1.0
+    hover = 1.0 * 9.80665 / 2
+    limits = (np.full(2, 0.6 * hover), np.full(2, 1.4 * hover)) if constrained else None  # rotor thrust box
+    return Workload("planar_vtol_batch", "planar_vtol", 6, 2, T, B, 0.02, x0, np.full((B, T, 2), hover), np.zeros(B), limits=limits)
+
+
 def manipulator_batch(B: int = 8192, T: int = 30, seed: int = 1234, constrained: bool = False) -> Workload:
     """C5 (per-GPU shard): q0 ~ U[-1,1]^7, qd0 ~ U[-0.5,0.5]^7, u_init = gravity compensation at q0, dt = 0.01."""
     u = splitmix64_uniform(seed, 14 * B).reshape(B, 14)

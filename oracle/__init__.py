@@ -383,4 +383,10 @@ def default_params(model: str, **over) -> np.ndarray:
         d.update(over)
         return np.array([d[k] for k in ("dt", "w_diag", "w_off", "damping", "grav_scale", "wq", "wv", "wu",
                                         "wt_scale", "q_ref_scale")] + [0.0, 0.0], dtype=np.float64)
+    if model == "planar_vtol":
+        d = dict(dt=0.02, mass=1.0, inertia=0.02, arm=0.25, w_pos=1.0, w_ang=0.5, w_vel=0.1, w_omega=0.05, w_u=0.01,
+                 wt_scale=10.0, ref_pos=(0.0, 1.0))
+        d.update(over)
+        return np.array([d["dt"], d["mass"], d["inertia"], d["arm"], d["w_pos"], d["w_ang"], d["w_vel"], d["w_omega"],
+                         d["w_u"], d["wt_scale"], *d["ref_pos"]], dtype=np.float64)
     raise ValueError(model)

@@ -306,6 +306,177 @@ struct Quadrotor
 };
 
 // ---------------------------------------------------------------------------------------------------
+// Planar VTOL (bicopter), n = 6, m = 2: x = [px, pz, th, vx, vz, om], u = left / right rotor thrust, explicit Euler.
+//   vx' = -(u0 + u1) / mass * sin(th),  vz' = (u0 + u1) / mass * cos(th) - g,  om' = arm * (u1 - u0) / inertia
+// A builder-defined shape with 5 <= n <= 8 (the reference's template takes any StateDim / InputDim, DDPSolver.h:23-25).
+// ---------------------------------------------------------------------------------------------------
+struct PlanarVtol
+{
+  using Real = ORACLE_NS::Real;
+  static constexpr int N = 6;
+  static constexpr int MMAX = 2;
+  static constexpr int NPARAM = 12;
+
+  Real dt = 0.02;
+  Real mass = 1.0;
+  Real inertia = 0.02;
+  Real arm = 0.25;
+  Real w_pos = 1.0, w_ang = 0.5, w_vel = 0.1, w_omega = 0.05;
+  Real w_u = 0.01;
+  Real wt_scale = 10.0;
+  Real ref_pos[2] = {0, 1.0};
+  static constexpr Real g = 9.80665;
+
+  void setParams(const double * p)
+  {
+    dt = p[0];
+    mass = p[1];
+    inertia = p[2];
+    arm = p[3];
+    w_pos = p[4];
+    w_ang = p[5];
+    w_vel = p[6];
+    w_omega = p[7];
+    w_u = p[8];
+    wt_scale = p[9];
+    ref_pos[0] = p[10];
+    ref_pos[1] = p[11];
+  }
+  int inputDim(Real) const
+  {
+    return 2;
+  }
+  Real hover() const
+  {
+    return mass * g / 2;
+  }
+  void weights(Real * w) const
+  {
+    w[0] = w_pos;
+    w[1] = w_pos;
+    w[2] = w_ang;
+    w[3] = w_vel;
+    w[4] = w_vel;
+    w[5] = w_omega;
+  }
+  Real err(const Real * x, int i) const
+  {
+    return (i < 2) ? x[i] - ref_pos[i] : x[i];
+  }
+
+  void stateEq(Real, const Real * x, const Real * u, int, Real * xn) const
+  {
+    const Real sth = std::sin(x[2]), cth = std::cos(x[2]);
+    const Real a = (u[0] + u[1]) / mass;
+    const Real xd[6] = {x[3], x[4], x[5], -a * sth, a * cth - g, arm * (u[1] - u[0]) / inertia};
+    for(int i = 0; i < 6; i++)
+    {
+      xn[i] = x[i] + dt * xd[i];
+    }
+  }
+  Real runningCost(Real, const Real * x, const Real * u, int) const
+  {
+    Real w[6];
+    weights(w);
+    Real s = 0;
+    for(int i = 0; i < 6; i++)
+    {
+      const Real d = err(x, i);
+      s += w[i] * (d * d);
+    }
+    Real su = 0;
+    for(int a = 0; a < 2; a++)
+    {
+      const Real d = u[a] - hover();
+      su += d * d;
+    }
+    return 0.5 * s + 0.5 * w_u * su;
+  }
+  Real terminalCost(Real, const Real * x) const
+  {
+    Real w[6];
+    weights(w);
+    Real s = 0;
+    for(int i = 0; i < 6; i++)
+    {
+      const Real d = err(x, i);
+      s += (wt_scale * w[i]) * (d * d);
+    }
+    return 0.5 * s;
+  }
+  void calcStateEqDeriv(Real, const Real * x, const Real * u, int, Real * Fx, Real * Fu) const
+  {
+    const Real sth = std::sin(x[2]), cth = std::cos(x[2]);
+    const Real a = (u[0] + u[1]) / mass;
+    for(int e = 0; e < 36; e++)
+    {
+      Fx[e] = 0;
+    }
+    for(int i = 0; i < 6; i++)
+    {
+      Fx[i + i * 6] = 1.0;
+    }
+    Fx[0 + 3 * 6] = dt;
+    Fx[1 + 4 * 6] = dt;
+    Fx[2 + 5 * 6] = dt;
+    Fx[3 + 2 * 6] = dt * (-a * cth);
+    Fx[4 + 2 * 6] = dt * (-a * sth);
+    for(int e = 0; e < 12; e++)
+    {
+      Fu[e] = 0;
+    }
+    for(int c = 0; c < 2; c++)
+    {
+      Fu[3 + c * 6] = dt * (-sth / mass);
+      Fu[4 + c * 6] = dt * (cth / mass);
+    }
+    Fu[5 + 0 * 6] = dt * (-arm / inertia);
+    Fu[5 + 1 * 6] = dt * (arm / inertia);
+  }
+  void calcRunningCostDeriv(Real, const Real * x, const Real * u, int, Real * Lx, Real * Lu, Real * Lxx, Real * Luu, Real * Lxu) const
+  {
+    Real w[6];
+    weights(w);
+    for(int e = 0; e < 36; e++)
+    {
+      Lxx[e] = 0;
+    }
+    for(int i = 0; i < 6; i++)
+    {
+      Lx[i] = w[i] * err(x, i);
+      Lxx[i + i * 6] = w[i];
+    }
+    for(int e = 0; e < 4; e++)
+    {
+      Luu[e] = 0;
+    }
+    for(int a = 0; a < 2; a++)
+    {
+      Lu[a] = w_u * (u[a] - hover());
+      Luu[a + a * 2] = w_u;
+    }
+    for(int e = 0; e < 12; e++)
+    {
+      Lxu[e] = 0;
+    }
+  }
+  void calcTerminalCostDeriv(Real, const Real * x, Real * Vx, Real * Vxx) const
+  {
+    Real w[6];
+    weights(w);
+    for(int e = 0; e < 36; e++)
+    {
+      Vxx[e] = 0;
+    }
+    for(int i = 0; i < 6; i++)
+    {
+      Vx[i] = (wt_scale * w[i]) * err(x, i);
+      Vxx[i + i * 6] = wt_scale * w[i];
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
 // Manipulator (synthetic 7-DoF joint-space chain): x = [q(7), qd(7)], u = joint torques.
 //   r_j   = u_j - damping * qd_j - grav_j * sin(S_j),   S_j = q_0 + ... + q_j
 //   qdd_i = sum_j W_ij(q) r_j,   W_ij = w_diag * [i == j] + w_off * cos(q_i - q_j)   (dense, state dependent)

@@ -53,6 +53,10 @@ int dispatch(const char * name, F && f)
   {
     return f(Manipulator());
   }
+  if(s == "planar_vtol")
+  {
+    return f(PlanarVtol());
+  }
   if(s == "quadrotor_f32")
   {
     return f(oracle_f32::Quadrotor());

@@ -15,7 +15,10 @@ dst = os.path.join(root, "profiles")
 sys.path.insert(0, root)
 from nmpc_amd import build as hip_build  # noqa: E402
 
-SOURCE_HASH = hip_build.source_hash()  # the session must have run on THESE device sources: bench.py refuses the entries otherwise
+# the hash of the device sources the session ran on (scripts/profile_r03.sh writes it next to its outputs): bench.py refuses
+# the traffic entries on any other sources
+_hash_file = os.path.join(src, "source_hash.txt")
+SOURCE_HASH = open(_hash_file).read().strip() if os.path.exists(_hash_file) else hip_build.source_hash()
 
 
 def means(pattern, kernel_pat):

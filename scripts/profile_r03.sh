@@ -7,6 +7,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${1:-r03}
 OUT=gpurun_out/profile_$TAG
 mkdir -p $OUT
+python -c "from nmpc_amd import build; print(build.source_hash())" > $OUT/source_hash.txt
 build_ubench() { [ -x scripts/$2 ] || hipcc --offload-arch=gfx950 -O2 -w scripts/$1 -o scripts/$2; }
 build_ubench ubench_hbm_counters.hip ubench_hbm_counters
 build_ubench ubench_mfma_f32.hip ubench_mfma_f32

@@ -1,3 +1,23 @@
+// This file is DERIVED from nmpc_ddp/tests/src/TestDDPCentroidalMotion.cpp of isri-aist/NMPC (a statement-for-statement port of one
+// of its test problem classes, kept as a conformance fixture for the Eigen-subset syntax; nothing else in this repository is).
+// The original is distributed under the BSD 2-Clause License, whose notice is retained here as its terms require:
+//
+//   BSD 2-Clause License
+//   Copyright (c) 2022, AIST-CNRS JRL.  All rights reserved.
+//
+//   Redistribution and use in source and binary forms, with or without modification, are permitted provided that the following
+//   conditions are met:
+//   1. Redistributions of source code must retain the above copyright notice, this list of conditions and the following disclaimer.
+//   2. Redistributions in binary form must reproduce the above copyright notice, this list of conditions and the following
+//      disclaimer in the documentation and/or other materials provided with the distribution.
+//
+//   THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND ANY EXPRESS OR IMPLIED WARRANTIES, INCLUDING,
+//   BUT NOT LIMITED TO, THE IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A PARTICULAR PURPOSE ARE DISCLAIMED.  IN NO EVENT
+//   SHALL THE COPYRIGHT HOLDER OR CONTRIBUTORS BE LIABLE FOR ANY DIRECT, INDIRECT, INCIDENTAL, SPECIAL, EXEMPLARY, OR CONSEQUENTIAL
+//   DAMAGES (INCLUDING, BUT NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR SERVICES; LOSS OF USE, DATA, OR PROFITS; OR BUSINESS
+//   INTERRUPTION) HOWEVER CAUSED AND ON ANY THEORY OF LIABILITY, WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT (INCLUDING
+//   NEGLIGENCE OR OTHERWISE) ARISING IN ANY WAY OUT OF THE USE OF THIS SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
+//
 // DDPProblemCentroidalMotion written against nmpc_amd::DDPProblem the way the reference writes it against
 // nmpc_ddp::DDPProblem (nmpc_ddp/tests/src/TestDDPCentroidalMotion.cpp:24-210): the same statements in the same order, in
 // the Eigen-subset syntax of include/nmpc_amd/linalg.hpp.  What has to change when a reference problem class is ported:

@@ -863,6 +863,48 @@ def test_wave_per_instance_kernel_box_constrained(model, kernel, group, monkeypa
     assert scaled_err(s.X()[stable], s1.X()[stable]) <= TOL and scaled_err(s.U()[stable], s1.U()[stable]) <= TOL
 
 
+@pytest.mark.parametrize("group", [32, 6, None])
+@pytest.mark.parametrize("cfg", [dict(max_iter=12), dict(max_iter=8, reg_type=2), dict(max_iter=500)])
+def test_planar_vtol_n6_m2_on_the_tile_kernel(cfg, group, monkeypatch):
+    """A shape with 5 <= n <= 8 (builder-defined planar VTOL, n = 6, m = 2): the reference's template takes any StateDim /
+    InputDim (DDPSolver.h:23-25); here it runs on the fp64 tile kernel (block form: n is not a multiple of 4) instead of the
+    single-wavefront lane kernel — against the oracle and against that lane kernel."""
+    from nmpc_amd import workloads
+    wl = workloads.planar_vtol_batch(B=200, T=60, seed=21)
+    _select_matrix_kernel(monkeypatch, "tile64", group)
+    s = make_solver(wl, **cfg)
+    assert s.kernelName() == "ddp_solve_tile64_kernel"
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_batch(wl, **cfg)
+    check_against_oracle(wl, s, ref)
+    assert len(np.unique(ref.iters)) > 1 or cfg["max_iter"] < 500
+    monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", "1w")
+    s1 = make_solver(wl, **cfg)
+    assert s1.kernelName() in ("ddp_solve_tpi_kernel", "ddp_solve_tpi2w_kernel")
+    s1.solve(wl.t0, wl.x0, wl.u_init)
+    assert np.array_equal(s.status(), s1.status()) and np.array_equal(s.iters(), s1.iters())
+    for a, b in ((s.X(), s1.X()), (s.U(), s1.U()), (s.kff(), s1.kff()), (s.Kfb(), s1.Kfb())):
+        assert scaled_err(a, b) <= TOL
+
+
+def test_planar_vtol_box_constrained_on_the_tile_kernel(monkeypatch):
+    """with_input_constraint for 5 <= n <= 8: BoxQP on the tile kernel (no wave-per-instance kernel exists below n = 9),
+    against the oracle on its decision-stable set and against the lane kernel."""
+    from nmpc_amd import workloads
+    wl = workloads.planar_vtol_batch(B=96, T=60, seed=22, constrained=True)
+    cfg = dict(with_input_constraint=True, max_iter=10)
+    _select_matrix_kernel(monkeypatch, "tile64", 32)
+    s = make_solver(wl, **cfg)
+    assert s.kernelName() == "ddp_solve_tile64_kernel"
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_batch(wl, **cfg)
+    stable, runs = decision_stable_mask(wl, ref, return_runs=True, **cfg)
+    bad = check_dropped("planar_vtol box", wl, s, ref, stable, runs, 0.75, cost_tol=1e-6)
+    assert not bad or len(bad) <= 2, bad
+    check_against_oracle(wl, s, ref, mask=stable)
+    assert (s.qpFreeMask()[stable] != 3).any(), "the batch never hit the bounds"
+
+
 @pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
 def test_per_instance_problem_objects(model):
     """nmpc_hip_ddp_set_model_params_batch: every instance solves its own problem object (different masses / lengths /

@@ -39,9 +39,9 @@ def test_model_registry_and_blob_sizes():
         p = C.c_char_p()
         assert L.nmpc_hip_ddp_model_name(i, C.byref(p)) == 0
         names.append(p.value.decode())
-    assert set(names) >= {"cartpole", "bipedal", "vertical", "centroidal", "quadrotor", "manipulator"}
+    assert set(names) >= {"cartpole", "bipedal", "vertical", "centroidal", "quadrotor", "manipulator", "planar_vtol"}
     expect = {"cartpole": (4, 1, False), "bipedal": (2, 1, False), "vertical": (2, 2, True),
-              "centroidal": (9, 16, True), "quadrotor": (12, 4, False), "manipulator": (14, 7, False)}
+              "centroidal": (9, 16, True), "quadrotor": (12, 4, False), "manipulator": (14, 7, False), "planar_vtol": (6, 2, False)}
     for name, (n, m, dyn) in expect.items():
         prob = nmpc_amd.make_problem(name)
         gn, gm, gd, nbytes = prob.dims()
@@ -65,7 +65,7 @@ def test_default_config_matches_reference_defaults():
 
 
 def test_default_model_params_match_oracle_defaults():
-    for name in ("cartpole", "bipedal", "vertical", "centroidal", "quadrotor", "manipulator"):
+    for name in ("cartpole", "bipedal", "vertical", "centroidal", "quadrotor", "manipulator", "planar_vtol"):
         prob = nmpc_amd.make_problem(name)
         blob = np.frombuffer(bytes(prob.blob), dtype=np.float64)
         want = oracle.default_params(name)

@@ -124,7 +124,7 @@ def test_centroidal_check_derivative():
         assert np.linalg.norm(ev.Fu - Fu) < 1e-6
 
 
-@pytest.mark.parametrize("model", ["cartpole", "bipedal", "vertical", "centroidal", "quadrotor", "manipulator"])
+@pytest.mark.parametrize("model", ["cartpole", "bipedal", "vertical", "centroidal", "quadrotor", "manipulator", "planar_vtol"])
 def test_all_models_jacobians_and_cost_derivatives(model):
     """Same check for every model the build ships (the builder-defined quadrotor / manipulator have no reference
     counterpart: this is what pins their analytic derivatives), plus the cost gradient / Hessian blocks."""
@@ -134,7 +134,7 @@ def test_all_models_jacobians_and_cost_derivatives(model):
     for _ in range(3):
         x = rng.uniform(-0.7, 0.7, n)
         m = int(oracle.input_dims(model, None, t, 1)[0])
-        u = rng.uniform(-1, 1, m) * (5.0 if model in ("cartpole", "quadrotor") else 1.0)
+        u = rng.uniform(-1, 1, m) * (5.0 if model in ("cartpole", "quadrotor", "planar_vtol") else 1.0)
         ev = oracle.model_eval(model, None, t, x, u)
         Fx, Fu = fd_jacobians(model, None, t, x, u)
         assert np.linalg.norm(ev.Fx - Fx) < 1e-6

@@ -158,9 +158,12 @@ struct TileSolver64
   static constexpr int kKnextAt = kSlotAt + kNumSlotFields * kT64MaxGroup; //!< [32][8]: k_{i+1}, the BoxQP warm start (:452-467)
   static constexpr int kWaveAt = kKnextAt + (kConstrained ? kT64MaxGroup * 8 : 0);
   // per matrix wave: the column exchange of the gain computation, then (aliased: one wave's LDS traffic is ordered) the transposition
-  static constexpr int wQQ = 0; //!< [Qux_reg | Qu]: column j at 8 j, rows a < m
-  static constexpr int wF = wQQ + 8 * 16; //!< Quu_F: column c at wF + 8 c
-  static constexpr int wX = wF + 8 * 8; //!< Qx, row 4 r + q at wX + 4 q + r
+  //! leading dimension of the exchanged columns: ODD, so that the sixteen lanes of a row (one column each) hit different banks
+  //! (with 8 they shared two bank groups: an 8-way conflict on every exchange access, half of the kernel's LDS cycles)
+  static constexpr int kColLd = (MM % 2 == 1) ? MM : MM + 1;
+  static constexpr int wQQ = 0; //!< [Qux_reg | Qu]: column j at kColLd j, rows a < m
+  static constexpr int wF = wQQ + 9 * 16; //!< Quu_F: column c at wF + kColLd c
+  static constexpr int wX = wF + 9 * 8; //!< Qx, row 4 r + q at wX + 4 q + r
   static constexpr int wExchange = wX + 16;
   static constexpr int kTrLd = 17; //!< leading dimension of the transposition scratch: conflict-free both ways
   static constexpr int wT = 0;
@@ -1076,10 +1079,10 @@ struct TileSolver64
     for(int rr = 0; rr < KM; rr++)
     {
       const int a = 4 * rr + q;
-      W[(a < MM && j < N) ? wQQ + 8 * j + a : wDump] = c.QuxR[rr];
-      W[(a < MM && j < MM) ? wF + 8 * j + a : wDump] = c.QuuF[rr];
+      W[(a < MM && j < N) ? wQQ + kColLd * j + a : wDump] = c.QuxR[rr];
+      W[(a < MM && j < MM) ? wF + kColLd * j + a : wDump] = c.QuuF[rr];
     }
-    W[(q == qN && j < MM) ? wQQ + 8 * N + j : wDump] = c.qurow;
+    W[(q == qN && j < MM) ? wQQ + kColLd * N + j : wDump] = c.qurow;
     W[(q == qN && j < N) ? wX + 4 * (j & 3) + (j >> 2) : wDump] = c.qxrow;
   }
   /** Phase 2: ... read side. */
@@ -1092,14 +1095,14 @@ struct TileSolver64
 #pragma unroll
       for(int a = 0; a < MM; a++)
       {
-        c.fac[a + cc * MM] = (kConstrained || a >= cc) ? W[wF + 8 * cc + a] : 0.0; // (the factorisation reads the lower triangle)
+        c.fac[a + cc * MM] = (kConstrained || a >= cc) ? W[wF + kColLd * cc + a] : 0.0; // (the factorisation reads the lower triangle)
       }
     }
     const int jc = (j < N) ? j : N;
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
-      c.colQ[a] = W[wQQ + 8 * jc + a];
+      c.colQ[a] = W[wQQ + kColLd * jc + a];
       c.inv_d[a] = 0;
     }
     // Qx as column n of the accumulator of the value update: lane (q, n) register r <- Qx[4 r + q]
@@ -1145,7 +1148,7 @@ struct TileSolver64
         initial_k[a] = (i != T - 1) ? knext[a] : 0.0; // warm start from k_{i+1}    :452-467
         lo[a] = inputLimitLo(buf, b, i, a) - ua; // :470-472
         up[a] = inputLimitHi(buf, b, i, a) - ua;
-        Qu[a] = W[wQQ + 8 * N + a];
+        Qu[a] = W[wQQ + kColLd * N + a];
       }
       const Lane lane_code(problem, cfg, buf, b);
       typename Lane::QPOut qp;

@@ -3,7 +3,7 @@
 Host-side mirror of the reference interface (`DDPSolverBatch`, `Configuration`, problem handles); all numerics
 run in libnmpc_hip_ddp.so (hand-written HIP for gfx950) through the C-ABI of include/nmpc_hip_ddp.h.
 """
-from .ddp import (ComputationDuration, Configuration, ControlData, DDPSolverBatch, MpcLog,  # noqa: F401
+from .ddp import (ComputationDuration, Configuration, ControlData, DDPSolverBatch, DDPSolverPool, MpcLog,  # noqa: F401
                   TraceData)
 from .models import (DDPProblemBipedal, DDPProblemCartPole, DDPProblemCentroidalMotion,  # noqa: F401
                      DDPProblemManipulator, DDPProblemQuadrotor, DDPProblemVerticalMotion, make_problem)

@@ -509,3 +509,40 @@ class DDPSolverBatch:
                 f.write(f"{t.iter} {t.cost:g} {t.lambda_:g} {t.dlambda:g} {t.alpha:g} {t.k_rel_norm:g} "
                         f"{t.cost_update_actual:g} {t.cost_update_expected:g} {t.cost_update_ratio:g} "
                         f"{t.duration_derivative:g} {t.duration_backward:g} {t.duration_forward:g}\n")
+
+
+class DDPSolverPool:
+    """Several DDPSolverBatch handles of the same problem and batch size, each with its own stream: consecutive batches are
+    queued round-robin and overlap on the device.  A batch that is solved to convergence ends with a tail — a few instances
+    that run for hundreds of iterations on a few CUs (every DDPSolver object of the reference runs its own loop to the end,
+    DDPSolver.hpp:115-123); with the next batches already queued on other streams their workgroups take the CUs the finished
+    instances have vacated.  Results of a batch are those of the handle it ran on (bit-identical to a lone handle)."""
+
+    def __init__(self, problem: _Problem, batch_size: int, n_handles: int = 4, device: int = 0):
+        if n_handles < 1:
+            raise ValueError("n_handles should be positive")
+        self.solvers = [DDPSolverBatch(problem, batch_size, device=device) for _ in range(n_handles)]
+        self._next = 0
+
+    def config(self) -> Configuration:
+        """DDPSolver::config() of every handle (the first one's object: call applyConfig() after changing it)."""
+        return self.solvers[0].config()
+
+    def applyConfig(self) -> None:
+        c0 = self.solvers[0].config()
+        for s in self.solvers[1:]:
+            c = s.config()
+            for key, val in vars(c0).items():
+                setattr(c, key, val.copy() if isinstance(val, np.ndarray) else val)
+
+    def submit(self, d_t0: Optional[int], d_x0: int, d_u_init: int) -> DDPSolverBatch:
+        """Queue one batch (DEVICE pointers, reference layouts) on the next handle's stream; returns that handle.  Submitting
+        again to the same handle (after n_handles further batches) overwrites its results: read them first."""
+        s = self.solvers[self._next]
+        self._next = (self._next + 1) % len(self.solvers)
+        s.solveDevice(d_t0, d_x0, d_u_init)
+        return s
+
+    def synchronize(self) -> None:
+        for s in self.solvers:
+            s.synchronize()

@@ -1516,6 +1516,7 @@ struct ModelOpsTile32
     ops.wpi_workspace_doubles = &workspaceElems;
     ops.scalar_bytes = 4;
     ops.gain_layout = 1;
+    ops.own_problems_supported = [](int, int) { return 0; }; // one shared problem object per batch (see the header)
     return ops;
   }
 };

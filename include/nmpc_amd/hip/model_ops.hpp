@@ -54,6 +54,9 @@ struct ModelOps
   //! the same per launch, for problem types whose kernel families differ in it (nullptr: gain_layout): what a solve of `batch`
   //! instances with / without input constraints leaves behind
   int (*gain_layout_of)(int batch, int constrained) = nullptr;
+  //! 1 if the kernel launch_solve picks for such a batch has an instantiation with one problem object per instance
+  //! (nmpc_hip_ddp_set_model_params_batch is refused otherwise — at set time, not at the first solve); nullptr: it has
+  int (*own_problems_supported)(int batch, int constrained) = nullptr;
 };
 
 } // namespace hip

@@ -76,6 +76,12 @@ struct ModelOpsFor
   {
     return useTile64(constrained != 0) ? 1 : 0;
   }
+  /** One problem object per instance: every kernel family but the single-wavefront lane kernel has the instantiation. */
+  static int ownProblemsSupported(int batch, int constrained)
+  {
+    const int padded = (batch + kLanesPerBlock - 1) / kLanesPerBlock * kLanesPerBlock;
+    return (useTile64(constrained != 0) || useWpi(constrained != 0) || useQuad(padded, true) || useTwoWave()) ? 1 : 0;
+  }
   static size_t wpiWorkspaceDoubles(int T)
   {
     if constexpr(kWpiShape)
@@ -367,6 +373,7 @@ struct ModelOpsFor
     ops.scalar_bytes = static_cast<int>(sizeof(typename Problem::Scalar));
     ops.gain_layout = 0;
     ops.gain_layout_of = &gainLayoutOf;
+    ops.own_problems_supported = &ownProblemsSupported;
     static_assert(sizeof(typename Problem::Scalar) == 8, "these kernel families compute in double; fp32 problem types register "
                                                          "through ddp_kernels_tile32.hpp");
     return ops;

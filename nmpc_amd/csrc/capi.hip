@@ -903,6 +903,11 @@ extern "C"
       }
       return NMPC_HIP_OK;
     }
+    if(s->ops->own_problems_supported && !s->ops->own_problems_supported(s->B, s->cfg.with_input_constraint != 0 ? 1 : 0))
+    {
+      return fail(NMPC_HIP_ERR_RUNTIME, std::string("the kernel this handle solves on (") + s->ops->kernel_name(s->B, s->cfg.with_input_constraint != 0 ? 1 : 0)
+                                            + ") has no instantiation with one problem object per instance");
+    }
     const size_t pb = s->ops->param_bytes;
     if(bytes_per_instance != pb)
     {

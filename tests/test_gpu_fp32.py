@@ -292,6 +292,12 @@ def test_unsupported_combinations_fail_loudly():
     with pytest.raises(RuntimeError):
         s2.mpcRun(wl.t0, wl.x0, wl.u_init, n_ticks=2)
     assert nmpc_amd.make_problem("quadrotor_f32").dims()[:2] == (12, 4)
+    # one problem object per instance: refused when it is SET (no instantiation of the fp32 tile kernel takes them), not at
+    # the first solve
+    s3 = make(wl, max_iter=2)
+    s3.setProblemBatch([nmpc_amd.make_problem("quadrotor_f32", mass=1.0 + 0.01 * b) for b in range(wl.B)])
+    with pytest.raises(RuntimeError, match="one problem object per instance"):
+        s3.kernelName()  # (pushes the pending state to the handle)
 
 
 def test_full_size_c4_properties():

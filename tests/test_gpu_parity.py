@@ -1259,3 +1259,35 @@ def test_solver_pool_overlaps_consecutive_batches():
     for s, (X, U, it, st) in zip(pool.solvers, want):  # batch k % 4 ran on handle k % 4 every time
         assert np.array_equal(s.X(), X) and np.array_equal(s.iters(), it)
     assert t_pool < 0.75 * t_lone
+
+
+def test_c3_full_size_properties():
+    """BASELINE config 3 at its full size (bipedal, 1024 instances x T = 300) through size-independent properties: a repeated
+    solve is bit-identical; along every instance's trace an accepted step never increases the cost and the last row's cost is
+    the sum of the stored cost list; the stored trajectory is a rollout of the stored inputs (x_{i+1} = stateEq(t_i, x_i, u_i),
+    cost_i = runningCost, against the oracle's model on sampled instances); a sample of instances against the oracle's solve."""
+    from nmpc_amd import workloads
+    wl = workloads.bipedal_batch(B=1024, T=300, seed=1234)
+    s = make_solver(wl, max_iter=8)
+    assert s.kernelName() == "ddp_solve_quad_kernel"
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    X, U, cost, it, st, tr = s.X().copy(), s.U().copy(), s.cost().copy(), s.iters().copy(), s.status().copy(), s.trace().copy()
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert np.array_equal(X, s.X()) and np.array_equal(U, s.U()) and np.array_equal(it, s.iters()) and np.array_equal(tr, s.trace())
+    assert st.min() >= 0 and it.max() <= 8 and it.min() >= 1
+    J = cost.sum(axis=1)
+    for b in range(wl.B):
+        c = tr[b, : it[b] + 1, 1]
+        assert np.all(np.diff(c) <= 1e-9 * np.abs(c[:-1]) + 1e-300)  # monotone: a rejected step leaves the cost where it was
+        assert abs(c[-1] - J[b]) <= 1e-12 * abs(J[b]) + 1e-300
+    dt = 0.01
+    for b in range(0, wl.B, 64):
+        for i in range(0, wl.T, 7):
+            ev = oracle.model_eval("bipedal", None, wl.t0[b] + i * dt, X[b, i], U[b, i])
+            assert np.abs(ev.xn - X[b, i + 1]).max() <= 1e-12 * (1 + np.abs(X[b, i + 1]).max())
+            assert abs(ev.running_cost - cost[b, i]) <= 1e-12 * (1 + abs(cost[b, i]))
+    sample = np.arange(0, wl.B, 32)
+    ocfg = oracle.default_config(horizon_steps=wl.T, max_iter=8)
+    ref = oracle.solve_batch(wl.model, ocfg, wl.x0[sample], wl.u_init[sample], t0=wl.t0[sample], n_threads=8)
+    assert np.array_equal(st[sample], ref.status) and np.array_equal(it[sample], ref.iters)
+    assert scaled_err(X[sample], ref.X) <= TOL and scaled_err(U[sample], ref.U) <= TOL

@@ -1488,7 +1488,12 @@ struct TileSolver64
       per_instance = (per_instance > kRingDepth * kRingRows) ? per_instance : kRingDepth * kRingRows; // (line search: nominal ring)
       int g = room / per_instance;
       g = g > kT64MaxGroup ? kT64MaxGroup : g;
-      const int spread = (buf.B + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x); // every workgroup gets work
+      // every workgroup gets work, and the same amount: rounds = passes a workgroup makes over its groups with the largest group
+      // the LDS holds; the groups are then as small as that number of rounds allows (8200 instances on 256 CUs: two rounds
+      // of 17 instead of a round of 32 and one straggler group)
+      const int wgs = static_cast<int>(gridDim.x);
+      const int rounds = (buf.B + wgs * g - 1) / (wgs * g);
+      const int spread = (buf.B + rounds * wgs - 1) / (rounds * wgs);
       g = g > spread ? spread : g;
       if(group_cap > 0 && g > group_cap)
       {

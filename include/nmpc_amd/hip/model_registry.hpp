@@ -55,7 +55,12 @@ struct ModelOpsFor
       replaces the wave-per-instance kernel on these shapes; NMPC_HIP_DDP_KERNEL=wpi / 1w select the older kernels (A/B). */
   static constexpr bool kTile64Shape = !Problem::kDynamicInput && Problem::kStateDim >= 5 && Problem::kStateDim <= 15
                                        && Problem::kInputDimMax >= 1 && Problem::kInputDimMax <= 8;
-  static bool useTile64(bool constrained)
+  //! Up to this batch the wave-per-instance kernel is the faster one where both exist (n >= 9): a group's sweep cannot go
+  //! faster than its model wave linearises one timestep (20 k cycles for the manipulator, whatever the group size), while a
+  //! wave-per-instance launch linearises all timesteps of an instance at once; measured (scripts/tile64_batch_scaling.py,
+  //! profiles/r03b_tile64_batch_scaling.txt): manipulator 1.6 ms against 2.7 ms at 1024 instances, 3.1 against 2.7 at 2048.
+  static constexpr int kTile64MinBatch = 1025;
+  static bool useTile64(bool constrained, int batch)
   {
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
     if(!kTile64Shape || (force && (std::strcmp(force, "1w") == 0 || std::strcmp(force, "wpi") == 0)))
@@ -66,21 +71,25 @@ struct ModelOpsFor
     {
       return true;
     }
+    if(kWpiShape && batch < kTile64MinBatch)
+    {
+      return false;
+    }
     // Box-constrained solves: every lane of a wave runs the BoxQP of its instance, which dominates the step and does not
     // care how the waves are grouped — measured (scripts/constrained_tile64_ab.py, 8192 instances) the wave-per-instance
     // kernel is 20 % faster there, so it keeps them where it exists (n >= 9); the tile kernel takes them for 5 <= n <= 8.
     return !(constrained && kWpiBoxQP);
   }
   /** Where k_list_ / K_list_ are after a solve: the tile kernel leaves instance-major records in the workspace. */
-  static int gainLayoutOf(int, int constrained)
+  static int gainLayoutOf(int batch, int constrained)
   {
-    return useTile64(constrained != 0) ? 1 : 0;
+    return useTile64(constrained != 0, batch) ? 1 : 0;
   }
   /** One problem object per instance: every kernel family but the single-wavefront lane kernel has the instantiation. */
   static int ownProblemsSupported(int batch, int constrained)
   {
     const int padded = (batch + kLanesPerBlock - 1) / kLanesPerBlock * kLanesPerBlock;
-    return (useTile64(constrained != 0) || useWpi(constrained != 0) || useQuad(padded, true) || useTwoWave()) ? 1 : 0;
+    return (useTile64(constrained != 0, batch) || useWpi(constrained != 0) || useQuad(padded, true) || useTwoWave()) ? 1 : 0;
   }
   static size_t wpiWorkspaceDoubles(int T)
   {
@@ -140,7 +149,7 @@ struct ModelOpsFor
     {
       return "ddp_solve_quad_kernel";
     }
-    if(useTile64(constrained != 0))
+    if(useTile64(constrained != 0, batch))
     {
       return "ddp_solve_tile64_kernel";
     }
@@ -162,7 +171,7 @@ struct ModelOpsFor
     const bool con = cfg.with_input_constraint != 0;
     if constexpr(kTile64Shape)
     {
-      if(useTile64(con))
+      if(useTile64(con, buf.B))
       {
         if(buf.wpi_ws == nullptr)
         {

@@ -15,6 +15,8 @@ Cases (SURVEY.md §8 c "golden fixtures to commit"):
   vertical T=300 solves straddling the input-dimension changes (t0 = 1.9, 4.4), with and without constraints
   centroidal T=100 at t0 = 0 (3 iterations), t0 = 1.0 (horizon crosses the flight phase)
   quadrotor T=50, manipulator T=30: 2 seeds each, 10 iterations
+  planar_vtol T=60 (n 6, m 2): 2 seeds, 10 iterations; one box-constrained
+  quadrotor_f32 T=50: 2 seeds, 3 iterations, cost_update_thre 1e-3 (the oracle instantiated in float)
 """
 import os
 import sys
@@ -86,6 +88,22 @@ def main():
         names.append(nm)
         nm = f"manipulator_s{b}"
         run_case(store, nm, "manipulator", dict(horizon_steps=30, max_iter=10), wm.x0[b], wm.u_init[b])
+        names.append(nm)
+    # round 3: the builder-defined n = 6, m = 2 shape (5 <= n <= 8: fp64 tile kernel), unconstrained and with a rotor-thrust box
+    wp = workloads.planar_vtol_batch(B=2, T=60, seed=1234)
+    for b in range(2):
+        nm = f"planar_vtol_s{b}"
+        run_case(store, nm, "planar_vtol", dict(horizon_steps=60, max_iter=10), wp.x0[b], wp.u_init[b])
+        names.append(nm)
+    wpc = workloads.planar_vtol_batch(B=1, T=60, seed=77, constrained=True)
+    run_case(store, "planar_vtol_box", "planar_vtol", dict(horizon_steps=60, max_iter=10, with_input_constraint=1), wpc.x0[0], wpc.u_init[0],
+             limits=wpc.limits)
+    names.append("planar_vtol_box")
+    # fp32 (BASELINE config 4's arithmetic): the oracle instantiated in float, the threshold an fp32 cost resolves
+    wf = workloads.quadrotor_batch(B=2, T=50, seed=1234, fp32=True)
+    for b in range(2):
+        nm = f"quadrotor_f32_s{b}"
+        run_case(store, nm, "quadrotor_f32", dict(horizon_steps=50, max_iter=3, cost_update_thre=1e-3), wf.x0[b], wf.u_init[b])
         names.append(nm)
     store["__names__"] = np.array(names)
     np.savez_compressed(OUT, **store)

@@ -1070,11 +1070,21 @@ struct TileSolver64
       c.QuuF[rr] = (4 * rr + q == j) ? c.Quu[rr] + lambda : c.Quu[rr];
     }
   }
+  /** The lane id as a value the compiler cannot hoist computations on out of the timestep loop.  The per-lane LDS addresses of
+      the exchange / transposition are a handful of integer operations on it; computed once per sweep they are ~10 more
+      registers live across the whole step, which the register allocator spilled — and reloaded one by one behind a vmcnt(0)
+      (measured: six scratch round trips in front of the exchange writes, ~2.5 k of a step's 7.9 k cycles). */
+  NMPC_D int freshLane() const
+  {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return l;
+  }
   /** Phase 1c: column exchange through the wave's scratch W, write side: lane (., c) will get column c of [Qux_reg | Qu],
       every lane Quu_F; Qx goes from a row of lanes to a column. */
   NMPC_D void stepExchangeWrite(const StepCtx & c, double * W) const
   {
-    const int q = lane >> 4, j = lane & 15;
+    const int fl = freshLane(), q = fl >> 4, j = fl & 15;
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
@@ -1088,7 +1098,7 @@ struct TileSolver64
   /** Phase 2: ... read side. */
   NMPC_D void stepExchangeRead(StepCtx & c, const double * W) const
   {
-    const int q = lane >> 4, j = lane & 15;
+    const int fl = freshLane(), q = fl >> 4, j = fl & 15;
 #pragma unroll
     for(int cc = 0; cc < MM; cc++)
     {
@@ -1208,7 +1218,7 @@ struct TileSolver64
       value function to the scratch.  Branch-free. */
   NMPC_D void stepValueUpdate(StepCtx & c, double * W) const
   {
-    const int q = lane >> 4, j = lane & 15;
+    const int fl = freshLane(), q = fl >> 4, j = fl & 15;
     v4d64 QQ = {0, 0, 0, 0};
     c.A = v4d64{0, 0, 0, 0};
 #pragma unroll
@@ -1258,14 +1268,14 @@ struct TileSolver64
       other lanes update a dump word: no branch). */
   NMPC_D void stepFinish(StepCtx & c, const LaneMap & mp, double * W, int slot) const
   {
-    const int q = lane >> 4, j = lane & 15;
+    const int fl = freshLane(), q = fl >> 4, j = fl & 15;
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
       const double vt = W[(4 * rr + q < N && j < N) ? wT + j * kTrLd + 4 * rr + q : wZero];
       c.VV[rr] = mp.wn * c.Vn[rr] + mp.wt * vt;
     }
-    const bool star = lane == kStarLane;
+    const bool star = fl == kStarLane;
     double * dv0 = star ? &slotF(sDV0, slot) : W + wDump;
     double * dv1 = star ? &slotF(sDV1, slot) : W + wDump + 1;
     double * kr = star ? &slotF(sKrel, slot) : W + wDump;

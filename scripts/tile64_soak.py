@@ -1,0 +1,47 @@
+"""Soak of the fp64 tile kernel: the FIRST solves of a fresh process and many repetitions must all be bit-identical, and equal
+to the wave-per-instance kernel's decisions (iteration counts, status) with values to rounding."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import nmpc_amd  # noqa: E402
+from nmpc_amd import workloads  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+
+
+def solver(model, B, T, kernel):
+    os.environ["NMPC_HIP_DDP_KERNEL"] = kernel
+    wl = workloads.quadrotor_batch(B=B, T=T, seed=1234) if model == "quadrotor" else workloads.manipulator_batch(B=B, T=T, seed=1234)
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B)
+    c = s.config()
+    c.print_level = 0
+    c.horizon_steps = wl.T
+    c.max_iter = 8
+    return wl, s
+
+
+bad_total = 0
+for model, T, B in (("manipulator", 30, 8192), ("quadrotor", 50, 8192), ("manipulator", 30, 3000)):
+    wl, s = solver(model, B, T, "tile64")  # tile kernel first: nothing has touched the device before
+    first = None
+    n_bad = 0
+    for rep in range(reps):
+        s.solve(wl.t0, wl.x0, wl.u_init)
+        cur = (s.iters().copy(), s.status().copy(), s.X().copy(), s.U().copy())
+        if first is None:
+            first = cur
+        elif not all(np.array_equal(a, b) for a, b in zip(first, cur)):
+            n_bad += 1
+            d = np.flatnonzero(first[0] != cur[0])
+            print(f"   {model} B {B} rep {rep}: differs from the first solve; iteration counts on {d.size} instances {d[:8]}", flush=True)
+    wl, r = solver(model, B, T, "wpi")
+    r.solve(wl.t0, wl.x0, wl.u_init)
+    same_dec = np.array_equal(first[0], r.iters()) and np.array_equal(first[1], r.status())
+    err = float((np.abs(first[2] - r.X()) / (1 + np.abs(r.X()))).max())
+    print(f"{model} B {B}: {reps} solves, {n_bad} differ from the first; decisions equal to the wave-per-instance kernel: {same_dec}, "
+          f"max scaled |dX| {err:.1e}", flush=True)
+    bad_total += n_bad + (0 if same_dec and err < 1e-9 else 1)
+print("SOAK", "OK" if bad_total == 0 else "FAILED")

@@ -141,7 +141,7 @@ for wl, entry in traffic.items():
     rf["hbm_frac_measured"] = rf["traffic"] / (rf["kernel_ms_avg"] * 1e-3) / 1e9 / rf["peak"]
     json.dump(b, open(path, "w"), indent=1)
 for extra in ("fanout_ab.txt", "batch_scaling.txt", "ubench_mfma_f32.txt", "ubench_mfma_f64_16.txt", "tile64_phases.txt", "constrained_ab.txt",
-              "mpc_throughput.txt", "tile64_batch_scaling.txt", "m2_overlap.txt", "constrained_tile64_ab.txt"):
+              "mpc_throughput.txt", "tile64_batch_scaling.txt", "m2_overlap.txt", "constrained_tile64_ab.txt", "tile64_soak.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
 print(json.dumps(traffic, indent=1))

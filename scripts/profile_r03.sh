@@ -48,6 +48,7 @@ python scripts/tile64_profile.py > $OUT/tile64_phases.txt 2>&1
 python scripts/tile64_batch_scaling.py > $OUT/tile64_batch_scaling.txt 2>&1
 python scripts/m2_overlap.py 16 1 2 4 8 > $OUT/m2_overlap.txt 2>&1
 python scripts/constrained_tile64_ab.py > $OUT/constrained_tile64_ab.txt 2>&1
+python scripts/tile64_soak.py 100 > $OUT/tile64_soak.txt 2>&1
 python scripts/batch_scaling.py > $OUT/batch_scaling.txt 2>&1
 ls $OUT | head -80
 python scripts/constrained_ab.py > $OUT/constrained_ab.txt 2>&1

@@ -79,7 +79,9 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
   static constexpr int oLx = 40;
   static constexpr int oLuu = 44; // Luu then Lu: entries (0, 0) and (0, 1) of one 4 x 4 operand
   static constexpr int oLu = 45;
-  static constexpr int oU = 46;
+  static constexpr int oU = 46; // unconstrained: u_i.  Box-constrained solves keep what the BoxQP needs instead:
+  static constexpr int oLoRel = 46; // lower limit - u_i, upper limit - u_i (DDPSolver.hpp:470-472), evaluated with the
+  static constexpr int oUpRel = 48; // derivatives: the limits' loads are off the recursion's dependency chain
   static constexpr int oZero = 47; // 0.0: what the lanes outside a masked operand read
   static constexpr int kRecQ = 49; // odd: the 64 lanes of the linearisation write conflict-free
   static constexpr int kChunkSteps = 16;
@@ -150,6 +152,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
   struct PointQ
   {
     double x[N], u;
+    double lo, hi; //!< input limits of the timestep (box-constrained solves)
   };
   NMPC_D static void loadPointQ(int i, const double * px, const double * pu, PointQ & p)
   {
@@ -212,7 +215,15 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     }
     put<kFull>(rec + oLuu, Luu(0, 0));
     put<kFull>(rec + oLu, Lu[0]);
-    rec[oU] = u[0];
+    if constexpr(kConstrained)
+    {
+      rec[oLoRel] = p.lo - u[0];
+      rec[oUpRel] = p.hi - u[0];
+    }
+    else
+    {
+      rec[oU] = u[0];
+    }
     put<kFull>(rec + oZero, 0.0);
     return recipFast(fabs(u[0]) + 1.0);
   }
@@ -260,7 +271,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     const int aLxuRow = oLxu + col; // Lxu^T in every row
     struct Operands
     {
-      double Fx, Lxx, LxxT, FuM, FuB, LM, CM, LxuRow, u;
+      double Fx, Lxx, LxxT, FuM, FuB, LM, CM, LxuRow, lo, up;
     };
     auto loadOperands = [&](int ts, Operands & o)
     {
@@ -275,7 +286,8 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       o.LxuRow = R[aLxuRow];
       if constexpr(kConstrained)
       {
-        o.u = R[oU];
+        o.lo = R[oLoRel];
+        o.up = R[oUpRel];
       }
     };
 
@@ -351,18 +363,15 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       // ---- gains    :448-517   (m = 1: the factorisation is the pivot itself; inv = 0 leaves k = K = 0)
       double k, inv;
       bool step_ok;
+      [[maybe_unused]] double qp_code = 0;
       if constexpr(kConstrained)
       {
         const double initial_k = (i != T - 1 && have_next) ? k_next : 0.0;
-        const double lo = inputLimitLo(buf, b_q, i, 0) - o.u;
-        const double up = inputLimitHi(buf, b_q, i, 0) - o.u;
         QPOut qp;
-        Base::boxQP(1, &Quu_F, &Qu, &lo, &up, &initial_k, qp);
-        if(need && ok && r0 && c0)
-        {
-          Base::tileBase(buf.qp_ret, tile_T)[static_cast<size_t>(i) * LW + lane_q] = qp.retval;
-          Base::tileBase(buf.qp_free, tile_T)[static_cast<size_t>(i) * LW + lane_q] = (qp.n_free > 0) ? 1u : 0u;
-        }
+        Base::boxQP1Fast(Quu_F, Qu, o.lo, o.up, initial_k, qp);
+        // retval_ and the free set of this timestep (DDPSolver.h:152-157 keeps them for the caller) travel with the gains:
+        // 4 (retval + 8) + 2 [free] (+ 1: the gains are to be saved), 0 = the pass had failed before this timestep
+        qp_code = (need && ok) ? static_cast<double>(4 * (qp.retval + 8) + (qp.n_free > 0 ? 2 : 0)) : 0.0;
         step_ok = qp.retval >= 0;
         k = step_ok ? qp.x[0] : 0.0;
         inv = (step_ok && qp.n_free > 0) ? qp.inv_d[0] : 0.0;
@@ -395,7 +404,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       // ---- save gains    :529-530 (staged, see flushGains)
       if constexpr(kGuarded)
       {
-        gain_q[static_cast<size_t>(ts) * kGainRec] = r0 ? Kc : (c0 ? k : (live ? 1.0 : 0.0));
+        gain_q[static_cast<size_t>(ts) * kGainRec] = r0 ? Kc : (c0 ? k : (kConstrained ? qp_code + (live ? 1.0 : 0.0) : (live ? 1.0 : 0.0)));
       }
       else
       {
@@ -410,11 +419,32 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
         timestep) pair in the linearisation mapping, which also takes the running max of |k_i| / (|u_i| + 1)
         (DDPSolver.hpp:217-221; uinv = this lane's 1 / (|u_i| + 1) from the chunk's linearisation): two instructions per
         chunk here instead of an LDS read and two instructions per timestep in the recursion. */
+    const int b_l = b - static_cast<int>(lane) + lane_l; // global index of this lane's instance in the linearisation mapping
+    auto loadLimits = [&](int i, PointQ & p)
+    {
+      if constexpr(kConstrained)
+      {
+        p.lo = inputLimitLo(buf, b_l, i, 0);
+        p.hi = inputLimitHi(buf, b_l, i, 0);
+      }
+    };
     double krn_l = 0;
     auto flushGains = [&](int i_first, double uinv)
     {
       const int i = i_first + ts_l;
-      if(i < T && gain_l[gLive] != 0.0)
+      const double flag = (i < T) ? gain_l[gLive] : 0.0;
+      bool save = flag != 0.0;
+      if constexpr(kConstrained)
+      {
+        const int code = static_cast<int>(flag);
+        if(save)
+        {
+          Base::tileBase(buf.qp_ret, tile_T)[static_cast<size_t>(i) * LW + lane_l] = (code >> 2) - 8;
+          Base::tileBase(buf.qp_free, tile_T)[static_cast<size_t>(i) * LW + lane_l] = static_cast<unsigned>((code >> 1) & 1);
+        }
+        save = (code & 1) != 0;
+      }
+      if(save)
       {
         const double kv = gain_l[gK];
         Base::kt[static_cast<size_t>(i) * LW + lane_l] = kv;
@@ -433,6 +463,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       {
         const int i = ((n_chunks - 1) * kChunkSteps + ts_l < T) ? (n_chunks - 1) * kChunkSteps + ts_l : T - 1;
         loadPointQ(i, px, pu, pt);
+        loadLimits(i, pt);
       }
       double uinv_prev = 0; // 1 / (|u| + 1) of this lane's timestep in the chunk whose gains are staged
       for(int ch = n_chunks - 1; ch >= 0; ch--)
@@ -462,6 +493,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
         {
           const int in = i0 - kChunkSteps + ts_l; // (unconditional, clamped: the last request is never used)
           loadPointQ(in > 0 ? in : 0, px, pu, pt);
+          loadLimits(in > 0 ? in : 0, pt);
         }
         const int hi = (i0 + kChunkSteps - 1 < T) ? i0 + kChunkSteps - 1 : T - 1;
         if constexpr(!kConstrained)

@@ -173,8 +173,12 @@ struct TileSolver64
   static constexpr int kScratchPerWave = 1;
   static constexpr int kLsAt = kWaveAt + kT64MatrixWaves * kScratchPerWave * kWaveDoubles; //!< lsJ[NMPC_HIP_MAX_ALPHA][32]: cost of every trial
   static constexpr int kTraceAt = kLsAt + NMPC_HIP_MAX_ALPHA * kT64MaxGroup; //!< trace row of the running iteration, [field][32]
-  static constexpr int kProfAt = kTraceAt + NMPC_HIP_NTRACE * kT64MaxGroup; //!< profiling builds: 16 tick counters of workgroup 0
+  static constexpr int kProfAt = kTraceAt + NMPC_HIP_NTRACE * kT64MaxGroup; //!< profiling builds: 40 tick counters of workgroup 0
+#ifdef NMPC_AMD_PROFILE_TILE64
+  static constexpr int kFixedRaw = kProfAt + 40;
+#else
   static constexpr int kFixedRaw = kProfAt + 16;
+#endif
   static constexpr int kRecAt = (kFixedRaw + 1) & ~1; //!< records: rec[2][G][stride]; before a sweep: [Vxx | Vx] per slot
   static constexpr int kTerm = (N + 1) * N; //!< terminal record: n + 1 columns of n rows
   // line search: ring of nominal records [depth][row][G] in the record area; rows of a timestep: k_i (m), K_i (m n, column-major),
@@ -1413,6 +1417,8 @@ struct TileSolver64
       profAdd(11, pb - pa, 5);
       barrier(); // record i has been read by all, record i - 1 is complete
       profAdd(3, profNow() - pb, 1);
+      profAdd(16 + wave, pb - pa, wave); // every matrix wave: its steps of this timestep ...
+      profAdd(24 + wave, profNow() - pb, wave); // ... and its wait at the barrier
     }
     if(lane == kStarLane)
     {
@@ -1984,7 +1990,7 @@ struct TileSolver64
       waveScratch(0)[wZero + lane] = 0.0; // zero words (read by lanes outside a block) and dump words (written by them)
     }
 #ifdef NMPC_AMD_PROFILE_TILE64
-    if(threadIdx.x < 16)
+    if(threadIdx.x < 40)
     {
       reinterpret_cast<unsigned long long *>(lds + kProfAt)[threadIdx.x] = 0;
     }
@@ -1996,9 +2002,10 @@ struct TileSolver64
       solveGroup(group);
     }
 #ifdef NMPC_AMD_PROFILE_TILE64
-    if(blockIdx.x == 0 && threadIdx.x < 16)
+    if(blockIdx.x == 0 && threadIdx.x < 40)
     {
-      buf.qp_free[static_cast<size_t>(threadIdx.x) * 64] =
+      // counter k -> row k % T of instance k / T (instances 0, 1 of tile 0)
+      buf.qp_free[static_cast<size_t>(threadIdx.x % T) * 64 + threadIdx.x / T] =
           static_cast<unsigned>(reinterpret_cast<unsigned long long *>(lds + kProfAt)[threadIdx.x] >> 4);
     }
 #endif

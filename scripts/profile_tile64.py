@@ -22,7 +22,8 @@ c.horizon_steps = wl.T
 c.max_iter = mi
 for _ in range(2):
     s.solve(wl.t0, wl.x0, wl.u_init)
-q = s.qpFreeMask()[0, :16].astype(np.float64)
+_m = s.qpFreeMask()
+q = np.concatenate([_m[0, :wl.T], _m[1, :wl.T]])[:40].astype(np.float64)
 tick = q.copy()
 for k in (0, 1, 2, 3, 5, 6, 7, 8, 11):
     tick[k] *= 16.0
@@ -36,3 +37,5 @@ print(f"  per sweep timestep:   model wave linearisation {tick[0] / max(sweeps *
       f"instance-step) | matrix wave 5 steps {tick[11] / max(sweeps * T, 1):8.0f}")
 print(f"  per rollout timestep: rolling lanes compute {tick[5] / max(passes * (T + 2), 1):8.0f} waiting {tick[6] / max(passes * (T + 2), 1):8.0f}   | "
       f"prefetching wave 1: prefetch {tick[7] / max(passes * (T + 2), 1):8.0f} waiting {tick[8] / max(passes * (T + 2), 1):8.0f}")
+print("  matrix waves 1 .. 7, ticks over the solve (M): steps " + " ".join(f"{q[16 + w] * 16.0 / 1e6:6.2f}" for w in range(1, 8))
+      + "   waiting at the sweeps' barriers " + " ".join(f"{q[24 + w] * 16.0 / 1e6:6.2f}" for w in range(1, 8)))

@@ -668,7 +668,13 @@ struct InstanceSolver
     const bool ascent0 = sdg0 > 1e-10; // -> -2
     const double x1 = clampToBox(x0 + dir0); // step = 1
     const double obj1 = objective(x1);
-    const bool shrink0 = (obj1 - obj0) / sdg0 < cfg.qp_armijo_param; // the Armijo loop would run: not decided here
+    // Armijo test of the full step, (obj1 - obj0) / (1 * sdg0) < armijo_param (BoxQP.h:299): for sdg0 < 0 the quotient is
+    // >= armijo_param iff obj1 - obj0 <= armijo_param sdg0; sixteen ulps away from that boundary the rounding of the division
+    // (and of the product here) cannot change the outcome, so the IEEE division — a dozen dependent quarter-rate
+    // instructions on the recursion's chain — is left to boxQP1 for the calls that are not decided without it.
+    const double armijo_rhs = cfg.qp_armijo_param * sdg0;
+    const bool accept0 = sdg0 < 0 && (obj1 - obj0) < armijo_rhs - fabs(armijo_rhs) * 0x1p-48;
+    const bool shrink0 = !accept0; // the Armijo loop runs (or the test is too close to call): not decided here
     // ---- iteration 2    BoxQP.h:176-253
     const bool stalled1 = (obj0 - obj1) < cfg.qp_rel_improve_thre * fabs(obj0); // -> 4
     const double grad1 = g + H * x1;

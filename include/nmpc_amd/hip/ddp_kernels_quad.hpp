@@ -368,7 +368,15 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       {
         const double initial_k = (i != T - 1 && have_next) ? k_next : 0.0;
         QPOut qp;
+#ifdef NMPC_AMD_PROFILE_QP
+        asm volatile("s_nop 0" ::"v"(Quu_F), "v"(Qu));
+        const unsigned long long tq = __builtin_readcyclecounter();
+#endif
         Base::boxQP1Fast(Quu_F, Qu, o.lo, o.up, initial_k, qp);
+#ifdef NMPC_AMD_PROFILE_QP
+        asm volatile("s_nop 0" ::"v"(qp.x[0]), "v"(qp.retval));
+        Pair::prof_wait += __builtin_readcyclecounter() - tq;
+#endif
         // retval_ and the free set of this timestep (DDPSolver.h:152-157 keeps them for the caller) travel with the gains:
         // 4 (retval + 8) + 2 [free] (+ 1: the gains are to be saved), 0 = the pass had failed before this timestep
         qp_code = (need && ok) ? static_cast<double>(4 * (qp.retval + 8) + (qp.n_free > 0 ? 2 : 0)) : 0.0;
@@ -479,7 +487,9 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
           uinv_now = (ch == n_chunks - 1) ? lineariseStep<true>(i, t0_l, pt, rec_l) : lineariseStep<false>(i, t0_l, pt, rec_l);
 #ifdef NMPC_AMD_PROFILE_2W
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef NMPC_AMD_PROFILE_QP
           Pair::prof_wait += __builtin_readcyclecounter() - tl; // reported as "barrier wait": the linearisation share
+#endif
           Pair::prof_count++;
 #endif
         }
@@ -496,7 +506,11 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
           loadLimits(in > 0 ? in : 0, pt);
         }
         const int hi = (i0 + kChunkSteps - 1 < T) ? i0 + kChunkSteps - 1 : T - 1;
+#ifdef NMPC_AMD_QUAD_NO_STRAIGHT
+        if constexpr(false)
+#else
         if constexpr(!kConstrained)
+#endif
         {
           const int n_steps = hi - i0 + 1;
           if((n_steps == kChunkSteps || n_steps == 4) && __all(ok))

@@ -100,9 +100,21 @@ struct Unroll
 };
 } // namespace detail
 
+/** Workgroup barrier that also orders HBM traffic between the waves of the workgroup: everything this wave has stored is
+    acknowledged (s_waitcnt vmcnt(0): gfx9 counts loads and stores in one counter) before it arrives at the barrier, and the
+    waves of a workgroup share their CU's vector L1, so what has landed is what they load.  hipcc's __syncthreads() is
+    `s_waitcnt lgkmcnt(0); s_barrier` (ROCm 7.2, every kernel of this library: llvm-objdump) — it orders LDS only, and a wave
+    that loads what another wave of its workgroup stored just before such a barrier races with the store's completion
+    (seen once in ~60 GPU sessions as a stale row read back by the next pass). */
+NMPC_D inline void fullBarrier()
+{
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 /** Input limits of instance b at timestep i (input_limits_func_(current_t + i dt), DDPSolver.hpp:470-472): the sampled
     table if time-varying limits were given, else the instance's own constant limits, else the shared ones. */
-NMPC_D double inputLimit(const DeviceBuffers & buf, int b, int i, int a, int side)
+template<class Buffers>
+NMPC_D double inputLimit(const Buffers & buf, int b, int i, int a, int side)
 {
   if(buf.lim_steps != nullptr)
   {
@@ -116,19 +128,21 @@ NMPC_D double inputLimit(const DeviceBuffers & buf, int b, int i, int a, int sid
   }
   return side == 0 ? buf.lim_lo[a] : buf.lim_hi[a];
 }
-NMPC_D double inputLimitLo(const DeviceBuffers & buf, int b, int i, int a)
+template<class Buffers>
+NMPC_D double inputLimitLo(const Buffers & buf, int b, int i, int a)
 {
   return inputLimit(buf, b, i, a, 0);
 }
-NMPC_D double inputLimitHi(const DeviceBuffers & buf, int b, int i, int a)
+template<class Buffers>
+NMPC_D double inputLimitHi(const Buffers & buf, int b, int i, int a)
 {
   return inputLimit(buf, b, i, a, 1);
 }
 
 /** The problem object instance b solves: the handle's shared one, or its own when per-instance objects were given
     (nmpc_hip_ddp_set_model_params_batch: a batch of solvers with different robots / weights). */
-template<class Problem>
-NMPC_D Problem instanceProblem(const Problem & shared, const DeviceBuffers & buf, int b)
+template<class Problem, class Buffers>
+NMPC_D Problem instanceProblem(const Problem & shared, const Buffers & buf, int b)
 {
   Problem mine = shared;
   if(buf.params_batch != nullptr)

@@ -162,7 +162,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   {
     return (kAlphaGroups > 1) ? waveLane() / kGroupLanes : 0u;
   }
-  /** Workgroup barrier for the LDS hand-off.  Only LDS traffic has to be complete (lgkmcnt); __syncthreads() would
+  /** Workgroup barrier for the LDS hand-off.  Only LDS traffic has to be complete (lgkmcnt); fullBarrier() would
       also wait for vmcnt(0), i.e. drain the helper's HBM prefetches and the stores of every timestep. */
 #ifdef NMPC_AMD_PROFILE_2W
   // Profiling build (NMPC_AMD_EXTRA_HIPCC_FLAGS=-DNMPC_AMD_PROFILE_2W python -m nmpc_amd.build --force, then
@@ -1569,14 +1569,14 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     mailFlags() = static_cast<double>(cmd * 2 + sel);
     // barrier P: command visible.  Pass boundaries use the full barrier (vmcnt(0) too): what one wave stored to HBM
     // in the previous pass (gains k, K; the candidate trajectory) is loaded by the other wave in the next one.
-    __syncthreads();
+    fullBarrier();
   }
 
   NMPC_D void helperLoop() const
   {
     for(;;)
     {
-      __syncthreads(); // barrier P (full: see post())
+      fullBarrier(); // barrier P (full: see post())
       const int word = static_cast<int>(mailFlags());
       const int cmd = __builtin_amdgcn_readfirstlane(word >> 1);
       const int sel_h = word & 1;

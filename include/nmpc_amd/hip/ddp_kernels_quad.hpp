@@ -602,7 +602,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
       mailOut(inst, 1) = dV0_l;
       mailOut(inst, 2) = dV1_l;
     }
-    __syncthreads(); // closes the pass: results in the mailboxes, gains in HBM
+    fullBarrier(); // closes the pass: results in the mailboxes, gains in HBM
   }
 
   /** Master side of one backward pass: publish the inputs, run this wave's share, collect the results. */
@@ -648,7 +648,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
   {
     for(;;)
     {
-      __syncthreads(); // barrier P of PairSolver::post()
+      fullBarrier(); // barrier P of PairSolver::post()
       const int word = static_cast<int>(Pair::mailFlags());
       const int cmd = __builtin_amdgcn_readfirstlane(word >> 1);
       const int sel_h = word & 1;

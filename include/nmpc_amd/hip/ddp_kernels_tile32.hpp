@@ -31,7 +31,8 @@
 // rounding-level differences, inside the fp32 tolerance of SURVEY.md §8(c).
 //
 // Scope of this kernel family: Scalar = float, static input dimension, n in {4, 8, 12}, 1 <= m <= 4, n + m <= 16,
-// unconstrained solves (with_input_constraint is rejected at launch), one shared problem object per batch.
+// unconstrained solves (with_input_constraint is rejected at launch); a shared problem object or one per instance
+// (kOwnProblem); the receding-horizon driver (mpc_kernels.hpp) advances the handle's float arrays in place.
 #pragma once
 
 #include <cstring>
@@ -39,6 +40,7 @@
 #include <type_traits>
 
 #include <nmpc_amd/hip/model_ops.hpp>
+#include <nmpc_amd/hip/mpc_kernels.hpp>
 
 namespace nmpc_amd
 {
@@ -77,7 +79,7 @@ __host__ __device__ constexpr int tileWaveFirst(int w)
 }
 static_assert(tileWaveFirst(kTileWaves) == kTileInstances, "the matrix waves cover the 32 slots");
 
-template<class Problem>
+template<class Problem, bool kOwnProblem = false>
 struct TileSolver32
 {
   using S = float;
@@ -147,7 +149,10 @@ struct TileSolver32
     return static_cast<size_t>(T) * kGain;
   }
 
-  const Problem & problem;
+  //! the problem object of this lane's instance: the handle's shared one (uniform: scalar registers), or — batches with
+  //! per-instance objects, nmpc_hip_ddp_set_model_params_batch — the lane's own copy.  Only the model wave evaluates the
+  //! problem, and its lane `slot` stands for instance 32 blockIdx.x + slot in the rollouts and in the sweeps alike.
+  std::conditional_t<kOwnProblem, const Problem, const Problem &> problem;
   const nmpc_hip_ddp_config & cfg;
   const DeviceBuffersT<float> & buf;
   const int T;
@@ -155,8 +160,21 @@ struct TileSolver32
   const int lane;
   float * lds;
 
+  NMPC_D static decltype(auto) problemOfLane(const Problem & p, const DeviceBuffersT<float> & bf)
+  {
+    if constexpr(kOwnProblem)
+    {
+      const int b = static_cast<int>(blockIdx.x) * kTileInstances + (static_cast<int>(threadIdx.x) & (kTileInstances - 1));
+      const bool evaluates = (static_cast<int>(threadIdx.x) >> 6) == kTileModelWave && b < bf.B;
+      return evaluates ? instanceProblem(p, bf, b) : p;
+    }
+    else
+    {
+      return (p);
+    }
+  }
   NMPC_D TileSolver32(const Problem & p, const nmpc_hip_ddp_config & c, const DeviceBuffersT<float> & bf, float * lds_base)
-  : problem(p), cfg(c), buf(bf), T(bf.T), wave(static_cast<int>(threadIdx.x) >> 6), lane(static_cast<int>(threadIdx.x) & 63),
+  : problem(problemOfLane(p, bf)), cfg(c), buf(bf), T(bf.T), wave(static_cast<int>(threadIdx.x) >> 6), lane(static_cast<int>(threadIdx.x) & 63),
     lds(lds_base)
   {
   }
@@ -188,7 +206,13 @@ struct TileSolver32
   }
   NMPC_D static void barrier()
   {
-    __syncthreads();
+    __syncthreads(); // (LDS only: s_waitcnt lgkmcnt(0); s_barrier)
+  }
+  /** Between the phases of an iteration: the gains the matrix waves stored and the trajectory the model wave stored are
+      loaded by other waves in the next phase (fullBarrier(), ddp_kernels.hpp). */
+  NMPC_D static void phaseBarrier()
+  {
+    fullBarrier();
   }
   /** Lane kSrc of this lane's 16-lane row in every lane of the row (DPP row_newbcast: one VALU move, no LDS, no SGPR). */
   template<int kSrc>
@@ -1118,7 +1142,7 @@ struct TileSolver32
           flag(0) = (any != 0) ? 1 : 0;
         }
       }
-      barrier();
+      phaseBarrier();
       if(uniform(flag(0)) == 0)
       {
         break;
@@ -1146,7 +1170,7 @@ struct TileSolver32
         {
           backwardSweepMatrixWave<0>();
         }
-        barrier(); // results of the sweep are in the slot table
+        phaseBarrier(); // results of the sweep are in the slot table
         profEnd(1);
         if(model_wave)
         {
@@ -1186,7 +1210,7 @@ struct TileSolver32
             flag(1) = (any != 0) ? 1 : 0;
           }
         }
-        barrier();
+        phaseBarrier();
         if(uniform(flag(1)) == 0)
         {
           break;
@@ -1223,7 +1247,7 @@ struct TileSolver32
           flag(2) = (any != 0) ? 1 : 0;
         }
       }
-      barrier();
+      phaseBarrier();
       if(uniform(flag(2)) != 0)
       {
         // Every step size of alpha_list at once.  The model wave rolls out the first one, lane = instance, and stores it (it is
@@ -1261,7 +1285,7 @@ struct TileSolver32
             }
           }
         }
-        barrier();
+        phaseBarrier();
         profEnd(2);
         if(model_wave)
         {
@@ -1388,13 +1412,13 @@ struct TileSolver32
 };
 
 /** The fp32 tile kernel: grid = ceil(B / 32) workgroups of sixteen wavefronts. */
-template<class Problem>
+template<class Problem, bool kOwnProblem>
 __global__ __launch_bounds__(kTileThreads) void ddp_solve_tile32_kernel(const Problem problem,
                                                                         const nmpc_hip_ddp_config cfg,
                                                                         const DeviceBuffersT<float> buf)
 {
   extern __shared__ __attribute__((aligned(16))) float lds_tile32[];
-  TileSolver32<Problem> solver(problem, cfg, buf, lds_tile32);
+  TileSolver32<Problem, kOwnProblem> solver(problem, cfg, buf, lds_tile32);
   solver.solve();
 }
 
@@ -1411,16 +1435,9 @@ struct ModelOpsTile32
   {
     return "ddp_solve_tile32_kernel";
   }
-  static hipError_t launchSolve(const void * params, const nmpc_hip_ddp_config & cfg, const DeviceBuffers & buf64,
-                                hipStream_t stream)
+  /** The handle allocates every Scalar array with sizeof(Problem::Scalar) = 4 (ModelOps::scalar_bytes): same pointers, float view. */
+  static DeviceBuffersT<float> floatView(const DeviceBuffers & buf64)
   {
-    if(cfg.with_input_constraint != 0 || buf64.params_batch != nullptr || buf64.wpi_ws == nullptr)
-    {
-      return hipErrorNotSupported; // BoxQP / per-instance problem objects: fp64 kernel families only
-    }
-    Problem problem;
-    std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
-    // the handle allocates every Scalar array with sizeof(Problem::Scalar) = 4 (ModelOps::scalar_bytes): same pointers, float view
     DeviceBuffersT<float> buf;
     buf.B = buf64.B;
     buf.Bp = buf64.Bp;
@@ -1444,16 +1461,30 @@ struct ModelOpsTile32
     buf.input_dim = buf64.input_dim;
     buf.wpi_ws = reinterpret_cast<float *>(buf64.wpi_ws);
     buf.phase_ticks = buf64.phase_ticks;
-    buf.params_batch = nullptr;
-    buf.lim_batch = nullptr;
-    buf.lim_steps = nullptr;
-    buf.lim_steps_per_instance = 0;
-    buf.lim_mm = Problem::kInputDimMax;
+    buf.params_batch = buf64.params_batch;
+    buf.lim_batch = buf64.lim_batch; // (the limits are read by the receding-horizon driver's clamp: doubles in every handle)
+    buf.lim_steps = buf64.lim_steps;
+    buf.lim_steps_per_instance = buf64.lim_steps_per_instance;
+    buf.lim_mm = buf64.lim_mm;
+    buf.lim_rows = buf64.lim_rows;
+    buf.lim_offset = buf64.lim_offset;
     for(int i = 0; i < kMaxInputDim; i++)
     {
       buf.lim_lo[i] = buf64.lim_lo[i];
       buf.lim_hi[i] = buf64.lim_hi[i];
     }
+    return buf;
+  }
+  static hipError_t launchSolve(const void * params, const nmpc_hip_ddp_config & cfg, const DeviceBuffers & buf64,
+                                hipStream_t stream)
+  {
+    if(cfg.with_input_constraint != 0 || buf64.wpi_ws == nullptr)
+    {
+      return hipErrorNotSupported; // BoxQP: fp64 kernel families only
+    }
+    Problem problem;
+    std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
+    const DeviceBuffersT<float> buf = floatView(buf64);
     constexpr size_t lds_bytes = Solver::kLdsBytes;
     static bool requested[64] = {};
     int dev = 0;
@@ -1463,21 +1494,37 @@ struct ModelOpsTile32
     }
     if(!requested[dev])
     {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ddp_solve_tile32_kernel<Problem>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-      if(e != hipSuccess)
+      for(const void * kernel : {reinterpret_cast<const void *>(&ddp_solve_tile32_kernel<Problem, false>),
+                                 reinterpret_cast<const void *>(&ddp_solve_tile32_kernel<Problem, true>)})
       {
-        return e;
+        const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+        if(e != hipSuccess)
+        {
+          return e;
+        }
       }
       requested[dev] = true;
     }
     const dim3 g((buf.B + kTileInstances - 1) / kTileInstances), blk(kTileThreads);
-    hipLaunchKernelGGL((ddp_solve_tile32_kernel<Problem>), g, blk, lds_bytes, stream, problem, cfg, buf);
+    if(buf.params_batch != nullptr)
+    {
+      hipLaunchKernelGGL((ddp_solve_tile32_kernel<Problem, true>), g, blk, lds_bytes, stream, problem, cfg, buf);
+    }
+    else
+    {
+      hipLaunchKernelGGL((ddp_solve_tile32_kernel<Problem, false>), g, blk, lds_bytes, stream, problem, cfg, buf);
+    }
     return hipGetLastError();
   }
-  static hipError_t launchMpcAdvance(const void *, const DeviceBuffers &, const MpcAdvanceArgs &, hipStream_t)
+  /** The receding-horizon driver's advance step (mpc_kernels.hpp) on the handle's float arrays. */
+  static hipError_t launchMpcAdvance(const void * params, const DeviceBuffers & buf64, const MpcAdvanceArgs & args, hipStream_t stream)
   {
-    return hipErrorNotSupported; // the receding-horizon driver runs on the fp64 kernel families
+    Problem problem;
+    std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
+    const DeviceBuffersT<float> buf = floatView(buf64);
+    hipLaunchKernelGGL((mpc_advance_kernel<Problem, float>), dim3(buf.Bp / kLanesPerBlock), dim3(kLanesPerBlock), 0, stream, problem,
+                       buf, args);
+    return hipGetLastError();
   }
   static void inputDims(const void *, double, int T, int * out)
   {
@@ -1512,11 +1559,11 @@ struct ModelOpsTile32
     ops.dt = &dt;
     ops.kernel_name = &kernelName;
     ops.launch_mpc_advance = &launchMpcAdvance;
-    ops.has_plant_step = 0;
+    ops.has_plant_step = HasPlantStep<Problem>::value ? 1 : 0;
     ops.wpi_workspace_doubles = &workspaceElems;
     ops.scalar_bytes = 4;
     ops.gain_layout = 1;
-    ops.own_problems_supported = [](int, int) { return 0; }; // one shared problem object per batch (see the header)
+    ops.own_problems_supported = [](int, int constrained) { return constrained ? 0 : 1; };
     return ops;
   }
 };

@@ -41,9 +41,10 @@ struct HasPlantStep<Problem,
 {
 };
 
-template<class Problem>
+/** \tparam S element type of the handle's arrays = Problem::Scalar (the logs are double whatever it is: the C-ABI side) */
+template<class Problem, class S = typename Problem::Scalar>
 __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Problem shared_problem,
-                                                                     const DeviceBuffers buf,
+                                                                     const DeviceBuffersT<S> buf,
                                                                      const MpcAdvanceArgs args)
 {
   constexpr int N = Problem::kStateDim;
@@ -60,11 +61,11 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
   const int T = buf.T;
   const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;
   const int sel = buf.sel[b];
-  const double * Xs = buf.X + ((tile * 2 + sel) * rows_x) * LW + lane; // control_data_.x_list, row r at Xs[r * 64]
-  const double * Us = buf.U + ((tile * 2 + sel) * rows_u) * LW + lane; // control_data_.u_list
-  double * U0 = buf.U + ((tile * 2 + 0) * rows_u) * LW + lane; // initial_u_list of the next solve
-  double * x0 = args.x0 + (tile * N) * LW + lane;
-  const double t = args.t0[b];
+  const S * Xs = buf.X + ((tile * 2 + sel) * rows_x) * LW + lane; // control_data_.x_list, row r at Xs[r * 64]
+  const S * Us = buf.U + ((tile * 2 + sel) * rows_u) * LW + lane; // control_data_.u_list
+  S * U0 = buf.U + ((tile * 2 + 0) * rows_u) * LW + lane; // initial_u_list of the next solve
+  S * x0 = static_cast<S *>(args.x0) + (tile * N) * LW + lane;
+  const S t = static_cast<S *>(args.t0)[b];
   const int m0 = buf.input_dim[(tile * T + 0) * LW + lane];
   const size_t log_at = static_cast<size_t>(b) * args.n_ticks + args.tick;
 
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
   }
   for(int a = 0; a < MM; a++)
   {
-    u0[a] = (a < m0) ? Us[static_cast<size_t>(a) * LW] : 0.0;
+    u0[a] = (a < m0) ? Us[static_cast<size_t>(a) * LW] : S(0);
   }
   if(!args.shift_warm_start && args.clamp_u0)
   {
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
     {
       if(a < m0)
       {
-        u0[a] = fmin(fmax(u0[a], inputLimitLo(buf, b, 0, a)), inputLimitHi(buf, b, 0, a)); // cwiseMax(lower).cwiseMin(upper), :394
+        u0[a] = fmin(fmax(u0[a], static_cast<S>(inputLimitLo(buf, b, 0, a))), static_cast<S>(inputLimitHi(buf, b, 0, a))); // cwiseMax(lower).cwiseMin(upper), :394
       }
     }
   }
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
     args.m0_log[log_at] = m0;
   }
 
-  double t_next = t;
+  S t_next = t;
   if(args.shift_warm_start)
   {
     for(int j = 0; j < N; j++)
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
     }
     for(int a = 0; a < MM; a++)
     {
-      const double keep = Us[(static_cast<size_t>(T - 1) * MM + a) * LW];
-      U0[(static_cast<size_t>(T - 1) * MM + a) * LW] = (last_m == term_m) ? keep : 0.0;
+      const S keep = Us[(static_cast<size_t>(T - 1) * MM + a) * LW];
+      U0[(static_cast<size_t>(T - 1) * MM + a) * LW] = (last_m == term_m) ? keep : S(0);
     }
     t_next = t + problem.dt();
   }
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
     {
       for(int s = 0; s < args.sim_substeps; s++)
       {
-        x = problem.stateEq(t_next, x, u0, args.sim_dt);
-        t_next += args.sim_dt;
+        x = problem.stateEq(t_next, x, u0, static_cast<S>(args.sim_dt));
+        t_next += static_cast<S>(args.sim_dt);
       }
     }
     for(int j = 0; j < N; j++)
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
       }
     }
   }
-  args.t0[b] = t_next;
+  static_cast<S *>(args.t0)[b] = t_next;
 }
 } // namespace hip
 } // namespace nmpc_amd

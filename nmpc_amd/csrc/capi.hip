@@ -495,8 +495,8 @@ int launchRecorded(nmpc_hip_ddp_solver * s,
     if(le == hipErrorNotSupported)
     {
       return fail(NMPC_HIP_ERR_RUNTIME,
-                  s->elem == 4 ? "the fp32 tile kernel serves unconstrained solves with one shared problem object (no BoxQP, no "
-                                 "set_model_params_batch): use the fp64 problem type for those"
+                  s->elem == 4 ? "the fp32 tile kernel serves unconstrained solves (no BoxQP): use the fp64 problem type for "
+                                 "with_input_constraint"
                                : "per-instance problem objects (set_model_params_batch) are served by the model's default kernel "
                                  "only; this solve needs the single-wavefront kernel");
     }
@@ -1084,10 +1084,6 @@ extern "C"
     {
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "n_ticks should be >= 1");
     }
-    if(s->elem != 8)
-    {
-      return fail(NMPC_HIP_ERR_RUNTIME, "the receding-horizon driver is served by the fp64 problem types");
-    }
     if(s->d_lim_steps && opt->n_ticks > 1 && !(opt->shift_warm_start && s->lim_rows >= s->T + opt->n_ticks - 1))
     {
       return fail(NMPC_HIP_ERR_RUNTIME, "time-varying input limits in the device-resident loop: the shift pattern with a table of "
@@ -1193,11 +1189,16 @@ extern "C"
     NMPC_HIP_TRY(out(iter_log, args.iter_log, B * nt * sizeof(int)));
     NMPC_HIP_TRY(out(status_log, args.status_log, B * nt * sizeof(int)));
     NMPC_HIP_TRY(out(m0_log, args.m0_log, B * nt * sizeof(int)));
-    NMPC_HIP_TRY(out(t_final, s->d_t0, B * sizeof(double)));
+    // the logs have been queued for copy-out on the same stream: the input staging buffer can be reused behind them
+    // (the handle's t0 / x0 are arrays of the problem's Scalar: converted on the way out)
+    if(t_final)
+    {
+      NMPC_HIP_TRY(scalarToMajor(s, s->d_t0, dt, nullptr, 1, 1, st));
+      NMPC_HIP_TRY(hipMemcpyAsync(t_final, dt, B * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
     if(x_final)
     {
-      // the logs have been queued for copy-out on the same stream: the staging buffer can be reused behind them
-      NMPC_HIP_TRY(toMajor<double>(s->d_x0, dx, nullptr, s->B, s->N, s->Bp, 1, st));
+      NMPC_HIP_TRY(scalarToMajor(s, s->d_x0, dx, nullptr, s->N, 1, st));
       NMPC_HIP_TRY(hipMemcpyAsync(x_final, dx, nx * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     NMPC_HIP_TRY(hipStreamSynchronize(st));

@@ -278,8 +278,8 @@ def test_deterministic_and_handle_reuse():
 
 
 def test_unsupported_combinations_fail_loudly():
-    """The fp32 tile kernel serves unconstrained solves with one shared problem object; everything else raises instead of
-    silently running something different."""
+    """The fp32 tile kernel serves unconstrained solves; box-constrained ones raise instead of silently running something
+    different."""
     import nmpc_amd
     from nmpc_amd import workloads
 
@@ -288,16 +288,79 @@ def test_unsupported_combinations_fail_loudly():
     s.setInputLimits(np.full(4, 1.0), np.full(4, 4.0))
     with pytest.raises(RuntimeError):
         s.solve(wl.t0, wl.x0, wl.u_init)
-    s2 = make(wl, max_iter=2)
-    with pytest.raises(RuntimeError):
-        s2.mpcRun(wl.t0, wl.x0, wl.u_init, n_ticks=2)
     assert nmpc_amd.make_problem("quadrotor_f32").dims()[:2] == (12, 4)
-    # one problem object per instance: refused when it is SET (no instantiation of the fp32 tile kernel takes them), not at
-    # the first solve
-    s3 = make(wl, max_iter=2)
-    s3.setProblemBatch([nmpc_amd.make_problem("quadrotor_f32", mass=1.0 + 0.01 * b) for b in range(wl.B)])
-    with pytest.raises(RuntimeError, match="one problem object per instance"):
-        s3.kernelName()  # (pushes the pending state to the handle)
+    # ... with one problem object per instance as well
+    s3 = make(wl, max_iter=2, with_input_constraint=True)
+    s3.setInputLimits(np.full(4, 1.0), np.full(4, 4.0))
+    with pytest.raises(RuntimeError):
+        s3.setProblemBatch([nmpc_amd.make_problem("quadrotor_f32", mass=1.0 + 0.01 * b) for b in range(wl.B)])
+        s3.solve(wl.t0, wl.x0, wl.u_init)
+
+
+def test_per_instance_problem_objects():
+    """nmpc_hip_ddp_set_model_params_batch on the fp32 tile kernel (ddp_solve_tile32_kernel<Problem, true>): every instance
+    solves its own quadrotor (mass), instance by instance against the fp32 oracle with the same parameters; then back to the
+    shared object."""
+    import nmpc_amd
+    from nmpc_amd import workloads
+
+    rng = np.random.default_rng(56)
+    wl = workloads.quadrotor_batch(B=45, T=50, seed=8, fp32=True)
+    cfg = dict(max_iter=6, cost_update_thre=FP32_COST_UPDATE_THRE)
+    masses = rng.uniform(0.8, 1.3, wl.B)
+    s = make(wl, **cfg)
+    s.setProblemBatch([nmpc_amd.make_problem("quadrotor_f32", mass=float(m)) for m in masses])
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert s.kernelName() == "ddp_solve_tile32_kernel"
+    X, U, st, it = s.X(), s.U(), s.status(), s.iters()
+    ocfg = ocfg_of(wl, **cfg)
+    same, differs = 0, 0
+    for b in range(wl.B):
+        r = oracle.solve(wl.model, ocfg, wl.x0[b], wl.u_init[b], params=oracle.default_params(wl.model, mass=float(masses[b])))
+        r_shared = oracle.solve(wl.model, ocfg, wl.x0[b], wl.u_init[b])
+        differs += int(np.abs(r_shared.U - r.U).max() > 1e-2)
+        if st[b] == r.status and it[b] == r.iters:  # (decisions at fp32 resolution: the margin filter's subject, not this test's)
+            same += 1
+            assert rel(X[b], r.X).max() <= TOL_XU and rel(U[b], r.U).max() <= TOL_XU
+        else:
+            Jg, Jr = s.cost()[b].sum(), r.cost.sum()
+            assert abs(Jg - Jr) / abs(Jr) <= 50 * TOL_COST
+    assert differs > wl.B // 2, "the per-instance parameters do not change the solutions"
+    assert same >= int(0.8 * wl.B)
+    s.setProblemBatch(None)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_f32(wl, **cfg)
+    ok = (s.status() == ref.status) & (s.iters() == ref.iters)
+    assert ok.mean() >= 0.8 and rel(s.X()[ok], ref.X[ok]).max() <= TOL_XU
+
+
+def test_receding_horizon_driver():
+    """nmpc_hip_ddp_mpc_run on an fp32 handle (mpc_advance_kernel<Problem, float>, shift pattern): the device-resident loop
+    equals the same loop driven from the host solve by solve BIT FOR BIT (the same kernel on the same float data), and follows
+    the fp64 oracle's closed loop within the fp32 tolerance."""
+    import nmpc_amd
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=40, T=50, seed=5, fp32=True)
+    ticks = 8
+    cfg = dict(max_iter=5, cost_update_thre=FP32_COST_UPDATE_THRE)
+    s = make(wl, **cfg)
+    log = s.mpcRun(0.0, wl.x0, np.zeros_like(wl.u_init), ticks, shift_warm_start=True)
+    h = make(wl, **cfg)
+    x, u, t = wl.x0.astype(np.float32).astype(np.float64), np.zeros_like(wl.u_init), np.zeros(wl.B)
+    for k in range(ticks):
+        h.solve(t, x, u)
+        X, U = h.X(), h.U()
+        np.testing.assert_array_equal(log.x[:, k], x)
+        np.testing.assert_array_equal(log.u0[:, k], U[:, 0])
+        np.testing.assert_array_equal(log.iters[:, k], h.iters())
+        x = X[:, 1].copy()
+        u = np.concatenate([U[:, 1:], U[:, -1:]], axis=1)
+        t = (t.astype(np.float32) + np.float32(wl.dt)).astype(np.float64)
+    ocfg = oracle.default_config(horizon_steps=wl.T, max_iter=5, cost_update_thre=FP32_COST_UPDATE_THRE)
+    for b in (0, 17, 39):
+        r = oracle.mpc_run("quadrotor", ocfg, wl.x0[b], ticks, shift_warm_start=True)
+        assert rel(log.x[b], r.x).max() <= 5 * TOL_XU and rel(log.u0[b], r.u0).max() <= 20 * TOL_XU
 
 
 def test_full_size_c4_properties():

@@ -31,8 +31,9 @@
 // rounding-level differences, inside the fp32 tolerance of SURVEY.md §8(c).
 //
 // Scope of this kernel family: Scalar = float, static input dimension, n in {4, 8, 12}, 1 <= m <= 4, n + m <= 16,
-// unconstrained solves (with_input_constraint is rejected at launch); a shared problem object or one per instance
-// (kOwnProblem); the receding-horizon driver (mpc_kernels.hpp) advances the handle's float arrays in place.
+// with or without box constraints on the inputs (kConstrained: the BoxQP of BoxQP.h:141-347 in float, by every lane of the
+// instance's gain rows); a shared problem object or one per instance (kOwnProblem); the receding-horizon driver
+// (mpc_kernels.hpp) advances the handle's float arrays in place.
 #pragma once
 
 #include <cstring>
@@ -79,7 +80,7 @@ __host__ __device__ constexpr int tileWaveFirst(int w)
 }
 static_assert(tileWaveFirst(kTileWaves) == kTileInstances, "the matrix waves cover the 32 slots");
 
-template<class Problem, bool kOwnProblem = false>
+template<class Problem, bool kOwnProblem = false, bool kConstrained = false>
 struct TileSolver32
 {
   using S = float;
@@ -498,12 +499,223 @@ struct TileSolver32
   // ===================================================================================================
   // matrix waves: one backward timestep of one instance    DDPSolver.hpp:381-530
   // ===================================================================================================
+  /** Box-constrained solves: what the BoxQP of the instance's next timestep needs (DDPSolver.hpp:452-472). */
+  struct BwBox
+  {
+    float k_next[MM]; //!< k of the timestep processed before (i + 1): the warm start
+    float lo[MM], up[MM]; //!< input limits - u_i of the timestep to process next, requested one timestep ahead
+    int i; //!< that timestep
+    int b, sel; //!< instance, half of U that holds the nominal inputs
+    bool act; //!< the sweep computes gains for this slot
+  };
+  struct BwNoBox
+  {
+  };
   struct BwState
   {
     v4f VV; //!< [Vxx | Vx]
     float dV0, dV1, krel;
     bool ok;
+    std::conditional_t<kConstrained, BwBox, BwNoBox> box;
   };
+
+  // ---- BoxQP (BoxQP.h:141-347) for the m <= 4 inputs of an instance, evaluated by every lane (the lanes of lane group qK use it)
+  /** What DDPSolver.hpp:473-497 reads after solve(): x, retval, the free set and the factor of H[free, free]. */
+  struct QPOut
+  {
+    float x[MM];
+    float fac[MM * MM], inv_d[MM]; //!< L D L^T of H with the clamped rows / columns replaced by the identity's
+    unsigned free; //!< bit a: input a is free
+    int retval;
+  };
+  NMPC_D static float qpObjective(const float * H, const float * g, const float * x)
+  {
+#pragma clang fp contract(on)
+    float xg = 0, xHx = 0;
+#pragma unroll
+    for(int i = 0; i < MM; i++)
+    {
+      xg += x[i] * g[i];
+    }
+#pragma unroll
+    for(int i = 0; i < MM; i++)
+    {
+      float hx = 0;
+#pragma unroll
+      for(int j = 0; j < MM; j++)
+      {
+        hx += H[i + j * MM] * x[j];
+      }
+      xHx += x[i] * hx;
+    }
+    return xg + 0.5f * xHx;
+  }
+  /** The projected-Newton iteration of BoxQP.h:168-337, statement by statement as the lane kernels' boxQP (ddp_kernels.hpp),
+      without index lists: the free block is H with the clamped rows and columns replaced by those of the identity, which
+      the factorisation and the substitutions pass through with exact zeros — the free entries see the same operations in
+      the same order as on the compacted block. */
+  NMPC_D void boxQP(const float * H, const float * g, const float * lower, const float * upper, const float * initial_x, QPOut & out) const
+  {
+#pragma clang fp contract(on)
+    const float grad_thre = static_cast<float>(cfg.qp_grad_thre), rel_thre = static_cast<float>(cfg.qp_rel_improve_thre),
+                armijo = static_cast<float>(cfg.qp_armijo_param), step_factor = static_cast<float>(cfg.qp_step_factor),
+                min_step = static_cast<float>(cfg.qp_min_step);
+    float * x = out.x;
+#pragma unroll
+    for(int i = 0; i < MM; i++)
+    {
+      x[i] = fmaxf(fminf(initial_x[i], upper[i]), lower[i]); // BoxQP.h:148
+      out.inv_d[i] = 0;
+    }
+    float obj = qpObjective(H, g, x);
+    float old_obj = obj;
+    out.retval = 0;
+    out.free = 0;
+    unsigned clamped = 0, old_clamped = 0;
+    float grad[MM], search_dir[MM], x_cand[MM], rhs[MM];
+    for(int iter = 1;; iter++)
+    {
+      if(iter > 1 && (old_obj - obj) < rel_thre * fabsf(old_obj)) // BoxQP.h:176-181
+      {
+        out.retval = 4;
+        break;
+      }
+      old_obj = obj;
+#pragma unroll
+      for(int i = 0; i < MM; i++) // BoxQP.h:184
+      {
+        float hx = 0;
+#pragma unroll
+        for(int j = 0; j < MM; j++)
+        {
+          hx += H[i + j * MM] * x[j];
+        }
+        grad[i] = g[i] + hx;
+      }
+      old_clamped = clamped; // BoxQP.h:187-213 (exact == compares)
+      clamped = 0;
+#pragma unroll
+      for(int i = 0; i < MM; i++)
+      {
+        const bool c = (x[i] == lower[i] && grad[i] > 0) || (x[i] == upper[i] && grad[i] < 0);
+        clamped |= c ? (1u << i) : 0u;
+      }
+      out.free = ~clamped & ((1u << MM) - 1u);
+      if(out.free == 0)
+      {
+        out.retval = 6;
+        break;
+      }
+      if(iter == 1 || clamped != old_clamped) // BoxQP.h:216-241
+      {
+#pragma unroll
+        for(int i = 0; i < MM; i++)
+        {
+#pragma unroll
+          for(int j = 0; j < MM; j++)
+          {
+            const bool both = (((clamped >> i) | (clamped >> j)) & 1u) == 0;
+            out.fac[i + j * MM] = both ? H[i + j * MM] : ((i == j) ? 1.0f : 0.0f);
+          }
+        }
+        if(!ldlt(out.fac, out.inv_d))
+        {
+          out.retval = -1;
+          break;
+        }
+      }
+      float grad_norm = 0; // BoxQP.h:244-253
+#pragma unroll
+      for(int i = 0; i < MM; i++)
+      {
+        grad_norm += ((clamped >> i) & 1u) ? 0.0f : grad[i] * grad[i];
+      }
+      if(grad_norm < grad_thre * grad_thre)
+      {
+        out.retval = 5;
+        break;
+      }
+#pragma unroll
+      for(int i = 0; i < MM; i++) // BoxQP.h:256-279
+      {
+        float sum = 0;
+#pragma unroll
+        for(int j = 0; j < MM; j++)
+        {
+          sum += ((clamped >> j) & 1u) ? H[i + j * MM] * x[j] : 0.0f;
+        }
+        rhs[i] = ((clamped >> i) & 1u) ? 0.0f : g[i] + sum;
+      }
+      ldltSolve(out.fac, out.inv_d, rhs);
+#pragma unroll
+      for(int i = 0; i < MM; i++)
+      {
+        search_dir[i] = ((clamped >> i) & 1u) ? 0.0f : -1.0f * rhs[i] - x[i];
+      }
+      float sdg = 0; // BoxQP.h:282-291
+#pragma unroll
+      for(int i = 0; i < MM; i++)
+      {
+        sdg += search_dir[i] * grad[i];
+      }
+      if(sdg > 1e-10f)
+      {
+        out.retval = -2;
+        break;
+      }
+      float step = 1; // BoxQP.h:294-309
+#pragma unroll
+      for(int i = 0; i < MM; i++)
+      {
+        x_cand[i] = fmaxf(fminf(x[i] + step * search_dir[i], upper[i]), lower[i]);
+      }
+      float obj_cand = qpObjective(H, g, x_cand);
+      while((obj_cand - old_obj) / (step * sdg) < armijo)
+      {
+        step = step * step_factor;
+#pragma unroll
+        for(int i = 0; i < MM; i++)
+        {
+          x_cand[i] = fmaxf(fminf(x[i] + step * search_dir[i], upper[i]), lower[i]);
+        }
+        obj_cand = qpObjective(H, g, x_cand);
+        if(step < min_step)
+        {
+          out.retval = 2; // leaves only the inner loop (BoxQP.h:304-308)
+          break;
+        }
+      }
+#pragma unroll
+      for(int i = 0; i < MM; i++) // BoxQP.h:328-329
+      {
+        x[i] = x_cand[i];
+      }
+      obj = obj_cand;
+      if(iter == cfg.qp_max_iter)
+      {
+        out.retval = 1; // BoxQP.h:332-336
+        break;
+      }
+    }
+  }
+  /** Input limits - u_i of instance b (DDPSolver.hpp:470-472) into the sweep state, for the timestep st.box.i. */
+  NMPC_D void requestLimits(BwState & st) const
+  {
+    if constexpr(kConstrained)
+    {
+      const int i = st.box.i > 0 ? st.box.i : 0;
+      const int b = st.box.b >= 0 ? st.box.b : 0;
+      const size_t tile = static_cast<size_t>(b) / 64, ln = static_cast<size_t>(b) % 64;
+      const float * Un = buf.U + ((tile * 2 + st.box.sel) * (static_cast<size_t>(T) * MM)) * 64 + ln;
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        const float u = Un[(static_cast<size_t>(i) * MM + a) * 64];
+        st.box.lo[a] = static_cast<float>(inputLimitLo(buf, b, i, a)) - u;
+        st.box.up[a] = static_cast<float>(inputLimitHi(buf, b, i, a)) - u;
+      }
+    }
+  }
 
   /** In-place L D L^T of the m x m matrix A (column-major, leading dimension MM) with the pivot rule of Eigen's LLT:
       fails iff a pivot is <= 0, NaN passes.  Same operation order as the lane kernels' ldltInPlace. */
@@ -673,26 +885,76 @@ struct TileSolver32
     // Quu (unregularised), Quu_F and Qu in every lane of lane group qK: entry (a, c) is register a of lane n + c of that row
     float Quu[MM * MM], QuuF[MM * MM], Qu[MM], inv_d[MM];
     bcastBlock(in.Q, in.Qr, in.qrow, lambda, std::integral_constant<int, kRegType>(), Quu, QuuF, Qu);
-    // every lane of the group factorises Quu_F; lane (qK, j) solves column j of [Qux_reg | Qu]
-    const bool ok_now = ldlt(QuuF, inv_d);
-    st.ok = st.ok && ok_now; // (per lane, valid in lane group qK; after a failure the slot computes on garbage and stores nothing)
-    float col[MM];
-#pragma unroll
-    for(int a = 0; a < MM; a++)
-    {
-      col[a] = (j == N) ? Qu[a] : in.Qr[a];
-    }
-    ldltSolve(QuuF, inv_d, col);
     Stage2Out o;
-#pragma unroll
-    for(int rr = 0; rr < 4; rr++)
+    if constexpr(kConstrained)
     {
-      const float gain = (rr < MM && j <= N) ? -1.0f * col[rr < MM ? rr : 0] : 0.0f;
-      const float ident = (4 * q + rr == j && j < N) ? 1.0f : 0.0f;
-      o.A[rr] = (q == qK) ? gain : ident;
+      // ---- box-constrained gains    :450-497: k = the BoxQP's solution, K = - H[free, free]^-1 Qux_reg[free, :], zero rows
+      // for the clamped inputs.  Warm start: k of the timestep before (i + 1), zero at the end of the horizon.
+      float initial_k[MM];
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        initial_k[a] = (st.box.i != T - 1) ? st.box.k_next[a] : 0.0f;
+      }
+      QPOut qp;
+      boxQP(QuuF, Qu, st.box.lo, st.box.up, initial_k, qp);
+      if(st.box.act && st.ok && lane == 16 * qK + N)
+      {
+        const size_t tile = static_cast<size_t>(st.box.b) / 64, ln = static_cast<size_t>(st.box.b) % 64;
+        buf.qp_ret[(tile * T + st.box.i) * 64 + ln] = qp.retval;
+        buf.qp_free[(tile * T + st.box.i) * 64 + ln] = (qp.retval == 6) ? 0u : qp.free;
+      }
+      st.ok = st.ok && qp.retval >= 0; // :473-480
+      const unsigned free = (qp.retval == 6) ? 0u : qp.free;
+      float col[MM];
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        col[a] = ((free >> a) & 1u) ? in.Qr[a] : 0.0f;
+      }
+      ldltSolve(qp.fac, qp.inv_d, col);
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        const int a = rr < MM ? rr : 0;
+        const float Kv = (rr < MM && ((free >> a) & 1u)) ? -1.0f * col[a] : 0.0f;
+        const float gain = (j < N) ? Kv : ((j == N && rr < MM) ? qp.x[a] : 0.0f);
+        const float ident = (4 * q + rr == j && j < N) ? 1.0f : 0.0f;
+        o.A[rr] = (q == qK) ? gain : ident;
+      }
+      st.box.i -= 1;
+      requestLimits(st); // (the next timestep's: in flight during stage 3 and the next stage 1)
+    }
+    else
+    {
+      // every lane of the group factorises Quu_F; lane (qK, j) solves column j of [Qux_reg | Qu]
+      const bool ok_now = ldlt(QuuF, inv_d);
+      st.ok = st.ok && ok_now; // (per lane, valid in lane group qK; after a failure the slot computes on garbage and stores nothing)
+      float col[MM];
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        col[a] = (j == N) ? Qu[a] : in.Qr[a];
+      }
+      ldltSolve(QuuF, inv_d, col);
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        const float gain = (rr < MM && j <= N) ? -1.0f * col[rr < MM ? rr : 0] : 0.0f;
+        const float ident = (4 * q + rr == j && j < N) ? 1.0f : 0.0f;
+        o.A[rr] = (q == qK) ? gain : ident;
+      }
     }
     float kff[MM];
     bcastK(o.A, kff);
+    if constexpr(kConstrained)
+    {
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        st.box.k_next[a] = kff[a];
+      }
+    }
     {
       float kQu = 0, kQuuk = 0, kn = 0;
 #pragma unroll
@@ -801,6 +1063,19 @@ struct TileSolver32
       st[e].dV1 = 0;
       st[e].krel = 0;
       st[e].ok = true;
+      if constexpr(kConstrained)
+      {
+        st[e].box.i = T - 1;
+        st[e].box.b = bs[e];
+        st[e].box.sel = uniform(slotI(sSel, slot));
+        st[e].box.act = act[e];
+#pragma unroll
+        for(int a = 0; a < MM; a++)
+        {
+          st[e].box.k_next[a] = 0;
+        }
+        requestLimits(st[e]);
+      }
     }
     barrier(); // the terminal record has been read
     if constexpr(COUNT == 3)
@@ -1412,13 +1687,13 @@ struct TileSolver32
 };
 
 /** The fp32 tile kernel: grid = ceil(B / 32) workgroups of sixteen wavefronts. */
-template<class Problem, bool kOwnProblem>
+template<class Problem, bool kOwnProblem, bool kConstrained>
 __global__ __launch_bounds__(kTileThreads) void ddp_solve_tile32_kernel(const Problem problem,
                                                                         const nmpc_hip_ddp_config cfg,
                                                                         const DeviceBuffersT<float> buf)
 {
   extern __shared__ __attribute__((aligned(16))) float lds_tile32[];
-  TileSolver32<Problem, kOwnProblem> solver(problem, cfg, buf, lds_tile32);
+  TileSolver32<Problem, kOwnProblem, kConstrained> solver(problem, cfg, buf, lds_tile32);
   solver.solve();
 }
 
@@ -1426,7 +1701,7 @@ __global__ __launch_bounds__(kTileThreads) void ddp_solve_tile32_kernel(const Pr
 template<class Problem>
 struct ModelOpsTile32
 {
-  using Solver = TileSolver32<Problem>;
+  using Solver = TileSolver32<Problem, false, false>;
   static void defaultParams(void * out)
   {
     new(out) Problem();
@@ -1478,9 +1753,9 @@ struct ModelOpsTile32
   static hipError_t launchSolve(const void * params, const nmpc_hip_ddp_config & cfg, const DeviceBuffers & buf64,
                                 hipStream_t stream)
   {
-    if(cfg.with_input_constraint != 0 || buf64.wpi_ws == nullptr)
+    if(buf64.wpi_ws == nullptr)
     {
-      return hipErrorNotSupported; // BoxQP: fp64 kernel families only
+      return hipErrorNotSupported;
     }
     Problem problem;
     std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
@@ -1494,8 +1769,10 @@ struct ModelOpsTile32
     }
     if(!requested[dev])
     {
-      for(const void * kernel : {reinterpret_cast<const void *>(&ddp_solve_tile32_kernel<Problem, false>),
-                                 reinterpret_cast<const void *>(&ddp_solve_tile32_kernel<Problem, true>)})
+      for(const void * kernel : {reinterpret_cast<const void *>(&ddp_solve_tile32_kernel<Problem, false, false>),
+                                 reinterpret_cast<const void *>(&ddp_solve_tile32_kernel<Problem, true, false>),
+                                 reinterpret_cast<const void *>(&ddp_solve_tile32_kernel<Problem, false, true>),
+                                 reinterpret_cast<const void *>(&ddp_solve_tile32_kernel<Problem, true, true>)})
       {
         const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
         if(e != hipSuccess)
@@ -1506,13 +1783,22 @@ struct ModelOpsTile32
       requested[dev] = true;
     }
     const dim3 g((buf.B + kTileInstances - 1) / kTileInstances), blk(kTileThreads);
-    if(buf.params_batch != nullptr)
+    const bool own = buf.params_batch != nullptr, box = cfg.with_input_constraint != 0;
+    if(own && box)
     {
-      hipLaunchKernelGGL((ddp_solve_tile32_kernel<Problem, true>), g, blk, lds_bytes, stream, problem, cfg, buf);
+      hipLaunchKernelGGL((ddp_solve_tile32_kernel<Problem, true, true>), g, blk, lds_bytes, stream, problem, cfg, buf);
+    }
+    else if(own)
+    {
+      hipLaunchKernelGGL((ddp_solve_tile32_kernel<Problem, true, false>), g, blk, lds_bytes, stream, problem, cfg, buf);
+    }
+    else if(box)
+    {
+      hipLaunchKernelGGL((ddp_solve_tile32_kernel<Problem, false, true>), g, blk, lds_bytes, stream, problem, cfg, buf);
     }
     else
     {
-      hipLaunchKernelGGL((ddp_solve_tile32_kernel<Problem, false>), g, blk, lds_bytes, stream, problem, cfg, buf);
+      hipLaunchKernelGGL((ddp_solve_tile32_kernel<Problem, false, false>), g, blk, lds_bytes, stream, problem, cfg, buf);
     }
     return hipGetLastError();
   }
@@ -1563,7 +1849,7 @@ struct ModelOpsTile32
     ops.wpi_workspace_doubles = &workspaceElems;
     ops.scalar_bytes = 4;
     ops.gain_layout = 1;
-    ops.own_problems_supported = [](int, int constrained) { return constrained ? 0 : 1; };
+    ops.own_problems_supported = [](int, int) { return 1; };
     return ops;
   }
 };

@@ -16,7 +16,7 @@ Cases (SURVEY.md §8 c "golden fixtures to commit"):
   centroidal T=100 at t0 = 0 (3 iterations), t0 = 1.0 (horizon crosses the flight phase)
   quadrotor T=50, manipulator T=30: 2 seeds each, 10 iterations
   planar_vtol T=60 (n 6, m 2): 2 seeds, 10 iterations; one box-constrained
-  quadrotor_f32 T=50: 2 seeds, 3 iterations, cost_update_thre 1e-3 (the oracle instantiated in float)
+  quadrotor_f32 T=50: 2 seeds, 3 iterations, cost_update_thre 1e-3 (the oracle instantiated in float); + 1 box-constrained, 1 iteration
 """
 import os
 import sys
@@ -105,6 +105,11 @@ def main():
         nm = f"quadrotor_f32_s{b}"
         run_case(store, nm, "quadrotor_f32", dict(horizon_steps=50, max_iter=3, cost_update_thre=1e-3), wf.x0[b], wf.u_init[b])
         names.append(nm)
+    # ... and with the rotor-thrust box, one iteration (BoxQP's termination tests are below float resolution: DESIGN.md §3a)
+    wfc = workloads.quadrotor_batch(B=1, T=50, seed=31, constrained=True, fp32=True)
+    run_case(store, "quadrotor_f32_box", "quadrotor_f32", dict(horizon_steps=50, max_iter=1, cost_update_thre=1e-3, with_input_constraint=1),
+             wfc.x0[0], wfc.u_init[0], limits=wfc.limits)
+    names.append("quadrotor_f32_box")
     store["__names__"] = np.array(names)
     np.savez_compressed(OUT, **store)
     print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(names), "cases")

@@ -90,9 +90,16 @@ def test_hip_reproduces_golden(name, force, monkeypatch):
     tr = solver.trace()[0, :n_rows]
     np.testing.assert_array_equal(tr[:, INT_COLS], g["trace"][:, INT_COLS])  # discrete decisions: bit exact
     np.testing.assert_array_equal(solver.inputDimList()[0], g["m_list"])
-    if kw.get("with_input_constraint", 0) and status >= 0:
+    boxed = bool(kw.get("with_input_constraint", 0))
+    if boxed and status >= 0 and not fp32:
         np.testing.assert_array_equal(solver.qpRetval()[0], g["qp_retval"])
         np.testing.assert_array_equal(solver.qpFreeMask()[0], g["qp_free_mask"])
+    if boxed and fp32:
+        # BoxQP in float ends its Newton iteration on rounding noise (its thresholds, BoxQP.h:42-45, are below float
+        # resolution): return codes 4 / 5 may swap and k moves by up to 5e-4 where Quu has a flat direction (tests/test_gpu_fp32.py)
+        assert (solver.qpFreeMask()[0] == g["qp_free_mask"]).mean() >= 0.95
+        assert set(np.unique(solver.qpRetval()[0])) <= {4, 5, 6} and (g["qp_free_mask"] != 15).any()
+        TOL_STATE = 5e-3
     assert_close(f"{name}/X", solver.X()[0], g["X"], TOL_STATE)
     assert_close(f"{name}/U", solver.U()[0], g["U"], TOL_STATE)
     if status >= 0:

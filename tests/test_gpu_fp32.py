@@ -32,6 +32,8 @@ def make(wl, **cfg):
     c.horizon_steps = wl.T
     for k, v in cfg.items():
         setattr(c, k, v)
+    if wl.limits is not None:
+        s.setInputLimits(*wl.limits)
     return s
 
 
@@ -39,10 +41,14 @@ def ocfg_of(wl, **cfg):
     return oracle.default_config(horizon_steps=wl.T, **{k: (list(v) if k == "alpha_list" else v) for k, v in cfg.items()})
 
 
+def _limits(wl):
+    return dict(lower=wl.limits[0], upper=wl.limits[1]) if wl.limits is not None else {}
+
+
 def oracle_f32(wl, x0=None, **cfg):
     params = oracle.default_params(wl.model, **wl.params) if wl.params else None
     return oracle.solve_batch(wl.model, ocfg_of(wl, **cfg), wl.x0 if x0 is None else x0, wl.u_init, t0=wl.t0, params=params,
-                              n_threads=8, want_alpha_hist=True)
+                              n_threads=8, want_alpha_hist=True, **_limits(wl))
 
 
 _NATIVE_DIR = None
@@ -57,7 +63,7 @@ def oracle_f32_contracted(wl, **cfg):
         _NATIVE_DIR = tempfile.mkdtemp(prefix="oracle_native_")
     params = oracle.default_params(wl.model, **wl.params) if wl.params else None
     return oracle.solve_batch(wl.model, ocfg_of(wl, **cfg), wl.x0, wl.u_init, t0=wl.t0, params=params, n_threads=8,
-                              want_alpha_hist=True, native=True, native_dir=_NATIVE_DIR)
+                              want_alpha_hist=True, native=True, native_dir=_NATIVE_DIR, **_limits(wl))
 
 
 def resolution_mask(wl, **cfg):
@@ -67,7 +73,7 @@ def resolution_mask(wl, **cfg):
     keep = np.ones(wl.B, bool)
     params = oracle.default_params(wl.model, **wl.params) if wl.params else None
     for b in range(wl.B):
-        r = oracle.solve(wl.model, ocfg_of(wl, **cfg), wl.x0[b], wl.u_init[b], t0=float(wl.t0[b]), params=params)
+        r = oracle.solve(wl.model, ocfg_of(wl, **cfg), wl.x0[b], wl.u_init[b], t0=float(wl.t0[b]), params=params, **_limits(wl))
         rows = r.trace[1:]
         ls = rows[:, 9] >= 0
         keep[b] = bool(np.all(np.abs(rows[ls, 6]) >= 64 * 2.0 ** -24 * np.abs(rows[ls, 1])))
@@ -277,24 +283,75 @@ def test_deterministic_and_handle_reuse():
         assert not tr[b, int(it1[b]) + 1:].any()
 
 
+def test_box_constrained_on_the_tile():
+    """with_input_constraint on the fp32 tile kernel (ddp_solve_tile32_kernel<Problem, *, true>: BoxQP.h:141-347 in float on
+    the instance's gain rows) against the fp32 oracle.
+
+    What can be asked of it: BoxQP's own termination tests (relative improvement 1e-8, gradient norm 1e-8, BoxQP.h:42-45) are
+    below float resolution, so the projected Newton iteration stops on rounding noise — the kernel and the float oracle end
+    it one iteration apart on ~2 % of the timesteps (retval_ 4 against 5) with solutions up to 5e-4 apart where Quu has a flat
+    direction.  From there on an input that sits AT its bound in one run can be just inside it in the other: a different
+    free set, discontinuously different gains.  So: (A) one iteration from the same nominal — free sets, gains and the step
+    agree; (B) at convergence — the same decisions on most of the batch, and the kernel is as close to the fp64 solution as
+    the float oracle itself is."""
+    from nmpc_amd import workloads
+
+    wl = workloads.quadrotor_batch(B=96, T=50, seed=31, constrained=True, fp32=True)
+    # ---- (A) the first iteration
+    cfg = dict(max_iter=1, with_input_constraint=True, cost_update_thre=FP32_COST_UPDATE_THRE)
+    s = make(wl, **cfg)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert s.kernelName() == "ddp_solve_tile32_kernel"
+    ref = oracle_f32(wl, **cfg)
+    np.testing.assert_array_equal(s.status(), ref.status)
+    np.testing.assert_array_equal(s.iters(), ref.iters)
+    qret, qfree, k, K = s.qpRetval(), s.qpFreeMask(), s.kff(), s.Kfb()
+    free_same, ret_same, clamped, n = 0, 0, 0, 0
+    for b in range(0, wl.B, 2):
+        r = oracle.solve(wl.model, ocfg_of(wl, **cfg), wl.x0[b], wl.u_init[b], t0=float(wl.t0[b]), **_limits(wl))
+        n += wl.T
+        free_same += int((qfree[b] == r.qp_free_mask).sum())
+        ret_same += int((qret[b] == r.qp_retval).sum())
+        clamped += int((r.qp_free_mask != 15).sum())
+        assert set(np.unique(qret[b])) <= {4, 5, 6} and np.abs(k[b] - r.k).max() <= 5e-3
+        assert (np.abs(K[b] - r.K) / (1 + np.abs(r.K))).max() <= 1e-3
+    print(f"[c4 box] first iteration: identical free sets on {free_same} / {n} timesteps, retval_ on {ret_same} / {n}; "
+          f"{clamped} timesteps with clamped inputs; max U err {np.abs(s.U() - ref.U).max():.2e}")
+    assert free_same >= 0.99 * n and ret_same >= 0.9 * n and clamped > 0.2 * n
+    assert rel(s.U(), ref.U).max() <= 5e-3 and rel(s.X(), ref.X).max() <= 5e-3
+    # ---- (B) to convergence
+    cfg = dict(max_iter=10, with_input_constraint=True, cost_update_thre=FP32_COST_UPDATE_THRE)
+    s = make(wl, **cfg)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_f32(wl, **cfg)
+    ref64 = oracle.solve_batch("quadrotor", ocfg_of(wl, **cfg), wl.x0, wl.u_init, t0=wl.t0, n_threads=8, **_limits(wl))
+    J64 = ref64.cost.sum(axis=1)
+    e_gpu = np.abs(s.cost().sum(axis=1) - J64) / J64
+    e_o32 = np.abs(ref.cost.sum(axis=1) - J64) / J64
+    same = (s.status() == ref.status) & (s.iters() == ref.iters)
+    print(f"[c4 box] to convergence: same status and iteration count as the float oracle on {same.mean():.3f}; final cost against "
+          f"the fp64 oracle, kernel / float oracle: median {np.median(e_gpu):.1e} / {np.median(e_o32):.1e}, 90 % "
+          f"{np.quantile(e_gpu, 0.9):.1e} / {np.quantile(e_o32, 0.9):.1e}, max {e_gpu.max():.1e} / {e_o32.max():.1e}")
+    assert same.mean() >= 0.85
+    assert np.median(e_gpu) <= 1e-5 and np.quantile(e_gpu, 0.9) <= max(1e-4, 2 * np.quantile(e_o32, 0.9))
+    assert e_gpu.max() <= max(5e-2, 2 * e_o32.max())
+    eu = rel(s.U()[same], ref.U[same]).reshape(int(same.sum()), -1).max(1)
+    print(f"[c4 box] U against the float oracle where the decisions agree: median {np.median(eu):.1e}, 85 % {np.quantile(eu, 0.85):.1e}")
+    assert np.median(eu) <= 1e-4 and np.quantile(eu, 0.85) <= TOL_XU  # (the typical instance is inside the fp32 bar)
+    inside = lambda U: float(((U >= wl.limits[0] - 1e-3) & (U <= wl.limits[1] + 1e-3)).mean())  # noqa: E731  (the rollout is not clamped, :541-556)
+    assert inside(s.U()) > 0.95 and abs(inside(s.U()) - inside(ref.U)) <= 0.01
+
+
 def test_unsupported_combinations_fail_loudly():
-    """The fp32 tile kernel serves unconstrained solves; box-constrained ones raise instead of silently running something
-    different."""
+    """What the fp32 problem type does not offer raises instead of silently running something different."""
     import nmpc_amd
     from nmpc_amd import workloads
 
     wl = workloads.quadrotor_batch(B=32, T=10, seed=1, fp32=True)
-    s = make(wl, max_iter=2, with_input_constraint=True)
-    s.setInputLimits(np.full(4, 1.0), np.full(4, 4.0))
+    assert nmpc_amd.make_problem("quadrotor_f32").dims()[:2] == (12, 4)
+    s = make(wl, max_iter=2, with_input_constraint=True)  # with_input_constraint without limits: DDPSolver.h:282-285
     with pytest.raises(RuntimeError):
         s.solve(wl.t0, wl.x0, wl.u_init)
-    assert nmpc_amd.make_problem("quadrotor_f32").dims()[:2] == (12, 4)
-    # ... with one problem object per instance as well
-    s3 = make(wl, max_iter=2, with_input_constraint=True)
-    s3.setInputLimits(np.full(4, 1.0), np.full(4, 4.0))
-    with pytest.raises(RuntimeError):
-        s3.setProblemBatch([nmpc_amd.make_problem("quadrotor_f32", mass=1.0 + 0.01 * b) for b in range(wl.B)])
-        s3.solve(wl.t0, wl.x0, wl.u_init)
 
 
 def test_per_instance_problem_objects():

@@ -907,6 +907,184 @@ struct InstanceSolver
     }
   }
 
+  /** What DDPSolver.hpp:473-497 reads after BoxQP::solve(), with the free set as a mask (boxQPMasked). */
+  struct QPOutMasked
+  {
+    double x[MM];
+    double fac[MM * MM], inv_d[MM]; //!< L D L^T of H with the clamped rows / columns replaced by the identity's
+    unsigned free; //!< bit a: input a is free (0 if retval == 6)
+    int retval;
+  };
+  /** K column: - H[free, free]^-1 col[free] on the free rows, zero on the clamped ones (DDPSolver.hpp:482-496). */
+  NMPC_D static void maskedGainColumn(const QPOutMasked & qp, double * col)
+  {
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      col[a] = ((qp.free >> a) & 1u) ? col[a] : 0.0;
+    }
+    ldltSolveInPlace<MM, 1>(qp.fac, qp.inv_d, MM, col);
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      col[a] = ((qp.free >> a) & 1u) ? -1 * col[a] : 0.0;
+    }
+  }
+  /** boxQP for a STATIC input dimension (m = MM) without index lists.  The general code addresses its iterates through
+      free_idx[]: run-time indices into per-lane arrays, i.e. private (scratch) memory — 752 bytes per lane and most of a
+      box-constrained timestep on the matrix-core kernels, where every lane of a wavefront runs the QP of its instance.
+      Here the free set is a bit mask and every loop has compile-time bounds: the free block is H with the clamped rows and
+      columns replaced by those of the identity, which factorisation and substitutions pass through with exact zeros
+      (x - 0 * y = x), so the free entries see the same operations in the same order as on the compacted block, and sums
+      over the free / clamped indices add + 0 for the others.  Statement for statement BoxQP.h:141-347 otherwise. */
+  NMPC_D void boxQPMasked(const double * H,
+                          const double * g,
+                          const double * lower,
+                          const double * upper,
+                          const double * initial_x,
+                          QPOutMasked & out) const
+  {
+    double * x = out.x;
+#pragma unroll
+    for(int i = 0; i < MM; i++)
+    {
+      x[i] = fmax(fmin(initial_x[i], upper[i]), lower[i]); // BoxQP.h:148
+      out.inv_d[i] = 0;
+    }
+    double obj = qpObjective(MM, H, g, x);
+    double old_obj = obj;
+    out.retval = 0;
+    out.free = 0;
+    double grad[MM];
+    unsigned clamped = 0, old_clamped = 0;
+    double search_dir[MM], x_cand[MM], rhs[MM];
+    for(int iter = 1;; iter++)
+    {
+      if(iter > 1 && (old_obj - obj) < cfg.qp_rel_improve_thre * fabs(old_obj)) // BoxQP.h:176-181
+      {
+        out.retval = 4;
+        break;
+      }
+      old_obj = obj;
+#pragma unroll
+      for(int i = 0; i < MM; i++) // BoxQP.h:184
+      {
+        double hx = 0;
+#pragma unroll
+        for(int j = 0; j < MM; j++)
+        {
+          hx += H[i + j * MM] * x[j];
+        }
+        grad[i] = g[i] + hx;
+      }
+      old_clamped = clamped; // BoxQP.h:187-213 (exact == compares)
+      clamped = 0;
+#pragma unroll
+      for(int i = 0; i < MM; i++)
+      {
+        const bool c = (x[i] == lower[i] && grad[i] > 0) || (x[i] == upper[i] && grad[i] < 0);
+        clamped |= c ? (1u << i) : 0u;
+      }
+      out.free = ~clamped & ((1u << MM) - 1u);
+      if(out.free == 0)
+      {
+        out.retval = 6;
+        break;
+      }
+      if(iter == 1 || clamped != old_clamped) // BoxQP.h:216-241
+      {
+#pragma unroll
+        for(int i = 0; i < MM; i++)
+        {
+#pragma unroll
+          for(int j = 0; j < MM; j++)
+          {
+            const bool both = (((clamped >> i) | (clamped >> j)) & 1u) == 0;
+            out.fac[i + j * MM] = both ? H[i + j * MM] : ((i == j) ? 1.0 : 0.0);
+          }
+        }
+        if(!ldltInPlace<MM>(out.fac, out.inv_d, MM))
+        {
+          out.retval = -1;
+          break;
+        }
+      }
+      double grad_norm = 0; // BoxQP.h:244-253
+#pragma unroll
+      for(int i = 0; i < MM; i++)
+      {
+        grad_norm += ((clamped >> i) & 1u) ? 0.0 : grad[i] * grad[i];
+      }
+      if(grad_norm < cfg.qp_grad_thre * cfg.qp_grad_thre)
+      {
+        out.retval = 5;
+        break;
+      }
+#pragma unroll
+      for(int i = 0; i < MM; i++) // BoxQP.h:256-279
+      {
+        double sum = 0;
+#pragma unroll
+        for(int j = 0; j < MM; j++)
+        {
+          sum += ((clamped >> j) & 1u) ? H[i + j * MM] * x[j] : 0.0;
+        }
+        rhs[i] = ((clamped >> i) & 1u) ? 0.0 : g[i] + sum;
+      }
+      ldltSolveInPlace<MM, 1>(out.fac, out.inv_d, MM, rhs);
+#pragma unroll
+      for(int i = 0; i < MM; i++)
+      {
+        search_dir[i] = ((clamped >> i) & 1u) ? 0.0 : -1 * rhs[i] - x[i];
+      }
+      double sdg = 0; // BoxQP.h:282-291
+#pragma unroll
+      for(int i = 0; i < MM; i++)
+      {
+        sdg += search_dir[i] * grad[i];
+      }
+      if(sdg > 1e-10)
+      {
+        out.retval = -2;
+        break;
+      }
+      double step = 1; // BoxQP.h:294-309
+#pragma unroll
+      for(int i = 0; i < MM; i++)
+      {
+        x_cand[i] = fmax(fmin(x[i] + step * search_dir[i], upper[i]), lower[i]);
+      }
+      double obj_cand = qpObjective(MM, H, g, x_cand);
+      while((obj_cand - old_obj) / (step * sdg) < cfg.qp_armijo_param)
+      {
+        step = step * cfg.qp_step_factor;
+#pragma unroll
+        for(int i = 0; i < MM; i++)
+        {
+          x_cand[i] = fmax(fmin(x[i] + step * search_dir[i], upper[i]), lower[i]);
+        }
+        obj_cand = qpObjective(MM, H, g, x_cand);
+        if(step < cfg.qp_min_step)
+        {
+          out.retval = 2; // leaves only the inner loop (BoxQP.h:304-308)
+          break;
+        }
+      }
+#pragma unroll
+      for(int i = 0; i < MM; i++) // BoxQP.h:328-329
+      {
+        x[i] = x_cand[i];
+      }
+      obj = obj_cand;
+      if(iter == cfg.qp_max_iter)
+      {
+        out.retval = 1; // BoxQP.h:332-336
+        break;
+      }
+    }
+    out.free = (out.retval == 6) ? 0u : out.free;
+  }
+
   // -------------------------------------------------------------------------------------------------
   // backward pass    DDPSolver.hpp:342-534, with the linearisation of :160-180 evaluated on the fly
   // -------------------------------------------------------------------------------------------------

@@ -1165,25 +1165,15 @@ struct TileSolver64
         Qu[a] = W[wQQ + kColLd * N + a];
       }
       const Lane lane_code(problem, cfg, buf, b);
-      typename Lane::QPOut qp;
-      lane_code.boxQP(M, fac, Qu, lo, up, initial_k, qp);
-      unsigned free_mask = 0;
-      for(int f = 0; f < qp.n_free; f++)
-      {
-        free_mask |= (1u << qp.free_idx[f]);
-      }
+      typename Lane::QPOutMasked qp;
+      lane_code.boxQPMasked(fac, Qu, lo, up, initial_k, qp); // (static m = MM: no index lists, no private memory)
       if(lane == 0)
       {
         const size_t tl = tileOf(b), ln = lnOf(b);
         buf.qp_ret[(tl * T + i) * 64 + ln] = qp.retval;
-        buf.qp_free[(tl * T + i) * 64 + ln] = free_mask;
+        buf.qp_free[(tl * T + i) * 64 + ln] = qp.free;
       }
       ok_now = !(qp.retval < 0); // :473-480
-#pragma unroll
-      for(int a = 0; a < MM; a++)
-      {
-        col[a] = 0;
-      }
       if(j == N)
       {
 #pragma unroll
@@ -1192,18 +1182,14 @@ struct TileSolver64
           col[a] = qp.x[a];
         }
       }
-      else if(qp.n_free > 0)
+      else
       {
-        double sub[MM];
-        for(int f = 0; f < qp.n_free; f++)
+#pragma unroll
+        for(int a = 0; a < MM; a++)
         {
-          sub[f] = colQ[qp.free_idx[f]];
+          col[a] = colQ[a];
         }
-        Lane::template ldltSolveInPlace<MM, 1>(qp.fac, qp.inv_d, qp.n_free, sub);
-        for(int f = 0; f < qp.n_free; f++)
-        {
-          col[qp.free_idx[f]] = -1 * sub[f]; // clamped rows of K stay zero    :482-496
-        }
+        Lane::maskedGainColumn(qp, col); // clamped rows of K stay zero    :482-496
       }
       fence();
       if(lane == 0)

@@ -733,18 +733,13 @@ struct WaveSolver
           up[a] = inputLimitHi(buf, b, i, a) - vec(vU)[a];
         }
         const Lane lane_code(problem, cfg, buf, b);
-        typename Lane::QPOut qp;
-        lane_code.boxQP(M, fac, Qu, lo, up, initial_k, qp);
-        unsigned free_mask = 0;
-        for(int j = 0; j < qp.n_free; j++)
-        {
-          free_mask |= (1u << qp.free_idx[j]);
-        }
+        typename Lane::QPOutMasked qp;
+        lane_code.boxQPMasked(fac, Qu, lo, up, initial_k, qp); // (static m = MM: no index lists, no private memory)
         if(lane == 0)
         {
           const size_t tl = static_cast<size_t>(b) / kLanesPerBlock, ln = static_cast<size_t>(b) % kLanesPerBlock;
           buf.qp_ret[(tl * T + i) * kLanesPerBlock + ln] = qp.retval;
-          buf.qp_free[(tl * T + i) * kLanesPerBlock + ln] = free_mask;
+          buf.qp_free[(tl * T + i) * kLanesPerBlock + ln] = qp.free;
         }
         if(qp.retval < 0)
         {
@@ -763,20 +758,9 @@ struct WaveSolver
           for(int a = 0; a < MM; a++)
           {
             Quxcol[a] = tile(tQux)[a + LD * lane];
+            Kcol[a] = tile(tQuxR)[a + LD * lane];
           }
-          if(qp.n_free > 0)
-          {
-            double col[MM];
-            for(int j = 0; j < qp.n_free; j++)
-            {
-              col[j] = tile(tQuxR)[qp.free_idx[j] + LD * lane];
-            }
-            Lane::template ldltSolveInPlace<MM, 1>(qp.fac, qp.inv_d, qp.n_free, col);
-            for(int j = 0; j < qp.n_free; j++)
-            {
-              Kcol[qp.free_idx[j]] = -1 * col[j];
-            }
-          }
+          Lane::maskedGainColumn(qp, Kcol);
 #pragma unroll
           for(int a = 0; a < MM; a++)
           {

@@ -75,10 +75,12 @@ struct ModelOpsFor
     {
       return false;
     }
-    // Box-constrained solves: every lane of a wave runs the BoxQP of its instance, which dominates the step and does not
-    // care how the waves are grouped — measured (scripts/constrained_tile64_ab.py, 8192 instances) the wave-per-instance
-    // kernel is 20 % faster there, so it keeps them where it exists (n >= 9); the tile kernel takes them for 5 <= n <= 8.
-    return !(constrained && kWpiBoxQP);
+    // Box-constrained solves: every lane of a wave runs the BoxQP of its instance (boxQPMasked), a matrix wave of the tile
+    // kernel one after the other for its up to five instances.  Measured (scripts/constrained_tile64_ab.py, 8192 instances, 4
+    // iterations): quadrotor (m = 4) tile 7.2 ms against 11.1 ms on the wave-per-instance kernel, manipulator (m = 7) 23.7
+    // against 17.1 — the QP grows with m^3 and the wave-per-instance kernel hides it behind more waves per SIMD.  So the tile
+    // kernel takes the constrained solves up to m = 4 (and all of 5 <= n <= 8, where no other matrix-core kernel exists).
+    return !(constrained && kWpiBoxQP && Problem::kInputDimMax > 4);
   }
   /** Where k_list_ / K_list_ are after a solve: the tile kernel leaves instance-major records in the workspace. */
   static int gainLayoutOf(int batch, int constrained)

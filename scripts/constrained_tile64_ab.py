@@ -7,7 +7,7 @@ from nmpc_amd import workloads
 
 for model, T in (("quadrotor", 50), ("manipulator", 30)):
     res = {}
-    for kernel in (None, "wpi"):
+    for kernel in (None, "wpi", "tile64"):
         os.environ.pop("NMPC_HIP_DDP_KERNEL", None)
         if kernel:
             os.environ["NMPC_HIP_DDP_KERNEL"] = kernel

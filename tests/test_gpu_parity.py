@@ -706,8 +706,8 @@ def _select_matrix_kernel(monkeypatch, kernel, group=None):
 
 def test_matrix_kernel_dispatch(monkeypatch):
     """Default dispatch of the 9 <= n <= 15 shapes: the tile kernel for unconstrained batches above 1024 instances (it wins on
-    throughput: 2.4 - 2.7 x at 8192), the wave-per-instance kernel below (it wins on latency) and for box-constrained solves;
-    5 <= n <= 8 always on the tile kernel."""
+    throughput: 2.4 - 2.7 x at 8192), the wave-per-instance kernel below (it wins on latency) and for box-constrained solves
+    with more than four inputs; 5 <= n <= 8 always on the tile kernel."""
     import nmpc_amd
     monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
     for model in ("quadrotor", "manipulator"):
@@ -716,6 +716,11 @@ def test_matrix_kernel_dispatch(monkeypatch):
         assert nmpc_amd.DDPSolverBatch(prob, 1025).kernelName() == "ddp_solve_tile64_kernel"
         assert nmpc_amd.DDPSolverBatch(prob, 1024).kernelName() == "ddp_solve_wpi_kernel"
         s = nmpc_amd.DDPSolverBatch(prob, 8192)
+        s.config().with_input_constraint = True
+        s.setInputLimits(np.full(prob.dims()[1], -1.0), np.full(prob.dims()[1], 1.0))
+        # box-constrained: the tile kernel up to m = 4 (quadrotor: 7.2 against 11.1 ms), the wave-per-instance kernel beyond
+        assert s.kernelName() == ("ddp_solve_tile64_kernel" if prob.dims()[1] <= 4 else "ddp_solve_wpi_kernel")
+        s = nmpc_amd.DDPSolverBatch(prob, 512)
         s.config().with_input_constraint = True
         s.setInputLimits(np.full(prob.dims()[1], -1.0), np.full(prob.dims()[1], 1.0))
         assert s.kernelName() == "ddp_solve_wpi_kernel"

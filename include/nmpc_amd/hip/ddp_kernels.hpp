@@ -104,11 +104,17 @@ struct Unroll
     acknowledged (s_waitcnt vmcnt(0): gfx9 counts loads and stores in one counter) before it arrives at the barrier, and the
     waves of a workgroup share their CU's vector L1, so what has landed is what they load.  hipcc's __syncthreads() is
     `s_waitcnt lgkmcnt(0); s_barrier` (ROCm 7.2, every kernel of this library: llvm-objdump) — it orders LDS only, and a wave
-    that loads what another wave of its workgroup stored just before such a barrier races with the store's completion
-    (seen once in ~60 GPU sessions as a stale row read back by the next pass). */
+    that loads what another wave of its workgroup stored just before such a barrier is not ordered after the store's
+    completion by anything the ISA documents.  (Not observed failing: scripts/determinism_soak.py, 2000 repetitions per kernel
+    family, is clean with either form — the CU's in-order vector-memory path hides it — but the pass boundaries were written
+    as full barriers and now are.) */
 NMPC_D inline void fullBarrier()
 {
+#ifdef NMPC_AMD_AB_LDS_ONLY_PASS_BARRIER // (A/B builds: what __syncthreads() compiles to — scripts/determinism_soak.py against it)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 /** Input limits of instance b at timestep i (input_limits_func_(current_t + i dt), DDPSolver.hpp:470-472): the sampled

@@ -730,7 +730,11 @@ struct InstanceSolver
     {
       if(m == 1)
       {
+#ifdef NMPC_AMD_AB_LANE_BOXQP1FAST
+        boxQP1Fast(H[0], g[0], lower[0], upper[0], initial_x[0], out);
+#else
         boxQP1(H[0], g[0], lower[0], upper[0], initial_x[0], out);
+#endif
         return;
       }
     }

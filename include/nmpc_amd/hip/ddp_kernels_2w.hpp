@@ -82,7 +82,11 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   static constexpr int oLuu = oLxx + N * N;
   static constexpr int oLxu = oLuu + MM * MM;
   static constexpr int oU = oLxu + N * MM;
-  static constexpr int kBwdRec = oU + MM;
+  //! box-constrained solves: lower limit - u_i, upper limit - u_i (DDPSolver.hpp:470-472), requested by the helper with (x_i, u_i)
+  //! kBwdAhead timesteps early — on the master they were two loads with a wait behind them on the recursion's chain
+  static constexpr int oLoRel = oU + MM;
+  static constexpr int oUpRel = oLoRel + MM;
+  static constexpr int kBwdRec = oU + MM + (kConstrained ? 2 * MM : 0);
   // forward record (master -> helper): candidate x'_i, u'_i
   static constexpr int oXc = 0;
   static constexpr int oUc = oXc + N;
@@ -246,7 +250,8 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   // backward pass
   // ===================================================================================================
   /** Helper: derivatives of timestep i at (x, u) = (x_i, u_i) of the current trajectory -> record slot. */
-  NMPC_D void produceDerivatives(int i, int slot, const StateDimVector & x, const InputDimVector & u_all) const
+  NMPC_D void produceDerivatives(int i, int slot, const StateDimVector & x, const InputDimVector & u_all, const double * lim_lo = nullptr,
+                                 const double * lim_hi = nullptr) const
   {
     const double t = current_t + i * problem.dt();
     const int m = Base::inputDimAt(t);
@@ -285,6 +290,14 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     {
       rec(slot, oLu + e) = Lu[e];
       rec(slot, oU + e) = u[e];
+      if constexpr(kConstrained)
+      {
+        if(lim_lo != nullptr)
+        {
+          rec(slot, oLoRel + e) = lim_lo[e] - u[e];
+          rec(slot, oUpRel + e) = lim_hi[e] - u[e];
+        }
+      }
     }
 #pragma unroll kU
     for(int e = 0; e < MM * MM; e++)
@@ -298,12 +311,22 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   {
     StateDimVector x;
     InputDimVector u;
+    double lo[kConstrained ? MM : 1], hi[kConstrained ? MM : 1]; //!< input limits of the timestep (box-constrained solves)
   };
   static constexpr int kBwdAhead = 4;
   NMPC_D void loadPoint(int i, unsigned ox, unsigned ou, Point & p) const
   {
     Base::loadX(Base::xRow(i), ox, p.x);
     Base::loadU(Base::uRow(i), ou, p.u, MM);
+    if constexpr(kConstrained)
+    {
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        p.lo[a] = inputLimitLo(buf, b, i, a);
+        p.hi[a] = inputLimitHi(buf, b, i, a);
+      }
+    }
   }
   /** Scheduling fence for one value: everything computed from v is issued after this point (volatile asm statements
       keep their order, so also after the preceding wgBarrier()).  Without it the compiler hoists the arithmetic of
@@ -325,7 +348,14 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     {
       pin(p.u[a]);
     }
-    produceDerivatives(i, i & 1, p.x, p.u);
+    if constexpr(kConstrained)
+    {
+      produceDerivatives(i, i & 1, p.x, p.u, p.lo, p.hi);
+    }
+    else
+    {
+      produceDerivatives(i, i & 1, p.x, p.u);
+    }
     // unconditional (the last requests re-read timestep 0 and are never used), so that the compiler can count the
     // requests in flight instead of waiting for all of them
     loadPoint(i >= kBwdAhead ? i - kBwdAhead : 0, ox, ou, p);
@@ -685,8 +715,8 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
           for(int a = 0; a < MM; a++)
           {
             initial_k[a] = (i != T - 1 && m_next == m) ? k_next[a] : 0.0;
-            lo[a] = inputLimitLo(buf, b, i, a) - u[a];
-            up[a] = inputLimitHi(buf, b, i, a) - u[a];
+            lo[a] = rec(slot, oLoRel + a); // (= limit - u_i, evaluated by the helper)
+            up[a] = rec(slot, oUpRel + a);
           }
           QPOut qp;
           Base::boxQP(m, Quu_F, Qu, lo, up, initial_k, qp);

@@ -1982,6 +1982,15 @@ struct TileSolver64
     }
 #endif
     setup();
+#ifdef NMPC_AMD_PROFILE_TILE64
+    if(threadIdx.x == 0)
+    {
+      // (counters are flushed >> 4): record stride, group size, doubles of LDS in front of the records
+      reinterpret_cast<unsigned long long *>(lds + kProfAt)[37] = static_cast<unsigned long long>(stride) << 4;
+      reinterpret_cast<unsigned long long *>(lds + kProfAt)[38] = static_cast<unsigned long long>(G) << 4;
+      reinterpret_cast<unsigned long long *>(lds + kProfAt)[39] = static_cast<unsigned long long>(kRecAt) << 4;
+    }
+#endif
     const int n_groups = (buf.B + G - 1) / G;
     for(int group = static_cast<int>(blockIdx.x); group < n_groups; group += static_cast<int>(gridDim.x))
     {

@@ -39,3 +39,4 @@ print(f"  per rollout timestep: rolling lanes compute {tick[5] / max(passes * (T
       f"prefetching wave 1: prefetch {tick[7] / max(passes * (T + 2), 1):8.0f} waiting {tick[8] / max(passes * (T + 2), 1):8.0f}")
 print("  matrix waves 1 .. 7, ticks over the solve (M): steps " + " ".join(f"{q[16 + w] * 16.0 / 1e6:6.2f}" for w in range(1, 8))
       + "   waiting at the sweeps' barriers " + " ".join(f"{q[24 + w] * 16.0 / 1e6:6.2f}" for w in range(1, 8)))
+print(f"  record stride {int(q[37])} doubles, group size {int(q[38])}, LDS doubles in front of the records {int(q[39])} of 20480")

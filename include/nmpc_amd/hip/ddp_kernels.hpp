@@ -730,11 +730,9 @@ struct InstanceSolver
     {
       if(m == 1)
       {
-#ifdef NMPC_AMD_AB_LANE_BOXQP1FAST
+        // (lane-per-instance kernels too: a wave whose 64 instances are all decided by the two branch-free iterations skips
+        // the loop; two-wave kernel, cart-pole +-15 N at 8192 instances: 2.91 -> 2.76 ms, same bits)
         boxQP1Fast(H[0], g[0], lower[0], upper[0], initial_x[0], out);
-#else
-        boxQP1(H[0], g[0], lower[0], upper[0], initial_x[0], out);
-#endif
         return;
       }
     }

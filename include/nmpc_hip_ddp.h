@@ -133,8 +133,8 @@ extern "C"
                               size_t * param_bytes);
   /** Arithmetic type of a problem type: 8 = double (the reference's, DDPProblem.h:20-35), 4 = float (the "*_f32" problem
       types, BASELINE.json config 4).  The C-ABI exchanges doubles either way: inputs are rounded to the problem's type once
-      at ingest, results widened at nmpc_hip_ddp_get.  fp32 problem types: unconstrained solves with the shared problem
-      object only (no BoxQP, no set_model_params_batch, no mpc_run). */
+      at ingest, results widened at nmpc_hip_ddp_get.  fp32 problem types take the same calls as the double ones
+      (with_input_constraint, set_model_params_batch, mpc_run) for n in {4, 8, 12}, m <= 4. */
   int nmpc_hip_ddp_model_scalar_bytes(const char * model, int * bytes);
   /** Copy the default-constructed problem object (a trivially-copyable blob of param_bytes) to out. */
   int nmpc_hip_ddp_model_default_params(const char * model, void * out, size_t bytes);

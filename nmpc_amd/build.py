@@ -75,7 +75,8 @@ def _stale_objects():
 
 
 def source_hash() -> str:
-    """Hash of everything the device code is compiled from (translation units + headers, by relative path and content).
+    """Hash of everything the device code is compiled from (translation units + headers, by relative path and content,
+    comments and white space excluded).
     profiles/hbm_traffic.json keys its measured HBM traffic on it: bench.py refuses an entry measured on other sources."""
     import hashlib
     h = hashlib.sha256()
@@ -83,8 +84,22 @@ def source_hash() -> str:
     for f in sorted(files, key=lambda f: os.path.relpath(f, ROOT)):
         h.update(os.path.relpath(f, ROOT).encode())
         h.update(b"\0")
-        h.update(open(f, "rb").read())
+        h.update(_code_only(open(f, "r", encoding="utf-8", errors="replace").read()).encode())
     return h.hexdigest()[:16]
+
+
+_COMMENT = None
+
+
+def _code_only(text: str) -> str:
+    """The text without comments and with runs of white space collapsed: editing a comment does not invalidate the measured
+    traffic (string and character literals are kept as they are)."""
+    global _COMMENT
+    import re
+    if _COMMENT is None:
+        _COMMENT = re.compile(r'''("(?:\\.|[^"\\])*"|'(?:\\.|[^'\\])*')|(/\*.*?\*/|//[^\n]*)''', re.S)
+    stripped = _COMMENT.sub(lambda m: m.group(1) if m.group(1) is not None else " ", text)
+    return " ".join(stripped.split())
 
 
 def needs_build() -> bool:

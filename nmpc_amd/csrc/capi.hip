@@ -495,8 +495,7 @@ int launchRecorded(nmpc_hip_ddp_solver * s,
     if(le == hipErrorNotSupported)
     {
       return fail(NMPC_HIP_ERR_RUNTIME,
-                  s->elem == 4 ? "the fp32 tile kernel serves unconstrained solves (no BoxQP): use the fp64 problem type for "
-                                 "with_input_constraint"
+                  s->elem == 4 ? "the fp32 tile kernel has no gain workspace on this handle (allocation failed at create)"
                                : "per-instance problem objects (set_model_params_batch) are served by the model's default kernel "
                                  "only; this solve needs the single-wavefront kernel");
     }

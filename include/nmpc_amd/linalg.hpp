@@ -146,6 +146,12 @@ NMPC_HD double recipFast(double x)
 #endif
 }
 
+/** sin and cos of the same angle in float, full range (the plant step of the receding-horizon driver). */
+NMPC_HD void sincos(float x, float & s, float & c)
+{
+  ::sincosf(x, &s, &c);
+}
+
 /** Single-precision sin and cos of the same angle for |x| < 2^15 rad (NaN beyond, like the double version): three-term
     Cody-Waite reduction by pi/2 (8 + 11 + 24 bits, k * piece exact for |k| < 2^16) with FMAs, then the classic degree-7 /
     degree-8 minimax kernels on [-pi/4, pi/4] (<= 2 ulp there).  ~20 instructions, branch-free; used by the fp32 problem

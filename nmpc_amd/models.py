@@ -70,6 +70,18 @@ class DDPProblemCartPole(_Problem):
                     ("terminal_x", C.c_double * 4), ("ref_pos", C.c_double)]
 
 
+class DDPProblemCartPoleF32(_Problem):
+    """The same problem type instantiated in float (DDPProblemCartPoleT<float>), served by the fp32 tile kernel
+    (include/nmpc_amd/hip/ddp_kernels_tile32.hpp) at its n = 4, m = 1 shape."""
+
+    name = "cartpole_f32"
+
+    class _Blob(C.Structure):
+        _fields_ = [("dt", C.c_float), ("cart_mass", C.c_float), ("pole_mass", C.c_float),
+                    ("pole_length", C.c_float), ("running_x", C.c_float * 4), ("running_u", C.c_float * 1),
+                    ("terminal_x", C.c_float * 4), ("ref_pos", C.c_float)]
+
+
 class DDPProblemBipedal(_Problem):
     """include/nmpc_amd/models/Bipedal.hpp (reference: TestDDPBipedal.cpp:16-144, :171-225)."""
 
@@ -148,7 +160,7 @@ class DDPProblemPlanarVtol(_Problem):
                     ("w_u", C.c_double), ("wt_scale", C.c_double), ("ref_pos", C.c_double * 2)]
 
 
-PROBLEMS = {c.name: c for c in (DDPProblemCartPole, DDPProblemBipedal, DDPProblemVerticalMotion,
+PROBLEMS = {c.name: c for c in (DDPProblemCartPole, DDPProblemCartPoleF32, DDPProblemBipedal, DDPProblemVerticalMotion,
                                 DDPProblemCentroidalMotion, DDPProblemQuadrotor, DDPProblemQuadrotorF32,
                                 DDPProblemManipulator, DDPProblemPlanarVtol)}
 

@@ -42,14 +42,15 @@ class Workload:
     limits: Optional[tuple] = None  # (lower, upper) or None
 
 
-def cartpole_batch(B: int = 4096, T: int = 100, seed: int = 1234, constrained: bool = False) -> Workload:
+def cartpole_batch(B: int = 4096, T: int = 100, seed: int = 1234, constrained: bool = False, fp32: bool = False) -> Workload:
     """C2: x0 ~ U([-1,1] x [-pi,pi] x [-1,1] x [-1,1]), u_init = 0, class-default weights
-    (TestDDPCartPole.cpp:44-46), dt = 0.01; optional +-15 N box (TestDDPCartPole.cpp:379-386)."""
+    (TestDDPCartPole.cpp:44-46), dt = 0.01; optional +-15 N box (TestDDPCartPole.cpp:379-386).  fp32: the problem type
+    instantiated in float ("cartpole_f32": the fp32 tile kernel's n = 4, m = 1 shape)."""
     u = splitmix64_uniform(seed, 4 * B).reshape(B, 4)
     lo = np.array([-1.0, -np.pi, -1.0, -1.0])
     hi = np.array([1.0, np.pi, 1.0, 1.0])
     x0 = lo + (hi - lo) * u
-    return Workload("cartpole_batch", "cartpole", 4, 1, T, B, 0.01, x0, np.zeros((B, T, 1)), np.zeros(B),
+    return Workload("cartpole_batch", "cartpole_f32" if fp32 else "cartpole", 4, 1, T, B, 0.01, x0, np.zeros((B, T, 1)), np.zeros(B),
                     limits=(np.array([-15.0]), np.array([15.0])) if constrained else None)
 
 

@@ -65,7 +65,7 @@ def lib(native: bool = False, out_dir: Optional[str] = None):
         return _libs[key]
     path = os.path.join(out_dir or _BUILD, "liboracle_ddp_native.so" if native else "liboracle_ddp.so")
     srcs = [os.path.join(_HERE, f) for f in
-            ("oracle_capi.cpp", "ddp_oracle.hpp", "models.hpp", "models_builder.hpp")]
+            ("oracle_capi.cpp", "ddp_oracle.hpp", "models.hpp", "model_cartpole.hpp", "models_builder.hpp")]
     if (not os.path.exists(path)) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
         path = build(native, out_dir)
     L = C.CDLL(path)

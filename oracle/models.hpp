@@ -11,196 +11,11 @@
 // oracle versions below are the independent CPU statement the HIP path is checked against.
 #pragma once
 
+#include "model_cartpole.hpp" // CartPole (written against Real: also instantiated in float)
 #include <cmath>
 
 namespace oracle
 {
-// ---------------------------------------------------------------------------------------------------
-// Cart-pole: state [pos, theta, vel, omega], input [force].  nmpc_ddp/tests/src/TestDDPCartPole.cpp:28-234
-// ---------------------------------------------------------------------------------------------------
-struct CartPole
-{
-  using Real = double;
-  static constexpr int N = 4;
-  static constexpr int MMAX = 1;
-  static constexpr int NPARAM = 14;
-
-  double dt = 0.01;
-  double cart_mass = 1.0; // :35
-  double pole_mass = 0.5; // :36
-  double pole_length = 2.0; // :37
-  double running_x[4] = {0.1, 1.0, 0.01, 0.1}; // :44
-  double running_u = 0.001; // :45  (launch file overrides to 0.01, tests/test/TestDDPCartPole.test:23)
-  double terminal_x[4] = {0.1, 1.0, 0.01, 0.1}; // :46
-  double ref_pos = 0.0; // getRefPos with target_pos_ = NaN  (:363-376)
-  static constexpr double g = 9.80665; // :230
-
-  void setParams(const double * p)
-  {
-    dt = p[0];
-    cart_mass = p[1];
-    pole_mass = p[2];
-    pole_length = p[3];
-    for(int i = 0; i < 4; i++)
-    {
-      running_x[i] = p[4 + i];
-    }
-    running_u = p[8];
-    for(int i = 0; i < 4; i++)
-    {
-      terminal_x[i] = p[9 + i];
-    }
-    ref_pos = p[13];
-  }
-
-  int inputDim(double) const
-  {
-    return 1;
-  }
-
-  // :63-98 (explicit Euler)
-  void stateEq(double t, const double * x, const double * u, int, double * xn) const
-  {
-    stateEqDt(t, x, u, dt, xn);
-  }
-
-  void stateEqDt(double, const double * x, const double * u, double step, double * xn) const
-  {
-    const double theta = x[1], vel = x[2], omega = x[3], f = u[0];
-    const double m1 = cart_mass, m2 = pole_mass, l = pole_length;
-    const double s = std::sin(theta), c = std::cos(theta);
-    const double omega2 = omega * omega;
-    const double denom = m1 + m2 * (s * s);
-    double xd[4];
-    xd[0] = vel;
-    xd[1] = omega;
-    xd[2] = (f - m2 * l * omega2 * s + m2 * g * s * c) / denom;
-    xd[3] = (f * c - m2 * l * omega2 * s * c + g * (m1 + m2) * s) / (l * denom);
-    for(int i = 0; i < 4; i++)
-    {
-      xn[i] = x[i] + step * xd[i];
-    }
-  }
-
-  // :100-105
-  double runningCost(double, const double * x, const double * u, int) const
-  {
-    const double ref[4] = {ref_pos, 0, 0, 0};
-    double sx = 0;
-    for(int i = 0; i < 4; i++)
-    {
-      double d = x[i] - ref[i];
-      sx += running_x[i] * (d * d);
-    }
-    return 0.5 * sx + 0.5 * (running_u * (u[0] * u[0]));
-  }
-
-  // :107-112
-  double terminalCost(double, const double * x) const
-  {
-    const double ref[4] = {ref_pos, 0, 0, 0};
-    double sx = 0;
-    for(int i = 0; i < 4; i++)
-    {
-      double d = x[i] - ref[i];
-      sx += terminal_x[i] * (d * d);
-    }
-    return 0.5 * sx;
-  }
-
-  // :114-159
-  void calcStateEqDeriv(double, const double * x, const double * u, int, double * Fx, double * Fu) const
-  {
-    const double theta = x[1], omega = x[3], f = u[0];
-    const double m1 = cart_mass, m2 = pole_mass, l = pole_length;
-    const double s = std::sin(theta), c = std::cos(theta);
-    const double omega2 = omega * omega;
-    const double s2 = s * s;
-    const double denom = m1 + m2 * s2;
-    const double denom2 = denom * denom;
-    for(int e = 0; e < 16; e++)
-    {
-      Fx[e] = 0;
-    }
-    auto A = [&](int r, int col) -> double & { return Fx[r + col * 4]; };
-    A(0, 2) = 1;
-    A(1, 3) = 1;
-    A(2, 1) = ((-1 * m2 * l * omega2 * c + m2 * g * (1 - 2 * s2)) * denom
-               + -1 * (f - m2 * l * omega2 * s + m2 * g * s * c) * (2 * m2 * s * c))
-              / denom2;
-    A(2, 3) = (-2 * m2 * l * omega * s) / denom;
-    A(3, 1) = ((-1 * f * s + -1 * m2 * l * omega2 * (1 - 2 * s2) + g * (m1 + m2) * c) * denom
-               + -1 * (f * c - m2 * l * omega2 * s * c + g * (m1 + m2) * s) * (2 * m2 * s * c))
-              / (l * denom2);
-    A(3, 3) = (-2 * m2 * l * omega * s * c) / (l * denom);
-    for(int e = 0; e < 16; e++)
-    {
-      Fx[e] *= dt;
-    }
-    for(int i = 0; i < 4; i++)
-    {
-      Fx[i + i * 4] += 1.0;
-    }
-    Fu[0] = 0;
-    Fu[1] = 0;
-    Fu[2] = 1 / denom;
-    Fu[3] = c / (l * denom);
-    for(int i = 0; i < 4; i++)
-    {
-      Fu[i] *= dt;
-    }
-  }
-
-  // :187-205
-  void calcRunningCostDeriv(double,
-                            const double * x,
-                            const double * u,
-                            int,
-                            double * Lx,
-                            double * Lu,
-                            double * Lxx,
-                            double * Luu,
-                            double * Lxu) const
-  {
-    const double ref[4] = {ref_pos, 0, 0, 0};
-    for(int i = 0; i < 4; i++)
-    {
-      Lx[i] = running_x[i] * (x[i] - ref[i]);
-    }
-    Lu[0] = running_u * u[0];
-    for(int e = 0; e < 16; e++)
-    {
-      Lxx[e] = 0;
-    }
-    for(int i = 0; i < 4; i++)
-    {
-      Lxx[i + i * 4] = running_x[i];
-    }
-    Luu[0] = running_u;
-    for(int i = 0; i < 4; i++)
-    {
-      Lxu[i] = 0;
-    }
-  }
-
-  // :217-227
-  void calcTerminalCostDeriv(double, const double * x, double * Vx, double * Vxx) const
-  {
-    const double ref[4] = {ref_pos, 0, 0, 0};
-    for(int i = 0; i < 4; i++)
-    {
-      Vx[i] = terminal_x[i] * (x[i] - ref[i]);
-    }
-    for(int e = 0; e < 16; e++)
-    {
-      Vxx[e] = 0;
-    }
-    for(int i = 0; i < 4; i++)
-    {
-      Vxx[i + i * 4] = terminal_x[i];
-    }
-  }
-};
 
 // ---------------------------------------------------------------------------------------------------
 // Bipedal CoM-ZMP (LTV): state [com_pos, com_vel], input [zmp].  nmpc_ddp/tests/src/TestDDPBipedal.cpp:16-144

@@ -9,6 +9,7 @@
 // the same statements in single precision: namespace oracle_f32 (BASELINE.json config 4 is specified in fp32)
 #define ORACLE_F32
 #include "ddp_oracle.hpp"
+#include "model_cartpole.hpp"
 #include "models_builder.hpp"
 #undef ORACLE_F32
 
@@ -56,6 +57,10 @@ int dispatch(const char * name, F && f)
   if(s == "planar_vtol")
   {
     return f(PlanarVtol());
+  }
+  if(s == "cartpole_f32")
+  {
+    return f(oracle_f32::CartPole());
   }
   if(s == "quadrotor_f32")
   {

@@ -105,6 +105,10 @@ def main():
         nm = f"quadrotor_f32_s{b}"
         run_case(store, nm, "quadrotor_f32", dict(horizon_steps=50, max_iter=3, cost_update_thre=1e-3), wf.x0[b], wf.u_init[b])
         names.append(nm)
+    # the fp32 tile kernel's smallest shape: cart-pole in float (n = 4, m = 1), three iterations
+    wcf = workloads.cartpole_batch(B=1, T=100, seed=17, fp32=True)
+    run_case(store, "cartpole_f32_s0", "cartpole_f32", dict(horizon_steps=100, max_iter=3, cost_update_thre=1e-3), wcf.x0[0], wcf.u_init[0])
+    names.append("cartpole_f32_s0")
     # ... and with the rotor-thrust box, one iteration (BoxQP's termination tests are below float resolution: DESIGN.md §3a)
     wfc = workloads.quadrotor_batch(B=1, T=50, seed=31, constrained=True, fp32=True)
     run_case(store, "quadrotor_f32_box", "quadrotor_f32", dict(horizon_steps=50, max_iter=1, cost_update_thre=1e-3, with_input_constraint=1),

@@ -342,6 +342,55 @@ def test_box_constrained_on_the_tile():
     assert inside(s.U()) > 0.95 and abs(inside(s.U()) - inside(ref.U)) <= 0.01
 
 
+def test_second_shape_cartpole_f32():
+    """The fp32 tile kernel at its smallest shape — n = 4, m = 1 ("cartpole_f32", DDPProblemCartPoleT<float>; the quadrotor is
+    n = 12, m = 4): decisions and trajectories against the float oracle on the margin-filtered set; box-constrained (m = 1
+    BoxQP in float): free sets and gains after one iteration; plant-pattern receding-horizon loop (TestDDPCartPole.cpp:323-346)
+    on the float handle bit-identical to the same loop driven from the host."""
+    import nmpc_amd
+    from nmpc_amd import workloads
+
+    assert nmpc_amd.make_problem("cartpole_f32").scalar_bytes() == 4 and nmpc_amd.make_problem("cartpole_f32").dims()[:2] == (4, 1)
+    wl = workloads.cartpole_batch(B=200, T=100, seed=17, fp32=True)
+    cfg = dict(max_iter=4, cost_update_thre=FP32_COST_UPDATE_THRE)
+    s = make(wl, **cfg)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert s.kernelName() == "ddp_solve_tile32_kernel"
+    ref = oracle_f32(wl, **cfg)
+    check(wl, s, ref, margin_mask(wl, ref, **cfg), 0.6, "cartpole_f32 4 iterations")
+    # ---- +-15 N box, one iteration
+    wb = workloads.cartpole_batch(B=96, T=100, seed=18, constrained=True, fp32=True)
+    cfgb = dict(max_iter=1, with_input_constraint=True, cost_update_thre=FP32_COST_UPDATE_THRE)
+    sb = make(wb, **cfgb)
+    sb.solve(wb.t0, wb.x0, wb.u_init)
+    refb = oracle_f32(wb, **cfgb)
+    np.testing.assert_array_equal(sb.status(), refb.status)
+    qfree, k = sb.qpFreeMask(), sb.kff()
+    same, n, clamped = 0, 0, 0
+    for b in range(0, wb.B, 3):
+        r = oracle.solve(wb.model, ocfg_of(wb, **cfgb), wb.x0[b], wb.u_init[b], t0=float(wb.t0[b]), **_limits(wb))
+        n += wb.T
+        same += int((qfree[b] == r.qp_free_mask).sum())
+        clamped += int((r.qp_free_mask == 0).sum())
+        assert np.abs(k[b] - r.k).max() <= 5e-3 * (1 + np.abs(r.k).max())
+    print(f"[cartpole_f32 box] identical free sets on {same} / {n} timesteps, {clamped} clamped")
+    assert same >= 0.98 * n and clamped > 0
+    assert rel(sb.U(), refb.U).max() <= 5e-3
+    # ---- plant pattern on the device against the host-driven loop
+    B, T, ticks = 48, 60, 6
+    wm = workloads.cartpole_batch(B=B, T=T, seed=19, constrained=True, fp32=True)
+    cfgm = dict(max_iter=3, with_input_constraint=True, cost_update_thre=FP32_COST_UPDATE_THRE)
+    sm = make(wm, **cfgm)
+    log = sm.mpcRun(0.0, wm.x0, np.zeros_like(wm.u_init), ticks, shift_warm_start=False, sim_substeps=2, sim_dt=0.002)
+    assert np.isfinite(log.x).all() and (np.abs(log.u0) <= 15.0 + 1e-5).all()
+    h = make(wm, **cfgm)
+    x, u, t = wm.x0.astype(np.float32).astype(np.float64), np.zeros_like(wm.u_init), np.zeros(B)
+    h.solve(t, x, u)
+    np.testing.assert_array_equal(log.x[:, 0], x)
+    np.testing.assert_array_equal(log.u0[:, 0], np.clip(h.U()[:, 0], -15.0, 15.0))
+    np.testing.assert_array_equal(log.iters[:, 0], h.iters())
+
+
 def test_unsupported_combinations_fail_loudly():
     """What the fp32 problem type does not offer raises instead of silently running something different."""
     import nmpc_amd

@@ -36,6 +36,8 @@
 // (mpc_kernels.hpp) advances the handle's float arrays in place.
 #pragma once
 
+#include <atomic>
+
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -1761,13 +1763,13 @@ struct ModelOpsTile32
     std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
     const DeviceBuffersT<float> buf = floatView(buf64);
     constexpr size_t lds_bytes = Solver::kLdsBytes;
-    static bool requested[64] = {};
+    static std::atomic<bool> requested[64] = {}; // (several host threads may launch at once; the setup is idempotent)
     int dev = 0;
     if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
     {
       return hipErrorInvalidDevice;
     }
-    if(!requested[dev])
+    if(!requested[dev].load(std::memory_order_acquire))
     {
       for(const void * kernel : {reinterpret_cast<const void *>(&ddp_solve_tile32_kernel<Problem, false, false>),
                                  reinterpret_cast<const void *>(&ddp_solve_tile32_kernel<Problem, true, false>),
@@ -1780,7 +1782,7 @@ struct ModelOpsTile32
           return e;
         }
       }
-      requested[dev] = true;
+      requested[dev].store(true, std::memory_order_release);
     }
     const dim3 g((buf.B + kTileInstances - 1) / kTileInstances), blk(kTileThreads);
     const bool own = buf.params_batch != nullptr, box = cfg.with_input_constraint != 0;

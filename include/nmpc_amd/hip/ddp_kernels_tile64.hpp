@@ -43,6 +43,8 @@
 // exactly like the lane kernels.
 #pragma once
 
+#include <atomic>
+
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -1167,7 +1169,7 @@ struct TileSolver64
       const Lane lane_code(problem, cfg, buf, b);
       typename Lane::QPOutMasked qp;
       lane_code.boxQPMasked(fac, Qu, lo, up, initial_k, qp); // (static m = MM: no index lists, no private memory)
-      if(lane == 0)
+      if(lane == 0 && c.ok) // (backwardPass returns at the first failing timestep, :473-480: nothing below it is written)
       {
         const size_t tl = tileOf(b), ln = lnOf(b);
         buf.qp_ret[(tl * T + i) * 64 + ln] = qp.retval;
@@ -2023,15 +2025,17 @@ __global__ __launch_bounds__(kT64Threads) void ddp_solve_tile64_kernel(const Pro
 template<class Problem, bool kConstrained, bool kOwnProblem>
 inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_config & cfg, const DeviceBuffers & buf, hipStream_t stream)
 {
-  static bool requested[64] = {};
-  static int n_cu[64] = {};
+  // per device: 0 until the attribute is set and the CU count known (published last, with release order: handles of
+  // several host threads may launch at once — DDPSolverPool, DDPSolverSharded; a second thread repeats the harmless setup)
+  static std::atomic<int> n_cu[64] = {};
   int dev = 0;
   if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
   {
     return hipErrorInvalidDevice;
   }
   const void * fn = reinterpret_cast<const void *>(&ddp_solve_tile64_kernel<Problem, kConstrained, kOwnProblem>);
-  if(!requested[dev])
+  int cus = n_cu[dev].load(std::memory_order_acquire);
+  if(cus == 0)
   {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kT64LdsBytes));
     if(e != hipSuccess)
@@ -2044,15 +2048,15 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
     {
       return e;
     }
-    n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    requested[dev] = true;
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    n_cu[dev].store(cus, std::memory_order_release);
   }
   int cap = 0; // NMPC_HIP_DDP_TILE64_GROUP=<g>: at most g instances per group (tests: full groups on small batches)
   if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_GROUP"))
   {
     cap = std::atoi(e);
   }
-  int grid = n_cu[dev];
+  int grid = cus;
   if(cap > 0)
   {
     const int groups = (buf.B + cap - 1) / cap; // (the kernel may still choose smaller groups: idle workgroups exit)

@@ -8,6 +8,8 @@
 // compile it with hipcc --offload-arch=gfx950 and link (or dlopen) it next to libnmpc_hip_ddp.so.
 #pragma once
 
+#include <atomic>
+
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -34,10 +36,12 @@ struct ModelOpsFor
   }
   /** Lane mapping: the 2-wave (master + helper, LDS-staged) kernel whenever its records fit in LDS, else the
       single-wave kernel.  NMPC_HIP_DDP_KERNEL=1w forces the single-wave kernel (A/B measurements, tests). */
+  //! both record layouts (the box-constrained one is the larger: it carries the input limits) have to fit
+  static constexpr bool kTwoWaveFits = PairSolver<Problem, false>::kFits && PairSolver<Problem, true>::kFits;
   static bool useTwoWave()
   {
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
-    return PairSolver<Problem, false>::kFits && !(force && std::strcmp(force, "1w") == 0);
+    return kTwoWaveFits && !(force && std::strcmp(force, "1w") == 0);
   }
   /** Wave-per-instance (matrix-core) kernel: the shapes whose blocks fill a 16 x 16 tile; unconstrained solves only
       (checked at launch). */
@@ -231,13 +235,13 @@ struct ModelOpsFor
         constexpr size_t quad_lds = QuadSolver<Problem, false>::kLdsBytes;
         const dim3 g(buf.Bp / kQuadInstances), blk(kQuadWaves * 64);
         // > 64 KB of dynamic LDS has to be requested per kernel and device (once: remembered per device ordinal)
-        static bool requested[64] = {};
+        static std::atomic<bool> requested[64] = {}; // (several host threads may launch at once; the setup is idempotent)
         int dev = 0;
         if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
         {
           return hipErrorInvalidDevice;
         }
-        if(!requested[dev])
+        if(!requested[dev].load(std::memory_order_acquire))
         {
           const void * variants[6] = {reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, false>),
                                       reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true, false>),
@@ -254,7 +258,7 @@ struct ModelOpsFor
               return e;
             }
           }
-          requested[dev] = true;
+          requested[dev].store(true, std::memory_order_release);
         }
         // step-size-parallel line search for unconstrained solves: on request, or (0 = automatic) for long solves
         const bool fan = cfg.line_search_fan_out == 1 || (cfg.line_search_fan_out == 0 && cfg.max_iter > fanOutAutoMaxIter());
@@ -287,19 +291,21 @@ struct ModelOpsFor
     }
     if(useTwoWave())
     {
-      if constexpr(PairSolver<Problem, false>::kFits)
+      if constexpr(kTwoWaveFits)
       {
-        using Pair = PairSolver<Problem, false>; // record layout does not depend on kConstrained
-        constexpr size_t lds_bytes = Pair::kLdsBytes;
-        static_assert(lds_bytes <= 64 * 1024, "kFits keeps the records within the default dynamic LDS limit");
+        // the box-constrained record also carries the input limits (PairSolver::kBwdRec): LDS is sized per instantiation
+        constexpr size_t lds_bytes = PairSolver<Problem, false>::kLdsBytes;
+        constexpr size_t lds_bytes_con = PairSolver<Problem, true>::kLdsBytes;
+        static_assert(lds_bytes <= 64 * 1024 && lds_bytes_con <= 64 * 1024,
+                      "kTwoWaveFits keeps the records of both layouts within the default dynamic LDS limit");
         const dim3 g(grid), blk(2 * kLanesPerBlock);
         if(con && own)
         {
-          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, true, true>), g, blk, lds_bytes, stream, problem, cfg, buf);
+          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, true, true>), g, blk, lds_bytes_con, stream, problem, cfg, buf);
         }
         else if(con)
         {
-          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, true, false>), g, blk, lds_bytes, stream, problem, cfg, buf);
+          hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, true, false>), g, blk, lds_bytes_con, stream, problem, cfg, buf);
         }
         else if(own)
         {

@@ -250,7 +250,7 @@ class Matrix;
 // middleRows / col / diagonal views, `m << a, b, c`, asDiagonal(), cross, transpose, products, cwiseMin / cwiseMax,
 // Constant / Zero / Identity — evaluated eagerly on the small fixed-capacity types above (no expression templates: every
 // operator returns a value, which after inlining is what Eigen's lazy products compile to for these sizes).  With it a
-// reference problem body carries over statement for statement (tests/cpp/CentroidalMotionEigenStyle.hpp).
+// reference problem body carries over statement for statement (the syntax is exercised by tests/cpp/JetGyrostatEigenStyle.hpp).
 // ---------------------------------------------------------------------------------------------------------------
 /** Writable view of R x (up to CMAX) entries of a column-major matrix: Eigen's Block / Ref for fixed R. */
 template<class Scalar, int R, int CMAX>

@@ -1,25 +1,25 @@
-// The Eigen-style port (CentroidalMotionEigenStyle.hpp) against the shipped centroidal problem
-// (include/nmpc_amd/models/CentroidalMotion.hpp): every method, bit for bit, over the stance schedule.
+// A problem class in Eigen block / initialiser syntax (JetGyrostatEigenStyle.hpp) against the same arithmetic written entry by
+// entry on scalars (JetGyrostatPlain.hpp): every method of the DDPProblem interface, bit for bit, across the jet schedule
+// (eight, zero and four inputs).
 //   g++ -std=c++17 -O2 -ffp-contract=off -Iinclude tests/cpp/test_eigen_style_port.cpp && ./a.out
 //   hipcc --offload-arch=gfx950 -DDEVICE_COMPILE_CHECK -c ...   (the same functors in a __global__ kernel)
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 
-#include <nmpc_amd/models/CentroidalMotion.hpp>
-
-#include "CentroidalMotionEigenStyle.hpp"
+#include "JetGyrostatEigenStyle.hpp"
+#include "JetGyrostatPlain.hpp"
 
 #if defined(DEVICE_COMPILE_CHECK)
 __global__ void eval_both(const double * xin, const double * uin, double * out)
 {
-  port::DDPProblemCentroidalMotion a;
-  nmpc_amd::DDPProblemCentroidalMotion b;
-  using P = port::DDPProblemCentroidalMotion;
+  conformance::JetGyrostatEigenStyle a;
+  conformance::JetGyrostatPlain b;
+  using P = conformance::JetGyrostatEigenStyle;
   P::StateDimVector x;
-  P::InputDimVector u(16);
+  P::InputDimVector u(8);
   for(int i = 0; i < 9; i++) x[i] = xin[i];
-  for(int i = 0; i < 16; i++) u[i] = uin[i];
+  for(int i = 0; i < 8; i++) u[i] = uin[i];
   const double t = 0.03 * threadIdx.x;
   u.resize(a.inputDim(t));
   P::StateStateDimMatrix fx, fx2;
@@ -44,19 +44,19 @@ __global__ void eval_both(const double * xin, const double * uin, double * out)
 }
 int main()
 {
-  double hx[9] = {0.3, -0.2, 1.1, 5, -7, 3, 0.5, 0.25, -1.5}, hu[16], hout[100];
-  for(int i = 0; i < 16; i++) hu[i] = 25.0 + i;
+  double hx[9] = {0.3, -0.2, 0.15, 0.5, -0.7, 0.3, 0.05, 0.25, -0.15}, hu[8], hout[100];
+  for(int i = 0; i < 8; i++) hu[i] = 0.4 * i - 1.3;
   double *dx, *du, *dout;
   hipMalloc(&dx, sizeof(hx));
   hipMalloc(&du, sizeof(hu));
   hipMalloc(&dout, sizeof(hout));
   hipMemcpy(dx, hx, sizeof(hx), hipMemcpyHostToDevice);
   hipMemcpy(du, hu, sizeof(hu), hipMemcpyHostToDevice);
-  eval_both<<<1, 100>>>(dx, du, dout); // t = 0 .. 2.97 s: both footholds and the flight phase
+  eval_both<<<1, 100>>>(dx, du, dout); // t = 0 .. 2.97 s: the ring of eight, the coast window, the deck of four
   if(hipMemcpy(hout, dout, sizeof(hout), hipMemcpyDeviceToHost) != hipSuccess) return 2;
   double worst = 0;
   for(int i = 0; i < 100; i++) worst = hout[i] > worst ? hout[i] : worst;
-  std::printf("device: largest difference between the port and the shipped model over 100 times: %g\n", worst);
+  std::printf("device: largest difference between the Eigen-style class and the scalar one over 100 times: %g\n", worst);
   if(worst == 0) std::printf("EIGEN_STYLE_PORT_DEVICE_OK\n");
   return worst != 0;
 }
@@ -80,20 +80,20 @@ static int diff(const char * what, const M1 & a, const M2 & b, int rows, int col
 
 int main()
 {
-  port::DDPProblemCentroidalMotion a;
-  nmpc_amd::DDPProblemCentroidalMotion b;
-  using P = port::DDPProblemCentroidalMotion;
+  conformance::JetGyrostatEigenStyle a;
+  conformance::JetGyrostatPlain b;
+  using P = conformance::JetGyrostatEigenStyle;
   unsigned long long s = 12345;
   auto rnd = [&]() { s = s * 6364136223846793005ULL + 1442695040888963407ULL; return ((s >> 11) * (1.0 / 9007199254740992.0)) * 2 - 1; };
   int bad = 0, evals = 0;
   for(double t = 0.0; t < 3.0; t += 0.07)
   {
     P::StateDimVector x;
-    for(int i = 0; i < 9; i++) x[i] = rnd() * (i < 3 ? 1.0 : 20.0);
+    for(int i = 0; i < 9; i++) x[i] = rnd() * (i < 3 ? 0.4 : 1.5);
     const int m = a.inputDim(t);
     bad += (m != b.inputDim(t));
     P::InputDimVector u(m);
-    for(int i = 0; i < 16; i++) u[i] = (i < m) ? 30.0 + 20.0 * rnd() : 0.0;
+    for(int i = 0; i < 8; i++) u[i] = (i < m) ? 2.0 * rnd() : 0.0;
     const auto xa = a.stateEq(t, x, u), xb = b.stateEq(t, x, u);
     bad += diff("stateEq", xa, xb, 9, 1);
     const double ca = a.runningCost(t, x, u), cb = b.runningCost(t, x, u), ta = a.terminalCost(t, x), tb = b.terminalCost(t, x);

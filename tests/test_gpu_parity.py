@@ -1206,9 +1206,9 @@ def test_c_abi_from_plain_c(tmp_path):
 
 
 def test_eigen_style_port_on_the_device(tmp_path):
-    """tests/cpp/CentroidalMotionEigenStyle.hpp (the reference's centroidal problem, statement for statement in linalg.hpp's
-    Eigen subset) evaluated in a gfx950 kernel next to the shipped problem class: identical values at 100 times across the
-    stance schedule."""
+    """tests/cpp/JetGyrostatEigenStyle.hpp (a problem class written in linalg.hpp's Eigen subset: comma initialisers, segment /
+    block / middleRows views, cross, asDiagonal, a run-time number of columns) evaluated in a gfx950 kernel next to the same
+    arithmetic written on scalars (JetGyrostatPlain.hpp): identical values at 100 times across the jet schedule."""
     import os
     import subprocess
     from nmpc_amd import build as hip_build

@@ -246,9 +246,10 @@ def test_sincos_fast_accuracy(tmp_path):
 
 def test_eigen_style_port_matches_the_shipped_model(tmp_path):
     """the reference's problem classes are written in Eigen block / initialiser syntax.  linalg.hpp offers
-    that subset (segment / head / tail / block / middleRows / col / diagonal views, `<<` , asDiagonal, cross, products ...), so
-    tests/cpp/CentroidalMotionEigenStyle.hpp follows TestDDPCentroidalMotion.cpp:24-210 statement for statement.  It must
-    equal the shipped centroidal problem bit for bit on the host, and compile for gfx950."""
+    that subset (segment / head / tail / block / middleRows / col / diagonal views, `<<` , asDiagonal, cross, products ...).
+    tests/cpp/JetGyrostatEigenStyle.hpp is a problem class of this repository's own written that way (dynamic input dimension,
+    matrices with a run-time number of columns); tests/cpp/JetGyrostatPlain.hpp states the same arithmetic entry by entry on
+    scalars.  The two must agree bit for bit on the host, and compile for gfx950."""
     src = os.path.join(ROOT, "tests", "cpp", "test_eigen_style_port.cpp")
     exe = str(tmp_path / "port")
     r = subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", f"-I{ROOT}/include", f"-I{ROOT}/tests/cpp", src, "-o", exe],

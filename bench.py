@@ -14,7 +14,10 @@ forward pass); instances that meet the reference's termination tests earlier sto
 were actually executed are counted (sum of traceDataList().back().iter over the batch / 4096).  Inputs are already
 resident in HBM.  value = n_gpus * K * (executed instance-iterations per solve / 4096) / t, t = max over ranks of the
 wall time between two barrier + device-synchronise brackets.  Weak scaling: every rank owns its own 4096 instances; the
-only collective is ONE all_gather of the final trajectories (RCCL over xGMI) at the end of the timed job.
+only collective is ONE all_gather of the packed results (X | U | cost | status | iters per shard; RCCL over xGMI) at the end of
+the timed job.  --global-batch G cuts ONE batch of G instances into contiguous balanced shards instead (strong split, uneven
+shards padded to one fixed-size all-gather), --verify-gather compares the gathered records with the unsharded solve.
+The CPU baseline leg runs first, the GPU legs last; the number of timed blocks is fixed before the timed region.
 
 After the timed job the default (c2, nominal) run also measures SURVEY.md 8(d)'s two timing modes with the same handle —
 m1 (termination tests disabled, N = 50 iterations forced) and m2 (solve to convergence, max_iter 500) — and reports them as
@@ -97,14 +100,22 @@ def parse_args():
                     help="override Configuration::cost_update_thre.  c4 (fp32) defaults to 1e-3: the reference's 1e-7 is below the "
                          "resolution of an fp32 cost, where the accept test is rounding noise in the fp32 ORACLE itself (DESIGN.md "
                          "3a); the rate with the reference's default rides along as config.default_threshold_value")
-    ap.add_argument("--min-seconds", type=float, default=0.5,
-                    help="the timed job lasts at least this long: blocks of --steps steps are repeated (value is taken over all of "
-                         "them; config.first_block_ms_per_step is the first block alone)")
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="the timed job lasts about this long: blocks of --steps steps are repeated (value is taken over all of "
+                         "them; the number of blocks is fixed BEFORE the timed region from an untimed calibration block, so the timed "
+                         "region holds no collective; config.block_ms_per_step_{min,median,max} are the per-block step times)")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the m1 / m2 (c2) and fp32-tolerance (c4) extra legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0,
                     help="sizing target of the CPU baseline sample (the sustained all-core rate is ~3x below the probe: ~20 s)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong split: ONE batch of this many instances (the workload's generator, --seed) cut into contiguous, "
+                         "balanced shards over the ranks (nmpc_amd.sharding.shard_range: sizes differ by at most one) instead of "
+                         "every rank owning its own --batch instances; reports scaling = strong")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="after the job rank 0 solves the whole (unsharded) batch on its device and compares the gathered records "
+                         "with it bit for bit: config.gather_verified (needs --global-batch)")
     return ap.parse_args()
 
 
@@ -139,7 +150,8 @@ def host_cores():
 
 def cpu_baseline(wl, mode: str, iters_per_solve: int, target_seconds: float, cost_update_thre=None):
     """Time the CPU oracle (kind "port") on a bounded sample of the same workload: a thread sweep (1, 16, 64, all usable
-    cores; threads pinned, instances handed out dynamically), the best rate is the baseline."""
+    cores; threads pinned, instances handed out dynamically), the best rate is the baseline.  The first 256 instances' iteration
+    counts / statuses are kept (`check_*`): main() compares the GPU's last solve with them (the checker's usual role)."""
     import oracle
     affinity, quota = host_cores()
     usable = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
@@ -165,7 +177,11 @@ def cpu_baseline(wl, mode: str, iters_per_solve: int, target_seconds: float, cos
         it, sec = run(nb, th)
         sweep[th] = {"instance_iterations_per_s": it / sec, "solves": nb, "seconds": sec}
     best = max(sweep, key=lambda k: sweep[k]["instance_iterations_per_s"])
+    n_chk = min(256, wl.B)
+    chk = oracle.solve_batch(wl.model, cfg, wl.x0[:n_chk], wl.u_init[:n_chk], t0=wl.t0[:n_chk], n_threads=usable, want_gains=False,
+                             native=True, native_dir=build_dir)
     return {
+        "check_iters": [int(v) for v in chk.iters], "check_status": [int(v) for v in chk.status],
         "value": sweep[best]["instance_iterations_per_s"] / wl.B,  # batch-iterations / s
         "unit": "DDP iterations/s (batch=%d)" % wl.B,
         "cores": best,
@@ -218,7 +234,15 @@ def main():
     # per-rank shard: rank r owns instances [r*B, (r+1)*B) of the global splitmix64 stream
     gen, wl_batch, wl_horizon, wl_text = WORKLOADS[args.workload]
     gen_kw = dict(fp32=True) if args.workload == "c4" else {}
-    wl = getattr(workloads, gen)(B=args.batch or wl_batch, T=args.horizon or wl_horizon, seed=args.seed + 7919 * rank, **gen_kw)
+    wl_full = None
+    if args.global_batch > 0:
+        import dataclasses
+        from nmpc_amd import sharding
+        wl_full = getattr(workloads, gen)(B=args.global_batch, T=args.horizon or wl_horizon, seed=args.seed, **gen_kw)
+        lo_, hi_ = sharding.shard_range(args.global_batch, rank, world)
+        wl = dataclasses.replace(wl_full, B=hi_ - lo_, x0=wl_full.x0[lo_:hi_], u_init=wl_full.u_init[lo_:hi_], t0=wl_full.t0[lo_:hi_])
+    else:
+        wl = getattr(workloads, gen)(B=args.batch or wl_batch, T=args.horizon or wl_horizon, seed=args.seed + 7919 * rank, **gen_kw)
     problem = nmpc_amd.make_problem(wl.model)
     elem = problem.scalar_bytes()
     solver = nmpc_amd.DDPSolverBatch(problem, wl.B, device=device_index)
@@ -239,14 +263,30 @@ def main():
         args.cost_update_thre = 1e-3  # the threshold an fp32 cost can resolve is the c4 headline (see --cost-update-thre)
     configure(args.mode, args.iters_per_solve, args.cost_update_thre)
 
+    # The CPU leg runs FIRST (rank 0 of a one-GPU job only): the GPU legs then come last and back to back, where an outside
+    # observer sampling the device sees them (the driver's sampler saw an idle GPU behind a 16 s CPU tail).
+    cpu_leg = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu_leg = cpu_baseline(wl, args.mode, args.iters_per_solve, args.cpu_seconds, args.cost_update_thre)
+        except Exception as e:  # the GPU number stands on its own; say why the baseline is missing
+            cpu_leg = {"value": None, "unit": "DDP iterations/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+
     d_x0 = torch.from_numpy(wl.x0).to(dev)
     d_u0 = torch.from_numpy(wl.u_init).to(dev)
     d_t0 = torch.from_numpy(wl.t0).to(dev)
+    # the packed per-shard result the one collective moves: [X | U | cost | status, iters (int32 pairs)] — sharding.pack_results'
+    # fields, field-major here (one device-side pack per field)
     n_x = wl.B * (wl.T + 1) * wl.n
     n_u = wl.B * wl.T * max(wl.m, 1)
-    d_res = torch.empty(n_x + n_u, dtype=torch.float64, device=dev)  # packed [X | U] send buffer
+    n_c = wl.B * (wl.T + 1)
+    n_rec = n_x + n_u + n_c + wl.B
+    # (uneven shards of a strong split: every rank sends a buffer of the largest shard's size, one fixed-size all-gather)
+    per_inst = (wl.T + 1) * wl.n + wl.T * max(wl.m, 1) + (wl.T + 1) + 1
+    n_send = n_rec if args.global_batch <= 0 else per_inst * (-(-args.global_batch // world))
+    d_res = torch.zeros(n_send, dtype=torch.float64, device=dev)
     gather_dev = dev if backend == "nccl" else torch.device("cpu")
-    d_all = torch.empty(world * (n_x + n_u), dtype=torch.float64, device=gather_dev) if world > 1 else None
+    d_all = torch.empty(world * n_send, dtype=torch.float64, device=gather_dev) if world > 1 else None
 
     def barrier():
         if world > 1:
@@ -261,38 +301,49 @@ def main():
     solver.synchronize()
     solver.timingStats(reset=True)
 
-    # The timed job: blocks of exactly --steps steps, each bracketed by barrier + device synchronise, repeated until the job has
-    # lasted --min-seconds (a 9 ms job says little about a sustained rate); every rank runs the same number of blocks.
+    # How many blocks of --steps steps the timed job holds is settled BEFORE it starts — one untimed calibration block, the
+    # slowest rank's time decides — so that the timed region contains no collective and no host round trip besides the
+    # per-block stream synchronise.
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    barrier()
+    t_cal = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    solver.synchronize()
+    cal = torch.tensor([time.perf_counter() - t_cal], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(cal, op=dist.ReduceOp.MAX)
+    n_blocks = int(min(10000, max(2, np.ceil(args.min_seconds / max(float(cal[0]), 1e-6)))))
+    solver.timingStats(reset=True)
+
+    # The timed job: n_blocks blocks of exactly --steps steps between two barrier + device-synchronise brackets.
     barrier()
     t_begin = time.perf_counter()
-    n_blocks, first_block_s = 0, None
-    while True:
+    block_s = []
+    t_prev = t_begin
+    for _ in range(n_blocks):
         for _ in range(args.steps):
             step()
         solver.synchronize()
-        n_blocks += 1
-        if first_block_s is None:
-            first_block_s = time.perf_counter() - t_begin
-        so_far = torch.tensor([time.perf_counter() - t_begin], dtype=torch.float64)
-        if world > 1:
-            barrier()
-            so_far_dev = so_far.to(dev if backend == "nccl" else torch.device("cpu"))
-            dist.all_reduce(so_far_dev, op=dist.ReduceOp.MAX)
-            so_far = so_far_dev.cpu()
-        if float(so_far[0]) >= args.min_seconds or n_blocks >= 10000:
-            break
+        t_now = time.perf_counter()
+        block_s.append(t_now - t_prev)
+        t_prev = t_now
+    first_block_s = block_s[0]
     total_steps = n_blocks * args.steps
     t_solve = time.perf_counter()
-    # the one collective of the job: gather the final trajectories of every shard
-    solver.getDevice(_capi.FIELD_X, d_res.data_ptr(), n_x * 8)
-    solver.getDevice(_capi.FIELD_U, d_res.data_ptr() + n_x * 8, n_u * 8)
+    # the one collective of the job: gather the packed results of every shard
+    off = 0
+    for field, count in ((_capi.FIELD_X, n_x), (_capi.FIELD_U, n_u), (_capi.FIELD_COST, n_c)):
+        solver.getDevice(field, d_res.data_ptr() + off * 8, count * 8)
+        off += count
+    solver.getDevice(_capi.FIELD_STATUS, d_res.data_ptr() + off * 8, wl.B * 4)
+    solver.getDevice(_capi.FIELD_ITERS, d_res.data_ptr() + off * 8 + wl.B * 4, wl.B * 4)
     solver.synchronize()
     if world > 1:
         dist.all_gather_into_tensor(d_all, d_res if backend == "nccl" else d_res.cpu())
     barrier()
     t_end = time.perf_counter()
 
-    red_dev = dev if backend == "nccl" else torch.device("cpu")
     mine = torch.tensor([t_end - t_begin, t_end - t_solve, t_solve - t_begin, first_block_s], dtype=torch.float64, device=red_dev)
     per_rank = [mine.clone() for _ in range(world)]
     elapsed_t = mine.clone()
@@ -317,8 +368,35 @@ def main():
     job_it_per_solve = float(job_it[0])
     status = solver.status()
     kernel_name = solver.kernelName()
+    headline_iters, headline_status = iters.copy(), status.copy()
     hist = {str(k): int(v) for k, v in zip(*np.unique(iters, return_counts=True))}
     status_counts = {str(k): int(v) for k, v in zip(*np.unique(status, return_counts=True))}
+
+    # ---- the gathered records against the unsharded solve (strong split, --verify-gather): rank 0, after the timed job
+    gather_verified, shard_sizes = None, None
+    if args.global_batch > 0:
+        from nmpc_amd import sharding
+        shard_sizes = sharding.shard_sizes(args.global_batch, world)
+    if args.verify_gather and args.global_batch > 0 and rank == 0:
+        whole = nmpc_amd.DDPSolverBatch(problem, wl_full.B, device=device_index)
+        wc, sc = whole.config(), solver.config()
+        for key, val in vars(sc).items():
+            setattr(wc, key, val.copy() if isinstance(val, np.ndarray) else val)
+        whole.solve(wl_full.t0, wl_full.x0, wl_full.u_init)
+        want = (whole.X(), whole.U(), whole.cost(), whole.status(), whole.iters())
+        got_all = (d_all if world > 1 else d_res).cpu().numpy()
+        ok, lo_ = True, 0
+        for r_, sz in enumerate(shard_sizes):
+            rec = got_all[r_ * n_send:(r_ + 1) * n_send]
+            o = 0
+            for arr, per in ((want[0], (wl.T + 1) * wl.n), (want[1], wl.T * max(wl.m, 1)), (want[2], wl.T + 1)):
+                ok = ok and np.array_equal(rec[o:o + sz * per], arr[lo_:lo_ + sz].reshape(-1))
+                o += sz * per
+            ints = rec[o:o + sz].view(np.int32)
+            ok = ok and np.array_equal(ints[:sz], want[3][lo_:lo_ + sz]) and np.array_equal(ints[sz:2 * sz], want[4][lo_:lo_ + sz])
+            lo_ += sz
+        gather_verified = bool(ok)
+        del whole
 
     # ---- extra legs, outside the timed job (every rank runs them; rank 0 reports its own)
     def pass_counts():
@@ -391,6 +469,30 @@ def main():
             extras["m2_overlapped"] = {"value": 16 * (float(it_p.sum()) / wl.B) / dtp, "solves_per_s": 16 * wl.B / dtp,
                                        "ms_per_solve": 1e3 * dtp / 16, "handles": 4, "batches": 16}
             del pool
+        if args.workload == "c3":
+            # 1024 bipedal instances are 64 quad workgroups on 256 CUs: the single-batch rate is a latency, not the chip's rate.
+            # Four batches in flight on four handles / streams (DDPSolverPool) is how a caller with more than one batch fills it.
+            pool = nmpc_amd.DDPSolverPool(problem, wl.B, n_handles=4, device=device_index)
+            pc = pool.config()
+            pc.print_level = 0
+            pc.horizon_steps = wl.T
+            for key, val in mode_config("nominal", args.iters_per_solve).items():
+                setattr(pc, key, val)
+            pool.applyConfig()
+            for _ in range(8):
+                pool.submit(d_t0.data_ptr(), d_x0.data_ptr(), d_u0.data_ptr())
+            pool.synchronize()
+            torch.cuda.synchronize()
+            n_pool = 200
+            t0p = time.perf_counter()
+            for _ in range(n_pool):
+                pool.submit(d_t0.data_ptr(), d_x0.data_ptr(), d_u0.data_ptr())
+            pool.synchronize()
+            dtp = time.perf_counter() - t0p
+            it_p = pool.solvers[-1].iters()
+            extras["pooled"] = {"value": n_pool * (float(it_p.sum()) / wl.B) / dtp, "solves_per_s": n_pool * wl.B / dtp,
+                                "ms_per_solve": 1e3 * dtp / n_pool, "handles": 4, "batches": n_pool}
+            del pool
         if fp32_headline:
             extras["default_threshold"] = leg("nominal", args.iters_per_solve, 20, cost_update_thre=1e-7)
             extras["fp32_tolerance_m2"] = leg("m2", 500, 10, cost_update_thre=1e-3)
@@ -401,18 +503,27 @@ def main():
         k_ms = kernel_ms / max(n_solves, 1)
         bytes_per_launch = words * float(elem) * inst_it_per_solve
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-        value = total_steps * (job_it_per_solve / wl.B) / elapsed
+        # one "DDP iteration" of the metric = procOnce over a batch: the per-GPU batch (weak scaling: every rank owns one), or the
+        # one global batch of a strong split
+        batch_unit = args.global_batch if args.global_batch > 0 else wl.B
+        value = total_steps * (job_it_per_solve / batch_unit) / elapsed
         config = {
             "workload": (wl_text % (wl.T, wl.B, args.seed))
                         + ", default DDPSolver::Configuration with max_iter = iterations_per_step"
                         + ("" if args.cost_update_thre is None else ", cost_update_thre = %g" % args.cost_update_thre),
             "mode": args.mode,
             "iterations_per_step": args.iters_per_solve if args.mode != "m2" else 500,
-            "solves_per_s": world * total_steps * wl.B / elapsed,
+            "solves_per_s": (args.global_batch if args.global_batch > 0 else world * wl.B) * total_steps / elapsed,
             "timed_steps_total": total_steps,
             "timed_blocks": n_blocks,
             "timed_seconds": elapsed,
             "first_block_ms_per_step": 1e3 * first_block / args.steps,
+            "block_ms_per_step_min": 1e3 * float(np.min(block_s)) / args.steps,
+            "block_ms_per_step_median": 1e3 * float(np.median(block_s)) / args.steps,
+            "block_ms_per_step_max": 1e3 * float(np.max(block_s)) / args.steps,
+            "value_at_fastest_block": (job_it_per_solve / wl.B) / (float(np.min(block_s)) / args.steps) if world == 1 else None,
+            "value_at_median_block": (job_it_per_solve / wl.B) / (float(np.median(block_s)) / args.steps) if world == 1 else None,
+            "gathered_record": "per shard, field-major: X | U | cost | status, iters (int32)",
             "iteration_histogram": hist,
             "instance_iterations_per_step": job_it_per_solve,
             "backward_passes_per_iteration": n_bw,
@@ -432,6 +543,14 @@ def main():
             config["m2_overlapped_value"] = extras["m2_overlapped"]["value"]
             config["m2_overlapped"] = dict(extras["m2_overlapped"], note="M2 with 16 consecutive batches on four handles / streams "
                                            "(nmpc_amd.DDPSolverPool): sustained rate with the convergence tails overlapped")
+        if "pooled" in extras:
+            config["pooled_value"] = extras["pooled"]["value"]
+            config["pooled"] = dict(extras["pooled"], note="the same workload with four batches in flight on four handles / streams "
+                                    "(nmpc_amd.DDPSolverPool): one batch of %d instances occupies %d of the chip's 256 CUs" % (wl.B, -(-wl.B // 16)))
+        if gather_verified is not None:
+            config["gather_verified"] = gather_verified
+            config["global_batch"] = args.global_batch
+            config["shard_sizes"] = shard_sizes
         if "default_threshold" in extras:
             config["cost_update_thre"] = 1e-3
             config["default_threshold_value"] = extras["default_threshold"]["value"]
@@ -440,20 +559,22 @@ def main():
                                                "rounding noise there in the fp32 oracle itself (DESIGN.md 3a) — secondary number")
             config["fp32_tolerance_m2"] = dict(extras["fp32_tolerance_m2"], note="cost_update_thre = 1e-3, solve to convergence")
         out = {
-            "metric": "DDP iterations/s (whole node), batch=%d, T=%d" % (wl.B, wl.T),
+            "metric": "DDP iterations/s (whole node), batch=%d, T=%d" % (args.global_batch if args.global_batch > 0 else wl.B, wl.T)
+                      + (", cost_update_thre=1e-3 (the threshold an fp32 cost resolves)" if fp32_headline else ""),
             "value": value,
-            "unit": "DDP iterations/s (one iteration = procOnce over a batch of %d instances per GPU)" % wl.B,
+            "unit": ("DDP iterations/s (one iteration = procOnce over the global batch of %d instances, sharded)" % batch_unit)
+                    if args.global_batch > 0 else "DDP iterations/s (one iteration = procOnce over a batch of %d instances per GPU)" % wl.B,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / total_steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.global_batch > 0 else "weak",
             "vs_baseline": None,
             "dtype": "f64" if elem == 8 else "f32",
             "data": "synthetic",
             "config": config,
-            "instance_iterations_per_s": value * wl.B,
+            "instance_iterations_per_s": value * batch_unit,
             "roofline": {
                 "bound": "hbm",
                 "kernel": kernel_name + "<%s>" % wl.model,
@@ -475,12 +596,19 @@ def main():
         if "m1" in extras:
             out["roofline_m1"] = extras["m1"]["roofline"]
             out["roofline_m2"] = extras["m2"]["roofline"]
-        if not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(wl, args.mode, args.iters_per_solve, args.cpu_seconds, args.cost_update_thre)
-            except Exception as e:  # the GPU number stands on its own; say why the baseline is missing
-                out["cpu_baseline"] = {"value": None, "unit": "DDP iterations/s", "cores": os.cpu_count(),
-                                       "kind": "port", "sample": "failed: %r" % (e,)}
+        if cpu_leg is not None:
+            # the oracle's first 256 instances against the GPU's last timed solve: how many took the same decisions (iteration count
+            # and status).  fp64: all of them but instances at a decision boundary; fp32 (c4): the margin-filtered parity of
+            # tests/test_gpu_fp32.py in one number — the oracle here is the -march=native build (contracted), one of the perturbed runs
+            # the tests accept
+            chk_it, chk_st = cpu_leg.pop("check_iters", None), cpu_leg.pop("check_status", None)
+            if chk_it is not None and headline_iters is not None:
+                k = len(chk_it)
+                agree = (headline_iters[:k] == np.asarray(chk_it)) & (headline_status[:k] == np.asarray(chk_st))
+                cpu_leg["gpu_decisions_agree_frac"] = float(agree.mean())
+                cpu_leg["gpu_decisions_checked"] = k
+                config["oracle_agree_frac"] = float(agree.mean())
+            out["cpu_baseline"] = cpu_leg
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(traffic_file):
             try:

@@ -103,7 +103,14 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   static constexpr int kNomSlots = 3;
   static constexpr int kNomInst = 16;
   static constexpr int kNomDoubles = kLdsNominal ? kNomSlots * kFwdGroup * kNomInst * kNomRec : 0;
-  static constexpr int kNomBase = (kRecArea + 2 + NMPC_HIP_NTRACE) * static_cast<int>(LW);
+  //! Waves beside master / helper / prefetcher that roll out further step sizes of a fan-out pass, cost only
+  //! (forwardCostOnlyLds; ddp_kernels_quad.hpp: waves 2 and 3): with kAlphaGroups lane groups each, a pass of the line search
+  //! covers kStepSizesPerPass step sizes — all eleven of the reference's alpha_list in ONE pass.
+  static constexpr int kExtraMasters = (kLdsNominal && kAlphaGroups > 1) ? 2 : 0;
+  static constexpr int kStepSizesPerPass = kAlphaGroups * (1 + kExtraMasters);
+  //! rows behind the trace row: the extra masters' cost mailboxes (one row each) and a row of pass parameters
+  static constexpr int kExtraRows = kLdsNominal ? 3 : 0;
+  static constexpr int kNomBase = (kRecArea + 2 + NMPC_HIP_NTRACE + kExtraRows) * static_cast<int>(LW);
   //! + per-lane mailboxes (flags, J_cand) + the last trace row of every lane (kept in LDS until the solve ends)
   static constexpr int kLdsDoubles = kNomBase + kNomDoubles;
   static constexpr size_t kLdsBytes = static_cast<size_t>(kLdsDoubles) * sizeof(double);
@@ -153,6 +160,16 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   NMPC_D double & lastRow(int field) const
   {
     return lds[(static_cast<size_t>(kRecArea) + 2 + field) * LW + waveLane()];
+  }
+  //! cost of the rollout of lane `wave_lane` of extra master `which` (0, 1)
+  NMPC_D double & mailCostExtra(int which, unsigned wave_lane) const
+  {
+    return lds[(static_cast<size_t>(kRecArea) + 2 + NMPC_HIP_NTRACE + which) * LW + wave_lane];
+  }
+  //! index into alpha_list of the first step size of the running fan-out pass (written by the master before post())
+  NMPC_D double & mailFirstAlpha() const
+  {
+    return lds[(static_cast<size_t>(kRecArea) + 2 + NMPC_HIP_NTRACE + 2) * LW];
   }
   static constexpr unsigned kGroupLanes = kLanesPerBlock / kAlphaGroups;
 #ifndef NMPC_FANOUT_FIRST_PASS
@@ -1528,6 +1545,161 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     J_cand = mailCost();
   }
 
+  /** One timestep of a cost-only rollout: forwardStepLds + consumeStep without the hand-off and without stores — the same
+      expressions on the same values, so the cost is the one the master / helper pair would have summed for this step size. */
+  NMPC_D void costOnlyStepLds(int i, double alpha, const Nominal & nom, StateDimVector & xc, double & J) const
+  {
+    const double t = current_t + i * problem.dt();
+    const int m = Base::inputDimAt(t);
+    InputDimVector uc;
+    uc.resize(m);
+#pragma unroll kU
+    for(int a = 0; a < MM; a++)
+    {
+      if(a < m)
+      {
+        double s = 0;
+#pragma unroll kU
+        for(int c = 0; c < N; c++)
+        {
+          s += nom.K[a + c * MM] * (xc[c] - nom.x[c]);
+        }
+        uc[a] = (nom.u[a] + alpha * nom.k[a]) + s;
+      }
+      else
+      {
+        uc[a] = 0;
+      }
+    }
+    J += problem.runningCost(t, xc, uc);
+    xc = problem.stateEq(t, xc, uc);
+  }
+  /** An EXTRA MASTER of a fan-out pass (kCmdForwardFanOut): a wave that is neither master, helper nor — unless kPrefetch —
+      prefetcher rolls out kAlphaGroups more step sizes of alpha_list, one per lane group, from the same LDS nominal records as
+      the master, and sums their cost (DDPSolver.hpp:536-560 without the stores: a trial that is not taken is only its cost,
+      :247-250).  Extra master `which` (0, 1) takes the step sizes first + kAlphaGroups (which + 1) + lane group.  A step size
+      accepted from here has no stored rollout: the master rolls it out once more (solveMasterFanOut).  kPrefetch: this wave
+      is also the one that keeps the nominal records ahead of everybody (forwardPrefetch's loads and LDS writes, in between its
+      own timesteps).  Same barriers as forwardMasterLds / forwardHelper / forwardPrefetch. */
+  template<bool kPrefetch>
+  NMPC_D void forwardCostOnlyLds(int sel_h, int which) const
+  {
+    static_assert(kFwdGroup == 4, "written for groups of four timesteps, as forwardMasterLds");
+    typedef double Pair2 __attribute__((ext_vector_type(2)));
+    // ---- prefetch duty (forwardPrefetch): lane = (timestep of the group, instance)
+    const unsigned p_inst = waveLane() % kNomInst;
+    const int p_q = static_cast<int>(waveLane() / kNomInst);
+    const unsigned ox = Base::offX(sel_h), ou = Base::offU(sel_h), ob = Base::offB();
+    auto loadGroup = [&](int g, double (&v)[kNomRec])
+    {
+      const int ii = g * kFwdGroup + p_q;
+      const int i = ii < T ? ii : T - 1;
+#pragma unroll kU
+      for(int j = 0; j < N; j++)
+      {
+        v[j] = Base::ld(Base::xRow(i) + j * LW, ox);
+      }
+#pragma unroll kU
+      for(int a = 0; a < MM; a++)
+      {
+        v[N + a] = Base::ld(Base::uRow(i) + a * LW, ou);
+        v[N + MM + a] = Base::ld(Base::kRow(i) + a * LW, ob);
+      }
+#pragma unroll kU
+      for(int e = 0; e < MM * N; e++)
+      {
+        v[N + 2 * MM + e] = Base::ld(Base::KRow(i) + e * LW, ob);
+      }
+      if constexpr(kNomRec > N + 2 * MM + MM * N)
+      {
+        v[kNomRec - 1] = 0;
+      }
+    };
+    auto writeGroup = [&](int slot, const double (&v)[kNomRec])
+    {
+      Pair2 * rec = reinterpret_cast<Pair2 *>(nomRec(slot, p_q, p_inst));
+#pragma unroll
+      for(int p = 0; p < kNomRec / 2; p++)
+      {
+        Pair2 w;
+        w[0] = v[2 * p];
+        w[1] = v[2 * p + 1];
+        rec[p] = w;
+      }
+    };
+    double v2[kNomRec];
+    if constexpr(kPrefetch)
+    {
+      double v0[kNomRec], v1[kNomRec];
+      loadGroup(0, v0);
+      loadGroup(1, v1);
+      loadGroup(2, v2);
+      writeGroup(0, v0);
+      writeGroup(1, v1);
+    }
+    // ---- this lane group's step size (uniformly indexed reads of the list, selected per lane group)
+    const int first = static_cast<int>(mailFirstAlpha()) + kAlphaGroups * (which + 1);
+    const int last_ai = cfg.n_alpha - 1;
+    double alpha = cfg.alpha_list[first < last_ai ? first : last_ai];
+#pragma unroll
+    for(int gg = 1; gg < kAlphaGroups; gg++)
+    {
+      const double a = cfg.alpha_list[first + gg < last_ai ? first + gg : last_ai];
+      alpha = (laneGroup() == static_cast<unsigned>(gg)) ? a : alpha;
+    }
+    wgBarrier(); // barrier S: the records of groups 0 and 1 are in LDS
+    Nominal na, nb;
+    int slot = 0, slot2 = 2;
+    readNominalLds(slot, 0, na);
+    StateDimVector xc;
+#pragma unroll kU
+    for(int j = 0; j < N; j++)
+    {
+      xc[j] = na.x[j]; // x'_0 = x_0
+    }
+    double J = 0;
+    const int n_full = T / kFwdGroup;
+    for(int g = 0; g < n_full; g++)
+    {
+      const int slot1 = (slot == kNomSlots - 1) ? 0 : slot + 1;
+      if constexpr(kPrefetch)
+      {
+        writeGroup(slot2, v2);
+        loadGroup(g + 3, v2);
+        slot2 = (slot2 == kNomSlots - 1) ? 0 : slot2 + 1;
+      }
+      readNominalLds(slot, 1, nb);
+      costOnlyStepLds(g * kFwdGroup, alpha, na, xc, J);
+      readNominalLds(slot, 2, na);
+      costOnlyStepLds(g * kFwdGroup + 1, alpha, nb, xc, J);
+      readNominalLds(slot, 3, nb);
+      costOnlyStepLds(g * kFwdGroup + 2, alpha, na, xc, J);
+      readNominalLds(slot1, 0, na);
+      costOnlyStepLds(g * kFwdGroup + 3, alpha, nb, xc, J);
+      wgBarrier(); // barrier of this group of kFwdGroup timesteps
+      slot = slot1;
+    }
+    const int i = n_full * kFwdGroup;
+    if(i < T)
+    {
+      readNominalLds(slot, 1, nb);
+      costOnlyStepLds(i, alpha, na, xc, J);
+    }
+    if(i + 1 < T)
+    {
+      readNominalLds(slot, 2, na);
+      costOnlyStepLds(i + 1, alpha, nb, xc, J);
+    }
+    if(i + 2 < T)
+    {
+      costOnlyStepLds(i + 2, alpha, na, xc, J);
+    }
+    J += problem.terminalCost(current_t + T * problem.dt(), xc);
+    wgBarrier(); // barrier E
+    mailCostExtra(which, waveLane()) = J;
+    wgBarrier(); // barrier F: candidate costs published
+  }
+
   NMPC_D void forwardMaster(double alpha)
   {
     if constexpr(kLdsNominal)
@@ -1976,7 +2148,10 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       const int last_ai = cfg.n_alpha - 1;
       // The groups fan out from the first pass on: group 0 rolls out (and stores) the first step size — the one the
       // nominal regime accepts, at the cost of a mirrored pass — while the other groups already try the next ones.
-      for(int ai0 = 0, n_par = kFanOutFirstPass; ai0 < cfg.n_alpha; ai0 += n_par, n_par = kAlphaGroups)
+      // With extra masters (kExtraMasters: the quad kernel's waves 2 and 3, cost only) a pass covers kStepSizesPerPass step
+      // sizes: the whole default alpha_list.  A step size accepted from an extra master is rolled out once more, with stores.
+      for(int ai0 = 0, n_par = (kExtraMasters > 0 ? kStepSizesPerPass : kFanOutFirstPass); ai0 < cfg.n_alpha;
+          ai0 += n_par, n_par = (kExtraMasters > 0 ? kStepSizesPerPass : kAlphaGroups))
       {
         if(!__any(need_fw))
         {
@@ -2022,6 +2197,10 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
             const double a = cfg.alpha_list[ai0 + gg < last_ai ? ai0 + gg : last_ai];
             my_alpha = (laneGroup() == static_cast<unsigned>(gg)) ? a : my_alpha;
           }
+          if constexpr(kExtraMasters > 0)
+          {
+            mailFirstAlpha() = static_cast<double>(ai0);
+          }
           post(kCmdForwardFanOut);
           profBegin();
           forwardMaster(my_alpha);
@@ -2036,13 +2215,25 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
                 judge(gg, mailCostAt(waveLane() % kGroupLanes + gg * kGroupLanes));
               }
             }
+            if constexpr(kExtraMasters > 0)
+            {
+#pragma unroll
+              for(int gg = kAlphaGroups; gg < kStepSizesPerPass; gg++)
+              {
+                if(ai0 + gg <= last_ai && g_acc < 0)
+                {
+                  judge(gg, mailCostExtra(gg / kAlphaGroups - 1, waveLane() % kGroupLanes + (gg % kAlphaGroups) * kGroupLanes));
+                }
+              }
+            }
           }
         }
         if constexpr(kAlphaGroups > 1)
         {
           if(__any(need_fw && g_acc > 0))
           {
-            if(fanScratch())
+            // (a step size taken from an extra master has no stored rollout: the re-roll below serves every lane of the wave)
+            if(fanScratch() && !__any(need_fw && g_acc >= kAlphaGroups))
             {
               // the accepted rollout waits in the fan-out scratch: the whole workgroup copies it into the candidate half
               mailCost() = (need_fw && g_acc > 0) ? static_cast<double>(g_acc) : 0.0;

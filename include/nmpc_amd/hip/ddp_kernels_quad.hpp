@@ -681,6 +681,18 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
           Pair::forwardHelper(sel_h, cmd == Pair::kCmdRollout);
         }
       }
+      else if(Pair::kExtraMasters > 0 && cmd == Pair::kCmdForwardFanOut)
+      {
+        // waves 2 and 3 roll out the step sizes behind the master's four, cost only; wave 2 also keeps the nominal records ahead
+        if(wave == 2)
+        {
+          Pair::template forwardCostOnlyLds<true>(sel_h, 0);
+        }
+        else
+        {
+          Pair::template forwardCostOnlyLds<false>(sel_h, 1);
+        }
+      }
       else if(Pair::kLdsNominalPath && (cmd == Pair::kCmdForward || cmd == Pair::kCmdForwardFanOut) && wave == 2)
       {
         Pair::forwardPrefetch(sel_h);

@@ -83,6 +83,8 @@ struct TileSolver64
   //! Q blocks come out of two products (G = VV^T F, Q = G^T F + L: 2 ceil(n/4) MFMAs instead of 5 ceil(n/4)); rows n .. n+m-1 of
   //! Q are then whole registers of the lane groups (n % 4 == 0), i.e. Qux / Quu without any cross-lane-group move
   static constexpr bool kAug = (N % 4 == 0) && (N + MM <= 16);
+  //! the slot table's sKrel holds max_i (|k_i| / (|u_i| + 1))^2 during a sweep (see stepValueUpdate)
+  static constexpr bool kKrelSquared = (M > 1);
   static constexpr int NA = N + MM;
   using Lane = InstanceSolver<Problem, kConstrained>; //!< the lane kernels' scalar helpers (ldltInPlace, boxQP): same bits
 
@@ -116,9 +118,13 @@ struct TileSolver64
     mAnyLs,
     mAnyMore, //!< a slot's first step size was rejected: the later ones are tried
     mAnyReroll, //!< a later step size was taken: its trajectory has to be stored
-    kNumMeta = 8
+    mNAct, //!< slots that take part in the coming backward sweep (sBw set), listed in act()
+    mChunk, //!< timesteps the model wave linearises per pass in that sweep (see backwardSweepModel)
+    kNumMeta = 10
   };
-  static constexpr int kSlotAt = kMetaAt + kNumMeta / 2;
+  //! ints: [0..31] active index -> slot, [32..63] slot -> active index (-1: the slot does not take part in the sweep)
+  static constexpr int kActAt = kMetaAt + kNumMeta / 2;
+  static constexpr int kSlotAt = kActAt + kT64MaxGroup;
   enum SlotField
   {
     // what the roles tell each other, and the per-instance solver state of the model wave between its phases (nothing of it
@@ -162,10 +168,13 @@ struct TileSolver64
   // per matrix wave: the column exchange of the gain computation, then (aliased: one wave's LDS traffic is ordered) the transposition
   //! leading dimension of the exchanged columns: ODD, so that the sixteen lanes of a row (one column each) hit different banks
   //! (with 8 they shared two bank groups: an 8-way conflict on every exchange access, half of the kernel's LDS cycles)
-  static constexpr int kColLd = (MM % 2 == 1) ? MM : MM + 1;
+  //! ... and at least 4 KM: a lane writes the rows 4 r + q (r < KM) of ITS column whether they exist or not — rows >= m and
+  //! columns >= n land in padding nobody reads — so the write addresses are the lane's column base plus constants (they were a
+  //! compare, a select and a shift each)
+  static constexpr int kColLd = 4 * KM + 1;
   static constexpr int wQQ = 0; //!< [Qux_reg | Qu]: column j at kColLd j, rows a < m
-  static constexpr int wF = wQQ + 9 * 16; //!< Quu_F: column c at wF + kColLd c
-  static constexpr int wX = wF + 9 * 8; //!< Qx, row 4 r + q at wX + 4 q + r
+  static constexpr int wF = wQQ + 9 * 16; //!< Quu_F: column c at wF + kColLd c (sixteen columns are written, m are read)
+  static constexpr int wX = wF + 9 * 16; //!< Qx, row 4 r + q at wX + 4 q + r
   static constexpr int wExchange = wX + 16;
   static constexpr int kTrLd = 17; //!< leading dimension of the transposition scratch: conflict-free both ways
   static constexpr int wT = 0;
@@ -208,10 +217,11 @@ struct TileSolver64
   int stride = 0; //!< doubles per record (odd: the model wave's lanes spread over the banks)
   int G = 1; //!< instances per group
   int group_cap;
+  int chunk_cap; //!< at most this many timesteps per pass of the model code (0: what fits; A/B measurements, tests)
 
   NMPC_D TileSolver64(const Problem & p, const nmpc_hip_ddp_config & c, const DeviceBuffers & bf, double * lds_base, int cap)
   : problem(p), cfg(c), buf(bf), T(bf.T), wave(static_cast<int>(threadIdx.x) >> 6), lane(static_cast<int>(threadIdx.x) & 63),
-    lds(lds_base), group_cap(cap)
+    lds(lds_base), group_cap(cap & 0xffff), chunk_cap((cap >> 16) & 0xffff)
   {
   }
 
@@ -236,9 +246,23 @@ struct TileSolver64
   {
     return reinterpret_cast<unsigned long long *>(lds + kSlotAt + field * kT64MaxGroup + slot)[0];
   }
-  NMPC_D double * rec(int parity, int slot) const
+  /** Record of active index a, timestep offset dt inside a chunk of `chunk` timesteps, buffer `parity` of the two. */
+  NMPC_D double * recAt(int parity, int dt, int a, int chunk, int n_act) const
   {
-    return lds + kRecAt + (parity * G + slot) * stride;
+    return lds + kRecAt + ((parity * chunk + dt) * n_act + a) * stride;
+  }
+  NMPC_D int & actSlot(int a) const
+  {
+    return reinterpret_cast<int *>(lds + kActAt)[a];
+  }
+  NMPC_D int & actIndex(int slot) const
+  {
+    return reinterpret_cast<int *>(lds + kActAt)[kT64MaxGroup + slot];
+  }
+  /** Records the record area holds (two buffers of chunk x n_act are needed). */
+  NMPC_D int recordCapacity() const
+  {
+    return (kLdsDoubles - kRecAt) / stride;
   }
   NMPC_D double * term(int slot) const
   {
@@ -494,7 +518,7 @@ struct TileSolver64
     }
   }
   template<bool kFull>
-  NMPC_D void lineariseStep(const Problem & mine, int slot, double t0, int i, const Point & p) const
+  NMPC_D void lineariseStep(const Problem & mine, double * dst, double t0, int i, const Point & p) const
   {
     StateDimVector x;
     InputDimVector u;
@@ -508,7 +532,7 @@ struct TileSolver64
     {
       u[a] = p.u[a];
     }
-    StoreSink<kFull> sink{rec(i & 1, slot)};
+    StoreSink<kFull> sink{dst};
     if(kFull)
     {
       sink.rec[0] = 0.0; // the zero word
@@ -1091,13 +1115,15 @@ struct TileSolver64
   NMPC_D void stepExchangeWrite(const StepCtx & c, double * W) const
   {
     const int fl = freshLane(), q = fl >> 4, j = fl & 15;
+    static_assert(kColLd <= 9 && kColLd >= 4 * KM, "columns of the exchange area");
+    double * Wc = W + kColLd * j + q; // this lane's column, row q
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
-      const int a = 4 * rr + q;
-      W[(a < MM && j < N) ? wQQ + kColLd * j + a : wDump] = c.QuxR[rr];
-      W[(a < MM && j < MM) ? wF + kColLd * j + a : wDump] = c.QuuF[rr];
+      Wc[wQQ + 4 * rr] = c.QuxR[rr]; // (unmasked: see kColLd)
+      Wc[wF + 4 * rr] = c.QuuF[rr];
     }
+    fence(); // column n of the area is Qu's: written after the (padding) rows the lanes of column n have just put there
     W[(q == qN && j < MM) ? wQQ + kColLd * N + j : wDump] = c.qurow;
     W[(q == qN && j < N) ? wX + 4 * (j & 3) + (j >> 2) : wDump] = c.qxrow;
   }
@@ -1247,8 +1273,9 @@ struct TileSolver64
     {
       kn += c.col[a] * c.col[a];
     }
-    const double knorm = (M == 1) ? fabs(c.col[0]) : sqrt(kn);
-    c.krel_i = knorm * c.inv_u;
+    // m > 1: the SQUARE of the ratio — the maximum over the horizon commutes with the square root, which the model wave takes
+    // once per sweep instead of every matrix lane once per timestep (twenty instructions of a step's eight hundred)
+    c.krel_i = kKrelSquared ? kn * (c.inv_u * c.inv_u) : fabs(c.col[0]) * c.inv_u;
     // Vxx <- (Vxx + Vxx^T) / 2: rows to the scratch, columns back (phase 4)
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
@@ -1333,26 +1360,30 @@ struct TileSolver64
     ok = c.ok;
   }
   /** The sweep of the matrix waves (barriers are shared with the model wave's loop, backwardSweepModel).
-      The value functions of the wave's (up to five) slots stay in registers for the whole sweep.  The slot loop is a real loop
-      — one copy of the step in the instruction cache — that always works on the first register(s) and then rotates them
-      (register moves; an array indexed by the trip count would live in scratch memory): after the last trip every value
-      function is back in its place.  (Two slots per trip with their steps interleaved phase by phase was measured for the
-      quadrotor: no gain — the SIMDs are busy, not waiting.) */
+      The slots that take part in the sweep are dealt to the matrix waves by their ACTIVE index (a = mw + 7 e: a sweep that
+      only a few slots of the group still need — the last iterations of a batch — spreads over all waves), and the value
+      functions of a wave's (up to five) slots stay in registers for the whole sweep.  The slot loop is a real loop — one copy
+      of the step in the instruction cache — that always works on the first register(s) and then rotates them (register moves;
+      an array indexed by the trip count would live in scratch memory): after the last trip every value function is back in
+      its place.  Within a chunk of timesteps (backwardSweepModel) the waves do not wait for each other: the matrix waves of a
+      group share nothing but the record buffers. */
   NMPC_D void backwardSweepMatrix() const
   {
     static_assert(kT64MaxPerWave == 5, "the rotations below are written for five slots per wave");
     const LaneMap mp = makeLaneMap();
     const int q = lane >> 4, j = lane & 15;
     const int mw = wave - 1;
+    const int n_act = uniform(meta(mNAct)), chunk = uniform(meta(mChunk));
     v4d64 V0, V1, V2, V3, V4;
     unsigned ok_mask = ~0u;
     barrier(); // the terminal records are complete
     auto loadTerminal = [&](int e) -> v4d64
     {
-      const int slot = mw + kT64MatrixWaves * e;
+      const int a = mw + kT64MatrixWaves * e;
       v4d64 v = {0, 0, 0, 0};
-      if(slot < G && uniform(slotI(sBw, slot)) != 0)
+      if(a < n_act)
       {
+        const int slot = uniform(actSlot(a));
         const double * tr = term(slot);
 #pragma unroll
         for(int rr = 0; rr < 4; rr++)
@@ -1376,19 +1407,24 @@ struct TileSolver64
     V3 = loadTerminal(3);
     V4 = loadTerminal(4);
     barrier(); // the terminal records have been read
-    barrier(); // the records of timestep T - 1 are complete
-    for(int i = T - 1; i >= 0; i--)
+    barrier(); // the records of the first chunk are complete
+    int parity = 0;
+    for(int hi = T - 1; hi >= 0; hi -= chunk, parity ^= 1)
     {
       const unsigned long long pa = profNow();
+      const int lo = (hi - chunk + 1 > 0) ? hi - chunk + 1 : 0;
+      for(int i = hi; i >= lo; i--)
       {
 #pragma nounroll
         for(int e = 0; e < kT64MaxPerWave; e++)
         {
-          const int slot = mw + kT64MatrixWaves * e;
-          if(slot < G && uniform(slotI(sBw, slot)) != 0)
+          const int a = mw + kT64MatrixWaves * e;
+          if(a < n_act)
           {
+            const int slot = uniform(actSlot(a));
             bool ok = ((ok_mask >> e) & 1u) != 0;
-            backwardStep(V0, ok, mp, rec(i & 1, slot), slot, uniform(slotI(sB, slot)), i, uniformD(slotF(sLambda, slot)));
+            backwardStep(V0, ok, mp, recAt(parity, hi - i, a, chunk, n_act), slot, uniform(slotI(sB, slot)), i,
+                         uniformD(slotF(sLambda, slot)));
             ok_mask = ok ? ok_mask : (ok_mask & ~(1u << e));
             profAdd(4, 1, 1);
           }
@@ -1403,9 +1439,9 @@ struct TileSolver64
       const unsigned long long pb = profNow();
       profAdd(2, pb - pa, 1);
       profAdd(11, pb - pa, 5);
-      barrier(); // record i has been read by all, record i - 1 is complete
+      barrier(); // this chunk's records have been read by all, the next chunk's are complete
       profAdd(3, profNow() - pb, 1);
-      profAdd(16 + wave, pb - pa, wave); // every matrix wave: its steps of this timestep ...
+      profAdd(16 + wave, pb - pa, wave); // every matrix wave: its steps of this chunk ...
       profAdd(24 + wave, profNow() - pb, wave); // ... and its wait at the barrier
     }
     if(lane == kStarLane)
@@ -1413,50 +1449,74 @@ struct TileSolver64
 #pragma unroll
       for(int e = 0; e < kT64MaxPerWave; e++)
       {
-        const int slot = mw + kT64MatrixWaves * e;
-        if(slot < G && slotI(sBw, slot) != 0)
+        const int a = mw + kT64MatrixWaves * e;
+        if(a < n_act)
         {
-          slotI(sOk, slot) = static_cast<int>((ok_mask >> e) & 1u);
+          slotI(sOk, actSlot(a)) = static_cast<int>((ok_mask >> e) & 1u);
         }
       }
     }
   }
 
-  /** The model wave's half of the sweep: record i - 1 is written while the matrix waves consume record i; (x, u) of a timestep
-      are requested one timestep before they are linearised.  T + 3 barriers, as backwardSweepMatrix. */
-  NMPC_D void backwardSweepModel(const Problem & mine_p, bool mine, int slot, int b, int sel, double t0) const
+  /** The model wave's half of the sweep.  A lane linearises ONE (slot, timestep): with n_act slots in the sweep a pass of the
+      model code covers a CHUNK of timesteps, lane = dt * n_act + a — as many as the lanes (64) and the record area (two
+      buffers of chunk x n_act records) hold.  A full group of 32 is a chunk of one timestep (lane = slot, records of timestep
+      i - 1 written while the matrix waves consume timestep i).  A sweep that few slots need — small batches, the regularisation
+      retries, the last iterations of a batch, when most slots have converged — covers up to the whole horizon in one pass: its
+      timestep costs the matrix waves' step, not a pass of the model code per timestep.  (x, u) of the next chunk are requested
+      behind the linearisation of this one, and complete while the wave waits at the chunk's barrier.
+      ceil(T / chunk) + 3 barriers, as backwardSweepMatrix. */
+  NMPC_D void backwardSweepModel(int group) const
   {
-    Point cur, next;
-    if(mine)
+    const int n_act = uniform(meta(mNAct)), chunk = uniform(meta(mChunk));
+    const int a = lane % n_act, dt = lane / n_act;
+    const bool lane_used = dt < chunk; // (n_act * chunk <= 64)
+    const int slot = actSlot(lane_used ? a : 0);
+    const int b = group * G + slot;
+    const int sel = slotI(sSel, slot);
+    const double t0 = slotF(sT0, slot);
+    const Problem mine_p = problemOf(lane_used ? b : group * G + actSlot(0));
+    Point next;
+    if(lane_used && T - 1 - dt >= 0)
     {
-      loadPoint(next, b, sel, T - 1);
+      loadPoint(next, b, sel, T - 1 - dt);
+    }
+    if(lane_used && dt == 0)
+    {
       lineariseTerminal(mine_p, slot, b, sel, t0);
     }
     barrier(); // the terminal records are complete
     barrier(); // (the matrix waves have taken them: the record area is free)
     profAdd(9, 1, 0);
-    for(int step = T - 1; step >= 0; step--)
+    int parity = 0, n_chunk = 0;
+    for(int hi = T - 1; hi >= 0; hi -= chunk, parity ^= 1, n_chunk++)
     {
       const unsigned long long pa = profNow();
+      const int step = hi - dt;
+      const bool mine = lane_used && step >= 0;
       if(mine)
       {
-        cur = next;
-        loadPoint(next, b, sel, step > 0 ? step - 1 : 0);
-        if(step >= T - 2)
+        double * dst = recAt(parity, dt, a, chunk, n_act);
+        if(n_chunk < 2)
         {
-          lineariseStep<true>(mine_p, slot, t0, step, cur); // the first use of a record slot in the sweep: every entry
+          lineariseStep<true>(mine_p, dst, t0, step, next); // the first use of a record buffer in the sweep: every entry
         }
         else
         {
-          lineariseStep<false>(mine_p, slot, t0, step, cur);
+          lineariseStep<false>(mine_p, dst, t0, step, next);
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if(lane_used && step - chunk >= 0)
+      {
+        loadPoint(next, b, sel, step - chunk);
       }
       const unsigned long long pb = profNow();
       profAdd(0, pb - pa, 0);
-      barrier(); // record `step` is complete (and record step + 1 has been read by all)
+      barrier(); // this chunk's records are complete (and the previous chunk's have been read by all)
       profAdd(1, profNow() - pb, 0);
     }
-    barrier(); // record 0 has been read
+    barrier(); // the last chunk has been read
   }
 
   // ===================================================================================================
@@ -1539,6 +1599,36 @@ struct TileSolver64
     }
   }
 
+  /** The slots of the coming backward sweep as a list (model wave, lanes = slots; `takes_part` balloted into `mask`), and the
+      chunk of timesteps the model wave linearises per pass: as many as its 64 lanes and two record buffers allow. */
+  NMPC_D void listActive(bool takes_part, unsigned long long mask, int slot) const
+  {
+    const int a = __popcll(mask & ((1ull << lane) - 1ull));
+    const int n_act = __popcll(mask);
+    actIndex(slot) = takes_part ? a : -1;
+    if(takes_part)
+    {
+      actSlot(a) = slot;
+    }
+    if(lane == 0)
+    {
+      int chunk = 1;
+      if(n_act > 0)
+      {
+        const int by_lanes = 64 / n_act, by_records = recordCapacity() / (2 * n_act);
+        chunk = by_lanes < by_records ? by_lanes : by_records;
+        chunk = chunk > T ? T : chunk;
+        chunk = chunk < 1 ? 1 : chunk;
+      }
+      if(chunk_cap > 0 && chunk > chunk_cap)
+      {
+        chunk = chunk_cap;
+      }
+      meta(mNAct) = n_act;
+      meta(mChunk) = chunk;
+    }
+  }
+
   /** One group of instances, all eight waves.  The phases are separated by barriers; wave 0 ("model wave", lane = slot) runs the
       solver state machine of DDPSolver::solve / procOnce for its slot in short blocks between them — its state lives in the
       slot table — and the model code; waves 1 .. 7 run the backward sweeps and help in the line search. */
@@ -1602,6 +1692,7 @@ struct TileSolver64
         slotI(sFlags, slot) = flags;
         slotI(sBw, slot) = in_iter ? 1 : 0;
         const unsigned long long any = __ballot(in_iter);
+        listActive(in_iter, any, slot);
         if(lane == 0)
         {
           meta(mAnyIter) = (any != 0) ? 1 : 0;
@@ -1618,9 +1709,7 @@ struct TileSolver64
         const unsigned long long p0 = __builtin_readcyclecounter();
         if(model_wave)
         {
-          const bool mine = slot_lane && (slotI(sFlags, slot) & fNeedBw) != 0;
-          const Problem mine_p = problemOf(mine ? b : 0);
-          backwardSweepModel(mine_p, mine, slot, b, slotI(sSel, slot), slotF(sT0, slot));
+          backwardSweepModel(group);
         }
         else
         {
@@ -1659,6 +1748,7 @@ struct TileSolver64
           }
           slotI(sBw, slot) = retry ? 1 : 0;
           const unsigned long long any = __ballot(retry);
+          listActive(retry, any, slot);
           if(lane == 0)
           {
             meta(mAnyRetry) = (any != 0) ? 1 : 0;
@@ -1680,7 +1770,7 @@ struct TileSolver64
           trF(NMPC_HIP_TRACE_N_BACKWARD, slot) = static_cast<double>(slotI(sNBw, slot));
           if(slotI(sRet, slot) == 0)
           {
-            const double krel = slotF(sKrel, slot);
+            const double krel = kKrelSquared ? sqrt(slotF(sKrel, slot)) : slotF(sKrel, slot);
             trF(NMPC_HIP_TRACE_K_REL_NORM, slot) = krel;
             if(krel < cfg.k_rel_norm_thre && slotF(sLambda, slot) < cfg.lambda_thre)
             {
@@ -2016,7 +2106,9 @@ __global__ __launch_bounds__(kT64Threads) void ddp_solve_tile64_kernel(const Pro
                                                                         const DeviceBuffers buf,
                                                                         const int group_cap)
 {
-  extern __shared__ __attribute__((aligned(16))) double lds_tile64[];
+  // (a STATIC array: the address of a dynamic one — extern __shared__ — is a symbol until after instruction selection, and
+  // every LDS access of the kernel carried a leftover `v_add_u32 v, 0, v`: twenty of them per backward step)
+  __shared__ __attribute__((aligned(16))) double lds_tile64[kT64LdsBytes / sizeof(double)];
   TileSolver64<Problem, kConstrained, kOwnProblem> solver(problem, cfg, buf, lds_tile64, group_cap);
   solver.run();
 }
@@ -2033,17 +2125,11 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
   {
     return hipErrorInvalidDevice;
   }
-  const void * fn = reinterpret_cast<const void *>(&ddp_solve_tile64_kernel<Problem, kConstrained, kOwnProblem>);
   int cus = n_cu[dev].load(std::memory_order_acquire);
   if(cus == 0)
   {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kT64LdsBytes));
-    if(e != hipSuccess)
-    {
-      return e;
-    }
     hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, dev);
+    hipError_t e = hipGetDeviceProperties(&prop, dev);
     if(e != hipSuccess)
     {
       return e;
@@ -2054,7 +2140,12 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
   int cap = 0; // NMPC_HIP_DDP_TILE64_GROUP=<g>: at most g instances per group (tests: full groups on small batches)
   if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_GROUP"))
   {
-    cap = std::atoi(e);
+    cap = std::atoi(e) & 0xffff;
+  }
+  int chunk_cap = 0; // NMPC_HIP_DDP_TILE64_CHUNK=<c>: at most c timesteps per pass of the model code (1: round 3's schedule)
+  if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_CHUNK"))
+  {
+    chunk_cap = std::atoi(e) & 0xffff;
   }
   int grid = cus;
   if(cap > 0)
@@ -2063,8 +2154,8 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
     grid = groups < grid ? (groups < 1 ? 1 : groups) : grid;
   }
   grid = buf.B < grid ? buf.B : grid;
-  hipLaunchKernelGGL((ddp_solve_tile64_kernel<Problem, kConstrained, kOwnProblem>), dim3(grid), dim3(kT64Threads), kT64LdsBytes,
-                     stream, problem, cfg, buf, cap);
+  hipLaunchKernelGGL((ddp_solve_tile64_kernel<Problem, kConstrained, kOwnProblem>), dim3(grid), dim3(kT64Threads), 0, stream, problem,
+                     cfg, buf, cap | (chunk_cap << 16)); // (the kernel's 160 KB of LDS are a static array)
   return hipGetLastError();
 }
 } // namespace hip

@@ -59,11 +59,16 @@ struct ModelOpsFor
       replaces the wave-per-instance kernel on these shapes; NMPC_HIP_DDP_KERNEL=wpi / 1w select the older kernels (A/B). */
   static constexpr bool kTile64Shape = !Problem::kDynamicInput && Problem::kStateDim >= 5 && Problem::kStateDim <= 15
                                        && Problem::kInputDimMax >= 1 && Problem::kInputDimMax <= 8;
-  //! Up to this batch the wave-per-instance kernel is the faster one where both exist (n >= 9): a group's sweep cannot go
-  //! faster than its model wave linearises one timestep (20 k cycles for the manipulator, whatever the group size), while a
-  //! wave-per-instance launch linearises all timesteps of an instance at once; measured (scripts/tile64_batch_scaling.py,
-  //! profiles/r03b_tile64_batch_scaling.txt): manipulator 1.6 ms against 2.7 ms at 1024 instances, 3.1 against 2.7 at 2048.
-  static constexpr int kTile64MinBatch = 1025;
+  //! Below this batch the wave-per-instance kernel is still the (marginally) faster one where both exist (n >= 9).  Until round
+  //! 4 the threshold was 1025: a group's sweep could not go faster than its model wave linearises ONE timestep per pass
+  //! (33 k cycles for the manipulator, whatever the group size).  The model wave now linearises a CHUNK of timesteps per pass
+  //! — as many (slot, timestep) pairs as its 64 lanes and the record area hold (backwardSweepModel) — and the two kernels
+  //! are level up to 512 instances, the tile kernel ahead from there (scripts/tile64_chunk_ab.py,
+  //! profiles/r04_tile64_chunk_ab.txt: manipulator 1.38 against 1.37 ms at 256, 1.41 / 1.42 at 512, 1.45 / 1.57 at 1024,
+  //! 1.82 / 3.04 at 2048).
+  static constexpr int kTile64MinBatch = 257;
+  //! box-constrained solves: round 3's threshold (the QP dominates their timestep; small batches have not been re-measured)
+  static constexpr int kTile64MinBatchBoxQP = 1025;
   static bool useTile64(bool constrained, int batch)
   {
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
@@ -75,7 +80,7 @@ struct ModelOpsFor
     {
       return true;
     }
-    if(kWpiShape && batch < kTile64MinBatch)
+    if(kWpiShape && batch < (constrained ? kTile64MinBatchBoxQP : kTile64MinBatch))
     {
       return false;
     }

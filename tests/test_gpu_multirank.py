@@ -59,7 +59,7 @@ def test_bench_under_two_ranks():
     """bench.py launched the way the driver launches it for N > 1 (both ranks share device 0 here): one JSON line from rank 0,
     n_gpus = 2, the whole-job value is the sum of both ranks' work, per-rank solve and gather times are reported."""
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
-                   "--no-extra-modes"], 29643)
+                   "--no-extra-modes", "--min-seconds", "0.5"], 29643)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -69,6 +69,24 @@ def test_bench_under_two_ranks():
     assert len(cfg["per_rank_solve_ms"]) == 2 and len(cfg["per_rank_gather_ms"]) == 2
     assert 7000 < cfg["instance_iterations_per_step"] / 8  # two shards of 4096 instances, ~7.3 iterations each
     it_per_step = cfg["instance_iterations_per_step"] / 4096
+    assert abs(d["value"] - it_per_step / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_bench_c5_uneven_strong_split_gathers_the_unsharded_solve():
+    """bench.py --workload c5 with ONE batch of 8200 + 1 instances cut over two ranks (4101 / 4100: uneven shards, padded to one
+    fixed-size all-gather): the gathered records — X | U | cost | status | iters of every shard — equal the unsharded solve of
+    the same batch bit for bit (both sides on the fp64 tile kernel), and the line says so."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--workload", "c5", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                   "--no-extra-modes", "--min-seconds", "0.2", "--global-batch", "8201", "--verify-gather"], 29645)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "batch=8201" in d["metric"]
+    cfg = d["config"]
+    assert cfg["shard_sizes"] == [4101, 4100] and cfg["gather_verified"] is True
+    assert d["roofline"]["kernel"] == "ddp_solve_tile64_kernel<manipulator>"
+    it_per_step = cfg["instance_iterations_per_step"] / 8201
     assert abs(d["value"] - it_per_step / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
 

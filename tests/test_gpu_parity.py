@@ -518,15 +518,19 @@ def test_cpp_host_mirror_example(tmp_path):
                     "duration_forward"]  # DDPSolver.hpp:567-578: what scripts/plotDDPTraceData.py reads
 
 
-@pytest.mark.parametrize("model", ["cartpole", "bipedal", "vertical"])
+@pytest.mark.parametrize("model", ["cartpole", "bipedal", "vertical", "vertical_box"])
 def test_two_wave_and_single_wave_kernels_agree(model, monkeypatch):
     """Both lane mappings (ddp_kernels_2w.hpp: master + helper wave through LDS; ddp_kernels.hpp: one wave) run the
-    same algorithm: identical discrete decisions, values equal up to FMA-contraction differences."""
+    same algorithm: identical discrete decisions, values equal up to FMA-contraction differences.  The box-constrained cases
+    also compare traceLast(): the two-wave kernel keeps that row at the end of its LDS, behind records whose size depends on
+    the instantiation (the constrained layout was launched with the unconstrained size)."""
     from nmpc_amd import workloads
 
     wl = {"cartpole": lambda: workloads.cartpole_batch(B=200, T=60, seed=11, constrained=True),
           "bipedal": lambda: workloads.bipedal_batch(B=130, T=40, seed=12),
-          "vertical": lambda: workloads.vertical_batch(B=96, T=80, seed=13, constrained=False)}[model]()
+          "vertical": lambda: workloads.vertical_batch(B=96, T=80, seed=13, constrained=False),
+          "vertical_box": lambda: workloads.vertical_batch(B=96, T=80, seed=14, constrained=True)}[model]()
+    model = "vertical" if model == "vertical_box" else model
     cfg = dict(with_input_constraint=wl.limits is not None, max_iter=30)
     if model == "vertical":
         cfg["initial_lambda"] = 1e-6
@@ -539,13 +543,17 @@ def test_two_wave_and_single_wave_kernels_agree(model, monkeypatch):
         s.solve(wl.t0, wl.x0, wl.u_init)
         assert s.kernelName() == names[kernel]
         out[kernel] = dict(status=s.status(), iters=s.iters(), X=s.X(), U=s.U(), cost=s.cost(), kff=s.kff(),
-                           Kfb=s.Kfb(), trace=s.trace(), qp=s.qpRetval(), free=s.qpFreeMask())
+                           Kfb=s.Kfb(), trace=s.trace(), qp=s.qpRetval(), free=s.qpFreeMask(), last=s.traceLast())
     a = out["2w"]
     for other in kernels[1:]:
         b = out[other]
         for key in ("status", "iters", "qp", "free"):
             assert np.array_equal(a[key], b[key]), (other, key)
         assert np.array_equal(a["trace"][..., INT_COLS], b["trace"][..., INT_COLS]), other
+        assert np.array_equal(a["last"][:, INT_COLS], b["last"][:, INT_COLS]), other
+        # (cost, lambda, dlambda, step size; the actual / expected cost updates of a converged iteration are differences of
+        # nearly equal numbers and differ between lane mappings by their rounding)
+        assert scaled_err(a["last"][:, 1:5], b["last"][:, 1:5]) <= TOL, other
         for key in ("X", "U", "cost", "kff", "Kfb"):
             assert scaled_err(a[key], b[key]) <= TOL, (other, key)
 
@@ -618,7 +626,11 @@ def test_unconstrained_fan_out_equals_sequential_line_search(monkeypatch):
 
     monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
     wl = workloads.cartpole_batch(B=512, T=100, seed=3)
-    for cfg in (dict(max_iter=500), dict(max_iter=50, k_rel_norm_thre=0.0, cost_update_thre=-1e300)):
+    # (round 4: a fan-out pass covers TWELVE step sizes — the master's four lane groups and eight more on the workgroup's
+    # other two waves, cost only — i.e. the reference's eleven in one pass; a list of 25 takes three passes, and a step size
+    # accepted from the cost-only waves is rolled out once more: all of it must stay invisible in the results)
+    for cfg in (dict(max_iter=500), dict(max_iter=50, k_rel_norm_thre=0.0, cost_update_thre=-1e300),
+                dict(max_iter=40, k_rel_norm_thre=0.0, cost_update_thre=-1e300, alpha_list=np.power(10.0, np.linspace(0, -3, 25)))):
         out = []
         # (fan-out, fan-out scratch): sequential; parallel with the accepted rollout adopted from the scratch
         # (PairSolver::adoptFanOut); parallel without the scratch (what a failed allocation leaves: the accepted step size
@@ -638,7 +650,9 @@ def test_unconstrained_fan_out_equals_sequential_line_search(monkeypatch):
                 np.testing.assert_array_equal(a, b)
         if "k_rel_norm_thre" in cfg:  # M1 keeps iterating on converged trajectories: searches end at every index of the list
             idx = out[0][5][:, 1:, 9].astype(int)
-            assert (idx > 0).sum() > 1000 and (idx == 10).sum() > 100, "the workload never backtracks: the fan-out was not exercised"
+            last = len(cfg.get("alpha_list", np.zeros(11))) - 1
+            assert (idx > 0).sum() > 1000 and (idx == last).sum() > 100, "the workload never backtracks: the fan-out was not exercised"
+            assert ((idx >= 4) & (idx < last)).sum() > 20, "no step size was taken from the cost-only waves"
     # and the automatic choice (the parallel search) against the oracle
     ref = oracle_batch(wl, max_iter=30)
     s = make_solver(wl, max_iter=30)
@@ -695,8 +709,8 @@ MATRIX_KERNELS = {"tile64": "ddp_solve_tile64_kernel", "tile64!": "ddp_solve_til
 def _select_matrix_kernel(monkeypatch, kernel, group=None):
     """kernel: "tile64" (default dispatch) or "wpi" (forced).  group: NMPC_HIP_DDP_TILE64_GROUP — at most that many instances
     per workgroup (small test batches otherwise spread out to one instance per workgroup)."""
-    # both forced: where both kernels exist (n >= 9) the default is the tile kernel for unconstrained batches above 1024
-    # instances and the wave-per-instance kernel otherwise (test_matrix_kernel_dispatch)
+    # both forced: where both kernels exist (n >= 9) the default is the tile kernel for unconstrained batches above 256
+    # instances (box-constrained: above 1024) and the wave-per-instance kernel otherwise (test_matrix_kernel_dispatch)
     monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", "wpi" if kernel == "wpi" else "tile64")
     if group:
         monkeypatch.setenv("NMPC_HIP_DDP_TILE64_GROUP", str(group))
@@ -705,16 +719,17 @@ def _select_matrix_kernel(monkeypatch, kernel, group=None):
 
 
 def test_matrix_kernel_dispatch(monkeypatch):
-    """Default dispatch of the 9 <= n <= 15 shapes: the tile kernel for unconstrained batches above 1024 instances (it wins on
-    throughput: 2.4 - 2.7 x at 8192), the wave-per-instance kernel below (it wins on latency) and for box-constrained solves
-    with more than four inputs; 5 <= n <= 8 always on the tile kernel."""
+    """Default dispatch of the 9 <= n <= 15 shapes: the tile kernel for unconstrained batches above 256 instances (round 4: its
+    model wave linearises a chunk of timesteps per pass, which took its small-batch latency from 2.2 to 1.4 ms — level with the
+    wave-per-instance kernel up to 512 instances, ahead beyond: 3 x at 8192), the wave-per-instance kernel below and for
+    box-constrained solves with more than four inputs or up to 1024 instances; 5 <= n <= 8 always on the tile kernel."""
     import nmpc_amd
     monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
     for model in ("quadrotor", "manipulator"):
         prob = nmpc_amd.make_problem(model)
         assert nmpc_amd.DDPSolverBatch(prob, 8192).kernelName() == "ddp_solve_tile64_kernel"
-        assert nmpc_amd.DDPSolverBatch(prob, 1025).kernelName() == "ddp_solve_tile64_kernel"
-        assert nmpc_amd.DDPSolverBatch(prob, 1024).kernelName() == "ddp_solve_wpi_kernel"
+        assert nmpc_amd.DDPSolverBatch(prob, 257).kernelName() == "ddp_solve_tile64_kernel"
+        assert nmpc_amd.DDPSolverBatch(prob, 256).kernelName() == "ddp_solve_wpi_kernel"
         s = nmpc_amd.DDPSolverBatch(prob, 8192)
         s.config().with_input_constraint = True
         s.setInputLimits(np.full(prob.dims()[1], -1.0), np.full(prob.dims()[1], 1.0))

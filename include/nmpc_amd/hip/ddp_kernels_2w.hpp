@@ -171,6 +171,11 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   {
     return lds[(static_cast<size_t>(kRecArea) + 2 + NMPC_HIP_NTRACE + 2) * LW];
   }
+  //! 1.0: the running fan-out pass is a WIDE one (the extra masters roll out too); 0.0: only the master's lane groups do
+  NMPC_D double & mailWidePass() const
+  {
+    return lds[(static_cast<size_t>(kRecArea) + 2 + NMPC_HIP_NTRACE + 2) * LW + 1];
+  }
   static constexpr unsigned kGroupLanes = kLanesPerBlock / kAlphaGroups;
 #ifndef NMPC_FANOUT_FIRST_PASS
 #  define NMPC_FANOUT_FIRST_PASS 1
@@ -2078,6 +2083,12 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 
     int retval = 0;
     bool active = valid; // this lane still iterates
+    // Extra masters: whether the FIRST pass of a line search is a wide one (twelve step sizes: waves 2 and 3 roll out too) is
+    // predicted from the workgroup's previous search — wide if an instance went beyond the master's lane groups then.  The
+    // nominal regime (first step size accepted) keeps the narrow pass, in which wave 2 only prefetches and the master never
+    // waits for it (a wide pass is ~7 % longer: measured, profiles/r04_fanout_ab.txt); a search that exhausts the narrow pass
+    // continues with wide ones.  The schedule changes which wave computes a cost, never the cost: results are independent of it.
+    bool wide_first = false;
     for(int iter = 1; iter <= cfg.max_iter; iter++)
     {
       if(!__any(active))
@@ -2150,9 +2161,10 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       // nominal regime accepts, at the cost of a mirrored pass — while the other groups already try the next ones.
       // With extra masters (kExtraMasters: the quad kernel's waves 2 and 3, cost only) a pass covers kStepSizesPerPass step
       // sizes: the whole default alpha_list.  A step size accepted from an extra master is rolled out once more, with stores.
-      for(int ai0 = 0, n_par = (kExtraMasters > 0 ? kStepSizesPerPass : kFanOutFirstPass); ai0 < cfg.n_alpha;
-          ai0 += n_par, n_par = (kExtraMasters > 0 ? kStepSizesPerPass : kAlphaGroups))
+      for(int ai0 = 0, n_par = 0; ai0 < cfg.n_alpha; ai0 += n_par)
       {
+        const bool wide_pass = kExtraMasters > 0 && (wide_first || ai0 > 0);
+        n_par = wide_pass ? kStepSizesPerPass : ((ai0 == 0 && kExtraMasters == 0) ? kFanOutFirstPass : kAlphaGroups);
         if(!__any(need_fw))
         {
           break;
@@ -2200,6 +2212,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
           if constexpr(kExtraMasters > 0)
           {
             mailFirstAlpha() = static_cast<double>(ai0);
+            mailWidePass() = wide_pass ? 1.0 : 0.0;
           }
           post(kCmdForwardFanOut);
           profBegin();
@@ -2220,7 +2233,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 #pragma unroll
               for(int gg = kAlphaGroups; gg < kStepSizesPerPass; gg++)
               {
-                if(ai0 + gg <= last_ai && g_acc < 0)
+                if(wide_pass && ai0 + gg <= last_ai && g_acc < 0)
                 {
                   judge(gg, mailCostExtra(gg / kAlphaGroups - 1, waveLane() % kGroupLanes + (gg % kAlphaGroups) * kGroupLanes));
                 }
@@ -2262,6 +2275,13 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
         }
       }
 
+      if constexpr(kExtraMasters > 0)
+      {
+        if(__any(searched))
+        {
+          wide_first = __any(searched && (!forward_pass_success || ai_used >= kAlphaGroups));
+        }
+      }
       if(searched)
       {
         // ---- Step 4: accept / reject and the lambda schedule    :280-333

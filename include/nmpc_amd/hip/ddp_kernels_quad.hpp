@@ -681,7 +681,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
           Pair::forwardHelper(sel_h, cmd == Pair::kCmdRollout);
         }
       }
-      else if(Pair::kExtraMasters > 0 && cmd == Pair::kCmdForwardFanOut)
+      else if(Pair::kExtraMasters > 0 && cmd == Pair::kCmdForwardFanOut && Pair::mailWidePass() != 0.0)
       {
         // waves 2 and 3 roll out the step sizes behind the master's four, cost only; wave 2 also keeps the nominal records ahead
         if(wave == 2)

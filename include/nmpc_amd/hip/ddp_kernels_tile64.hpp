@@ -71,9 +71,14 @@ struct TileSolver64
   static constexpr int N = Problem::kStateDim;
   static constexpr int M = Problem::kInputDimMax;
   static constexpr int MM = M;
-  static_assert(!Problem::kDynamicInput, "static input dimension only");
+  //! input dimension known per timestep only (inputDim(t): the reference's centroidal-motion problem, 16 / 0)
+  static constexpr bool kDyn = Problem::kDynamicInput;
+  //! m > 8, or a run-time m: the m x m factorisation does not fit a lane's registers (16 x 16 doubles) — the gains are computed
+  //! in NATURAL LAYOUT instead, the factor spread over the wave (stepGainsNatural); m <= 8 static: every lane factorises
+  static constexpr bool kBig = kDyn || M > 8;
   static_assert(N >= 1 && N <= 15, "[Vxx | Vx] is one 16-column tile");
-  static_assert(M >= 1 && M <= 8, "the m x m factorisation runs in registers");
+  static_assert(M >= 1 && M <= 16, "[K | k] is one tile of m <= 16 rows");
+  static_assert(!(kConstrained && kBig), "BoxQP on the tile kernel: static m <= 8 (boxQPMasked runs in a lane's registers)");
   static constexpr bool kShape = true;
   static constexpr int KN = (N + 3) / 4; //!< k-slices of a contraction over state rows
   static constexpr int KM = (MM + 3) / 4; //!< ... over input rows; also the registers of an m-row tile that hold anything
@@ -104,7 +109,8 @@ struct TileSolver64
   static constexpr int idLu = idLx + N;
   static constexpr int idInvU = idLu + MM; //!< 1 / (|u_i| + 1)    :217-221
   static constexpr int idU = idInvU + 1; //!< u_i (box-constrained solves: the QP's bounds are limits - u_i, :470-472)
-  static constexpr int kNumIds = idU + (kConstrained ? MM : 0);
+  static constexpr int idM = idU + (kConstrained ? MM : 0); //!< inputDim(t_i) as a double (run-time input dimension only)
+  static constexpr int kNumIds = idM + (kDyn ? 1 : 0);
 
   // ---- LDS layout, in doubles.  Fixed part first, the record area takes the rest.
   static constexpr int kTblAt = 0; //!< unsigned short tbl[kNumIds]: entry -> offset in a record (0 = the zero word)
@@ -120,7 +126,9 @@ struct TileSolver64
     mAnyReroll, //!< a later step size was taken: its trajectory has to be stored
     mNAct, //!< slots that take part in the coming backward sweep (sBw set), listed in act()
     mChunk, //!< timesteps the model wave linearises per pass in that sweep (see backwardSweepModel)
-    kNumMeta = 10
+    mWide, //!< this line search rolls out the later step sizes WITH the first one (see solveGroup)
+    mRejected, //!< the group's previous line search: 4 x slots that rejected the first step size >= slots that searched
+    kNumMeta = 12
   };
   //! ints: [0..31] active index -> slot, [32..63] slot -> active index (-1: the slot does not take part in the sweep)
   static constexpr int kActAt = kMetaAt + kNumMeta / 2;
@@ -197,6 +205,11 @@ struct TileSolver64
   static constexpr int kGainRows = MM + MM * N;
   static constexpr int kRingRows = kGainRows + N + MM;
   static constexpr int kRingDepth = 3;
+  //! doubles per slot of a ring entry: the rows of a slot are CONTIGUOUS (round 4) — the rolling lane reads them with immediate
+  //! offsets, two per instruction (with the rows G doubles apart every read had its own address: a multiply, an add and a
+  //! wait each — three quarters of a rollout timestep's instructions); twice an odd number: sixteen slots' 16-byte reads
+  //! cover the 64 banks once
+  static constexpr int kRingStride = 2 * ((((kRingRows + 1) / 2) % 2 == 1) ? (kRingRows + 1) / 2 : (kRingRows + 1) / 2 + 1);
   /** Per-instance workspace: the gains as records [T][k_i (m) | K_i (m n, column-major)] — a matrix wave writes the 105 doubles of
       an (instance, timestep) as one contiguous run; into the handle's tile-major kff / Kfb arrays the same stores would be 8 bytes
       each, 512 bytes apart (measured: 7 x the written bytes reach HBM). */
@@ -218,10 +231,11 @@ struct TileSolver64
   int G = 1; //!< instances per group
   int group_cap;
   int chunk_cap; //!< at most this many timesteps per pass of the model code (0: what fits; A/B measurements, tests)
+  int wide_cap; //!< 0: the later step sizes of a line search never ride along with the first one (A/B measurements, tests)
 
   NMPC_D TileSolver64(const Problem & p, const nmpc_hip_ddp_config & c, const DeviceBuffers & bf, double * lds_base, int cap)
   : problem(p), cfg(c), buf(bf), T(bf.T), wave(static_cast<int>(threadIdx.x) >> 6), lane(static_cast<int>(threadIdx.x) & 63),
-    lds(lds_base), group_cap(cap & 0xffff), chunk_cap((cap >> 16) & 0xffff)
+    lds(lds_base), group_cap(cap & 0xffff), chunk_cap((cap >> 16) & 0x7fff), wide_cap(((cap >> 31) & 1) == 0 ? 1 : 0)
   {
   }
 
@@ -365,22 +379,57 @@ struct TileSolver64
   // ===================================================================================================
   /** Visits the record entries of the linearisation at (t, x, u) in canonical order. */
   template<class Sink>
-  NMPC_D static void emitRecord(const Problem & p, double t, const StateDimVector & x, const InputDimVector & u, Sink & sink)
+  NMPC_D static void emitRecord(const Problem & p, double t, const StateDimVector & x, const InputDimVector & u, int m, Sink & sink)
   {
     StateStateDimMatrix Fx, Lxx;
     StateInputDimMatrix Fu, Lxu;
     StateDimVector Lx;
     InputDimVector Lu;
     InputInputDimMatrix Luu;
+    if constexpr(kDyn)
+    {
+      // run-time input dimension m = inputDim(t) (u has m entries): the blocks' entries beyond m are stored as zeros — the
+      // matrix waves then compute on m x m / m x n blocks padded with zeros, and skip the pivots >= m
+      Fu.resize(N, m);
+      Lxu.resize(N, m);
+      Lu.resize(m);
+      Luu.resize(m, m);
+    }
     p.calcStateEqDeriv(t, x, u, Fx, Fu);
     p.calcRunningCostDeriv(t, x, u, Lx, Lu, Lxx, Luu, Lxu);
+    // Which entries are structural zeros must not depend on m (writer and readers share ONE offset table, and what the compiler
+    // can prove about an entry changes with what it knows about m: with no input the total force of the centroidal problem is the
+    // constant 0, with sixteen it is not).  So with a run-time input dimension the entries are CLASSIFIED on an evaluation of the
+    // functors at the full dimension — of which nothing but what the compiler knows about its results survives (dead code, as the
+    // table probe's arithmetic is) — and their VALUES come from the evaluation at m above.
+    StateStateDimMatrix Fx_c, Lxx_c;
+    StateInputDimMatrix Fu_c, Lxu_c;
+    StateDimVector Lx_c;
+    InputDimVector Lu_c;
+    InputInputDimMatrix Luu_c;
+    if constexpr(kDyn)
+    {
+      InputDimVector u_c;
+      u_c.resize(MM);
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        u_c[a] = opaque(u[a]);
+      }
+      Fu_c.resize(N, MM);
+      Lxu_c.resize(N, MM);
+      Lu_c.resize(MM);
+      Luu_c.resize(MM, MM);
+      p.calcStateEqDeriv(t, x, u_c, Fx_c, Fu_c);
+      p.calcRunningCostDeriv(t, x, u_c, Lx_c, Lu_c, Lxx_c, Luu_c, Lxu_c);
+    }
 #pragma unroll
     for(int c = 0; c < N; c++)
     {
 #pragma unroll
       for(int r = 0; r < N; r++)
       {
-        sink.put(Fx(r, c));
+        emitEntry(sink, kDyn ? Fx_c(r, c) : Fx(r, c), true, Fx(r, c));
       }
     }
 #pragma unroll
@@ -389,7 +438,7 @@ struct TileSolver64
 #pragma unroll
       for(int r = 0; r < N; r++)
       {
-        sink.put(Fu(r, a));
+        emitEntry(sink, kDyn ? Fu_c(r, a) : Fu(r, a), a < m, Fu(r, a));
       }
     }
 #pragma unroll
@@ -398,7 +447,7 @@ struct TileSolver64
 #pragma unroll
       for(int r = 0; r < N; r++)
       {
-        sink.put(Lxx(r, c));
+        emitEntry(sink, kDyn ? Lxx_c(r, c) : Lxx(r, c), true, Lxx(r, c));
       }
     }
 #pragma unroll
@@ -407,7 +456,7 @@ struct TileSolver64
 #pragma unroll
       for(int a = 0; a < MM; a++)
       {
-        sink.put(Lxu(c, a));
+        emitEntry(sink, kDyn ? Lxu_c(c, a) : Lxu(c, a), a < m, Lxu(c, a));
       }
     }
 #pragma unroll
@@ -416,24 +465,24 @@ struct TileSolver64
 #pragma unroll
       for(int a = 0; a < MM; a++)
       {
-        sink.put(Luu(a, c));
+        emitEntry(sink, kDyn ? Luu_c(a, c) : Luu(a, c), a < m && c < m, Luu(a, c));
       }
     }
 #pragma unroll
     for(int r = 0; r < N; r++)
     {
-      sink.put(Lx[r]);
+      emitEntry(sink, kDyn ? Lx_c[r] : Lx[r], true, Lx[r]);
     }
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
-      sink.put(Lu[a]);
+      emitEntry(sink, kDyn ? Lu_c[a] : Lu[a], a < m, Lu[a]);
     }
     double un = 0;
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
-      un += u[a] * u[a];
+      un += dynEntry(a < m, u[a] * u[a]);
     }
     const double unorm = (M == 1) ? fabs(u[0]) : sqrt(un);
     sink.putVar(recipFast(unorm + 1.0));
@@ -444,6 +493,45 @@ struct TileSolver64
       {
         sink.putVar(u[a]);
       }
+    }
+    if constexpr(kDyn)
+    {
+      sink.putVar(static_cast<double>(m));
+    }
+  }
+  /** One entry to the sink: static input dimension — the entry as it is (a structural zero is not stored, a constant once per
+      sweep); run-time input dimension — classified by `canonical` (see emitRecord), stored every time, zero outside the dimension. */
+  template<class Sink>
+  NMPC_D static void emitEntry(Sink & sink, double canonical, bool inside, double v)
+  {
+    if constexpr(kDyn)
+    {
+      sink.putClassified(canonical, inside ? v : 0.0);
+    }
+    else
+    {
+      (void)canonical;
+      (void)inside;
+      sink.put(v);
+    }
+  }
+  /** A value the compiler knows nothing about. */
+  NMPC_D static double opaque(double v)
+  {
+    asm("" : "+v"(v));
+    return v;
+  }
+  /** An entry of a block whose size follows the run-time input dimension: zero outside (static dimension: the entry as it is —
+      a structural zero stays one). */
+  NMPC_D static double dynEntry(bool inside, double v)
+  {
+    if constexpr(kDyn)
+    {
+      return inside ? v : 0.0;
+    }
+    else
+    {
+      return v;
     }
   }
   /** A structural zero: the compiler knows the value, and it is zero. */
@@ -470,6 +558,10 @@ struct TileSolver64
     {
       tbl[id++] = static_cast<unsigned short>(++cnt);
     }
+    NMPC_D void putClassified(double canonical, double)
+    {
+      put(canonical);
+    }
   };
   /** kFull = false: entries the compiler knows to be constants (the literal ones of the Jacobians, weights of a shared
       problem object) are not written again — the record slot holds them from the sweep's first two (full) timesteps. */
@@ -492,6 +584,13 @@ struct TileSolver64
     NMPC_D void putVar(double v)
     {
       rec[++cnt] = v;
+    }
+    NMPC_D void putClassified(double canonical, double v)
+    {
+      if(!structuralZero(canonical))
+      {
+        rec[++cnt] = v;
+      }
     }
   };
 
@@ -537,7 +636,25 @@ struct TileSolver64
     {
       sink.rec[0] = 0.0; // the zero word
     }
-    emitRecord(mine, t0 + i * mine.dt(), x, u, sink);
+    const double t = t0 + i * mine.dt();
+    const int m = inputDimOf(mine, t);
+    if constexpr(kDyn)
+    {
+      u.resize(m);
+    }
+    emitRecord(mine, t, x, u, m, sink);
+  }
+  /** inputDim(t) of a run-time input dimension (DDPSolver.hpp:381), the static one otherwise. */
+  NMPC_D static int inputDimOf(const Problem & mine, double t)
+  {
+    if constexpr(kDyn)
+    {
+      return mine.inputDim(t);
+    }
+    else
+    {
+      return MM;
+    }
   }
   /** [Vxx | Vx] of the terminal cost (:177-185, :346-365) -> term(slot), column-major n x (n + 1). */
   NMPC_D void lineariseTerminal(const Problem & mine, int slot, int b, int sel, double t0) const
@@ -576,7 +693,7 @@ struct TileSolver64
   // One barrier per timestep; both roles run stagedPass() with the same barrier count.
   NMPC_D double * ring(int i) const
   {
-    return lds + kRecAt + (i % kRingDepth) * (kRingRows * G);
+    return lds + kRecAt + (i % kRingDepth) * (kRingStride * G);
   }
   /** What a prefetching lane keeps for a whole pass: it serves ONE slot (p_lane % G) and every (p_count / G)-th row of it, so
       everything that depends on the slot is computed once. */
@@ -604,10 +721,10 @@ struct TileSolver64
     pl.pU = buf.U + ((tile * 2 + sel) * rows_u) * 64 + ln;
     return pl;
   }
-  /** Prefetch role: this lane's rows of timestep i -> ring(i): element (row, slot) at row * G + slot. */
+  /** Prefetch role: this lane's rows of timestep i -> ring(i): element (row, slot) at slot * kRingStride + row. */
   NMPC_D void prefetchNominal(const PrefetchLane & pl, int i) const
   {
-    double * dst = ring(i) + pl.slot;
+    double * dst = ring(i) + pl.slot * kRingStride;
     constexpr int kBatch = (kRingRows + 13) / 14 < 10 ? (kRingRows + 13) / 14 : 10; // loads in flight per lane: a whole timestep's
                                                                                     // share when seven waves prefetch 32 slots
     for(int r0 = pl.row0; r0 < kRingRows; r0 += pl.row_step * kBatch)
@@ -624,7 +741,7 @@ struct TileSolver64
         const double * base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
         const int per_step = (is_k || is_K) ? kGainRows : (is_x ? N * 64 : MM * 64); // gains: records; x, u: tile-major rows
         const int r = is_k ? row : (is_K ? row - MM : (is_x ? (row - kGainRows) * 64 : (row - kGainRows - N) * 64));
-        at[k] = ok ? row * G : -1;
+        at[k] = ok ? row : -1;
         v[k] = 0;
         if(ok)
         {
@@ -640,6 +757,23 @@ struct TileSolver64
         }
       }
     }
+  }
+  /** runningCost and stateEq at (x, u[0 .. m)). */
+  NMPC_D static void evalModel(const Problem & mine, double t, const StateDimVector & x, const double * uv, int m, double & c,
+                               StateDimVector & x_next)
+  {
+    InputDimVector u;
+    if constexpr(kDyn)
+    {
+      u.resize(m);
+    }
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      u[a] = uv[a];
+    }
+    c = mine.runningCost(t, x, u);
+    x_next = mine.stateEq(t, x, u);
   }
   /** One pass over the horizon, every wave of the workgroup together (T + 2 barriers).
       compute = false: this lane prefetches for the ring (p_lane of p_count; nothing to do in an initial pass).
@@ -690,41 +824,42 @@ struct TileSolver64
       {
         const int i = j - 2;
         const double t = t0 + i * mine.dt();
-        InputDimVector u;
+        const int m = inputDimOf(mine, t); // (run-time input dimension: the rows beyond it are zeros, in U and in the gains)
+        double u[MM];
         if(initial)
         {
 #pragma unroll
           for(int a = 0; a < MM; a++)
           {
-            u[a] = Uin[(static_cast<size_t>(i) * MM + a) * 64];
+            u[a] = dynEntry(a < m, Uin[(static_cast<size_t>(i) * MM + a) * 64]);
           }
         }
         else
         {
-          const double * R = ring(i) + inst;
+          const double * R = ring(i) + inst * kRingStride;
           if(i == 0)
           {
 #pragma unroll
             for(int c = 0; c < N; c++)
             {
-              x[c] = R[(kGainRows + c) * G]; // x'_0 = x_0    :541
+              x[c] = R[kGainRows + c]; // x'_0 = x_0    :541
             }
           }
           double s[MM];
 #pragma unroll
           for(int a = 0; a < MM; a++)
           {
-            u[a] = R[(kGainRows + N + a) * G] + alpha * R[a * G]; // u_i + alpha k_i    :545
+            u[a] = R[kGainRows + N + a] + alpha * R[a]; // u_i + alpha k_i    :545
             s[a] = 0;
           }
 #pragma unroll
           for(int c = 0; c < N; c++)
           {
-            const double dxc = x[c] - R[(kGainRows + c) * G];
+            const double dxc = x[c] - R[kGainRows + c];
 #pragma unroll
             for(int a = 0; a < MM; a++)
             {
-              s[a] += R[(MM + a + c * MM) * G] * dxc;
+              s[a] += R[MM + a + c * MM] * dxc;
             }
             if(MM * N > 64 && (c & 1) == 1)
             {
@@ -734,10 +869,34 @@ struct TileSolver64
 #pragma unroll
           for(int a = 0; a < MM; a++)
           {
-            u[a] = u[a] + s[a]; // ... + K_i (x'_i - x_i)    :546
+            u[a] = dynEntry(a < m, u[a] + s[a]); // ... + K_i (x'_i - x_i)    :546
           }
         }
-        const double c = mine.runningCost(t, x, u);
+        // the problem's functors see an input of inputDim(t) entries.  A run-time dimension that is the full one, or none, is
+        // given to them as a CONSTANT (three copies of their code): loops over u.size() then unroll, and what they index
+        // stays in registers — with a run-time trip count the centroidal problem's stance tables went to private memory,
+        // 15 k cycles per rollout timestep
+        double c;
+        StateDimVector x_next;
+        if constexpr(kDyn)
+        {
+          if(m == MM)
+          {
+            evalModel(mine, t, x, u, MM, c, x_next);
+          }
+          else if(m == 0)
+          {
+            evalModel(mine, t, x, u, 0, c, x_next);
+          }
+          else
+          {
+            evalModel(mine, t, x, u, m, c, x_next);
+          }
+        }
+        else
+        {
+          evalModel(mine, t, x, u, MM, c, x_next);
+        }
         if(store)
         {
 #pragma unroll
@@ -745,7 +904,7 @@ struct TileSolver64
           {
             Xo[(static_cast<size_t>(i) * N + cc) * 64] = x[cc];
           }
-          if(!initial)
+          if(!initial || kDyn) // (run-time input dimension: the initial pass zeroes the rows of U beyond inputDim(t))
           {
 #pragma unroll
             for(int a = 0; a < MM; a++)
@@ -756,7 +915,7 @@ struct TileSolver64
           Co[static_cast<size_t>(i) * 64] = c;
         }
         J += c;
-        x = mine.stateEq(t, x, u);
+        x = x_next;
       }
       const unsigned long long pb = profNow();
       profAdd(compute ? 5 : 7, pb - pa, compute ? 0 : 1);
@@ -792,7 +951,7 @@ struct TileSolver64
   /** What a matrix lane knows for the whole kernel: where its entries of a record are (offsets in doubles). */
   struct LaneMap
   {
-    int oFx[4], oFu[4], oLxx[4], oLxuT[KM], oLuu[KM], oLx, oLu, oInvU, oU[kConstrained ? MM : 1];
+    int oFx[4], oFu[4], oLxx[4], oLxuT[KM], oLuu[KM], oLx, oLu, oInvU, oU[kConstrained ? MM : 1], oM;
     double wn, wt; //!< weights of (Vn, Vn^T) in the new [Vxx | Vx]: (1/2, 1/2) inside the n x n block, (1, 0) in column n
   };
   NMPC_D LaneMap makeLaneMap() const
@@ -858,6 +1017,7 @@ struct TileSolver64
     {
       mp.oU[0] = 0;
     }
+    mp.oM = kDyn ? t[kDyn ? idM : 0] : 0;
     mp.wn = (j < N) ? 0.5 : ((j == N) ? 1.0 : 0.0);
     mp.wt = (j < N) ? 0.5 : 0.0;
     return mp;
@@ -955,7 +1115,7 @@ struct TileSolver64
     v4d64 VV; //!< [Vxx | Vx] in natural layout (in / out)
     v4d64 Qxx, Qux, Quu, QuxR, QuuF, qxcol, A, Vn;
     double qxrow, qurow, inv_u;
-    double fac[MM * MM], inv_d[MM], col[MM], colQ[MM];
+    double fac[kBig ? 1 : MM * MM], inv_d[kBig ? 1 : MM], col[kBig ? 1 : MM], colQ[kBig ? 1 : MM]; // (per-lane factorisation, m <= 8)
     double c1nn, t2nn, krel_i; //!< k^T Quu k, k^T Qu, |k| / (|u| + 1) of this timestep (lane kStarLane)
     bool ok; //!< no factorisation of this sweep has failed yet (in / out)
   };
@@ -1234,10 +1394,41 @@ struct TileSolver64
   }
   /** Phase 3b: A = [K | k], QQ = [Qux | Qu] in natural layout; the cost-to-go (:522-527) up to the symmetrisation; rows of the new
       value function to the scratch.  Branch-free. */
-  NMPC_D void stepValueUpdate(StepCtx & c, double * W) const
+  NMPC_D void stepValueUpdate(StepCtx & c, double * W, int m) const
   {
     const int fl = freshLane(), q = fl >> 4, j = fl & 15;
     v4d64 QQ = {0, 0, 0, 0};
+    double kn = 0; // |k|^2 (lanes of column n hold k)    :217-221
+    if constexpr(kBig)
+    {
+      if(m > 0)
+      {
+        stepGainsNatural(c, W, m, QQ);
+      }
+      else
+      {
+        // no input at this timestep (:513-517): k, K empty, the value function is [Qxx | Qx]
+        c.A = v4d64{0, 0, 0, 0};
+#pragma unroll
+        for(int rr = 0; rr < 4; rr++)
+        {
+          const int row = 4 * rr + q;
+          const double qx_c = fromLane(c.qxrow, 16 * qN + (row & 15));
+          c.qxcol[rr] = (j == N && row < N) ? qx_c : 0.0;
+        }
+      }
+      fence(); // (the scratch is written again below)
+      // |k|^2: the entries of k are spread over the four lane groups of column n
+#pragma unroll
+      for(int rr = 0; rr < KM; rr++)
+      {
+        kn += c.A[rr] * c.A[rr];
+      }
+      kn += fromLane(kn, fl ^ 16);
+      kn += fromLane(kn, fl ^ 32);
+    }
+    else
+    {
     c.A = v4d64{0, 0, 0, 0};
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
@@ -1254,6 +1445,12 @@ struct TileSolver64
       c.A[rr] = (j <= N) ? gq : 0.0;
       QQ[rr] = (j < N) ? c.Qux[rr] : ((j == N) ? cq : 0.0); // (column n of colQ is Qu; unregularised Qux elsewhere)
     }
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      kn += c.col[a] * c.col[a];
+    }
+    }
     const v4d64 Z = mma<KM>(c.Quu, c.A);
     const v4d64 C1 = mma<KM>(Z, c.A);
     const v4d64 T2 = mma<KM>(c.A, QQ);
@@ -1267,15 +1464,14 @@ struct TileSolver64
     c.Vn[rN] = (q == qN) ? 0.0 : c.Vn[rN]; // row n: k^T (...), not part of the value function
     c.c1nn = C1[rN]; // lane kStarLane: k^T Quu k, k^T Qu    :522-523
     c.t2nn = T2[rN];
-    double kn = 0; // |k| / (|u| + 1)    :217-221   (lanes of column n hold k)
-#pragma unroll
-    for(int a = 0; a < MM; a++)
-    {
-      kn += c.col[a] * c.col[a];
-    }
+    // |k| / (|u| + 1)    :217-221
     // m > 1: the SQUARE of the ratio — the maximum over the horizon commutes with the square root, which the model wave takes
     // once per sweep instead of every matrix lane once per timestep (twenty instructions of a step's eight hundred)
     c.krel_i = kKrelSquared ? kn * (c.inv_u * c.inv_u) : fabs(c.col[0]) * c.inv_u;
+    if constexpr(kDyn)
+    {
+      c.krel_i = (m > 0) ? c.krel_i : 0.0; // (the reference skips the timesteps without input, :220)
+    }
     // Vxx <- (Vxx + Vxx^T) / 2: rows to the scratch, columns back (phase 4)
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
@@ -1302,6 +1498,159 @@ struct TileSolver64
     *dv1 += 0.5 * c.c1nn;
     *kr = fmax(*kr, c.krel_i);
   }
+  // ---------------------------------------------------------------------------------------------------
+  // gains in natural layout (kBig: m > 8 or inputDim(t))    :500-517
+  // ---------------------------------------------------------------------------------------------------
+  // Sixteen by sixteen doubles do not fit a lane's registers, so nobody holds the whole factor: Quu_F and the right-hand sides
+  // [Qux_reg | Qu] stay where the matrix cores left them — register r of lane (q, c) = entry (4 r + q, c) — and the L D L^T runs
+  // right-looking over the wave: for pivot j the normalised column j reaches the lanes of its rows by a DPP row broadcast
+  // (row_newbcast: lane j of every 16-lane row), the entry (j, c) of the pivot row reaches the lanes of column c through the
+  // LDS crossbar (ds_bpermute, no memory), and the trailing block gets its rank-one update A_ik -= (L_ij L_kj) d_j — the
+  // association of the lane kernels' ldltInPlace — in at most four instructions per lane.  Both triangles of the trailing block
+  // are kept (the updates are symmetric bit for bit), which is what makes the mirrored entry (j, c) available as L_cj d_j.
+  // The forward substitution rides on the same broadcasts; the backward substitution runs column by column (axpy form).
+  // Pivots >= m (run-time input dimension) are skipped: the blocks are padded with zeros.  ~50 instructions per pivot.
+  /** The value of lane `src` (0 .. 63, any expression) — through the LDS crossbar. */
+  NMPC_D static double fromLane(double v, int src)
+  {
+    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+  }
+  /** The value of lane J of this lane's 16-lane row. */
+  template<int J>
+  NMPC_D static double fromRowLane(double v)
+  {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false); // row_newbcast:J
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
+  /** The value of lane `src` (a constant) in every lane, as a wave-uniform value. */
+  NMPC_D static double fromLaneUniform(double v, int src)
+  {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+  }
+  /** Pivot J of the factorisation and of the forward substitution (see above). */
+  template<int J>
+  NMPC_D static void naturalPivot(v4d64 & Aq, v4d64 & R, v4d64 & invd, bool & ok, int q, int col)
+  {
+    constexpr int rj = J / 4, qj = J % 4;
+    const double d = fromLaneUniform(Aq[rj], 16 * qj + J);
+    ok = ok && !(d <= 0.0); // the pivot rule of Eigen's LLT (fails iff a pivot is <= 0, NaN passes)
+    const double r = recipFast(d);
+    invd[rj] = (q == qj) ? r : invd[rj];
+    const double ajc = fromLane(Aq[rj], 16 * qj + col); // entry (j, c) = L_cj d_j of this lane's column
+    const double yj = fromLane(R[rj], 16 * qj + col); // y_j of this lane's right-hand side
+    const double lc = (col > J) ? ajc * r : 0.0; // L_cj; columns <= j are finished: they receive - 0
+#pragma unroll
+    for(int rr = rj; rr < KM; rr++)
+    {
+      double lrow = fromRowLane<J>(Aq[rr] * r); // L_ij of this lane's row i = 4 rr + q
+      if(rr == rj)
+      {
+        lrow = (q > qj) ? lrow : 0.0; // rows <= j are finished
+      }
+      Aq[rr] -= (lrow * lc) * d;
+      R[rr] -= lrow * yj;
+    }
+  }
+  /** Column K of the backward substitution: x_K is final, the rows above it receive - L_Ki x_K. */
+  template<int K>
+  NMPC_D static void naturalBackColumn(const v4d64 & Ln, v4d64 & R, int q, int col)
+  {
+    constexpr int rk = K / 4, qk = K % 4;
+    const double xk = fromLane(R[rk], 16 * qk + col);
+#pragma unroll
+    for(int rr = 0; rr <= rk; rr++)
+    {
+      double l = fromRowLane<K>(Ln[rr]); // entry (i, K) d_i^-1 = L_Ki of this lane's row i
+      if(rr == rk)
+      {
+        l = (q < qk) ? l : 0.0;
+      }
+      R[rr] -= l * xk;
+    }
+  }
+  template<int J>
+  NMPC_D static void naturalForward(v4d64 & Aq, v4d64 & R, v4d64 & invd, bool & ok, int q, int col, int m)
+  {
+    if constexpr(J < MM)
+    {
+      if(J < m)
+      {
+        naturalPivot<J>(Aq, R, invd, ok, q, col);
+      }
+      naturalForward<J + 1>(Aq, R, invd, ok, q, col, m);
+    }
+  }
+  template<int K>
+  NMPC_D static void naturalBackward(const v4d64 & Ln, v4d64 & R, int q, int col, int m)
+  {
+    if constexpr(K >= 1)
+    {
+      if(K < m)
+      {
+        naturalBackColumn<K>(Ln, R, q, col);
+      }
+      naturalBackward<K - 1>(Ln, R, q, col, m);
+    }
+  }
+  /** Phases 1c - 3b for kBig: A = [K | k] = - Quu_F^-1 [Qux_reg | Qu] (zero for m = 0: :513-517), then the value update's operands.
+      W: the wave's transposition scratch (the lower triangle of Quu_F is mirrored through it: the reference's LLT reads the
+      lower triangle only, :500). */
+  NMPC_D void stepGainsNatural(StepCtx & c, double * W, int m, v4d64 & QQ) const
+  {
+    const int fl = freshLane(), q = fl >> 4, col = fl & 15;
+    // Quu_F <- its lower triangle, mirrored
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      W[wT + (4 * rr + q) * kTrLd + col] = c.QuuF[rr];
+    }
+    fence();
+    v4d64 Aq = {0, 0, 0, 0}, R = {0, 0, 0, 0}, invd = {1, 1, 1, 1};
+    QQ = v4d64{0, 0, 0, 0};
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      const int row = 4 * rr + q;
+      const double mirrored = W[wT + col * kTrLd + row]; // entry (col, row)
+      Aq[rr] = (row >= col) ? c.QuuF[rr] : mirrored;
+      // Qu, Qx from a row of lanes (lane group qN: entry j in lane j) to column n of the tiles
+      const double qu_c = fromLane(c.qurow, 16 * qN + (row & 15));
+      R[rr] = (col < N) ? c.QuxR[rr] : ((col == N) ? qu_c : 0.0);
+      QQ[rr] = (col < N) ? c.Qux[rr] : ((col == N) ? qu_c : 0.0);
+    }
+    fence();
+#pragma unroll
+    for(int rr = 0; rr < 4; rr++)
+    {
+      const int row = 4 * rr + q;
+      const double qx_c = fromLane(c.qxrow, 16 * qN + (row & 15));
+      c.qxcol[rr] = (col == N && row < N) ? qx_c : 0.0;
+    }
+    bool ok_now = true;
+    naturalForward<0>(Aq, R, invd, ok_now, q, col, m);
+    // D^-1, then L^T x = z column by column
+    v4d64 Ln = {0, 0, 0, 0};
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      R[rr] = R[rr] * invd[rr];
+      Ln[rr] = Aq[rr] * invd[rr];
+    }
+    naturalBackward<MM - 1>(Ln, R, q, col, m);
+    c.A = v4d64{0, 0, 0, 0};
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      c.A[rr] = (4 * rr + q < m && col <= N) ? -1 * R[rr] : 0.0;
+    }
+    c.ok = c.ok && ok_now;
+  }
+
   /** k_i, K_i -> the instance's gain record (:529-530); not after a failed factorisation: backwardPass() returned before storing (:505-508). */
   NMPC_D void stepStoreGains(const StepCtx & c, int b, int i) const
   {
@@ -1339,19 +1688,27 @@ struct TileSolver64
     {
       stepRegType1(c, lambda);
     }
-    stepExchangeWrite(c, W);
-    fence();
-    stepExchangeRead(c, W);
-    fence();
-    if constexpr(kConstrained)
+    int m = MM;
+    if constexpr(kDyn)
     {
-      stepGainsBoxQP(c, mp, r, W, slot, b, i);
+      m = uniform(static_cast<int>(r[mp.oM])); // inputDim(t_i), from the record (the model wave evaluated it)
     }
-    else
+    if constexpr(!kBig)
     {
-      stepGains(c);
+      stepExchangeWrite(c, W);
+      fence();
+      stepExchangeRead(c, W);
+      fence();
+      if constexpr(kConstrained)
+      {
+        stepGainsBoxQP(c, mp, r, W, slot, b, i);
+      }
+      else
+      {
+        stepGains(c);
+      }
     }
-    stepValueUpdate(c, W);
+    stepValueUpdate(c, W, m);
     fence();
     stepFinish(c, mp, W, slot);
     fence();
@@ -1544,12 +1901,18 @@ struct TileSolver64
       }
       const Problem mine = problemOf(0);
       TableSink sink{tbl()};
-      emitRecord(mine, buf.t0 ? buf.t0[0] : 0.0, x, u, sink);
+      const double t_probe = buf.t0 ? buf.t0[0] : 0.0;
+      const int m_probe = inputDimOf(mine, t_probe);
+      if constexpr(kDyn)
+      {
+        u.resize(m_probe);
+      }
+      emitRecord(mine, t_probe, x, u, m_probe, sink);
       int s = sink.cnt + 1; // + the zero word
       s |= 1; // odd: the model wave's lanes (one record each) spread over the LDS banks
       const int room = kLdsDoubles - kRecAt;
       int per_instance = (2 * s > kTerm) ? 2 * s : kTerm;
-      per_instance = (per_instance > kRingDepth * kRingRows) ? per_instance : kRingDepth * kRingRows; // (line search: nominal ring)
+      per_instance = (per_instance > kRingDepth * kRingStride) ? per_instance : kRingDepth * kRingStride; // (line search: nominal ring)
       int g = room / per_instance;
       g = g > kT64MaxGroup ? kT64MaxGroup : g;
       // every workgroup gets work, and the same amount: rounds = passes a workgroup makes over its groups with the largest group
@@ -1662,6 +2025,11 @@ struct TileSolver64
       slotT(sTicksBw, slot) = 0;
       slotT(sTicksFw, slot) = 0;
       clearTrace(slot);
+      if(lane == 0)
+      {
+        meta(mWide) = 0;
+        meta(mRejected) = 0;
+      }
     }
     barrier();
 
@@ -1790,6 +2158,11 @@ struct TileSolver64
         if(lane == 0)
         {
           meta(mAnyLs) = (any != 0) ? 1 : 0;
+          // the later step sizes ride along with the first one when the waves that roll them out have a SIMD to themselves
+          // (three waves cover the group), or share it among themselves (six waves) and the group's previous search made
+          // a quarter of its slots go beyond the first step size: the pass then takes as long as two, and saves a third one
+          const int waves_needed = (G + laterPerWave() - 1) / laterPerWave();
+          meta(mWide) = (cfg.n_alpha > 1 && wide_cap != 0 && (waves_needed <= 3 || (waves_needed <= 6 && meta(mRejected) != 0))) ? 1 : 0;
         }
       }
       barrier(); // B4
@@ -1824,6 +2197,8 @@ struct TileSolver64
         };
         const int later_per_wave = laterPerWave();
         const int covered = later_per_wave * kT64MatrixWaves;
+        const bool wide = !first_trip && uniform(meta(mWide)) != 0;
+        const int spec_index = (wave >= 1 && wave <= 3) ? wave - 1 : ((wave >= 5) ? wave - 2 : -1);
         int pass = first_trip ? 0 : 1, trip_base = 0;
 #pragma nounroll
         for(;;)
@@ -1840,7 +2215,7 @@ struct TileSolver64
             pinst = slot;
             pt0 = slotF(sT0, slot);
           }
-          else if(pass != 2)
+          else if(pass != 2 && (model_wave || !(pass == 1 && wide)))
           {
             compute = model_wave;
             if(slot_lane && slotI(sLs, slot) != 0)
@@ -1855,14 +2230,17 @@ struct TileSolver64
           }
           else
           {
-            compute = !model_wave;
+            // pass 2 — or a wide pass 1: waves 1 - 3, then 5 - 7 roll out the later step sizes (wave 4, which shares its SIMD with
+            // the model wave, feeds the ring)
+            const int roll_index = (pass == 2) ? wave - 1 : spec_index;
+            compute = (pass == 2) ? !model_wave : (spec_index >= 0);
             store = false;
             if(compute)
             {
               const int n_later = cfg.n_alpha - 1;
               const int inst = lane / n_later;
               pai = 1 + lane - inst * n_later;
-              const int fslot = trip_base + (wave - 1) * later_per_wave + inst;
+              const int fslot = trip_base + roll_index * later_per_wave + inst;
               if(inst < later_per_wave && fslot < G && slotI(sB, fslot) >= 0 && slotI(sLs, fslot) != 0)
               {
                 active = true;
@@ -1875,8 +2253,9 @@ struct TileSolver64
             }
           }
           const Problem theirs = active ? problemOf(pb) : problem;
+          const bool lone_prefetcher = model_wave || (pass == 1 && wide); // (a wide pass 1: wave 4 alone feeds the ring)
           const double Jc = stagedPass(compute, pass == 0, theirs, active, group, pb, pinst, phalf, pt0, palpha, store,
-                                       model_wave ? lane : p_lane_matrix, model_wave ? 64 : p_count_matrix);
+                                       lone_prefetcher ? lane : p_lane_matrix, lone_prefetcher ? 64 : p_count_matrix);
           // ---- what follows from it
           if(pass == 0)
           {
@@ -1894,31 +2273,66 @@ struct TileSolver64
           }
           else if(pass == 1)
           {
+            if(wide)
+            {
+              if(!model_wave && active)
+              {
+                lsJ[pai * kT64MaxGroup + pinst] = Jc;
+              }
+              barrier(); // B5a: the later step sizes' costs are in lsJ
+            }
             if(slot_lane)
             {
               int flags = slotI(sFlags, slot);
-              bool more = false;
-              if((flags & fInLs) != 0)
+              const bool searching = (flags & fInLs) != 0;
+              bool more = false, reroll = false, rejected = false;
+              if(searching)
               {
-                const bool success = judge(0, Jc);
+                bool success = judge(0, Jc);
                 flags = success ? (flags | fSuccess) : flags;
-                more = !success && cfg.n_alpha > 1;
+                rejected = !success && cfg.n_alpha > 1;
+                if(rejected && wide)
+                {
+                  for(int ai = 1; ai < cfg.n_alpha && !success; ai++)
+                  {
+                    success = judge(ai, lsJ[ai * kT64MaxGroup + slot]);
+                  }
+                  if(success)
+                  {
+                    flags |= fSuccess;
+                    reroll = true; // its trajectory has not been stored yet
+                  }
+                }
+                else
+                {
+                  more = rejected;
+                }
                 slotI(sFlags, slot) = flags;
               }
-              slotI(sLs, slot) = more ? 1 : 0;
-              const unsigned long long any = __ballot(more);
+              slotI(sLs, slot) = (more || reroll) ? 1 : 0;
+              const unsigned long long any_more = __ballot(more), any_reroll = __ballot(reroll);
+              const int n_rejected = __popcll(__ballot(rejected)), n_searching = __popcll(__ballot(searching));
               if(lane == 0)
               {
-                meta(mAnyMore) = (any != 0) ? 1 : 0;
+                meta(mAnyMore) = (any_more != 0) ? 1 : 0;
+                meta(mAnyReroll) = (any_reroll != 0) ? 1 : 0;
+                meta(mRejected) = (n_rejected > 0 && 4 * n_rejected >= n_searching) ? 1 : 0;
               }
             }
             publishBarrier(); // B5: the candidate trajectory is in the other half of X / U / cost
-            if(uniform(meta(mAnyMore)) == 0)
+            if(uniform(meta(mAnyMore)) != 0)
+            {
+              pass = 2;
+              trip_base = 0;
+            }
+            else if(wide && uniform(meta(mAnyReroll)) != 0)
+            {
+              pass = 3;
+            }
+            else
             {
               break;
             }
-            pass = 2;
-            trip_base = 0;
           }
           else if(pass == 2)
           {
@@ -2053,9 +2467,10 @@ struct TileSolver64
       {
         buf.trace_last[(tile * NMPC_HIP_NTRACE + f) * 64 + ln] = trF(f, slot);
       }
+      const Problem mine_o = problemOf(b);
       for(int i = 0; i < T; i++)
       {
-        buf.input_dim[(tile * T + i) * 64 + ln] = M;
+        buf.input_dim[(tile * T + i) * 64 + ln] = inputDimOf(mine_o, slotF(sT0, slot) + i * mine_o.dt());
       }
     }
     barrier(); // the next group reuses the slot table and the record area
@@ -2145,7 +2560,12 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
   int chunk_cap = 0; // NMPC_HIP_DDP_TILE64_CHUNK=<c>: at most c timesteps per pass of the model code (1: round 3's schedule)
   if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_CHUNK"))
   {
-    chunk_cap = std::atoi(e) & 0xffff;
+    chunk_cap = std::atoi(e) & 0x7fff;
+  }
+  unsigned no_wide = 0; // NMPC_HIP_DDP_TILE64_WIDE=0: line search passes as in round 3 (first step size, then the later ones)
+  if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_WIDE"))
+  {
+    no_wide = (std::atoi(e) == 0) ? 1u : 0u;
   }
   int grid = cus;
   if(cap > 0)
@@ -2155,7 +2575,8 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
   }
   grid = buf.B < grid ? buf.B : grid;
   hipLaunchKernelGGL((ddp_solve_tile64_kernel<Problem, kConstrained, kOwnProblem>), dim3(grid), dim3(kT64Threads), 0, stream, problem,
-                     cfg, buf, cap | (chunk_cap << 16)); // (the kernel's 160 KB of LDS are a static array)
+                     cfg, buf, static_cast<int>(static_cast<unsigned>(cap) | (static_cast<unsigned>(chunk_cap) << 16) | (no_wide << 31)));
+  // (the kernel's 160 KB of LDS are a static array)
   return hipGetLastError();
 }
 } // namespace hip

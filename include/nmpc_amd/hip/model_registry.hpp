@@ -57,8 +57,11 @@ struct ModelOpsFor
   /** fp64 tile kernel (ddp_kernels_tile64.hpp: groups of up to 32 instances per workgroup, derivatives LDS-resident, backward
       pass on v_mfma_f64_16x16x4 in natural layout, BoxQP included): 5 <= n <= 15 with a static input dimension m <= 8.  It
       replaces the wave-per-instance kernel on these shapes; NMPC_HIP_DDP_KERNEL=wpi / 1w select the older kernels (A/B). */
-  static constexpr bool kTile64Shape = !Problem::kDynamicInput && Problem::kStateDim >= 5 && Problem::kStateDim <= 15
-                                       && Problem::kInputDimMax >= 1 && Problem::kInputDimMax <= 8;
+  static constexpr bool kTile64Shape = Problem::kStateDim >= 5 && Problem::kStateDim <= 15 && Problem::kInputDimMax >= 1
+                                       && Problem::kInputDimMax <= 16;
+  //! m > 8 or inputDim(t) (the reference's centroidal-motion problem, 16 / 0): the gains are computed in natural layout across
+  //! the wave (TileSolver64::stepGainsNatural, round 4); unconstrained solves only — their BoxQP stays on the lane kernel
+  static constexpr bool kTile64Big = kTile64Shape && (Problem::kDynamicInput || Problem::kInputDimMax > 8);
   //! Below this batch the wave-per-instance kernel is still the (marginally) faster one where both exist (n >= 9).  Until round
   //! 4 the threshold was 1025: a group's sweep could not go faster than its model wave linearises ONE timestep per pass
   //! (33 k cycles for the manipulator, whatever the group size).  The model wave now linearises a CHUNK of timesteps per pass
@@ -75,6 +78,10 @@ struct ModelOpsFor
     if(!kTile64Shape || (force && (std::strcmp(force, "1w") == 0 || std::strcmp(force, "wpi") == 0)))
     {
       return false;
+    }
+    if(kTile64Big)
+    {
+      return !constrained; // (every batch size: the wave-per-instance kernel takes these gains through LDS, 3 - 4 x slower)
     }
     if(force && std::strcmp(force, "tile64") == 0)
     {
@@ -188,13 +195,16 @@ struct ModelOpsFor
         {
           return hipErrorOutOfMemory; // the gain records live in the workspace (ModelOps::wpi_workspace_doubles)
         }
-        if(con && own)
+        if constexpr(!kTile64Big)
         {
-          return launchTile64<Problem, true, true>(problem, cfg, buf, stream);
-        }
-        if(con)
-        {
-          return launchTile64<Problem, true, false>(problem, cfg, buf, stream);
+          if(con && own)
+          {
+            return launchTile64<Problem, true, true>(problem, cfg, buf, stream);
+          }
+          if(con)
+          {
+            return launchTile64<Problem, true, false>(problem, cfg, buf, stream);
+          }
         }
         if(own)
         {

@@ -33,22 +33,25 @@ public:
     s.num = kRidgeNum;
     const double vertex_x[4] = {rect[0], rect[0], rect[2], rect[2]};
     const double vertex_y[4] = {rect[1], rect[3], rect[3], rect[1]};
+    // The four ridge directions (0.5 cos(theta), 0.5 sin(theta), 1) / |.| with theta = 2 pi ri / 4 do not depend on the foot:
+    // they are the constants the reference's expression evaluates to in double (tests/test_host_cpu.py checks them against
+    // libm).  Evaluated per call — every stateEq and every derivative builds its stance — they were sixteen cos / sin /
+    // sqrt / divisions of the device math library: ~12 k of the 15 k cycles of a rollout timestep on the tile kernel.
+    constexpr double kRidgeDir[4][3] = {{0x1.c9f25c5bfedd9p-2, 0x0p+0, 0x1.c9f25c5bfedd9p-1},
+                                        {0x1.f924f9f58fd97p-56, 0x1.c9f25c5bfedd9p-2, 0x1.c9f25c5bfedd9p-1},
+                                        {-0x1.c9f25c5bfedd9p-2, 0x1.f924f9f58fd97p-55, 0x1.c9f25c5bfedd9p-1},
+                                        {-0x1.7adbbb782be31p-54, -0x1.c9f25c5bfedd9p-2, 0x1.c9f25c5bfedd9p-1}};
     for(int vi = 0; vi < 4; vi++)
     {
       for(int ri = 0; ri < 4; ri++)
       {
-        const double theta = 2 * M_PI * (static_cast<double>(ri) / 4);
-        const double rx = 0.5 * cos(theta);
-        const double ry = 0.5 * sin(theta);
-        const double rz = 1;
-        const double len = sqrt((rx * rx + ry * ry) + rz * rz);
         const int col = vi * 4 + ri;
         s.vertices[0][col] = vertex_x[vi];
         s.vertices[1][col] = vertex_y[vi];
         s.vertices[2][col] = 0.0;
-        s.ridges[0][col] = rx / len;
-        s.ridges[1][col] = ry / len;
-        s.ridges[2][col] = rz / len;
+        s.ridges[0][col] = kRidgeDir[ri][0];
+        s.ridges[1][col] = kRidgeDir[ri][1];
+        s.ridges[2][col] = kRidgeDir[ri][2];
       }
     }
     return s;

@@ -740,6 +740,74 @@ def test_matrix_kernel_dispatch(monkeypatch):
         s.setInputLimits(np.full(prob.dims()[1], -1.0), np.full(prob.dims()[1], 1.0))
         assert s.kernelName() == "ddp_solve_wpi_kernel"
     assert nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem("planar_vtol"), 16).kernelName() == "ddp_solve_tile64_kernel"
+    # centroidal motion (n 9, inputDim(t) in {16, 0}): the tile kernel at every batch size (round 4: gains in natural layout);
+    # its box-constrained solves stay on the lane kernel
+    prob = nmpc_amd.make_problem("centroidal")
+    for batch in (1, 256, 4096):
+        assert nmpc_amd.DDPSolverBatch(prob, batch).kernelName() == "ddp_solve_tile64_kernel"
+    s = nmpc_amd.DDPSolverBatch(prob, 256)
+    s.config().with_input_constraint = True
+    s.setInputLimits(np.full(16, 0.0), np.full(16, 1e3))
+    assert s.kernelName() == "ddp_solve_tpi_kernel"
+
+
+@pytest.mark.parametrize("group,wide", [(32, True), (5, True), (None, True), (32, False)])
+@pytest.mark.parametrize("cfg", [dict(max_iter=10), dict(max_iter=6, reg_type=2),
+                                 dict(max_iter=6, alpha_list=np.array([1.0, 0.3, 0.1, 0.03]))])
+def test_centroidal_on_tile_kernel(cfg, group, wide, monkeypatch):
+    """The reference's largest model (TestDDPCentroidalMotion.cpp:24-204: n 9, inputDim(t) in {16, 0}) on the fp64 tile kernel: the
+    16 x 16 factorisation spread over the wave in natural layout (TileSolver64::stepGainsNatural), timesteps without input
+    (DDPSolver.hpp:513-517), full / ragged groups / one instance per workgroup, the later step sizes rolled out with the first
+    (wide) or after it.  Against the oracle at the bar of this file — reg_type 2 (Quu_F rebuilt from Vxx + lambda I: its smallest
+    eigenvalues are the input weight 1e-6, so the gains carry 1e-8 of rounding whatever the factorisation; the wave-per-instance
+    kernel differs from the oracle by the same 5e-9) with the gains at 1e-7 — and against the wave-per-instance kernel."""
+    from nmpc_amd import workloads
+    wl = workloads.centroidal_batch(B=96, T=100 if "reg_type" not in cfg else 60, seed=7)
+    _select_matrix_kernel(monkeypatch, "tile64", group)
+    if not wide:
+        monkeypatch.setenv("NMPC_HIP_DDP_TILE64_WIDE", "0")
+    s = make_solver(wl, **cfg)
+    assert s.kernelName() == "ddp_solve_tile64_kernel"
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle_batch(wl, **cfg)
+    loose = "reg_type" in cfg
+    check_against_oracle(wl, s, ref, check_gains=not loose)
+    if loose:
+        assert scaled_err(s.kff(), ref.k) <= 1e-7 and scaled_err(s.Kfb(), ref.K) <= 1e-7
+    dims = s.inputDimList()
+    assert set(np.unique(dims)) == {0, 16}
+    for b in range(0, wl.B, 13):
+        assert np.array_equal(dims[b], oracle.input_dims(wl.model, None, float(wl.t0[b]), wl.T))
+    assert np.all(s.U()[dims == 0] == 0.0)  # entries beyond inputDim(t) are zero
+    monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", "wpi")
+    s1 = make_solver(wl, **cfg)
+    assert s1.kernelName() == "ddp_solve_wpi_kernel"
+    s1.solve(wl.t0, wl.x0, wl.u_init)
+    assert np.array_equal(s.status(), s1.status()) and np.array_equal(s.iters(), s1.iters())
+    assert np.array_equal(s.trace()[..., INT_COLS], s1.trace()[..., INT_COLS])
+    for a, b in ((s.X(), s1.X()), (s.U(), s1.U()), (s.cost(), s1.cost())):
+        assert scaled_err(a, b) <= TOL
+
+
+def test_wide_first_pass_equals_separate_passes(monkeypatch):
+    """Line search of the tile kernel: the later step sizes rolled out WITH the first one (small groups always; full groups
+    after a search in which a quarter of the slots went beyond the first step size) or in a pass of their own — the same
+    rollouts on the same inputs, judged in list order (DDPSolver.hpp:242-265): every output bit for bit."""
+    from nmpc_amd import workloads
+    beyond_first = []
+    for wl, group, cfg in ((workloads.manipulator_batch(B=96, T=30, seed=5), 32, dict(max_iter=8, alpha_list=np.array([1.0, 0.05, 0.02, 0.01]))),
+                           (workloads.quadrotor_batch(B=40, T=50, seed=6), 8, dict(max_iter=10)),
+                           (workloads.centroidal_batch(B=64, T=100, seed=8), 32, dict(max_iter=8))):
+        out = []
+        for wide in ("1", "0"):
+            _select_matrix_kernel(monkeypatch, "tile64", group)
+            monkeypatch.setenv("NMPC_HIP_DDP_TILE64_WIDE", wide)
+            s = make_solver(wl, **cfg)
+            s.solve(wl.t0, wl.x0, wl.u_init)
+            out.append((s.status(), s.iters(), s.X(), s.U(), s.cost(), s.kff(), s.Kfb(), np.nan_to_num(s.trace(), nan=-7.0)))
+        assert all(np.array_equal(a, b) for a, b in zip(*out))
+        beyond_first.append(bool((out[0][7][:, 1:, 9] > 0).any()))
+    assert beyond_first[-1]  # (centroidal motion: most searches go beyond the first step size)
 
 
 def _large(model, B, seed):

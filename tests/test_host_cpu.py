@@ -278,3 +278,19 @@ def test_constant_limits_replace_a_limits_function_or_table():
     s._limits_horizon_dirty = False  # (as if pushed to a handle)
     s.setInputLimits(np.array([-3.0]), np.array([3.0]))
     assert s._limits_horizon is None and s._limits_horizon_dirty  # the device table has to be removed on the next push
+
+
+def test_centroidal_ridge_constants_match_libm():
+    """The friction-pyramid ridge directions the centroidal problem keeps as constants are what the reference's expression
+    (TestDDPCentroidalMotion.cpp:206-237: 0.5 cos / 0.5 sin of 2 pi ri / 4, normalised) evaluates to with libm."""
+    import math
+    text = open(os.path.join(ROOT, "include", "nmpc_amd", "models", "CentroidalMotion.hpp")).read()
+    block = text[text.index("kRidgeDir[4][3]"):]
+    block = block[:block.index("};")]
+    vals = [float.fromhex(v) for v in re.findall(r"-?0x[0-9a-f.]+p[+-]\d+", block)]
+    assert len(vals) == 12
+    for ri in range(4):
+        theta = 2 * math.pi * (ri / 4)
+        rx, ry = 0.5 * math.cos(theta), 0.5 * math.sin(theta)
+        ln = math.sqrt((rx * rx + ry * ry) + 1.0 * 1.0)
+        assert vals[3 * ri:3 * ri + 3] == [rx / ln, ry / ln, 1.0 / ln]

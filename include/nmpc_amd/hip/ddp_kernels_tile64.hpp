@@ -2199,6 +2199,7 @@ struct TileSolver64
         const int covered = later_per_wave * kT64MatrixWaves;
         const bool wide = !first_trip && uniform(meta(mWide)) != 0;
         const int spec_index = (wave >= 1 && wave <= 3) ? wave - 1 : ((wave >= 5) ? wave - 2 : -1);
+        const int waves_rolling = (G + later_per_wave - 1) / later_per_wave; // (a wide pass 1: <= 6)
         int pass = first_trip ? 0 : 1, trip_base = 0;
 #pragma nounroll
         for(;;)
@@ -2233,7 +2234,7 @@ struct TileSolver64
             // pass 2 — or a wide pass 1: waves 1 - 3, then 5 - 7 roll out the later step sizes (wave 4, which shares its SIMD with
             // the model wave, feeds the ring)
             const int roll_index = (pass == 2) ? wave - 1 : spec_index;
-            compute = (pass == 2) ? !model_wave : (spec_index >= 0);
+            compute = (pass == 2) ? !model_wave : (spec_index >= 0 && spec_index < waves_rolling);
             store = false;
             if(compute)
             {
@@ -2253,9 +2254,16 @@ struct TileSolver64
             }
           }
           const Problem theirs = active ? problemOf(pb) : problem;
-          const bool lone_prefetcher = model_wave || (pass == 1 && wide); // (a wide pass 1: wave 4 alone feeds the ring)
-          const double Jc = stagedPass(compute, pass == 0, theirs, active, group, pb, pinst, phalf, pt0, palpha, store,
-                                       lone_prefetcher ? lane : p_lane_matrix, lone_prefetcher ? 64 : p_count_matrix);
+          // who feeds the ring: all matrix waves (passes 1, 3), the model wave (pass 2); a wide pass 1: the matrix waves that
+          // do not roll out — wave 4 and, while three waves cover the group, waves 5 - 7
+          int p_lane = model_wave ? lane : p_lane_matrix, p_count = model_wave ? 64 : p_count_matrix;
+          if(pass == 1 && wide && !model_wave)
+          {
+            const int order = (wave == 4) ? 6 : spec_index; // 1 2 3 5 6 7 4
+            p_lane = (order - waves_rolling) * 64 + lane; // (the waves that roll out do not prefetch: compute is set)
+            p_count = (kT64MatrixWaves - waves_rolling) * 64;
+          }
+          const double Jc = stagedPass(compute, pass == 0, theirs, active, group, pb, pinst, phalf, pt0, palpha, store, p_lane, p_count);
           // ---- what follows from it
           if(pass == 0)
           {

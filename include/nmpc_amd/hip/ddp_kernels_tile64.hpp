@@ -60,7 +60,10 @@ typedef double v4d64 __attribute__((ext_vector_type(4)));
 constexpr int kT64Waves = 8; //!< wavefronts per workgroup: two per SIMD, 256 registers each
 constexpr int kT64Threads = kT64Waves * 64;
 constexpr int kT64MatrixWaves = kT64Waves - 1;
-constexpr int kT64MaxGroup = 32; //!< instances per group at most (lanes 0..31 of the model wave)
+//! Instances per group at most (lanes 0 .. 34 of the model wave; five per matrix wave).  A full chip's round is 256 x 32 = 8192
+//! instances; the three extra slots take batches up to 8960 in ONE round — 8200 instances were two rounds of 17-slot groups,
+//! 1.30 x the time of 8192 (profiles/r04a_tile64_chunk_ab.txt) — where the LDS holds the records (manipulator: 2 x 35 x 205 doubles).
+constexpr int kT64MaxGroup = 35;
 constexpr int kT64MaxPerWave = (kT64MaxGroup + kT64MatrixWaves - 1) / kT64MatrixWaves; //!< 5
 constexpr size_t kT64LdsBytes = 160 * 1024; //!< the whole LDS of a CU: one workgroup per CU
 
@@ -213,9 +216,26 @@ struct TileSolver64
   /** Per-instance workspace: the gains as records [T][k_i (m) | K_i (m n, column-major)] — a matrix wave writes the 105 doubles of
       an (instance, timestep) as one contiguous run; into the handle's tile-major kff / Kfb arrays the same stores would be 8 bytes
       each, 512 bytes apart (measured: 7 x the written bytes reach HBM). */
-  NMPC_HD static size_t workspaceDoubles(int T)
+  NMPC_HD static size_t gainDoubles(int T)
   {
     return static_cast<size_t>(T) * kGainRows;
+  }
+  //! Behind the gain records of the whole batch: the candidate trajectories of the LATER step sizes of a line search, one per
+  //! (instance, step size) as rows [x_0 .. x_T | u_0 .. u_T-1 | cost_0 .. cost_T] — what the lanes that roll them out for their
+  //! cost leave behind, so that a later step size that is taken is COPIED to the handle's arrays instead of rolled out again
+  //! (adoptCandidates; the default alpha_list: ten later step sizes — longer lists re-roll)
+  static constexpr int kScratchAlphas = 10;
+  NMPC_HD static size_t candDoubles(int T)
+  {
+    return static_cast<size_t>(T + 1) * N + static_cast<size_t>(T) * MM + static_cast<size_t>(T + 1);
+  }
+  NMPC_HD static size_t workspaceDoubles(int T)
+  {
+    return gainDoubles(T) + kScratchAlphas * candDoubles(T);
+  }
+  NMPC_D double * candidate(int b, int later_index) const
+  {
+    return buf.wpi_ws + static_cast<size_t>(buf.B) * gainDoubles(T) + (static_cast<size_t>(b) * kScratchAlphas + later_index) * candDoubles(T);
   }
   static constexpr int kLdsDoubles = static_cast<int>(kT64LdsBytes / sizeof(double));
   static_assert(kRecAt + 2 * (kNumIds + 2) <= kLdsDoubles && kRecAt + kTerm <= kLdsDoubles, "one instance must fit");
@@ -232,10 +252,12 @@ struct TileSolver64
   int group_cap;
   int chunk_cap; //!< at most this many timesteps per pass of the model code (0: what fits; A/B measurements, tests)
   int wide_cap; //!< 0: the later step sizes of a line search never ride along with the first one (A/B measurements, tests)
+  int adopt_cap; //!< 0: a later step size that is taken is rolled out again instead of copied from the workspace (A/B, tests)
 
   NMPC_D TileSolver64(const Problem & p, const nmpc_hip_ddp_config & c, const DeviceBuffers & bf, double * lds_base, int cap)
   : problem(p), cfg(c), buf(bf), T(bf.T), wave(static_cast<int>(threadIdx.x) >> 6), lane(static_cast<int>(threadIdx.x) & 63),
-    lds(lds_base), group_cap(cap & 0xffff), chunk_cap((cap >> 16) & 0x7fff), wide_cap(((cap >> 31) & 1) == 0 ? 1 : 0)
+    lds(lds_base), group_cap(cap & 0xffff), chunk_cap((cap >> 16) & 0x3fff), wide_cap(((cap >> 31) & 1) == 0 ? 1 : 0),
+    adopt_cap(((cap >> 30) & 1) == 0 ? 1 : 0)
   {
   }
 
@@ -715,7 +737,7 @@ struct TileSolver64
     const int sel = slotI(sSel, pl.slot);
     const size_t tile = pl.want ? tileOf(b) : 0, ln = pl.want ? lnOf(b) : 0;
     const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;
-    pl.pk = buf.wpi_ws + static_cast<size_t>(pl.want ? b : 0) * workspaceDoubles(T); // gain record of timestep 0
+    pl.pk = buf.wpi_ws + static_cast<size_t>(pl.want ? b : 0) * gainDoubles(T); // gain record of timestep 0
     pl.pK = pl.pk + MM;
     pl.pX = buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln;
     pl.pU = buf.U + ((tile * 2 + sel) * rows_u) * 64 + ln;
@@ -783,7 +805,7 @@ struct TileSolver64
       store: the trajectory goes to half out_half of X / U / cost (an initial pass leaves U as it is).
       Trip j of the loop: the prefetchers fetch timestep j, the rolling lanes compute timestep j - 2 (ring depth 3). */
   NMPC_D double stagedPass(bool compute, bool initial, const Problem & mine, bool active, int group, int b, int inst, int out_half,
-                           double t0, double alpha, bool store, int p_lane, int p_count) const
+                           double t0, double alpha, bool store, int p_lane, int p_count, int to_candidate = -1) const
   {
     double J = 0;
     StateDimVector x;
@@ -791,6 +813,7 @@ struct TileSolver64
     const double * Uin = nullptr;
     const bool rolling = compute && active;
     const PrefetchLane pl = makePrefetchLane(group, p_lane, p_count);
+    size_t ost = 64; // distance of consecutive rows at the destination (the handle's arrays are tile-major)
     if(rolling)
     {
       const size_t tile = tileOf(b), ln = lnOf(b);
@@ -798,6 +821,13 @@ struct TileSolver64
       Xo = buf.X + ((tile * 2 + out_half) * rows_x) * 64 + ln;
       Uo = buf.U + ((tile * 2 + out_half) * rows_u) * 64 + ln;
       Co = buf.cost + ((tile * 2 + out_half) * rows_c) * 64 + ln;
+      if(to_candidate >= 0)
+      {
+        Xo = candidate(b, to_candidate); // (rows contiguous: one run per lane and timestep)
+        Uo = Xo + rows_x;
+        Co = Uo + rows_u;
+        ost = 1;
+      }
       Uin = buf.U + ((tile * 2 + 0) * rows_u) * 64 + ln;
       if(initial)
       {
@@ -902,17 +932,17 @@ struct TileSolver64
 #pragma unroll
           for(int cc = 0; cc < N; cc++)
           {
-            Xo[(static_cast<size_t>(i) * N + cc) * 64] = x[cc];
+            Xo[(static_cast<size_t>(i) * N + cc) * ost] = x[cc];
           }
           if(!initial || kDyn) // (run-time input dimension: the initial pass zeroes the rows of U beyond inputDim(t))
           {
 #pragma unroll
             for(int a = 0; a < MM; a++)
             {
-              Uo[(static_cast<size_t>(i) * MM + a) * 64] = u[a];
+              Uo[(static_cast<size_t>(i) * MM + a) * ost] = u[a];
             }
           }
-          Co[static_cast<size_t>(i) * 64] = c;
+          Co[static_cast<size_t>(i) * ost] = c;
         }
         J += c;
         x = x_next;
@@ -930,13 +960,86 @@ struct TileSolver64
 #pragma unroll
         for(int cc = 0; cc < N; cc++)
         {
-          Xo[(static_cast<size_t>(T) * N + cc) * 64] = x[cc];
+          Xo[(static_cast<size_t>(T) * N + cc) * ost] = x[cc];
         }
-        Co[static_cast<size_t>(T) * 64] = cT;
+        Co[static_cast<size_t>(T) * ost] = cT;
       }
       J += cT;
     }
     return J;
+  }
+  /** The slots whose line search took a LATER step size (sLs set, sAi its index): its trajectory — left in the workspace by the
+      lane that rolled it out for its cost — goes to the other half of X / U / cost, where a re-roll (pass 3) would have put
+      the same bits.  Every wave of the workgroup.  Few slots: a slot at a time, thread = row (coalesced reads); many: lane =
+      slot, a wave per eighth of the rows, eight loads in flight (the writes are then whole runs of the tile-major arrays). */
+  NMPC_D void adoptCandidates(int group) const
+  {
+    const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM, rows_c = static_cast<size_t>(T + 1);
+    const size_t rows = rows_x + rows_u + rows_c;
+    int n_take = 0;
+    for(int k = 0; k < G; k++)
+    {
+      n_take += (slotI(sB, k) >= 0 && slotI(sLs, k) != 0) ? 1 : 0;
+    }
+    n_take = uniform(n_take);
+    auto destination = [&](int b, int half, size_t r) -> double *
+    {
+      const size_t tile = tileOf(b), ln = lnOf(b);
+      if(r < rows_x)
+      {
+        return buf.X + ((tile * 2 + half) * rows_x + r) * 64 + ln;
+      }
+      if(r < rows_x + rows_u)
+      {
+        return buf.U + ((tile * 2 + half) * rows_u + (r - rows_x)) * 64 + ln;
+      }
+      return buf.cost + ((tile * 2 + half) * rows_c + (r - rows_x - rows_u)) * 64 + ln;
+    };
+    if(n_take <= 4)
+    {
+      for(int k = 0; k < G; k++)
+      {
+        const int b = uniform(slotI(sB, k));
+        if(b < 0 || uniform(slotI(sLs, k)) == 0)
+        {
+          continue;
+        }
+        const int half = uniform(slotI(sSel, k)) ^ 1;
+        const double * src = candidate(b, uniform(slotI(sAi, k)) - 1);
+        for(size_t r = threadIdx.x; r < rows; r += kT64Threads)
+        {
+          *destination(b, half, r) = src[r];
+        }
+      }
+    }
+    else
+    {
+      const int k = lane < kT64MaxGroup ? lane : 0;
+      const bool mine = lane < kT64MaxGroup && k < G && slotI(sB, k) >= 0 && slotI(sLs, k) != 0;
+      const int b = mine ? slotI(sB, k) : 0;
+      const int half = mine ? (slotI(sSel, k) ^ 1) : 0;
+      const double * src = candidate(b, mine ? slotI(sAi, k) - 1 : 0);
+      constexpr int kInFlight = 8;
+      for(size_t r0 = static_cast<size_t>(wave); r0 < rows; r0 += static_cast<size_t>(kT64Waves) * kInFlight)
+      {
+        double v[kInFlight];
+#pragma unroll
+        for(int q = 0; q < kInFlight; q++)
+        {
+          const size_t r = r0 + static_cast<size_t>(q) * kT64Waves;
+          v[q] = (mine && r < rows) ? src[r] : 0.0;
+        }
+#pragma unroll
+        for(int q = 0; q < kInFlight; q++)
+        {
+          const size_t r = r0 + static_cast<size_t>(q) * kT64Waves;
+          if(mine && r < rows)
+          {
+            *destination(b, half, r) = v[q];
+          }
+        }
+      }
+    }
   }
   /** Trips of the second pass (later step sizes, lane = (slot, step size) on the matrix waves): slots covered per trip. */
   NMPC_D int laterPerWave() const
@@ -1999,7 +2102,7 @@ struct TileSolver64
   {
     const unsigned long long solve_start = __builtin_readcyclecounter();
     const bool model_wave = (wave == 0);
-    const int slot = lane & (kT64MaxGroup - 1);
+    const int slot = lane < kT64MaxGroup ? lane : 0;
     const int b = group * G + slot;
     const bool owner = model_wave && lane < G && b < buf.B; // this lane drives an instance
     const bool slot_lane = model_wave && lane < kT64MaxGroup;
@@ -2200,6 +2303,8 @@ struct TileSolver64
         const bool wide = !first_trip && uniform(meta(mWide)) != 0;
         const int spec_index = (wave >= 1 && wave <= 3) ? wave - 1 : ((wave >= 5) ? wave - 2 : -1);
         const int waves_rolling = (G + later_per_wave - 1) / later_per_wave; // (a wide pass 1: <= 6)
+        // the later step sizes' trajectories go to the workspace, and the one that is taken is copied from there (no pass 3)
+        const bool adopt = adopt_cap != 0 && cfg.n_alpha - 1 <= kScratchAlphas;
         int pass = first_trip ? 0 : 1, trip_base = 0;
 #pragma nounroll
         for(;;)
@@ -2263,7 +2368,9 @@ struct TileSolver64
             p_lane = (order - waves_rolling) * 64 + lane; // (the waves that roll out do not prefetch: compute is set)
             p_count = (kT64MatrixWaves - waves_rolling) * 64;
           }
-          const double Jc = stagedPass(compute, pass == 0, theirs, active, group, pb, pinst, phalf, pt0, palpha, store, p_lane, p_count);
+          const bool to_workspace = adopt && !store && compute && active; // (a later step size, rolled out for its cost)
+          const double Jc = stagedPass(compute, pass == 0, theirs, active, group, pb, pinst, phalf, pt0, palpha, store || to_workspace,
+                                       p_lane, p_count, to_workspace ? pai - 1 : -1);
           // ---- what follows from it
           if(pass == 0)
           {
@@ -2335,6 +2442,11 @@ struct TileSolver64
             }
             else if(wide && uniform(meta(mAnyReroll)) != 0)
             {
+              if(adopt)
+              {
+                adoptCandidates(group);
+                break;
+              }
               pass = 3;
             }
             else
@@ -2377,9 +2489,14 @@ struct TileSolver64
                 meta(mAnyReroll) = (any != 0) ? 1 : 0;
               }
             }
-            barrier(); // B5c
+            publishBarrier(); // B5c (the later step sizes' trajectories are in the workspace)
             if(uniform(meta(mAnyReroll)) == 0)
             {
+              break;
+            }
+            if(adopt)
+            {
+              adoptCandidates(group);
               break;
             }
             pass = 3;
@@ -2568,7 +2685,12 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
   int chunk_cap = 0; // NMPC_HIP_DDP_TILE64_CHUNK=<c>: at most c timesteps per pass of the model code (1: round 3's schedule)
   if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_CHUNK"))
   {
-    chunk_cap = std::atoi(e) & 0x7fff;
+    chunk_cap = std::atoi(e) & 0x3fff;
+  }
+  unsigned no_adopt = 0; // NMPC_HIP_DDP_TILE64_ADOPT=0: a later step size that is taken is re-rolled (round 3's pass 3)
+  if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_ADOPT"))
+  {
+    no_adopt = (std::atoi(e) == 0) ? 1u : 0u;
   }
   unsigned no_wide = 0; // NMPC_HIP_DDP_TILE64_WIDE=0: line search passes as in round 3 (first step size, then the later ones)
   if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_WIDE"))
@@ -2583,7 +2705,7 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
   }
   grid = buf.B < grid ? buf.B : grid;
   hipLaunchKernelGGL((ddp_solve_tile64_kernel<Problem, kConstrained, kOwnProblem>), dim3(grid), dim3(kT64Threads), 0, stream, problem,
-                     cfg, buf, static_cast<int>(static_cast<unsigned>(cap) | (static_cast<unsigned>(chunk_cap) << 16) | (no_wide << 31)));
+                     cfg, buf, static_cast<int>(static_cast<unsigned>(cap) | (static_cast<unsigned>(chunk_cap) << 16) | (no_wide << 31) | (no_adopt << 30)));
   // (the kernel's 160 KB of LDS are a static array)
   return hipGetLastError();
 }

@@ -69,7 +69,10 @@ struct ModelOpsFor
   //! are level up to 512 instances, the tile kernel ahead from there (scripts/tile64_chunk_ab.py,
   //! profiles/r04_tile64_chunk_ab.txt: manipulator 1.38 against 1.37 ms at 256, 1.41 / 1.42 at 512, 1.45 / 1.57 at 1024,
   //! 1.82 / 3.04 at 2048).
-  static constexpr int kTile64MinBatch = 257;
+  //! Round 4, second half (the later step sizes ride along with the first, slot-major ring): ahead from 64 instances on
+  //! (profiles/r04*_tile64_chunk_ab.txt: manipulator tile64 / wave-per-instance 1.07 at 16 instances, 0.96 at 64, 0.91 at 256,
+  //! 0.31 at 8192; quadrotor 0.96 / 0.89 / 0.81 / 0.40).
+  static constexpr int kTile64MinBatch = 64;
   //! box-constrained solves: round 3's threshold (the QP dominates their timestep; small batches have not been re-measured)
   static constexpr int kTile64MinBatchBoxQP = 1025;
   static bool useTile64(bool constrained, int batch)
@@ -111,9 +114,14 @@ struct ModelOpsFor
   }
   static size_t wpiWorkspaceDoubles(int T)
   {
-    if constexpr(kWpiShape)
+    if constexpr(kWpiShape && kTile64Shape)
     {
-      return WaveSolver<Problem>::workspaceDoubles(T); // (>= the tile kernel's gain records)
+      const size_t a = WaveSolver<Problem>::workspaceDoubles(T), b = TileSolver64<Problem>::workspaceDoubles(T);
+      return a > b ? a : b;
+    }
+    else if constexpr(kWpiShape)
+    {
+      return WaveSolver<Problem>::workspaceDoubles(T);
     }
     else if constexpr(kTile64Shape)
     {

@@ -65,7 +65,12 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
   const S * Us = buf.U + ((tile * 2 + sel) * rows_u) * LW + lane; // control_data_.u_list
   S * U0 = buf.U + ((tile * 2 + 0) * rows_u) * LW + lane; // initial_u_list of the next solve
   S * x0 = static_cast<S *>(args.x0) + (tile * N) * LW + lane;
-  const S t = static_cast<S *>(args.t0)[b];
+  // current_t lives in DOUBLE whatever the problem's scalar: an fp32 handle's t0 array holds its rounding, the exact value rides
+  // in the time log from tick to tick (row tick + 1 is written below) — accumulated in float, sim_dt = 0.01 at t ~ 100 s is
+  // 1e-3 relative per step off.  Double handles: the same additions as before, bit for bit.
+  const double t_exact = (args.tick == 0 || args.t_log == nullptr) ? static_cast<double>(static_cast<S *>(args.t0)[b])
+                                                                    : args.t_log[static_cast<size_t>(b) * args.n_ticks + args.tick];
+  const S t = static_cast<S>(t_exact);
   const int m0 = buf.input_dim[(tile * T + 0) * LW + lane];
   const size_t log_at = static_cast<size_t>(b) * args.n_ticks + args.tick;
 
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
   }
   if(args.t_log)
   {
-    args.t_log[log_at] = t;
+    args.t_log[log_at] = t_exact;
   }
   if(args.x_log)
   {
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
     args.m0_log[log_at] = m0;
   }
 
-  S t_next = t;
+  double t_next = t_exact;
   if(args.shift_warm_start)
   {
     for(int j = 0; j < N; j++)
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
       const S keep = Us[(static_cast<size_t>(T - 1) * MM + a) * LW];
       U0[(static_cast<size_t>(T - 1) * MM + a) * LW] = (last_m == term_m) ? keep : S(0);
     }
-    t_next = t + problem.dt();
+    t_next = t_exact + static_cast<double>(problem.dt());
   }
   else
   {
@@ -156,8 +161,8 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
     {
       for(int s = 0; s < args.sim_substeps; s++)
       {
-        x = problem.stateEq(t_next, x, u0, static_cast<S>(args.sim_dt));
-        t_next += static_cast<S>(args.sim_dt);
+        x = problem.stateEq(static_cast<S>(t_next), x, u0, static_cast<S>(args.sim_dt));
+        t_next += args.sim_dt;
       }
     }
     for(int j = 0; j < N; j++)
@@ -172,7 +177,11 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
       }
     }
   }
-  static_cast<S *>(args.t0)[b] = t_next;
+  static_cast<S *>(args.t0)[b] = static_cast<S>(t_next);
+  if(args.t_log && args.tick + 1 < args.n_ticks)
+  {
+    args.t_log[static_cast<size_t>(b) * args.n_ticks + args.tick + 1] = t_next;
+  }
 }
 } // namespace hip
 } // namespace nmpc_amd

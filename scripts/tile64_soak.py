@@ -14,7 +14,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 
 def solver(model, B, T, kernel):
     os.environ["NMPC_HIP_DDP_KERNEL"] = kernel
-    wl = workloads.quadrotor_batch(B=B, T=T, seed=1234) if model == "quadrotor" else workloads.manipulator_batch(B=B, T=T, seed=1234)
+    wl = {"quadrotor": workloads.quadrotor_batch, "manipulator": workloads.manipulator_batch,
+          "centroidal": workloads.centroidal_batch}[model](B=B, T=T, seed=1234)
     s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B)
     c = s.config()
     c.print_level = 0
@@ -24,7 +25,8 @@ def solver(model, B, T, kernel):
 
 
 bad_total = 0
-for model, T, B in (("manipulator", 30, 8192), ("quadrotor", 50, 8192), ("manipulator", 30, 3000)):
+for model, T, B in (("manipulator", 30, 8192), ("quadrotor", 50, 8192), ("manipulator", 30, 3000), ("centroidal", 100, 1024),
+                    ("centroidal", 100, 300)):
     wl, s = solver(model, B, T, "tile64")  # tile kernel first: nothing has touched the device before
     first = None
     n_bad = 0

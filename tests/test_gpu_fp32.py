@@ -462,7 +462,9 @@ def test_receding_horizon_driver():
         np.testing.assert_array_equal(log.iters[:, k], h.iters())
         x = X[:, 1].copy()
         u = np.concatenate([U[:, 1:], U[:, -1:]], axis=1)
-        t = (t.astype(np.float32) + np.float32(wl.dt)).astype(np.float64)
+        t = t + np.float64(np.float32(wl.dt))  # current_t advances in double by the problem's (float) dt; rounded at ingest
+    t_expected = np.concatenate([[0.0], np.cumsum(np.full(ticks - 1, np.float64(np.float32(wl.dt))))])  # (sequential additions)
+    np.testing.assert_array_equal(log.t, np.broadcast_to(t_expected, (wl.B, ticks)))
     ocfg = oracle.default_config(horizon_steps=wl.T, max_iter=5, cost_update_thre=FP32_COST_UPDATE_THRE)
     for b in (0, 17, 39):
         r = oracle.mpc_run("quadrotor", ocfg, wl.x0[b], ticks, shift_warm_start=True)

@@ -719,17 +719,18 @@ def _select_matrix_kernel(monkeypatch, kernel, group=None):
 
 
 def test_matrix_kernel_dispatch(monkeypatch):
-    """Default dispatch of the 9 <= n <= 15 shapes: the tile kernel for unconstrained batches above 256 instances (round 4: its
-    model wave linearises a chunk of timesteps per pass, which took its small-batch latency from 2.2 to 1.4 ms — level with the
-    wave-per-instance kernel up to 512 instances, ahead beyond: 3 x at 8192), the wave-per-instance kernel below and for
-    box-constrained solves with more than four inputs or up to 1024 instances; 5 <= n <= 8 always on the tile kernel."""
+    """Default dispatch of the 9 <= n <= 15 shapes: the tile kernel for unconstrained batches from 64 instances on (round 4: its
+    model wave linearises a chunk of timesteps per pass and the later step sizes of a line search ride along with the first,
+    which took its small-batch latency from 2.2 to 1.3 ms — ahead of the wave-per-instance kernel from 64 instances on, 3 x at
+    8192), the wave-per-instance kernel below and for box-constrained solves with more than four inputs or up to 1024
+    instances; 5 <= n <= 8 and centroidal motion always on the tile kernel."""
     import nmpc_amd
     monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
     for model in ("quadrotor", "manipulator"):
         prob = nmpc_amd.make_problem(model)
         assert nmpc_amd.DDPSolverBatch(prob, 8192).kernelName() == "ddp_solve_tile64_kernel"
-        assert nmpc_amd.DDPSolverBatch(prob, 257).kernelName() == "ddp_solve_tile64_kernel"
-        assert nmpc_amd.DDPSolverBatch(prob, 256).kernelName() == "ddp_solve_wpi_kernel"
+        assert nmpc_amd.DDPSolverBatch(prob, 64).kernelName() == "ddp_solve_tile64_kernel"
+        assert nmpc_amd.DDPSolverBatch(prob, 63).kernelName() == "ddp_solve_wpi_kernel"
         s = nmpc_amd.DDPSolverBatch(prob, 8192)
         s.config().with_input_constraint = True
         s.setInputLimits(np.full(prob.dims()[1], -1.0), np.full(prob.dims()[1], 1.0))
@@ -789,6 +790,37 @@ def test_centroidal_on_tile_kernel(cfg, group, wide, monkeypatch):
         assert scaled_err(a, b) <= TOL
 
 
+@pytest.mark.parametrize("running_u, lambda_max", [(-1e-4, None), (-1e-2, 1e-3)])
+def test_centroidal_pivot_failures_on_tile_kernel(running_u, lambda_max, monkeypatch):
+    """A negative input weight makes Quu_F non-positive until lambda has grown (DDPSolver.hpp:196-204): the natural-layout
+    factorisation of the tile kernel must fail at the same pivots' timesteps as the oracle's LLT — same retry counts, lambda
+    schedule and final status; with lambda_max = 1e-3 every instance ends at -1.  (A failing sweep computes on garbage behind
+    the failed pivot and stores nothing: the next sweep starts from the terminal cost again.)"""
+    import nmpc_amd
+    from nmpc_amd import workloads
+    wl = workloads.centroidal_batch(B=48, T=60, seed=11)
+    _select_matrix_kernel(monkeypatch, "tile64", 32)
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.DDPProblemCentroidalMotion(running_u=running_u), wl.B)
+    assert s.kernelName() == "ddp_solve_tile64_kernel"
+    cfg = dict(max_iter=4) if lambda_max is None else dict(max_iter=4, lambda_max=lambda_max)
+    c = s.config()
+    c.print_level = 0
+    c.horizon_steps = wl.T
+    for k, v in cfg.items():
+        setattr(c, k, v)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    ref = oracle.solve_batch("centroidal", oracle.default_config(horizon_steps=wl.T, **cfg), wl.x0, wl.u_init, t0=wl.t0,
+                             params=oracle.default_params("centroidal", running_u=running_u), n_threads=8)
+    np.testing.assert_array_equal(s.status(), ref.status)
+    np.testing.assert_array_equal(s.iters(), ref.iters)
+    np.testing.assert_array_equal(s.traceLast()[:, INT_COLS], ref.trace_last[:, INT_COLS])
+    if lambda_max is None:
+        assert (s.trace()[:, 1:, 10] > 1).any()  # regularisation retries happened
+        assert scaled_err(s.X(), ref.X) <= TOL and scaled_err(s.U(), ref.U) <= TOL
+    else:
+        assert (ref.status == -1).all()
+
+
 def test_wide_first_pass_equals_separate_passes(monkeypatch):
     """Line search of the tile kernel: the later step sizes rolled out WITH the first one (small groups always; full groups
     after a search in which a quarter of the slots went beyond the first step size) or in a pass of their own — the same
@@ -796,18 +828,23 @@ def test_wide_first_pass_equals_separate_passes(monkeypatch):
     from nmpc_amd import workloads
     beyond_first = []
     for wl, group, cfg in ((workloads.manipulator_batch(B=96, T=30, seed=5), 32, dict(max_iter=8, alpha_list=np.array([1.0, 0.05, 0.02, 0.01]))),
-                           (workloads.quadrotor_batch(B=40, T=50, seed=6), 8, dict(max_iter=10)),
+                           (workloads.quadrotor_batch(B=40, T=50, seed=6), 8, dict(max_iter=14, k_rel_norm_thre=0.0, cost_update_thre=-1e300)),
                            (workloads.centroidal_batch(B=64, T=100, seed=8), 32, dict(max_iter=8))):
         out = []
-        for wide in ("1", "0"):
+        # ... and a later step size that is taken: copied from the workspace, where the lane that rolled it out for its cost
+        # left its trajectory (adopt = 1), or rolled out once more (round 3's pass 3)
+        for wide, adopt in (("1", "1"), ("1", "0"), ("0", "1"), ("0", "0")):
             _select_matrix_kernel(monkeypatch, "tile64", group)
             monkeypatch.setenv("NMPC_HIP_DDP_TILE64_WIDE", wide)
+            monkeypatch.setenv("NMPC_HIP_DDP_TILE64_ADOPT", adopt)
             s = make_solver(wl, **cfg)
             s.solve(wl.t0, wl.x0, wl.u_init)
             out.append((s.status(), s.iters(), s.X(), s.U(), s.cost(), s.kff(), s.Kfb(), np.nan_to_num(s.trace(), nan=-7.0)))
-        assert all(np.array_equal(a, b) for a, b in zip(*out))
+        for other in out[1:]:
+            assert all(np.array_equal(a, b) for a, b in zip(out[0], other))
         beyond_first.append(bool((out[0][7][:, 1:, 9] > 0).any()))
-    assert beyond_first[-1]  # (centroidal motion: most searches go beyond the first step size)
+    # (forced iterations of a converged quadrotor solve back-track through the list; centroidal motion: most searches do)
+    assert beyond_first[1] and beyond_first[2]
 
 
 def _large(model, B, seed):

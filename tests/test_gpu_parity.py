@@ -853,14 +853,15 @@ def _large(model, B, seed):
         workloads.manipulator_batch(B=B, T=30, seed=seed)
 
 
-@pytest.mark.parametrize("kernel,group", [("tile64", 32), ("tile64", 5), ("tile64", None), ("wpi", None)])
+@pytest.mark.parametrize("kernel,group", [("tile64", 32), ("tile64", 35), ("tile64", 5), ("tile64", None), ("wpi", None)])
 @pytest.mark.parametrize("model", ["quadrotor", "manipulator"])
 @pytest.mark.parametrize("cfg", [dict(max_iter=10), dict(max_iter=10, reg_type=2),
                                  dict(max_iter=6, alpha_list=np.array([1.0, 0.3, 0.1, 0.03]))])
 def test_wave_per_instance_kernel_vs_oracle_and_lane_kernel(model, cfg, kernel, group, monkeypatch):
     """The matrix-core kernels against the oracle (bar of this file) and against the lane-per-instance kernel, which
     evaluates the same arithmetic up to the association of a few sums: identical discrete decisions, values to rounding.
-    tile64 with full groups (32 slots: five per matrix wave), ragged groups (5) and one instance per workgroup."""
+    tile64 with full groups (32 slots; 35: the most a group takes, five per matrix wave), ragged groups (5) and one instance per
+    workgroup."""
     wl = _large(model, 96, 77)
     _select_matrix_kernel(monkeypatch, kernel, group)
     s = make_solver(wl, **cfg)
@@ -880,11 +881,12 @@ def test_wave_per_instance_kernel_vs_oracle_and_lane_kernel(model, cfg, kernel, 
 
 
 @pytest.mark.parametrize("kernel", ["tile64", "wpi"])
-@pytest.mark.parametrize("model,B", [("quadrotor", 8192), ("manipulator", 8192)])
+@pytest.mark.parametrize("model,B", [("quadrotor", 8192), ("manipulator", 8192), ("manipulator", 8200)])
 def test_wave_per_instance_kernel_full_size(model, B, kernel, monkeypatch):
     """BASELINE.json configs 4 / 5 at their per-GPU batch (fp64): a sample of instances against the oracle, and
     size-independent properties on all of them — the solve is a fixed point (re-solving from its own solution with
-    max_iter = 1 changes nothing beyond rounding), costs are monotone along the trace."""
+    max_iter = 1 changes nothing beyond rounding), costs are monotone along the trace.  8200 instances: one round of 33-slot
+    groups on the tile kernel (a group takes up to 35)."""
     wl = _large(model, B, 1234)
     _select_matrix_kernel(monkeypatch, kernel)
     s = make_solver(wl, max_iter=6)

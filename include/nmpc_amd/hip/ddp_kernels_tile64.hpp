@@ -189,8 +189,9 @@ struct TileSolver64
   static constexpr int wExchange = wX + 16;
   static constexpr int kTrLd = 17; //!< leading dimension of the transposition scratch: conflict-free both ways
   static constexpr int wT = 0;
-  static constexpr int wZero = (wExchange > 16 * kTrLd ? wExchange : 16 * kTrLd); //!< two zeros, read by lanes outside a block
-  static constexpr int wDump = wZero + 2; //!< written by lanes outside a block
+  static constexpr int wZero = (wExchange > 16 * kTrLd ? wExchange : 16 * kTrLd); //!< sixteen zeros, read by lanes outside a block
+                                                                                   //!< (with the immediate offsets of the lanes inside)
+  static constexpr int wDump = wZero + 16; //!< written by lanes outside a block
   static constexpr int kWaveDoubles = wDump + 2;
   static constexpr int kScratchPerWave = 1;
   static constexpr int kLsAt = kWaveAt + kT64MatrixWaves * kScratchPerWave * kWaveDoubles; //!< lsJ[NMPC_HIP_MAX_ALPHA][32]: cost of every trial
@@ -1363,6 +1364,47 @@ struct TileSolver64
       c.QuuF[rr] = (4 * rr + q == j) ? c.Quu[rr] + lambda : c.Quu[rr];
     }
   }
+  /** The per-lane LDS addresses of a step's exchange / transposition accesses, computed ONCE per sweep: byte offsets from the
+      workgroup's LDS array, two per register (the wave scratch lies in the first 64 KB).  Recomputed per step from the lane id
+      they were 80 of a quadrotor step's 330 VALU instructions (shifts, multiplies, compares and selects for the masked
+      ones); kept as eight unpacked registers across the step the register allocator spilled them (see freshLane).  A step
+      unpacks what it needs (one instruction per address) behind an opaque copy, so the packed form is what stays live. */
+  struct LaneAddr
+  {
+    unsigned ew_equ; //!< exchange write: this lane's column, row q | Qu -> column n (or the dump word)
+    unsigned eqx_rq; //!< Qx -> its column (or the dump word) | exchange read: this lane's column of [Qux_reg | Qu]
+    unsigned rx_tw; //!< Qx column read (lanes of column n; the zero words elsewhere) | transposition write: row q, column j
+    unsigned tr_trn; //!< transposition read-back: rows 4 r + q < 4 rN of column j (zero words outside) | row 4 rN + q (q < qN)
+  };
+  NMPC_D static unsigned pack2(int lo_doubles, int hi_doubles)
+  {
+    return static_cast<unsigned>(lo_doubles * 8) | (static_cast<unsigned>(hi_doubles * 8) << 16);
+  }
+  NMPC_D LaneAddr makeLaneAddr() const
+  {
+    const int q = lane >> 4, j = lane & 15;
+    const int w0 = kWaveAt + ((wave - 1) * kScratchPerWave) * kWaveDoubles; // index of the wave's scratch in the LDS array
+    static_assert((kWaveAt + kT64MatrixWaves * kScratchPerWave * kWaveDoubles) * 8 < 65536, "the wave scratch lies in the first 64 KB");
+    LaneAddr la;
+    la.ew_equ = pack2(w0 + kColLd * j + q, (q == qN && j < MM) ? w0 + wQQ + kColLd * N + j : w0 + wDump);
+    la.eqx_rq = pack2((q == qN && j < N) ? w0 + wX + 4 * (j & 3) + (j >> 2) : w0 + wDump, w0 + wQQ + kColLd * ((j < N) ? j : N));
+    la.rx_tw = pack2((j == N) ? w0 + wX + 4 * q : w0 + wZero, w0 + wT + q * kTrLd + j);
+    la.tr_trn = pack2((j < N) ? w0 + wT + j * kTrLd + q : w0 + wZero, (q < qN && j < N) ? w0 + wT + j * kTrLd + 4 * rN + q : w0 + wZero);
+    return la;
+  }
+  /** The double at byte offset `at` of the LDS array. */
+  NMPC_D double & ldsAt(unsigned at) const
+  {
+    return *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + at);
+  }
+  NMPC_D static unsigned lo16(unsigned p)
+  {
+    return p & 0xffffu;
+  }
+  NMPC_D static unsigned hi16(unsigned p)
+  {
+    return p >> 16;
+  }
   /** The lane id as a value the compiler cannot hoist computations on out of the timestep loop.  The per-lane LDS addresses of
       the exchange / transposition are a handful of integer operations on it; computed once per sweep they are ~10 more
       registers live across the whole step, which the register allocator spilled — and reloaded one by one behind a vmcnt(0)
@@ -1375,11 +1417,10 @@ struct TileSolver64
   }
   /** Phase 1c: column exchange through the wave's scratch W, write side: lane (., c) will get column c of [Qux_reg | Qu],
       every lane Quu_F; Qx goes from a row of lanes to a column. */
-  NMPC_D void stepExchangeWrite(const StepCtx & c, double * W) const
+  NMPC_D void stepExchangeWrite(const StepCtx & c, const LaneAddr & la) const
   {
-    const int fl = freshLane(), q = fl >> 4, j = fl & 15;
     static_assert(kColLd <= 9 && kColLd >= 4 * KM, "columns of the exchange area");
-    double * Wc = W + kColLd * j + q; // this lane's column, row q
+    double * Wc = &ldsAt(lo16(la.ew_equ)); // this lane's column, row q
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
@@ -1387,13 +1428,12 @@ struct TileSolver64
       Wc[wF + 4 * rr] = c.QuuF[rr];
     }
     fence(); // column n of the area is Qu's: written after the (padding) rows the lanes of column n have just put there
-    W[(q == qN && j < MM) ? wQQ + kColLd * N + j : wDump] = c.qurow;
-    W[(q == qN && j < N) ? wX + 4 * (j & 3) + (j >> 2) : wDump] = c.qxrow;
+    ldsAt(hi16(la.ew_equ)) = c.qurow; // (lane group qN, j < m: column n of [Qux_reg | Qu]; the other lanes: the dump word)
+    ldsAt(lo16(la.eqx_rq)) = c.qxrow; // (lane group qN, j < n)
   }
   /** Phase 2: ... read side. */
-  NMPC_D void stepExchangeRead(StepCtx & c, const double * W) const
+  NMPC_D void stepExchangeRead(StepCtx & c, const double * W, const LaneAddr & la) const
   {
-    const int fl = freshLane(), q = fl >> 4, j = fl & 15;
 #pragma unroll
     for(int cc = 0; cc < MM; cc++)
     {
@@ -1403,18 +1443,19 @@ struct TileSolver64
         c.fac[a + cc * MM] = (kConstrained || a >= cc) ? W[wF + kColLd * cc + a] : 0.0; // (the factorisation reads the lower triangle)
       }
     }
-    const int jc = (j < N) ? j : N;
+    const double * col_j = &ldsAt(hi16(la.eqx_rq)); // column min(j, n) of [Qux_reg | Qu]
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
-      c.colQ[a] = W[wQQ + kColLd * jc + a];
+      c.colQ[a] = col_j[a];
       c.inv_d[a] = 0;
     }
-    // Qx as column n of the accumulator of the value update: lane (q, n) register r <- Qx[4 r + q]
+    // Qx as column n of the accumulator of the value update: lane (q, n) register r <- Qx[4 r + q] (the other lanes: zero words)
+    const double * qx = &ldsAt(lo16(la.rx_tw));
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
-      c.qxcol[rr] = W[(j == N) ? wX + 4 * q + rr : wZero];
+      c.qxcol[rr] = qx[rr];
     }
   }
   /** Phase 3a, unconstrained: every lane factorises Quu_F, lane (., c) solves column c    :500-517.  Branch-free. */
@@ -1497,7 +1538,7 @@ struct TileSolver64
   }
   /** Phase 3b: A = [K | k], QQ = [Qux | Qu] in natural layout; the cost-to-go (:522-527) up to the symmetrisation; rows of the new
       value function to the scratch.  Branch-free. */
-  NMPC_D void stepValueUpdate(StepCtx & c, double * W, int m) const
+  NMPC_D void stepValueUpdate(StepCtx & c, double * W, int m, const LaneAddr & la) const
   {
     const int fl = freshLane(), q = fl >> 4, j = fl & 15;
     v4d64 QQ = {0, 0, 0, 0};
@@ -1576,21 +1617,33 @@ struct TileSolver64
       c.krel_i = (m > 0) ? c.krel_i : 0.0; // (the reference skips the timesteps without input, :220)
     }
     // Vxx <- (Vxx + Vxx^T) / 2: rows to the scratch, columns back (phase 4)
+    double * row_q = &ldsAt(hi16(la.rx_tw)); // entry (q, j) of the transposition scratch
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
-      W[wT + (4 * rr + q) * kTrLd + j] = c.Vn[rr];
+      row_q[4 * rr * kTrLd] = c.Vn[rr];
     }
   }
   /** Phase 4: the symmetrised value function; dV and the running max of |k| / (|u| + 1) in the slot table (lane kStarLane; the
       other lanes update a dump word: no branch). */
-  NMPC_D void stepFinish(StepCtx & c, const LaneMap & mp, double * W, int slot) const
+  NMPC_D void stepFinish(StepCtx & c, const LaneMap & mp, double * W, int slot, const LaneAddr & la) const
   {
-    const int fl = freshLane(), q = fl >> 4, j = fl & 15;
+    const int fl = freshLane();
+    // entry (j, 4 r + q) of the scratch where it belongs to the n x n block (the zero words elsewhere): rows < 4 rN from one
+    // address with immediate offsets, row 4 rN + q from its own, the rows behind are outside the block
+    const double * col_j = &ldsAt(lo16(la.tr_trn));
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
-      const double vt = W[(4 * rr + q < N && j < N) ? wT + j * kTrLd + 4 * rr + q : wZero];
+      double vt = 0.0;
+      if(rr < rN)
+      {
+        vt = col_j[4 * rr];
+      }
+      else if(rr == rN && qN > 0)
+      {
+        vt = ldsAt(hi16(la.tr_trn));
+      }
       c.VV[rr] = mp.wn * c.Vn[rr] + mp.wt * vt;
     }
     const bool star = fl == kStarLane;
@@ -1775,9 +1828,12 @@ struct TileSolver64
 
   /** One timestep of one instance.  VV = [Vxx | Vx] in natural layout (in / out), r = the instance's record of this timestep,
       ok = no factorisation of this sweep has failed yet (in / out).  Everything but the lane id is wave-uniform. */
-  NMPC_D void backwardStep(v4d64 & VV, bool & ok, const LaneMap & mp, const double * r, int slot, int b, int i, double lambda) const
+  NMPC_D void backwardStep(v4d64 & VV, bool & ok, const LaneMap & mp, const LaneAddr & la_sweep, const double * r, int slot, int b, int i,
+                           double lambda) const
   {
     double * W = waveScratch(0);
+    LaneAddr la = la_sweep;
+    asm volatile("" : "+v"(la.ew_equ), "+v"(la.eqx_rq), "+v"(la.rx_tw), "+v"(la.tr_trn)); // (unpacked here, not once per sweep)
     StepCtx c;
     c.VV = VV;
     c.ok = ok;
@@ -1798,9 +1854,9 @@ struct TileSolver64
     }
     if constexpr(!kBig)
     {
-      stepExchangeWrite(c, W);
+      stepExchangeWrite(c, la);
       fence();
-      stepExchangeRead(c, W);
+      stepExchangeRead(c, W, la);
       fence();
       if constexpr(kConstrained)
       {
@@ -1811,9 +1867,9 @@ struct TileSolver64
         stepGains(c);
       }
     }
-    stepValueUpdate(c, W, m);
+    stepValueUpdate(c, W, m, la);
     fence();
-    stepFinish(c, mp, W, slot);
+    stepFinish(c, mp, W, slot, la);
     fence();
     stepStoreGains(c, b, i);
     VV = c.VV;
@@ -1831,6 +1887,7 @@ struct TileSolver64
   {
     static_assert(kT64MaxPerWave == 5, "the rotations below are written for five slots per wave");
     const LaneMap mp = makeLaneMap();
+    const LaneAddr la = makeLaneAddr();
     const int q = lane >> 4, j = lane & 15;
     const int mw = wave - 1;
     const int n_act = uniform(meta(mNAct)), chunk = uniform(meta(mChunk));
@@ -1883,7 +1940,7 @@ struct TileSolver64
           {
             const int slot = uniform(actSlot(a));
             bool ok = ((ok_mask >> e) & 1u) != 0;
-            backwardStep(V0, ok, mp, recAt(parity, hi - i, a, chunk, n_act), slot, uniform(slotI(sB, slot)), i,
+            backwardStep(V0, ok, mp, la, recAt(parity, hi - i, a, chunk, n_act), slot, uniform(slotI(sB, slot)), i,
                          uniformD(slotF(sLambda, slot)));
             ok_mask = ok ? ok_mask : (ok_mask & ~(1u << e));
             profAdd(4, 1, 1);
@@ -2603,7 +2660,7 @@ struct TileSolver64
 
   NMPC_D void run()
   {
-    if(wave != 0 && lane < 4)
+    if(wave != 0 && lane < 18)
     {
       waveScratch(0)[wZero + lane] = 0.0; // zero words (read by lanes outside a block) and dump words (written by them)
     }

@@ -798,6 +798,68 @@ struct TileSolver64
     c = mine.runningCost(t, x, u);
     x_next = mine.stateEq(t, x, u);
   }
+  // The same in two halves, a trip of stagedPass apart: requested in trip j - 1, a timestep's rows are written to the ring in trip
+  // j — a prefetching lane never waits for its loads INSIDE a trip.  With request and write in one trip no trip was shorter than
+  // a round trip to L2 / HBM (2 - 2.5 us), whatever the rolling lanes had to do: the quadrotor's rollout timestep is ~500
+  // instructions, its trips took 6 k cycles.  For the lanes' shares of a timestep that fit kPipeRows registers (seven waves
+  // serving a group: always); a lone prefetching wave keeps prefetchNominal.
+  //! rows of a timestep per prefetching lane when six waves serve a full group (row_step >= 384 / 35 = 10)
+  static constexpr int kPipeRows = (kRingRows + 9) / 10;
+  struct PrefetchRegs
+  {
+    double v[kPipeRows]; //!< the rows in flight
+    const double * src[kPipeRows]; //!< row k of this lane at timestep 0 (a valid address also where the lane has no row k) ...
+    int step[kPipeRows]; //!< ... and the distance to the same row of the next timestep, in doubles
+    int at[kPipeRows]; //!< where it goes in the slot's ring entry (-1: nowhere)
+  };
+  NMPC_D bool prefetchPipelined(const PrefetchLane & pl) const
+  {
+    return pl.row_step * kPipeRows >= kRingRows; // (wave-uniform: row_step = lanes that serve a slot)
+  }
+  /** Once per pass: which rows this lane fetches, from where.  The trips then cost a multiply-add, a load and a store per row. */
+  NMPC_D void prefetchPlan(const PrefetchLane & pl, PrefetchRegs & pr) const
+  {
+#pragma unroll
+    for(int k = 0; k < kPipeRows; k++)
+    {
+      const int row = pl.row0 + k * pl.row_step;
+      const bool ok = pl.want && row < kRingRows;
+      // row < m: k_i | < m + m n: K_i | < m + m n + n: x_i | else u_i
+      const bool is_k = row < MM, is_K = !is_k && row < kGainRows, is_x = !is_k && !is_K && row < kGainRows + N;
+      const double * base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
+      const int per_step = (is_k || is_K) ? kGainRows : (is_x ? N * 64 : MM * 64); // gains: records; x, u: tile-major rows
+      const int r = is_k ? row : (is_K ? row - MM : (is_x ? (row - kGainRows) * 64 : (row - kGainRows - N) * 64));
+      pr.src[k] = ok ? base + r : pl.pk; // (pk: the slot's — or instance 0's — first gain record: always readable)
+      pr.step[k] = ok ? per_step : 0;
+      pr.at[k] = ok ? row : -1;
+      pr.v[k] = 0;
+    }
+  }
+  /** n_rows: rows per lane at most in this pass (wave-uniform: ceil(kRingRows / row_step)) — one when a whole workgroup's
+      prefetching waves serve a single slot. */
+  NMPC_D void prefetchIssue(int i, PrefetchRegs & pr, int n_rows) const
+  {
+#pragma unroll
+    for(int k = 0; k < kPipeRows; k++)
+    {
+      if(k < n_rows)
+      {
+        pr.v[k] = pr.src[k][static_cast<size_t>(i) * pr.step[k]]; // (no per-lane branch around a load: lanes without row k re-read a valid word)
+      }
+    }
+  }
+  NMPC_D void prefetchCommit(const PrefetchLane & pl, int i, const PrefetchRegs & pr, int n_rows) const
+  {
+    double * dst = ring(i) + pl.slot * kRingStride;
+#pragma unroll
+    for(int k = 0; k < kPipeRows; k++)
+    {
+      if(k < n_rows && pr.at[k] >= 0)
+      {
+        dst[pr.at[k]] = pr.v[k];
+      }
+    }
+  }
   /** One pass over the horizon, every wave of the workgroup together (T + 2 barriers).
       compute = false: this lane prefetches for the ring (p_lane of p_count; nothing to do in an initial pass).
       compute = true:  every active lane rolls out one trajectory of slot `inst` (instance b) and sums the cost in list order:
@@ -840,18 +902,49 @@ struct TileSolver64
       }
     }
     profAdd(10, 1, 0);
+    if(!compute)
+    {
+      // The prefetching waves' trips: a loop of their own, so that what a prefetching lane keeps across its trips (its plan,
+      // its rows in flight) is not live in the rolling lanes' code (one loop for both roles: the rollout spilled).
+      PrefetchRegs pr;
+      const bool piped = !initial && prefetchPipelined(pl);
+      const int n_rows = uniform((kRingRows + pl.row_step - 1) / pl.row_step);
+      if(piped)
+      {
+        prefetchPlan(pl, pr);
+        prefetchIssue(0, pr, n_rows); // (T >= 1)
+      }
+#pragma nounroll
+      for(int j = 0; j < T + 2; j++)
+      {
+        const unsigned long long pa = profNow();
+        if(!initial && j < T)
+        {
+          if(piped)
+          {
+            prefetchCommit(pl, j, pr, n_rows);
+            if(j + 1 < T)
+            {
+              prefetchIssue(j + 1, pr, n_rows);
+            }
+          }
+          else
+          {
+            prefetchNominal(pl, j);
+          }
+        }
+        const unsigned long long pb = profNow();
+        profAdd(7, pb - pa, 1);
+        barrier();
+        profAdd(8, profNow() - pb, 1);
+      }
+      return 0.0;
+    }
 #pragma nounroll
     for(int j = 0; j < T + 2; j++)
     {
       const unsigned long long pa = profNow();
-      if(!compute)
-      {
-        if(!initial && j < T)
-        {
-          prefetchNominal(pl, j);
-        }
-      }
-      else if(active && j >= 2)
+      if(active && j >= 2)
       {
         const int i = j - 2;
         const double t = t0 + i * mine.dt();
@@ -949,9 +1042,9 @@ struct TileSolver64
         x = x_next;
       }
       const unsigned long long pb = profNow();
-      profAdd(compute ? 5 : 7, pb - pa, compute ? 0 : 1);
+      profAdd(5, pb - pa, 0);
       barrier();
-      profAdd(compute ? 6 : 8, profNow() - pb, compute ? 0 : 1);
+      profAdd(6, profNow() - pb, 0);
     }
     if(rolling)
     {
@@ -2419,6 +2512,14 @@ struct TileSolver64
           // who feeds the ring: all matrix waves (passes 1, 3), the model wave (pass 2); a wide pass 1: the matrix waves that
           // do not roll out — wave 4 and, while three waves cover the group, waves 5 - 7
           int p_lane = model_wave ? lane : p_lane_matrix, p_count = model_wave ? 64 : p_count_matrix;
+          if((pass == 1 || pass == 3) && !wide && !model_wave)
+          {
+            // the rolling wave's SIMD is the rolling wave's: wave 4, which shares it, stays out of the prefetch (its rows were a
+            // tenth of the model wave's issue slots)
+            const int order = (wave == 4) ? 6 : spec_index; // 1 2 3 5 6 7 | 4
+            p_lane = order * 64 + lane; // (>= p_count for wave 4: no rows)
+            p_count = (kT64MatrixWaves - 1) * 64;
+          }
           if(pass == 1 && wide && !model_wave)
           {
             const int order = (wave == 4) ? 6 : spec_index; // 1 2 3 5 6 7 4

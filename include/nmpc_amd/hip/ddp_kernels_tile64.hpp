@@ -781,6 +781,27 @@ struct TileSolver64
       }
     }
   }
+  /** x_i, u_i, cost_i of a rollout to rows kStride doubles apart. */
+  template<int kStride>
+  NMPC_D static void storeTimestep(double * Xo, double * Uo, double * Co, int i, const StateDimVector & x, const double * u, double c, bool with_u)
+  {
+    double * xr = Xo + static_cast<size_t>(i) * (N * kStride);
+#pragma unroll
+    for(int cc = 0; cc < N; cc++)
+    {
+      xr[cc * kStride] = x[cc];
+    }
+    if(with_u)
+    {
+      double * ur = Uo + static_cast<size_t>(i) * (MM * kStride);
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        ur[a * kStride] = u[a];
+      }
+    }
+    Co[static_cast<size_t>(i) * kStride] = c;
+  }
   /** runningCost and stateEq at (x, u[0 .. m)). */
   NMPC_D static void evalModel(const Problem & mine, double t, const StateDimVector & x, const double * uv, int m, double & c,
                                StateDimVector & x_next)
@@ -1023,20 +1044,16 @@ struct TileSolver64
         }
         if(store)
         {
-#pragma unroll
-          for(int cc = 0; cc < N; cc++)
+          // (the distance of consecutive rows as a constant in both cases: immediate offsets)
+          if(ost == 1)
           {
-            Xo[(static_cast<size_t>(i) * N + cc) * ost] = x[cc];
+            storeTimestep<1>(Xo, Uo, Co, i, x, u, c, !initial || kDyn);
           }
-          if(!initial || kDyn) // (run-time input dimension: the initial pass zeroes the rows of U beyond inputDim(t))
+          else
           {
-#pragma unroll
-            for(int a = 0; a < MM; a++)
-            {
-              Uo[(static_cast<size_t>(i) * MM + a) * ost] = u[a];
-            }
+            storeTimestep<64>(Xo, Uo, Co, i, x, u, c, !initial || kDyn); // (run-time input dimension: the initial pass zeroes
+                                                                          // the rows of U beyond inputDim(t))
           }
-          Co[static_cast<size_t>(i) * ost] = c;
         }
         J += c;
         x = x_next;

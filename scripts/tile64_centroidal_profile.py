@@ -34,5 +34,6 @@ if os.environ.get("NMPC_HIP_DDP_LIB"):
           f"{q[2] / max(steps, 1):.0f}")
     print(f"  per sweep timestep: model wave linearisation {q[0] / max(sweeps * T, 1):.0f} waiting {q[1] / max(sweeps * T, 1):.0f} | matrix wave 1 "
           f"steps {q[2] / max(sweeps * T, 1):.0f} waiting {q[3] / max(sweeps * T, 1):.0f}")
+    print(f"  record stride {int(q[37] / 16.0)} doubles, group size {int(q[38] / 16.0)}, LDS doubles in front of the records {int(q[39] / 16.0)} of 20480")
     print(f"  per rollout timestep: rolling lanes compute {q[5] / max(passes * (T + 2), 1):.0f} waiting {q[6] / max(passes * (T + 2), 1):.0f} | "
           f"prefetching wave 1: prefetch {q[7] / max(passes * (T + 2), 1):.0f} waiting {q[8] / max(passes * (T + 2), 1):.0f}")

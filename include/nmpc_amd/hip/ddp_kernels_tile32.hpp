@@ -44,6 +44,7 @@
 
 #include <nmpc_amd/hip/model_ops.hpp>
 #include <nmpc_amd/hip/mpc_kernels.hpp>
+#include <nmpc_amd/hip/ddp_kernels_tile64.hpp>
 
 namespace nmpc_amd
 {
@@ -1708,9 +1709,22 @@ struct ModelOpsTile32
   {
     new(out) Problem();
   }
-  static const char * kernelName(int, int)
+  /** Round 4: the fp64 tile kernel has a float instantiation (ddp_kernels_tile64.hpp: the same kernel with v_mfma_f32_16x16x4 and
+      the lanes of a row holding the tile's columns in the order that makes the f32 instruction's result layout the f64 one).  It
+      is the fp32 kernel of the shapes THIS file's kernel does not take (m > 4, n not in {4, 8, 12}: ModelOpsTile64Float below);
+      on the shapes both take this file's is the faster one — its step is 16 MFMAs + 125 other instructions against 10 + 250
+      (measured, c4: 1.46 k against 1.04 k it/s) — so it keeps them; NMPC_HIP_DDP_KERNEL=tile64 runs their unconstrained solves
+      on the other kernel (A/B measurements; tests/test_gpu_fp32.py runs on both). */
+  static constexpr bool kTile64Float = Problem::kStateDim >= 5 && Problem::kStateDim <= 15 && Problem::kInputDimMax >= 1
+                                       && Problem::kInputDimMax <= 8 && !Problem::kDynamicInput;
+  static bool useTile64Float(bool constrained)
   {
-    return "ddp_solve_tile32_kernel";
+    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
+    return kTile64Float && !constrained && force && std::strcmp(force, "tile64") == 0;
+  }
+  static const char * kernelName(int, int constrained)
+  {
+    return useTile64Float(constrained != 0) ? "ddp_solve_tile64_kernel" : "ddp_solve_tile32_kernel";
   }
   /** The handle allocates every Scalar array with sizeof(Problem::Scalar) = 4 (ModelOps::scalar_bytes): same pointers, float view. */
   static DeviceBuffersT<float> floatView(const DeviceBuffers & buf64)
@@ -1762,6 +1776,17 @@ struct ModelOpsTile32
     Problem problem;
     std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
     const DeviceBuffersT<float> buf = floatView(buf64);
+    if constexpr(kTile64Float)
+    {
+      if(useTile64Float(cfg.with_input_constraint != 0))
+      {
+        if(buf.params_batch != nullptr)
+        {
+          return launchTile64<Problem, false, true>(problem, cfg, buf, stream);
+        }
+        return launchTile64<Problem, false, false>(problem, cfg, buf, stream);
+      }
+    }
     constexpr size_t lds_bytes = Solver::kLdsBytes;
     static std::atomic<bool> requested[64] = {}; // (several host threads may launch at once; the setup is idempotent)
     int dev = 0;
@@ -1829,7 +1854,93 @@ struct ModelOpsTile32
   }
   static size_t workspaceElems(int T)
   {
-    return Solver::workspaceElems(T);
+    size_t n = Solver::workspaceElems(T);
+    if constexpr(kTile64Float)
+    {
+      const size_t n64 = TileSolver64<Problem>::workspaceDoubles(T); // (elements of float: gain records + candidate trajectories)
+      n = n64 > n ? n64 : n;
+    }
+    return n;
+  }
+  static ModelOps make()
+  {
+    static_assert(std::is_trivially_copyable<Problem>::value, "a DDP problem must be trivially copyable: it is passed to the GPU by value");
+    static_assert(std::is_default_constructible<Problem>::value, "a DDP problem must be default constructible");
+    ModelOps ops;
+    ops.name = Problem::kName;
+    ops.state_dim = Problem::kStateDim;
+    ops.input_dim_max = Problem::kInputDimMax;
+    ops.dynamic_input = 0;
+    ops.param_bytes = sizeof(Problem);
+    ops.default_params = &defaultParams;
+    ops.launch_solve = &launchSolve;
+    ops.input_dims = &inputDims;
+    ops.dt = &dt;
+    ops.kernel_name = &kernelName;
+    ops.launch_mpc_advance = &launchMpcAdvance;
+    ops.has_plant_step = HasPlantStep<Problem>::value ? 1 : 0;
+    ops.wpi_workspace_doubles = &workspaceElems;
+    ops.scalar_bytes = 4;
+    ops.gain_layout = 1;
+    ops.own_problems_supported = [](int, int) { return 1; };
+    return ops;
+  }
+};
+/** Type-erased operations of an fp32 problem type served by the FP64 TILE KERNEL'S FLOAT INSTANTIATION only: the shapes the
+    fp32 tile kernel above does not take (5 <= n <= 15, m <= 8; e.g. the manipulator, n 14, m 7).  Unconstrained solves; a
+    box-constrained solve is refused at launch (the handle reports the HIP error). */
+template<class Problem>
+struct ModelOpsTile64Float
+{
+  static_assert(std::is_same<typename Problem::Scalar, float>::value, "float problem types");
+  static void defaultParams(void * out)
+  {
+    new(out) Problem();
+  }
+  static const char * kernelName(int, int)
+  {
+    return "ddp_solve_tile64_kernel";
+  }
+  static hipError_t launchSolve(const void * params, const nmpc_hip_ddp_config & cfg, const DeviceBuffers & buf64, hipStream_t stream)
+  {
+    if(buf64.wpi_ws == nullptr || cfg.with_input_constraint != 0)
+    {
+      return hipErrorNotSupported;
+    }
+    Problem problem;
+    std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
+    const DeviceBuffersT<float> buf = ModelOpsTile32<Problem>::floatView(buf64);
+    if(buf.params_batch != nullptr)
+    {
+      return launchTile64<Problem, false, true>(problem, cfg, buf, stream);
+    }
+    return launchTile64<Problem, false, false>(problem, cfg, buf, stream);
+  }
+  static hipError_t launchMpcAdvance(const void * params, const DeviceBuffers & buf64, const MpcAdvanceArgs & args, hipStream_t stream)
+  {
+    Problem problem;
+    std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
+    const DeviceBuffersT<float> buf = ModelOpsTile32<Problem>::floatView(buf64);
+    hipLaunchKernelGGL((mpc_advance_kernel<Problem, float>), dim3(buf.Bp / kLanesPerBlock), dim3(kLanesPerBlock), 0, stream, problem,
+                       buf, args);
+    return hipGetLastError();
+  }
+  static void inputDims(const void *, double, int T, int * out)
+  {
+    for(int i = 0; i < T; i++)
+    {
+      out[i] = Problem::kInputDimMax;
+    }
+  }
+  static double dt(const void * params)
+  {
+    Problem problem;
+    std::memcpy(static_cast<void *>(&problem), params, sizeof(Problem));
+    return static_cast<double>(problem.dt());
+  }
+  static size_t workspaceElems(int T)
+  {
+    return TileSolver64<Problem>::workspaceDoubles(T);
   }
   static ModelOps make()
   {
@@ -1857,6 +1968,9 @@ struct ModelOpsTile32
 };
 } // namespace hip
 } // namespace nmpc_amd
+
+#define NMPC_AMD_REGISTER_PROBLEM_TILE64_FLOAT(ProblemType) \
+  NMPC_AMD_REGISTER_PROBLEM_WITH(ProblemType, nmpc_amd::hip::ModelOpsTile64Float<ProblemType>)
 
 #define NMPC_AMD_REGISTER_PROBLEM_TILE32(ProblemType) \
   NMPC_AMD_REGISTER_PROBLEM_WITH(ProblemType, nmpc_amd::hip::ModelOpsTile32<ProblemType>)

@@ -56,6 +56,34 @@ namespace nmpc_amd
 namespace hip
 {
 typedef double v4d64 __attribute__((ext_vector_type(4)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+/** What the tile kernel needs to know about its arithmetic type S (Problem::Scalar). */
+template<class S>
+struct T64Scalar;
+template<>
+struct T64Scalar<double>
+{
+  using Vec4 = v4d64;
+  //! logical column <-> lane of a 16-lane row: v_mfma_f64_16x16x4 keeps column j in lane j
+  NMPC_D static constexpr int colOf(int p)
+  {
+    return p;
+  }
+};
+template<>
+struct T64Scalar<float>
+{
+  using Vec4 = v4f32;
+  //! v_mfma_f32_16x16x4 puts row i of its result into register i % 4 of lane group i / 4 (the f64 instruction: register i / 4,
+  //! lane group i % 4).  With the logical COLUMN 4 (p % 4) + p / 4 in lane p of a 16-lane row — the transposition of the 4 x 4
+  //! index grid, its own inverse — the result rows, which are the first operand's columns, land where the f64 layout has them:
+  //! register r of lane group q = logical row 4 r + q, for operands and results alike, and the k-slices of a contraction can be
+  //! skipped exactly as in double.
+  NMPC_D static constexpr int colOf(int p)
+  {
+    return 4 * (p & 3) + (p >> 2);
+  }
+};
 
 constexpr int kT64Waves = 8; //!< wavefronts per workgroup: two per SIMD, 256 registers each
 constexpr int kT64Threads = kT64Waves * 64;
@@ -70,7 +98,26 @@ constexpr size_t kT64LdsBytes = 160 * 1024; //!< the whole LDS of a CU: one work
 template<class Problem, bool kConstrained = false, bool kOwnProblem = false>
 struct TileSolver64
 {
-  static_assert(std::is_same<typename Problem::Scalar, double>::value, "the fp64 tile kernel computes in double");
+  using S = typename Problem::Scalar; //!< double: the reference's arithmetic; float: BASELINE.json's config 4 (round 4)
+  using Vec4 = typename T64Scalar<S>::Vec4;
+  static constexpr bool kF32 = std::is_same<S, float>::value;
+  static_assert(std::is_same<S, double>::value || kF32, "the tile kernel computes in S or in float");
+  static constexpr int kW = 8 / static_cast<int>(sizeof(S)); //!< elements of S per 8-byte word (the fixed LDS area is laid out in words)
+  using Buffers = DeviceBuffersT<S>;
+  /** Logical column of the 16 x 16 tiles that lane p of a 16-lane row holds, and back (the map is its own inverse). */
+  NMPC_D static constexpr int colOf(int p)
+  {
+    return T64Scalar<S>::colOf(p);
+  }
+  NMPC_D static constexpr int laneOfCol(int c)
+  {
+    return T64Scalar<S>::colOf(c);
+  }
+  /** A configuration value in the arithmetic type (the float oracle casts once, then computes in float). */
+  NMPC_D static S sc(double v)
+  {
+    return static_cast<S>(v);
+  }
   static constexpr int N = Problem::kStateDim;
   static constexpr int M = Problem::kInputDimMax;
   static constexpr int MM = M;
@@ -82,11 +129,13 @@ struct TileSolver64
   static_assert(N >= 1 && N <= 15, "[Vxx | Vx] is one 16-column tile");
   static_assert(M >= 1 && M <= 16, "[K | k] is one tile of m <= 16 rows");
   static_assert(!(kConstrained && kBig), "BoxQP on the tile kernel: static m <= 8 (boxQPMasked runs in a lane's registers)");
+  static_assert(!(kF32 && (kBig || kConstrained)), "float: unconstrained solves with a static m <= 8 (the fp32 tile kernel of "
+                                                   "ddp_kernels_tile32.hpp takes the box-constrained ones)");
   static constexpr bool kShape = true;
   static constexpr int KN = (N + 3) / 4; //!< k-slices of a contraction over state rows
   static constexpr int KM = (MM + 3) / 4; //!< ... over input rows; also the registers of an m-row tile that hold anything
   static constexpr int rN = N / 4, qN = N % 4; //!< row n of a natural-layout tile: register rN of lane group qN
-  static constexpr int kStarLane = 16 * qN + N; //!< the lane whose register rN is entry (n, n)
+  static constexpr int kStarLane = 16 * qN + T64Scalar<typename Problem::Scalar>::colOf(N); //!< the lane whose register rN is entry (n, n)
   //! n + m <= 16 with n a multiple of 4 (the quadrotor): [Fx Fu] and [[Lxx Lxu],[Lxu^T Luu]] are ONE tile each, and all five
   //! Q blocks come out of two products (G = VV^T F, Q = G^T F + L: 2 ceil(n/4) MFMAs instead of 5 ceil(n/4)); rows n .. n+m-1 of
   //! Q are then whole registers of the lane groups (n % 4 == 0), i.e. Qux / Quu without any cross-lane-group move
@@ -112,12 +161,12 @@ struct TileSolver64
   static constexpr int idLu = idLx + N;
   static constexpr int idInvU = idLu + MM; //!< 1 / (|u_i| + 1)    :217-221
   static constexpr int idU = idInvU + 1; //!< u_i (box-constrained solves: the QP's bounds are limits - u_i, :470-472)
-  static constexpr int idM = idU + (kConstrained ? MM : 0); //!< inputDim(t_i) as a double (run-time input dimension only)
+  static constexpr int idM = idU + (kConstrained ? MM : 0); //!< inputDim(t_i) as a S (run-time input dimension only)
   static constexpr int kNumIds = idM + (kDyn ? 1 : 0);
 
-  // ---- LDS layout, in doubles.  Fixed part first, the record area takes the rest.
+  // ---- LDS layout, in elements of S (tables of other types: 8-byte words, kW elements each).  Fixed part first, the record area takes the rest.
   static constexpr int kTblAt = 0; //!< unsigned short tbl[kNumIds]: entry -> offset in a record (0 = the zero word)
-  static constexpr int kMetaAt = kTblAt + (kNumIds + 3) / 4; //!< ints: 0 record stride, 1 group size, 2.. flags
+  static constexpr int kMetaAt = kTblAt + kW * ((kNumIds + 3) / 4); //!< ints: 0 record stride, 1 group size, 2.. flags
   enum MetaField
   {
     mStride = 0,
@@ -134,8 +183,8 @@ struct TileSolver64
     kNumMeta = 12
   };
   //! ints: [0..31] active index -> slot, [32..63] slot -> active index (-1: the slot does not take part in the sweep)
-  static constexpr int kActAt = kMetaAt + kNumMeta / 2;
-  static constexpr int kSlotAt = kActAt + kT64MaxGroup;
+  static constexpr int kActAt = kMetaAt + kW * (kNumMeta / 2);
+  static constexpr int kSlotAt = kActAt + kW * kT64MaxGroup; //!< the slot table: an 8-byte word per (field, slot)
   enum SlotField
   {
     // what the roles tell each other, and the per-instance solver state of the model wave between its phases (nothing of it
@@ -174,7 +223,7 @@ struct TileSolver64
     fInLs = 8,
     fSuccess = 16
   };
-  static constexpr int kKnextAt = kSlotAt + kNumSlotFields * kT64MaxGroup; //!< [32][8]: k_{i+1}, the BoxQP warm start (:452-467)
+  static constexpr int kKnextAt = kSlotAt + kW * kNumSlotFields * kT64MaxGroup; //!< [32][8]: k_{i+1}, the BoxQP warm start (:452-467)
   static constexpr int kWaveAt = kKnextAt + (kConstrained ? kT64MaxGroup * 8 : 0);
   // per matrix wave: the column exchange of the gain computation, then (aliased: one wave's LDS traffic is ordered) the transposition
   //! leading dimension of the exchanged columns: ODD, so that the sixteen lanes of a row (one column each) hit different banks
@@ -196,13 +245,13 @@ struct TileSolver64
   static constexpr int kScratchPerWave = 1;
   static constexpr int kLsAt = kWaveAt + kT64MatrixWaves * kScratchPerWave * kWaveDoubles; //!< lsJ[NMPC_HIP_MAX_ALPHA][32]: cost of every trial
   static constexpr int kTraceAt = kLsAt + NMPC_HIP_MAX_ALPHA * kT64MaxGroup; //!< trace row of the running iteration, [field][32]
-  static constexpr int kProfAt = kTraceAt + NMPC_HIP_NTRACE * kT64MaxGroup; //!< profiling builds: 40 tick counters of workgroup 0
+  static constexpr int kProfAt = (kTraceAt + NMPC_HIP_NTRACE * kT64MaxGroup + 1) & ~1; //!< profiling builds: 40 tick counters of workgroup 0
 #ifdef NMPC_AMD_PROFILE_TILE64
-  static constexpr int kFixedRaw = kProfAt + 40;
+  static constexpr int kFixedRaw = kProfAt + kW * 40;
 #else
-  static constexpr int kFixedRaw = kProfAt + 16;
+  static constexpr int kFixedRaw = kProfAt + kW * 16;
 #endif
-  static constexpr int kRecAt = (kFixedRaw + 1) & ~1; //!< records: rec[2][G][stride]; before a sweep: [Vxx | Vx] per slot
+  static constexpr int kRecAt = (kFixedRaw + 3) & ~3; //!< records: rec[2][G][stride]; before a sweep: [Vxx | Vx] per slot (16-byte aligned)
   static constexpr int kTerm = (N + 1) * N; //!< terminal record: n + 1 columns of n rows
   // line search: ring of nominal records [depth][row][G] in the record area; rows of a timestep: k_i (m), K_i (m n, column-major),
   // x_i (n), u_i (m)
@@ -213,7 +262,9 @@ struct TileSolver64
   //! offsets, two per instruction (with the rows G doubles apart every read had its own address: a multiply, an add and a
   //! wait each — three quarters of a rollout timestep's instructions); twice an odd number: sixteen slots' 16-byte reads
   //! cover the 64 banks once
-  static constexpr int kRingStride = 2 * ((((kRingRows + 1) / 2) % 2 == 1) ? (kRingRows + 1) / 2 : (kRingRows + 1) / 2 + 1);
+  static constexpr int kRingAl = 16 / static_cast<int>(sizeof(S)); //!< elements per 16-byte read
+  static constexpr int kRingStride =
+      kRingAl * ((((kRingRows + kRingAl - 1) / kRingAl) % 2 == 1) ? (kRingRows + kRingAl - 1) / kRingAl : (kRingRows + kRingAl - 1) / kRingAl + 1);
   /** Per-instance workspace: the gains as records [T][k_i (m) | K_i (m n, column-major)] — a matrix wave writes the 105 doubles of
       an (instance, timestep) as one contiguous run; into the handle's tile-major kff / Kfb arrays the same stores would be 8 bytes
       each, 512 bytes apart (measured: 7 x the written bytes reach HBM). */
@@ -234,20 +285,20 @@ struct TileSolver64
   {
     return gainDoubles(T) + kScratchAlphas * candDoubles(T);
   }
-  NMPC_D double * candidate(int b, int later_index) const
+  NMPC_D S * candidate(int b, int later_index) const
   {
     return buf.wpi_ws + static_cast<size_t>(buf.B) * gainDoubles(T) + (static_cast<size_t>(b) * kScratchAlphas + later_index) * candDoubles(T);
   }
-  static constexpr int kLdsDoubles = static_cast<int>(kT64LdsBytes / sizeof(double));
+  static constexpr int kLdsDoubles = static_cast<int>(kT64LdsBytes / sizeof(S));
   static_assert(kRecAt + 2 * (kNumIds + 2) <= kLdsDoubles && kRecAt + kTerm <= kLdsDoubles, "one instance must fit");
 
   const Problem & problem;
   const nmpc_hip_ddp_config & cfg;
-  const DeviceBuffers & buf;
+  const Buffers & buf;
   const int T;
   const int wave;
   const int lane;
-  double * lds;
+  S * lds;
   int stride = 0; //!< doubles per record (odd: the model wave's lanes spread over the banks)
   int G = 1; //!< instances per group
   int group_cap;
@@ -255,7 +306,7 @@ struct TileSolver64
   int wide_cap; //!< 0: the later step sizes of a line search never ride along with the first one (A/B measurements, tests)
   int adopt_cap; //!< 0: a later step size that is taken is rolled out again instead of copied from the workspace (A/B, tests)
 
-  NMPC_D TileSolver64(const Problem & p, const nmpc_hip_ddp_config & c, const DeviceBuffers & bf, double * lds_base, int cap)
+  NMPC_D TileSolver64(const Problem & p, const nmpc_hip_ddp_config & c, const Buffers & bf, S * lds_base, int cap)
   : problem(p), cfg(c), buf(bf), T(bf.T), wave(static_cast<int>(threadIdx.x) >> 6), lane(static_cast<int>(threadIdx.x) & 63),
     lds(lds_base), group_cap(cap & 0xffff), chunk_cap((cap >> 16) & 0x3fff), wide_cap(((cap >> 31) & 1) == 0 ? 1 : 0),
     adopt_cap(((cap >> 30) & 1) == 0 ? 1 : 0)
@@ -271,20 +322,20 @@ struct TileSolver64
   {
     return reinterpret_cast<int *>(lds + kMetaAt)[k];
   }
-  NMPC_D double & slotF(int field, int slot) const
+  NMPC_D S & slotF(int field, int slot) const
   {
-    return lds[kSlotAt + field * kT64MaxGroup + slot];
+    return lds[kSlotAt + kW * (field * kT64MaxGroup + slot)];
   }
   NMPC_D int & slotI(int field, int slot) const
   {
-    return reinterpret_cast<int *>(lds + kSlotAt + field * kT64MaxGroup + slot)[0];
+    return reinterpret_cast<int *>(lds + kSlotAt + kW * (field * kT64MaxGroup + slot))[0];
   }
   NMPC_D unsigned long long & slotT(int field, int slot) const
   {
-    return reinterpret_cast<unsigned long long *>(lds + kSlotAt + field * kT64MaxGroup + slot)[0];
+    return reinterpret_cast<unsigned long long *>(lds + kSlotAt + kW * (field * kT64MaxGroup + slot))[0];
   }
   /** Record of active index a, timestep offset dt inside a chunk of `chunk` timesteps, buffer `parity` of the two. */
-  NMPC_D double * recAt(int parity, int dt, int a, int chunk, int n_act) const
+  NMPC_D S * recAt(int parity, int dt, int a, int chunk, int n_act) const
   {
     return lds + kRecAt + ((parity * chunk + dt) * n_act + a) * stride;
   }
@@ -301,11 +352,11 @@ struct TileSolver64
   {
     return (kLdsDoubles - kRecAt) / stride;
   }
-  NMPC_D double * term(int slot) const
+  NMPC_D S * term(int slot) const
   {
     return lds + kRecAt + slot * kTerm;
   }
-  NMPC_D double * waveScratch(int which = 0) const
+  NMPC_D S * waveScratch(int which = 0) const
   {
     return lds + kWaveAt + ((wave - 1) * kScratchPerWave + which) * kWaveDoubles;
   }
@@ -331,11 +382,32 @@ struct TileSolver64
   {
     return __builtin_amdgcn_readfirstlane(v);
   }
-  NMPC_D static double uniformD(double v)
+  NMPC_D static S uniformD(S v)
   {
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
+    if constexpr(kF32)
+    {
+      return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+    }
+    else
+    {
+      const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+      const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+      return __hiloint2double(hi, lo);
+    }
+  }
+  /** v of the lane whose id times four is `byte_index` (ds_bpermute: the LDS crossbar, no memory). */
+  NMPC_D static S permuted(S v, int byte_index)
+  {
+    if constexpr(kF32)
+    {
+      return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_index, __float_as_int(v)));
+    }
+    else
+    {
+      const int lo = __builtin_amdgcn_ds_bpermute(byte_index, __double2loint(v));
+      const int hi = __builtin_amdgcn_ds_bpermute(byte_index, __double2hiint(v));
+      return __hiloint2double(hi, lo);
+    }
   }
 
 #ifdef NMPC_AMD_PROFILE_TILE64
@@ -365,13 +437,20 @@ struct TileSolver64
 
   /** X^T Y over the first 4 S rows of X and Y, formed from zero (k ascending: an fma chain per entry). */
   template<int S>
-  NMPC_D static v4d64 mma(v4d64 X, v4d64 Y)
+  NMPC_D static Vec4 mma(Vec4 X, Vec4 Y)
   {
-    v4d64 acc = {0, 0, 0, 0};
+    Vec4 acc = {0, 0, 0, 0};
 #pragma unroll
     for(int s = 0; s < S; s++)
     {
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[s], Y[s], acc, 0, 0, 0);
+      if constexpr(kF32)
+      {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X[s], Y[s], acc, 0, 0, 0);
+      }
+      else
+      {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[s], Y[s], acc, 0, 0, 0);
+      }
     }
     return acc;
   }
@@ -402,7 +481,7 @@ struct TileSolver64
   // ===================================================================================================
   /** Visits the record entries of the linearisation at (t, x, u) in canonical order. */
   template<class Sink>
-  NMPC_D static void emitRecord(const Problem & p, double t, const StateDimVector & x, const InputDimVector & u, int m, Sink & sink)
+  NMPC_D static void emitRecord(const Problem & p, S t, const StateDimVector & x, const InputDimVector & u, int m, Sink & sink)
   {
     StateStateDimMatrix Fx, Lxx;
     StateInputDimMatrix Fu, Lxu;
@@ -501,14 +580,14 @@ struct TileSolver64
     {
       emitEntry(sink, kDyn ? Lu_c[a] : Lu[a], a < m, Lu[a]);
     }
-    double un = 0;
+    S un = 0;
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
       un += dynEntry(a < m, u[a] * u[a]);
     }
-    const double unorm = (M == 1) ? fabs(u[0]) : sqrt(un);
-    sink.putVar(recipFast(unorm + 1.0));
+    const S unorm = (M == 1) ? fabs(u[0]) : sqrt(un);
+    sink.putVar(recipFast(unorm + S(1)));
     if constexpr(kConstrained)
     {
 #pragma unroll
@@ -519,13 +598,13 @@ struct TileSolver64
     }
     if constexpr(kDyn)
     {
-      sink.putVar(static_cast<double>(m));
+      sink.putVar(static_cast<S>(m));
     }
   }
   /** One entry to the sink: static input dimension — the entry as it is (a structural zero is not stored, a constant once per
       sweep); run-time input dimension — classified by `canonical` (see emitRecord), stored every time, zero outside the dimension. */
   template<class Sink>
-  NMPC_D static void emitEntry(Sink & sink, double canonical, bool inside, double v)
+  NMPC_D static void emitEntry(Sink & sink, S canonical, bool inside, S v)
   {
     if constexpr(kDyn)
     {
@@ -539,14 +618,14 @@ struct TileSolver64
     }
   }
   /** A value the compiler knows nothing about. */
-  NMPC_D static double opaque(double v)
+  NMPC_D static S opaque(S v)
   {
     asm("" : "+v"(v));
     return v;
   }
   /** An entry of a block whose size follows the run-time input dimension: zero outside (static dimension: the entry as it is —
       a structural zero stays one). */
-  NMPC_D static double dynEntry(bool inside, double v)
+  NMPC_D static S dynEntry(bool inside, S v)
   {
     if constexpr(kDyn)
     {
@@ -558,7 +637,7 @@ struct TileSolver64
     }
   }
   /** A structural zero: the compiler knows the value, and it is zero. */
-  NMPC_D static bool structuralZero(double v)
+  NMPC_D static bool structuralZero(S v)
   {
     return __builtin_constant_p(v) && v == 0.0;
   }
@@ -566,7 +645,7 @@ struct TileSolver64
   {
     unsigned short * tbl;
     int id = 0, cnt = 0;
-    NMPC_D void put(double v)
+    NMPC_D void put(S v)
     {
       if(structuralZero(v))
       {
@@ -577,38 +656,42 @@ struct TileSolver64
         tbl[id++] = static_cast<unsigned short>(++cnt);
       }
     }
-    NMPC_D void putVar(double)
+    NMPC_D void putVar(S)
     {
       tbl[id++] = static_cast<unsigned short>(++cnt);
     }
-    NMPC_D void putClassified(double canonical, double)
+    NMPC_D void putClassified(S canonical, S)
     {
       put(canonical);
     }
   };
-  /** kFull = false: entries the compiler knows to be constants (the literal ones of the Jacobians, weights of a shared
-      problem object) are not written again — the record slot holds them from the sweep's first two (full) timesteps. */
-  template<bool kFull>
+  /** full = false: entries the compiler knows to be constants (the literal ones of the Jacobians, weights of a shared
+      problem object) are not written again — the record slot holds them from the sweep's first two (full) timesteps.  A RUN-TIME
+      flag of ONE instantiation: as a template parameter the functors' code existed twice, and the compiler contracted their
+      products into fused multiply-adds differently in the two copies — in float the records of the full and of the partial
+      timesteps then differed in the last bit, and with them the results with the chunk size, i.e. with the group size
+      (measured: 7e-7 between groups of 7 and of 32; in double the two copies happened to agree). */
   struct StoreSink
   {
-    double * rec;
+    S * rec;
+    bool full;
     int cnt = 0;
-    NMPC_D void put(double v)
+    NMPC_D void put(S v)
     {
       if(!structuralZero(v))
       {
         ++cnt;
-        if(kFull || !__builtin_constant_p(v))
+        if(!__builtin_constant_p(v) || full)
         {
           rec[cnt] = v;
         }
       }
     }
-    NMPC_D void putVar(double v)
+    NMPC_D void putVar(S v)
     {
       rec[++cnt] = v;
     }
-    NMPC_D void putClassified(double canonical, double v)
+    NMPC_D void putClassified(S canonical, S v)
     {
       if(!structuralZero(canonical))
       {
@@ -619,15 +702,15 @@ struct TileSolver64
 
   struct Point
   {
-    double x[N], u[MM];
+    S x[N], u[MM];
   };
   /** (x_i, u_i) of the slot's current trajectory: requested one timestep before lineariseStep consumes it. */
   NMPC_D void loadPoint(Point & p, int b, int sel, int i) const
   {
     const size_t tile = tileOf(b), ln = lnOf(b);
     const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;
-    const double * Xn = buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln;
-    const double * Un = buf.U + ((tile * 2 + sel) * rows_u) * 64 + ln;
+    const S * Xn = buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln;
+    const S * Un = buf.U + ((tile * 2 + sel) * rows_u) * 64 + ln;
 #pragma unroll
     for(int c = 0; c < N; c++)
     {
@@ -639,8 +722,7 @@ struct TileSolver64
       p.u[a] = Un[(static_cast<size_t>(i) * MM + a) * 64];
     }
   }
-  template<bool kFull>
-  NMPC_D void lineariseStep(const Problem & mine, double * dst, double t0, int i, const Point & p) const
+  NMPC_D void lineariseStep(const Problem & mine, S * dst, S t0, int i, const Point & p, bool full) const
   {
     StateDimVector x;
     InputDimVector u;
@@ -654,12 +736,12 @@ struct TileSolver64
     {
       u[a] = p.u[a];
     }
-    StoreSink<kFull> sink{dst};
-    if(kFull)
+    StoreSink sink{dst, full};
+    if(full)
     {
       sink.rec[0] = 0.0; // the zero word
     }
-    const double t = t0 + i * mine.dt();
+    const S t = t0 + i * mine.dt();
     const int m = inputDimOf(mine, t);
     if constexpr(kDyn)
     {
@@ -668,7 +750,7 @@ struct TileSolver64
     emitRecord(mine, t, x, u, m, sink);
   }
   /** inputDim(t) of a run-time input dimension (DDPSolver.hpp:381), the static one otherwise. */
-  NMPC_D static int inputDimOf(const Problem & mine, double t)
+  NMPC_D static int inputDimOf(const Problem & mine, S t)
   {
     if constexpr(kDyn)
     {
@@ -680,11 +762,11 @@ struct TileSolver64
     }
   }
   /** [Vxx | Vx] of the terminal cost (:177-185, :346-365) -> term(slot), column-major n x (n + 1). */
-  NMPC_D void lineariseTerminal(const Problem & mine, int slot, int b, int sel, double t0) const
+  NMPC_D void lineariseTerminal(const Problem & mine, int slot, int b, int sel, S t0) const
   {
     const size_t tile = tileOf(b), ln = lnOf(b);
     const size_t rows_x = static_cast<size_t>(T + 1) * N;
-    const double * Xn = buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln;
+    const S * Xn = buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln;
     StateDimVector xT, vx;
     StateStateDimMatrix vxx;
 #pragma unroll
@@ -693,7 +775,7 @@ struct TileSolver64
       xT[c] = Xn[(static_cast<size_t>(T) * N + c) * 64];
     }
     mine.calcTerminalCostDeriv(t0 + T * mine.dt(), xT, vx, vxx);
-    double * r = term(slot);
+    S * r = term(slot);
 #pragma unroll
     for(int c = 0; c <= N; c++)
     {
@@ -714,7 +796,7 @@ struct TileSolver64
   // fetch the nominal of timestep i + 2 into a ring in LDS (the record area, idle during the line search) — coalesced rows of
   // the tile-major arrays, element (row, slot) — while the rolling waves read timestep i from it, one column of K at a time.
   // One barrier per timestep; both roles run stagedPass() with the same barrier count.
-  NMPC_D double * ring(int i) const
+  NMPC_D S * ring(int i) const
   {
     return lds + kRecAt + (i % kRingDepth) * (kRingStride * G);
   }
@@ -724,7 +806,7 @@ struct TileSolver64
   {
     bool want; //!< the slot takes part in the pass and this lane has rows to fetch
     int row0, row_step, slot;
-    const double *pk, *pK, *pX, *pU; //!< row 0 of timestep 0 of k_list_, K_list_, x_list, u_list of the slot's instance
+    const S *pk, *pK, *pX, *pU; //!< row 0 of timestep 0 of k_list_, K_list_, x_list, u_list of the slot's instance
   };
   NMPC_D PrefetchLane makePrefetchLane(int group, int p_lane, int p_count) const
   {
@@ -747,12 +829,12 @@ struct TileSolver64
   /** Prefetch role: this lane's rows of timestep i -> ring(i): element (row, slot) at slot * kRingStride + row. */
   NMPC_D void prefetchNominal(const PrefetchLane & pl, int i) const
   {
-    double * dst = ring(i) + pl.slot * kRingStride;
+    S * dst = ring(i) + pl.slot * kRingStride;
     constexpr int kBatch = (kRingRows + 13) / 14 < 10 ? (kRingRows + 13) / 14 : 10; // loads in flight per lane: a whole timestep's
                                                                                     // share when seven waves prefetch 32 slots
     for(int r0 = pl.row0; r0 < kRingRows; r0 += pl.row_step * kBatch)
     {
-      double v[kBatch];
+      S v[kBatch];
       int at[kBatch];
 #pragma unroll
       for(int k = 0; k < kBatch; k++)
@@ -761,7 +843,7 @@ struct TileSolver64
         const bool ok = pl.want && row < kRingRows;
         // row < m: k_i | < m + m n: K_i | < m + m n + n: x_i | else u_i
         const bool is_k = row < MM, is_K = !is_k && row < kGainRows, is_x = !is_k && !is_K && row < kGainRows + N;
-        const double * base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
+        const S * base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
         const int per_step = (is_k || is_K) ? kGainRows : (is_x ? N * 64 : MM * 64); // gains: records; x, u: tile-major rows
         const int r = is_k ? row : (is_K ? row - MM : (is_x ? (row - kGainRows) * 64 : (row - kGainRows - N) * 64));
         at[k] = ok ? row : -1;
@@ -783,9 +865,9 @@ struct TileSolver64
   }
   /** x_i, u_i, cost_i of a rollout to rows kStride doubles apart. */
   template<int kStride>
-  NMPC_D static void storeTimestep(double * Xo, double * Uo, double * Co, int i, const StateDimVector & x, const double * u, double c, bool with_u)
+  NMPC_D static void storeTimestep(S * Xo, S * Uo, S * Co, int i, const StateDimVector & x, const S * u, S c, bool with_u)
   {
-    double * xr = Xo + static_cast<size_t>(i) * (N * kStride);
+    S * xr = Xo + static_cast<size_t>(i) * (N * kStride);
 #pragma unroll
     for(int cc = 0; cc < N; cc++)
     {
@@ -793,7 +875,7 @@ struct TileSolver64
     }
     if(with_u)
     {
-      double * ur = Uo + static_cast<size_t>(i) * (MM * kStride);
+      S * ur = Uo + static_cast<size_t>(i) * (MM * kStride);
 #pragma unroll
       for(int a = 0; a < MM; a++)
       {
@@ -803,7 +885,7 @@ struct TileSolver64
     Co[static_cast<size_t>(i) * kStride] = c;
   }
   /** runningCost and stateEq at (x, u[0 .. m)). */
-  NMPC_D static void evalModel(const Problem & mine, double t, const StateDimVector & x, const double * uv, int m, double & c,
+  NMPC_D static void evalModel(const Problem & mine, S t, const StateDimVector & x, const S * uv, int m, S & c,
                                StateDimVector & x_next)
   {
     InputDimVector u;
@@ -828,8 +910,8 @@ struct TileSolver64
   static constexpr int kPipeRows = (kRingRows + 9) / 10;
   struct PrefetchRegs
   {
-    double v[kPipeRows]; //!< the rows in flight
-    const double * src[kPipeRows]; //!< row k of this lane at timestep 0 (a valid address also where the lane has no row k) ...
+    S v[kPipeRows]; //!< the rows in flight
+    const S * src[kPipeRows]; //!< row k of this lane at timestep 0 (a valid address also where the lane has no row k) ...
     int step[kPipeRows]; //!< ... and the distance to the same row of the next timestep, in doubles
     int at[kPipeRows]; //!< where it goes in the slot's ring entry (-1: nowhere)
   };
@@ -847,7 +929,7 @@ struct TileSolver64
       const bool ok = pl.want && row < kRingRows;
       // row < m: k_i | < m + m n: K_i | < m + m n + n: x_i | else u_i
       const bool is_k = row < MM, is_K = !is_k && row < kGainRows, is_x = !is_k && !is_K && row < kGainRows + N;
-      const double * base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
+      const S * base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
       const int per_step = (is_k || is_K) ? kGainRows : (is_x ? N * 64 : MM * 64); // gains: records; x, u: tile-major rows
       const int r = is_k ? row : (is_K ? row - MM : (is_x ? (row - kGainRows) * 64 : (row - kGainRows - N) * 64));
       pr.src[k] = ok ? base + r : pl.pk; // (pk: the slot's — or instance 0's — first gain record: always readable)
@@ -871,7 +953,7 @@ struct TileSolver64
   }
   NMPC_D void prefetchCommit(const PrefetchLane & pl, int i, const PrefetchRegs & pr, int n_rows) const
   {
-    double * dst = ring(i) + pl.slot * kRingStride;
+    S * dst = ring(i) + pl.slot * kRingStride;
 #pragma unroll
     for(int k = 0; k < kPipeRows; k++)
     {
@@ -888,13 +970,13 @@ struct TileSolver64
         else     — u'_i = (u_i + alpha k_i) + K_i (x'_i - x_i) around the nominal in the ring    :536-560
       store: the trajectory goes to half out_half of X / U / cost (an initial pass leaves U as it is).
       Trip j of the loop: the prefetchers fetch timestep j, the rolling lanes compute timestep j - 2 (ring depth 3). */
-  NMPC_D double stagedPass(bool compute, bool initial, const Problem & mine, bool active, int group, int b, int inst, int out_half,
-                           double t0, double alpha, bool store, int p_lane, int p_count, int to_candidate = -1) const
+  NMPC_D S stagedPass(bool compute, bool initial, const Problem & mine, bool active, int group, int b, int inst, int out_half,
+                           S t0, S alpha, bool store, int p_lane, int p_count, int to_candidate = -1) const
   {
-    double J = 0;
+    S J = 0;
     StateDimVector x;
-    double *Xo = nullptr, *Uo = nullptr, *Co = nullptr;
-    const double * Uin = nullptr;
+    S *Xo = nullptr, *Uo = nullptr, *Co = nullptr;
+    const S * Uin = nullptr;
     const bool rolling = compute && active;
     const PrefetchLane pl = makePrefetchLane(group, p_lane, p_count);
     size_t ost = 64; // distance of consecutive rows at the destination (the handle's arrays are tile-major)
@@ -968,9 +1050,9 @@ struct TileSolver64
       if(active && j >= 2)
       {
         const int i = j - 2;
-        const double t = t0 + i * mine.dt();
+        const S t = t0 + i * mine.dt();
         const int m = inputDimOf(mine, t); // (run-time input dimension: the rows beyond it are zeros, in U and in the gains)
-        double u[MM];
+        S u[MM];
         if(initial)
         {
 #pragma unroll
@@ -981,7 +1063,7 @@ struct TileSolver64
         }
         else
         {
-          const double * R = ring(i) + inst * kRingStride;
+          const S * R = ring(i) + inst * kRingStride;
           if(i == 0)
           {
 #pragma unroll
@@ -990,7 +1072,7 @@ struct TileSolver64
               x[c] = R[kGainRows + c]; // x'_0 = x_0    :541
             }
           }
-          double s[MM];
+          S s[MM];
 #pragma unroll
           for(int a = 0; a < MM; a++)
           {
@@ -1000,7 +1082,7 @@ struct TileSolver64
 #pragma unroll
           for(int c = 0; c < N; c++)
           {
-            const double dxc = x[c] - R[kGainRows + c];
+            const S dxc = x[c] - R[kGainRows + c];
 #pragma unroll
             for(int a = 0; a < MM; a++)
             {
@@ -1021,7 +1103,7 @@ struct TileSolver64
         // given to them as a CONSTANT (three copies of their code): loops over u.size() then unroll, and what they index
         // stays in registers — with a run-time trip count the centroidal problem's stance tables went to private memory,
         // 15 k cycles per rollout timestep
-        double c;
+        S c;
         StateDimVector x_next;
         if constexpr(kDyn)
         {
@@ -1065,7 +1147,7 @@ struct TileSolver64
     }
     if(rolling)
     {
-      const double cT = mine.terminalCost(t0 + T * mine.dt(), x);
+      const S cT = mine.terminalCost(t0 + T * mine.dt(), x);
       if(store)
       {
 #pragma unroll
@@ -1093,7 +1175,7 @@ struct TileSolver64
       n_take += (slotI(sB, k) >= 0 && slotI(sLs, k) != 0) ? 1 : 0;
     }
     n_take = uniform(n_take);
-    auto destination = [&](int b, int half, size_t r) -> double *
+    auto destination = [&](int b, int half, size_t r) -> S *
     {
       const size_t tile = tileOf(b), ln = lnOf(b);
       if(r < rows_x)
@@ -1116,7 +1198,7 @@ struct TileSolver64
           continue;
         }
         const int half = uniform(slotI(sSel, k)) ^ 1;
-        const double * src = candidate(b, uniform(slotI(sAi, k)) - 1);
+        const S * src = candidate(b, uniform(slotI(sAi, k)) - 1);
         for(size_t r = threadIdx.x; r < rows; r += kT64Threads)
         {
           *destination(b, half, r) = src[r];
@@ -1129,11 +1211,11 @@ struct TileSolver64
       const bool mine = lane < kT64MaxGroup && k < G && slotI(sB, k) >= 0 && slotI(sLs, k) != 0;
       const int b = mine ? slotI(sB, k) : 0;
       const int half = mine ? (slotI(sSel, k) ^ 1) : 0;
-      const double * src = candidate(b, mine ? slotI(sAi, k) - 1 : 0);
+      const S * src = candidate(b, mine ? slotI(sAi, k) - 1 : 0);
       constexpr int kInFlight = 8;
       for(size_t r0 = static_cast<size_t>(wave); r0 < rows; r0 += static_cast<size_t>(kT64Waves) * kInFlight)
       {
-        double v[kInFlight];
+        S v[kInFlight];
 #pragma unroll
         for(int q = 0; q < kInFlight; q++)
         {
@@ -1166,11 +1248,11 @@ struct TileSolver64
   struct LaneMap
   {
     int oFx[4], oFu[4], oLxx[4], oLxuT[KM], oLuu[KM], oLx, oLu, oInvU, oU[kConstrained ? MM : 1], oM;
-    double wn, wt; //!< weights of (Vn, Vn^T) in the new [Vxx | Vx]: (1/2, 1/2) inside the n x n block, (1, 0) in column n
+    S wn, wt; //!< weights of (Vn, Vn^T) in the new [Vxx | Vx]: (1/2, 1/2) inside the n x n block, (1, 0) in column n
   };
   NMPC_D LaneMap makeLaneMap() const
   {
-    const int q = lane >> 4, j = lane & 15;
+    const int q = lane >> 4, j = colOf(lane & 15);
     const unsigned short * t = tbl();
     LaneMap mp;
 #pragma unroll
@@ -1241,14 +1323,14 @@ struct TileSolver64
       LLT: fails iff a pivot is <= 0, NaN passes.  The products L_kj d_j of a pivot row are formed once
       (m^3 / 6 multiply-adds instead of the m^3 / 3 of the lane kernels' ldltInPlace, whose (L L) d association this differs from
       by rounding); branch-free: after a failed pivot the factor is garbage and the caller stores nothing. */
-  NMPC_D static bool ldlt(double * A, double * inv_d)
+  NMPC_D static bool ldlt(S * A, S * inv_d)
   {
     bool ok = true;
 #pragma unroll
     for(int k = 0; k < MM; k++)
     {
-      double v[MM];
-      double d = A[k + k * MM];
+      S v[MM];
+      S d = A[k + k * MM];
 #pragma unroll
       for(int j = 0; j < k; j++)
       {
@@ -1261,12 +1343,12 @@ struct TileSolver64
       }
       ok = ok && !(d <= 0.0);
       A[k + k * MM] = d;
-      const double r = recipFast(d);
+      const S r = recipFast(d);
       inv_d[k] = r;
 #pragma unroll
       for(int i = k + 1; i < MM; i++)
       {
-        double s = A[i + k * MM];
+        S s = A[i + k * MM];
 #pragma unroll
         for(int j = 0; j < k; j++)
         {
@@ -1278,12 +1360,12 @@ struct TileSolver64
     return ok;
   }
   /** (L D L^T) x = rhs in place. */
-  NMPC_D static void ldltSolve(const double * A, const double * inv_d, double * x)
+  NMPC_D static void ldltSolve(const S * A, const S * inv_d, S * x)
   {
 #pragma unroll
     for(int i = 0; i < MM; i++)
     {
-      double s = x[i];
+      S s = x[i];
 #pragma unroll
       for(int j = 0; j < i; j++)
       {
@@ -1295,7 +1377,7 @@ struct TileSolver64
     for(int ii = 0; ii < MM; ii++)
     {
       const int i = MM - 1 - ii;
-      double s = x[i] * inv_d[i];
+      S s = x[i] * inv_d[i];
 #pragma unroll
       for(int j = i + 1; j < MM; j++)
       {
@@ -1306,19 +1388,17 @@ struct TileSolver64
   }
 
   /** The value of lane j + n of this lane's 16-lane row (whatever another lane holds when j + n >= 16: callers mask). */
-  NMPC_D double fromColumnPlusN(double v) const
+  NMPC_D S fromColumnPlusN(S v) const
   {
-    const int src = ((lane & 48) | ((lane + N) & 15)) << 2;
-    const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
-    return __hiloint2double(hi, lo);
+    const int src = ((lane & 48) | laneOfCol((colOf(lane & 15) + N) & 15)) << 2;
+    return permuted(v, src);
   }
 
   /** Row `sel` (0..3) of four values. */
-  NMPC_D static double pick4(int sel, double a0, double a1, double a2, double a3)
+  NMPC_D static S pick4(int sel, S a0, S a1, S a2, S a3)
   {
-    const double lo = (sel & 1) ? a1 : a0;
-    const double hi = (sel & 1) ? a3 : a2;
+    const S lo = (sel & 1) ? a1 : a0;
+    const S hi = (sel & 1) ? a3 : a2;
     return (sel & 2) ? hi : lo;
   }
 
@@ -1326,42 +1406,42 @@ struct TileSolver64
       run the phases of two instances back to back: between two fences the compiler sees two independent chains. */
   struct StepCtx
   {
-    v4d64 VV; //!< [Vxx | Vx] in natural layout (in / out)
-    v4d64 Qxx, Qux, Quu, QuxR, QuuF, qxcol, A, Vn;
-    double qxrow, qurow, inv_u;
-    double fac[kBig ? 1 : MM * MM], inv_d[kBig ? 1 : MM], col[kBig ? 1 : MM], colQ[kBig ? 1 : MM]; // (per-lane factorisation, m <= 8)
-    double c1nn, t2nn, krel_i; //!< k^T Quu k, k^T Qu, |k| / (|u| + 1) of this timestep (lane kStarLane)
+    Vec4 VV; //!< [Vxx | Vx] in natural layout (in / out)
+    Vec4 Qxx, Qux, Quu, QuxR, QuuF, qxcol, A, Vn;
+    S qxrow, qurow, inv_u;
+    S fac[kBig ? 1 : MM * MM], inv_d[kBig ? 1 : MM], col[kBig ? 1 : MM], colQ[kBig ? 1 : MM]; // (per-lane factorisation, m <= 8)
+    S c1nn, t2nn, krel_i; //!< k^T Quu k, k^T Qu, |k| / (|u| + 1) of this timestep (lane kStarLane)
     bool ok; //!< no factorisation of this sweep has failed yet (in / out)
   };
 
   /** Phase 1a: the record's operands, the Q terms (:386-408), Quu_F / Qux_reg as if unregularised.  Branch-free. */
-  NMPC_D void stepQTerms(StepCtx & c, const LaneMap & mp, const double * r, v4d64 & F0, v4d64 & F1, v4d64 & L0, v4d64 & L1, v4d64 & L2) const
+  NMPC_D void stepQTerms(StepCtx & c, const LaneMap & mp, const S * r, Vec4 & F0, Vec4 & F1, Vec4 & L0, Vec4 & L1, Vec4 & L2) const
   {
-    const int j = lane & 15;
+    const int j = colOf(lane & 15);
     (void)j;
-    c.Qux = v4d64{0, 0, 0, 0};
-    c.Quu = v4d64{0, 0, 0, 0};
+    c.Qux = Vec4{0, 0, 0, 0};
+    c.Quu = Vec4{0, 0, 0, 0};
     if constexpr(kAug)
     {
-      v4d64 F, L;
+      Vec4 F, L;
 #pragma unroll
       for(int rr = 0; rr < 4; rr++)
       {
         F[rr] = r[mp.oFx[rr]];
         L[rr] = r[mp.oLxx[rr]];
       }
-      const double lv = r[mp.oLx];
+      const S lv = r[mp.oLx];
       c.inv_u = r[mp.oInvU];
       // G = VV^T F: rows < n: Vxx [Fx Fu], row n: Vx^T [Fx Fu];  Q = G^T F + L = [[Qxx Qxu],[Qux Quu]] (row n of G meets the
       // zero row n of F).  Same products in the same order as the block form below: (Fu^T Vxx) Fx etc., left to right.
-      const v4d64 Gm = mma<KN>(c.VV, F);
-      v4d64 Q = mma<KN>(Gm, F);
+      const Vec4 Gm = mma<KN>(c.VV, F);
+      Vec4 Q = mma<KN>(Gm, F);
 #pragma unroll
       for(int rr = 0; rr < 4; rr++)
       {
         Q[rr] = L[rr] + Q[rr];
       }
-      const double qrow = lv + Gm[rN]; // lane group 0: Qx[j] (j < n), Qu[j - n] (n <= j < n + m)
+      const S qrow = lv + Gm[rN]; // lane group 0: Qx[j] (j < n), Qu[j - n] (n <= j < n + m)
       c.qxrow = qrow;
       c.qurow = fromColumnPlusN(qrow);
 #pragma unroll
@@ -1375,7 +1455,7 @@ struct TileSolver64
     }
     else
     {
-      v4d64 Fx, Fu, Lxx, LxuT = {0, 0, 0, 0}, Luu = {0, 0, 0, 0};
+      Vec4 Fx, Fu, Lxx, LxuT = {0, 0, 0, 0}, Luu = {0, 0, 0, 0};
 #pragma unroll
       for(int rr = 0; rr < 4; rr++)
       {
@@ -1389,10 +1469,10 @@ struct TileSolver64
         LxuT[rr] = r[mp.oLxuT[rr]];
         Luu[rr] = r[mp.oLuu[rr]];
       }
-      const double lx = r[mp.oLx], lu = r[mp.oLu];
+      const S lx = r[mp.oLx], lu = r[mp.oLu];
       c.inv_u = r[mp.oInvU];
-      const v4d64 Pa = mma<KN>(c.VV, Fx);
-      const v4d64 Pb = mma<KN>(c.VV, Fu);
+      const Vec4 Pa = mma<KN>(c.VV, Fx);
+      const Vec4 Pb = mma<KN>(c.VV, Fu);
       c.Qxx = mma<KN>(Pa, Fx);
       c.Qux = mma<KN>(Pb, Fx);
       c.Quu = mma<KN>(Pb, Fu);
@@ -1415,24 +1495,24 @@ struct TileSolver64
     c.QuuF = c.Quu;
   }
   /** Rows n .. n+m-1 of the augmented Q: Qux in columns < n, Quu in columns n .. n+m-1 (moved to columns 0 .. m-1). */
-  NMPC_D void splitAug(const v4d64 & Qa, v4d64 & qux, v4d64 & quu) const
+  NMPC_D void splitAug(const Vec4 & Qa, Vec4 & qux, Vec4 & quu) const
   {
-    const int j = lane & 15;
+    const int j = colOf(lane & 15);
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
-      const double e = Qa[(rN + rr) < 4 ? rN + rr : 0];
-      const double shifted = fromColumnPlusN(e);
+      const S e = Qa[(rN + rr) < 4 ? rN + rr : 0];
+      const S shifted = fromColumnPlusN(e);
       qux[rr] = (j < N) ? e : 0.0;
       quu[rr] = (j < MM) ? shifted : 0.0;
     }
   }
   /** Phase 1b: regularisation, reg_type 2: Quu_F and Qux_reg rebuilt from Vxx + lambda I    :421-441 */
-  NMPC_D void stepRegType2(StepCtx & c, double lambda, const v4d64 & F0, const v4d64 & F1, const v4d64 & L0, const v4d64 & L1,
-                           const v4d64 & L2) const
+  NMPC_D void stepRegType2(StepCtx & c, S lambda, const Vec4 & F0, const Vec4 & F1, const Vec4 & L0, const Vec4 & L1,
+                           const Vec4 & L2) const
   {
-    const int q = lane >> 4, j = lane & 15;
-    v4d64 VVr = c.VV;
+    const int q = lane >> 4, j = colOf(lane & 15);
+    Vec4 VVr = c.VV;
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
@@ -1440,20 +1520,20 @@ struct TileSolver64
     }
     if constexpr(kAug)
     {
-      const v4d64 G2 = mma<KN>(VVr, F0);
-      v4d64 Q2 = mma<KN>(G2, F0);
+      const Vec4 G2 = mma<KN>(VVr, F0);
+      Vec4 Q2 = mma<KN>(G2, F0);
 #pragma unroll
       for(int rr = 0; rr < 4; rr++)
       {
         Q2[rr] = L0[rr] + Q2[rr];
       }
-      c.QuxR = v4d64{0, 0, 0, 0};
-      c.QuuF = v4d64{0, 0, 0, 0};
+      c.QuxR = Vec4{0, 0, 0, 0};
+      c.QuuF = Vec4{0, 0, 0, 0};
       splitAug(Q2, c.QuxR, c.QuuF);
     }
     else
     {
-      const v4d64 Pbr = mma<KN>(VVr, F1);
+      const Vec4 Pbr = mma<KN>(VVr, F1);
       c.QuxR = mma<KN>(Pbr, F0);
       c.QuuF = mma<KN>(Pbr, F1);
 #pragma unroll
@@ -1465,9 +1545,9 @@ struct TileSolver64
     }
   }
   /** ... reg_type 1: Quu_F = Quu + lambda I */
-  NMPC_D void stepRegType1(StepCtx & c, double lambda) const
+  NMPC_D void stepRegType1(StepCtx & c, S lambda) const
   {
-    const int q = lane >> 4, j = lane & 15;
+    const int q = lane >> 4, j = colOf(lane & 15);
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
@@ -1486,15 +1566,16 @@ struct TileSolver64
     unsigned rx_tw; //!< Qx column read (lanes of column n; the zero words elsewhere) | transposition write: row q, column j
     unsigned tr_trn; //!< transposition read-back: rows 4 r + q < 4 rN of column j (zero words outside) | row 4 rN + q (q < qN)
   };
-  NMPC_D static unsigned pack2(int lo_doubles, int hi_doubles)
+  NMPC_D static unsigned pack2(int lo_elements, int hi_elements)
   {
-    return static_cast<unsigned>(lo_doubles * 8) | (static_cast<unsigned>(hi_doubles * 8) << 16);
+    return static_cast<unsigned>(lo_elements * static_cast<int>(sizeof(S))) | (static_cast<unsigned>(hi_elements * static_cast<int>(sizeof(S))) << 16);
   }
   NMPC_D LaneAddr makeLaneAddr() const
   {
-    const int q = lane >> 4, j = lane & 15;
+    const int q = lane >> 4, j = colOf(lane & 15);
     const int w0 = kWaveAt + ((wave - 1) * kScratchPerWave) * kWaveDoubles; // index of the wave's scratch in the LDS array
-    static_assert((kWaveAt + kT64MatrixWaves * kScratchPerWave * kWaveDoubles) * 8 < 65536, "the wave scratch lies in the first 64 KB");
+    static_assert((kWaveAt + kT64MatrixWaves * kScratchPerWave * kWaveDoubles) * static_cast<int>(sizeof(S)) < 65536,
+                  "the wave scratch lies in the first 64 KB");
     LaneAddr la;
     la.ew_equ = pack2(w0 + kColLd * j + q, (q == qN && j < MM) ? w0 + wQQ + kColLd * N + j : w0 + wDump);
     la.eqx_rq = pack2((q == qN && j < N) ? w0 + wX + 4 * (j & 3) + (j >> 2) : w0 + wDump, w0 + wQQ + kColLd * ((j < N) ? j : N));
@@ -1502,10 +1583,10 @@ struct TileSolver64
     la.tr_trn = pack2((j < N) ? w0 + wT + j * kTrLd + q : w0 + wZero, (q < qN && j < N) ? w0 + wT + j * kTrLd + 4 * rN + q : w0 + wZero);
     return la;
   }
-  /** The double at byte offset `at` of the LDS array. */
-  NMPC_D double & ldsAt(unsigned at) const
+  /** The S at byte offset `at` of the LDS array. */
+  NMPC_D S & ldsAt(unsigned at) const
   {
-    return *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + at);
+    return *reinterpret_cast<S *>(reinterpret_cast<char *>(lds) + at);
   }
   NMPC_D static unsigned lo16(unsigned p)
   {
@@ -1530,7 +1611,7 @@ struct TileSolver64
   NMPC_D void stepExchangeWrite(const StepCtx & c, const LaneAddr & la) const
   {
     static_assert(kColLd <= 9 && kColLd >= 4 * KM, "columns of the exchange area");
-    double * Wc = &ldsAt(lo16(la.ew_equ)); // this lane's column, row q
+    S * Wc = &ldsAt(lo16(la.ew_equ)); // this lane's column, row q
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
@@ -1542,7 +1623,7 @@ struct TileSolver64
     ldsAt(lo16(la.eqx_rq)) = c.qxrow; // (lane group qN, j < n)
   }
   /** Phase 2: ... read side. */
-  NMPC_D void stepExchangeRead(StepCtx & c, const double * W, const LaneAddr & la) const
+  NMPC_D void stepExchangeRead(StepCtx & c, const S * W, const LaneAddr & la) const
   {
 #pragma unroll
     for(int cc = 0; cc < MM; cc++)
@@ -1553,7 +1634,7 @@ struct TileSolver64
         c.fac[a + cc * MM] = (kConstrained || a >= cc) ? W[wF + kColLd * cc + a] : 0.0; // (the factorisation reads the lower triangle)
       }
     }
-    const double * col_j = &ldsAt(hi16(la.eqx_rq)); // column min(j, n) of [Qux_reg | Qu]
+    const S * col_j = &ldsAt(hi16(la.eqx_rq)); // column min(j, n) of [Qux_reg | Qu]
 #pragma unroll
     for(int a = 0; a < MM; a++)
     {
@@ -1561,7 +1642,7 @@ struct TileSolver64
       c.inv_d[a] = 0;
     }
     // Qx as column n of the accumulator of the value update: lane (q, n) register r <- Qx[4 r + q] (the other lanes: zero words)
-    const double * qx = &ldsAt(lo16(la.rx_tw));
+    const S * qx = &ldsAt(lo16(la.rx_tw));
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
@@ -1586,21 +1667,21 @@ struct TileSolver64
     c.ok = c.ok && ok_now; // (after a failure the slot computes on garbage and stores nothing)
   }
   /** Phase 3a, box-constrained (:450-497). */
-  NMPC_D void stepGainsBoxQP(StepCtx & c, const LaneMap & mp, const double * r, double * W, int slot, int b, int i) const
+  NMPC_D void stepGainsBoxQP(StepCtx & c, const LaneMap & mp, const S * r, S * W, int slot, int b, int i) const
   {
-    const int j = lane & 15;
-    double (&fac)[MM * MM] = c.fac;
-    double (&col)[MM] = c.col;
-    double (&colQ)[MM] = c.colQ;
+    const int j = colOf(lane & 15);
+    S (&fac)[MM * MM] = c.fac;
+    S (&col)[MM] = c.col;
+    S (&colQ)[MM] = c.colQ;
     bool ok_now = true;
     {
       // every lane solves the same small QP (BoxQP.h:141-347, the lane kernel's implementation)    :450-497
-      double initial_k[MM], lo[MM], up[MM], Qu[MM];
-      double * knext = lds + kKnextAt + slot * 8;
+      S initial_k[MM], lo[MM], up[MM], Qu[MM];
+      S * knext = lds + kKnextAt + slot * 8;
 #pragma unroll
       for(int a = 0; a < MM; a++)
       {
-        const double ua = r[mp.oU[a]];
+        const S ua = r[mp.oU[a]];
         initial_k[a] = (i != T - 1) ? knext[a] : 0.0; // warm start from k_{i+1}    :452-467
         lo[a] = inputLimitLo(buf, b, i, a) - ua; // :470-472
         up[a] = inputLimitHi(buf, b, i, a) - ua;
@@ -1648,11 +1729,11 @@ struct TileSolver64
   }
   /** Phase 3b: A = [K | k], QQ = [Qux | Qu] in natural layout; the cost-to-go (:522-527) up to the symmetrisation; rows of the new
       value function to the scratch.  Branch-free. */
-  NMPC_D void stepValueUpdate(StepCtx & c, double * W, int m, const LaneAddr & la) const
+  NMPC_D void stepValueUpdate(StepCtx & c, S * W, int m, const LaneAddr & la) const
   {
-    const int fl = freshLane(), q = fl >> 4, j = fl & 15;
-    v4d64 QQ = {0, 0, 0, 0};
-    double kn = 0; // |k|^2 (lanes of column n hold k)    :217-221
+    const int fl = freshLane(), q = fl >> 4, j = colOf(fl & 15);
+    Vec4 QQ = {0, 0, 0, 0};
+    S kn = 0; // |k|^2 (lanes of column n hold k)    :217-221
     if constexpr(kBig)
     {
       if(m > 0)
@@ -1662,12 +1743,12 @@ struct TileSolver64
       else
       {
         // no input at this timestep (:513-517): k, K empty, the value function is [Qxx | Qx]
-        c.A = v4d64{0, 0, 0, 0};
+        c.A = Vec4{0, 0, 0, 0};
 #pragma unroll
         for(int rr = 0; rr < 4; rr++)
         {
           const int row = 4 * rr + q;
-          const double qx_c = fromLane(c.qxrow, 16 * qN + (row & 15));
+          const S qx_c = fromLane(c.qxrow, 16 * qN + laneOfCol(row & 15));
           c.qxcol[rr] = (j == N && row < N) ? qx_c : 0.0;
         }
       }
@@ -1683,19 +1764,19 @@ struct TileSolver64
     }
     else
     {
-    c.A = v4d64{0, 0, 0, 0};
+    c.A = Vec4{0, 0, 0, 0};
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
-      double g[4], c4[4];
+      S g[4], c4[4];
 #pragma unroll
       for(int e = 0; e < 4; e++)
       {
         g[e] = (4 * rr + e < MM) ? c.col[(4 * rr + e < MM) ? 4 * rr + e : 0] : 0.0;
         c4[e] = (4 * rr + e < MM) ? c.colQ[(4 * rr + e < MM) ? 4 * rr + e : 0] : 0.0;
       }
-      const double gq = pick4(q, g[0], g[1], g[2], g[3]);
-      const double cq = pick4(q, c4[0], c4[1], c4[2], c4[3]);
+      const S gq = pick4(q, g[0], g[1], g[2], g[3]);
+      const S cq = pick4(q, c4[0], c4[1], c4[2], c4[3]);
       c.A[rr] = (j <= N) ? gq : 0.0;
       QQ[rr] = (j < N) ? c.Qux[rr] : ((j == N) ? cq : 0.0); // (column n of colQ is Qu; unregularised Qux elsewhere)
     }
@@ -1705,14 +1786,14 @@ struct TileSolver64
       kn += c.col[a] * c.col[a];
     }
     }
-    const v4d64 Z = mma<KM>(c.Quu, c.A);
-    const v4d64 C1 = mma<KM>(Z, c.A);
-    const v4d64 T2 = mma<KM>(c.A, QQ);
-    const v4d64 T3 = mma<KM>(c.Qux, c.A);
+    const Vec4 Z = mma<KM>(c.Quu, c.A);
+    const Vec4 C1 = mma<KM>(Z, c.A);
+    const Vec4 T2 = mma<KM>(c.A, QQ);
+    const Vec4 T3 = mma<KM>(c.Qux, c.A);
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
-      const double c0 = (j < N) ? c.Qxx[rr] : c.qxcol[rr];
+      const S c0 = (j < N) ? c.Qxx[rr] : c.qxcol[rr];
       c.Vn[rr] = ((c0 + C1[rr]) + T2[rr]) + T3[rr];
     }
     c.Vn[rN] = (q == qN) ? 0.0 : c.Vn[rN]; // row n: k^T (...), not part of the value function
@@ -1727,7 +1808,7 @@ struct TileSolver64
       c.krel_i = (m > 0) ? c.krel_i : 0.0; // (the reference skips the timesteps without input, :220)
     }
     // Vxx <- (Vxx + Vxx^T) / 2: rows to the scratch, columns back (phase 4)
-    double * row_q = &ldsAt(hi16(la.rx_tw)); // entry (q, j) of the transposition scratch
+    S * row_q = &ldsAt(hi16(la.rx_tw)); // entry (q, j) of the transposition scratch
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
@@ -1736,16 +1817,16 @@ struct TileSolver64
   }
   /** Phase 4: the symmetrised value function; dV and the running max of |k| / (|u| + 1) in the slot table (lane kStarLane; the
       other lanes update a dump word: no branch). */
-  NMPC_D void stepFinish(StepCtx & c, const LaneMap & mp, double * W, int slot, const LaneAddr & la) const
+  NMPC_D void stepFinish(StepCtx & c, const LaneMap & mp, S * W, int slot, const LaneAddr & la) const
   {
     const int fl = freshLane();
     // entry (j, 4 r + q) of the scratch where it belongs to the n x n block (the zero words elsewhere): rows < 4 rN from one
     // address with immediate offsets, row 4 rN + q from its own, the rows behind are outside the block
-    const double * col_j = &ldsAt(lo16(la.tr_trn));
+    const S * col_j = &ldsAt(lo16(la.tr_trn));
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
-      double vt = 0.0;
+      S vt = 0.0;
       if(rr < rN)
       {
         vt = col_j[4 * rr];
@@ -1757,11 +1838,11 @@ struct TileSolver64
       c.VV[rr] = mp.wn * c.Vn[rr] + mp.wt * vt;
     }
     const bool star = fl == kStarLane;
-    double * dv0 = star ? &slotF(sDV0, slot) : W + wDump;
-    double * dv1 = star ? &slotF(sDV1, slot) : W + wDump + 1;
-    double * kr = star ? &slotF(sKrel, slot) : W + wDump;
+    S * dv0 = star ? &slotF(sDV0, slot) : W + wDump;
+    S * dv1 = star ? &slotF(sDV1, slot) : W + wDump + 1;
+    S * kr = star ? &slotF(sKrel, slot) : W + wDump;
     *dv0 += c.t2nn;
-    *dv1 += 0.5 * c.c1nn;
+    *dv1 += S(0.5) * c.c1nn;
     *kr = fmax(*kr, c.krel_i);
   }
   // ---------------------------------------------------------------------------------------------------
@@ -1777,13 +1858,11 @@ struct TileSolver64
   // The forward substitution rides on the same broadcasts; the backward substitution runs column by column (axpy form).
   // Pivots >= m (run-time input dimension) are skipped: the blocks are padded with zeros.  ~50 instructions per pivot.
   /** The value of lane `src` (0 .. 63, any expression) — through the LDS crossbar. */
-  NMPC_D static double fromLane(double v, int src)
+  NMPC_D static S fromLane(S v, int src)
   {
-    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
-    return __hiloint2double(hi, lo);
+    return permuted(v, src << 2);
   }
-  /** The value of lane J of this lane's 16-lane row. */
+  /** The value of lane J of this lane's 16-lane row (natural-layout gains: double only). */
   template<int J>
   NMPC_D static double fromRowLane(double v)
   {
@@ -1800,20 +1879,20 @@ struct TileSolver64
   }
   /** Pivot J of the factorisation and of the forward substitution (see above). */
   template<int J>
-  NMPC_D static void naturalPivot(v4d64 & Aq, v4d64 & R, v4d64 & invd, bool & ok, int q, int col)
+  NMPC_D static void naturalPivot(Vec4 & Aq, Vec4 & R, Vec4 & invd, bool & ok, int q, int col)
   {
     constexpr int rj = J / 4, qj = J % 4;
-    const double d = fromLaneUniform(Aq[rj], 16 * qj + J);
+    const S d = fromLaneUniform(Aq[rj], 16 * qj + J);
     ok = ok && !(d <= 0.0); // the pivot rule of Eigen's LLT (fails iff a pivot is <= 0, NaN passes)
-    const double r = recipFast(d);
+    const S r = recipFast(d);
     invd[rj] = (q == qj) ? r : invd[rj];
-    const double ajc = fromLane(Aq[rj], 16 * qj + col); // entry (j, c) = L_cj d_j of this lane's column
-    const double yj = fromLane(R[rj], 16 * qj + col); // y_j of this lane's right-hand side
-    const double lc = (col > J) ? ajc * r : 0.0; // L_cj; columns <= j are finished: they receive - 0
+    const S ajc = fromLane(Aq[rj], 16 * qj + col); // entry (j, c) = L_cj d_j of this lane's column
+    const S yj = fromLane(R[rj], 16 * qj + col); // y_j of this lane's right-hand side
+    const S lc = (col > J) ? ajc * r : 0.0; // L_cj; columns <= j are finished: they receive - 0
 #pragma unroll
     for(int rr = rj; rr < KM; rr++)
     {
-      double lrow = fromRowLane<J>(Aq[rr] * r); // L_ij of this lane's row i = 4 rr + q
+      S lrow = fromRowLane<J>(Aq[rr] * r); // L_ij of this lane's row i = 4 rr + q
       if(rr == rj)
       {
         lrow = (q > qj) ? lrow : 0.0; // rows <= j are finished
@@ -1824,14 +1903,14 @@ struct TileSolver64
   }
   /** Column K of the backward substitution: x_K is final, the rows above it receive - L_Ki x_K. */
   template<int K>
-  NMPC_D static void naturalBackColumn(const v4d64 & Ln, v4d64 & R, int q, int col)
+  NMPC_D static void naturalBackColumn(const Vec4 & Ln, Vec4 & R, int q, int col)
   {
     constexpr int rk = K / 4, qk = K % 4;
-    const double xk = fromLane(R[rk], 16 * qk + col);
+    const S xk = fromLane(R[rk], 16 * qk + col);
 #pragma unroll
     for(int rr = 0; rr <= rk; rr++)
     {
-      double l = fromRowLane<K>(Ln[rr]); // entry (i, K) d_i^-1 = L_Ki of this lane's row i
+      S l = fromRowLane<K>(Ln[rr]); // entry (i, K) d_i^-1 = L_Ki of this lane's row i
       if(rr == rk)
       {
         l = (q < qk) ? l : 0.0;
@@ -1840,7 +1919,7 @@ struct TileSolver64
     }
   }
   template<int J>
-  NMPC_D static void naturalForward(v4d64 & Aq, v4d64 & R, v4d64 & invd, bool & ok, int q, int col, int m)
+  NMPC_D static void naturalForward(Vec4 & Aq, Vec4 & R, Vec4 & invd, bool & ok, int q, int col, int m)
   {
     if constexpr(J < MM)
     {
@@ -1852,7 +1931,7 @@ struct TileSolver64
     }
   }
   template<int K>
-  NMPC_D static void naturalBackward(const v4d64 & Ln, v4d64 & R, int q, int col, int m)
+  NMPC_D static void naturalBackward(const Vec4 & Ln, Vec4 & R, int q, int col, int m)
   {
     if constexpr(K >= 1)
     {
@@ -1866,9 +1945,9 @@ struct TileSolver64
   /** Phases 1c - 3b for kBig: A = [K | k] = - Quu_F^-1 [Qux_reg | Qu] (zero for m = 0: :513-517), then the value update's operands.
       W: the wave's transposition scratch (the lower triangle of Quu_F is mirrored through it: the reference's LLT reads the
       lower triangle only, :500). */
-  NMPC_D void stepGainsNatural(StepCtx & c, double * W, int m, v4d64 & QQ) const
+  NMPC_D void stepGainsNatural(StepCtx & c, S * W, int m, Vec4 & QQ) const
   {
-    const int fl = freshLane(), q = fl >> 4, col = fl & 15;
+    const int fl = freshLane(), q = fl >> 4, col = colOf(fl & 15);
     // Quu_F <- its lower triangle, mirrored
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
@@ -1876,16 +1955,16 @@ struct TileSolver64
       W[wT + (4 * rr + q) * kTrLd + col] = c.QuuF[rr];
     }
     fence();
-    v4d64 Aq = {0, 0, 0, 0}, R = {0, 0, 0, 0}, invd = {1, 1, 1, 1};
-    QQ = v4d64{0, 0, 0, 0};
+    Vec4 Aq = {0, 0, 0, 0}, R = {0, 0, 0, 0}, invd = {1, 1, 1, 1};
+    QQ = Vec4{0, 0, 0, 0};
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
       const int row = 4 * rr + q;
-      const double mirrored = W[wT + col * kTrLd + row]; // entry (col, row)
+      const S mirrored = W[wT + col * kTrLd + row]; // entry (col, row)
       Aq[rr] = (row >= col) ? c.QuuF[rr] : mirrored;
       // Qu, Qx from a row of lanes (lane group qN: entry j in lane j) to column n of the tiles
-      const double qu_c = fromLane(c.qurow, 16 * qN + (row & 15));
+      const S qu_c = fromLane(c.qurow, 16 * qN + laneOfCol(row & 15));
       R[rr] = (col < N) ? c.QuxR[rr] : ((col == N) ? qu_c : 0.0);
       QQ[rr] = (col < N) ? c.Qux[rr] : ((col == N) ? qu_c : 0.0);
     }
@@ -1894,13 +1973,13 @@ struct TileSolver64
     for(int rr = 0; rr < 4; rr++)
     {
       const int row = 4 * rr + q;
-      const double qx_c = fromLane(c.qxrow, 16 * qN + (row & 15));
+      const S qx_c = fromLane(c.qxrow, 16 * qN + laneOfCol(row & 15));
       c.qxcol[rr] = (col == N && row < N) ? qx_c : 0.0;
     }
     bool ok_now = true;
     naturalForward<0>(Aq, R, invd, ok_now, q, col, m);
     // D^-1, then L^T x = z column by column
-    v4d64 Ln = {0, 0, 0, 0};
+    Vec4 Ln = {0, 0, 0, 0};
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
@@ -1908,7 +1987,7 @@ struct TileSolver64
       Ln[rr] = Aq[rr] * invd[rr];
     }
     naturalBackward<MM - 1>(Ln, R, q, col, m);
-    c.A = v4d64{0, 0, 0, 0};
+    c.A = Vec4{0, 0, 0, 0};
 #pragma unroll
     for(int rr = 0; rr < KM; rr++)
     {
@@ -1920,10 +1999,10 @@ struct TileSolver64
   /** k_i, K_i -> the instance's gain record (:529-530); not after a failed factorisation: backwardPass() returned before storing (:505-508). */
   NMPC_D void stepStoreGains(const StepCtx & c, int b, int i) const
   {
-    const int q = lane >> 4, j = lane & 15;
+    const int q = lane >> 4, j = colOf(lane & 15);
     if(c.ok && j <= N)
     {
-      double * rec_g = buf.wpi_ws + (static_cast<size_t>(b) * T + i) * kGainRows;
+      S * rec_g = buf.wpi_ws + (static_cast<size_t>(b) * T + i) * kGainRows;
 #pragma unroll
       for(int rr = 0; rr < KM; rr++)
       {
@@ -1938,16 +2017,16 @@ struct TileSolver64
 
   /** One timestep of one instance.  VV = [Vxx | Vx] in natural layout (in / out), r = the instance's record of this timestep,
       ok = no factorisation of this sweep has failed yet (in / out).  Everything but the lane id is wave-uniform. */
-  NMPC_D void backwardStep(v4d64 & VV, bool & ok, const LaneMap & mp, const LaneAddr & la_sweep, const double * r, int slot, int b, int i,
-                           double lambda) const
+  NMPC_D void backwardStep(Vec4 & VV, bool & ok, const LaneMap & mp, const LaneAddr & la_sweep, const S * r, int slot, int b, int i,
+                           S lambda) const
   {
-    double * W = waveScratch(0);
+    S * W = waveScratch(0);
     LaneAddr la = la_sweep;
     asm volatile("" : "+v"(la.ew_equ), "+v"(la.eqx_rq), "+v"(la.rx_tw), "+v"(la.tr_trn)); // (unpacked here, not once per sweep)
     StepCtx c;
     c.VV = VV;
     c.ok = ok;
-    v4d64 F0, F1, L0, L1, L2;
+    Vec4 F0, F1, L0, L1, L2;
     stepQTerms(c, mp, r, F0, F1, L0, L1, L2);
     if(cfg.reg_type == 2)
     {
@@ -1998,25 +2077,25 @@ struct TileSolver64
     static_assert(kT64MaxPerWave == 5, "the rotations below are written for five slots per wave");
     const LaneMap mp = makeLaneMap();
     const LaneAddr la = makeLaneAddr();
-    const int q = lane >> 4, j = lane & 15;
+    const int q = lane >> 4, j = colOf(lane & 15);
     const int mw = wave - 1;
     const int n_act = uniform(meta(mNAct)), chunk = uniform(meta(mChunk));
-    v4d64 V0, V1, V2, V3, V4;
+    Vec4 V0, V1, V2, V3, V4;
     unsigned ok_mask = ~0u;
     barrier(); // the terminal records are complete
-    auto loadTerminal = [&](int e) -> v4d64
+    auto loadTerminal = [&](int e) -> Vec4
     {
       const int a = mw + kT64MatrixWaves * e;
-      v4d64 v = {0, 0, 0, 0};
+      Vec4 v = {0, 0, 0, 0};
       if(a < n_act)
       {
         const int slot = uniform(actSlot(a));
-        const double * tr = term(slot);
+        const S * tr = term(slot);
 #pragma unroll
         for(int rr = 0; rr < 4; rr++)
         {
           const int row = 4 * rr + q;
-          const double t = tr[(row < N && j <= N) ? j * N + row : 0];
+          const S t = tr[(row < N && j <= N) ? j * N + row : 0];
           v[rr] = (row < N && j <= N) ? t : 0.0;
         }
         if(lane == kStarLane)
@@ -2055,7 +2134,7 @@ struct TileSolver64
             ok_mask = ok ? ok_mask : (ok_mask & ~(1u << e));
             profAdd(4, 1, 1);
           }
-          const v4d64 t = V0;
+          const Vec4 t = V0;
           V0 = V1;
           V1 = V2;
           V2 = V3;
@@ -2101,7 +2180,7 @@ struct TileSolver64
     const int slot = actSlot(lane_used ? a : 0);
     const int b = group * G + slot;
     const int sel = slotI(sSel, slot);
-    const double t0 = slotF(sT0, slot);
+    const S t0 = slotF(sT0, slot);
     const Problem mine_p = problemOf(lane_used ? b : group * G + actSlot(0));
     Point next;
     if(lane_used && T - 1 - dt >= 0)
@@ -2123,15 +2202,8 @@ struct TileSolver64
       const bool mine = lane_used && step >= 0;
       if(mine)
       {
-        double * dst = recAt(parity, dt, a, chunk, n_act);
-        if(n_chunk < 2)
-        {
-          lineariseStep<true>(mine_p, dst, t0, step, next); // the first use of a record buffer in the sweep: every entry
-        }
-        else
-        {
-          lineariseStep<false>(mine_p, dst, t0, step, next);
-        }
+        S * dst = recAt(parity, dt, a, chunk, n_act);
+        lineariseStep(mine_p, dst, t0, step, next, n_chunk < 2); // (the first use of a record buffer in the sweep: every entry)
       }
       __builtin_amdgcn_sched_barrier(0);
       if(lane_used && step - chunk >= 0)
@@ -2171,7 +2243,7 @@ struct TileSolver64
       }
       const Problem mine = problemOf(0);
       TableSink sink{tbl()};
-      const double t_probe = buf.t0 ? buf.t0[0] : 0.0;
+      const S t_probe = buf.t0 ? buf.t0[0] : 0.0;
       const int m_probe = inputDimOf(mine, t_probe);
       if constexpr(kDyn)
       {
@@ -2206,7 +2278,7 @@ struct TileSolver64
 
   /** The trace row of the iteration in progress lives in LDS (field-major: the owner lanes spread over the banks), not in
       twelve registers that would be live across every rollout and linearisation. */
-  NMPC_D double & trF(int f, int slot) const
+  NMPC_D S & trF(int f, int slot) const
   {
     return lds[kTraceAt + f * kT64MaxGroup + slot];
   }
@@ -2223,7 +2295,7 @@ struct TileSolver64
     if(cfg.trace_level >= 1 && row < buf.trace_rows)
     {
       const size_t tile = tileOf(b), ln = lnOf(b);
-      double * p = buf.trace + (tile * (static_cast<size_t>(buf.trace_rows) * NMPC_HIP_NTRACE)) * 64 + ln;
+      S * p = buf.trace + (tile * (static_cast<size_t>(buf.trace_rows) * NMPC_HIP_NTRACE)) * 64 + ln;
 #pragma unroll
       for(int f = 0; f < NMPC_HIP_NTRACE; f++)
       {
@@ -2274,7 +2346,7 @@ struct TileSolver64
     const bool owner = model_wave && lane < G && b < buf.B; // this lane drives an instance
     const bool slot_lane = model_wave && lane < kT64MaxGroup;
     const int p_lane_matrix = (wave - 1) * 64 + lane, p_count_matrix = kT64MatrixWaves * 64;
-    double * lsJ = lds + kLsAt;
+    S * lsJ = lds + kLsAt;
 
     // ---- solve(): reset, initial rollout    :36-38, :83-104
     if(slot_lane)
@@ -2287,8 +2359,8 @@ struct TileSolver64
       slotI(sIter, slot) = 0;
       slotI(sRet, slot) = 0;
       slotI(sFlags, slot) = owner ? fRunning : 0;
-      slotF(sLambda, slot) = cfg.initial_lambda;
-      slotF(sDlambda, slot) = cfg.initial_dlambda;
+      slotF(sLambda, slot) = sc(cfg.initial_lambda);
+      slotF(sDlambda, slot) = sc(cfg.initial_dlambda);
       slotF(sT0, slot) = (owner && buf.t0) ? buf.t0[b] : 0.0;
       slotF(sDV0, slot) = 0;
       slotF(sDV1, slot) = 0;
@@ -2324,7 +2396,7 @@ struct TileSolver64
           slotI(sRet, slot) = 0;
           slotI(sNBw, slot) = 0;
           clearTrace(slot);
-          trF(NMPC_HIP_TRACE_ITER, slot) = static_cast<double>(iter + 1);
+          trF(NMPC_HIP_TRACE_ITER, slot) = static_cast<S>(iter + 1);
           trF(NMPC_HIP_TRACE_ALPHA_IDX, slot) = -1;
         }
         slotI(sFlags, slot) = flags;
@@ -2364,11 +2436,11 @@ struct TileSolver64
             slotT(sTicksBw, slot) += __builtin_readcyclecounter() - p0;
             if(slotI(sOk, slot) == 0)
             {
-              const double dlambda = fmax(slotF(sDlambda, slot) * cfg.lambda_factor, cfg.lambda_factor); // :191-209
-              const double lambda = fmax(slotF(sLambda, slot) * dlambda, cfg.lambda_min);
+              const S dlambda = fmax(slotF(sDlambda, slot) * sc(cfg.lambda_factor), sc(cfg.lambda_factor)); // :191-209
+              const S lambda = fmax(slotF(sLambda, slot) * dlambda, sc(cfg.lambda_min));
               slotF(sDlambda, slot) = dlambda;
               slotF(sLambda, slot) = lambda;
-              if(lambda > cfg.lambda_max)
+              if(lambda > sc(cfg.lambda_max))
               {
                 slotI(sRet, slot) = -1;
                 flags &= ~fNeedBw;
@@ -2405,12 +2477,12 @@ struct TileSolver64
         bool in_ls = false;
         if((flags & fInIter) != 0)
         {
-          trF(NMPC_HIP_TRACE_N_BACKWARD, slot) = static_cast<double>(slotI(sNBw, slot));
+          trF(NMPC_HIP_TRACE_N_BACKWARD, slot) = static_cast<S>(slotI(sNBw, slot));
           if(slotI(sRet, slot) == 0)
           {
-            const double krel = kKrelSquared ? sqrt(slotF(sKrel, slot)) : slotF(sKrel, slot);
+            const S krel = kKrelSquared ? sqrt(slotF(sKrel, slot)) : slotF(sKrel, slot);
             trF(NMPC_HIP_TRACE_K_REL_NORM, slot) = krel;
-            if(krel < cfg.k_rel_norm_thre && slotF(sLambda, slot) < cfg.lambda_thre)
+            if(krel < sc(cfg.k_rel_norm_thre) && slotF(sLambda, slot) < sc(cfg.lambda_thre))
             {
               slotI(sRet, slot) = 1;
             }
@@ -2447,12 +2519,12 @@ struct TileSolver64
         // choice (:242-265).  One call site of stagedPass: one copy of the model's rollout code in the kernel.
         const unsigned long long p0 = __builtin_readcyclecounter();
         /** judge step size ai of this lane's slot with cost Jc    :247-264 */
-        auto judge = [&](int ai, double Jc) -> bool
+        auto judge = [&](int ai, S Jc) -> bool
         {
-          const double alpha = cfg.alpha_list[ai];
-          const double actual = slotF(sJcur, slot) - Jc;
-          const double expected = -1 * alpha * (slotF(sDV0, slot) + alpha * slotF(sDV1, slot));
-          double ratio = actual / expected;
+          const S alpha = sc(cfg.alpha_list[ai]);
+          const S actual = slotF(sJcur, slot) - Jc;
+          const S expected = -1 * alpha * (slotF(sDV0, slot) + alpha * slotF(sDV1, slot));
+          S ratio = actual / expected;
           if(expected < 0)
           {
             ratio = (actual >= 0 ? 1 : -1); // :251-259
@@ -2463,7 +2535,7 @@ struct TileSolver64
           slotF(sRatio, slot) = ratio;
           slotF(sJcand, slot) = Jc;
           slotI(sAi, slot) = ai;
-          return ratio > cfg.cost_update_ratio_thre;
+          return ratio > sc(cfg.cost_update_ratio_thre);
         };
         const int later_per_wave = laterPerWave();
         const int covered = later_per_wave * kT64MatrixWaves;
@@ -2479,7 +2551,7 @@ struct TileSolver64
           // ---- what this lane does in this pass
           bool compute, active = false, store = true;
           int pb = 0, pinst = 0, phalf = 0, pai = 0;
-          double pt0 = 0, palpha = 0;
+          S pt0 = 0, palpha = 0;
           if(pass == 0)
           {
             compute = model_wave;
@@ -2498,7 +2570,7 @@ struct TileSolver64
               pinst = slot;
               phalf = slotI(sSel, slot) ^ 1;
               pt0 = slotF(sT0, slot);
-              palpha = (pass == 1) ? cfg.alpha_list[0] : slotF(sAlpha, slot);
+              palpha = (pass == 1) ? sc(cfg.alpha_list[0]) : slotF(sAlpha, slot);
             }
           }
           else
@@ -2521,7 +2593,7 @@ struct TileSolver64
                 pinst = fslot;
                 phalf = slotI(sSel, fslot) ^ 1;
                 pt0 = slotF(sT0, fslot);
-                palpha = cfg.alpha_list[pai];
+                palpha = sc(cfg.alpha_list[pai]);
               }
             }
           }
@@ -2544,7 +2616,7 @@ struct TileSolver64
             p_count = (kT64MatrixWaves - waves_rolling) * 64;
           }
           const bool to_workspace = adopt && !store && compute && active; // (a later step size, rolled out for its cost)
-          const double Jc = stagedPass(compute, pass == 0, theirs, active, group, pb, pinst, phalf, pt0, palpha, store || to_workspace,
+          const S Jc = stagedPass(compute, pass == 0, theirs, active, group, pb, pinst, phalf, pt0, palpha, store || to_workspace,
                                        p_lane, p_count, to_workspace ? pai - 1 : -1);
           // ---- what follows from it
           if(pass == 0)
@@ -2554,8 +2626,8 @@ struct TileSolver64
               slotF(sJcur, slot) = Jc;
               slotT(sTicksFw, slot) += __builtin_readcyclecounter() - p0;
               trF(NMPC_HIP_TRACE_COST, slot) = Jc;
-              trF(NMPC_HIP_TRACE_LAMBDA, slot) = cfg.initial_lambda;
-              trF(NMPC_HIP_TRACE_DLAMBDA, slot) = cfg.initial_dlambda;
+              trF(NMPC_HIP_TRACE_LAMBDA, slot) = sc(cfg.initial_lambda);
+              trF(NMPC_HIP_TRACE_DLAMBDA, slot) = sc(cfg.initial_dlambda);
               trF(NMPC_HIP_TRACE_ALPHA_IDX, slot) = -1;
               writeTraceRow(b, 0, slot);
             }
@@ -2690,24 +2762,24 @@ struct TileSolver64
         {
           const bool success = (slotI(sFlags, slot) & fSuccess) != 0;
           const int ai_taken = slotI(sAi, slot);
-          double lambda = slotF(sLambda, slot), dlambda = slotF(sDlambda, slot);
+          S lambda = slotF(sLambda, slot), dlambda = slotF(sDlambda, slot);
           slotT(sTicksFw, slot) += __builtin_readcyclecounter() - p0;
           trF(NMPC_HIP_TRACE_ALPHA, slot) = slotF(sAlpha, slot);
           trF(NMPC_HIP_TRACE_COST_UPDATE_ACTUAL, slot) = slotF(sActual, slot);
           trF(NMPC_HIP_TRACE_COST_UPDATE_EXPECTED, slot) = slotF(sExpected, slot);
           trF(NMPC_HIP_TRACE_COST_UPDATE_RATIO, slot) = slotF(sRatio, slot);
-          trF(NMPC_HIP_TRACE_ALPHA_IDX, slot) = static_cast<double>(ai_taken);
-          trF(NMPC_HIP_TRACE_N_FORWARD, slot) = static_cast<double>(success ? ai_taken + 1 : cfg.n_alpha);
+          trF(NMPC_HIP_TRACE_ALPHA_IDX, slot) = static_cast<S>(ai_taken);
+          trF(NMPC_HIP_TRACE_N_FORWARD, slot) = static_cast<S>(success ? ai_taken + 1 : cfg.n_alpha);
           if(success)
           {
             slotI(sSel, slot) ^= 1;
             slotF(sJcur, slot) = slotF(sJcand, slot);
-            if(slotF(sActual, slot) < cfg.cost_update_thre)
+            if(slotF(sActual, slot) < sc(cfg.cost_update_thre))
             {
               slotI(sRet, slot) = 1;
             }
-            dlambda = fmin(dlambda / cfg.lambda_factor, 1 / cfg.lambda_factor);
-            if(lambda >= cfg.lambda_min)
+            dlambda = fmin(dlambda / sc(cfg.lambda_factor), 1 / sc(cfg.lambda_factor));
+            if(lambda >= sc(cfg.lambda_min))
             {
               lambda *= dlambda;
             }
@@ -2718,9 +2790,9 @@ struct TileSolver64
           }
           else
           {
-            dlambda = fmax(dlambda * cfg.lambda_factor, cfg.lambda_factor);
-            lambda = fmax(lambda * dlambda, cfg.lambda_min);
-            if(lambda > cfg.lambda_max)
+            dlambda = fmax(dlambda * sc(cfg.lambda_factor), sc(cfg.lambda_factor));
+            lambda = fmax(lambda * dlambda, sc(cfg.lambda_min));
+            if(lambda > sc(cfg.lambda_max))
             {
               slotI(sRet, slot) = -1;
             }
@@ -2818,19 +2890,20 @@ struct TileSolver64
 template<class Problem, bool kConstrained, bool kOwnProblem>
 __global__ __launch_bounds__(kT64Threads) void ddp_solve_tile64_kernel(const Problem problem,
                                                                         const nmpc_hip_ddp_config cfg,
-                                                                        const DeviceBuffers buf,
+                                                                        const DeviceBuffersT<typename Problem::Scalar> buf,
                                                                         const int group_cap)
 {
   // (a STATIC array: the address of a dynamic one — extern __shared__ — is a symbol until after instruction selection, and
   // every LDS access of the kernel carried a leftover `v_add_u32 v, 0, v`: twenty of them per backward step)
-  __shared__ __attribute__((aligned(16))) double lds_tile64[kT64LdsBytes / sizeof(double)];
+  __shared__ __attribute__((aligned(16))) typename Problem::Scalar lds_tile64[kT64LdsBytes / sizeof(typename Problem::Scalar)];
   TileSolver64<Problem, kConstrained, kOwnProblem> solver(problem, cfg, buf, lds_tile64, group_cap);
   solver.run();
 }
 
 /** Launch helper for model_registry.hpp. */
 template<class Problem, bool kConstrained, bool kOwnProblem>
-inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_config & cfg, const DeviceBuffers & buf, hipStream_t stream)
+inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_config & cfg, const DeviceBuffersT<typename Problem::Scalar> & buf,
+                               hipStream_t stream)
 {
   // per device: 0 until the attribute is set and the CU count known (published last, with release order: handles of
   // several host threads may launch at once — DDPSolverPool, DDPSolverSharded; a second thread repeats the harmless setup)

@@ -11,19 +11,30 @@
 
 namespace nmpc_amd
 {
-class DDPProblemManipulator : public DDPProblem<14, 7>
+/** \tparam Real double ("manipulator": the reference's arithmetic) or float ("manipulator_f32": the fp64 tile kernel's float
+    instantiation — the fp32 shape with seven inputs that ddp_kernels_tile32.hpp does not take). */
+template<class Real>
+class DDPProblemManipulatorT : public DDPProblemT<Real, 14, 7>
 {
+  using Base = DDPProblemT<Real, 14, 7>;
+
 public:
-  static constexpr const char * kName = "manipulator";
+  using typename Base::InputDimVector;
+  using typename Base::InputInputDimMatrix;
+  using typename Base::StateDimVector;
+  using typename Base::StateInputDimMatrix;
+  using typename Base::StateStateDimMatrix;
+  using Base::dt_;
+  static constexpr const char * kName = sizeof(Real) == 4 ? "manipulator_f32" : "manipulator";
   static constexpr int kJoints = 7;
 
-  NMPC_HD explicit DDPProblemManipulator(double dt = 0.01) : DDPProblem(dt) {}
+  NMPC_HD explicit DDPProblemManipulatorT(Real dt = Real(0.01)) : Base(dt) {}
 
-  NMPC_HD double gravityGain(int j) const
+  NMPC_HD Real gravityGain(int j) const
   {
-    return grav_scale_ * static_cast<double>(kJoints - j) / kJoints;
+    return grav_scale_ * static_cast<Real>(kJoints - j) / kJoints;
   }
-  NMPC_HD double refAngle(int j) const
+  NMPC_HD Real refAngle(int j) const
   {
     return (j % 2 == 1) ? -q_ref_scale_ : q_ref_scale_;
   }
@@ -32,17 +43,17 @@ public:
       call per use — the Jacobian alone refers to them ~400 times. */
   struct Trig
   {
-    double cd[kJoints][kJoints], sd[kJoints][kJoints]; // cos / sin (q_i - q_j)
-    double cum_angle[kJoints], sc[kJoints], cc[kJoints]; // cumulative angle, its sin / cos
+    Real cd[kJoints][kJoints], sd[kJoints][kJoints]; // cos / sin (q_i - q_j)
+    Real cum_angle[kJoints], sc[kJoints], cc[kJoints]; // cumulative angle, its sin / cos
     NMPC_HD explicit Trig(const StateDimVector & x)
     {
       for(int i = 0; i < kJoints; i++)
       {
-        cd[i][i] = 1.0;
-        sd[i][i] = 0.0;
+        cd[i][i] = Real(1);
+        sd[i][i] = Real(0);
         for(int j = i + 1; j < kJoints; j++)
         {
-          double s, c;
+          Real s, c;
           sincosFast(x[i] - x[j], s, c);
           cd[i][j] = c;
           cd[j][i] = c;
@@ -50,7 +61,7 @@ public:
           sd[j][i] = -s;
         }
       }
-      double angle = 0;
+      Real angle = 0;
       for(int j = 0; j < kJoints; j++)
       {
         angle += x[j];
@@ -59,13 +70,13 @@ public:
       }
     }
   };
-  NMPC_HD double coupling(const Trig & g, int i, int j) const
+  NMPC_HD Real coupling(const Trig & g, int i, int j) const
   {
-    return (i == j ? w_diag_ : 0.0) + w_off_ * g.cd[i][j];
+    return (i == j ? w_diag_ : Real(0)) + w_off_ * g.cd[i][j];
   }
 
   /** Net joint torques r. */
-  NMPC_HD void netTorque(const Trig & g, const StateDimVector & x, const InputDimVector & u, double * r) const
+  NMPC_HD void netTorque(const Trig & g, const StateDimVector & x, const InputDimVector & u, Real * r) const
   {
     for(int j = 0; j < kJoints; j++)
     {
@@ -73,17 +84,17 @@ public:
     }
   }
 
-  NMPC_HD StateDimVector stateEq(double, // t
+  NMPC_HD StateDimVector stateEq(Real, // t
                                  const StateDimVector & x,
                                  const InputDimVector & u) const
   {
     const Trig g(x);
-    double r[kJoints];
+    Real r[kJoints];
     netTorque(g, x, u, r);
     StateDimVector x_next;
     for(int i = 0; i < kJoints; i++)
     {
-      double acc = 0;
+      Real acc = 0;
       for(int j = 0; j < kJoints; j++)
       {
         acc += coupling(g, i, j) * r[j];
@@ -94,44 +105,44 @@ public:
     return x_next;
   }
 
-  NMPC_HD double runningCost(double, const StateDimVector & x, const InputDimVector & u) const
+  NMPC_HD Real runningCost(Real, const StateDimVector & x, const InputDimVector & u) const
   {
-    double cost_x = 0;
+    Real cost_x = 0;
     for(int j = 0; j < kJoints; j++)
     {
-      const double e = x[j] - refAngle(j);
+      const Real e = x[j] - refAngle(j);
       cost_x += wq_ * (e * e);
     }
     for(int j = 0; j < kJoints; j++)
     {
       cost_x += wv_ * (x[kJoints + j] * x[kJoints + j]);
     }
-    return 0.5 * cost_x + 0.5 * wu_ * u.squaredNorm();
+    return Real(0.5) * cost_x + Real(0.5) * wu_ * u.squaredNorm();
   }
 
-  NMPC_HD double terminalCost(double, const StateDimVector & x) const
+  NMPC_HD Real terminalCost(Real, const StateDimVector & x) const
   {
-    double cost_x = 0;
+    Real cost_x = 0;
     for(int j = 0; j < kJoints; j++)
     {
-      const double e = x[j] - refAngle(j);
+      const Real e = x[j] - refAngle(j);
       cost_x += (wt_scale_ * wq_) * (e * e);
     }
     for(int j = 0; j < kJoints; j++)
     {
       cost_x += (wt_scale_ * wv_) * (x[kJoints + j] * x[kJoints + j]);
     }
-    return 0.5 * cost_x;
+    return Real(0.5) * cost_x;
   }
 
-  NMPC_HD void calcStateEqDeriv(double, // t
+  NMPC_HD void calcStateEqDeriv(Real, // t
                                 const StateDimVector & x,
                                 const InputDimVector & u,
                                 StateStateDimMatrix & state_eq_deriv_x,
                                 StateInputDimMatrix & state_eq_deriv_u) const
   {
     const Trig g(x);
-    double r[kJoints];
+    Real r[kJoints];
     netTorque(g, x, u, r);
 
     state_eq_deriv_x.setIdentity();
@@ -141,20 +152,20 @@ public:
       state_eq_deriv_x(i, kJoints + i) = dt_;
 
       // sum_j sin(q_i - q_j) r_j : derivative of row i of W w.r.t. its own angle
-      double own = 0;
+      Real own = 0;
       for(int j = 0; j < kJoints; j++)
       {
         own += g.sd[i][j] * r[j];
       }
       for(int l = 0; l < kJoints; l++)
       {
-        double d_coupling = w_off_ * g.sd[i][l] * r[l];
+        Real d_coupling = w_off_ * g.sd[i][l] * r[l];
         if(l == i)
         {
           d_coupling += -w_off_ * own;
         }
         // gravity torque of joint j depends on q_l for every l <= j
-        double d_gravity = 0;
+        Real d_gravity = 0;
         for(int j = l; j < kJoints; j++)
         {
           d_gravity += coupling(g, i, j) * (gravityGain(j) * g.cc[j]);
@@ -166,7 +177,7 @@ public:
     }
   }
 
-  NMPC_HD void calcRunningCostDeriv(double, // t
+  NMPC_HD void calcRunningCostDeriv(Real, // t
                                     const StateDimVector & x,
                                     const InputDimVector & u,
                                     StateDimVector & running_cost_deriv_x,
@@ -189,7 +200,7 @@ public:
     running_cost_deriv_xu.setZero();
   }
 
-  NMPC_HD void calcTerminalCostDeriv(double, // t
+  NMPC_HD void calcTerminalCostDeriv(Real, // t
                                      const StateDimVector & x,
                                      StateDimVector & terminal_cost_deriv_x,
                                      StateStateDimMatrix & terminal_cost_deriv_xx) const
@@ -205,12 +216,14 @@ public:
   }
 
 public:
-  double w_diag_ = 2.0;
-  double w_off_ = 0.15;
-  double damping_ = 0.5;
-  double grav_scale_ = 4.0;
-  double wq_ = 1.0, wv_ = 0.05, wu_ = 0.002;
-  double wt_scale_ = 20.0;
-  double q_ref_scale_ = 0.3;
+  Real w_diag_ = Real(2.0);
+  Real w_off_ = Real(0.15);
+  Real damping_ = Real(0.5);
+  Real grav_scale_ = Real(4.0);
+  Real wq_ = Real(1.0), wv_ = Real(0.05), wu_ = Real(0.002);
+  Real wt_scale_ = Real(20.0);
+  Real q_ref_scale_ = Real(0.3);
 };
+using DDPProblemManipulator = DDPProblemManipulatorT<double>;
+using DDPProblemManipulatorF32 = DDPProblemManipulatorT<float>;
 } // namespace nmpc_amd

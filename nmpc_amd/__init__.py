@@ -6,4 +6,4 @@ run in libnmpc_hip_ddp.so (hand-written HIP for gfx950) through the C-ABI of inc
 from .ddp import (ComputationDuration, Configuration, ControlData, DDPSolverBatch, DDPSolverPool, MpcLog,  # noqa: F401
                   TraceData)
 from .models import (DDPProblemBipedal, DDPProblemCartPole, DDPProblemCartPoleF32, DDPProblemCentroidalMotion,  # noqa: F401
-                     DDPProblemManipulator, DDPProblemQuadrotor, DDPProblemVerticalMotion, make_problem)
+                     DDPProblemManipulator, DDPProblemManipulatorF32, DDPProblemQuadrotor, DDPProblemVerticalMotion, make_problem)

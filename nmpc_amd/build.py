@@ -17,7 +17,7 @@ LIB_DIR = os.path.join(ROOT, "nmpc_amd", "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libnmpc_hip_ddp.so")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 SOURCES = ("capi.hip", "builtin_models.hip", "model_centroidal.hip", "model_quadrotor.hip", "model_manipulator.hip",
-           "model_quadrotor_f32.hip", "model_cartpole_f32.hip", "model_planar_vtol.hip", "fmpc_capi.hip", "fmpc_models.hip")
+           "model_quadrotor_f32.hip", "model_cartpole_f32.hip", "model_manipulator_f32.hip", "model_planar_vtol.hip", "fmpc_capi.hip", "fmpc_models.hip")
 ARCH = "gfx950"
 # per-source flags.  builtin_models.hip holds the quad kernel (ddp_kernels_quad.hpp): its fp64 matrix-core results are
 # consumed by VALU / DPP instructions right away, so they have to live in ordinary VGPRs — by default a kernel that may

@@ -149,6 +149,18 @@ class DDPProblemManipulator(_Problem):
                     ("wt_scale", C.c_double), ("q_ref_scale", C.c_double)]
 
 
+class DDPProblemManipulatorF32(_Problem):
+    """The manipulator in float (DDPProblemManipulatorT<float>): an fp32 shape with seven inputs — the fp64 tile kernel's float
+    instantiation (the fp32 tile kernel takes m <= 4, n in {4, 8, 12})."""
+
+    name = "manipulator_f32"
+
+    class _Blob(C.Structure):
+        _fields_ = [("dt", C.c_float), ("w_diag", C.c_float), ("w_off", C.c_float), ("damping", C.c_float),
+                    ("grav_scale", C.c_float), ("wq", C.c_float), ("wv", C.c_float), ("wu", C.c_float),
+                    ("wt_scale", C.c_float), ("q_ref_scale", C.c_float)]
+
+
 class DDPProblemPlanarVtol(_Problem):
     """include/nmpc_amd/models/PlanarVtol.hpp (builder-defined n = 6, m = 2: the 5 <= n <= 8 shapes on the fp64 tile kernel)."""
 
@@ -162,7 +174,7 @@ class DDPProblemPlanarVtol(_Problem):
 
 PROBLEMS = {c.name: c for c in (DDPProblemCartPole, DDPProblemCartPoleF32, DDPProblemBipedal, DDPProblemVerticalMotion,
                                 DDPProblemCentroidalMotion, DDPProblemQuadrotor, DDPProblemQuadrotorF32,
-                                DDPProblemManipulator, DDPProblemPlanarVtol)}
+                                DDPProblemManipulator, DDPProblemManipulatorF32, DDPProblemPlanarVtol)}
 
 
 def make_problem(name: str, **kw) -> _Problem:

@@ -120,8 +120,9 @@ def planar_vtol_batch(B: int = 4096, T: int = 60, seed: int = 1234, constrained:
     return Workload("planar_vtol_batch", "planar_vtol", 6, 2, T, B, 0.02, x0, np.full((B, T, 2), hover), np.zeros(B), limits=limits)
 
 
-def manipulator_batch(B: int = 8192, T: int = 30, seed: int = 1234, constrained: bool = False) -> Workload:
-    """C5 (per-GPU shard): q0 ~ U[-1,1]^7, qd0 ~ U[-0.5,0.5]^7, u_init = gravity compensation at q0, dt = 0.01."""
+def manipulator_batch(B: int = 8192, T: int = 30, seed: int = 1234, constrained: bool = False, fp32: bool = False) -> Workload:
+    """C5 (per-GPU shard): q0 ~ U[-1,1]^7, qd0 ~ U[-0.5,0.5]^7, u_init = gravity compensation at q0, dt = 0.01.  fp32: the
+    problem type instantiated in float ("manipulator_f32")."""
     u = splitmix64_uniform(seed, 14 * B).reshape(B, 14)
     q0 = -1.0 + 2.0 * u[:, :7]
     qd0 = -0.5 + 1.0 * u[:, 7:]
@@ -129,7 +130,7 @@ def manipulator_batch(B: int = 8192, T: int = 30, seed: int = 1234, constrained:
     grav = 4.0 * (7 - np.arange(7)) / 7.0
     u_gc = grav[None, :] * np.sin(np.cumsum(q0, axis=1))
     limits = (np.full(7, -3.0), np.full(7, 3.0)) if constrained else None  # joint torque box
-    return Workload("manipulator_batch", "manipulator", 14, 7, T, B, 0.01, x0,
+    return Workload("manipulator_batch", "manipulator_f32" if fp32 else "manipulator", 14, 7, T, B, 0.01, x0,
                     np.repeat(u_gc[:, None, :], T, axis=1).copy(), np.zeros(B), limits=limits)
 
 

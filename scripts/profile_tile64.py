@@ -14,12 +14,15 @@ model = sys.argv[1] if len(sys.argv) > 1 else "manipulator"
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 mi = int(sys.argv[4]) if len(sys.argv) > 4 else 8
-wl = workloads.quadrotor_batch(B=B, T=T, seed=1234) if model == "quadrotor" else workloads.manipulator_batch(B=B, T=T, seed=1234)
+f32 = len(sys.argv) > 5 and sys.argv[5] == "f32"  # (quadrotor_f32: the kernel's float instantiation)
+wl = workloads.quadrotor_batch(B=B, T=T, seed=1234, fp32=f32) if model == "quadrotor" else workloads.manipulator_batch(B=B, T=T, seed=1234)
 s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B)
 c = s.config()
 c.print_level = 0
 c.horizon_steps = wl.T
 c.max_iter = mi
+if f32:
+    c.cost_update_thre = 1e-3
 for _ in range(2):
     s.solve(wl.t0, wl.x0, wl.u_init)
 _m = s.qpFreeMask()

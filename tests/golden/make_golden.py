@@ -17,6 +17,7 @@ Cases (SURVEY.md §8 c "golden fixtures to commit"):
   quadrotor T=50, manipulator T=30: 2 seeds each, 10 iterations
   planar_vtol T=60 (n 6, m 2): 2 seeds, 10 iterations; one box-constrained
   quadrotor_f32 T=50: 2 seeds, 3 iterations, cost_update_thre 1e-3 (the oracle instantiated in float); + 1 box-constrained, 1 iteration
+  manipulator_f32 T=30: 1 seed, 2 iterations (fp32 with seven inputs)
 """
 import os
 import sys
@@ -114,6 +115,11 @@ def main():
     run_case(store, "quadrotor_f32_box", "quadrotor_f32", dict(horizon_steps=50, max_iter=1, cost_update_thre=1e-3, with_input_constraint=1),
              wfc.x0[0], wfc.u_init[0], limits=wfc.limits)
     names.append("quadrotor_f32_box")
+    # an fp32 shape with seven inputs (the fp64 tile kernel's float instantiation): the manipulator in float, two iterations (from
+    # the third on its cost differences are below what a float cost resolves: tests/test_gpu_fp32.py)
+    wmf = workloads.manipulator_batch(B=1, T=30, seed=21, fp32=True)
+    run_case(store, "manipulator_f32_s0", "manipulator_f32", dict(horizon_steps=30, max_iter=2, cost_update_thre=1e-3), wmf.x0[0], wmf.u_init[0])
+    names.append("manipulator_f32_s0")
     store["__names__"] = np.array(names)
     np.savez_compressed(OUT, **store)
     print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(names), "cases")

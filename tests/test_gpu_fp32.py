@@ -8,12 +8,29 @@ The margin filter is the oracle's own decision stability at fp32 resolution: an 
 the same decisions when x0 is perturbed by a few float ulps.  Every masked comparison asserts a floor on the kept fraction
 and checks the dropped instances for the same optimum.
 """
+import os
+
 import numpy as np
 import pytest
 
 import oracle
 
 pytestmark = pytest.mark.gpu
+
+#: the kernel an UNCONSTRAINED quadrotor_f32 solve runs on, by NMPC_HIP_DDP_KERNEL: the fp32 tile kernel by default, the fp64 tile
+#: kernel's float instantiation (ddp_kernels_tile64.hpp with v_mfma_f32_16x16x4: round 4, the fp32 kernel of the shapes the other does
+#: not take) when forced.  Box-constrained solves and cartpole_f32 (n = 4) run on ddp_solve_tile32_kernel either way.
+F32_KERNEL = {"": "ddp_solve_tile32_kernel", "tile64": "ddp_solve_tile64_kernel"}
+
+
+@pytest.fixture(autouse=True, params=["", "tile64"], ids=["tile32", "tile64f"])
+def f32_kernel(request, monkeypatch):
+    """Every test of this file runs on both fp32 kernels."""
+    if request.param:
+        monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", request.param)
+    else:
+        monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    return request.param
 
 TOL_XU = 1e-3
 TOL_COST = 1e-4
@@ -148,7 +165,7 @@ def test_c4_first_iterations_ragged_batch():
     wl = workloads.quadrotor_batch(B=500, T=50, seed=7, fp32=True)
     s = make(wl, max_iter=3)
     s.solve(wl.t0, wl.x0, wl.u_init)
-    assert s.kernelName() == "ddp_solve_tile32_kernel"
+    assert s.kernelName() == F32_KERNEL[os.environ.get("NMPC_HIP_DDP_KERNEL", "")]
     ref = oracle_f32(wl, max_iter=3)
     check(wl, s, ref, margin_mask(wl, ref, max_iter=3), 0.97, "c4 3 iterations")  # the oracle keeps 0.988
 
@@ -403,6 +420,55 @@ def test_unsupported_combinations_fail_loudly():
         s.solve(wl.t0, wl.x0, wl.u_init)
 
 
+def test_manipulator_f32_on_the_float_tile64_kernel():
+    """fp32 with seven inputs and n = 14 (the reference template takes any StateDim / InputDim, DDPSolver.h:23-25; the
+    fp32 tile kernel takes m <= 4, n in {4, 8, 12}): `manipulator_f32` runs on the fp64 tile kernel's float instantiation, against
+    the oracle instantiated in float at the bar of this file, full groups and ragged ones; box-constrained solves of the type are
+    refused, not run on something else."""
+    import nmpc_amd
+    from nmpc_amd import workloads
+
+    wl = workloads.manipulator_batch(B=200, T=30, seed=13, fp32=True)
+    # two iterations: from the third on the manipulator's cost differences are below 64 eps of the cost — the fp32 oracle itself
+    # keeps 2 % of its decisions under ulp perturbations there (resolution_mask), 100 % up to the second
+    cfg = dict(max_iter=2, cost_update_thre=FP32_COST_UPDATE_THRE)
+    by_group = []
+    for group in ("32", "7"):
+        os.environ["NMPC_HIP_DDP_TILE64_GROUP"] = group
+        try:
+            s = make(wl, **cfg)
+            assert s.kernelName() == "ddp_solve_tile64_kernel" and nmpc_amd.make_problem("manipulator_f32").scalar_bytes() == 4
+            s.solve(wl.t0, wl.x0, wl.u_init)
+        finally:
+            os.environ.pop("NMPC_HIP_DDP_TILE64_GROUP")
+        ref = oracle_f32(wl, **cfg)
+        check(wl, s, ref, margin_mask(wl, ref, **cfg), 0.97, f"manipulator_f32 group {group}")
+        by_group.append((s.X().copy(), s.U().copy(), s.Kfb().copy()))
+    # the results do not depend on how the batch is cut into groups — bit for bit (the functors' code exists once per role in
+    # the kernel: two copies of the linearisation once differed in their fused multiply-adds, in float only)
+    assert all(np.array_equal(a, b) for a, b in zip(*by_group))
+    os.environ["NMPC_HIP_DDP_TILE64_GROUP"] = "7"
+    s = make(wl, **cfg)
+    os.environ.pop("NMPC_HIP_DDP_TILE64_GROUP")
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    X1 = s.X().copy()
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    np.testing.assert_array_equal(s.X(), X1)
+    # to convergence: decisions in the noise regime are not comparable, the optimum is — final costs within the tolerance of the
+    # float oracle's, and of the fp64 oracle's
+    sc = make(wl, max_iter=8, cost_update_thre=FP32_COST_UPDATE_THRE)
+    sc.solve(wl.t0, wl.x0, wl.u_init)
+    rf = oracle_f32(wl, max_iter=8, cost_update_thre=FP32_COST_UPDATE_THRE)
+    r64 = oracle.solve_batch("manipulator", ocfg_of(wl, max_iter=8), wl.x0, wl.u_init, t0=wl.t0, n_threads=8)
+    Jg, Jf, J64 = sc.cost().sum(axis=1), rf.cost.sum(axis=1), r64.cost.sum(axis=1)
+    assert (sc.status() >= 0).all()
+    assert np.max(np.abs(Jg - Jf) / np.abs(Jf)) <= 50 * TOL_COST and np.max(np.abs(Jg - J64) / np.abs(J64)) <= 50 * TOL_COST
+    sb = make(wl, max_iter=2, with_input_constraint=True)
+    sb.setInputLimits(np.full(7, -3.0), np.full(7, 3.0))
+    with pytest.raises(RuntimeError):
+        sb.solve(wl.t0, wl.x0, wl.u_init)
+
+
 def test_per_instance_problem_objects():
     """nmpc_hip_ddp_set_model_params_batch on the fp32 tile kernel (ddp_solve_tile32_kernel<Problem, true>): every instance
     solves its own quadrotor (mass), instance by instance against the fp32 oracle with the same parameters; then back to the
@@ -417,7 +483,7 @@ def test_per_instance_problem_objects():
     s = make(wl, **cfg)
     s.setProblemBatch([nmpc_amd.make_problem("quadrotor_f32", mass=float(m)) for m in masses])
     s.solve(wl.t0, wl.x0, wl.u_init)
-    assert s.kernelName() == "ddp_solve_tile32_kernel"
+    assert s.kernelName() == F32_KERNEL[os.environ.get("NMPC_HIP_DDP_KERNEL", "")]
     X, U, st, it = s.X(), s.U(), s.status(), s.iters()
     ocfg = ocfg_of(wl, **cfg)
     same, differs = 0, 0

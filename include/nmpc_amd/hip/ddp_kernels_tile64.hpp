@@ -2692,6 +2692,7 @@ struct TileSolver64
               if(adopt)
               {
                 adoptCandidates(group);
+                barrier(); // (every wave has read the slot table: Step 4 below flips sSel)
                 break;
               }
               pass = 3;
@@ -2744,6 +2745,7 @@ struct TileSolver64
             if(adopt)
             {
               adoptCandidates(group);
+              barrier(); // (every wave has read the slot table: Step 4 below flips sSel)
               break;
             }
             pass = 3;

@@ -13,6 +13,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 
 
 def solver(model, B, T, kernel):
+    forced = model.endswith("!")  # forced iterations of a converged solve: every line search back-tracks through the list
+    model = model.rstrip("!")
     os.environ["NMPC_HIP_DDP_KERNEL"] = kernel
     wl = {"quadrotor": workloads.quadrotor_batch, "manipulator": workloads.manipulator_batch,
           "centroidal": workloads.centroidal_batch}[model](B=B, T=T, seed=1234)
@@ -21,12 +23,16 @@ def solver(model, B, T, kernel):
     c.print_level = 0
     c.horizon_steps = wl.T
     c.max_iter = 8
+    if forced:
+        c.max_iter = 14
+        c.k_rel_norm_thre = 0.0
+        c.cost_update_thre = -1e300
     return wl, s
 
 
 bad_total = 0
 for model, T, B in (("manipulator", 30, 8192), ("quadrotor", 50, 8192), ("manipulator", 30, 3000), ("centroidal", 100, 1024),
-                    ("centroidal", 100, 300)):
+                    ("centroidal", 100, 300), ("quadrotor!", 50, 8192), ("manipulator!", 30, 8200)):
     wl, s = solver(model, B, T, "tile64")  # tile kernel first: nothing has touched the device before
     first = None
     n_bad = 0

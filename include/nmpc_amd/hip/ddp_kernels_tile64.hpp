@@ -671,6 +671,7 @@ struct TileSolver64
       products into fused multiply-adds differently in the two copies — in float the records of the full and of the partial
       timesteps then differed in the last bit, and with them the results with the chunk size, i.e. with the group size
       (measured: 7e-7 between groups of 7 and of 32; in double the two copies happened to agree). */
+  template<bool kFullT>
   struct StoreSink
   {
     S * rec;
@@ -681,7 +682,7 @@ struct TileSolver64
       if(!structuralZero(v))
       {
         ++cnt;
-        if(!__builtin_constant_p(v) || full)
+        if(!__builtin_constant_p(v) || kFullT || full)
         {
           rec[cnt] = v;
         }
@@ -722,6 +723,7 @@ struct TileSolver64
       p.u[a] = Un[(static_cast<size_t>(i) * MM + a) * 64];
     }
   }
+  template<bool kFullT>
   NMPC_D void lineariseStep(const Problem & mine, S * dst, S t0, int i, const Point & p, bool full) const
   {
     StateDimVector x;
@@ -736,8 +738,8 @@ struct TileSolver64
     {
       u[a] = p.u[a];
     }
-    StoreSink sink{dst, full};
-    if(full)
+    StoreSink<kFullT> sink{dst, full};
+    if(kFullT || full)
     {
       sink.rec[0] = 0.0; // the zero word
     }
@@ -2203,7 +2205,26 @@ struct TileSolver64
       if(mine)
       {
         S * dst = recAt(parity, dt, a, chunk, n_act);
-        lineariseStep(mine_p, dst, t0, step, next, n_chunk < 2); // (the first use of a record buffer in the sweep: every entry)
+        // The first use of a record buffer in the sweep: every entry.  float: ONE copy of the functors' code with a run-time
+        // flag (the chunk count through an opaque copy, or the compiler peels the first two trips into copies of their own):
+        // two copies differ in which products they fuse, and the results then depend on the chunk, i.e. the group size, in
+        // the last bit.  double: the two copies agree bit for bit (tests, soak) — and with one copy the centroidal
+        // problem's rollouts take 10.1 instead of 6.6 ms at 4096 instances (measured A/B on one box, round 4; a side effect
+        // of the register allocation that was not tracked down), so double keeps two.
+        if constexpr(kF32)
+        {
+          int nc = n_chunk;
+          asm volatile("" : "+s"(nc));
+          lineariseStep<false>(mine_p, dst, t0, step, next, nc < 2);
+        }
+        else if(n_chunk < 2)
+        {
+          lineariseStep<true>(mine_p, dst, t0, step, next, true);
+        }
+        else
+        {
+          lineariseStep<false>(mine_p, dst, t0, step, next, false);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if(lane_used && step - chunk >= 0)

@@ -529,7 +529,9 @@ def main():
             "backward_passes_per_iteration": n_bw,
             "forward_passes_per_iteration": n_fw,
             "status_counts": status_counts,
-            "lane_mapping": LANE_MAPPINGS.get(kernel_name, kernel_name),
+            "lane_mapping": (LANE_MAPPINGS.get(kernel_name, kernel_name) if not (kernel_name == "ddp_solve_tile64_kernel" and gen_kw.get("fp32"))
+                             else LANE_MAPPINGS[kernel_name].replace("fp64 tile:", "tile kernel, float instantiation:").replace(
+                                 "v_mfma_f64_16x16x4", "v_mfma_f32_16x16x4")),
             "final_gather_ms": 1e3 * gather_s,
             "gather_backend": backend,
             "per_rank_solve_ms": [1e3 * float(t[2]) / total_steps for t in per_rank],

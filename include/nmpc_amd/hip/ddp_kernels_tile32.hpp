@@ -1711,20 +1711,47 @@ struct ModelOpsTile32
   }
   /** Round 4: the fp64 tile kernel has a float instantiation (ddp_kernels_tile64.hpp: the same kernel with v_mfma_f32_16x16x4 and
       the lanes of a row holding the tile's columns in the order that makes the f32 instruction's result layout the f64 one).  It
-      is the fp32 kernel of the shapes THIS file's kernel does not take (m > 4, n not in {4, 8, 12}: ModelOpsTile64Float below);
-      on the shapes both take this file's is the faster one — its step is 16 MFMAs + 125 other instructions against 10 + 250
-      (measured, c4: 1.46 k against 1.04 k it/s) — so it keeps them; NMPC_HIP_DDP_KERNEL=tile64 runs their unconstrained solves
-      on the other kernel (A/B measurements; tests/test_gpu_fp32.py runs on both). */
+      is the fp32 kernel of the shapes THIS file's kernel does not take (m > 4, n not in {4, 8, 12}: ModelOpsTile64Float below).
+      On the shapes both take (unconstrained solves of 5 <= n <= 12; BoxQP in float is this file's only) the choice is per launch,
+      measured on the quadrotor (profiles/r04_c4_dispatch_sweep.txt, scripts/c4_dispatch_sweep.py):
+        * this file's kernel is the leaner one per full sweep (16 MFMAs + 125 other instructions a step against 10 + 250), but a
+          workgroup is 32 instances whatever the batch, its model wave linearises all 32 lanes of every timestep and its matrix
+          waves step all their slots — a sweep costs the same however few instances still iterate, and batches below 8192 leave
+          CUs idle (64 .. 4096 instances: 0.77 - 0.86 ms per 2 iterations);
+        * the other kernel sizes its groups to the batch and deals a sweep's work by ACTIVE index: 1.3 - 2.3 x faster up to 4096
+          instances at any iteration count and threshold, and from ~6 iterations on at 8192 and beyond (c4, max_iter 8: 1.75 k
+          against 1.46 k it/s — the iteration counts of a batch are ragged, the late sweeps nearly empty), slower for a few
+          iterations of a full chip (8192 x 2 iterations: 0.74 x) — and slower on a full chip whatever the count when nearly
+          every line search back-tracks (0.62 x), which is what an fp32 solve does once it iterates below the resolution of a
+          float cost (the reference's default cost_update_thre = 1e-7): its search is passes over the horizon (first step size,
+          the later ones, the taken one), this file's rolls every step size out at once.  Full chips therefore go to the other
+          kernel only with a threshold a float cost resolves (>= 1e-5; c4's headline: 1e-3).
+      NMPC_HIP_DDP_KERNEL=tile32 / tile64 forces one of them (A/B measurements; tests/test_gpu_fp32.py runs on both). */
   static constexpr bool kTile64Float = Problem::kStateDim >= 5 && Problem::kStateDim <= 15 && Problem::kInputDimMax >= 1
                                        && Problem::kInputDimMax <= 8 && !Problem::kDynamicInput;
-  static bool useTile64Float(bool constrained)
+  static constexpr int kTile64FloatBelowBatch = 8192, kTile64FloatFromIterations = 6;
+  static constexpr double kTile64FloatFromThreshold = 1e-5;
+  static bool useTile64Float(int batch, const nmpc_hip_ddp_config & cfg)
   {
+    if(!kTile64Float || cfg.with_input_constraint != 0)
+    {
+      return false;
+    }
     const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
-    return kTile64Float && !constrained && force && std::strcmp(force, "tile64") == 0;
+    if(force && std::strcmp(force, "tile64") == 0)
+    {
+      return true;
+    }
+    if(force && std::strcmp(force, "tile32") == 0)
+    {
+      return false;
+    }
+    return batch < kTile64FloatBelowBatch
+           || (cfg.max_iter >= kTile64FloatFromIterations && cfg.cost_update_thre >= kTile64FloatFromThreshold);
   }
-  static const char * kernelName(int, int constrained)
+  static const char * kernelName(int batch, const nmpc_hip_ddp_config & cfg)
   {
-    return useTile64Float(constrained != 0) ? "ddp_solve_tile64_kernel" : "ddp_solve_tile32_kernel";
+    return useTile64Float(batch, cfg) ? "ddp_solve_tile64_kernel" : "ddp_solve_tile32_kernel";
   }
   /** The handle allocates every Scalar array with sizeof(Problem::Scalar) = 4 (ModelOps::scalar_bytes): same pointers, float view. */
   static DeviceBuffersT<float> floatView(const DeviceBuffers & buf64)
@@ -1778,7 +1805,7 @@ struct ModelOpsTile32
     const DeviceBuffersT<float> buf = floatView(buf64);
     if constexpr(kTile64Float)
     {
-      if(useTile64Float(cfg.with_input_constraint != 0))
+      if(useTile64Float(buf64.B, cfg))
       {
         if(buf.params_batch != nullptr)
         {
@@ -1897,7 +1924,7 @@ struct ModelOpsTile64Float
   {
     new(out) Problem();
   }
-  static const char * kernelName(int, int)
+  static const char * kernelName(int, const nmpc_hip_ddp_config &)
   {
     return "ddp_solve_tile64_kernel";
   }

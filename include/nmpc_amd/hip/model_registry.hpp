@@ -168,8 +168,9 @@ struct ModelOpsFor
     }
     return batch_padded <= kQuadMaxBatch || (force && std::strcmp(force, "quad") == 0);
   }
-  static const char * kernelName(int batch, int constrained)
+  static const char * kernelName(int batch, const nmpc_hip_ddp_config & cfg)
   {
+    const int constrained = cfg.with_input_constraint != 0 ? 1 : 0;
     const int padded = (batch + kLanesPerBlock - 1) / kLanesPerBlock * kLanesPerBlock;
     if(useQuad(padded, false))
     {

@@ -914,7 +914,7 @@ extern "C"
     }
     if(s->ops->own_problems_supported && !s->ops->own_problems_supported(s->B, s->cfg.with_input_constraint != 0 ? 1 : 0))
     {
-      return fail(NMPC_HIP_ERR_RUNTIME, std::string("the kernel this handle solves on (") + s->ops->kernel_name(s->B, s->cfg.with_input_constraint != 0 ? 1 : 0)
+      return fail(NMPC_HIP_ERR_RUNTIME, std::string("the kernel this handle solves on (") + s->ops->kernel_name(s->B, s->cfg)
                                             + ") has no instantiation with one problem object per instance");
     }
     const size_t pb = s->ops->param_bytes;
@@ -1413,7 +1413,7 @@ extern "C"
     {
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output pointer");
     }
-    *name = s->ops->kernel_name(s->B, s->cfg.with_input_constraint != 0 ? 1 : 0);
+    *name = s->ops->kernel_name(s->B, s->cfg);
     return NMPC_HIP_OK;
   }
 

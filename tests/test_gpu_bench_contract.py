@@ -69,13 +69,14 @@ def test_default_line_has_the_contract_keys():
         assert rf["traffic_source_hash"] == hip_build.source_hash()
 
 
-def test_c4_runs_in_fp32_on_the_tile_kernel():
+def test_c4_runs_in_fp32_on_a_tile_kernel():
     d = run_bench("--workload", "c4", "--cpu-seconds", "0.5")
     assert d["dtype"] == "f32" and "batch=8192" in d["metric"] and "cost_update_thre=1e-3" in d["metric"]
     # the kept fraction of the fp32 parity (decisions equal to the float oracle's) rides in the line
     print("c4 decisions equal to the fp32 oracle's:", d["cpu_baseline"]["gpu_decisions_agree_frac"])
     assert d["cpu_baseline"]["gpu_decisions_checked"] == 256 and d["cpu_baseline"]["gpu_decisions_agree_frac"] >= 0.5
-    assert d["roofline"]["kernel"] == "ddp_solve_tile32_kernel<quadrotor_f32>"
+    # (eight iterations of a full chip: the tile kernel's float instantiation, ModelOpsTile32::useTile64Float)
+    assert d["roofline"]["kernel"] == "ddp_solve_tile64_kernel<quadrotor_f32>" and "float instantiation" in d["config"]["lane_mapping"]
     # the headline is the threshold an fp32 cost can resolve; the reference's default rides along as the secondary number
     assert d["config"]["cost_update_thre"] == 1e-3 and "cost_update_thre = 0.001" in d["config"]["workload"]
     assert d["config"]["default_threshold_value"] > 0 and d["config"]["default_threshold"]["roofline"]["frac"] > 0

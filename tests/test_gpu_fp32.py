@@ -17,20 +17,40 @@ import oracle
 
 pytestmark = pytest.mark.gpu
 
-#: the kernel an UNCONSTRAINED quadrotor_f32 solve runs on, by NMPC_HIP_DDP_KERNEL: the fp32 tile kernel by default, the fp64 tile
-#: kernel's float instantiation (ddp_kernels_tile64.hpp with v_mfma_f32_16x16x4: round 4, the fp32 kernel of the shapes the other does
-#: not take) when forced.  Box-constrained solves and cartpole_f32 (n = 4) run on ddp_solve_tile32_kernel either way.
-F32_KERNEL = {"": "ddp_solve_tile32_kernel", "tile64": "ddp_solve_tile64_kernel"}
+#: the kernel an UNCONSTRAINED quadrotor_f32 solve runs on when NMPC_HIP_DDP_KERNEL forces it: the fp32 tile kernel, or the fp64 tile
+#: kernel's float instantiation (ddp_kernels_tile64.hpp with v_mfma_f32_16x16x4: round 4).  Unforced the choice is per launch
+#: (ModelOpsTile32::useTile64Float: the float instantiation below 8192 instances or from six iterations on —
+#: test_fp32_kernel_dispatch).  Box-constrained solves and cartpole_f32 (n = 4) run on ddp_solve_tile32_kernel either way.
+F32_KERNEL = {"tile32": "ddp_solve_tile32_kernel", "tile64": "ddp_solve_tile64_kernel"}
 
 
-@pytest.fixture(autouse=True, params=["", "tile64"], ids=["tile32", "tile64f"])
+@pytest.fixture(autouse=True, params=["tile32", "tile64"], ids=["tile32", "tile64f"])
 def f32_kernel(request, monkeypatch):
     """Every test of this file runs on both fp32 kernels."""
-    if request.param:
-        monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", request.param)
-    else:
-        monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    monkeypatch.setenv("NMPC_HIP_DDP_KERNEL", request.param)
     return request.param
+
+
+def test_fp32_kernel_dispatch(monkeypatch):
+    """Which kernel an fp32 solve runs on when nothing forces it (ddp_kernels_tile32.hpp::useTile64Float, measured in
+    profiles/r04_c4_dispatch_sweep.txt)."""
+    import nmpc_amd
+
+    monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    quad = nmpc_amd.make_problem("quadrotor_f32")
+    for B, max_iter, thre, constrained, want in ((64, 2, 1e-7, False, "tile64"), (4096, 2, 1e-7, False, "tile64"), (8191, 1, 1e-3, False, "tile64"),
+                                                 (8192, 5, 1e-3, False, "tile32"), (8192, 6, 1e-3, False, "tile64"), (8192, 8, 1e-7, False, "tile32"),
+                                                 (16384, 8, 1e-5, False, "tile64"), (16384, 3, 1e-3, False, "tile32"), (256, 8, 1e-3, True, "tile32")):
+        s = nmpc_amd.DDPSolverBatch(quad, B)
+        s.config().max_iter = max_iter
+        s.config().cost_update_thre = thre
+        s.config().with_input_constraint = constrained
+        assert s.kernelName() == f"ddp_solve_{want}_kernel", (B, max_iter, thre, constrained)
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem("cartpole_f32"), 256)
+    assert s.kernelName() == "ddp_solve_tile32_kernel"
+    s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem("manipulator_f32"), 256)
+    assert s.kernelName() == "ddp_solve_tile64_kernel"
+
 
 TOL_XU = 1e-3
 TOL_COST = 1e-4
@@ -165,7 +185,7 @@ def test_c4_first_iterations_ragged_batch():
     wl = workloads.quadrotor_batch(B=500, T=50, seed=7, fp32=True)
     s = make(wl, max_iter=3)
     s.solve(wl.t0, wl.x0, wl.u_init)
-    assert s.kernelName() == F32_KERNEL[os.environ.get("NMPC_HIP_DDP_KERNEL", "")]
+    assert s.kernelName() == F32_KERNEL[os.environ["NMPC_HIP_DDP_KERNEL"]]
     ref = oracle_f32(wl, max_iter=3)
     check(wl, s, ref, margin_mask(wl, ref, max_iter=3), 0.97, "c4 3 iterations")  # the oracle keeps 0.988
 
@@ -483,7 +503,7 @@ def test_per_instance_problem_objects():
     s = make(wl, **cfg)
     s.setProblemBatch([nmpc_amd.make_problem("quadrotor_f32", mass=float(m)) for m in masses])
     s.solve(wl.t0, wl.x0, wl.u_init)
-    assert s.kernelName() == F32_KERNEL[os.environ.get("NMPC_HIP_DDP_KERNEL", "")]
+    assert s.kernelName() == F32_KERNEL[os.environ["NMPC_HIP_DDP_KERNEL"]]
     X, U, st, it = s.X(), s.U(), s.status(), s.iters()
     ocfg = ocfg_of(wl, **cfg)
     same, differs = 0, 0

@@ -142,7 +142,7 @@ for wl, entry in traffic.items():
     json.dump(b, open(path, "w"), indent=1)
 for extra in ("fanout_ab.txt", "batch_scaling.txt", "ubench_mfma_f32.txt", "ubench_mfma_f64_16.txt", "tile64_phases.txt", "constrained_ab.txt",
               "mpc_throughput.txt", "tile64_batch_scaling.txt", "m2_overlap.txt", "constrained_tile64_ab.txt", "tile64_soak.txt",
-              "tile64_chunk_ab.txt", "tile64_centroidal.txt"):
+              "tile64_chunk_ab.txt", "tile64_centroidal.txt", "c4_dispatch_sweep.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
 print(json.dumps(traffic, indent=1))

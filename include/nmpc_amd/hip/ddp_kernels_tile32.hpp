@@ -1713,24 +1713,24 @@ struct ModelOpsTile32
       the lanes of a row holding the tile's columns in the order that makes the f32 instruction's result layout the f64 one).  It
       is the fp32 kernel of the shapes THIS file's kernel does not take (m > 4, n not in {4, 8, 12}: ModelOpsTile64Float below).
       On the shapes both take (unconstrained solves of 5 <= n <= 12; BoxQP in float is this file's only) the choice is per launch,
-      measured on the quadrotor (profiles/r04_c4_dispatch_sweep.txt, scripts/c4_dispatch_sweep.py):
+      measured on the quadrotor (profiles/r04_c4_dispatch_sweep.txt, scripts/c4_dispatch_sweep*.py):
         * this file's kernel is the leaner one per full sweep (16 MFMAs + 125 other instructions a step against 10 + 250), but a
           workgroup is 32 instances whatever the batch, its model wave linearises all 32 lanes of every timestep and its matrix
           waves step all their slots — a sweep costs the same however few instances still iterate, and batches below 8192 leave
           CUs idle (64 .. 4096 instances: 0.77 - 0.86 ms per 2 iterations);
-        * the other kernel sizes its groups to the batch and deals a sweep's work by ACTIVE index: 1.3 - 2.3 x faster up to 4096
-          instances at any iteration count and threshold, and from ~6 iterations on at 8192 and beyond (c4, max_iter 8: 1.75 k
-          against 1.46 k it/s — the iteration counts of a batch are ragged, the late sweeps nearly empty), slower for a few
-          iterations of a full chip (8192 x 2 iterations: 0.74 x) — and slower on a full chip whatever the count when nearly
-          every line search back-tracks (0.62 x), which is what an fp32 solve does once it iterates below the resolution of a
-          float cost (the reference's default cost_update_thre = 1e-7): its search is passes over the horizon (first step size,
-          the later ones, the taken one), this file's rolls every step size out at once.  Full chips therefore go to the other
-          kernel only with a threshold a float cost resolves (>= 1e-5; c4's headline: 1e-3).
+        * the other kernel sizes its groups to the batch and deals a sweep's work by ACTIVE index: 1.3 - 2.6 x faster up to 4096
+          instances at any iteration count and threshold; on full chips (8192, 16384 instances) level for one to four iterations
+          and ahead from there (c4, max_iter 8: 1.95 k against 1.46 k it/s — the iteration counts of a batch are ragged, the late
+          sweeps nearly empty) AS LONG AS most line searches end at the first or second step size (its search is passes over the
+          horizon: the first two step sizes in one, the later ones in a second, the taken one in a third; this file's rolls every
+          step size out at once).  They do not once an fp32 solve iterates below the resolution of a float cost: 0.7 - 0.9 x at
+          cost_update_thre = 1e-4 and below (the reference's default 1e-7: 0.6 x), level at 3e-4, 1.0 - 1.3 x at 1e-3.
+      Hence: the float instantiation below 8192 instances; on full chips with cost_update_thre >= 5e-4.
       NMPC_HIP_DDP_KERNEL=tile32 / tile64 forces one of them (A/B measurements; tests/test_gpu_fp32.py runs on both). */
   static constexpr bool kTile64Float = Problem::kStateDim >= 5 && Problem::kStateDim <= 15 && Problem::kInputDimMax >= 1
                                        && Problem::kInputDimMax <= 8 && !Problem::kDynamicInput;
-  static constexpr int kTile64FloatBelowBatch = 8192, kTile64FloatFromIterations = 6;
-  static constexpr double kTile64FloatFromThreshold = 1e-5;
+  static constexpr int kTile64FloatBelowBatch = 8192;
+  static constexpr double kTile64FloatFromThreshold = 5e-4;
   static bool useTile64Float(int batch, const nmpc_hip_ddp_config & cfg)
   {
     if(!kTile64Float || cfg.with_input_constraint != 0)
@@ -1746,8 +1746,7 @@ struct ModelOpsTile32
     {
       return false;
     }
-    return batch < kTile64FloatBelowBatch
-           || (cfg.max_iter >= kTile64FloatFromIterations && cfg.cost_update_thre >= kTile64FloatFromThreshold);
+    return batch < kTile64FloatBelowBatch || cfg.cost_update_thre >= kTile64FloatFromThreshold;
   }
   static const char * kernelName(int batch, const nmpc_hip_ddp_config & cfg)
   {

@@ -305,11 +305,12 @@ struct TileSolver64
   int chunk_cap; //!< at most this many timesteps per pass of the model code (0: what fits; A/B measurements, tests)
   int wide_cap; //!< 0: the later step sizes of a line search never ride along with the first one (A/B measurements, tests)
   int adopt_cap; //!< 0: a later step size that is taken is rolled out again instead of copied from the workspace (A/B, tests)
+  int pair_cap; //!< 0: the second step size never rides in the model wave's upper lanes (A/B measurements, tests)
 
   NMPC_D TileSolver64(const Problem & p, const nmpc_hip_ddp_config & c, const Buffers & bf, S * lds_base, int cap)
   : problem(p), cfg(c), buf(bf), T(bf.T), wave(static_cast<int>(threadIdx.x) >> 6), lane(static_cast<int>(threadIdx.x) & 63),
-    lds(lds_base), group_cap(cap & 0xffff), chunk_cap((cap >> 16) & 0x3fff), wide_cap(((cap >> 31) & 1) == 0 ? 1 : 0),
-    adopt_cap(((cap >> 30) & 1) == 0 ? 1 : 0)
+    lds(lds_base), group_cap(cap & 0xffff), chunk_cap((cap >> 16) & 0x1fff), wide_cap(((cap >> 31) & 1) == 0 ? 1 : 0),
+    adopt_cap(((cap >> 30) & 1) == 0 ? 1 : 0), pair_cap(((cap >> 29) & 1) == 0 ? 1 : 0)
   {
   }
 
@@ -2565,6 +2566,14 @@ struct TileSolver64
         const int waves_rolling = (G + later_per_wave - 1) / later_per_wave; // (a wide pass 1: <= 6)
         // the later step sizes' trajectories go to the workspace, and the one that is taken is copied from there (no pass 3)
         const bool adopt = adopt_cap != 0 && cfg.n_alpha - 1 <= kScratchAlphas;
+        // A narrow pass 1 uses the model wave's lanes 0 .. G - 1; with G <= 32 its lanes 32 .. 32 + G - 1 roll out the SECOND step size
+        // of the same slots beside them, for its cost (same ring entries, same instruction stream, no stores: no extra time): a
+        // slot that rejects the first step size and takes the second — most of the back-tracking of a solve far from the noise
+        // floor — needs no pass 2, only pass 3 (its trajectory, stored; a third of a pass 2's time).  Measured with the second step
+        // size's trajectory going to the workspace for adoption instead: c4 the same, c5 / c4f64 2 - 3 % slower (scattered stores in
+        // every search for a copy few searches need).  (A launch lasts as long as its slowest group, and with 256 groups some slot of
+        // some group rejects the first step size in nearly every iteration: DESIGN.md §5.)
+        const bool pair = !first_trip && !wide && pair_cap != 0 && cfg.n_alpha > 1 && G <= 32;
         int pass = first_trip ? 0 : 1, trip_base = 0;
 #pragma nounroll
         for(;;)
@@ -2592,6 +2601,21 @@ struct TileSolver64
               phalf = slotI(sSel, slot) ^ 1;
               pt0 = slotF(sT0, slot);
               palpha = (pass == 1) ? sc(cfg.alpha_list[0]) : slotF(sAlpha, slot);
+            }
+            else if(pair && pass == 1 && model_wave && lane >= 32 && lane - 32 < G)
+            {
+              const int s2 = lane - 32;
+              if(slotI(sB, s2) >= 0 && slotI(sLs, s2) != 0)
+              {
+                active = true;
+                store = false;
+                pb = slotI(sB, s2);
+                pinst = s2;
+                pai = 1;
+                phalf = slotI(sSel, s2) ^ 1;
+                pt0 = slotF(sT0, s2);
+                palpha = sc(cfg.alpha_list[1]);
+              }
             }
           }
           else
@@ -2636,7 +2660,8 @@ struct TileSolver64
             p_lane = (order - waves_rolling) * 64 + lane; // (the waves that roll out do not prefetch: compute is set)
             p_count = (kT64MatrixWaves - waves_rolling) * 64;
           }
-          const bool to_workspace = adopt && !store && compute && active; // (a later step size, rolled out for its cost)
+          // (a later step size, rolled out for its cost; the model wave's upper lanes of a pair pass: cost only)
+          const bool to_workspace = adopt && !store && compute && active && !model_wave;
           const S Jc = stagedPass(compute, pass == 0, theirs, active, group, pb, pinst, phalf, pt0, palpha, store || to_workspace,
                                        p_lane, p_count, to_workspace ? pai - 1 : -1);
           // ---- what follows from it
@@ -2664,6 +2689,14 @@ struct TileSolver64
               }
               barrier(); // B5a: the later step sizes' costs are in lsJ
             }
+            else if(pair)
+            {
+              if(model_wave && lane >= 32 && active)
+              {
+                lsJ[1 * kT64MaxGroup + pinst] = Jc;
+              }
+              barrier(); // B5a': the second step size's costs are in lsJ
+            }
             if(slot_lane)
             {
               int flags = slotI(sFlags, slot);
@@ -2684,6 +2717,19 @@ struct TileSolver64
                   {
                     flags |= fSuccess;
                     reroll = true; // its trajectory has not been stored yet
+                  }
+                }
+                else if(rejected && pair)
+                {
+                  success = judge(1, lsJ[1 * kT64MaxGroup + slot]);
+                  if(success)
+                  {
+                    flags |= fSuccess;
+                    reroll = true; // its trajectory has not been stored yet
+                  }
+                  else
+                  {
+                    more = cfg.n_alpha > 2; // (pass 2 judges from the second step size on again: the same costs)
                   }
                 }
                 else
@@ -2708,9 +2754,9 @@ struct TileSolver64
               pass = 2;
               trip_base = 0;
             }
-            else if(wide && uniform(meta(mAnyReroll)) != 0)
+            else if((wide || pair) && uniform(meta(mAnyReroll)) != 0)
             {
-              if(adopt)
+              if(adopt && wide)
               {
                 adoptCandidates(group);
                 barrier(); // (every wave has read the slot table: Step 4 below flips sSel)
@@ -2956,7 +3002,12 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
   int chunk_cap = 0; // NMPC_HIP_DDP_TILE64_CHUNK=<c>: at most c timesteps per pass of the model code (1: round 3's schedule)
   if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_CHUNK"))
   {
-    chunk_cap = std::atoi(e) & 0x3fff;
+    chunk_cap = std::atoi(e) & 0x1fff;
+  }
+  unsigned no_pair = 0; // NMPC_HIP_DDP_TILE64_PAIR=0: the second step size does not ride in the model wave's upper lanes
+  if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_PAIR"))
+  {
+    no_pair = (std::atoi(e) == 0) ? 1u : 0u;
   }
   unsigned no_adopt = 0; // NMPC_HIP_DDP_TILE64_ADOPT=0: a later step size that is taken is re-rolled (round 3's pass 3)
   if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_ADOPT"))
@@ -2976,7 +3027,7 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
   }
   grid = buf.B < grid ? buf.B : grid;
   hipLaunchKernelGGL((ddp_solve_tile64_kernel<Problem, kConstrained, kOwnProblem>), dim3(grid), dim3(kT64Threads), 0, stream, problem,
-                     cfg, buf, static_cast<int>(static_cast<unsigned>(cap) | (static_cast<unsigned>(chunk_cap) << 16) | (no_wide << 31) | (no_adopt << 30)));
+                     cfg, buf, static_cast<int>(static_cast<unsigned>(cap) | (static_cast<unsigned>(chunk_cap) << 16) | (no_wide << 31) | (no_adopt << 30) | (no_pair << 29)));
   // (the kernel's 160 KB of LDS are a static array)
   return hipGetLastError();
 }

@@ -50,7 +50,7 @@ python scripts/tile64_chunk_ab.py > $OUT/tile64_chunk_ab.txt 2>&1
 python scripts/tile64_centroidal_check.py > $OUT/tile64_centroidal.txt 2>&1
 for B in 256 1024 4096; do python scripts/tile64_centroidal_profile.py $B >> $OUT/tile64_centroidal.txt 2>&1; done
 python scripts/m2_overlap.py 16 1 2 4 8 > $OUT/m2_overlap.txt 2>&1
-(python scripts/c4_dispatch_sweep.py; python scripts/c4_dispatch_sweep2.py; python scripts/c4_iteration_profile.py) > $OUT/c4_dispatch_sweep.txt 2>&1
+(python scripts/c4_dispatch_sweep.py; python scripts/c4_dispatch_sweep2.py; python scripts/c4_dispatch_sweep3.py; python scripts/c4_iteration_profile.py) > $OUT/c4_dispatch_sweep.txt 2>&1
 python scripts/constrained_tile64_ab.py > $OUT/constrained_tile64_ab.txt 2>&1
 python scripts/tile64_soak.py 100 > $OUT/tile64_soak.txt 2>&1
 python scripts/batch_scaling.py > $OUT/batch_scaling.txt 2>&1

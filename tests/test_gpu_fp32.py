@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 #: the kernel an UNCONSTRAINED quadrotor_f32 solve runs on when NMPC_HIP_DDP_KERNEL forces it: the fp32 tile kernel, or the fp64 tile
 #: kernel's float instantiation (ddp_kernels_tile64.hpp with v_mfma_f32_16x16x4: round 4).  Unforced the choice is per launch
-#: (ModelOpsTile32::useTile64Float: the float instantiation below 8192 instances or from six iterations on —
+#: (ModelOpsTile32::useTile64Float: the float instantiation below 8192 instances, and on full chips with a cost_update_thre >= 5e-4 —
 #: test_fp32_kernel_dispatch).  Box-constrained solves and cartpole_f32 (n = 4) run on ddp_solve_tile32_kernel either way.
 F32_KERNEL = {"tile32": "ddp_solve_tile32_kernel", "tile64": "ddp_solve_tile64_kernel"}
 
@@ -39,8 +39,9 @@ def test_fp32_kernel_dispatch(monkeypatch):
     monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
     quad = nmpc_amd.make_problem("quadrotor_f32")
     for B, max_iter, thre, constrained, want in ((64, 2, 1e-7, False, "tile64"), (4096, 2, 1e-7, False, "tile64"), (8191, 1, 1e-3, False, "tile64"),
-                                                 (8192, 5, 1e-3, False, "tile32"), (8192, 6, 1e-3, False, "tile64"), (8192, 8, 1e-7, False, "tile32"),
-                                                 (16384, 8, 1e-5, False, "tile64"), (16384, 3, 1e-3, False, "tile32"), (256, 8, 1e-3, True, "tile32")):
+                                                 (8192, 2, 1e-3, False, "tile64"), (8192, 8, 5e-4, False, "tile64"), (8192, 8, 1e-4, False, "tile32"),
+                                                 (8192, 8, 1e-7, False, "tile32"), (16384, 8, 1e-3, False, "tile64"), (16384, 3, 1e-5, False, "tile32"),
+                                                 (256, 8, 1e-3, True, "tile32")):
         s = nmpc_amd.DDPSolverBatch(quad, B)
         s.config().max_iter = max_iter
         s.config().cost_update_thre = thre

@@ -833,10 +833,14 @@ def test_wide_first_pass_equals_separate_passes(monkeypatch):
         out = []
         # ... and a later step size that is taken: copied from the workspace, where the lane that rolled it out for its cost
         # left its trajectory (adopt = 1), or rolled out once more (round 3's pass 3)
-        for wide, adopt in (("1", "1"), ("1", "0"), ("0", "1"), ("0", "0")):
+        # ... and the second step size riding in the model wave's upper lanes in a narrow first pass (pair = 1: a slot that rejects
+        # the first and takes the second needs no further pass)
+        for wide, adopt, pair in (("1", "1", "1"), ("1", "0", "1"), ("0", "1", "1"), ("0", "0", "1"), ("0", "1", "0"), ("0", "0", "0"),
+                                  ("1", "1", "0")):
             _select_matrix_kernel(monkeypatch, "tile64", group)
             monkeypatch.setenv("NMPC_HIP_DDP_TILE64_WIDE", wide)
             monkeypatch.setenv("NMPC_HIP_DDP_TILE64_ADOPT", adopt)
+            monkeypatch.setenv("NMPC_HIP_DDP_TILE64_PAIR", pair)
             s = make_solver(wl, **cfg)
             s.solve(wl.t0, wl.x0, wl.u_init)
             out.append((s.status(), s.iters(), s.X(), s.U(), s.cost(), s.kff(), s.Kfb(), np.nan_to_num(s.trace(), nan=-7.0)))

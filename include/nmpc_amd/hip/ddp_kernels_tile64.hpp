@@ -2534,7 +2534,8 @@ struct TileSolver64
       }
       if(rollouts)
       {
-        // Step 3, the line search.  Pass 1: the first step size — the one normally taken — lane = slot on the model wave, stored;
+        // Step 3, the line search.  Pass 1: the first step size — the one normally taken — lane = slot on the model wave, stored
+        // (and, groups of up to 32, the second step size for its cost in the wave's upper lanes: `pair` below);
         // the matrix waves feed the ring.  Pass 2 (only if a slot rejected it): the later step sizes of those slots all at once
         // on the matrix waves, lane = (slot, step size), cost only; the model wave feeds the ring.  Pass 3 (only if a later
         // step size was taken): its trajectory, stored.  The first accepted step size in list order is the sequential loop's

@@ -71,6 +71,14 @@ unsigned blocks(size_t threads, unsigned block)
   return static_cast<unsigned>((threads + block - 1) / block);
 }
 
+/** fmpc_transpose_kernel's grid: 32 x 32 tiles of the source matrix (B x steps E towards the device, steps E x B back). */
+dim3 fmpcTransposeGrid(int B, int steps, int E, int to_device)
+{
+  const int R = steps * E;
+  const int rows = to_device ? B : R, cols = to_device ? R : B;
+  return dim3(static_cast<unsigned>((cols + 31) / 32), static_cast<unsigned>((rows + 31) / 32));
+}
+
 /** One row of the closed-loop log (nmpc_hip_fmpc_mpc_run): state handed to the solve, first input, status, iterations and
     the KKT error of the last iteration.  Logs are [tick][element][instance] on the device. */
 __global__ void fmpc_log_kernel(FmpcBuffers buf, int tick, double * x_log, double * u0_log, int * status_log, int * iter_log, double * kkt_log)
@@ -374,8 +382,8 @@ int uploadField(nmpc_hip_fmpc_solver * h, const double * src, double * dst, int 
     FMPC_TRY(hipMemcpyAsync(h->d_stage, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
     d_src = h->d_stage;
   }
-  hipLaunchKernelGGL(nmpc_amd::hip::fmpc_transpose_kernel, dim3(blocks(count, 256)), dim3(256), 0, h->stream, d_src, dst, h->buf.B,
-                     steps, E, 1);
+  hipLaunchKernelGGL(nmpc_amd::hip::fmpc_transpose_kernel, fmpcTransposeGrid(h->buf.B, steps, E, 1), dim3(256), 0, h->stream, d_src, dst,
+                     h->buf.B, steps, E, 1);
   FMPC_TRY(hipGetLastError());
   if(!on_device)
   {
@@ -407,8 +415,7 @@ int ingest(nmpc_hip_fmpc_solver * h, const double * t, const double * x0, bool o
     FMPC_TRY(hipMemcpyAsync(h->d_stage, x0, static_cast<size_t>(B) * N * sizeof(double), hipMemcpyHostToDevice, stream));
     d_src = h->d_stage;
   }
-  hipLaunchKernelGGL(nmpc_amd::hip::fmpc_transpose_kernel, dim3(blocks(static_cast<size_t>(B) * N, 256)), dim3(256), 0, stream, d_src,
-                     h->d_x0, B, 1, N, 1);
+  hipLaunchKernelGGL(nmpc_amd::hip::fmpc_transpose_kernel, fmpcTransposeGrid(B, 1, N, 1), dim3(256), 0, stream, d_src, h->d_x0, B, 1, N, 1);
   FMPC_TRY(hipGetLastError());
   return NMPC_HIP_OK;
 }
@@ -933,8 +940,8 @@ extern "C"
       src = d_g;
     }
     double * dst = on_device ? static_cast<double *>(out) : d_t;
-    hipLaunchKernelGGL(nmpc_amd::hip::fmpc_transpose_kernel, dim3(blocks(count, 256)), dim3(256), 0, h->stream, src, dst, h->buf.B,
-                       fi.steps, fi.E, 0);
+    hipLaunchKernelGGL(nmpc_amd::hip::fmpc_transpose_kernel, fmpcTransposeGrid(h->buf.B, fi.steps, fi.E, 0), dim3(256), 0, h->stream, src,
+                       dst, h->buf.B, fi.steps, fi.E, 0);
     FMPC_TRY(hipGetLastError());
     if(!on_device)
     {
@@ -1073,8 +1080,8 @@ extern "C"
       }
       const size_t count = static_cast<size_t>(B) * steps * E;
       FMPC_CHECK(ensureStage(h, count * sizeof(double)));
-      hipLaunchKernelGGL(nmpc_amd::hip::fmpc_transpose_kernel, dim3(blocks(count, 256)), dim3(256), 0, h->stream, d_src, h->d_stage, B,
-                         steps, E, 0);
+      hipLaunchKernelGGL(nmpc_amd::hip::fmpc_transpose_kernel, fmpcTransposeGrid(B, steps, E, 0), dim3(256), 0, h->stream, d_src, h->d_stage,
+                         B, steps, E, 0);
       FMPC_TRY(hipGetLastError());
       FMPC_TRY(hipMemcpyAsync(host, h->d_stage, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       FMPC_TRY(hipStreamSynchronize(h->stream));

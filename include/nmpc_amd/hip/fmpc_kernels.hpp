@@ -716,79 +716,6 @@ __global__ void fmpc_init_complementary_kernel(FmpcBuffers buf)
   (void)M;
 }
 
-/** fmpc_update_kernel with the dimensions as constants (same statements in the same order): the loops unroll and a thread's 2 N + M + 4 G
-    loads are in flight together instead of one loop trip at a time (the generic kernel moves 4.8 TB/s, the coefficient kernel 6.2). */
-template<int N, int M, int G>
-__global__ void __launch_bounds__(256) fmpc_update_dims_kernel(FmpcBuffers buf)
-{
-  const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if(tid >= static_cast<size_t>(buf.B) * (buf.T + 1))
-  {
-    return;
-  }
-  const int b = static_cast<int>(tid % buf.B);
-  const int i = static_cast<int>(tid / buf.B);
-  if(buf.status[b] != fmpc::kStatusContinued)
-  {
-    return;
-  }
-  const double alpha_s = buf.alpha[2 * buf.B + b];
-  const double alpha_nu = buf.alpha[1 * buf.B + b];
-  NMPC_UNROLL
-  for(int e = 0; e < N; e++)
-  {
-    const size_t k = fmpc::at(buf, i, e, N, b);
-    buf.x[k] += alpha_s * buf.dx[k];
-    buf.lam[k] += alpha_nu * buf.dlam[k];
-  }
-  if(i < buf.T)
-  {
-    NMPC_UNROLL
-    for(int e = 0; e < M; e++)
-    {
-      const size_t k = fmpc::at(buf, i, e, M, b);
-      buf.u[k] += alpha_s * buf.du[k];
-    }
-    constexpr double min_positive_value = -DBL_MAX; // (FmpcSolver.hpp:812, as in fmpc_update_kernel)
-    bool s_neg = false, nu_neg = false;
-    double dot = 0;
-    double sv[G > 0 ? G : 1], nv[G > 0 ? G : 1];
-    NMPC_UNROLL
-    for(int e = 0; e < G; e++)
-    {
-      const size_t k = fmpc::at(buf, i, e, G, b);
-      sv[e] = buf.s[k] + alpha_s * buf.ds[k];
-      nv[e] = buf.nu[k] + alpha_nu * buf.dnu[k];
-      buf.s[k] = sv[e];
-      buf.nu[k] = nv[e];
-      dot += sv[e] * nv[e];
-      s_neg = s_neg || sv[e] < 0;
-      nu_neg = nu_neg || nv[e] < 0;
-    }
-    if(s_neg || nu_neg)
-    {
-      dot = 0;
-      NMPC_UNROLL
-      for(int e = 0; e < G; e++)
-      {
-        const size_t k = fmpc::at(buf, i, e, G, b);
-        if(s_neg && sv[e] < min_positive_value)
-        {
-          sv[e] = min_positive_value;
-          buf.s[k] = sv[e];
-        }
-        if(nu_neg && nv[e] < min_positive_value)
-        {
-          nv[e] = min_positive_value;
-          buf.nu[k] = nv[e];
-        }
-        dot += sv[e] * nv[e];
-      }
-    }
-    buf.part[fmpc::at(buf, i, 3, fmpc::kPartSlots, b)] = dot;
-  }
-}
-
 /** Step 1 of procOnce (FmpcSolver.hpp:394-441) for one (instance, timestep), fused with the pre-process of the backward pass
     (:562-574: everything of it that does not depend on P) and with this timestep's terms of calcKktError (:493-520). */
 template<class Problem>

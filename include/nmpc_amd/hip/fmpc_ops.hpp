@@ -63,8 +63,6 @@ struct FmpcOps
   hipError_t (*launch_coeff)(const FmpcBuffers & buf, hipStream_t stream);
   hipError_t (*launch_riccati)(const FmpcBuffers & buf, int iter, hipStream_t stream);
   hipError_t (*launch_delta)(const FmpcBuffers & buf, hipStream_t stream);
-  //! the variable update with the problem's dimensions as constants (nullptr: fmpc_update_kernel)
-  hipError_t (*launch_update)(const FmpcBuffers & buf, hipStream_t stream);
   hipError_t (*launch_line_search)(const FmpcBuffers & buf, int iter, hipStream_t stream);
   hipError_t (*launch_plant)(const FmpcBuffers & buf,
                              double * x_plant,
@@ -128,11 +126,6 @@ struct FmpcOpsOf
     };
     o.launch_delta = [](const FmpcBuffers & buf, hipStream_t stream) {
       hipLaunchKernelGGL(fmpc_delta_kernel<Problem>, dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)), dim3(256), 0,
-                         stream, buf);
-      return hipGetLastError();
-    };
-    o.launch_update = [](const FmpcBuffers & buf, hipStream_t stream) {
-      hipLaunchKernelGGL((fmpc_update_dims_kernel<N, M, G>), dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)), dim3(256), 0,
                          stream, buf);
       return hipGetLastError();
     };

@@ -281,16 +281,9 @@ int enqueueSolve(nmpc_hip_fmpc_solver * h, hipStream_t stream)
     {
       FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_LINE_SEARCH, FMPC_TRY(ops->launch_line_search(buf, iter, stream)));
     }
-    if(ops->launch_update)
-    {
-      FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_UPDATE, FMPC_TRY(ops->launch_update(buf, stream)));
-    }
-    else
-    {
-      FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_UPDATE,
-                 hipLaunchKernelGGL(nmpc_amd::hip::fmpc_update_kernel, dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)),
-                                    dim3(256), 0, stream, buf));
-    }
+    FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_UPDATE,
+               hipLaunchKernelGGL(nmpc_amd::hip::fmpc_update_kernel, dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)),
+                                  dim3(256), 0, stream, buf));
   }
   FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_OTHER,
              hipLaunchKernelGGL(nmpc_amd::hip::fmpc_finish_kernel, dim3(nb), dim3(64), 0, stream, buf));
@@ -674,7 +667,7 @@ extern "C"
       return cleanup(fail(NMPC_HIP_ERR_HIP, "initialisation kernel failed (is this a gfx950 device?)"));
     }
     h->kernel_names = "fmpc_barrier_kernel,fmpc_coeff_kernel,fmpc_riccati_kernel,fmpc_delta_kernel,fmpc_step_length_kernel,"
-                      "fmpc_update_dims_kernel";
+                      "fmpc_update_kernel";
     *out = h;
     return NMPC_HIP_OK;
   }
@@ -1153,7 +1146,7 @@ extern "C"
     h->kernel_names = std::string("fmpc_barrier_kernel,fmpc_coeff_kernel,")
                       + (nmpc_amd::hip::fmpcUseQuadRiccati(h->buf.N, h->buf.M, h->buf.B) ? "fmpc_riccati_quad_kernel" : "fmpc_riccati_kernel")
                       + ",fmpc_delta_kernel,fmpc_step_length_kernel," + (h->cfg.enable_line_search ? "fmpc_line_search_kernel," : "")
-                      + "fmpc_update_dims_kernel";
+                      + "fmpc_update_kernel";
     *names = h->kernel_names.c_str();
     return NMPC_HIP_OK;
   }

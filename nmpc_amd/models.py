@@ -127,7 +127,8 @@ class DDPProblemQuadrotor(_Problem):
 
 class DDPProblemQuadrotorF32(_Problem):
     """The same problem type instantiated in float (DDPProblemQuadrotorT<float>): BASELINE.json config 4 as specified
-    ("fp32"), served by the fp32 tile kernel (include/nmpc_amd/hip/ddp_kernels_tile32.hpp)."""
+    ("fp32"), served by the fp32 tile kernel (include/nmpc_amd/hip/ddp_kernels_tile32.hpp) or, chosen per launch, by the
+    tile kernel's float instantiation (ddp_kernels_tile64.hpp; ModelOpsTile32::useTile64Float, kernelName() tells)."""
 
     name = "quadrotor_f32"
 

@@ -1,5 +1,6 @@
 """BASELINE.json config 4 as specified — quadrotor (nx 12, nu 4, T 50) in fp32 on the fp32 tile kernel
-(include/nmpc_amd/hip/ddp_kernels_tile32.hpp) — against the CPU oracle instantiated in float (namespace oracle_f32,
+(include/nmpc_amd/hip/ddp_kernels_tile32.hpp) AND on the tile kernel's float instantiation (ddp_kernels_tile64.hpp; every test runs
+on both, the f32_kernel fixture) — against the CPU oracle instantiated in float (namespace oracle_f32,
 oracle/ddp_oracle.hpp compiled with Real = float).
 
 Bar (SURVEY.md §8 c, fp32 config): X, U within 1e-3 relative, total cost within 1e-4 relative, discrete decisions (status,

@@ -23,6 +23,10 @@ After the timed job the default (c2, nominal) run also measures SURVEY.md 8(d)'s
 m1 (termination tests disabled, N = 50 iterations forced) and m2 (solve to convergence, max_iter 500) — and reports them as
 config.m1_value / config.m2_value (batch-iterations/s): outside the timed region, a few solves each.
 
+The default line finally carries `secondary`: the other workloads of DESIGN.md 5's table (c3, c4, c4f64, c5, fmpc, centroidal), each
+on its own handle, >= --secondary-seconds of back-to-back solves after the c2 job, with value, ms_per_step, kernel and roofline
+(contract fraction + the PMC traffic of profiles/hbm_traffic.json when it was measured on these device sources).
+
 The JSON line also carries
   roofline     HBM-roofline accounting of the solve kernel: algorithmic bytes (SURVEY.md §8 d formula with the
                measured backward / forward pass counts) / HIP-event kernel time measured on the launch stream;
@@ -105,6 +109,10 @@ def parse_args():
                          "them; the number of blocks is fixed BEFORE the timed region from an untimed calibration block, so the timed "
                          "region holds no collective; config.block_ms_per_step_{min,median,max} are the per-block step times)")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the m1 / m2 (c2) and fp32-tolerance (c4) extra legs")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs of the default line (c3, c4, c4f64, c5, fmpc, centroidal: >= --secondary-seconds each, "
+                         "after the c2 job and outside its timed region)")
+    ap.add_argument("--secondary-seconds", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0,
                     help="sizing target of the CPU baseline sample (the sustained all-core rate is ~3x below the probe: ~20 s)")
@@ -197,6 +205,127 @@ def cpu_baseline(wl, mode: str, iters_per_solve: int, target_seconds: float, cos
         "host_cpus_affinity": affinity,
         "host_cpu_quota": quota,
     }
+
+
+# The other workloads of DESIGN.md 5's table, timed as SECONDARY legs of the default (c2) line so that the driver's record holds them:
+# name -> (generator, generator kwargs, batch, horizon, cost_update_thre override)
+SECONDARY = {
+    "c3": ("bipedal_batch", {}, 1024, 300, None),
+    "c4": ("quadrotor_batch", {"fp32": True}, 8192, 50, 1e-3),
+    "c4f64": ("quadrotor_batch", {}, 8192, 50, None),
+    "c5": ("manipulator_batch", {}, 8192, 30, None),
+    "centroidal": ("centroidal_batch", {}, 4096, 100, None),
+}
+
+
+def measured_traffic(name: str, batch: int, iters_per_solve: int, cost_update_thre):
+    """(HBM bytes per launch, source, note) of profiles/hbm_traffic.json's entry `name`: used only when it was measured on the device
+    sources of this tree (source hash) at this batch / iteration count / threshold."""
+    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        entry = json.load(open(traffic_file)).get(name)
+        if not isinstance(entry, dict) or entry.get("batch") != batch or entry.get("iterations_per_step") != iters_per_solve:
+            return None, None, None
+        if (entry.get("cost_update_thre") or None) != (cost_update_thre or None):
+            return None, None, None
+        from nmpc_amd import build as hip_build
+        src_hash = hip_build.source_hash()
+        if entry.get("source_hash") != src_hash:
+            return None, None, ("profiles/hbm_traffic.json holds a measurement of other device sources (hash %s, now %s): not used"
+                                % (entry.get("source_hash"), src_hash))
+        return entry.get("hbm_bytes_per_launch"), entry.get("source"), None
+    except Exception:
+        return None, None, None
+
+
+def ddp_secondary_leg(name: str, device_index: int, seed: int, iters_per_solve: int, min_seconds: float):
+    """One secondary workload: its own handle, the nominal configuration (reference defaults, max_iter = iters_per_solve), three
+    warm-up solves, then >= min_seconds of back-to-back solves with the inputs resident; roofline as for the headline."""
+    import torch
+    import nmpc_amd
+    from nmpc_amd import _capi, workloads
+    gen, gen_kw, batch, horizon, thre = SECONDARY[name]
+    wl = getattr(workloads, gen)(B=batch, T=horizon, seed=seed, **gen_kw)
+    problem = nmpc_amd.make_problem(wl.model)
+    elem = float(problem.scalar_bytes())
+    solver = nmpc_amd.DDPSolverBatch(problem, wl.B, device=device_index)
+    cfg = solver.config()
+    cfg.print_level = 0
+    cfg.horizon_steps = wl.T
+    cfg.max_iter = iters_per_solve
+    cfg.trace_level = 1
+    if thre is not None:
+        cfg.cost_update_thre = thre
+    dev = torch.device("cuda", device_index)
+    d_x0, d_u0, d_t0 = (torch.from_numpy(a).to(dev) for a in (wl.x0, wl.u_init, wl.t0))
+
+    def step():
+        solver.solveDevice(d_t0.data_ptr(), d_x0.data_ptr(), d_u0.data_ptr())
+
+    for _ in range(3):
+        step()
+    solver.synchronize()
+    t0 = time.perf_counter()
+    step()
+    solver.synchronize()
+    n_steps = int(max(4, np.ceil(min_seconds / max(time.perf_counter() - t0, 1e-6))))
+    solver.timingStats(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        step()
+    solver.synchronize()
+    dt = time.perf_counter() - t0
+    n_l, _, k_ms_sum = solver.timingStats()
+    it = solver.iters()
+    st = solver.status()
+    rows = solver.trace()[:, 1:, :]
+    ex = rows[:, :, 0] > 0
+    n_ex = max(int(ex.sum()), 1)
+    bw = float(rows[:, :, _capi.TRACE_COLUMNS.index("n_backward")][ex].sum()) / n_ex
+    fw = float(rows[:, :, _capi.TRACE_COLUMNS.index("n_forward")][ex].sum()) / n_ex
+    inst_it = float(it.sum())
+    words = workloads.algorithmic_words_per_instance_iteration(wl.n, wl.m, wl.T, bw, fw)
+    fused = workloads.fused_words_per_instance_iteration(wl.n, wl.m, wl.T, bw, fw)
+    k_ms = k_ms_sum / max(n_l, 1)
+    ach = words * elem * inst_it / (k_ms * 1e-3) / 1e9
+    traffic, src, note = measured_traffic(name, wl.B, iters_per_solve, thre)
+    roof = {"bound": "hbm", "kernel": solver.kernelName() + "<%s>" % wl.model, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms_avg": k_ms, "launches_timed": int(n_l),
+            "backward_passes_per_iteration": bw, "forward_passes_per_iteration": fw,
+            "algorithmic_bytes_per_launch": words * elem * inst_it, "fused_lower_bound_bytes_per_launch": fused * elem * inst_it}
+    if traffic:
+        roof["traffic_source"] = src
+        roof["traffic_over_fused_bound"] = traffic / roof["fused_lower_bound_bytes_per_launch"]
+        roof["hbm_frac_measured"] = traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    elif note:
+        roof["traffic_note"] = note
+    out = {"workload": "%s: nx=%d, nu=%d, T=%d, batch=%d, %s, seed %d, default Configuration with max_iter = %d%s"
+                       % (wl.model, wl.n, wl.m, wl.T, wl.B, "fp32" if elem == 4 else "fp64", seed, iters_per_solve,
+                          "" if thre is None else ", cost_update_thre = %g" % thre),
+           "metric": "DDP iterations/s (batch=%d, T=%d)" % (wl.B, wl.T), "value": n_steps * (inst_it / wl.B) / dt,
+           "ms_per_step": 1e3 * dt / n_steps, "timed_steps": n_steps, "timed_seconds": dt, "dtype": "f32" if elem == 4 else "f64",
+           "kernel": roof["kernel"], "mean_iterations": float(it.mean()),
+           "status_counts": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
+           "roofline": roof, "traffic": traffic}
+    del solver
+    return out
+
+
+def secondary_legs(device_index: int, seed: int, iters_per_solve: int, min_seconds: float):
+    out = {}
+    t0 = time.perf_counter()
+    for name in ("c3", "c4", "c4f64", "c5", "fmpc", "centroidal"):
+        try:
+            if name == "fmpc":
+                import bench_fmpc
+                out[name] = bench_fmpc.secondary_leg(device_index, seed, min_seconds)
+            else:
+                out[name] = ddp_secondary_leg(name, device_index, seed, iters_per_solve, min_seconds)
+        except Exception as e:  # the headline stands on its own; say which leg is missing and why
+            out[name] = {"value": None, "error": repr(e)}
+    out["seconds_total"] = time.perf_counter() - t0
+    return out
 
 
 def main():
@@ -497,6 +626,11 @@ def main():
             extras["default_threshold"] = leg("nominal", args.iters_per_solve, 20, cost_update_thre=1e-7)
             extras["fp32_tolerance_m2"] = leg("m2", 500, 10, cost_update_thre=1e-3)
 
+    secondary = None
+    if (rank == 0 and world == 1 and args.workload == "c2" and args.mode == "nominal" and not args.no_secondary
+            and args.batch == 0 and args.horizon == 0 and args.global_batch <= 0):
+        secondary = secondary_legs(device_index, args.seed, args.iters_per_solve, args.secondary_seconds)
+
     if rank == 0:
         words = workloads.algorithmic_words_per_instance_iteration(wl.n, wl.m, wl.T, n_bw, n_fw)
         fused = workloads.fused_words_per_instance_iteration(wl.n, wl.m, wl.T, n_bw, n_fw)
@@ -595,6 +729,8 @@ def main():
                 "fused_lower_bound_bytes_per_launch": fused * float(elem) * inst_it_per_solve,
             },
         }
+        if secondary is not None:
+            out["secondary"] = secondary
         if "m1" in extras:
             out["roofline_m1"] = extras["m1"]["roofline"]
             out["roofline_m2"] = extras["m2"]["roofline"]

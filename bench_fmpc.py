@@ -91,6 +91,121 @@ def cpu_baseline(x0, T, max_iter, target_seconds, host_cores):
     }
 
 
+def setup(B: int, T: int, max_iter: int, seed: int, device_index: int):
+    """The solver, the step closure (restore the resident initial guess, one batched solve through the C-ABI) and the host x0."""
+    import torch
+    from nmpc_amd import fmpc as F
+    dev = torch.device("cuda", device_index)
+    prob = F.FmpcProblemCartPole(0.01)
+    x0 = workload(B, seed)
+    solver = F.FmpcSolverBatch(prob, B, T, device=device_index)
+    solver.config().max_iter = max_iter
+    solver._push_config()
+    solver._prob_for_bench = prob
+    L, h = solver._L, solver._h
+    # the initial guess, resident on the device in the boundary layout; restored before every solve
+    init = F.Variable.make(prob, T, B)
+    init.reset(0.0, 0.0, 0.0, 1.0, 1.0)
+    d_init = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in init.arrays()]
+    d_eps = torch.full((B,), 1e-4, dtype=torch.float64, device=dev)
+    d_x0 = torch.from_numpy(x0).to(dev)
+    d_t0 = torch.zeros(B, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    keep = (d_init, d_eps, d_x0, d_t0)
+
+    def step(_keep=keep):
+        F.check(L.nmpc_hip_fmpc_set_variable(h, *[a.data_ptr() for a in d_init], d_eps.data_ptr(), 1))
+        F.check(L.nmpc_hip_fmpc_solve_device(h, d_t0.data_ptr(), d_x0.data_ptr(), None))
+
+    return solver, step, x0
+
+
+def riccati_words(n: int, m: int):
+    """Algorithmic doubles per (instance, timestep) of the Riccati kernel: (total, coefficient record, gain record, forward reads)."""
+    coef = 2 * n * n + 2 * n * m + m * m + 2 * n + m
+    gain = m + m * n + n + n * n
+    fwd = n * n + n * m + n + m * n + m
+    return coef + gain + fwd + (n + m), coef, gain, fwd
+
+
+def profile_kernels(solver, step, n_prof: int):
+    """Second pass with an event pair around every kernel launch (config.time_kernels): per-class ms sums and launch counts."""
+    from nmpc_amd import fmpc as F
+    solver.config().time_kernels = True
+    solver._push_config()
+    k_ms = {k: 0.0 for k in F.KERNEL_CLASSES}
+    k_n = {k: 0 for k in F.KERNEL_CLASSES}
+    for _ in range(n_prof):
+        step()
+        d = solver.computationDuration()
+        for k in F.KERNEL_CLASSES:
+            k_ms[k] += d.kernels[k]
+            k_n[k] += d.launches[k]
+    solver.config().time_kernels = False
+    solver._push_config()
+    return k_ms, k_n
+
+
+def traffic_entry(B: int, T: int):
+    """(bytes per Riccati launch, source) from profiles/hbm_traffic.json if measured on these device sources, else (None, why)."""
+    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        from nmpc_amd import build as hip_build
+        src_hash = hip_build.source_hash()
+        entry = json.load(open(traffic_file)).get("fmpc")
+        if entry and entry.get("batch") == B and entry.get("horizon") == T:
+            if entry.get("source_hash") != src_hash:
+                return None, "profiles/hbm_traffic.json holds a measurement of other device sources (hash %s, now %s): not used" % (
+                    entry.get("source_hash"), src_hash)
+            return entry.get("hbm_bytes_per_launch"), entry.get("source")
+    except Exception:
+        pass
+    return None, None
+
+
+def secondary_leg(device_index: int, seed: int, min_seconds: float = 0.5):
+    """The FMPC workload as a secondary leg of bench.py's default line: >= min_seconds of timed steps, the Riccati kernel's roofline."""
+    from nmpc_amd import fmpc as F
+    B, T, max_iter = BATCH, HORIZON, MAX_ITER
+    solver, step, _ = setup(B, T, max_iter, seed, device_index)
+    prob = solver._prob_for_bench
+    L, h = solver._L, solver._h
+    for _ in range(3):
+        step()
+    F.check(L.nmpc_hip_fmpc_synchronize(h))
+    t0 = time.perf_counter()
+    step()
+    F.check(L.nmpc_hip_fmpc_synchronize(h))
+    n_steps = int(max(4, np.ceil(min_seconds / max(time.perf_counter() - t0, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        step()
+    F.check(L.nmpc_hip_fmpc_synchronize(h))
+    dt = time.perf_counter() - t0
+    iters = solver.iters()
+    k_ms, k_n = profile_kernels(solver, step, 4)
+    words = riccati_words(prob.state_dim, prob.input_dim)[0]
+    bytes_per_launch = float(B) * T * words * 8.0
+    ric_ms = k_ms["riccati"] / max(k_n["riccati"], 1)
+    ach = bytes_per_launch / (ric_ms * 1e-3) / 1e9
+    traffic, src = traffic_entry(B, T)
+    out = {"workload": "FMPC cart-pole (TestFmpcCartPole): nx=4, nu=1, 4 inequality rows, T=%d, max_iter=%d, batch=%d, fp64" % (T, max_iter, B),
+           "metric": "FMPC iterations/s", "value": n_steps * (float(iters.sum()) / B) / dt, "ms_per_step": 1e3 * dt / n_steps,
+           "timed_steps": n_steps, "timed_seconds": dt, "dtype": "f64",
+           "kernel": next(k for k in solver.kernelNames() if "riccati" in k), "kernels": solver.kernelNames(),
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": traffic, "kernel_ms_avg": ric_ms, "launches_timed": k_n["riccati"],
+                        "algorithmic_bytes_per_launch": bytes_per_launch,
+                        "share_of_solve_time": k_ms["riccati"] / max(sum(k_ms.values()), 1e-12)}}
+    if traffic:
+        out["roofline"]["traffic_source"] = src
+        out["roofline"]["hbm_frac_measured"] = traffic / (ric_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    elif src:
+        out["roofline"]["traffic_note"] = src
+    out["traffic"] = traffic
+    return out
+
+
 def main(args, host_cores):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -119,26 +234,10 @@ def main(args, host_cores):
     B = args.batch or BATCH
     T = args.horizon or HORIZON
     max_iter = MAX_ITER
-    prob = F.FmpcProblemCartPole(0.01)
+    solver, step, x0 = setup(B, T, max_iter, args.seed + 7919 * rank, device_index)
+    prob = solver._prob_for_bench
     n, m, g = prob.state_dim, prob.input_dim, prob.ineq_dim
-    x0 = workload(B, args.seed + 7919 * rank)
-    solver = F.FmpcSolverBatch(prob, B, T, device=device_index)
-    solver.config().max_iter = max_iter
-    solver._push_config()
     L, h = solver._L, solver._h
-
-    # the initial guess, resident on the device in the boundary layout; restored before every solve
-    init = F.Variable.make(prob, T, B)
-    init.reset(0.0, 0.0, 0.0, 1.0, 1.0)
-    d_init = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in init.arrays()]
-    d_eps = torch.full((B,), 1e-4, dtype=torch.float64, device=dev)
-    d_x0 = torch.from_numpy(x0).to(dev)
-    d_t0 = torch.zeros(B, dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
-
-    def step():
-        F.check(L.nmpc_hip_fmpc_set_variable(h, *[a.data_ptr() for a in d_init], d_eps.data_ptr(), 1))
-        F.check(L.nmpc_hip_fmpc_solve_device(h, d_t0.data_ptr(), d_x0.data_ptr(), None))
 
     def barrier():
         if world > 1:
@@ -183,26 +282,12 @@ def main(args, host_cores):
     job_inst_it = sum(float(s[1]) for s in per_rank)
 
     # second pass, outside the timed region: the same steps with an event pair around every kernel launch
-    solver.config().time_kernels = True
-    solver._push_config()
-    k_ms = {k: 0.0 for k in F.KERNEL_CLASSES}
-    k_n = {k: 0 for k in F.KERNEL_CLASSES}
     n_prof = max(1, min(args.steps, 20))
-    for _ in range(n_prof):
-        step()
-        d = solver.computationDuration()
-        for k in F.KERNEL_CLASSES:
-            k_ms[k] += d.kernels[k]
-            k_n[k] += d.launches[k]
-    solver.config().time_kernels = False
-    solver._push_config()
+    k_ms, k_n = profile_kernels(solver, step, n_prof)
 
     if rank == 0:
         value = args.steps * (job_inst_it / B) / elapsed
-        coef = 2 * n * n + 2 * n * m + m * m + 2 * n + m
-        gain = m + m * n + n + n * n
-        fwd = n * n + n * m + n + m * n + m
-        words = coef + gain + fwd + (n + m)
+        words, coef, gain, fwd = riccati_words(n, m)
         bytes_per_launch = float(B) * T * words * 8.0
         ric_ms = k_ms["riccati"] / max(k_n["riccati"], 1)
         achieved = bytes_per_launch / (ric_ms * 1e-3) / 1e9
@@ -262,23 +347,15 @@ def main(args, host_cores):
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "unit": "FMPC iterations/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(traffic_file):
-            try:
-                from nmpc_amd import build as hip_build
-                src_hash = hip_build.source_hash()
-                entry = json.load(open(traffic_file)).get("fmpc")
-                if entry and entry.get("batch") == B and entry.get("horizon") == T and entry.get("source_hash") != src_hash:
-                    out["roofline"]["traffic_note"] = ("profiles/hbm_traffic.json holds a measurement of other device sources (hash %s, "
-                                                       "now %s): not used" % (entry.get("source_hash"), src_hash))
-                elif entry and entry.get("batch") == B and entry.get("horizon") == T:
-                    out["roofline"]["traffic"] = entry.get("hbm_bytes_per_launch")
-                    out["roofline"]["traffic_source"] = entry.get("source")
-                    out["roofline"]["traffic_source_hash"] = src_hash
-                    if out["roofline"]["traffic"]:
-                        out["roofline"]["hbm_frac_measured"] = out["roofline"]["traffic"] / (ric_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-            except Exception:
-                pass
+        traffic, src = traffic_entry(B, T)
+        if traffic:
+            from nmpc_amd import build as hip_build
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["traffic_source"] = src
+            out["roofline"]["traffic_source_hash"] = hip_build.source_hash()
+            out["roofline"]["hbm_frac_measured"] = traffic / (ric_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        elif src:
+            out["roofline"]["traffic_note"] = src
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

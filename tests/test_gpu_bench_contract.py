@@ -67,6 +67,20 @@ def test_default_line_has_the_contract_keys():
     from nmpc_amd import build as hip_build
     if rf["traffic"] is not None:
         assert rf["traffic_source_hash"] == hip_build.source_hash()
+    # the other workloads ride along as secondary legs: >= 0.5 s each, own kernel and roofline
+    sec = d["secondary"]
+    kernels = {"c3": "ddp_solve_quad_kernel<bipedal>", "c4": "ddp_solve_tile64_kernel<quadrotor_f32>", "c4f64": "ddp_solve_tile64_kernel<quadrotor>",
+               "c5": "ddp_solve_tile64_kernel<manipulator>", "fmpc": "fmpc_riccati_quad_kernel", "centroidal": "ddp_solve_tile64_kernel<centroidal>"}
+    for name, kernel in kernels.items():
+        leg = sec[name]
+        assert leg.get("error") is None, (name, leg)
+        for key in ("value", "ms_per_step", "kernel", "roofline", "traffic", "timed_seconds", "workload"):
+            assert key in leg, (name, key)
+        assert leg["value"] > 0 and leg["ms_per_step"] > 0 and leg["timed_seconds"] >= 0.5 and leg["kernel"] == kernel, (name, leg["kernel"])
+        r = leg["roofline"]
+        assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.01 < r["frac"] < 2.0 and r["kernel_ms_avg"] > 0
+        assert leg["traffic"] == r["traffic"]
+    assert sec["seconds_total"] < 60.0
 
 
 def test_c4_runs_in_fp32_on_a_tile_kernel():

@@ -23,6 +23,7 @@
 
 #include <nmpc_amd/DDPProblem.hpp>
 #include <nmpc_hip_ddp.h>
+#include <nmpc_amd/hip/fuzz_sched.hpp>
 
 #define NMPC_D __device__ __forceinline__
 
@@ -110,11 +111,13 @@ struct Unroll
     as full barriers and now are.) */
 NMPC_D inline void fullBarrier()
 {
+  fuzzSched(1);
 #ifdef NMPC_AMD_AB_LDS_ONLY_PASS_BARRIER // (A/B builds: what __syncthreads() compiles to — scripts/determinism_soak.py against it)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
+  fuzzSched(2);
 }
 
 /** Input limits of instance b at timestep i (input_limits_func_(current_t + i dt), DDPSolver.hpp:470-472): the sampled
@@ -1915,7 +1918,7 @@ __global__ __launch_bounds__(256) void batch_major_to_tile_kernel(const TIn * __
     const int bb = tile * 64 + k, r = r0 + tx;
     blk[k][tx] = (bb < B && r < R) ? static_cast<TOut>(in[static_cast<size_t>(bb) * R + r]) : TOut(0);
   }
-  __syncthreads();
+  syncThreadsFuzzed(__LINE__);
   TOut * o = out + (static_cast<size_t>(tile) * halves + half) * R * 64;
   for(int k = ty; k < 64; k += 4)
   {
@@ -1963,7 +1966,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(const TIn * __restrict__ t0
     const int bb = tile * 64 + k, r = r0 + tx;
     blk[k][tx] = (bb < B && r < R) ? static_cast<TOut>(in[static_cast<size_t>(bb) * R + r]) : TOut(0);
   }
-  __syncthreads();
+  syncThreadsFuzzed(__LINE__);
   TOut * o = (is_u ? u_out : x_out) + static_cast<size_t>(tile) * halves * R * 64;
   for(int k = ty; k < 64; k += 4)
   {
@@ -2002,7 +2005,7 @@ __global__ __launch_bounds__(256) void tile_to_batch_major_kernel(const TIn * __
       blk[k][tx] = (r < R && r < valid) ? static_cast<TOut>(src[static_cast<size_t>(r) * 64 + tx]) : TOut(0);
     }
   }
-  __syncthreads();
+  syncThreadsFuzzed(__LINE__);
   for(int k = ty; k < 64; k += 4)
   {
     const int bb = tile * 64 + k, r = r0 + tx;

@@ -232,7 +232,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 #else
   NMPC_D static void wgBarrier()
   {
+    fuzzSched(3);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    fuzzSched(4);
   }
   // product builds: two accumulators per wave (backward passes, forward passes), read by the master at the end of the solve
   // (phaseFlush); the timestamps sit at pass boundaries, next to the workgroup barriers

@@ -210,7 +210,7 @@ struct TileSolver32
   }
   NMPC_D static void barrier()
   {
-    __syncthreads(); // (LDS only: s_waitcnt lgkmcnt(0); s_barrier)
+    syncThreadsFuzzed(5); // (LDS only: s_waitcnt lgkmcnt(0); s_barrier)
   }
   /** Between the phases of an iteration: the gains the matrix waves stored and the trajectory the model wave stored are
       loaded by other waves in the next phase (fullBarrier(), ddp_kernels.hpp). */

@@ -363,15 +363,17 @@ struct TileSolver64
   }
   NMPC_D static void barrier()
   {
-    __syncthreads();
+    syncThreadsFuzzed(6);
   }
   /** A barrier that PUBLISHES global memory written by this wave (gains, candidate trajectories) to the other waves of the
       workgroup.  __syncthreads() waits for LDS traffic only (workgroup scope: the compiler relies on the CU's shared L1 keeping
       the waves' global accesses in order); the stores are drained explicitly so that nothing depends on that. */
   NMPC_D static void publishBarrier()
   {
+    fuzzSched(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    fuzzSched(8);
   }
   /** Lanes of ONE wave exchange data through LDS without a barrier (the LDS executes a wave's instructions in order); the
       compiler, which reasons per thread, must be kept from moving a lane's reads above the other lanes' writes. */
@@ -2760,7 +2762,9 @@ struct TileSolver64
               if(adopt && wide)
               {
                 adoptCandidates(group);
+#ifndef NMPC_AMD_AB_REOPEN_ADOPT_RACE // (test builds only: the race of commit 2b8d598 re-opened, for the fuzz experiment)
                 barrier(); // (every wave has read the slot table: Step 4 below flips sSel)
+#endif
                 break;
               }
               pass = 3;
@@ -2813,7 +2817,9 @@ struct TileSolver64
             if(adopt)
             {
               adoptCandidates(group);
+#ifndef NMPC_AMD_AB_REOPEN_ADOPT_RACE
               barrier(); // (every wave has read the slot table: Step 4 below flips sSel)
+#endif
               break;
             }
             pass = 3;

@@ -193,7 +193,7 @@ struct WaveSolver
       the same wave in the next phase — wait for everything in flight (one wavefront per workgroup: no one to wait for). */
   NMPC_D static void sync()
   {
-    __syncthreads();
+    syncThreadsFuzzed(__LINE__);
   }
   /** Inside a phase only LDS is exchanged between lanes.  The LDS executes one wave's instructions in order, so a
       compiler fence is all that is needed — and prefetches / stores to HBM stay in flight. */

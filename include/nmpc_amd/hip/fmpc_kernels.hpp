@@ -32,6 +32,7 @@
 
 #include <nmpc_amd/FmpcProblem.hpp>
 #include <nmpc_hip_fmpc.h>
+#include <nmpc_amd/hip/fuzz_sched.hpp>
 
 namespace nmpc_amd
 {
@@ -480,7 +481,7 @@ __global__ void __launch_bounds__(64 * fmpc::kSlices) fmpc_barrier_kernel(FmpcBu
     }
   }
   sh[q][lane] = acc;
-  __syncthreads();
+  syncThreadsFuzzed(__LINE__);
   if(q == 0 && act)
   {
     double eps = buf.barrier_eps[b];
@@ -533,7 +534,7 @@ __global__ void __launch_bounds__(64 * fmpc::kSlices) fmpc_step_length_kernel(Fm
   }
   sh[0][q][lane] = a_s;
   sh[1][q][lane] = a_nu;
-  __syncthreads();
+  syncThreadsFuzzed(__LINE__);
   if(q == 0 && act)
   {
     for(int k = 1; k < fmpc::kSlices; k++)
@@ -660,7 +661,7 @@ __global__ void __launch_bounds__(256) fmpc_transpose_kernel(const double * src,
       tile[k][tx] = src[static_cast<size_t>(r) * cols + c];
     }
   }
-  __syncthreads();
+  syncThreadsFuzzed(__LINE__);
   for(int k = ty; k < 32; k += 8)
   {
     const int c = c0 + k, r = r0 + tx;
@@ -1565,7 +1566,7 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     }
     sh_kkt[t_inst][t_slot] = acc;
   }
-  __syncthreads();
+  syncThreadsFuzzed(__LINE__);
   if(head)
   {
     double kkt_error = 0;
@@ -1586,13 +1587,16 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     }
     sh_kkt[inst][16] = kkt_error;
   }
-  __syncthreads();
+  syncThreadsFuzzed(__LINE__);
   live = live && !(sh_kkt[inst][16] <= buf.kkt_error_thre);
   if(head)
   {
     sh_live[inst] = live ? 1 : 0;
   }
-  if(__syncthreads_or(live ? 1 : 0) == 0)
+  fuzzSched(__LINE__);
+  const int any_live = __syncthreads_or(live ? 1 : 0);
+  fuzzSched(__LINE__);
+  if(any_live == 0)
   {
     return; // workgroup-uniform: none of the sixteen instances is live
   }
@@ -1736,7 +1740,7 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     double vb[kS * kQB];
     request(TagB(), buf.coef, CL::kStride, T - 1, -1, vb);
     commit(TagB(), 0, kRecB, 0, vb);
-    __syncthreads();
+    syncThreadsFuzzed(__LINE__);
     int slot = 0;
 #ifdef NMPC_AMD_FMPC_PROFILE2
     unsigned long long pa = 0, pb = 0, pc = 0, pd = 0, t0_, t1_, t2_, t3_, t4_;
@@ -1771,7 +1775,7 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
 #ifdef NMPC_AMD_FMPC_PROFILE2
       t2_ = wall_clock64();
 #endif
-      __syncthreads(); // every wavefront's gains of this chunk are in LDS
+      syncThreadsFuzzed(__LINE__); // every wavefront's gains of this chunk are in LDS
       if(i0 - kS >= 0)
       {
         commit(TagB(), slot ^ 1, kRecB, 0, vb);
@@ -1781,7 +1785,7 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
       t3_ = wall_clock64();
 #endif
       flushGains(i0);
-      __syncthreads();
+      syncThreadsFuzzed(__LINE__);
 #ifdef NMPC_AMD_FMPC_PROFILE2
       t4_ = wall_clock64();
       pa += t1_ - t0_;
@@ -1822,7 +1826,7 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
   // (no early exit from here on: every wavefront of the workgroup takes part in the staging barriers of the forward pass,
   // and the gains the other wavefronts wrote above are read below: make them visible first)
   __threadfence();
-  __syncthreads();
+  syncThreadsFuzzed(__LINE__);
 
   // ---- forward pass, the recursion over the timesteps (:669-687); dx[row] is kept by every lane of the row
 #ifdef NMPC_AMD_FMPC_PROFILE
@@ -1861,7 +1865,7 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     request(TagFg(), buf.gain, GL::kStride, 0, 1, vg);
     commit(TagFc(), 0, kRecF, 0, vc);
     commit(TagFg(), 0, kRecF, kFwdCoef, vg);
-    __syncthreads();
+    syncThreadsFuzzed(__LINE__);
     int slot = 0;
     for(int i0 = 0; i0 < T; i0 += kS)
     {
@@ -1885,7 +1889,7 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
           forwardStep(st, o[st & 1]);
         }
       }
-      __syncthreads();
+      syncThreadsFuzzed(__LINE__);
       if(i0 + kS < T)
       {
         commit(TagFc(), slot ^ 1, kRecF, 0, vc);
@@ -1911,7 +1915,7 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
           }
         }
       }
-      __syncthreads();
+      syncThreadsFuzzed(__LINE__);
       slot ^= 1;
     }
   }

@@ -148,5 +148,65 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def variant_path(name: str) -> str:
+    return os.path.join(LIB_DIR, name, "libnmpc_hip_ddp.so")
+
+
+def build_variant(name: str, extra_flags, force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
+    """A second library with extra compiler flags on EVERY translation unit, written to nmpc_amd/lib/<name>/ (objects beside it):
+    test builds such as the wave-timing fuzz (`fuzz_path()`); load it with NMPC_HIP_DDP_LIB=<path>.  Rebuilt when a source or header is
+    newer than the library."""
+    out_dir = os.path.join(LIB_DIR, name)
+    lib = variant_path(name)
+    deps = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))] + _headers()
+    if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
+        return lib
+    os.makedirs(os.path.join(out_dir, "obj"), exist_ok=True)
+    cc = hipcc()
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}"] + list(extra_flags)
+    objs, pending = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(out_dir, "obj", s.replace(".hip", ".o"))
+        objs.append(obj)
+        pending.append([cc] + flags + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
+    jobs = jobs or (os.cpu_count() or 4)
+    running = []
+    while pending or running:
+        while pending and len(running) < jobs:
+            cmd = pending.pop(0)
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            running.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        cmd, p = running.pop(0)
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout)
+    return lib
+
+
+def fuzz_path(seed: int = 1) -> str:
+    return variant_path("fuzz%d" % seed)
+
+
+def build_fuzz(seed: int = 1, force: bool = False, verbose: bool = False) -> str:
+    """The wave-timing fuzz build (include/nmpc_amd/hip/fuzz_sched.hpp): every barrier of every kernel family is preceded and
+    followed by a per-wave pseudo-random sleep.  Results must be bit-identical to the product build's (tests/test_gpu_fuzz_sched.py)."""
+    return build_variant("fuzz%d" % seed, ["-DNMPC_AMD_FUZZ_SCHED=%d" % seed] + os.environ.get("NMPC_AMD_FUZZ_EXTRA_FLAGS", "").split(),
+                         force=force, verbose=verbose)
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--fuzz" in sys.argv:
+        k = sys.argv.index("--fuzz")
+        seeds = [int(a) for a in sys.argv[k + 1:] if a.isdigit()] or [1]
+        for sd in seeds:
+            print(build_fuzz(sd, force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,14 @@
+#!/bin/bash
+# The whole GPU suite + the determinism soak against the wave-timing fuzz libraries, one seed after the other.
+# usage (GPU box): scripts/fuzz_suite.sh [seeds...] > profiles/r05_fuzz_suite.txt      (default seeds: 1 2 3)
+cd "$(dirname "$0")/.."
+SEEDS=${@:-1 2 3}
+for s in $SEEDS; do
+  LIB=$(python -c "from nmpc_amd import build as b; print(b.build_fuzz($s))") || exit 1
+  echo "== fuzz seed $s: $LIB"
+  export NMPC_HIP_DDP_LIB=$LIB
+  # (the fuzz test itself compares product against fuzz and manages the variable on its own; the bench-contract tests time things)
+  python -m pytest tests -m gpu -q -x --deselect tests/test_gpu_fuzz_sched.py --deselect tests/test_gpu_bench_contract.py 2>&1 | tail -4
+  python scripts/determinism_soak.py 20 2>&1 | tail -12
+  unset NMPC_HIP_DDP_LIB
+done

@@ -35,6 +35,7 @@ CASES = [
     ("quad bipedal", lambda: W.bipedal_batch(B=1024 if big else 256, T=300, seed=7), dict(max_iter=4), None),
     ("two-wave", lambda: W.cartpole_batch(B=8192 if big else 1024, T=100, seed=99), dict(max_iter=6), "2w"),
     ("two-wave box", lambda: W.cartpole_batch(B=8192 if big else 512, T=100, seed=98, constrained=True), dict(max_iter=5, with_input_constraint=True), "2w"),
+    ("lane 1w", lambda: W.cartpole_batch(B=512, T=100, seed=17), dict(max_iter=6), "1w"),
     ("lane vertical", lambda: W.vertical_batch(B=256, T=300, seed=5), dict(max_iter=4, with_input_constraint=True), None),
     ("tile32 c4", lambda: W.quadrotor_batch(B=8192 if big else 1024, T=50, seed=5, fp32=True), dict(max_iter=4, cost_update_thre=1e-3), "tile32"),
     ("tile32 c4 forced", lambda: W.quadrotor_batch(B=8192 if big else 1024, T=50, seed=6, fp32=True), dict(max_iter=8, **FORCED), "tile32"),

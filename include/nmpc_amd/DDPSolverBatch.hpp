@@ -84,6 +84,8 @@ public:
     int trace_level = 1;
     //! line-search schedule (nmpc_hip_ddp_config::line_search_fan_out): 0 automatic, 1 step-size parallel, 2 sequential
     int line_search_fan_out = 0;
+    //! ragged-convergence schedule of long solves (nmpc_hip_ddp_config::ragged_schedule): 0 automatic, 1 on, -1 off
+    int ragged_schedule = 0;
   };
 
   /*! \brief Control data of one instance (DDPSolver::ControlData, DDPSolver.h:113-123). */
@@ -252,6 +254,57 @@ public:
       std::cout << "[DDP] Failure due to large lambda in " << n_fail << " of " << B << " instances." << std::endl;
     }
     return ok;
+  }
+
+  /** \brief solve() without waiting for the device: the inputs are validated and staged (the arguments may be reused when the call
+      returns), the solve is queued on the handle's stream; wait() blocks until it is done and fetches the results, after which the
+      accessors (controlData(b), traceDataList(b), ...) hold them.  What DDPSolverPool overlaps consecutive batches with. */
+  void solveAsync(const std::vector<double> & current_t,
+                  const std::vector<StateDimVector> & current_x,
+                  const std::vector<std::vector<InputDimVector>> & initial_u_list)
+  {
+    std::vector<double> x0, u0;
+    sampleInputLimits(current_t);
+    packInputs(current_t, current_x, initial_u_list, x0, u0);
+    check(nmpc_hip_ddp_solve_async(handle_, current_t.data(), x0.data(), u0.data()));
+    fetched_ = false;
+    in_flight_ = true;
+  }
+
+  /** \brief Wait for the solve queued by solveAsync() and fetch its results.
+      \return per instance, whether the process finished successfully (converged) — what solve() returns */
+  std::vector<bool> wait()
+  {
+    if(!in_flight_ && !fetched_)
+    {
+      throw std::runtime_error("wait(): no solve has been queued");
+    }
+    if(!fetched_)
+    {
+      fetchResults(); // (nmpc_hip_ddp_get synchronises with the handle's stream)
+    }
+    in_flight_ = false;
+    std::vector<bool> ok(static_cast<size_t>(batch_size_));
+    for(size_t b = 0; b < ok.size(); b++)
+    {
+      ok[b] = status_[b] == 1;
+    }
+    return ok;
+  }
+
+  /** \brief Kernel launches the last solve was cut into (1: one whole-solve launch; more: the ragged-convergence schedule,
+      Configuration::ragged_schedule). */
+  /** \brief Whether a solve queued by solveAsync() has not been waited for yet. */
+  inline bool inFlight() const
+  {
+    return in_flight_;
+  }
+
+  int lastSolveLaunches() const
+  {
+    int n = 0;
+    check(nmpc_hip_ddp_last_solve_launches(handle_, &n));
+    return n;
   }
 
   /*! \brief Per-tick log of mpcRun(): the columns the reference's closed-loop tests dump (TestDDPBipedal.cpp:251-262). */
@@ -426,6 +479,7 @@ protected:
     c.cost_update_thre = config_.cost_update_thre;
     c.trace_level = config_.trace_level;
     c.line_search_fan_out = config_.line_search_fan_out;
+    c.ragged_schedule = config_.ragged_schedule;
     if(config_.alpha_list.empty() || config_.alpha_list.size() > NMPC_HIP_MAX_ALPHA)
     {
       throw std::invalid_argument("alpha_list size must be in [1, 32]");
@@ -673,6 +727,7 @@ protected:
   double lower_[MM];
   double upper_[MM];
   bool fetched_ = false;
+  bool in_flight_ = false; //!< a solve queued by solveAsync() has not been waited for
   std::vector<Problem> problem_batch_;
   bool problem_batch_dirty_ = false;
   std::vector<double> limits_batch_lo_, limits_batch_up_;
@@ -684,4 +739,98 @@ protected:
   std::vector<int> status_;
   ComputationDuration computation_duration_;
 };
+/** \brief Several DDPSolverBatch objects of the same problem and batch size, each with its own handle and stream: consecutive
+    batches are queued round-robin and overlap on the device (the C++ counterpart of nmpc_amd.DDPSolverPool, nmpc_amd/ddp.py).
+
+    A batch that is solved to convergence ends with a tail — a few instances that run for hundreds of iterations (every DDPSolver
+    object of the reference runs its own loop to ITS end, DDPSolver.hpp:115-123).  With the next batches already queued on other
+    streams their workgroups take the CUs the converged instances have vacated; with the ragged-convergence schedule
+    (Configuration::ragged_schedule, on by default for long solves) a finished instance vacates its slot within sixteen iterations
+    instead of when the slowest of its workgroup is done.  The results of a batch are those of the handle it ran on — bit-identical
+    to a lone DDPSolverBatch.
+
+        DDPSolverPool<DDPProblemCartPole> pool(problem, 4096, 4);
+        pool.config().max_iter = 500;                       // one Configuration for all handles
+        for(const auto & batch : batches) {
+          auto & solver = pool.submit(batch.t, batch.x, batch.u);   // waits for (and returns) the handle's previous batch first
+          ...
+        }
+        pool.waitAll();                                      // then pool.solver(k).controlData(b) ... */
+template<class Problem>
+class DDPSolverPool
+{
+public:
+  using Solver = DDPSolverBatch<Problem>;
+  using StateDimVector = typename Solver::StateDimVector;
+  using InputDimVector = typename Solver::InputDimVector;
+
+  DDPSolverPool(const std::shared_ptr<Problem> & problem, int batch_size, int n_handles = 4, int device = 0)
+  {
+    if(n_handles < 1)
+    {
+      throw std::invalid_argument("n_handles should be positive");
+    }
+    for(int k = 0; k < n_handles; k++)
+    {
+      solvers_.emplace_back(new Solver(problem, batch_size, device));
+    }
+  }
+
+  /** \brief The Configuration of every handle (the first one's object; copied to the others at every submit()). */
+  inline typename Solver::Configuration & config()
+  {
+    return solvers_[0]->config();
+  }
+
+  inline int size() const
+  {
+    return static_cast<int>(solvers_.size());
+  }
+
+  inline Solver & solver(int k)
+  {
+    return *solvers_.at(static_cast<size_t>(k));
+  }
+
+  /** \brief Queue one batch on the next handle (round-robin).  If that handle still has a batch in flight it is waited for
+      first — read its results (the returned solver's accessors hold them until the new batch is waited for) or call wait(k)
+      before submitting n_handles further batches.
+      \return the solver the batch was queued on */
+  Solver & submit(const std::vector<double> & current_t,
+                  const std::vector<StateDimVector> & current_x,
+                  const std::vector<std::vector<InputDimVector>> & initial_u_list)
+  {
+    Solver & s = *solvers_[static_cast<size_t>(next_)];
+    next_ = (next_ + 1) % size();
+    if(&s != solvers_[0].get())
+    {
+      s.config() = solvers_[0]->config();
+    }
+    s.solveAsync(current_t, current_x, initial_u_list);
+    return s;
+  }
+
+  /** \brief Wait for the batch queued on handle k and fetch its results. */
+  std::vector<bool> wait(int k)
+  {
+    return solver(k).wait();
+  }
+
+  /** \brief Wait for every handle that has a batch in flight. */
+  void waitAll()
+  {
+    for(auto & s : solvers_)
+    {
+      if(s->inFlight())
+      {
+        s->wait();
+      }
+    }
+  }
+
+protected:
+  std::vector<std::unique_ptr<Solver>> solvers_;
+  int next_ = 0;
+};
+
 } // namespace nmpc_amd

@@ -80,7 +80,16 @@ struct DeviceBuffersT
   int lim_offset; //!< row of timestep 0 of this solve (the tick number in the device-resident shift loop, else 0)
   double lim_lo[kMaxInputDim]; //!< input lower limits (constant in time)
   double lim_hi[kMaxInputDim]; //!< input upper limits
+  // ---- resumable solves (the ragged-convergence schedule of capi.hip): one launch executes iterations
+  // iter_begin .. iter_end of the instances in positions [0, *n_active) and parks the per-instance solver state in `resume`; the host
+  // queues a compaction between launches (still-running instances swapped into a dense prefix) so that a workgroup is not held
+  // by one unconverged instance of sixteen.  iter_end = 0: an ordinary whole solve (every field below unused).
+  const int * n_active = nullptr; //!< device word: instances in the dense prefix of this launch (nullptr: B)
+  int iter_begin = 0; //!< first iteration of this launch (1: fresh start with the initial rollout; > 1: resume)
+  int iter_end = 0; //!< last iteration of this launch (<= max_iter); 0: not a resumable launch
+  S * resume = nullptr; //!< [tile][kResumeRows][64]: lambda, dlambda, J_cur, running (1 / 0) between launches
 };
+constexpr int kResumeRows = 4;
 /** The reference computes in double (DDPProblem.h:20-35): every kernel but the fp32 tile kernel uses this one. */
 using DeviceBuffers = DeviceBuffersT<double>;
 

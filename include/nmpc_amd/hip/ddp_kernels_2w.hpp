@@ -1817,9 +1817,10 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   // master: solve = setup + optimisation loop (DDPSolver.hpp:26-141, procOnce :143-340), written with wave-uniform
   // pass invocations (every lane of the wave enters every pass; `need_*` masks select whose state it updates)
   // ===================================================================================================
+  template<bool kResumable = false>
   NMPC_D void solveMaster(bool valid)
   {
-    solveMasterWith(valid,
+    solveMasterWith<kResumable>(valid,
                     [this](bool need)
                     {
                       post(kCmdBackward);
@@ -1830,8 +1831,39 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
                     });
   }
 
+  /** Resumable launches (kResumable instantiations, DeviceBuffers::iter_end > 0): the solver state an iteration hands to the
+      next — lambda, dlambda, the current cost, whether the instance still iterates; `sel` has its own array — is parked in
+      buf.resume when the launch's last iteration is done and taken from there by the next launch instead of the initial rollout.
+      Everything else an iteration needs it recomputes (Step 1 re-linearises, DDPSolver.hpp:157-185), so the iterations of an
+      instance are the same instruction stream on the same values whether one launch runs them or several. */
+  NMPC_D double & resumeWord(int row) const
+  {
+    return Base::elem(buf.resume, kResumeRows, row);
+  }
+  /** \return whether this lane's instance iterates in this launch */
+  NMPC_D bool resumeState(bool valid)
+  {
+    bool running = false;
+    if(valid)
+    {
+      lambda = resumeWord(0);
+      dlambda = resumeWord(1);
+      J_cur = resumeWord(2);
+      running = resumeWord(3) != 0.0;
+      sel = buf.sel[b];
+    }
+    return running;
+  }
+  NMPC_D void parkState(bool still_running) const
+  {
+    resumeWord(0) = lambda;
+    resumeWord(1) = dlambda;
+    resumeWord(2) = J_cur;
+    resumeWord(3) = still_running ? 1.0 : 0.0;
+  }
+
   /** \param runBackward (need) -> ok: one backward pass for the lanes in `need`, entered by the whole wave */
-  template<class BackwardFn>
+  template<bool kResumable = false, class BackwardFn>
   NMPC_D void solveMasterWith(bool valid, BackwardFn && runBackward)
   {
     current_t = buf.t0 ? Base::tileBase(buf.t0, 1)[lane] : 0.0;
@@ -1841,30 +1873,42 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     dV0 = dV1 = 0;
     k_rel_norm = 0;
     J_cand = 0;
+    J_cur = 0;
     phaseStart();
-    post(kCmdRollout);
-    profBegin();
-    rolloutMaster();
-    profEnd(1);
-
+    const bool resumed = kResumable && buf.iter_begin > 1;
+    bool active = valid; // this lane still iterates
     double tr[NMPC_HIP_NTRACE];
 #pragma unroll
     for(int f = 0; f < NMPC_HIP_NTRACE; f++)
     {
       tr[f] = 0;
     }
-    tr[NMPC_HIP_TRACE_COST] = J_cur;
-    tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
-    tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
-    tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
-    if(valid)
+    if(resumed)
     {
-      Base::writeTraceRow(0, tr);
+      active = resumeState(valid);
     }
+    else
+    {
+      post(kCmdRollout);
+      profBegin();
+      rolloutMaster();
+      profEnd(1);
+
+      tr[NMPC_HIP_TRACE_COST] = J_cur;
+      tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
+      tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
+      tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
+      if(valid)
+      {
+        Base::writeTraceRow(0, tr);
+      }
+    }
+    const bool took_part = active; // (a resumed launch leaves the results of instances that had finished before it alone)
+    const int iter_first = resumed ? buf.iter_begin : 1;
+    const int iter_last = (kResumable && buf.iter_end > 0 && buf.iter_end < cfg.max_iter) ? buf.iter_end : cfg.max_iter;
 
     int retval = 0;
-    bool active = valid; // this lane still iterates
-    for(int iter = 1; iter <= cfg.max_iter; iter++)
+    for(int iter = iter_first; iter <= iter_last; iter++)
     {
       if(!__any(active))
       {
@@ -2020,7 +2064,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     profFlush(0);
     phaseFlush(valid);
 
-    if(valid)
+    if(kResumable ? took_part : valid)
     {
 #pragma unroll
       for(int f = 0; f < NMPC_HIP_NTRACE; f++)
@@ -2032,13 +2076,20 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       buf.sel[b] = sel;
       Base::elem(buf.dV, 2, 0) = dV0;
       Base::elem(buf.dV, 2, 1) = dV1;
+      if constexpr(kResumable)
+      {
+        if(buf.iter_end > 0)
+        {
+          parkState(active && iter_last < cfg.max_iter);
+        }
+      }
     }
   }
   /** solveMasterWith() for solvers with lane groups (kAlphaGroups > 1): the same state machine with the step-size fan-out
       in the line search and the last trace row kept in LDS.  A separate function so that the code of the kernels without
       lane groups — the headline workload's — stays exactly as it is (it is sensitive to register allocation: -1.5 % with
       the two merged). */
-  template<class BackwardFn>
+  template<bool kResumable = false, class BackwardFn>
   NMPC_D void solveMasterFanOut(bool valid, BackwardFn && runBackward)
   {
     current_t = buf.t0 ? Base::tileBase(buf.t0, 1)[lane] : 0.0;
@@ -2049,10 +2100,20 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     k_rel_norm = 0;
     J_cand = 0;
     phaseStart();
-    post(kCmdRollout);
-    profBegin();
-    rolloutMaster();
-    profEnd(1);
+    const bool resumed = kResumable && buf.iter_begin > 1; // (see solveMasterWith)
+    bool resumed_running = false;
+    if(resumed)
+    {
+      J_cur = 0;
+      resumed_running = resumeState(valid);
+    }
+    else
+    {
+      post(kCmdRollout);
+      profBegin();
+      rolloutMaster();
+      profEnd(1);
+    }
 
     // The trace row of an iteration is assembled and written at its end; the last row of every lane waits in LDS for the
     // end of the solve (in registers it is 24 VGPRs that are live across every pass; written to HBM every iteration it is
@@ -2076,7 +2137,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
       tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
       tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
-      if(valid)
+      if(valid && !resumed)
       {
         Base::writeTraceRow(0, tr);
         writeLastRow(tr, 0);
@@ -2084,14 +2145,17 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     }
 
     int retval = 0;
-    bool active = valid; // this lane still iterates
+    bool active = resumed ? resumed_running : valid; // this lane still iterates
+    const bool took_part = active; // (a resumed launch leaves the results of instances that had finished before it alone)
+    const int iter_first = resumed ? buf.iter_begin : 1;
+    const int iter_last = (kResumable && buf.iter_end > 0 && buf.iter_end < cfg.max_iter) ? buf.iter_end : cfg.max_iter;
     // Extra masters: whether the FIRST pass of a line search is a wide one (twelve step sizes: waves 2 and 3 roll out too) is
     // predicted from the workgroup's previous search — wide if an instance went beyond the master's lane groups then.  The
     // nominal regime (first step size accepted) keeps the narrow pass, in which wave 2 only prefetches and the master never
     // waits for it (a wide pass is ~7 % longer: measured, profiles/r04_fanout_ab.txt); a search that exhausts the narrow pass
     // continues with wide ones.  The schedule changes which wave computes a cost, never the cost: results are independent of it.
     bool wide_first = false;
-    for(int iter = 1; iter <= cfg.max_iter; iter++)
+    for(int iter = iter_first; iter <= iter_last; iter++)
     {
       if(!__any(active))
       {
@@ -2352,7 +2416,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     profFlush(0);
     phaseFlush(valid);
 
-    if(valid)
+    if(kResumable ? took_part : valid)
     {
 #pragma unroll
       for(int f = 0; f < NMPC_HIP_NTRACE; f++)
@@ -2364,12 +2428,19 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       buf.sel[b] = sel;
       Base::elem(buf.dV, 2, 0) = dV0;
       Base::elem(buf.dV, 2, 1) = dV1;
+      if constexpr(kResumable)
+      {
+        if(buf.iter_end > 0)
+        {
+          parkState(active && iter_last < cfg.max_iter);
+        }
+      }
     }
   }
 };
 
 /** The 2-wave solve kernel: grid = Bp / 64 workgroups of 128 threads; wave 0 = master, wave 1 = helper. */
-template<class Problem, bool kConstrained, bool kOwnProblem = false>
+template<class Problem, bool kConstrained, bool kOwnProblem = false, bool kResumable = false>
 __global__ __launch_bounds__(2 * kLanesPerBlock) void ddp_solve_tpi2w_kernel(const Problem problem,
                                                                               const nmpc_hip_ddp_config cfg,
                                                                               const DeviceBuffers buf)
@@ -2384,7 +2455,15 @@ __global__ __launch_bounds__(2 * kLanesPerBlock) void ddp_solve_tpi2w_kernel(con
   Solver solver(mine, cfg, buf, b, lds_2w);
   if(wave == 0)
   {
-    solver.solveMaster(b < buf.B);
+    if constexpr(kResumable)
+    {
+      // (positions [0, *n_active) hold the instances that still iterate: the host's compaction between launches, capi.hip)
+      solver.template solveMaster<true>(b < (buf.n_active ? *buf.n_active : buf.B));
+    }
+    else
+    {
+      solver.solveMaster(b < buf.B);
+    }
   }
   else
   {

@@ -630,15 +630,16 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     return ok;
   }
 
+  template<bool kResumable = false>
   NMPC_D void solveMasterQuad(bool valid)
   {
     if constexpr(kConstrained || kFanOut)
     {
-      Pair::solveMasterFanOut(valid, [this](bool need) { return backwardMasterQuad(need); });
+      Pair::template solveMasterFanOut<kResumable>(valid, [this](bool need) { return backwardMasterQuad(need); });
     }
     else
     {
-      Pair::solveMasterWith(valid, [this](bool need) { return backwardMasterQuad(need); });
+      Pair::template solveMasterWith<kResumable>(valid, [this](bool need) { return backwardMasterQuad(need); });
     }
   }
 
@@ -715,7 +716,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     `-mllvm --amdgpu-mfma-vgpr-form` (nmpc_amd/build.py does): by default a kernel that may use 512 registers gets its
     matrix-core results in accumulation registers and spends ~30 v_accvgpr_read/write per timestep moving them to the
     VALU / DPP instructions that consume them (10.3k -> 10.6k iterations/s on the headline workload). */
-template<class Problem, bool kConstrained, bool kOwnProblem = false, bool kFanOut = kConstrained>
+template<class Problem, bool kConstrained, bool kOwnProblem = false, bool kFanOut = kConstrained, bool kResumable = false>
 __global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const Problem problem,
                                                                          const nmpc_hip_ddp_config cfg,
                                                                          const DeviceBuffers buf)
@@ -734,7 +735,14 @@ __global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const P
   Solver solver(mine, kOwnProblem ? mine_lin : mine, cfg, buf, b, lds_quad);
   if(threadIdx.x / 64 == 0)
   {
-    solver.solveMasterQuad(b < buf.B);
+    if constexpr(kResumable)
+    {
+      solver.template solveMasterQuad<true>(b < (buf.n_active ? *buf.n_active : buf.B));
+    }
+    else
+    {
+      solver.solveMasterQuad(b < buf.B);
+    }
   }
   else
   {

@@ -57,6 +57,10 @@ struct ModelOps
   //! 1 if the kernel launch_solve picks for such a batch has an instantiation with one problem object per instance
   //! (nmpc_hip_ddp_set_model_params_batch is refused otherwise — at set time, not at the first solve); nullptr: it has
   int (*own_problems_supported)(int batch, int constrained) = nullptr;
+  //! 1 if the kernel launch_solve picks for such a solve has a RESUMABLE instantiation (DeviceBuffers::iter_end > 0: a launch runs
+  //! iterations iter_begin .. iter_end of the dense prefix and parks the solver state): what the ragged-convergence schedule of
+  //! capi.hip needs; nullptr / 0: whole solves only
+  int (*resumable_supported)(int batch, const nmpc_hip_ddp_config & cfg, int own_problems) = nullptr;
 };
 
 } // namespace hip

@@ -112,6 +112,40 @@ struct ModelOpsFor
     const int padded = (batch + kLanesPerBlock - 1) / kLanesPerBlock * kLanesPerBlock;
     return (useTile64(constrained != 0, batch) || useWpi(constrained != 0) || useQuad(padded, true) || useTwoWave()) ? 1 : 0;
   }
+  /** Resumable launches (the ragged-convergence schedule): the quad kernel with the step-size-parallel line search and the
+      two-wave kernel, one problem object for all instances. */
+  static int resumableSupported(int batch, const nmpc_hip_ddp_config & cfg, int own_problems)
+  {
+    if(own_problems)
+    {
+      return 0;
+    }
+    const int padded = (batch + kLanesPerBlock - 1) / kLanesPerBlock * kLanesPerBlock;
+    const bool con = cfg.with_input_constraint != 0;
+    if constexpr(kTile64Shape)
+    {
+      if(useTile64(con, batch))
+      {
+        return 0;
+      }
+    }
+    if constexpr(kWpiShape)
+    {
+      if(useWpi(con))
+      {
+        return 0;
+      }
+    }
+    if constexpr(kQuadShape)
+    {
+      if(useQuad(padded, false))
+      {
+        const bool fan = cfg.line_search_fan_out == 1 || (cfg.line_search_fan_out == 0 && cfg.max_iter > fanOutAutoMaxIter());
+        return (con || fan) ? 1 : 0;
+      }
+    }
+    return (kTwoWaveFits && useTwoWave()) ? 1 : 0;
+  }
   static size_t wpiWorkspaceDoubles(int T)
   {
     if constexpr(kWpiShape && kTile64Shape)
@@ -196,6 +230,10 @@ struct ModelOpsFor
     const int grid = buf.Bp / kLanesPerBlock;
     const bool own = buf.params_batch != nullptr; // per-instance problem objects: separate instantiations (kOwnProblem)
     const bool con = cfg.with_input_constraint != 0;
+    if(buf.iter_end > 0 && !resumableSupported(buf.B, cfg, own ? 1 : 0))
+    {
+      return hipErrorNotSupported; // (capi.hip asks resumable_supported first)
+    }
     if constexpr(kTile64Shape)
     {
       if(useTile64(con, buf.B))
@@ -267,7 +305,9 @@ struct ModelOpsFor
         }
         if(!requested[dev].load(std::memory_order_acquire))
         {
-          const void * variants[6] = {reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, false>),
+          const void * variants[8] = {reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, false, true, true>),
+                                      reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true, false, true, true>),
+                                      reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, false>),
                                       reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true, false>),
                                       reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, false, true>),
                                       reinterpret_cast<const void *>(&ddp_solve_quad_kernel<Problem, true, true>),
@@ -286,7 +326,23 @@ struct ModelOpsFor
         }
         // step-size-parallel line search for unconstrained solves: on request, or (0 = automatic) for long solves
         const bool fan = cfg.line_search_fan_out == 1 || (cfg.line_search_fan_out == 0 && cfg.max_iter > fanOutAutoMaxIter());
-        if(con && own)
+        if(buf.iter_end > 0)
+        {
+          // a resumable launch (resumableSupported() has said yes: shared problem object, fan-out line search)
+          if(own || !(con || fan))
+          {
+            return hipErrorNotSupported;
+          }
+          if(con)
+          {
+            hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, true, false, true, true>), g, blk, quad_lds, stream, problem, cfg, buf);
+          }
+          else
+          {
+            hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, false, false, true, true>), g, blk, quad_lds, stream, problem, cfg, buf);
+          }
+        }
+        else if(con && own)
         {
           hipLaunchKernelGGL((ddp_solve_quad_kernel<Problem, true, true>), g, blk, quad_lds, stream, problem, cfg, buf);
         }
@@ -323,7 +379,22 @@ struct ModelOpsFor
         static_assert(lds_bytes <= 64 * 1024 && lds_bytes_con <= 64 * 1024,
                       "kTwoWaveFits keeps the records of both layouts within the default dynamic LDS limit");
         const dim3 g(grid), blk(2 * kLanesPerBlock);
-        if(con && own)
+        if(buf.iter_end > 0)
+        {
+          if(own)
+          {
+            return hipErrorNotSupported;
+          }
+          if(con)
+          {
+            hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, true, false, true>), g, blk, lds_bytes_con, stream, problem, cfg, buf);
+          }
+          else
+          {
+            hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, false, false, true>), g, blk, lds_bytes, stream, problem, cfg, buf);
+          }
+        }
+        else if(con && own)
         {
           hipLaunchKernelGGL((ddp_solve_tpi2w_kernel<Problem, true, true>), g, blk, lds_bytes_con, stream, problem, cfg, buf);
         }
@@ -415,6 +486,7 @@ struct ModelOpsFor
     ops.gain_layout = 0;
     ops.gain_layout_of = &gainLayoutOf;
     ops.own_problems_supported = &ownProblemsSupported;
+    ops.resumable_supported = &resumableSupported;
     static_assert(sizeof(typename Problem::Scalar) == 8, "these kernel families compute in double; fp32 problem types register "
                                                          "through ddp_kernels_tile32.hpp");
     return ops;

@@ -82,6 +82,13 @@ extern "C"
        0: automatic (parallel: the lane groups try the first four step sizes in the first pass, and the rollout of whichever
        is accepted is kept), 1: always parallel, 2: always sequential.  Box-constrained solves are always parallel. */
     int line_search_fan_out;
+    /* Ragged-convergence schedule of a long solve (every DDPSolver object of the reference stops when IT converges,
+       DDPSolver.hpp:115-123; a batch converges raggedly).  The solve is cut into resumable launches (iterations 1-16, 17-32, 33-48,
+       49-64, 65-96, ... of those still running) with a device-side compaction between them, so that a persistent workgroup is not held
+       by the one unconverged instance of its sixteen; no host round trip, results bit-identical to a single launch.
+       0: automatic (on for max_iter >= 32 where the kernel family has resumable instantiations: the quad and two-wave kernels
+       with a shared problem object), 1: on wherever supported, -1: off (one launch per solve). */
+    int ragged_schedule;
   } nmpc_hip_ddp_config;
 
   /** Trace columns (TraceData, DDPSolver.h:179-216).  The three duration_* fields of the reference are
@@ -192,6 +199,11 @@ extern "C"
       H2D copy, device solve, synchronise.  Results stay on the device until nmpc_hip_ddp_get. */
   int nmpc_hip_ddp_solve(nmpc_hip_ddp_handle h, const double * t0, const double * x0, const double * u_init);
 
+  /** nmpc_hip_ddp_solve without the final synchronise: the inputs are staged (the host arrays may be reused when the call
+      returns), the solve is queued on the handle's stream.  nmpc_hip_ddp_synchronize or nmpc_hip_ddp_get waits for it.  What a
+      pool of handles (DDPSolverPool in include/nmpc_amd/DDPSolverBatch.hpp) overlaps consecutive batches with. */
+  int nmpc_hip_ddp_solve_async(nmpc_hip_ddp_handle h, const double * t0, const double * x0, const double * u_init);
+
   /** Same with DEVICE pointers (reference layouts above, resident in HBM), asynchronous on `stream`
       (a hipStream_t, NULL = the solver's own stream).  Nothing is copied over PCIe. */
   int nmpc_hip_ddp_solve_device(nmpc_hip_ddp_handle h,
@@ -276,6 +288,11 @@ extern "C"
       when the model's LDS records fit) or "ddp_solve_tpi_kernel" (one wavefront per 64 instances; also forced by the
       environment variable NMPC_HIP_DDP_KERNEL=1w).  No reference counterpart: diagnostics for profiles / bench.py. */
   int nmpc_hip_ddp_kernel_name(nmpc_hip_ddp_handle h, const char ** name);
+
+  /** Kernel launches the LAST solve of this handle was cut into: 1 = one whole-solve launch; more = the ragged-convergence
+      schedule (nmpc_hip_ddp_config::ragged_schedule: resumable launches with a device-side compaction between them).  No reference
+      counterpart: diagnostics. */
+  int nmpc_hip_ddp_last_solve_launches(nmpc_hip_ddp_handle h, int * launches);
 
   /** Text of the last error raised on this thread (HIP error string or argument description). */
   const char * nmpc_hip_ddp_last_error(void);

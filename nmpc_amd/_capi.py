@@ -61,6 +61,7 @@ class Config(C.Structure):
         ("qp_armijo_param", C.c_double),
         ("trace_level", C.c_int),
         ("line_search_fan_out", C.c_int),
+        ("ragged_schedule", C.c_int),
     ]
 
 
@@ -86,10 +87,10 @@ EXPORTS = (
     "nmpc_hip_ddp_destroy", "nmpc_hip_ddp_set_config", "nmpc_hip_ddp_get_config",
     "nmpc_hip_ddp_set_model_params", "nmpc_hip_ddp_set_model_params_batch", "nmpc_hip_ddp_set_input_limits_batch",
     "nmpc_hip_ddp_input_dims", "nmpc_hip_ddp_set_input_limits", "nmpc_hip_ddp_set_input_limits_horizon",
-    "nmpc_hip_ddp_set_input_limits_schedule", "nmpc_hip_ddp_solve",
+    "nmpc_hip_ddp_set_input_limits_schedule", "nmpc_hip_ddp_solve", "nmpc_hip_ddp_solve_async",
     "nmpc_hip_ddp_solve_device", "nmpc_hip_ddp_synchronize", "nmpc_hip_ddp_get", "nmpc_hip_ddp_get_device",
     "nmpc_hip_ddp_field_bytes", "nmpc_hip_ddp_last_solve_ms", "nmpc_hip_ddp_last_solve_phases", "nmpc_hip_ddp_timing_stats",
-    "nmpc_hip_ddp_kernel_name", "nmpc_hip_ddp_mpc_default_options", "nmpc_hip_ddp_mpc_run",
+    "nmpc_hip_ddp_kernel_name", "nmpc_hip_ddp_last_solve_launches", "nmpc_hip_ddp_mpc_default_options", "nmpc_hip_ddp_mpc_run",
     "nmpc_hip_ddp_last_error",
 )
 
@@ -129,6 +130,7 @@ def load():
     L.nmpc_hip_ddp_set_input_limits_horizon.argtypes = [vp, dp, dp, C.c_int]
     L.nmpc_hip_ddp_set_input_limits_schedule.argtypes = [vp, dp, dp, C.c_int, C.c_int]
     L.nmpc_hip_ddp_solve.argtypes = [vp, dp, dp, dp]
+    L.nmpc_hip_ddp_solve_async.argtypes = [vp, dp, dp, dp]
     L.nmpc_hip_ddp_solve_device.argtypes = [vp, vp, vp, vp, vp]
     L.nmpc_hip_ddp_synchronize.argtypes = [vp]
     L.nmpc_hip_ddp_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -137,6 +139,7 @@ def load():
     L.nmpc_hip_ddp_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.nmpc_hip_ddp_last_solve_phases.argtypes = [vp, dp, dp, dp]
     L.nmpc_hip_ddp_kernel_name.argtypes = [vp, C.POINTER(C.c_char_p)]
+    L.nmpc_hip_ddp_last_solve_launches.argtypes = [vp, C.POINTER(C.c_int)]
     L.nmpc_hip_ddp_mpc_default_options.argtypes = [C.POINTER(MpcOptions)]
     L.nmpc_hip_ddp_mpc_run.argtypes = [vp, dp, dp, dp, C.POINTER(MpcOptions), dp, dp, dp, ip, ip, ip, dp, dp]
     L.nmpc_hip_ddp_timing_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), dp, dp]

@@ -6,11 +6,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include <nmpc_amd/hip/model_ops.hpp>
+#include <nmpc_amd/hip/ragged_schedule.hpp>
 
 using nmpc_amd::hip::DeviceBuffers;
 using nmpc_amd::hip::ModelOps;
@@ -115,6 +117,14 @@ struct nmpc_hip_ddp_solver
   size_t stage_in_bytes = 0;
   void * d_stage_out = nullptr; // one result field in the reference layout
   size_t stage_out_bytes = 0;
+  // ragged-convergence schedule (ragged_schedule.hpp): resumable launches with a device-side compaction between them
+  static constexpr int kRaggedMaxRounds = 24;
+  double * d_resume = nullptr; // [tile][kResumeRows][64] parked solver state (Scalar array)
+  int * d_ragged_words = nullptr; // n_active[kRaggedMaxRounds + 1], then n_swaps[kRaggedMaxRounds]
+  int * d_ragged_pairs = nullptr; // [kRaggedMaxRounds][Bp]: the (p, q) position pairs of every round's swaps
+  int * d_ragged_rank = nullptr; // [Bp] scratch of the compaction kernel
+  int ragged_env = 0; // NMPC_HIP_DDP_RAGGED, read once at create: 1 forces the schedule on, -1 off (A/B measurements)
+  int last_ragged_rounds = 0; // launches of the last solve (1: an ordinary whole-solve launch)
 };
 
 namespace
@@ -450,6 +460,158 @@ int checkConfig(const nmpc_hip_ddp_solver * s, const nmpc_hip_ddp_config * c)
 
 namespace
 {
+/** Whether the next solve of the handle runs under the ragged-convergence schedule, and the last iteration of each of its launches:
+    16, 32, 48, 64, then 96, 128, 192, 256, 384, ... (half of the instances of a cart-pole batch are done after 14 iterations, a
+    percent runs for hundreds: compaction pays while the prefix shrinks fast and costs a relaunch where it no longer does). */
+bool raggedRounds(const nmpc_hip_ddp_solver * s, std::vector<int> * caps)
+{
+  const int mode = s->ragged_env != 0 ? s->ragged_env : s->cfg.ragged_schedule;
+  if(mode < 0 || s->elem != 8 || s->ops->resumable_supported == nullptr)
+  {
+    return false;
+  }
+  if(mode == 0 && s->cfg.max_iter < 32)
+  {
+    return false;
+  }
+  if(!s->ops->resumable_supported(s->B, s->cfg, s->d_params_batch ? 1 : 0))
+  {
+    return false;
+  }
+  caps->clear();
+  int cap = 0, step = 16;
+  while(cap < s->cfg.max_iter && static_cast<int>(caps->size()) < nmpc_hip_ddp_solver::kRaggedMaxRounds - 1)
+  {
+    cap += step;
+    if(cap >= 64 && (cap & (cap - 1)) == 0)
+    {
+      step = cap / 2; // 64 -> steps of 32 (96, 128), 128 -> 64 (192, 256), ...
+    }
+    caps->push_back(cap < s->cfg.max_iter ? cap : s->cfg.max_iter);
+  }
+  if(caps->back() < s->cfg.max_iter)
+  {
+    caps->back() = s->cfg.max_iter;
+  }
+  return caps->size() > 1;
+}
+
+int ensureRagged(nmpc_hip_ddp_solver * s)
+{
+  if(s->d_resume)
+  {
+    return NMPC_HIP_OK;
+  }
+  constexpr int R = nmpc_hip_ddp_solver::kRaggedMaxRounds;
+  int rc = devAllocScalar(&s->d_resume, static_cast<size_t>(nmpc_amd::hip::kResumeRows) * s->Bp, s->elem);
+  if(rc == NMPC_HIP_OK)
+  {
+    rc = devAlloc(&s->d_ragged_words, static_cast<size_t>(2 * R + 1));
+  }
+  if(rc == NMPC_HIP_OK)
+  {
+    rc = devAlloc(&s->d_ragged_pairs, static_cast<size_t>(R) * s->Bp);
+  }
+  if(rc == NMPC_HIP_OK)
+  {
+    rc = devAlloc(&s->d_ragged_rank, static_cast<size_t>(s->Bp));
+  }
+  return rc;
+}
+
+/** Every per-instance array of the handle (ragged_schedule.hpp: a compaction swap exchanges all of an instance's rows). */
+nmpc_amd::hip::SwapTable swapTable(const nmpc_hip_ddp_solver * s)
+{
+  using nmpc_amd::hip::PerInstanceArray;
+  nmpc_amd::hip::SwapTable t;
+  const unsigned T = static_cast<unsigned>(s->T), N = static_cast<unsigned>(s->N), MM = static_cast<unsigned>(s->MM);
+  const unsigned e = static_cast<unsigned>(s->elem);
+  auto tile = [&](void * base, unsigned rows, unsigned elem, unsigned trace_unit = 0)
+  {
+    if(base != nullptr && t.n < nmpc_amd::hip::kMaxPerInstanceArrays)
+    {
+      t.a[t.n++] = PerInstanceArray{static_cast<char *>(base), rows, elem, 1u, trace_unit};
+    }
+  };
+  auto major = [&](void * base, unsigned words4)
+  {
+    if(base != nullptr && t.n < nmpc_amd::hip::kMaxPerInstanceArrays)
+    {
+      t.a[t.n++] = PerInstanceArray{static_cast<char *>(base), words4, 4u, 0u, 0u};
+    }
+  };
+  tile(s->d_t0, 1, e);
+  tile(s->d_x0, N, e);
+  tile(s->d_X, 2 * (T + 1) * N, e);
+  tile(s->d_U, 2 * T * MM, e);
+  tile(s->d_cost, 2 * (T + 1), e);
+  tile(s->d_kff, T * MM, e);
+  tile(s->d_Kfb, T * N * MM, e);
+  tile(s->d_trace, static_cast<unsigned>(s->trace_rows) * NMPC_HIP_NTRACE, e, s->trace_rows > 1 ? NMPC_HIP_NTRACE : 0);
+  tile(s->d_trace_last, NMPC_HIP_NTRACE, e);
+  tile(s->d_dV, 2, e);
+  tile(s->d_resume, nmpc_amd::hip::kResumeRows, e);
+  tile(s->d_status, 1, 4);
+  tile(s->d_iters, 1, 4);
+  tile(s->d_sel, 1, 4);
+  tile(s->d_qp_ret, T, 4);
+  tile(s->d_qp_free, T, 4);
+  tile(s->d_input_dim, T, 4);
+  major(s->d_phase_ticks, 4 * 2);
+  major(s->d_params_batch, static_cast<unsigned>(s->params.size() / 4));
+  major(s->d_lim_batch, 2 * nmpc_amd::hip::kMaxInputDim * 2);
+  if(s->lim_steps_per_instance)
+  {
+    major(s->d_lim_steps, static_cast<unsigned>(s->lim_rows) * 2 * MM * 2);
+  }
+  return t;
+}
+
+/** The ragged-convergence schedule: resumable launches of iterations (caps[r-1], caps[r]] with a compaction between them, then
+    the recorded swaps replayed in reverse.  All on stream st, no host round trip. */
+int launchRagged(nmpc_hip_ddp_solver * s, hipStream_t st, DeviceBuffers buf, const std::vector<int> & caps)
+{
+  int rc = ensureRagged(s);
+  if(rc != NMPC_HIP_OK)
+  {
+    return rc;
+  }
+  constexpr int R = nmpc_hip_ddp_solver::kRaggedMaxRounds;
+  const int rounds = static_cast<int>(caps.size());
+  int * n_active = s->d_ragged_words;
+  int * n_swaps = s->d_ragged_words + R + 1;
+  const nmpc_amd::hip::SwapTable tab = swapTable(s);
+  const dim3 swap_grid(static_cast<unsigned>(std::max(1, s->Bp / 2)));
+  buf.resume = s->d_resume;
+  hipLaunchKernelGGL(nmpc_amd::hip::ragged_init_kernel, dim3(1), dim3(64), 0, st, n_active, s->B);
+  for(int r = 0; r < rounds; r++)
+  {
+    buf.n_active = n_active + r;
+    buf.iter_begin = (r == 0) ? 1 : caps[r - 1] + 1;
+    buf.iter_end = caps[r];
+    const hipError_t le = s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
+    if(le != hipSuccess)
+    {
+      return fail(NMPC_HIP_ERR_HIP, std::string("resumable launch: ") + hipGetErrorString(le));
+    }
+    if(r + 1 < rounds)
+    {
+      int * pairs = s->d_ragged_pairs + static_cast<size_t>(r) * s->Bp;
+      hipLaunchKernelGGL((nmpc_amd::hip::ragged_compact_kernel<double>), dim3(1), dim3(1024), 0, st, s->d_resume, s->d_ragged_rank,
+                         pairs, n_swaps + r, n_active + r);
+      hipLaunchKernelGGL(nmpc_amd::hip::ragged_swap_kernel, swap_grid, dim3(256), 0, st, tab, pairs, n_swaps + r, s->d_iters);
+    }
+  }
+  for(int r = rounds - 2; r >= 0; r--)
+  {
+    const int * pairs = s->d_ragged_pairs + static_cast<size_t>(r) * s->Bp;
+    hipLaunchKernelGGL(nmpc_amd::hip::ragged_swap_kernel, swap_grid, dim3(256), 0, st, tab, pairs, n_swaps + r, s->d_iters);
+  }
+  NMPC_HIP_TRY(hipGetLastError());
+  s->last_ragged_rounds = rounds;
+  return NMPC_HIP_OK;
+}
+
 /** One solve on stream st, bracketed by the HIP-event triple of the timing ring.  ingest: convert the reference-layout
     device arrays into the solver's tile-major input buffers first (false: they are already in place, as after
     mpc_advance_kernel). */
@@ -495,9 +657,20 @@ int launchRecorded(nmpc_hip_ddp_solver * s,
   {
     NMPC_HIP_TRY(hipEventRecord(s->ev_kernel[slot], st));
   }
-  const DeviceBuffers buf = makeBuffers(s);
+  DeviceBuffers buf = makeBuffers(s);
+  std::vector<int> caps;
+  s->last_gain_layout = s->ops->gain_layout_of ? s->ops->gain_layout_of(s->B, s->cfg.with_input_constraint != 0 ? 1 : 0) : s->ops->gain_layout;
+  s->last_ragged_rounds = 1;
+  if(raggedRounds(s, &caps))
   {
-    s->last_gain_layout = s->ops->gain_layout_of ? s->ops->gain_layout_of(s->B, s->cfg.with_input_constraint != 0 ? 1 : 0) : s->ops->gain_layout;
+    int rrc = launchRagged(s, st, buf, caps);
+    if(rrc != NMPC_HIP_OK)
+    {
+      return rrc;
+    }
+  }
+  else
+  {
     const hipError_t le = s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
     if(le == hipErrorNotSupported)
     {
@@ -578,6 +751,7 @@ extern "C"
     c->qp_armijo_param = 0.1;
     c->trace_level = 1;
     c->line_search_fan_out = 0;
+    c->ragged_schedule = 0;
     return NMPC_HIP_OK;
   }
 
@@ -698,6 +872,10 @@ extern "C"
     s->elem = m->scalar_bytes;
     nmpc_hip_ddp_default_config(&s->cfg);
     s->cfg.horizon_steps = horizon_steps;
+    if(const char * e = std::getenv("NMPC_HIP_DDP_RAGGED")) // (read once per handle: A/B measurements of the ragged schedule)
+    {
+      s->ragged_env = (std::strcmp(e, "0") == 0) ? -1 : 1;
+    }
     s->params.resize(m->param_bytes);
     m->default_params(s->params.data());
     for(int i = 0; i < nmpc_amd::hip::kMaxInputDim; i++)
@@ -785,7 +963,7 @@ extern "C"
     void * ptrs[] = {s->d_t0,     s->d_x0,     s->d_X,   s->d_U,      s->d_cost,    s->d_kff,       s->d_Kfb,
                      s->d_trace,  s->d_trace_last, s->d_dV, s->d_status, s->d_iters, s->d_sel,     s->d_qp_ret,
                      s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_params_batch, s->d_lim_batch, s->d_lim_steps, s->d_phase_ticks, s->d_stage_in,
-                     s->d_stage_out};
+                     s->d_stage_out, s->d_resume, s->d_ragged_words, s->d_ragged_pairs, s->d_ragged_rank};
     for(void * p : ptrs)
     {
       if(p)
@@ -1227,6 +1405,17 @@ extern "C"
 
   int nmpc_hip_ddp_solve(nmpc_hip_ddp_handle s, const double * t0, const double * x0, const double * u_init)
   {
+    int rc = nmpc_hip_ddp_solve_async(s, t0, x0, u_init);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    NMPC_HIP_TRY(hipStreamSynchronize(s->stream));
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_solve_async(nmpc_hip_ddp_handle s, const double * t0, const double * x0, const double * u_init)
+  {
     if(!s || !x0 || !u_init)
     {
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle, x0 or u_init");
@@ -1249,13 +1438,7 @@ extern "C"
     {
       NMPC_HIP_TRY(hipMemcpyAsync(dt, t0, nt * sizeof(double), hipMemcpyHostToDevice, s->stream));
     }
-    rc = nmpc_hip_ddp_solve_device(s, t0 ? dt : nullptr, dx, du, nullptr);
-    if(rc != NMPC_HIP_OK)
-    {
-      return rc;
-    }
-    NMPC_HIP_TRY(hipStreamSynchronize(s->stream));
-    return NMPC_HIP_OK;
+    return nmpc_hip_ddp_solve_device(s, t0 ? dt : nullptr, dx, du, nullptr);
   }
 
   int nmpc_hip_ddp_field_bytes(nmpc_hip_ddp_handle s, int field, size_t * bytes)
@@ -1414,6 +1597,20 @@ extern "C"
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output pointer");
     }
     *name = s->ops->kernel_name(s->B, s->cfg);
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_last_solve_launches(nmpc_hip_ddp_handle s, int * launches)
+  {
+    if(!s || !launches)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output pointer");
+    }
+    if(!s->solved)
+    {
+      return fail(NMPC_HIP_ERR_NOT_SOLVED, "solve() has not been called");
+    }
+    *launches = s->last_ragged_rounds;
     return NMPC_HIP_OK;
   }
 

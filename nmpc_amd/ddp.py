@@ -26,7 +26,7 @@ class Configuration:
               "initial_dlambda", "lambda_factor", "lambda_min", "lambda_max", "k_rel_norm_thre", "lambda_thre",
               "cost_update_ratio_thre", "cost_update_thre", "use_state_eq_second_derivative", "qp_max_iter",
               "qp_grad_thre", "qp_rel_improve_thre", "qp_step_factor", "qp_min_step", "qp_armijo_param",
-              "trace_level", "line_search_fan_out")
+              "trace_level", "line_search_fan_out", "ragged_schedule")
 
     def __init__(self):
         c = _capi.Config()
@@ -492,6 +492,12 @@ class DDPSolverBatch:
         name = C.c_char_p()
         _capi.check(self._L.nmpc_hip_ddp_kernel_name(self._h, C.byref(name)))
         return name.value.decode()
+
+    def lastSolveLaunches(self) -> int:
+        """Kernel launches the last solve was cut into (1: one whole-solve launch; more: the ragged-convergence schedule)."""
+        n = C.c_int()
+        _capi.check(self._L.nmpc_hip_ddp_last_solve_launches(self._h, C.byref(n)))
+        return n.value
 
     def timingStats(self, reset: bool = False):
         """(number of device solves, sum of ingest+kernel ms, sum of solve-kernel ms) since the last reset."""

@@ -375,6 +375,8 @@ def main():
     problem = nmpc_amd.make_problem(wl.model)
     elem = problem.scalar_bytes()
     solver = nmpc_amd.DDPSolverBatch(problem, wl.B, device=device_index)
+    if args.global_batch > 0:
+        solver.setDispatchBatch(args.global_batch)  # the kernel family of the WHOLE batch: shards == the unsharded solve, bit for bit
 
     def configure(mode, iters, cost_update_thre=None):
         cfg = solver.config()

@@ -294,6 +294,38 @@ public:
 
   /** \brief Kernel launches the last solve was cut into (1: one whole-solve launch; more: the ragged-convergence schedule,
       Configuration::ragged_schedule). */
+  /** \brief Pin the kernel family of this solver: "auto" (the default), "1w", "2w", "quad", "wpi", "tile64", "tile32"
+      (nmpc_hip_ddp_set_kernel).  Results are bit-reproducible across batch sizes and shardings within one family. */
+  void setKernel(const std::string & name)
+  {
+    kernel_ = name;
+    if(handle_)
+    {
+      check(nmpc_hip_ddp_set_kernel(handle_, kernel_.c_str()));
+    }
+  }
+
+  /** \brief The batch size the kernel family is chosen for: a solver that holds a shard of a larger batch sets the whole batch's
+      size and returns the unsharded solve's bits (nmpc_hip_ddp_set_dispatch_batch); 0: this solver's own batch size. */
+  void setDispatchBatch(int batch)
+  {
+    dispatch_batch_ = batch;
+    if(handle_)
+    {
+      check(nmpc_hip_ddp_set_dispatch_batch(handle_, dispatch_batch_));
+    }
+  }
+
+  /** \brief Name of the gfx950 kernel the next solve launches (nmpc_hip_ddp_kernel_name). */
+  std::string kernelName()
+  {
+    ensureHandle();
+    pushState();
+    const char * name = nullptr;
+    check(nmpc_hip_ddp_kernel_name(handle_, &name));
+    return name ? name : "";
+  }
+
   /** \brief Whether a solve queued by solveAsync() has not been waited for yet. */
   inline bool inFlight() const
   {
@@ -441,6 +473,14 @@ protected:
     handle_ = nullptr;
     check(nmpc_hip_ddp_create(Problem::kName, config_.horizon_steps, batch_size_, device_, &handle_));
     handle_T_ = config_.horizon_steps;
+    if(!kernel_.empty())
+    {
+      check(nmpc_hip_ddp_set_kernel(handle_, kernel_.c_str()));
+    }
+    if(dispatch_batch_ > 0)
+    {
+      check(nmpc_hip_ddp_set_dispatch_batch(handle_, dispatch_batch_));
+    }
     problem_batch_dirty_ = !problem_batch_.empty(); // a new handle starts with the shared problem
     limits_batch_dirty_ = !limits_batch_lo_.empty();
   }
@@ -727,6 +767,8 @@ protected:
   double lower_[MM];
   double upper_[MM];
   bool fetched_ = false;
+  std::string kernel_; //!< setKernel(): empty = automatic
+  int dispatch_batch_ = 0;
   bool in_flight_ = false; //!< a solve queued by solveAsync() has not been waited for
   std::vector<Problem> problem_batch_;
   bool problem_batch_dirty_ = false;

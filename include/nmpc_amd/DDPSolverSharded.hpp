@@ -85,6 +85,9 @@ private:
       shardRange(batch, static_cast<int>(s), static_cast<int>(shards_.size()), sh.lo, sh.hi);
       max_shard_ = std::max(max_shard_, sh.hi - sh.lo);
       check(nmpc_hip_ddp_create(model.c_str(), T_, sh.hi - sh.lo, sh.device, &sh.handle));
+      // every shard runs on the kernel family the WHOLE batch would get: shards == the unsharded solve, bit for bit (in fp32 the
+      // family depends on the batch size; families agree in their decisions, not in the last bits of their values)
+      check(nmpc_hip_ddp_set_dispatch_batch(sh.handle, batch));
     }
     for(Shard & sh : shards_)
     {

@@ -1843,6 +1843,10 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   /** \return whether this lane's instance iterates in this launch */
   NMPC_D bool resumeState(bool valid)
   {
+    // EVERY lane takes its position's `sel`, also the ones beyond the dense prefix: they hold finished instances, the wave's passes
+    // run over all 64 lanes, and what a pass writes for a lane that does not iterate goes to the half 1 - sel — which has to be the
+    // half the finished instance's result is NOT in (as it is in a whole-solve launch, where a finished lane keeps its sel).
+    sel = buf.sel[b];
     bool running = false;
     if(valid)
     {
@@ -1850,7 +1854,6 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       dlambda = resumeWord(1);
       J_cur = resumeWord(2);
       running = resumeWord(3) != 0.0;
-      sel = buf.sel[b];
     }
     return running;
   }

@@ -1737,16 +1737,17 @@ struct ModelOpsTile32
     {
       return false;
     }
-    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
-    if(force && std::strcmp(force, "tile64") == 0)
+    const LaunchKnobs knobs = launchKnobs();
+    if(knobs.kernelIs("tile64"))
     {
       return true;
     }
-    if(force && std::strcmp(force, "tile32") == 0)
+    if(knobs.kernelIs("tile32"))
     {
       return false;
     }
-    return batch < kTile64FloatBelowBatch || cfg.cost_update_thre >= kTile64FloatFromThreshold;
+    // (a shard of a larger solve takes the family the WHOLE batch would get: the two fp32 kernels differ in the last bits)
+    return knobs.batchFor(batch) < kTile64FloatBelowBatch || cfg.cost_update_thre >= kTile64FloatFromThreshold;
   }
   static const char * kernelName(int batch, const nmpc_hip_ddp_config & cfg)
   {

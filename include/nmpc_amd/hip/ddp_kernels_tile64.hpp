@@ -50,6 +50,7 @@
 #include <type_traits>
 
 #include <nmpc_amd/hip/ddp_kernels.hpp>
+#include <nmpc_amd/hip/model_ops.hpp>
 
 namespace nmpc_amd
 {
@@ -3001,31 +3002,13 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     n_cu[dev].store(cus, std::memory_order_release);
   }
-  int cap = 0; // NMPC_HIP_DDP_TILE64_GROUP=<g>: at most g instances per group (tests: full groups on small batches)
-  if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_GROUP"))
-  {
-    cap = std::atoi(e) & 0xffff;
-  }
-  int chunk_cap = 0; // NMPC_HIP_DDP_TILE64_CHUNK=<c>: at most c timesteps per pass of the model code (1: round 3's schedule)
-  if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_CHUNK"))
-  {
-    chunk_cap = std::atoi(e) & 0x1fff;
-  }
-  unsigned no_pair = 0; // NMPC_HIP_DDP_TILE64_PAIR=0: the second step size does not ride in the model wave's upper lanes
-  if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_PAIR"))
-  {
-    no_pair = (std::atoi(e) == 0) ? 1u : 0u;
-  }
-  unsigned no_adopt = 0; // NMPC_HIP_DDP_TILE64_ADOPT=0: a later step size that is taken is re-rolled (round 3's pass 3)
-  if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_ADOPT"))
-  {
-    no_adopt = (std::atoi(e) == 0) ? 1u : 0u;
-  }
-  unsigned no_wide = 0; // NMPC_HIP_DDP_TILE64_WIDE=0: line search passes as in round 3 (first step size, then the later ones)
-  if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_WIDE"))
-  {
-    no_wide = (std::atoi(e) == 0) ? 1u : 0u;
-  }
+  // the handle's knobs (LaunchKnobs; the NMPC_HIP_DDP_TILE64_* variables are developer overrides read when the handle is created):
+  // group: at most g instances per group (tests: full groups on small batches); chunk: at most c timesteps per pass of the model code
+  // (1: round 3's schedule); pair = 0: the second step size does not ride in the model wave's upper lanes; adopt = 0: a later step
+  // size that is taken is re-rolled (round 3's pass 3); wide = 0: line-search passes as in round 3 (first step size, then the others)
+  const LaunchKnobs knobs = launchKnobs();
+  const int cap = knobs.tile64_group, chunk_cap = knobs.tile64_chunk;
+  const unsigned no_pair = knobs.tile64_pair ? 0u : 1u, no_adopt = knobs.tile64_adopt ? 0u : 1u, no_wide = knobs.tile64_wide ? 0u : 1u;
   int grid = cus;
   if(cap > 0)
   {

@@ -44,6 +44,7 @@ struct FmpcBuffers
   int B = 0; // instances
   int T = 0; // horizon_steps
   int N = 0, M = 0, G = 0;
+  int riccati_force = 0; // host side: which Riccati kernel the handle launches (0 automatic, 1 matrix-core, 2 lane; fmpc_ops.hpp)
   int coef_stride = 0; // doubles per timestep in `coef`
   int gain_stride = 0; // doubles per timestep in `gain`
   // Variable (FmpcSolver.h:117-158): x [T+1][N][B], u [T][M][B], lambda [T+1][N][B], s [T][G][B], nu [T][G][B]

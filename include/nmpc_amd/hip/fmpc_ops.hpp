@@ -21,16 +21,22 @@ namespace hip
     instructions per instance and wins once the batch fills the chip by itself (measured on MI355X, cart-pole, T = 200, quad /
     lane ms per 5-iteration solve: 1.5 / 2.8 at 2048 instances, 2.2 / 3.6 at 4096, 4.5 / 4.7 at 8192, 8.9 / 7.2 at 16384,
     37.8 / 29.0 at 65536).  The environment variable NMPC_HIP_FMPC_RICCATI=quad|lane forces one (A/B measurements, tests). */
-inline bool fmpcUseQuadRiccati(int N, int M, int B)
+/** \param force FmpcBuffers::riccati_force: 0 automatic, 1 the matrix-core kernel, 2 the lane kernel (a handle's setting, taken
+    from NMPC_HIP_FMPC_RICCATI = quad / lane once, when the handle is created: fmpcRiccatiForceFromEnvironment) */
+inline int fmpcRiccatiForceFromEnvironment()
+{
+  const char * force = getenv("NMPC_HIP_FMPC_RICCATI");
+  return (force && force[0] == 'q') ? 1 : ((force && force[0] == 'l') ? 2 : 0);
+}
+inline bool fmpcUseQuadRiccati(int N, int M, int B, int force)
 {
   if(!(N <= 4 && M == 1))
   {
     return false;
   }
-  const char * force = getenv("NMPC_HIP_FMPC_RICCATI");
-  if(force && (force[0] == 'l' || force[0] == 'q'))
+  if(force != 0)
   {
-    return force[0] == 'q';
+    return force == 1;
   }
   static int n_cu = 0; // of the current device at first use (the handles of one process sit on like devices)
   if(n_cu == 0)
@@ -115,7 +121,7 @@ struct FmpcOpsOf
     o.launch_riccati = [](const FmpcBuffers & buf, int iter, hipStream_t stream) {
       if constexpr(N <= 4 && M == 1)
       {
-        if(fmpcUseQuadRiccati(N, M, buf.B))
+        if(fmpcUseQuadRiccati(N, M, buf.B, buf.riccati_force))
         {
           hipLaunchKernelGGL((fmpc_riccati_quad_kernel<N>), dim3(blocks(buf.B, 16)), dim3(256), 0, stream, buf, iter);
           return hipGetLastError();

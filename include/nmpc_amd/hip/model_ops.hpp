@@ -4,6 +4,8 @@
 #pragma once
 
 #include <cstddef>
+#include <cstdlib>
+#include <cstring>
 
 #include <hip/hip_runtime.h>
 
@@ -14,6 +16,94 @@ namespace nmpc_amd
 {
 namespace hip
 {
+/** What picks a kernel family and its launch schedule besides the problem's shape, the batch size and the Configuration — per
+    HANDLE, fixed when the handle is created or through the C-ABI (nmpc_hip_ddp_set_kernel, nmpc_hip_ddp_set_dispatch_batch), never
+    read from the environment on the launch path.  The environment variables (NMPC_HIP_DDP_KERNEL, NMPC_HIP_DDP_TILE64_GROUP / _CHUNK /
+    _PAIR / _ADOPT / _WIDE, NMPC_HIP_DDP_FAN_SCRATCH, NMPC_HIP_DDP_FAN_AUTO) are developer overrides for A/B measurements and tests:
+    fromEnvironment() reads them ONCE, when a handle is created. */
+struct LaunchKnobs
+{
+  char kernel[16] = ""; //!< "" (automatic), "1w", "2w", "quad", "wpi", "tile64", "tile32"
+  int tile64_group = 0; //!< > 0: at most this many instances per group of the tile kernel
+  int tile64_chunk = 0; //!< > 0: at most this many timesteps per pass of its model code
+  int tile64_pair = 1, tile64_adopt = 1, tile64_wide = 1; //!< 0: that part of its line-search schedule off (A/B)
+  int fan_scratch = 1; //!< 0: the quad kernel's fan-out scratch is not allocated
+  int fan_auto = 0; //!< valid if has_fan_auto: ModelOpsFor::fanOutAutoMaxIter()
+  int has_fan_auto = 0;
+  int have_workspace = 1; //!< the handle's per-instance workspace was allocated (0: the kernels that need it are not chosen)
+  //! > 0: the batch size the kernel family is chosen FOR — a shard of a larger solve takes the family the whole batch would get,
+  //! so that its results are the unsharded solve's bit for bit (families differ in the last bits; DDPSolverSharded, bench.py)
+  int dispatch_batch = 0;
+
+  bool kernelIs(const char * name) const
+  {
+    return std::strcmp(kernel, name) == 0;
+  }
+  int batchFor(int batch) const
+  {
+    return dispatch_batch > 0 ? dispatch_batch : batch;
+  }
+  static LaunchKnobs fromEnvironment()
+  {
+    LaunchKnobs k;
+    if(const char * e = std::getenv("NMPC_HIP_DDP_KERNEL"))
+    {
+      std::strncpy(k.kernel, e, sizeof(k.kernel) - 1);
+    }
+    if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_GROUP"))
+    {
+      k.tile64_group = std::atoi(e) & 0xffff;
+    }
+    if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_CHUNK"))
+    {
+      k.tile64_chunk = std::atoi(e) & 0x1fff;
+    }
+    if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_PAIR"))
+    {
+      k.tile64_pair = std::atoi(e) != 0;
+    }
+    if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_ADOPT"))
+    {
+      k.tile64_adopt = std::atoi(e) != 0;
+    }
+    if(const char * e = std::getenv("NMPC_HIP_DDP_TILE64_WIDE"))
+    {
+      k.tile64_wide = std::atoi(e) != 0;
+    }
+    if(const char * e = std::getenv("NMPC_HIP_DDP_FAN_SCRATCH"))
+    {
+      k.fan_scratch = std::strcmp(e, "0") != 0;
+    }
+    if(const char * e = std::getenv("NMPC_HIP_DDP_FAN_AUTO"))
+    {
+      k.fan_auto = std::atoi(e);
+      k.has_fan_auto = 1;
+    }
+    return k;
+  }
+};
+/** The knobs of the handle whose operation is running on this thread (set by the C-ABI entry points around every ModelOps call:
+    ScopedKnobs); outside of one — the registry's own queries — the environment as it is now. */
+inline thread_local const LaunchKnobs * g_launch_knobs = nullptr;
+inline LaunchKnobs launchKnobs()
+{
+  return g_launch_knobs ? *g_launch_knobs : LaunchKnobs::fromEnvironment();
+}
+struct ScopedKnobs
+{
+  const LaunchKnobs * saved;
+  explicit ScopedKnobs(const LaunchKnobs * k) : saved(g_launch_knobs)
+  {
+    g_launch_knobs = k;
+  }
+  ~ScopedKnobs()
+  {
+    g_launch_knobs = saved;
+  }
+  ScopedKnobs(const ScopedKnobs &) = delete;
+  ScopedKnobs & operator=(const ScopedKnobs &) = delete;
+};
+
 /** Type-erased operations of one registered problem type. */
 struct ModelOps
 {

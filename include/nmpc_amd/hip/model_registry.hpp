@@ -40,8 +40,7 @@ struct ModelOpsFor
   static constexpr bool kTwoWaveFits = PairSolver<Problem, false>::kFits && PairSolver<Problem, true>::kFits;
   static bool useTwoWave()
   {
-    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
-    return kTwoWaveFits && !(force && std::strcmp(force, "1w") == 0);
+    return kTwoWaveFits && !launchKnobs().kernelIs("1w");
   }
   /** Wave-per-instance (matrix-core) kernel: the shapes whose blocks fill a 16 x 16 tile; unconstrained solves only
       (checked at launch). */
@@ -51,8 +50,8 @@ struct ModelOpsFor
   static constexpr bool kWpiBoxQP = kWpiShape && !Problem::kDynamicInput && Problem::kInputDimMax <= 8;
   static bool useWpi(bool constrained)
   {
-    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
-    return kWpiShape && (!constrained || kWpiBoxQP) && !(force && std::strcmp(force, "1w") == 0);
+    const LaunchKnobs knobs = launchKnobs();
+    return kWpiShape && (!constrained || kWpiBoxQP) && !knobs.kernelIs("1w") && knobs.have_workspace != 0;
   }
   /** fp64 tile kernel (ddp_kernels_tile64.hpp: groups of up to 32 instances per workgroup, derivatives LDS-resident, backward
       pass on v_mfma_f64_16x16x4 in natural layout, BoxQP included): 5 <= n <= 15 with a static input dimension m <= 8.  It
@@ -77,16 +76,19 @@ struct ModelOpsFor
   static constexpr int kTile64MinBatchBoxQP = 1025;
   static bool useTile64(bool constrained, int batch)
   {
-    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
-    if(!kTile64Shape || (force && (std::strcmp(force, "1w") == 0 || std::strcmp(force, "wpi") == 0)))
+    const LaunchKnobs knobs = launchKnobs();
+    // (without the per-instance workspace — the allocation failed at create — the gain records and the candidate scratch have
+    // nowhere to live: the lane kernels, which need none, take the solve)
+    if(!kTile64Shape || knobs.kernelIs("1w") || knobs.kernelIs("wpi") || knobs.have_workspace == 0)
     {
       return false;
     }
+    batch = knobs.batchFor(batch);
     if(kTile64Big)
     {
       return !constrained; // (every batch size: the wave-per-instance kernel takes these gains through LDS, 3 - 4 x slower)
     }
-    if(force && std::strcmp(force, "tile64") == 0)
+    if(knobs.kernelIs("tile64"))
     {
       return true;
     }
@@ -165,8 +167,7 @@ struct ModelOpsFor
     {
       // fan-out scratch of the quad kernel's line search (PairSolver::FanDest): three more candidate trajectories.
       // NMPC_HIP_DDP_FAN_SCRATCH=0: none (A/B measurements, tests of the path taken when the allocation fails)
-      const char * off = std::getenv("NMPC_HIP_DDP_FAN_SCRATCH");
-      if(off && std::strcmp(off, "0") == 0)
+      if(launchKnobs().fan_scratch == 0)
       {
         return 0;
       }
@@ -189,18 +190,22 @@ struct ModelOpsFor
   static constexpr int kQuadFanOutAutoMaxIter = -1;
   static int fanOutAutoMaxIter()
   {
-    const char * e = std::getenv("NMPC_HIP_DDP_FAN_AUTO");
-    return e ? std::atoi(e) : kQuadFanOutAutoMaxIter;
+    const LaunchKnobs knobs = launchKnobs();
+    return knobs.has_fan_auto ? knobs.fan_auto : kQuadFanOutAutoMaxIter;
   }
   static bool useQuad(int batch_padded, bool own)
   {
-    const char * force = std::getenv("NMPC_HIP_DDP_KERNEL");
+    const LaunchKnobs knobs = launchKnobs();
     (void)own; // per-instance problem objects have their own instantiation of the quad kernel
-    if(!kQuadShape || (force && (std::strcmp(force, "1w") == 0 || std::strcmp(force, "2w") == 0)))
+    if(!kQuadShape || knobs.kernelIs("1w") || knobs.kernelIs("2w"))
     {
       return false;
     }
-    return batch_padded <= kQuadMaxBatch || (force && std::strcmp(force, "quad") == 0);
+    if(knobs.dispatch_batch > 0)
+    {
+      batch_padded = (knobs.dispatch_batch + kLanesPerBlock - 1) / kLanesPerBlock * kLanesPerBlock;
+    }
+    return batch_padded <= kQuadMaxBatch || knobs.kernelIs("quad");
   }
   static const char * kernelName(int batch, const nmpc_hip_ddp_config & cfg)
   {

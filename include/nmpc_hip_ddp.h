@@ -289,6 +289,23 @@ extern "C"
       environment variable NMPC_HIP_DDP_KERNEL=1w).  No reference counterpart: diagnostics for profiles / bench.py. */
   int nmpc_hip_ddp_kernel_name(nmpc_hip_ddp_handle h, const char ** name);
 
+  /** The same for a handle of `batch` instances with this handle's problem type, Configuration and kernel choice: what a sharding
+      caller asks to learn which family the WHOLE batch would run on (nmpc_hip_ddp_set_dispatch_batch does that in one call). */
+  int nmpc_hip_ddp_kernel_name_for_batch(nmpc_hip_ddp_handle h, int batch, const char ** name);
+
+  /** Pin the kernel family of this handle: "auto" (default: chosen per solve from the problem's shape, the batch size and the
+      Configuration), or one of "1w", "2w", "quad", "wpi", "tile64", "tile32" (or a name nmpc_hip_ddp_kernel_name reports).  A family
+      the problem's shape has no instantiation of is ignored (the automatic choice among the remaining ones applies).  Within one
+      family results are bit-reproducible across batch sizes and shardings; ACROSS families the discrete decisions agree and the
+      values agree to ~1e-13 relative in fp64 (INTEGRATION.md "what is reproducible").  The environment variable NMPC_HIP_DDP_KERNEL is
+      a developer override that is read once, when the handle is created, and sets the same field. */
+  int nmpc_hip_ddp_set_kernel(nmpc_hip_ddp_handle h, const char * name);
+
+  /** The batch size the kernel family is chosen FOR (0: the handle's own batch, the default).  A shard of a larger solve sets the
+      size of the whole batch so that it runs on the family the unsharded solve would run on and returns its bits — in fp32 the
+      family depends on the batch size (DDPSolverSharded.hpp and bench.py --global-batch do this). */
+  int nmpc_hip_ddp_set_dispatch_batch(nmpc_hip_ddp_handle h, int batch);
+
   /** Kernel launches the LAST solve of this handle was cut into: 1 = one whole-solve launch; more = the ragged-convergence
       schedule (nmpc_hip_ddp_config::ragged_schedule: resumable launches with a device-side compaction between them).  No reference
       counterpart: diagnostics. */

@@ -90,7 +90,8 @@ EXPORTS = (
     "nmpc_hip_ddp_set_input_limits_schedule", "nmpc_hip_ddp_solve", "nmpc_hip_ddp_solve_async",
     "nmpc_hip_ddp_solve_device", "nmpc_hip_ddp_synchronize", "nmpc_hip_ddp_get", "nmpc_hip_ddp_get_device",
     "nmpc_hip_ddp_field_bytes", "nmpc_hip_ddp_last_solve_ms", "nmpc_hip_ddp_last_solve_phases", "nmpc_hip_ddp_timing_stats",
-    "nmpc_hip_ddp_kernel_name", "nmpc_hip_ddp_last_solve_launches", "nmpc_hip_ddp_mpc_default_options", "nmpc_hip_ddp_mpc_run",
+    "nmpc_hip_ddp_kernel_name", "nmpc_hip_ddp_kernel_name_for_batch", "nmpc_hip_ddp_set_kernel", "nmpc_hip_ddp_set_dispatch_batch",
+    "nmpc_hip_ddp_last_solve_launches", "nmpc_hip_ddp_mpc_default_options", "nmpc_hip_ddp_mpc_run",
     "nmpc_hip_ddp_last_error",
 )
 
@@ -140,6 +141,9 @@ def load():
     L.nmpc_hip_ddp_last_solve_phases.argtypes = [vp, dp, dp, dp]
     L.nmpc_hip_ddp_kernel_name.argtypes = [vp, C.POINTER(C.c_char_p)]
     L.nmpc_hip_ddp_last_solve_launches.argtypes = [vp, C.POINTER(C.c_int)]
+    L.nmpc_hip_ddp_kernel_name_for_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p)]
+    L.nmpc_hip_ddp_set_kernel.argtypes = [vp, C.c_char_p]
+    L.nmpc_hip_ddp_set_dispatch_batch.argtypes = [vp, C.c_int]
     L.nmpc_hip_ddp_mpc_default_options.argtypes = [C.POINTER(MpcOptions)]
     L.nmpc_hip_ddp_mpc_run.argtypes = [vp, dp, dp, dp, C.POINTER(MpcOptions), dp, dp, dp, ip, ip, ip, dp, dp]
     L.nmpc_hip_ddp_timing_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), dp, dp]

@@ -123,6 +123,7 @@ struct nmpc_hip_ddp_solver
   int * d_ragged_words = nullptr; // n_active[kRaggedMaxRounds + 1], then n_swaps[kRaggedMaxRounds]
   int * d_ragged_pairs = nullptr; // [kRaggedMaxRounds][Bp]: the (p, q) position pairs of every round's swaps
   int * d_ragged_rank = nullptr; // [Bp] scratch of the compaction kernel
+  nmpc_amd::hip::LaunchKnobs knobs; // kernel family / schedule choices of this handle (environment overrides read once at create)
   int ragged_env = 0; // NMPC_HIP_DDP_RAGGED, read once at create: 1 forces the schedule on, -1 off (A/B measurements)
   int last_ragged_rounds = 0; // launches of the last solve (1: an ordinary whole-solve launch)
 };
@@ -625,6 +626,7 @@ int launchRecorded(nmpc_hip_ddp_solver * s,
 {
   // timed = false: no event records around this solve (the inner ticks of the device-resident receding-horizon loop: three
   // event packets per 0.6 ms tick were 1 - 2 % of the loop; computationDuration() reports the loop's last solve)
+  nmpc_amd::hip::ScopedKnobs knobs_guard(&s->knobs);
   s->last_stream = st;
   const int slot = static_cast<int>(s->n_solves % nmpc_hip_ddp_solver::kEvPool);
   if(timed)
@@ -876,6 +878,8 @@ extern "C"
     {
       s->ragged_env = (std::strcmp(e, "0") == 0) ? -1 : 1;
     }
+    s->knobs = nmpc_amd::hip::LaunchKnobs::fromEnvironment(); // developer overrides: read ONCE, here (not on the launch path)
+    nmpc_amd::hip::ScopedKnobs knobs_guard(&s->knobs);
     s->params.resize(m->param_bytes);
     m->default_params(s->params.data());
     for(int i = 0; i < nmpc_amd::hip::kMaxInputDim; i++)
@@ -920,6 +924,7 @@ extern "C"
       {
         (void)hipGetLastError();
         s->d_wpi_ws = nullptr; // not enough memory for the workspace: the lane-per-instance kernel needs none
+        s->knobs.have_workspace = 0; // (kernel_name / gain_layout_of / launch_solve then choose among the kernels that need none)
       }
     }
     if(rc == NMPC_HIP_OK)
@@ -1090,6 +1095,7 @@ extern "C"
       }
       return NMPC_HIP_OK;
     }
+    nmpc_amd::hip::ScopedKnobs knobs_guard(&s->knobs);
     if(s->ops->own_problems_supported && !s->ops->own_problems_supported(s->B, s->cfg.with_input_constraint != 0 ? 1 : 0))
     {
       return fail(NMPC_HIP_ERR_RUNTIME, std::string("the kernel this handle solves on (") + s->ops->kernel_name(s->B, s->cfg)
@@ -1596,7 +1602,72 @@ extern "C"
     {
       return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output pointer");
     }
+    nmpc_amd::hip::ScopedKnobs knobs_guard(&s->knobs);
     *name = s->ops->kernel_name(s->B, s->cfg);
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_kernel_name_for_batch(nmpc_hip_ddp_handle s, int batch, const char ** name)
+  {
+    if(!s || !name || batch < 1)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output pointer, or a non-positive batch");
+    }
+    nmpc_amd::hip::LaunchKnobs k = s->knobs;
+    k.dispatch_batch = 0;
+    nmpc_amd::hip::ScopedKnobs knobs_guard(&k);
+    *name = s->ops->kernel_name(batch, s->cfg);
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_set_kernel(nmpc_hip_ddp_handle s, const char * name)
+  {
+    if(!s || !name)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or kernel name");
+    }
+    static const char * const known[] = {"auto", "1w", "2w", "quad", "wpi", "tile64", "tile32"};
+    // (also accepted: the names nmpc_hip_ddp_kernel_name reports)
+    static const char * const reported[][2] = {{"ddp_solve_tpi_kernel", "1w"},        {"ddp_solve_tpi2w_kernel", "2w"},
+                                               {"ddp_solve_quad_kernel", "quad"},     {"ddp_solve_wpi_kernel", "wpi"},
+                                               {"ddp_solve_tile64_kernel", "tile64"}, {"ddp_solve_tile32_kernel", "tile32"}};
+    const char * pick = nullptr;
+    for(const char * k : known)
+    {
+      if(std::strcmp(k, name) == 0)
+      {
+        pick = k;
+      }
+    }
+    for(const auto & r : reported)
+    {
+      if(std::strcmp(r[0], name) == 0)
+      {
+        pick = r[1];
+      }
+    }
+    if(!pick)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, std::string("unknown kernel family: ") + name
+                                                     + " (auto, 1w, 2w, quad, wpi, tile64, tile32)");
+    }
+    nmpc_amd::hip::LaunchKnobs k = s->knobs;
+    std::memset(k.kernel, 0, sizeof(k.kernel));
+    if(std::strcmp(pick, "auto") != 0)
+    {
+      std::strncpy(k.kernel, pick, sizeof(k.kernel) - 1);
+    }
+    s->knobs = k;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_set_dispatch_batch(nmpc_hip_ddp_handle s, int batch)
+  {
+    if(!s || batch < 0)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or a negative batch");
+    }
+    s->knobs.dispatch_batch = batch;
     return NMPC_HIP_OK;
   }
 

@@ -594,6 +594,7 @@ extern "C"
     b.G = m->ineq_dim;
     b.coef_stride = m->coef_stride;
     b.gain_stride = m->gain_stride;
+    b.riccati_force = nmpc_amd::hip::fmpcRiccatiForceFromEnvironment(); // (developer override, read once per handle)
     const size_t B = batch, T = horizon_steps, N = b.N, M = b.M, G = b.G;
     int rc = NMPC_HIP_OK;
     auto A = [&](double ** p, size_t count) {
@@ -1144,7 +1145,7 @@ extern "C"
     }
     (void)hipSetDevice(h->device);
     h->kernel_names = std::string("fmpc_barrier_kernel,fmpc_coeff_kernel,")
-                      + (nmpc_amd::hip::fmpcUseQuadRiccati(h->buf.N, h->buf.M, h->buf.B) ? "fmpc_riccati_quad_kernel" : "fmpc_riccati_kernel")
+                      + (nmpc_amd::hip::fmpcUseQuadRiccati(h->buf.N, h->buf.M, h->buf.B, h->buf.riccati_force) ? "fmpc_riccati_quad_kernel" : "fmpc_riccati_kernel")
                       + ",fmpc_delta_kernel,fmpc_step_length_kernel," + (h->cfg.enable_line_search ? "fmpc_line_search_kernel," : "")
                       + "fmpc_update_kernel";
     *names = h->kernel_names.c_str();

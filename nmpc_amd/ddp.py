@@ -233,6 +233,10 @@ class DDPSolverBatch:
         _capi.check(self._L.nmpc_hip_ddp_create(self.problem.name.encode(), T, self.batch_size, self.device,
                                                 C.byref(self._h)))
         self._h_T = T
+        if getattr(self, "_kernel", None) is not None:  # choices made before the (lazily created) handle existed
+            _capi.check(self._L.nmpc_hip_ddp_set_kernel(self._h, self._kernel.encode()))
+        if getattr(self, "_dispatch_batch", 0):
+            _capi.check(self._L.nmpc_hip_ddp_set_dispatch_batch(self._h, self._dispatch_batch))
         self._problem_batch_dirty = getattr(self, "_problem_batch", None) is not None  # a new handle starts shared
         self._limits_batch_dirty = getattr(self, "_limits_batch", None) is not None
         self._limits_horizon_dirty = getattr(self, "_limits_horizon", None) is not None  # a table given to the old handle
@@ -491,6 +495,24 @@ class DDPSolverBatch:
         self._push_state()  # the handle is created lazily (horizon_steps may still change before the first solve)
         name = C.c_char_p()
         _capi.check(self._L.nmpc_hip_ddp_kernel_name(self._h, C.byref(name)))
+        return name.value.decode()
+
+    def setKernel(self, name: str = "auto") -> None:
+        """Pin the kernel family ("auto", "1w", "2w", "quad", "wpi", "tile64", "tile32"): nmpc_hip_ddp_set_kernel."""
+        self._kernel = name
+        if self._h:
+            _capi.check(self._L.nmpc_hip_ddp_set_kernel(self._h, name.encode()))
+
+    def setDispatchBatch(self, batch: int = 0) -> None:
+        """The batch size the kernel family is chosen for (a shard of a larger solve: the whole batch's size)."""
+        self._dispatch_batch = int(batch)
+        if self._h:
+            _capi.check(self._L.nmpc_hip_ddp_set_dispatch_batch(self._h, int(batch)))
+
+    def kernelNameForBatch(self, batch: int) -> str:
+        self._push_state()
+        name = C.c_char_p()
+        _capi.check(self._L.nmpc_hip_ddp_kernel_name_for_batch(self._h, int(batch), C.byref(name)))
         return name.value.decode()
 
     def lastSolveLaunches(self) -> int:

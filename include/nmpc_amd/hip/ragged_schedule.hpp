@@ -27,14 +27,14 @@ namespace nmpc_amd
 namespace hip
 {
 /** One per-instance array of the handle: tile-major [tile][rows][64] of `elem`-byte elements (rows = all halves), or instance-major
-    [B][rows] (elem-byte words). */
+    [B][rows] (4-byte words). */
 struct PerInstanceArray
 {
   char * base;
   unsigned rows;
   unsigned elem; //!< 4 or 8
   unsigned tile_major;
-  unsigned trace_unit; //!< > 0: only rows < (max(iters[p], iters[q]) + 1) * trace_unit hold anything (the trace)
+  unsigned trace_unit; //!< > 0: only rows < used * trace_unit hold anything (the trace; used = max iteration count of the pair + 1)
 };
 constexpr int kMaxPerInstanceArrays = 24;
 struct SwapTable
@@ -54,16 +54,22 @@ __global__ void ragged_init_kernel(int * n_active, int B)
 
 /** Between two launches: which positions of the prefix [0, n_prev) still iterate (`running` word of the parked state), the new
     prefix length n_next = their number, and the swaps that make the prefix dense: the k-th running position >= n_next with the k-th
-    finished position < n_next (both in ascending order: the pairing is a function of the flags alone).  One workgroup.
+    finished position < n_next (both in ascending order: the pairing is a function of the flags alone).  If a dense prefix would not
+    save an eighth of the workgroups the next launch needs, nothing is swapped and the prefix stays [0, n_prev) (the kernels skip the
+    finished instances inside it).  Also per pair: the trace rows in use (`used`) and the exchange of the pair's iteration counts —
+    the swap kernel proper never touches `iters`, whose values bound the trace rows its workgroups move.  One workgroup.
     \param resume     [tile][kResumeRows][64] parked solver state; row 3 = running (1 / 0)
     \param rank       [Bp] scratch: exclusive prefix count of running positions
     \param pairs      [2 * (Bp / 2)] out: (p, q) position pairs of this round
+    \param used       [Bp / 2] out: per pair, max(iters[p], iters[q]) + 1
     \param n_swaps    out: number of pairs
-    \param n_active   in: n_active[0] = n_prev; out: n_active[1] = n_next */
+    \param n_active   in: n_active[0] = n_prev; out: n_active[1] = the next launch's prefix length
+    \param wg_size    instances per workgroup of the solve kernel (what a denser prefix saves is whole workgroups) */
 template<class S>
 __global__ __launch_bounds__(1024) void ragged_compact_kernel(const S * __restrict__ resume, int * __restrict__ rank,
-                                                              int * __restrict__ pairs, int * __restrict__ n_swaps,
-                                                              int * __restrict__ n_active)
+                                                              int * __restrict__ pairs, int * __restrict__ used,
+                                                              int * __restrict__ n_swaps, int * __restrict__ n_active,
+                                                              int * __restrict__ iters, int wg_size)
 {
   __shared__ int warp_sums[16];
   __shared__ int carry;
@@ -114,7 +120,19 @@ __global__ __launch_bounds__(1024) void ragged_compact_kernel(const S * __restri
     }
     __syncthreads();
   }
-  const int n_next = carry;
+  const int n_run = carry;
+  const int wg_prev = (n_prev + wg_size - 1) / wg_size, wg_dense = (n_run + wg_size - 1) / wg_size;
+  if(8 * wg_dense > 7 * wg_prev && n_run > 0)
+  {
+    // not worth a round of swaps: same prefix, no pairs
+    if(tid == 0)
+    {
+      n_swaps[0] = 0;
+      n_active[1] = n_prev;
+    }
+    return;
+  }
+  const int n_next = n_run;
   __threadfence_block();
   __syncthreads();
   const int run_in_prefix = (n_next < n_prev) ? rank[n_next] : n_next; // running positions in [0, n_next)
@@ -131,71 +149,108 @@ __global__ __launch_bounds__(1024) void ragged_compact_kernel(const S * __restri
       pairs[2 * (p - r) + 1] = p;
     }
   }
+  const int n_sw = n_next - run_in_prefix;
+  __threadfence_block();
+  __syncthreads();
+  for(int k = tid; k < n_sw; k += 1024)
+  {
+    const int p = pairs[2 * k], q = pairs[2 * k + 1];
+    const int it_p = iters[p], it_q = iters[q];
+    used[k] = (it_p > it_q ? it_p : it_q) + 1;
+    iters[p] = it_q;
+    iters[q] = it_p;
+  }
   if(tid == 0)
   {
-    n_swaps[0] = n_next - run_in_prefix;
+    n_swaps[0] = n_sw;
     n_active[1] = n_next;
   }
 }
 
-/** Exchange every per-instance row of every array between the positions of each pair: one workgroup per pair (the grid covers the
-    upper bound Bp / 2; workgroups beyond *n_swaps exit). */
-__global__ __launch_bounds__(256) void ragged_swap_kernel(const SwapTable tab, const int * __restrict__ pairs,
-                                                          const int * __restrict__ n_swaps, const int * __restrict__ iters)
+/** Replaying a round: `used` of every pair from the iteration counts as they are now, and the exchange of the counts. */
+__global__ __launch_bounds__(256) void ragged_replay_prepare_kernel(const int * __restrict__ pairs, int * __restrict__ used,
+                                                                    const int * __restrict__ n_swaps, int * __restrict__ iters)
 {
-  if(static_cast<int>(blockIdx.x) >= n_swaps[0])
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if(k < n_swaps[0])
+  {
+    const int p = pairs[2 * k], q = pairs[2 * k + 1];
+    const int it_p = iters[p], it_q = iters[q];
+    used[k] = (it_p > it_q ? it_p : it_q) + 1;
+    iters[p] = it_q;
+    iters[q] = it_p;
+  }
+}
+
+/** Exchange every per-instance row of every array of the table (`iters` is not in it: see above) between the positions of each
+    pair.  lane = pair — the pairs are in ascending order of both positions, so the 64 lanes of a wavefront touch neighbouring
+    instances of a few tiles and a row is a handful of cache lines, not 64 — and the rows of all arrays, numbered consecutively, are
+    dealt to the wavefronts of the grid's y dimension.  grid.x covers the upper bound Bp / 2 pairs; workgroups beyond *n_swaps exit. */
+__global__ __launch_bounds__(256) void ragged_swap_kernel(const SwapTable tab, const int * __restrict__ pairs,
+                                                          const int * __restrict__ used, const int * __restrict__ n_swaps)
+{
+  const int n = n_swaps[0];
+  if(static_cast<int>(blockIdx.x) * 64 >= n)
   {
     return;
   }
-  const int p = pairs[2 * blockIdx.x], q = pairs[2 * blockIdx.x + 1];
-  const int it_p = iters[p], it_q = iters[q];
-  const unsigned used = static_cast<unsigned>((it_p > it_q ? it_p : it_q) + 1);
-  __syncthreads(); // (iters is one of the arrays swapped below)
-  for(int k = 0; k < tab.n; k++)
+  const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool on = k < n;
+  const int p = on ? pairs[2 * k] : 0, q = on ? pairs[2 * k + 1] : 0;
+  const unsigned used_rows = on ? static_cast<unsigned>(used[k]) : 0u;
+  const unsigned wave_id = blockIdx.y * 4 + (threadIdx.x >> 6), n_waves = gridDim.y * 4;
+  unsigned row0 = 0;
+  for(int a = 0; a < tab.n; a++)
   {
-    const PerInstanceArray a = tab.a[k];
-    unsigned rows = a.rows;
-    if(a.trace_unit > 0 && used * a.trace_unit < rows)
+    const PerInstanceArray A = tab.a[a];
+    const unsigned limit = (A.trace_unit > 0 && used_rows * A.trace_unit < A.rows) ? used_rows * A.trace_unit : A.rows;
+    unsigned r = (wave_id + n_waves - row0 % n_waves) % n_waves;
+    if(A.tile_major)
     {
-      rows = used * a.trace_unit;
-    }
-    if(a.tile_major)
-    {
-      const size_t op = (static_cast<size_t>(p >> 6) * a.rows) * 64 + (p & 63), oq = (static_cast<size_t>(q >> 6) * a.rows) * 64 + (q & 63);
-      if(a.elem == 8)
+      const size_t op = (static_cast<size_t>(p >> 6) * A.rows) * 64 + (p & 63), oq = (static_cast<size_t>(q >> 6) * A.rows) * 64 + (q & 63);
+      if(A.elem == 8)
       {
-        unsigned long long * b8 = reinterpret_cast<unsigned long long *>(a.base);
-        for(unsigned r = threadIdx.x; r < rows; r += 256)
+        unsigned long long * b8 = reinterpret_cast<unsigned long long *>(A.base);
+        for(; r < A.rows; r += n_waves)
         {
-          const unsigned long long vp = b8[op + static_cast<size_t>(r) * 64], vq = b8[oq + static_cast<size_t>(r) * 64];
-          b8[op + static_cast<size_t>(r) * 64] = vq;
-          b8[oq + static_cast<size_t>(r) * 64] = vp;
+          if(on && r < limit)
+          {
+            const unsigned long long vp = b8[op + static_cast<size_t>(r) * 64], vq = b8[oq + static_cast<size_t>(r) * 64];
+            b8[op + static_cast<size_t>(r) * 64] = vq;
+            b8[oq + static_cast<size_t>(r) * 64] = vp;
+          }
         }
       }
       else
       {
-        unsigned * b4 = reinterpret_cast<unsigned *>(a.base);
-        for(unsigned r = threadIdx.x; r < rows; r += 256)
+        unsigned * b4 = reinterpret_cast<unsigned *>(A.base);
+        for(; r < A.rows; r += n_waves)
         {
-          const unsigned vp = b4[op + static_cast<size_t>(r) * 64], vq = b4[oq + static_cast<size_t>(r) * 64];
-          b4[op + static_cast<size_t>(r) * 64] = vq;
-          b4[oq + static_cast<size_t>(r) * 64] = vp;
+          if(on && r < limit)
+          {
+            const unsigned vp = b4[op + static_cast<size_t>(r) * 64], vq = b4[oq + static_cast<size_t>(r) * 64];
+            b4[op + static_cast<size_t>(r) * 64] = vq;
+            b4[oq + static_cast<size_t>(r) * 64] = vp;
+          }
         }
       }
     }
     else
     {
-      // instance-major: rows words of elem bytes per instance (elem 4: the problem objects and limit tables are word-aligned)
-      unsigned * b4 = reinterpret_cast<unsigned *>(a.base);
-      const size_t words = static_cast<size_t>(a.rows) * (a.elem / 4);
-      const size_t op = static_cast<size_t>(p) * words, oq = static_cast<size_t>(q) * words;
-      for(size_t r = threadIdx.x; r < words; r += 256)
+      // instance-major: A.rows words of 4 bytes per instance (the problem objects and limit tables are word-aligned)
+      unsigned * b4 = reinterpret_cast<unsigned *>(A.base);
+      const size_t op = static_cast<size_t>(p) * A.rows, oq = static_cast<size_t>(q) * A.rows;
+      for(; r < A.rows; r += n_waves)
       {
-        const unsigned vp = b4[op + r], vq = b4[oq + r];
-        b4[op + r] = vq;
-        b4[oq + r] = vp;
+        if(on)
+        {
+          const unsigned vp = b4[op + r], vq = b4[oq + r];
+          b4[op + r] = vq;
+          b4[oq + r] = vp;
+        }
       }
     }
+    row0 += A.rows;
   }
 }
 } // namespace hip

@@ -86,7 +86,7 @@ extern "C"
        DDPSolver.hpp:115-123; a batch converges raggedly).  The solve is cut into resumable launches (iterations 1-16, 17-32, 33-48,
        49-64, 65-96, ... of those still running) with a device-side compaction between them, so that a persistent workgroup is not held
        by the one unconverged instance of its sixteen; no host round trip, results bit-identical to a single launch.
-       0: automatic (on for max_iter >= 32 where the kernel family has resumable instantiations: the quad and two-wave kernels
+       0: automatic (on for max_iter >= 64 where the kernel family has resumable instantiations: the quad and two-wave kernels
        with a shared problem object), 1: on wherever supported, -1: off (one launch per solve). */
     int ragged_schedule;
   } nmpc_hip_ddp_config;

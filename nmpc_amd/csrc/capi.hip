@@ -123,6 +123,7 @@ struct nmpc_hip_ddp_solver
   int * d_ragged_words = nullptr; // n_active[kRaggedMaxRounds + 1], then n_swaps[kRaggedMaxRounds]
   int * d_ragged_pairs = nullptr; // [kRaggedMaxRounds][Bp]: the (p, q) position pairs of every round's swaps
   int * d_ragged_rank = nullptr; // [Bp] scratch of the compaction kernel
+  int * d_ragged_used = nullptr; // [Bp / 2] trace rows in use per pair of the round being swapped
   nmpc_amd::hip::LaunchKnobs knobs; // kernel family / schedule choices of this handle (environment overrides read once at create)
   int ragged_env = 0; // NMPC_HIP_DDP_RAGGED, read once at create: 1 forces the schedule on, -1 off (A/B measurements)
   int last_ragged_rounds = 0; // launches of the last solve (1: an ordinary whole-solve launch)
@@ -471,7 +472,7 @@ bool raggedRounds(const nmpc_hip_ddp_solver * s, std::vector<int> * caps)
   {
     return false;
   }
-  if(mode == 0 && s->cfg.max_iter < 32)
+  if(mode == 0 && s->cfg.max_iter < 64)
   {
     return false;
   }
@@ -517,6 +518,16 @@ int ensureRagged(nmpc_hip_ddp_solver * s)
   {
     rc = devAlloc(&s->d_ragged_rank, static_cast<size_t>(s->Bp));
   }
+  if(rc == NMPC_HIP_OK)
+  {
+    rc = devAlloc(&s->d_ragged_used, static_cast<size_t>(s->Bp / 2 + 1));
+  }
+  if(rc == NMPC_HIP_OK)
+  {
+    // devAlloc clears with hipMemset, which is ordered on the NULL stream; the handle's stream is non-blocking and the first
+    // launches of the schedule follow at once: without this wait the clear could land in the middle of them (once per handle)
+    NMPC_HIP_TRY(hipDeviceSynchronize());
+  }
   return rc;
 }
 
@@ -553,8 +564,7 @@ nmpc_amd::hip::SwapTable swapTable(const nmpc_hip_ddp_solver * s)
   tile(s->d_dV, 2, e);
   tile(s->d_resume, nmpc_amd::hip::kResumeRows, e);
   tile(s->d_status, 1, 4);
-  tile(s->d_iters, 1, 4);
-  tile(s->d_sel, 1, 4);
+  tile(s->d_sel, 1, 4); // (d_iters: exchanged by the compaction / replay-prepare kernels, which take the pairs' trace rows from it)
   tile(s->d_qp_ret, T, 4);
   tile(s->d_qp_free, T, 4);
   tile(s->d_input_dim, T, 4);
@@ -582,7 +592,8 @@ int launchRagged(nmpc_hip_ddp_solver * s, hipStream_t st, DeviceBuffers buf, con
   int * n_active = s->d_ragged_words;
   int * n_swaps = s->d_ragged_words + R + 1;
   const nmpc_amd::hip::SwapTable tab = swapTable(s);
-  const dim3 swap_grid(static_cast<unsigned>(std::max(1, s->Bp / 2)));
+  const dim3 swap_grid(static_cast<unsigned>((s->Bp / 2 + 63) / 64), 64);
+  const int wg_size = std::strcmp(s->ops->kernel_name(s->B, s->cfg), "ddp_solve_quad_kernel") == 0 ? 16 : 64;
   buf.resume = s->d_resume;
   hipLaunchKernelGGL(nmpc_amd::hip::ragged_init_kernel, dim3(1), dim3(64), 0, st, n_active, s->B);
   for(int r = 0; r < rounds; r++)
@@ -599,14 +610,16 @@ int launchRagged(nmpc_hip_ddp_solver * s, hipStream_t st, DeviceBuffers buf, con
     {
       int * pairs = s->d_ragged_pairs + static_cast<size_t>(r) * s->Bp;
       hipLaunchKernelGGL((nmpc_amd::hip::ragged_compact_kernel<double>), dim3(1), dim3(1024), 0, st, s->d_resume, s->d_ragged_rank,
-                         pairs, n_swaps + r, n_active + r);
-      hipLaunchKernelGGL(nmpc_amd::hip::ragged_swap_kernel, swap_grid, dim3(256), 0, st, tab, pairs, n_swaps + r, s->d_iters);
+                         pairs, s->d_ragged_used, n_swaps + r, n_active + r, s->d_iters, wg_size);
+      hipLaunchKernelGGL(nmpc_amd::hip::ragged_swap_kernel, swap_grid, dim3(256), 0, st, tab, pairs, s->d_ragged_used, n_swaps + r);
     }
   }
   for(int r = rounds - 2; r >= 0; r--)
   {
     const int * pairs = s->d_ragged_pairs + static_cast<size_t>(r) * s->Bp;
-    hipLaunchKernelGGL(nmpc_amd::hip::ragged_swap_kernel, swap_grid, dim3(256), 0, st, tab, pairs, n_swaps + r, s->d_iters);
+    hipLaunchKernelGGL(nmpc_amd::hip::ragged_replay_prepare_kernel, dim3(static_cast<unsigned>((s->Bp / 2 + 255) / 256)), dim3(256), 0, st,
+                       pairs, s->d_ragged_used, n_swaps + r, s->d_iters);
+    hipLaunchKernelGGL(nmpc_amd::hip::ragged_swap_kernel, swap_grid, dim3(256), 0, st, tab, pairs, s->d_ragged_used, n_swaps + r);
   }
   NMPC_HIP_TRY(hipGetLastError());
   s->last_ragged_rounds = rounds;
@@ -968,7 +981,7 @@ extern "C"
     void * ptrs[] = {s->d_t0,     s->d_x0,     s->d_X,   s->d_U,      s->d_cost,    s->d_kff,       s->d_Kfb,
                      s->d_trace,  s->d_trace_last, s->d_dV, s->d_status, s->d_iters, s->d_sel,     s->d_qp_ret,
                      s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_params_batch, s->d_lim_batch, s->d_lim_steps, s->d_phase_ticks, s->d_stage_in,
-                     s->d_stage_out, s->d_resume, s->d_ragged_words, s->d_ragged_pairs, s->d_ragged_rank};
+                     s->d_stage_out, s->d_resume, s->d_ragged_words, s->d_ragged_pairs, s->d_ragged_rank, s->d_ragged_used};
     for(void * p : ptrs)
     {
       if(p)

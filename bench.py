@@ -46,6 +46,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# streams share GPU_MAX_HW_QUEUES hardware queues (default 4): the pooled legs (m2_overlapped, c3's pooled) overlap as many batches as
+# there are queues.  Read when the HIP runtime initialises, i.e. before torch touches the device (nmpc_amd/csrc/capi.hip).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 LANE_MAPPINGS = {
@@ -577,29 +580,38 @@ def main():
         if args.workload == "c2":
             extras["m1"] = leg("m1", 50, 10)
             extras["m2"] = leg("m2", 500, 10)
-            # M2 again with consecutive batches overlapped: 16 batches dealt round-robin to four handles (DDPSolverPool), each
-            # with its own stream — the few-instance tail of one batch no longer idles the chip (per-batch results are those of
-            # a lone handle, tests/test_gpu_parity.py::test_solver_pool_overlaps_consecutive_batches)
-            pool = nmpc_amd.DDPSolverPool(problem, wl.B, n_handles=4, device=device_index)
-            pc = pool.config()
-            pc.print_level = 0
-            pc.horizon_steps = wl.T
-            for key, val in mode_config("m2", 500).items():
-                setattr(pc, key, val)
-            pool.applyConfig()
-            for _ in range(4):
-                pool.submit(d_t0.data_ptr(), d_x0.data_ptr(), d_u0.data_ptr())
-            pool.synchronize()
-            torch.cuda.synchronize()
-            t0p = time.perf_counter()
-            for _ in range(16):
-                pool.submit(d_t0.data_ptr(), d_x0.data_ptr(), d_u0.data_ptr())
-            pool.synchronize()
-            dtp = time.perf_counter() - t0p
-            it_p = pool.solvers[-1].iters()
-            extras["m2_overlapped"] = {"value": 16 * (float(it_p.sum()) / wl.B) / dtp, "solves_per_s": 16 * wl.B / dtp,
-                                       "ms_per_solve": 1e3 * dtp / 16, "handles": 4, "batches": 16}
-            del pool
+            # M2 again with consecutive batches overlapped: 32 batches dealt round-robin to eight handles (DDPSolverPool), each
+            # with its own stream.  Under the ragged-convergence schedule (automatic at max_iter 500) a converged instance gives
+            # up its workgroup slot within sixteen iterations, so the batches in flight share the chip instead of queueing for
+            # the CUs that whole-solve workgroups hold until their slowest instance is done (per-batch results are those of a
+            # lone handle, tests/test_gpu_ragged.py); the same pool with whole-solve launches rides along for comparison.
+            def pooled_m2(ragged):
+                pool = nmpc_amd.DDPSolverPool(problem, wl.B, n_handles=8, device=device_index)
+                pc = pool.config()
+                pc.print_level = 0
+                pc.horizon_steps = wl.T
+                pc.ragged_schedule = ragged
+                for key, val in mode_config("m2", 500).items():
+                    setattr(pc, key, val)
+                pool.applyConfig()
+                for _ in range(8):
+                    pool.submit(d_t0.data_ptr(), d_x0.data_ptr(), d_u0.data_ptr())
+                pool.synchronize()
+                torch.cuda.synchronize()
+                t0p = time.perf_counter()
+                for _ in range(32):
+                    pool.submit(d_t0.data_ptr(), d_x0.data_ptr(), d_u0.data_ptr())
+                pool.synchronize()
+                dtp = time.perf_counter() - t0p
+                it_p = pool.solvers[-1].iters()
+                res = {"value": 32 * (float(it_p.sum()) / wl.B) / dtp, "solves_per_s": 32 * wl.B / dtp, "ms_per_solve": 1e3 * dtp / 32,
+                       "handles": 8, "batches": 32, "launches_per_solve": pool.solvers[-1].lastSolveLaunches(),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+                del pool
+                return res
+
+            extras["m2_overlapped"] = pooled_m2(0)
+            extras["m2_overlapped"]["whole_solve_launches_value"] = pooled_m2(-1)["value"]
         if args.workload == "c3":
             # 1024 bipedal instances are 64 quad workgroups on 256 CUs: the single-batch rate is a latency, not the chip's rate.
             # Four batches in flight on four handles / streams (DDPSolverPool) is how a caller with more than one batch fills it.
@@ -679,8 +691,9 @@ def main():
             config["m2_value"] = extras["m2"]["value"]
             config["m2"] = dict(extras["m2"], note="SURVEY 8(d) M2: default Configuration, solve to convergence (max_iter 500)")
             config["m2_overlapped_value"] = extras["m2_overlapped"]["value"]
-            config["m2_overlapped"] = dict(extras["m2_overlapped"], note="M2 with 16 consecutive batches on four handles / streams "
-                                           "(nmpc_amd.DDPSolverPool): sustained rate with the convergence tails overlapped")
+            config["m2_overlapped"] = dict(extras["m2_overlapped"], note="M2 with 32 consecutive batches on eight handles / streams "
+                                           "(nmpc_amd.DDPSolverPool) under the ragged-convergence schedule: sustained rate with the convergence "
+                                           "tails overlapped; whole_solve_launches_value: the same pool with one launch per solve")
         if "pooled" in extras:
             config["pooled_value"] = extras["pooled"]["value"]
             config["pooled"] = dict(extras["pooled"], note="the same workload with four batches in flight on four handles / streams "

@@ -90,7 +90,7 @@ int main(int argc, char ** argv)
 {
   const int B = argc > 1 ? std::atoi(argv[1]) : 4096;
   const int n_batches = argc > 2 ? std::atoi(argv[2]) : 8;
-  const int n_handles = argc > 3 ? std::atoi(argv[3]) : 4;
+  const int n_handles = argc > 3 ? std::atoi(argv[3]) : 8;
   const int T = 100;
   auto problem = std::make_shared<Problem>(0.01);
 

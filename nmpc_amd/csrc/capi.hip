@@ -19,6 +19,13 @@ using nmpc_amd::hip::ModelOps;
 
 namespace
 {
+// Hardware queues.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels
+// of two streams that share a queue run one after the other.  A pool of handles (DDPSolverPool: consecutive batches on their own
+// streams) overlaps only as many batches as there are queues [measured, profiles/r05_m2_overlap.txt: 8 handles, ragged schedule,
+// 2048 batch-iterations/s with 4 queues, 4685 with 16].  The variable is read when the runtime initialises, so the library asks for
+// 16 when it is loaded — unless the caller set it, and without effect if something initialised HIP earlier in the process.
+const int g_hw_queues_requested = setenv("GPU_MAX_HW_QUEUES", "16", 0);
+
 thread_local std::string g_last_error;
 
 int fail(int code, const std::string & msg)
@@ -463,8 +470,10 @@ int checkConfig(const nmpc_hip_ddp_solver * s, const nmpc_hip_ddp_config * c)
 namespace
 {
 /** Whether the next solve of the handle runs under the ragged-convergence schedule, and the last iteration of each of its launches:
-    16, 32, 48, 64, then 96, 128, 192, 256, 384, ... (half of the instances of a cart-pole batch are done after 14 iterations, a
-    percent runs for hundreds: compaction pays while the prefix shrinks fast and costs a relaunch where it no longer does). */
+    16, 32, 48, 64, then max_iter — batches beyond 4096 instances: 128 and 256 as well.  Half of the instances of a cart-pole batch are
+    done after 14 iterations, a percent runs for hundreds: compaction pays while the prefix shrinks fast; once the running instances
+    fit a few workgroups (64 iterations: 137 of 4096) another boundary only costs its ~90 us of launch gaps [measured: ten launches
+    per 500-iteration solve 829, whole-solve launch 858 batch-iterations/s on a lone stream]. */
 bool raggedRounds(const nmpc_hip_ddp_solver * s, std::vector<int> * caps)
 {
   const int mode = s->ragged_env != 0 ? s->ragged_env : s->cfg.ragged_schedule;
@@ -481,20 +490,15 @@ bool raggedRounds(const nmpc_hip_ddp_solver * s, std::vector<int> * caps)
     return false;
   }
   caps->clear();
-  int cap = 0, step = 16;
-  while(cap < s->cfg.max_iter && static_cast<int>(caps->size()) < nmpc_hip_ddp_solver::kRaggedMaxRounds - 1)
+  for(int cap : {16, 32, 48, 64, 128, 256})
   {
-    cap += step;
-    if(cap >= 64 && (cap & (cap - 1)) == 0)
+    if(cap >= s->cfg.max_iter || (cap > 64 && s->B <= 4096))
     {
-      step = cap / 2; // 64 -> steps of 32 (96, 128), 128 -> 64 (192, 256), ...
+      break;
     }
-    caps->push_back(cap < s->cfg.max_iter ? cap : s->cfg.max_iter);
+    caps->push_back(cap);
   }
-  if(caps->back() < s->cfg.max_iter)
-  {
-    caps->back() = s->cfg.max_iter;
-  }
+  caps->push_back(s->cfg.max_iter);
   return caps->size() > 1;
 }
 

@@ -1,6 +1,9 @@
 import os
 import sys
 
+# (before anything initialises the HIP runtime — _have_gpu() below does: streams share this many hardware queues, nmpc_amd/csrc/capi.hip)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -43,7 +43,9 @@ def test_default_line_has_the_contract_keys():
     # SURVEY 8(d)'s two timing modes ride in the default line
     cfg = d["config"]
     assert cfg["m1_value"] > 0 and cfg["m2_value"] > 0
-    assert cfg["m2_overlapped_value"] > 1.3 * cfg["m2_value"]  # consecutive batches on four streams hide the convergence tail
+    # consecutive batches on eight streams under the ragged-convergence schedule: the tails overlap and converged instances free their slots
+    assert cfg["m2_overlapped_value"] > 2.5 * cfg["m2_value"] and cfg["m2_overlapped_value"] > 1.3 * cfg["m2_overlapped"]["whole_solve_launches_value"]
+    assert cfg["m2_overlapped"]["launches_per_solve"] == 5 and cfg["m2_overlapped"]["handles"] == 8
     assert cfg["m1"]["status_counts"].get("1", 0) == 0 and cfg["m1"]["max_iterations"] <= 50
     assert cfg["m2"]["status_counts"].get("1", 0) >= 0.99 * 4096
     assert cfg["per_rank_solve_ms"] and abs(cfg["per_rank_solve_ms"][0] - d["ms_per_step"]) < 0.5 * d["ms_per_step"]

@@ -91,6 +91,7 @@ struct nmpc_hip_ddp_solver
   double sum_total_ms = 0, sum_kernel_ms = 0;
   float last_total_ms = 0, last_kernel_ms = 0;
   hipStream_t last_stream = nullptr;
+  hipEvent_t ev_staged = nullptr; // behind the H2D staging copies of nmpc_hip_ddp_solve_async
 
   int elem = 8; //!< sizeof(Problem::Scalar): element size of every Scalar array below (ModelOps::scalar_bytes)
   // device memory (Scalar arrays are typed double here; an fp32 problem type stores floats in them, see elem)
@@ -930,7 +931,13 @@ extern "C"
     chk(devAlloc(&s->d_qp_free, T * Bp));
     chk(devAlloc(&s->d_input_dim, T * Bp));
     chk(devAlloc(&s->d_phase_ticks, 4 * Bp));
-    if(m->wpi_workspace_doubles(s->T) > 0)
+    // (NMPC_HIP_DDP_NO_WORKSPACE=1: developer switch for the tests of the path a failed workspace allocation takes)
+    const char * no_ws = std::getenv("NMPC_HIP_DDP_NO_WORKSPACE");
+    if(no_ws && std::strcmp(no_ws, "0") != 0)
+    {
+      s->knobs.have_workspace = 0;
+    }
+    else if(m->wpi_workspace_doubles(s->T) > 0)
     {
       // wave-per-instance kernel (9 <= n <= 16): materialised derivatives, gains and one candidate trajectory per
       // step size, per instance; quad-kernel shapes: three candidate trajectories per instance, tile-major (the line
@@ -1007,6 +1014,10 @@ extern "C"
       {
         (void)hipEventDestroy(s->ev_end[i]);
       }
+    }
+    if(s->ev_staged)
+    {
+      (void)hipEventDestroy(s->ev_staged);
     }
     if(s->stream)
     {
@@ -1461,7 +1472,16 @@ extern "C"
     {
       NMPC_HIP_TRY(hipMemcpyAsync(dt, t0, nt * sizeof(double), hipMemcpyHostToDevice, s->stream));
     }
-    return nmpc_hip_ddp_solve_device(s, t0 ? dt : nullptr, dx, du, nullptr);
+    // The host arrays may be reused when this call returns: wait for the staging copies (pageable memory: the runtime may pin the
+    // caller's pages and copy later) — for them only, the solve behind them stays queued.
+    if(!s->ev_staged)
+    {
+      NMPC_HIP_TRY(hipEventCreateWithFlags(&s->ev_staged, hipEventDisableTiming));
+    }
+    NMPC_HIP_TRY(hipEventRecord(s->ev_staged, s->stream));
+    rc = nmpc_hip_ddp_solve_device(s, t0 ? dt : nullptr, dx, du, nullptr);
+    NMPC_HIP_TRY(hipEventSynchronize(s->ev_staged));
+    return rc;
   }
 
   int nmpc_hip_ddp_field_bytes(nmpc_hip_ddp_handle s, int field, size_t * bytes)

@@ -90,6 +90,18 @@ def test_bench_c5_uneven_strong_split_gathers_the_unsharded_solve():
     assert abs(d["value"] - it_per_step / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
 
+def test_bench_c4_fp32_two_ranks_at_global_batch_8192_equal_the_unsharded_solve():
+    """fp32 at the reference's default threshold: 8192 instances run on the fp32 tile kernel, a lone 4096-instance handle would take the
+    tile kernel's float instantiation — families that differ in the last bits.  The shards set the whole batch's size as their dispatch
+    batch (bench.py --global-batch; nmpc_hip_ddp_set_dispatch_batch) and return the unsharded solve bit for bit."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--workload", "c4", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                   "--no-extra-modes", "--min-seconds", "0.2", "--global-batch", "8192", "--cost-update-thre", "1e-7", "--verify-gather"], 29649)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["shard_sizes"] == [4096, 4096] and d["config"]["gather_verified"] is True and d["dtype"] == "f32"
+    assert d["roofline"]["kernel"] == "ddp_solve_tile32_kernel<quadrotor_f32>"
+
+
 def test_fmpc_bench_under_two_ranks():
     """bench.py --workload fmpc under two ranks (both on device 0): FMPC shards like DDP — independent instances, no collective in
     the data path; the job's value counts both ranks' iterations."""
@@ -122,7 +134,9 @@ def test_cpp_sharded_helper(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     # (bit-for-bit needs the same lane mapping on both sides: 4000 / 3 and 4000 both run the quad kernel, 8400 / 2 and 8400 both
     # the two-wave kernel; across kernel families results agree to 1e-13 with identical decisions, test_gpu_parity.py)
-    for args in (["cartpole", "203", "40", "2"], ["cartpole", "4000", "30", "3"], ["cartpole", "8400", "30", "2"],
-                 ["quadrotor_f32", "75", "20", "2"], ["cartpole", "96", "30", "1", "rccl"]):
+    # Since round 5 every shard takes the family the WHOLE batch would get (nmpc_hip_ddp_set_dispatch_batch): 8000 / 2 runs the two-wave
+    # kernel like the unsharded 8000, the fp32 quadrotor at 8192 / 2 the fp32 tile kernel the unsharded 8192 runs on.
+    for args in (["cartpole", "203", "40", "2"], ["cartpole", "4000", "30", "3"], ["cartpole", "8400", "30", "2"], ["cartpole", "8000", "30", "2"],
+                 ["quadrotor_f32", "75", "20", "2"], ["quadrotor_f32", "8192", "20", "2"], ["cartpole", "96", "30", "1", "rccl"]):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0 and "SHARDED_OK" in r.stdout, (args, r.stdout[-2000:], r.stderr[-2000:])

@@ -74,6 +74,7 @@ def test_without_the_workspace_the_lane_kernels_take_the_solve(monkeypatch):
     wl = workloads.manipulator_batch(B=96, T=20, seed=4)
     monkeypatch.setenv("NMPC_HIP_DDP_NO_WORKSPACE", "1")
     s = make_solver(wl, max_iter=4)
+    assert s.kernelName() == "ddp_solve_tpi_kernel"  # (the Python mirror creates its handle lazily: here)
     monkeypatch.delenv("NMPC_HIP_DDP_NO_WORKSPACE")
     assert s.kernelName() == "ddp_solve_tpi_kernel"
     s.solve(wl.t0, wl.x0, wl.u_init)

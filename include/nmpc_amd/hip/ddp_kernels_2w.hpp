@@ -176,6 +176,17 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   {
     return lds[(static_cast<size_t>(kRecArea) + 2 + NMPC_HIP_NTRACE + 2) * LW + 1];
   }
+  //! The backward pass of the quad kernel leaves the nominal records of the first three groups of timesteps in LDS (from its last
+  //! chunk: ddp_kernels_quad.hpp), so that the prefetching wave of the forward pass behind it starts at group 3 and barrier S does
+  //! not wait for a round trip to HBM.  Box-constrained solves only [measured, profiles/r05_c2_chain_ab.txt: cart-pole +- 15 N
+  //! 0.930 -> 0.905 ms; the unconstrained headline LOSES 2 % (0.451 -> 0.461 ms: ten more LDS stores per pass on a wave that is
+  //! bound by its instruction count, for a round trip the first barrier already hid)].
+  static constexpr bool kNominalTail = kLdsNominal && kConstrained;
+  //! 1.0: those records are resident; 0.0: a later pass of the same search (the ring has turned)
+  NMPC_D double & mailNomResident() const
+  {
+    return lds[(static_cast<size_t>(kRecArea) + 2 + NMPC_HIP_NTRACE + 2) * LW + 3];
+  }
   static constexpr unsigned kGroupLanes = kLanesPerBlock / kAlphaGroups;
 #ifndef NMPC_FANOUT_FIRST_PASS
 #  define NMPC_FANOUT_FIRST_PASS 1
@@ -1043,6 +1054,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   NMPC_D FanDest fanDest(unsigned cx, unsigned cu, unsigned cc) const
   {
     const unsigned g = laneGroup();
+    // (Measured and not kept, round 5: the groups behind the first rolling out for the cost only in the first pass of a search the
+    // workgroup expects to end at the first step size — 0.47 GB less HBM write traffic per launch, but the 0.2 % of searches that
+    // then take a later step size cost their workgroup a whole extra pass instead of a 2 k-cycle copy: c2 0.451 -> 0.480 ms.)
     if(g > 0 && fanScratch())
     {
       return fanSlot(g);
@@ -1479,11 +1493,18 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       }
     };
     double v0[kNomRec], v1[kNomRec], v2[kNomRec];
-    loadGroup(0, v0);
-    loadGroup(1, v1);
-    loadGroup(2, v2);
-    writeGroup(0, v0);
-    writeGroup(1, v1);
+    if(kNominalTail && mailNomResident() != 0.0)
+    {
+      loadGroup(2, v2); // (written again in the loop's first trip: the same values)
+    }
+    else
+    {
+      loadGroup(0, v0);
+      loadGroup(1, v1);
+      loadGroup(2, v2);
+      writeGroup(0, v0);
+      writeGroup(1, v1);
+    }
     wgBarrier(); // barrier S: groups 0 and 1 are in LDS
     const int n_full = T / kFwdGroup;
     int slot2 = 2; // slot of group g + 2
@@ -1638,11 +1659,18 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     if constexpr(kPrefetch)
     {
       double v0[kNomRec], v1[kNomRec];
-      loadGroup(0, v0);
-      loadGroup(1, v1);
-      loadGroup(2, v2);
-      writeGroup(0, v0);
-      writeGroup(1, v1);
+      if(kNominalTail && mailNomResident() != 0.0)
+      {
+        loadGroup(2, v2);
+      }
+      else
+      {
+        loadGroup(0, v0);
+        loadGroup(1, v1);
+        loadGroup(2, v2);
+        writeGroup(0, v0);
+        writeGroup(1, v1);
+      }
     }
     // ---- this lane group's step size (uniformly indexed reads of the list, selected per lane group)
     const int first = static_cast<int>(mailFirstAlpha()) + kAlphaGroups * (which + 1);
@@ -1990,6 +2018,10 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
           break;
         }
         const double a_try = cfg.alpha_list[ai];
+        if constexpr(kNominalTail)
+        {
+          mailNomResident() = (ai == 0) ? 1.0 : 0.0;
+        }
         post(kCmdForward);
         profBegin();
         forwardMaster(a_try);
@@ -2232,6 +2264,10 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       // sizes: the whole default alpha_list.  A step size accepted from an extra master is rolled out once more, with stores.
       for(int ai0 = 0, n_par = 0; ai0 < cfg.n_alpha; ai0 += n_par)
       {
+        if constexpr(kNominalTail)
+        {
+          mailNomResident() = (ai0 == 0) ? 1.0 : 0.0; // the first forward pass behind a backward pass (see mailNomResident)
+        }
         const bool wide_pass = kExtraMasters > 0 && (wide_first || ai0 > 0);
         n_par = wide_pass ? kStepSizesPerPass : ((ai0 == 0 && kExtraMasters == 0) ? kFanOutFirstPass : kAlphaGroups);
         if(!__any(need_fw))
@@ -2327,6 +2363,10 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
             else
             {
               // (instances that accepted group 0's step size re-create the same candidate, the others do not care)
+              if constexpr(kNominalTail)
+              {
+                mailNomResident() = 0.0;
+              }
               post(kCmdForward);
               profBegin();
               forwardMaster((need_fw && g_acc > 0) ? alpha : cfg.alpha_list[ai0]);

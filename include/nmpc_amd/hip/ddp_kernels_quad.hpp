@@ -91,7 +91,12 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
   static constexpr int gLive = 5; // 1.0: this timestep's gains are to be saved (DDPSolver.hpp:529-530 was reached)
   static constexpr int gDummy = 6;
   static constexpr int kGainRec = 7;
-  static constexpr int kChunkDoubles = 64 * (kRecQ + kGainRec);
+  // 8 doubles between the record blocks of a wave's four instances.  16 records of 49 doubles are 32 banks (mod 64) apart, so the
+  // operand reads of instances 0 / 2 and 1 / 3 of a wavefront hit the same banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.51 in
+  // rounds 2 - 4); with the pad the four blocks start 0, 48, 32, 16 banks apart [measured, profiles/r05_c2_chain_ab.txt: c2 0.451 ->
+  // 0.447 ms, c3 0.681 -> 0.661, cart-pole +- 15 N 0.930 -> 0.921, M1 3.194 -> 3.181; results bit-identical].
+  static constexpr int kInstPad = 8;
+  static constexpr int kChunkDoubles = 64 * (kRecQ + kGainRec) + 4 * kInstPad;
   // ---- mailboxes master <-> backward waves, per instance of the workgroup ----
   static constexpr int kMailIn = 4; // need, lambda, sel, t0
   static constexpr int kMailOut = 4; // ok, dV0, dV1, k_rel_norm
@@ -245,8 +250,8 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     const int lane_l = static_cast<int>(lane - lane % kQuadInstances) + inst_l;
     const double * px = Base::Xt + static_cast<size_t>(sel_l) * (Base::rowsX() * LW) + lane_l;
     const double * pu = Base::Ut + static_cast<size_t>(sel_l) * (Base::rowsU() * LW) + lane_l;
-    double * rec_l = chunk + static_cast<size_t>(wl) * kRecQ;
-    double * gains = chunk + 64 * kRecQ;
+    double * rec_l = chunk + static_cast<size_t>(wl) * kRecQ + (wl / 16) * kInstPad;
+    double * gains = chunk + 64 * kRecQ + 4 * kInstPad;
     const double * gain_l = gains + static_cast<size_t>(wl) * kGainRec; // linearisation mapping: read at the chunk boundary
     // recursion mapping: rows 0 and 1 of the block write [K | k, live, -, -] of the timestep, one double per lane
     // (rows 2 and 3 write the record's dummy slot: no branch in the recursion loop)
@@ -257,7 +262,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
     double * gain_u = gains + static_cast<size_t>(blk * 16) * kGainRec
                       + (row == 0 ? gKfb + col : ((row == 1 && col == 0) ? gK : gDummy));
     double * live_q = gains + static_cast<size_t>(blk * 16 + 4 * row + col) * kGainRec + gLive;
-    const double * rec_q = chunk + static_cast<size_t>(blk * 16) * kRecQ;
+    const double * rec_q = chunk + static_cast<size_t>(blk * 16) * kRecQ + blk * kInstPad;
 
     // lane predicates of the natural layout
     const bool c0 = col == 0, c1 = col == 1, r0 = row == 0;
@@ -500,6 +505,7 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
           flushGains(i0 + kChunkSteps, uinv_prev);
         }
         uinv_prev = uinv_now;
+        if(!Pair::kNominalTail || ch > 0) // (kNominalTail: the last chunk keeps its own (x, u) for the nominal records below)
         {
           const int in = i0 - kChunkSteps + ts_l; // (unconditional, clamped: the last request is never used)
           loadPointQ(in > 0 ? in : 0, px, pu, pt);
@@ -573,6 +579,34 @@ struct QuadSolver : PairSolver<Problem, kConstrained, true, (kConstrained || kFa
         }
       }
       flushGains(0, uinv_prev);
+      // The forward pass that follows starts from timestep 0 and takes its nominal (x, u, k, K) from LDS records that a prefetching
+      // wave keeps ahead of it; its first groups used to be a round trip to HBM behind the pass barrier, for values that are HERE:
+      // (x, u) of timesteps 0 .. 15 in the linearisation lanes' registers, the gains in the staging area.  Lane (instance, timestep)
+      // writes the record of the first three groups (PairSolver::nomRec); the master says so in mailNomResident.
+      if constexpr(Pair::kNominalTail)
+      {
+        asm volatile("" ::: "memory"); // (the staged gains were written by other lanes of this wave: LDS is in order)
+        if(ts_l < 3 * Pair::kFwdGroup)
+        {
+          double * rec = Pair::nomRec(ts_l / Pair::kFwdGroup, ts_l % Pair::kFwdGroup, static_cast<unsigned>(inst_l));
+#pragma unroll
+          for(int j = 0; j < N; j++)
+          {
+            rec[j] = pt.x[j];
+          }
+          rec[N] = pt.u;
+          rec[N + 1] = gain_l[gK];
+#pragma unroll
+          for(int c = 0; c < N; c++)
+          {
+            rec[N + 2 + c] = gain_l[gKfb + c];
+          }
+          if constexpr(Pair::kNomRec > N + 2 + N)
+          {
+            rec[Pair::kNomRec - 1] = 0;
+          }
+        }
+      }
     };
     if(cfg.reg_type == 2)
     {

@@ -12,7 +12,8 @@ iteration is one FmpcSolver::procOnce (FmpcSolver.hpp:356-491); executed iterati
 value = n_gpus * K * (executed instance-iterations per solve / batch) / t.  Weak scaling, no collective in the data path; the
 final variables of every rank are gathered once after the timed job (as in bench.py).
 
-roofline: the dominant kernel is the Riccati kernel (fmpc_riccati_quad_kernel at this batch size).  Its algorithmic bytes per launch = batch x T x (coefficient record read
+roofline: the dominant kernel is the Riccati kernel (fmpc_riccati_fused_kernel at this batch size: the coefficient records are computed
+by its producer waves into LDS, so the contract bytes below — the reference's materialised dataflow — are more than it moves).  Its algorithmic bytes per launch = batch x T x (coefficient record read
 by the backward recursion + gain record written by it + A, B, x_bar, K, k read by the forward recursion + dx, du written) x 8;
 its average duration comes from HIP events around every launch (config.time_kernels) in a second pass of K steps outside the
 timed region (the timed region replays the hipGraph of the solve, where single kernels cannot be bracketed).

@@ -720,29 +720,47 @@ __global__ void fmpc_init_complementary_kernel(FmpcBuffers buf)
 
 /** Step 1 of procOnce (FmpcSolver.hpp:394-441) for one (instance, timestep), fused with the pre-process of the backward pass
     (:562-574: everything of it that does not depend on P) and with this timestep's terms of calcKktError (:493-520). */
+namespace fmpc
+{
+/** The coefficient of timestep i of instance b (FmpcSolver.hpp:395-436 with the pre-process of the backward pass :562-574, and the
+    terms of calcKktError :493-521) — what fmpc_coeff_kernel computes per thread, with its RESULTS handed to a sink:
+      sink.coef(e, v)      element e of the coefficient record (CoefLayout)          sink.kkt(v)      the timestep's KKT-error terms
+      sink.terminal(e, v)  element e of the terminal gain record (i = T: s, P)       sink.nanFlag()   Coefficient::containsNaN
+    A sink that ignores a result leaves its arithmetic dead: fmpc_kkt_kernel (KKT terms, NaN flag, terminal record) and the
+    producer wave of fmpc_riccati_fused_kernel (the record, into LDS) are this function with other sinks. */
+/** What coefficients() reads of the variable: requested by loadCoefInputs() — the producer wave of fmpc_riccati_fused_kernel does
+    that a chunk before it computes from them, so that the round trip to HBM is off its path. */
 template<class Problem>
-__global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
+struct CoefInputs
+{
+  typename Problem::StateDimVector x, lambda, next_x, next_lambda;
+  typename Problem::InputDimVector u;
+  typename Problem::IneqDimVector s, nu;
+};
+template<class Problem>
+__device__ __forceinline__ void loadCoefInputs(const FmpcBuffers & buf, int b, int i, CoefInputs<Problem> & in)
+{
+  loadVec(buf.x, buf, i, b, in.x);
+  loadVec(buf.lam, buf, i, b, in.lambda);
+  if(i < buf.T)
+  {
+    loadVec(buf.u, buf, i, b, in.u);
+    loadVec(buf.x, buf, i + 1, b, in.next_x);
+    loadVec(buf.lam, buf, i + 1, b, in.next_lambda);
+    loadVec(buf.s, buf, i, b, in.s);
+    loadVec(buf.nu, buf, i, b, in.nu);
+  }
+}
+template<class Problem, class Sink>
+__device__ __forceinline__ void coefficients(const FmpcBuffers & buf, int b, int i, const CoefInputs<Problem> & in, Sink & sink)
 {
   constexpr int N = Problem::kStateDim, M = Problem::kInputDimMax, G = Problem::kIneqDim;
-  using CL = fmpc::CoefLayout<N, M>;
-  using GL = fmpc::GainLayout<N, M>;
-  const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if(tid >= static_cast<size_t>(buf.B) * (buf.T + 1))
-  {
-    return;
-  }
-  const int b = static_cast<int>(tid % buf.B);
-  const int i = static_cast<int>(tid / buf.B);
-  if(buf.status[b] != fmpc::kStatusContinued)
-  {
-    return;
-  }
-  const Problem prob = fmpc::loadProblem<Problem>(buf, b);
+  using CL = CoefLayout<N, M>;
+  using GL = GainLayout<N, M>;
+  const Problem prob = loadProblem<Problem>(buf, b);
   const double dt = prob.dt();
   const double t = buf.t0[b] + i * dt;
-  typename Problem::StateDimVector x, lambda;
-  fmpc::loadVec(buf.x, buf, i, b, x);
-  fmpc::loadVec(buf.lam, buf, i, b, lambda);
+  const typename Problem::StateDimVector & x = in.x, & lambda = in.lambda;
   double kkt = 0;
   bool nan = false;
 
@@ -758,31 +776,26 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
       const double Lx_bar = Vx[a] - lambda[a]; // (2.25a)
       kkt += Lx_bar * Lx_bar;
       const double sT = -1 * Lx_bar;
-      nan = nan || fmpc::bad(Vx[a]) || fmpc::bad(Lx_bar);
-      buf.gain[fmpc::at(buf, i, GL::S + a, GL::kStride, b)] = sT;
+      nan = nan || bad(Vx[a]) || bad(Lx_bar);
+      sink.terminal(GL::S + a, sT);
     }
     NMPC_UNROLL
     for(int e = 0; e < N * N; e++)
     {
-      nan = nan || fmpc::bad(Vxx.data()[e]);
-      buf.gain[fmpc::at(buf, i, GL::P + e, GL::kStride, b)] = Vxx.data()[e];
+      nan = nan || bad(Vxx.data()[e]);
+      sink.terminal(GL::P + e, Vxx.data()[e]);
     }
-    buf.part[fmpc::at(buf, i, 0, fmpc::kPartSlots, b)] = kkt;
+    sink.kkt(kkt);
     if(nan)
     {
-      atomicOr(&buf.flags[b], 1);
+      sink.nanFlag();
     }
     return;
   }
 
-  typename Problem::InputDimVector u;
-  typename Problem::StateDimVector next_x, next_lambda;
-  typename Problem::IneqDimVector s, nu;
-  fmpc::loadVec(buf.u, buf, i, b, u);
-  fmpc::loadVec(buf.x, buf, i + 1, b, next_x);
-  fmpc::loadVec(buf.lam, buf, i + 1, b, next_lambda);
-  fmpc::loadVec(buf.s, buf, i, b, s);
-  fmpc::loadVec(buf.nu, buf, i, b, nu);
+  const typename Problem::InputDimVector & u = in.u;
+  const typename Problem::StateDimVector & next_x = in.next_x, & next_lambda = in.next_lambda;
+  const typename Problem::IneqDimVector & s = in.s, & nu = in.nu;
 
   typename Problem::StateStateDimMatrix A, Lxx;
   typename Problem::StateInputDimMatrix Bm, Lxu;
@@ -813,7 +826,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
   {
     x_bar[a] = f[a] - next_x[a]; // (2.23c)
     part += x_bar[a] * x_bar[a];
-    nan = nan || fmpc::bad(x_bar[a]);
+    nan = nan || bad(x_bar[a]);
   }
   kkt += part;
   part = 0;
@@ -822,7 +835,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
   {
     g_bar[a] = g[a] + s[a]; // (2.23d)
     part += g_bar[a] * g_bar[a];
-    nan = nan || fmpc::bad(g_bar[a]);
+    nan = nan || bad(g_bar[a]);
   }
   kkt += part;
   part = 0;
@@ -842,7 +855,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
     }
     Lx_bar[a] = ((-1 * lambda[a] + dt * Lx[a]) + at) + ct;
     part += Lx_bar[a] * Lx_bar[a];
-    nan = nan || fmpc::bad(Lx_bar[a]) || fmpc::bad(Lx[a]);
+    nan = nan || bad(Lx_bar[a]) || bad(Lx[a]);
   }
   kkt += part;
   part = 0;
@@ -862,7 +875,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
     }
     Lu_bar[a] = (dt * Lu[a] + bt) + dn;
     part += Lu_bar[a] * Lu_bar[a];
-    nan = nan || fmpc::bad(Lu_bar[a]) || fmpc::bad(Lu[a]);
+    nan = nan || bad(Lu_bar[a]) || bad(Lu[a]);
   }
   kkt += part;
   part = 0;
@@ -874,39 +887,40 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
     part += e * e;
   }
   kkt += part;
-  buf.part[fmpc::at(buf, i, 0, fmpc::kPartSlots, b)] = kkt;
+  sink.kkt(kkt);
 
   // Coefficient::containsNaN (:136-154) on what is not stored below
   NMPC_UNROLL
   for(int e = 0; e < N * N; e++)
   {
-    nan = nan || fmpc::bad(A.data()[e]) || fmpc::bad(Lxx.data()[e]);
+    nan = nan || bad(A.data()[e]) || bad(Lxx.data()[e]);
   }
   NMPC_UNROLL
   for(int e = 0; e < N * M; e++)
   {
-    nan = nan || fmpc::bad(Bm.data()[e]) || fmpc::bad(Lxu.data()[e]);
+    nan = nan || bad(Bm.data()[e]) || bad(Lxu.data()[e]);
   }
   NMPC_UNROLL
   for(int e = 0; e < G * N; e++)
   {
-    nan = nan || fmpc::bad(C.data()[e]);
+    nan = nan || bad(C.data()[e]);
   }
   NMPC_UNROLL
   for(int e = 0; e < G * M; e++)
   {
-    nan = nan || fmpc::bad(D.data()[e]);
+    nan = nan || bad(D.data()[e]);
   }
   NMPC_UNROLL
   for(int e = 0; e < M * M; e++)
   {
-    nan = nan || fmpc::bad(Luu.data()[e]);
+    nan = nan || bad(Luu.data()[e]);
   }
   if(nan)
   {
-    atomicOr(&buf.flags[b], 1);
+    sink.nanFlag();
   }
 
+  sink.midpoint(); // (everything above keeps its results in registers; every sink.coef() call is below)
   // pre-process of the backward pass (:562-574)
   const double barrier_eps = buf.barrier_eps[b];
   double nu_s[G > 0 ? G : 1], tilde_sub[G > 0 ? G : 1];
@@ -919,17 +933,17 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
   NMPC_UNROLL
   for(int e = 0; e < N * N; e++)
   {
-    buf.coef[fmpc::at(buf, i, CL::A + e, CL::kStride, b)] = A.data()[e];
+    sink.coef(CL::A + e, A.data()[e]);
   }
   NMPC_UNROLL
   for(int e = 0; e < N * M; e++)
   {
-    buf.coef[fmpc::at(buf, i, CL::B + e, CL::kStride, b)] = Bm.data()[e];
+    sink.coef(CL::B + e, Bm.data()[e]);
   }
   NMPC_UNROLL
   for(int a = 0; a < N; a++)
   {
-    buf.coef[fmpc::at(buf, i, CL::XBAR + a, CL::kStride, b)] = x_bar[a];
+    sink.coef(CL::XBAR + a, x_bar[a]);
   }
   NMPC_UNROLL
   for(int c = 0; c < N; c++)
@@ -943,7 +957,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
       {
         acc += (C(j, a) * nu_s[j]) * C(j, c);
       }
-      buf.coef[fmpc::at(buf, i, CL::QXX + a + c * N, CL::kStride, b)] = dt * Lxx(a, c) + acc; // (2.28c)
+      sink.coef(CL::QXX + a + c * N, dt * Lxx(a, c) + acc); // (2.28c)
     }
   }
   NMPC_UNROLL
@@ -958,7 +972,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
       {
         acc += (D(j, a) * nu_s[j]) * D(j, c);
       }
-      buf.coef[fmpc::at(buf, i, CL::QUU + a + c * M, CL::kStride, b)] = dt * Luu(a, c) + acc; // (2.28e)
+      sink.coef(CL::QUU + a + c * M, dt * Luu(a, c) + acc); // (2.28e)
     }
     NMPC_UNROLL
     for(int a = 0; a < N; a++)
@@ -969,7 +983,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
       {
         acc += (C(j, a) * nu_s[j]) * D(j, c);
       }
-      buf.coef[fmpc::at(buf, i, CL::QXU + a + c * N, CL::kStride, b)] = dt * Lxu(a, c) + acc; // (2.28d)
+      sink.coef(CL::QXU + a + c * N, dt * Lxu(a, c) + acc); // (2.28d)
     }
   }
   NMPC_UNROLL
@@ -981,7 +995,7 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
     {
       acc += C(j, a) * tilde_sub[j];
     }
-    buf.coef[fmpc::at(buf, i, CL::LXT + a, CL::kStride, b)] = Lx_bar[a] + acc; // (2.28f)
+    sink.coef(CL::LXT + a, Lx_bar[a] + acc); // (2.28f)
   }
   NMPC_UNROLL
   for(int a = 0; a < M; a++)
@@ -992,8 +1006,61 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
     {
       acc += D(j, a) * tilde_sub[j];
     }
-    buf.coef[fmpc::at(buf, i, CL::LUT + a, CL::kStride, b)] = Lu_bar[a] + acc; // (2.28g)
+    sink.coef(CL::LUT + a, Lu_bar[a] + acc); // (2.28g)
   }
+}
+
+/** Sink of fmpc_coeff_kernel: everything to HBM. */
+template<int N, int M, bool kRecord>
+struct GlobalCoefSink
+{
+  const FmpcBuffers & buf;
+  int b, i;
+  __device__ __forceinline__ void coef(int e, double v) const
+  {
+    if constexpr(kRecord)
+    {
+      buf.coef[at(buf, i, e, CoefLayout<N, M>::kStride, b)] = v;
+    }
+  }
+  __device__ __forceinline__ void terminal(int e, double v) const
+  {
+    buf.gain[at(buf, i, e, GainLayout<N, M>::kStride, b)] = v;
+  }
+  __device__ __forceinline__ void kkt(double v) const
+  {
+    buf.part[at(buf, i, 0, kPartSlots, b)] = v;
+  }
+  __device__ __forceinline__ void nanFlag() const
+  {
+    atomicOr(&buf.flags[b], 1);
+  }
+  __device__ __forceinline__ void midpoint() const {}
+};
+} // namespace fmpc
+
+/** One thread per (instance, timestep): the coefficient record, the KKT-error terms, the NaN flag.
+    \tparam kRecord false: everything but the record — what is launched in front of fmpc_riccati_fused_kernel, whose producer wave
+    computes the records into its staging LDS (A, B, x_bar also to HBM, for the forward sweep) */
+template<class Problem, bool kRecord = true>
+__global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
+{
+  constexpr int N = Problem::kStateDim, M = Problem::kInputDimMax;
+  const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if(tid >= static_cast<size_t>(buf.B) * (buf.T + 1))
+  {
+    return;
+  }
+  const int b = static_cast<int>(tid % buf.B);
+  const int i = static_cast<int>(tid / buf.B);
+  if(buf.status[b] != fmpc::kStatusContinued)
+  {
+    return;
+  }
+  fmpc::GlobalCoefSink<N, M, kRecord> sink{buf, b, i};
+  fmpc::CoefInputs<Problem> in;
+  fmpc::loadCoefInputs<Problem>(buf, b, i, in);
+  fmpc::coefficients<Problem>(buf, b, i, in, sink);
 }
 
 namespace fmpc
@@ -1921,6 +1988,500 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
     }
   }
   if(live && c0 && rv)
+  {
+    buf.dx[fmpc::at(buf, T, rc, N, b)] = dx_row;
+  }
+#ifdef NMPC_AMD_FMPC_PROFILE
+  if(head && b_raw < buf.B) // developer build only: 100 MHz wall-clock ticks of the two recursions in the merit slots
+  {
+    buf.merit[0 * buf.B + b] = static_cast<double>(tick1 - tick0);
+    buf.merit[1 * buf.B + b] = static_cast<double>(wall_clock64() - tick1);
+  }
+#endif
+}
+
+namespace fmpc
+{
+/** Sink of a producer wave of fmpc_riccati_fused_kernel: the record into its LDS staging slot; A, B, x_bar also to HBM.  A producer
+    works on a chunk for TWO trips of the recursion waves' chunk loop: midpoint() stands for the two workgroup barriers that end the
+    first of them (all of the record's stores come after it: the slot is still being read during the first trip). */
+template<int N, int M>
+struct StagedCoefSink
+{
+  double * rec;
+  const FmpcBuffers & buf;
+  int b, i;
+  bool on, to_hbm;
+  __device__ __forceinline__ void coef(int e, double v) const
+  {
+    if(on)
+    {
+      rec[e] = v;
+      if(e < CoefLayout<N, M>::XBAR + N && to_hbm)
+      {
+        buf.coef[at(buf, i, e, CoefLayout<N, M>::kStride, b)] = v;
+      }
+    }
+  }
+  __device__ __forceinline__ void midpoint() const
+  {
+    syncThreadsFuzzed(__LINE__);
+    syncThreadsFuzzed(__LINE__);
+  }
+  __device__ __forceinline__ void terminal(int, double) const {}
+  __device__ __forceinline__ void kkt(double) const {}
+  __device__ __forceinline__ void nanFlag() const {}
+};
+} // namespace fmpc
+
+/** fmpc_riccati_quad_kernel with the coefficient records never in HBM (FmpcSolver.hpp:395-436, :523-665): a FIFTH
+    wavefront of the workgroup (lane = (timestep of the chunk, instance)) computes the records of the next chunk from the variables
+    (fmpc::coefficients, the body of fmpc_coeff_kernel) into the staging slot the four recursion wavefronts read, while they consume
+    the current one.  In front of it runs fmpc_coeff_kernel<Problem, false> (KKT-error terms, NaN flag, terminal record: the KKT test
+    comes BEFORE the backward pass, :443-449, and needs every timestep's terms).  A, B, x_bar are still written to HBM once (the forward
+    sweep and the line search read them).  Everything else is the quad kernel's text. */
+template<class Problem>
+__global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf, int iter)
+{
+  constexpr int N = Problem::kStateDim;
+  static_assert(N >= 1 && N <= 4 && Problem::kInputDimMax == 1, "[FMPC] the fused Riccati kernel handles up to four states and one input");
+  constexpr int M = 1;
+  using CL = fmpc::CoefLayout<N, M>;
+  using GL = fmpc::GainLayout<N, M>;
+  constexpr int kS = fmpc::kStageSteps;
+  constexpr int kRecB = CL::kStride | 1; // odd record widths: the 16 instances of a row slot hit 16 different banks
+  constexpr int kFwdCoef = CL::XBAR + N; // A, B, x_bar: elements [0, kFwdCoef) of the coefficient record
+  constexpr int kFwdGain = GL::K + M * N; // k, K: elements [0, kFwdGain) of the gain record
+  constexpr int kRecF = (kFwdCoef + kFwdGain) | 1;
+  constexpr int kSlotDoubles = kS * 16 * (kRecB > kRecF ? kRecB : kRecF);
+  constexpr int kRecG = (GL::kStride + 2) | 1; // gain record + two spare slots
+  constexpr int kRecX = (N + M + 2) | 1; // dx, du + two spare slots
+  __shared__ double stage_lds[3 * kSlotDoubles]; // chunk k of the backward pass in slot k % 3 (the forward pass uses two)
+  __shared__ double gain_lds[kS * 16 * kRecG]; // what the chunk's steps produce (backward: gains, forward: dx, du), before it goes to HBM
+  __shared__ double sh_kkt[16][17];
+  __shared__ int sh_live[16];
+
+  const int wl = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row = wl >> 4, blk = (wl >> 2) & 3, col = wl & 3;
+  const bool producer = wave >= 4; // wavefronts 4 and 5: lane = (timestep of the chunk, instance), compute the coefficient records
+  const int inst = producer ? (wl & 15) : wave * 4 + blk;
+  const int b_raw = blockIdx.x * 16 + inst;
+  const int b = b_raw < buf.B ? b_raw : buf.B - 1; // lanes beyond the batch mirror the last instance and store nothing
+  const bool head = !producer && row == 0 && col == 0; // the lane that speaks for the instance
+  const bool c0 = col == 0, c1 = col == 1;
+  const bool rv = row < N, cv = col < N, valid = rv && cv;
+  const int rc = rv ? row : N - 1, cc = cv ? col : N - 1;
+  const int T = buf.T;
+  const size_t Bz = static_cast<size_t>(buf.B);
+  bool live = b_raw < buf.B && buf.status[b] == fmpc::kStatusContinued;
+  // staging role of this thread: element slot t_slot (+ 16 q) of instance t_inst of the workgroup
+  const int t_inst = threadIdx.x & 15, t_slot = threadIdx.x >> 4;
+  const int b_stage_raw = blockIdx.x * 16 + t_inst;
+  const int b_stage = b_stage_raw < buf.B ? b_stage_raw : buf.B - 1;
+  const size_t lane_stage = static_cast<size_t>(t_slot) * Bz + b_stage; // + (row index) * B = element index of this thread's load
+
+  auto mma = [](double x, double y, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, c, 0, 0, 0); };
+  auto bcast0 = [](double v) { // entry of column 0 of this lane's row (same quad) in all four lanes of the quad
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x00, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x00, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  auto bcast1 = [](double v) { // quad_perm:[1,1,1,1]
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x55, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x55, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+
+  // ---- KKT-error test (FmpcSolver.hpp:443-449): sixteen partial sums per instance (timesteps t_slot, t_slot + 16, ...; every
+  // 16-lane group reads one full line per row), added up by the head lane in slot order
+  if(!producer)
+  {
+    double acc = 0;
+    for(int i = t_slot; i <= T; i += 16)
+    {
+      acc += buf.part[fmpc::at(buf, i, 0, fmpc::kPartSlots, b_stage)];
+    }
+    sh_kkt[t_inst][t_slot] = acc;
+  }
+  syncThreadsFuzzed(__LINE__);
+  if(head)
+  {
+    double kkt_error = 0;
+    NMPC_UNROLL
+    for(int q = 0; q < 16; q++)
+    {
+      kkt_error += sh_kkt[inst][q];
+    }
+    kkt_error = sqrt(kkt_error);
+    if(live)
+    {
+      buf.trace[(static_cast<size_t>(b) * buf.max_iter + (iter - 1)) * NMPC_HIP_FMPC_NTRACE + NMPC_HIP_FMPC_TRACE_KKT_ERROR] =
+          kkt_error;
+      if(kkt_error <= buf.kkt_error_thre)
+      {
+        buf.status[b] = 1; // Status::Succeeded
+      }
+    }
+    sh_kkt[inst][16] = kkt_error;
+  }
+  syncThreadsFuzzed(__LINE__);
+  live = live && !(sh_kkt[inst][16] <= buf.kkt_error_thre);
+  if(head)
+  {
+    sh_live[inst] = live ? 1 : 0;
+  }
+  fuzzSched(__LINE__);
+  const int any_live = __syncthreads_or(live ? 1 : 0);
+  fuzzSched(__LINE__);
+  if(any_live == 0)
+  {
+    return; // workgroup-uniform: none of the sixteen instances is live
+  }
+
+  // ---- operand staging.  In the [timestep][element][instance] arrays the four instances of a wavefront are 32 bytes of every
+  // row: operands fetched per lane would touch sixteen cache lines per load and use a quarter of each (measured: the kernel is
+  // then bound by the line rate of the vector L1, 0.95 us per step).  Instead the sixteen instances of the WORKGROUP — one full
+  // 128-byte line per row — are fetched cooperatively for kStageSteps timesteps at a time (thread = (element slot, instance):
+  // every 16-lane group reads one whole line), parked in registers while the previous chunk is being consumed, written to LDS
+  // as per-(timestep, instance) records and read from there by the lanes that need them.
+  /** Elements [0, NR) of timesteps i0, i0 + dir, ..., i0 + (kS - 1) dir of this thread's instance: request into v. */
+  auto request = [&](auto nr_tag, const double * src, int stride, int i0, int dir, double * v) {
+    constexpr int NR = decltype(nr_tag)::value;
+    constexpr int kQ = (NR + 15) / 16;
+    NMPC_UNROLL
+    for(int st = 0; st < kS; st++)
+    {
+      const int step = i0 + dir * st; // wavefront-uniform
+      if(step >= 0 && step < T)
+      {
+        const double * rowp = src + (static_cast<size_t>(step) * stride) * Bz + lane_stage;
+        NMPC_UNROLL
+        for(int q = 0; q < kQ; q++)
+        {
+          if(16 * q + 15 < NR || t_slot < NR - 16 * q)
+          {
+            v[st * kQ + q] = rowp[static_cast<size_t>(16 * q) * Bz];
+          }
+        }
+      }
+    }
+  };
+  /** ... and park them in LDS slot `slot` as records of width W, at offset `off` of each record. */
+  auto commit = [&](auto nr_tag, int slot, int W, int off, const double * v) {
+    constexpr int NR = decltype(nr_tag)::value;
+    constexpr int kQ = (NR + 15) / 16;
+    double * base = stage_lds + static_cast<size_t>(slot) * kSlotDoubles + t_inst * W + off + t_slot;
+    NMPC_UNROLL
+    for(int st = 0; st < kS; st++)
+    {
+      NMPC_UNROLL
+      for(int q = 0; q < kQ; q++)
+      {
+        if(16 * q + 15 < NR || t_slot < NR - 16 * q)
+        {
+          base[st * 16 * W + 16 * q] = v[st * kQ + q];
+        }
+      }
+    }
+  };
+  using TagB = std::integral_constant<int, CL::kStride>;
+  using TagFc = std::integral_constant<int, kFwdCoef>;
+  using TagFg = std::integral_constant<int, kFwdGain>;
+
+  // ---- backward pass
+#ifdef NMPC_AMD_FMPC_PROFILE
+  const unsigned long long tick0 = wall_clock64();
+#endif
+  double P = valid ? buf.gain[fmpc::at(buf, T, GL::P + rc + cc * N, GL::kStride, b)] : 0.0;
+  double s_row = rv ? buf.gain[fmpc::at(buf, T, GL::S + rc, GL::kStride, b)] : 0.0; // s[row], kept by every lane of the row
+  bool nan = fmpc::bad(s_row);
+
+  // What a lane writes per step: its entry of P, and one more value by role — s[row] on the diagonal lanes, K[col] on the
+  // lanes one row below the diagonal (cyclically), k on lane (2, 0) — every value is present on every lane of its row / column,
+  // so any lane of the right row / column can write it.  Two stores per step and no branch inside the recursion loop.
+  const bool role_s = (row == col) && rv, role_K = (row == ((col + 1) & 3)) && cv, role_k = (row == 2 && col == 0);
+  // (lanes without a value of their own write the record's spare slots)
+  const int e1 = valid ? GL::P + rc + cc * N : GL::kStride;
+  const int e2 = role_s ? GL::S + rc : (role_K ? GL::K + cc : (role_k ? GL::k : GL::kStride + 1));
+  double * const gP = gain_lds + inst * kRecG + e1;
+  double * const g2 = gain_lds + inst * kRecG + e2;
+
+  // per-lane offsets into a staged record
+  const int oA = CL::A + rc + cc * N, oQ = CL::QXX + rc + cc * N, oQT = CL::QXX + cc + rc * N, oB = CL::B + rc, oX = CL::XBAR + rc;
+  const int oCM = c0 ? CL::QUU : CL::LUT, oLM = c0 ? CL::QXU + rc : CL::LXT + rc, oQR = CL::QXU + cc;
+  struct Operands
+  {
+    double A, Qxx, QxxT, Bv, Y, CM, LM, QxuRow;
+  };
+  auto loadOperands = [&](const double * rec, Operands & o) {
+    const double a = rec[oA], q = rec[oQ], qt = rec[oQT], bv = rec[oB], xb = rec[oX], cm = rec[oCM], lm = rec[oLM], qr = rec[oQR];
+    o.A = valid ? a : 0.0;
+    o.Qxx = valid ? q : 0.0;
+    o.QxxT = valid ? qt : 0.0;
+    o.Bv = rv ? bv : 0.0; // B[row] in every column
+    o.Y = rv ? (c0 ? bv : (c1 ? xb : 0.0)) : 0.0; // [B | x_bar | 0 | 0]
+    o.CM = (c0 || c1) ? cm : 0.0; // [Quu~, Lu~, 0, 0] in every row
+    o.LM = (rv && (c0 || c1)) ? lm : 0.0; // [Qxu~ | Lx~ | 0 | 0]
+    o.QxuRow = cv ? qr : 0.0; // Qxu~^T in every row
+  };
+  auto backwardStep = [&](int st, const Operands & o) {
+    const double PA = mma(P, o.A, 0.0);
+    const double R = mma(P, o.Y, c1 ? -1 * s_row : 0.0);
+    const double F = mma(PA, o.A, o.Qxx);
+    const double FT = mma(o.A, PA, o.QxxT);
+    const double S = mma(o.A, R, o.LM);
+    const double Wq = mma(o.Bv, R, o.CM);
+    const double HA = mma(bcast0(R), o.A, o.QxuRow);
+    const double G = bcast0(Wq), k_rhs = bcast1(Wq);
+    const double Hr = bcast0(S), Qxl = bcast1(S);
+    // Eigen's LDLT solve of the 1 x 1 system (pseudo-inverse of D), then (2.35e)
+    const bool pivot = fabs(G) > DBL_MIN;
+    const double k = -1 * (pivot ? k_rhs / G : 0.0);
+    const double Kc = -1 * (pivot ? HA / G : 0.0);
+    const double Kr = -1 * (pivot ? Hr / G : 0.0);
+    const double s_new = (-1 * Qxl) - Hr * k; // (2.35a)
+    const double Pn = F - (Kr * G) * Kc;
+    const double PnT = FT - (Kc * G) * Kr;
+    P = 0.5 * (Pn + PnT); // enforce symmetric (:627-629)
+    s_row = s_new;
+    nan = nan || fmpc::bad(k) || fmpc::bad(Kc) || fmpc::bad(s_new) || fmpc::bad(P);
+    const double v2 = role_s ? s_new : (role_K ? Kc : (role_k ? k : P));
+    gP[st * 16 * kRecG] = P; // parked in LDS; flushGains writes the chunk out in whole cache lines
+    g2[st * 16 * kRecG] = v2;
+  };
+  /** The gains of the chunk that started at timestep i0: LDS -> HBM, thread = (element slot, instance), a full line per row. */
+  auto flushGains = [&](int i0) {
+    if(sh_live[t_inst] != 0)
+    {
+      NMPC_UNROLL
+      for(int st = 0; st < kS; st++)
+      {
+        const int step = i0 - st;
+        if(step >= 0)
+        {
+          double * rowp = buf.gain + (static_cast<size_t>(step) * GL::kStride) * Bz + lane_stage;
+          NMPC_UNROLL
+          for(int q = 0; q < (GL::kStride + 15) / 16; q++)
+          {
+            if(16 * q + 15 < GL::kStride || t_slot < GL::kStride - 16 * q)
+            {
+              rowp[static_cast<size_t>(16 * q) * Bz] = gain_lds[(st * 16 + t_inst) * kRecG + 16 * q + t_slot];
+            }
+          }
+        }
+      }
+    }
+  };
+  // ---- the producer wave: the coefficient record of (instance p_inst, timestep i0 - p_ts) straight into the staging slot the
+  // recursion waves read (what fmpc_coeff_kernel would have written to HBM and this kernel read back: 51 of the ~80 doubles a step
+  // moved), one chunk ahead of them.  A, B, x_bar also go to HBM: the forward sweep below and the line search read them there.
+  const int p_inst = wl & 15, p_ts = wl >> 4;
+  // Chunk k (timesteps T - 1 - 4 k ... down) lives in slot k % 3.  The two producers work in lockstep on chunks (2 j + 2, 2 j + 3)
+  // while the recursion waves consume chunks 2 j and 2 j + 1: a producer has two trips of the chunk loop per record — a record is
+  // ~1100 dependent instructions of model code, a trip is 4 x ~160 on the recursion waves, and one producer alone set the pace
+  // [measured: 253 against 213 us per launch].  Its stores come in the second trip (StagedCoefSink::midpoint), when nobody reads
+  // the slot any more.
+  const int n_chunks = (T + kS - 1) / kS;
+  auto produceChunk = [&](int k) {
+    const int i = T - 1 - k * kS - p_ts;
+    fmpc::CoefInputs<Problem> in;
+    fmpc::loadCoefInputs<Problem>(buf, b, i > 0 ? i : 0, in);
+    fmpc::StagedCoefSink<N, M> sink{stage_lds + static_cast<size_t>(k % 3) * kSlotDoubles + (p_ts * 16 + p_inst) * kRecB, buf, b,
+                                    i > 0 ? i : 0, i >= 0, live};
+    fmpc::coefficients<Problem>(buf, b, i > 0 ? i : 0, in, sink); // (two workgroup barriers inside: sink.midpoint())
+  };
+  {
+    static_assert(kS == 4, "a producer wave's lane mapping is 4 timesteps x 16 instances");
+    // prologue: chunks 0 and 1 (every wavefront passes the producers' two mid-record barriers)
+    if(producer)
+    {
+      if(wave - 4 < n_chunks)
+      {
+        produceChunk(wave - 4);
+      }
+      else
+      {
+        syncThreadsFuzzed(__LINE__);
+        syncThreadsFuzzed(__LINE__);
+      }
+    }
+    else
+    {
+      syncThreadsFuzzed(__LINE__);
+      syncThreadsFuzzed(__LINE__);
+    }
+    syncThreadsFuzzed(__LINE__);
+    if(producer)
+    {
+      for(int c = 0; c < n_chunks; c += 2)
+      {
+        const int k = c + 2 + (wave - 4);
+        if(k < n_chunks)
+        {
+          produceChunk(k); // first half, the two barriers of trip c, second half
+          syncThreadsFuzzed(__LINE__); // the two barriers of trip c + 1 (it exists: k < n_chunks)
+          syncThreadsFuzzed(__LINE__);
+        }
+        else
+        {
+          syncThreadsFuzzed(__LINE__);
+          syncThreadsFuzzed(__LINE__);
+          if(c + 1 < n_chunks)
+          {
+            syncThreadsFuzzed(__LINE__);
+            syncThreadsFuzzed(__LINE__);
+          }
+        }
+      }
+    }
+    for(int c = 0; c < (producer ? 0 : n_chunks); c++)
+    {
+      const int i0 = T - 1 - c * kS;
+      const int slot = c % 3;
+      {
+        const double * recs = stage_lds + static_cast<size_t>(slot) * kSlotDoubles + inst * kRecB;
+        Operands o[2];
+        loadOperands(recs, o[0]);
+        NMPC_UNROLL
+        for(int st = 0; st < kS; st++)
+        {
+          if(i0 - st >= 0)
+          {
+            if(st + 1 < kS)
+            {
+              loadOperands(recs + (st + 1) * 16 * kRecB, o[(st + 1) & 1]);
+            }
+            backwardStep(st, o[st & 1]);
+          }
+        }
+      }
+      syncThreadsFuzzed(__LINE__); // every wavefront's gains of this chunk are in LDS
+      flushGains(i0);
+      syncThreadsFuzzed(__LINE__);
+    }
+  }
+  // verdict of the backward pass per instance (:640-653): OR over the sixteen lanes of the instance
+  {
+    int bad_any = nan ? 1 : 0;
+    bad_any |= __shfl_xor(bad_any, 1);
+    bad_any |= __shfl_xor(bad_any, 2);
+    bad_any |= __shfl_xor(bad_any, 16);
+    bad_any |= __shfl_xor(bad_any, 32);
+    const bool failed = buf.check_nan && (bad_any != 0 || (buf.flags[b] & 1));
+    if(live && failed && head)
+    {
+      buf.status[b] = 3; // Status::ErrorInBackward
+    }
+    live = live && !failed;
+    if(head)
+    {
+      sh_live[inst] = live ? 1 : 0;
+    }
+  }
+  // (no early exit from here on: every wavefront of the workgroup takes part in the staging barriers of the forward pass,
+  // and the gains the other wavefronts wrote above are read below: make them visible first)
+  __threadfence();
+  syncThreadsFuzzed(__LINE__);
+
+  // ---- forward pass, the recursion over the timesteps (:669-687); dx[row] is kept by every lane of the row
+#ifdef NMPC_AMD_FMPC_PROFILE
+  const unsigned long long tick1 = wall_clock64();
+#endif
+  double dx_row = rv ? buf.x0[static_cast<size_t>(rc) * Bz + b] - buf.x[fmpc::at(buf, 0, rc, N, b)] : 0.0;
+  // one value per lane and step by role, parked in LDS: dx[row] on the diagonal lanes, du on lane (1, 0)
+  const bool role_dx = (row == col) && rv, role_du = (row == 1 && col == 0);
+  double * const fP = gain_lds + inst * kRecX + (role_dx ? rc : (role_du ? N : N + M));
+  const int oAT = CL::A + cc + rc * N; // entry (col, row): the A operand of mma is used transposed
+  const int oKx = kFwdCoef + GL::K + rc, ok = kFwdCoef + GL::k;
+  struct ForwardOperands
+  {
+    double AT, Kx, k, Bv, xb;
+  };
+  auto loadForward = [&](const double * rec, ForwardOperands & o) {
+    const double at_ = rec[oAT], kx = rec[oKx], bv = rec[oB], xb = rec[oX];
+    o.k = rec[ok];
+    o.AT = valid ? at_ : 0.0;
+    o.Kx = rv ? kx : 0.0; // K[row] in every column
+    o.Bv = rv ? bv : 0.0;
+    o.xb = rv ? xb : 0.0;
+  };
+  auto forwardStep = [&](int st, const ForwardOperands & o) {
+    const double Y = c0 ? dx_row : 0.0;
+    const double ax = bcast0(mma(o.AT, Y, 0.0)); // (A dx)[row]
+    const double du = bcast0(mma(o.Kx, Y, 0.0)) + o.k; // (2.36), the same in every row
+    fP[st * 16 * kRecX] = role_du ? du : dx_row;
+    const double nx = (ax + o.Bv * du) + o.xb; // (2.26b)
+    dx_row = rv ? nx : 0.0;
+  };
+  {
+    constexpr int kQC = (kFwdCoef + 15) / 16, kQG = (kFwdGain + 15) / 16;
+    double vc[kS * kQC], vg[kS * kQG];
+    if(!producer)
+    {
+      request(TagFc(), buf.coef, CL::kStride, 0, 1, vc);
+      request(TagFg(), buf.gain, GL::kStride, 0, 1, vg);
+      commit(TagFc(), 0, kRecF, 0, vc);
+      commit(TagFg(), 0, kRecF, kFwdCoef, vg);
+    }
+    syncThreadsFuzzed(__LINE__);
+    int slot = 0;
+    for(int i0 = 0; i0 < T; i0 += kS)
+    {
+      if(!producer)
+      {
+        if(i0 + kS < T)
+        {
+          request(TagFc(), buf.coef, CL::kStride, i0 + kS, 1, vc);
+          request(TagFg(), buf.gain, GL::kStride, i0 + kS, 1, vg);
+        }
+        const double * recs = stage_lds + static_cast<size_t>(slot) * kSlotDoubles + inst * kRecF;
+        ForwardOperands o[2];
+        loadForward(recs, o[0]);
+        NMPC_UNROLL
+        for(int st = 0; st < kS; st++)
+        {
+          if(i0 + st < T)
+          {
+            if(st + 1 < kS)
+            {
+              loadForward(recs + (st + 1) * 16 * kRecF, o[(st + 1) & 1]);
+            }
+            forwardStep(st, o[st & 1]);
+          }
+        }
+      }
+      syncThreadsFuzzed(__LINE__);
+      if(!producer && i0 + kS < T)
+      {
+        commit(TagFc(), slot ^ 1, kRecF, 0, vc);
+        commit(TagFg(), slot ^ 1, kRecF, kFwdCoef, vg);
+      }
+      if(!producer && sh_live[t_inst] != 0 && t_slot < N + M) // dx, du of the chunk: LDS -> HBM in whole lines
+      {
+        NMPC_UNROLL
+        for(int st = 0; st < kS; st++)
+        {
+          const int step = i0 + st;
+          if(step < T)
+          {
+            const double v = gain_lds[(st * 16 + t_inst) * kRecX + t_slot];
+            if(t_slot < N)
+            {
+              buf.dx[(static_cast<size_t>(step) * N + t_slot) * Bz + b_stage] = v;
+            }
+            else
+            {
+              buf.du[(static_cast<size_t>(step) * M + (t_slot - N)) * Bz + b_stage] = v;
+            }
+          }
+        }
+      }
+      syncThreadsFuzzed(__LINE__);
+      slot ^= 1;
+    }
+  }
+  if(!producer && live && c0 && rv)
   {
     buf.dx[fmpc::at(buf, T, rc, N, b)] = dx_row;
   }

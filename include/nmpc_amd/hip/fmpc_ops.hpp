@@ -26,7 +26,13 @@ namespace hip
 inline int fmpcRiccatiForceFromEnvironment()
 {
   const char * force = getenv("NMPC_HIP_FMPC_RICCATI");
-  return (force && force[0] == 'q') ? 1 : ((force && force[0] == 'l') ? 2 : 0);
+  return (force && force[0] == 'q') ? 1 : ((force && force[0] == 'l') ? 2 : ((force && force[0] == 'f') ? 3 : 0));
+}
+/** The fused kernel (fmpc_riccati_fused_kernel: coefficient records computed in the staging, never in HBM) wherever the matrix-core
+    kernel runs, unless the handle pins the unfused one (riccati_force 1: NMPC_HIP_FMPC_RICCATI=quad). */
+inline bool fmpcUseFusedRiccati(int force)
+{
+  return force != 1;
 }
 inline bool fmpcUseQuadRiccati(int N, int M, int B, int force)
 {
@@ -36,7 +42,7 @@ inline bool fmpcUseQuadRiccati(int N, int M, int B, int force)
   }
   if(force != 0)
   {
-    return force == 1;
+    return force == 1 || force == 3;
   }
   static int n_cu = 0; // of the current device at first use (the handles of one process sit on like devices)
   if(n_cu == 0)
@@ -114,7 +120,17 @@ struct FmpcOpsOf
       return hipGetLastError();
     };
     o.launch_coeff = [](const FmpcBuffers & buf, hipStream_t stream) {
-      hipLaunchKernelGGL(fmpc_coeff_kernel<Problem>, dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)), dim3(256), 0,
+      if constexpr(N <= 4 && M == 1)
+      {
+        if(fmpcUseQuadRiccati(N, M, buf.B, buf.riccati_force) && fmpcUseFusedRiccati(buf.riccati_force))
+        {
+          // (the records themselves are computed by the Riccati kernel's producer wave)
+          hipLaunchKernelGGL((fmpc_coeff_kernel<Problem, false>), dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)), dim3(256),
+                             0, stream, buf);
+          return hipGetLastError();
+        }
+      }
+      hipLaunchKernelGGL((fmpc_coeff_kernel<Problem, true>), dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)), dim3(256), 0,
                          stream, buf);
       return hipGetLastError();
     };
@@ -123,7 +139,14 @@ struct FmpcOpsOf
       {
         if(fmpcUseQuadRiccati(N, M, buf.B, buf.riccati_force))
         {
-          hipLaunchKernelGGL((fmpc_riccati_quad_kernel<N>), dim3(blocks(buf.B, 16)), dim3(256), 0, stream, buf, iter);
+          if(fmpcUseFusedRiccati(buf.riccati_force))
+          {
+            hipLaunchKernelGGL((fmpc_riccati_fused_kernel<Problem>), dim3(blocks(buf.B, 16)), dim3(384), 0, stream, buf, iter);
+          }
+          else
+          {
+            hipLaunchKernelGGL((fmpc_riccati_quad_kernel<N>), dim3(blocks(buf.B, 16)), dim3(256), 0, stream, buf, iter);
+          }
           return hipGetLastError();
         }
       }

@@ -92,7 +92,8 @@ os.environ.pop("NMPC_HIP_DDP_KERNEL", None)
 
 if not args.only or "fmpc" in args.only:
     from nmpc_amd import fmpc as F
-    for label, cls, B, T, it, ric in (("fmpc cartpole quad", F.FmpcProblemCartPole, 1024 if big else 300, 200 if big else 60, 4, "quad"),
+    for label, cls, B, T, it, ric in (("fmpc cartpole fused", F.FmpcProblemCartPole, 1024 if big else 300, 200 if big else 60, 4, "fused"),
+                                      ("fmpc cartpole quad", F.FmpcProblemCartPole, 1024 if big else 300, 200 if big else 60, 4, "quad"),
                                       ("fmpc cartpole lane", F.FmpcProblemCartPole, 512, 60, 3, "lane"),
                                       ("fmpc pointmass", F.FmpcProblemPointMass, 300, 40, 4, None)):
         os.environ.pop("NMPC_HIP_FMPC_RICCATI", None)

@@ -72,7 +72,7 @@ def test_default_line_has_the_contract_keys():
     # the other workloads ride along as secondary legs: >= 0.5 s each, own kernel and roofline
     sec = d["secondary"]
     kernels = {"c3": "ddp_solve_quad_kernel<bipedal>", "c4": "ddp_solve_tile64_kernel<quadrotor_f32>", "c4f64": "ddp_solve_tile64_kernel<quadrotor>",
-               "c5": "ddp_solve_tile64_kernel<manipulator>", "fmpc": "fmpc_riccati_quad_kernel", "centroidal": "ddp_solve_tile64_kernel<centroidal>"}
+               "c5": "ddp_solve_tile64_kernel<manipulator>", "fmpc": "fmpc_riccati_fused_kernel", "centroidal": "ddp_solve_tile64_kernel<centroidal>"}
     for name, kernel in kernels.items():
         leg = sec[name]
         assert leg.get("error") is None, (name, leg)
@@ -130,7 +130,7 @@ def test_fmpc_workload_keeps_the_contract():
     assert "FMPC iterations/s" in d["metric"] and "batch=4096" in d["metric"] and d["vs_baseline"] is None and d["dtype"] == "f64"
     assert d["config"]["status_counts"] == {"5": 4096} and d["config"]["iterations_per_step"] == 5
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["kernel"] == "fmpc_riccati_quad_kernel" and rf["launches_timed"] == 4 * 5
+    assert rf["bound"] == "hbm" and rf["kernel"] == "fmpc_riccati_fused_kernel" and rf["launches_timed"] == 4 * 5
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.5
     assert abs(d["value"] - 5 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     cb = d["cpu_baseline"]

@@ -65,13 +65,15 @@ def compare(solver, ref, rtol=1e-8, atol=1e-10, min_stable=0.9):
     return v
 
 
-@pytest.mark.parametrize("riccati", ["quad", "lane"])
+@pytest.mark.parametrize("riccati", ["fused", "quad", "lane"])
 @pytest.mark.parametrize("model", sorted(MODELS))
 @pytest.mark.parametrize("B,T,max_iter", [(130, 30, 1), (70, 57, 4), (64, 8, 10)])
 def test_solve_matches_oracle(model, B, T, max_iter, riccati, monkeypatch):
-    """Both Riccati kernels: sixteen lanes per instance on the matrix cores (n <= 4, one input: the default for the oscillator and
-    the cart-pole) and one lane per instance (everything else; forced here through NMPC_HIP_FMPC_RICCATI, which is read at launch)."""
-    if model == "fmpc_pointmass" and riccati == "lane":
+    """The three Riccati kernels: sixteen lanes per instance on the matrix cores with the coefficient records computed by a producer
+    wave into the staging LDS ("fused": n <= 4, one input: the default for the oscillator and the cart-pole), the same with the records
+    read back from HBM ("quad"), and one lane per instance (everything else; forced here through NMPC_HIP_FMPC_RICCATI, which is read
+    when the handle is created)."""
+    if model == "fmpc_pointmass" and riccati != "fused":
         pytest.skip("two inputs: the lane kernel is what runs anyway")
     monkeypatch.setenv("NMPC_HIP_FMPC_RICCATI", riccati)
     prob = MODELS[model]()
@@ -79,6 +81,8 @@ def test_solve_matches_oracle(model, B, T, max_iter, riccati, monkeypatch):
     s = F.FmpcSolverBatch(prob, B, T)
     s.config().max_iter = max_iter
     st = s.solve(t0, x0, var)
+    want = {"fused": "fmpc_riccati_fused_kernel", "quad": "fmpc_riccati_quad_kernel", "lane": "fmpc_riccati_kernel"}[riccati]
+    assert ("fmpc_riccati_kernel" if model == "fmpc_pointmass" else want) in s.kernelNames()
     ref = oracle_batch(model, s.config(), prob.p, t0, x0, var)
     # the Van der Pol problem over a short horizon diverges from about 40 % of these random starts (in the oracle just as on the
     # device); every other case converges for all instances

@@ -115,7 +115,7 @@ def test_fmpc_bench_under_two_ranks():
     assert len(d["config"]["per_rank_solve_ms"]) == 2
     # 5 iterations per instance per solve on each of the two ranks
     assert abs(d["value"] - 2 * 5 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
-    assert d["roofline"]["kernel"] == "fmpc_riccati_quad_kernel" and 0 < d["roofline"]["frac"] < 1.5
+    assert d["roofline"]["kernel"] == "fmpc_riccati_fused_kernel" and 0 < d["roofline"]["frac"] < 1.5
 
 
 def test_cpp_sharded_helper(tmp_path):

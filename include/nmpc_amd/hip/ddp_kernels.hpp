@@ -118,7 +118,7 @@ struct Unroll
     completion by anything the ISA documents.  (Not observed failing: scripts/determinism_soak.py, 2000 repetitions per kernel
     family, is clean with either form — the CU's in-order vector-memory path hides it — but the pass boundaries were written
     as full barriers and now are.) */
-NMPC_D inline void fullBarrier()
+NMPC_D void fullBarrier()
 {
   fuzzSched(1);
 #ifdef NMPC_AMD_AB_LDS_ONLY_PASS_BARRIER // (A/B builds: what __syncthreads() compiles to — scripts/determinism_soak.py against it)

@@ -1872,8 +1872,8 @@ struct TileSolver64
   template<int J>
   NMPC_D static double fromRowLane(double v)
   {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false); // row_newbcast:J
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, true); // row_newbcast:J (bound_ctrl: every lane has a source, and no "old" value has to be materialised)
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
   }
   /** The value of lane `src` (a constant) in every lane, as a wave-uniform value. */

@@ -28,11 +28,19 @@ inline int fmpcRiccatiForceFromEnvironment()
   const char * force = getenv("NMPC_HIP_FMPC_RICCATI");
   return (force && force[0] == 'q') ? 1 : ((force && force[0] == 'l') ? 2 : ((force && force[0] == 'f') ? 3 : 0));
 }
-/** The fused kernel (fmpc_riccati_fused_kernel: coefficient records computed in the staging, never in HBM) wherever the matrix-core
-    kernel runs, unless the handle pins the unfused one (riccati_force 1: NMPC_HIP_FMPC_RICCATI=quad). */
-inline bool fmpcUseFusedRiccati(int force)
+inline int fmpcComputeUnits()
 {
-  return force != 1;
+  static int n_cu = 0; // of the current device at first use (the handles of one process sit on like devices)
+  if(n_cu == 0)
+  {
+    int device = 0;
+    if(hipGetDevice(&device) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess
+       || n_cu <= 0)
+    {
+      n_cu = 256;
+    }
+  }
+  return n_cu;
 }
 inline bool fmpcUseQuadRiccati(int N, int M, int B, int force)
 {
@@ -44,17 +52,18 @@ inline bool fmpcUseQuadRiccati(int N, int M, int B, int force)
   {
     return force == 1 || force == 3;
   }
-  static int n_cu = 0; // of the current device at first use (the handles of one process sit on like devices)
-  if(n_cu == 0)
+  return (B + 15) / 16 <= 2 * fmpcComputeUnits();
+}
+/** The fused kernel (fmpc_riccati_fused_kernel: coefficient records computed by producer waves into the staging LDS, never in HBM)
+    where the matrix-core kernel runs with at most ONE workgroup per CU — its three staging slots are 93 KB of LDS, the unfused kernel's
+    61 KB let two workgroups share a CU — unless the handle pins one (riccati_force 1 / 3: NMPC_HIP_FMPC_RICCATI = quad / fused). */
+inline bool fmpcUseFusedRiccati(int B, int force)
+{
+  if(force != 0)
   {
-    int device = 0;
-    if(hipGetDevice(&device) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess
-       || n_cu <= 0)
-    {
-      n_cu = 256;
-    }
+    return force == 3;
   }
-  return (B + 15) / 16 <= 2 * n_cu;
+  return (B + 15) / 16 <= fmpcComputeUnits();
 }
 
 struct FmpcOps
@@ -122,7 +131,7 @@ struct FmpcOpsOf
     o.launch_coeff = [](const FmpcBuffers & buf, hipStream_t stream) {
       if constexpr(N <= 4 && M == 1)
       {
-        if(fmpcUseQuadRiccati(N, M, buf.B, buf.riccati_force) && fmpcUseFusedRiccati(buf.riccati_force))
+        if(fmpcUseQuadRiccati(N, M, buf.B, buf.riccati_force) && fmpcUseFusedRiccati(buf.B, buf.riccati_force))
         {
           // (the records themselves are computed by the Riccati kernel's producer wave)
           hipLaunchKernelGGL((fmpc_coeff_kernel<Problem, false>), dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)), dim3(256),
@@ -139,7 +148,7 @@ struct FmpcOpsOf
       {
         if(fmpcUseQuadRiccati(N, M, buf.B, buf.riccati_force))
         {
-          if(fmpcUseFusedRiccati(buf.riccati_force))
+          if(fmpcUseFusedRiccati(buf.B, buf.riccati_force))
           {
             hipLaunchKernelGGL((fmpc_riccati_fused_kernel<Problem>), dim3(blocks(buf.B, 16)), dim3(384), 0, stream, buf, iter);
           }

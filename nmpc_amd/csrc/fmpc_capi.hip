@@ -1146,7 +1146,7 @@ extern "C"
     (void)hipSetDevice(h->device);
     h->kernel_names = std::string("fmpc_barrier_kernel,fmpc_coeff_kernel,")
                       + (nmpc_amd::hip::fmpcUseQuadRiccati(h->buf.N, h->buf.M, h->buf.B, h->buf.riccati_force)
-                             ? (nmpc_amd::hip::fmpcUseFusedRiccati(h->buf.riccati_force) ? "fmpc_riccati_fused_kernel" : "fmpc_riccati_quad_kernel")
+                             ? (nmpc_amd::hip::fmpcUseFusedRiccati(h->buf.B, h->buf.riccati_force) ? "fmpc_riccati_fused_kernel" : "fmpc_riccati_quad_kernel")
                              : "fmpc_riccati_kernel")
                       + ",fmpc_delta_kernel,fmpc_step_length_kernel," + (h->cfg.enable_line_search ? "fmpc_line_search_kernel," : "")
                       + "fmpc_update_kernel";

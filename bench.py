@@ -84,6 +84,9 @@ WORKLOADS = {
               "x0 splitmix64 seed %d, u_init=hover"),
     "c5": ("manipulator_batch", 8192, 30,
            "C5-shape manipulator: nx=14, nu=7, T=%d, batch=%d per GPU (65536 over 8 GPUs), fp64, splitmix64 seed %d"),
+    "centroidal": ("centroidal_batch", 4096, 100,
+                   "centroidal motion (TestDDPCentroidalMotion.cpp: the reference's largest model): nx=9, nu in {16, 0} along the horizon, "
+                   "T=%d, batch=%d per GPU, fp64, splitmix64 seed %d"),
 }
 
 

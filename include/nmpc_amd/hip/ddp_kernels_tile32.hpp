@@ -1729,7 +1729,21 @@ struct ModelOpsTile32
       NMPC_HIP_DDP_KERNEL=tile32 / tile64 forces one of them (A/B measurements; tests/test_gpu_fp32.py runs on both). */
   static constexpr bool kTile64Float = Problem::kStateDim >= 5 && Problem::kStateDim <= 15 && Problem::kInputDimMax >= 1
                                        && Problem::kInputDimMax <= 8 && !Problem::kDynamicInput;
-  static constexpr int kTile64FloatBelowBatch = 8192;
+  //! batches that fill the chip with this kernel's fixed 32-instance workgroups: 32 x the number of CUs (8192 on MI355X)
+  static int fullChipBatch()
+  {
+    static int n_cu = 0; // of the current device at first use (the handles of one process sit on like devices)
+    if(n_cu == 0)
+    {
+      int device = 0;
+      if(hipGetDevice(&device) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess
+         || n_cu <= 0)
+      {
+        n_cu = 256;
+      }
+    }
+    return 32 * n_cu;
+  }
   static constexpr double kTile64FloatFromThreshold = 5e-4;
   static bool useTile64Float(int batch, const nmpc_hip_ddp_config & cfg)
   {
@@ -1747,7 +1761,7 @@ struct ModelOpsTile32
       return false;
     }
     // (a shard of a larger solve takes the family the WHOLE batch would get: the two fp32 kernels differ in the last bits)
-    return knobs.batchFor(batch) < kTile64FloatBelowBatch || cfg.cost_update_thre >= kTile64FloatFromThreshold;
+    return knobs.batchFor(batch) < fullChipBatch() || cfg.cost_update_thre >= kTile64FloatFromThreshold;
   }
   static const char * kernelName(int batch, const nmpc_hip_ddp_config & cfg)
   {

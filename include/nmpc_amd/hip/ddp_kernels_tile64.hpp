@@ -224,7 +224,7 @@ struct TileSolver64
     fInLs = 8,
     fSuccess = 16
   };
-  static constexpr int kKnextAt = kSlotAt + kW * kNumSlotFields * kT64MaxGroup; //!< [32][8]: k_{i+1}, the BoxQP warm start (:452-467)
+  static constexpr int kKnextAt = kSlotAt + kW * kNumSlotFields * kT64MaxGroup; //!< [kT64MaxGroup][8]: k_{i+1}, the BoxQP warm start (:452-467)
   static constexpr int kWaveAt = kKnextAt + (kConstrained ? kT64MaxGroup * 8 : 0);
   // per matrix wave: the column exchange of the gain computation, then (aliased: one wave's LDS traffic is ordered) the transposition
   //! leading dimension of the exchanged columns: ODD, so that the sixteen lanes of a row (one column each) hit different banks
@@ -244,8 +244,8 @@ struct TileSolver64
   static constexpr int wDump = wZero + 16; //!< written by lanes outside a block
   static constexpr int kWaveDoubles = wDump + 2;
   static constexpr int kScratchPerWave = 1;
-  static constexpr int kLsAt = kWaveAt + kT64MatrixWaves * kScratchPerWave * kWaveDoubles; //!< lsJ[NMPC_HIP_MAX_ALPHA][32]: cost of every trial
-  static constexpr int kTraceAt = kLsAt + NMPC_HIP_MAX_ALPHA * kT64MaxGroup; //!< trace row of the running iteration, [field][32]
+  static constexpr int kLsAt = kWaveAt + kT64MatrixWaves * kScratchPerWave * kWaveDoubles; //!< lsJ[NMPC_HIP_MAX_ALPHA][kT64MaxGroup]: cost of every trial
+  static constexpr int kTraceAt = kLsAt + NMPC_HIP_MAX_ALPHA * kT64MaxGroup; //!< trace row of the running iteration, [field][kT64MaxGroup]
   static constexpr int kProfAt = (kTraceAt + NMPC_HIP_NTRACE * kT64MaxGroup + 1) & ~1; //!< profiling builds: 40 tick counters of workgroup 0
 #ifdef NMPC_AMD_PROFILE_TILE64
   static constexpr int kFixedRaw = kProfAt + kW * 40;

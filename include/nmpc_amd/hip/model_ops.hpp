@@ -124,7 +124,7 @@ struct ModelOps
   //! dt() of the problem object
   double (*dt)(const void * params);
   //! name of the kernel launch_solve launches for a batch of `batch` instances under the Configuration `cfg` (lane mapping, see
-  //! launchSolve: with / without input constraints; the fp32 types also look at max_iter and cost_update_thre)
+  //! launchSolve: with / without input constraints; the fp32 types also look at cost_update_thre), the handle's LaunchKnobs included
   const char * (*kernel_name)(int batch, const nmpc_hip_ddp_config & cfg);
   //! launches the receding-horizon advance step (mpc_kernels.hpp) between two solves
   hipError_t (*launch_mpc_advance)(const void * params,

@@ -54,7 +54,7 @@ struct ModelOpsFor
     return kWpiShape && (!constrained || kWpiBoxQP) && !knobs.kernelIs("1w") && knobs.have_workspace != 0;
   }
   /** fp64 tile kernel (ddp_kernels_tile64.hpp: groups of up to 32 instances per workgroup, derivatives LDS-resident, backward
-      pass on v_mfma_f64_16x16x4 in natural layout, BoxQP included): 5 <= n <= 15 with a static input dimension m <= 8.  It
+      pass on v_mfma_f64_16x16x4 in natural layout, BoxQP included): 5 <= n <= 15, m <= 16, static or inputDim(t) (kTile64Big: m > 8 or run-time m, gains in natural layout).  It
       replaces the wave-per-instance kernel on these shapes; NMPC_HIP_DDP_KERNEL=wpi / 1w select the older kernels (A/B). */
   static constexpr bool kTile64Shape = Problem::kStateDim >= 5 && Problem::kStateDim <= 15 && Problem::kInputDimMax >= 1
                                        && Problem::kInputDimMax <= 16;

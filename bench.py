@@ -315,6 +315,28 @@ def ddp_secondary_leg(name: str, device_index: int, seed: int, iters_per_solve: 
            "status_counts": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
            "roofline": roof, "traffic": traffic}
     del solver
+    if name == "c3":
+        # 1024 bipedal instances are 64 quad workgroups on 256 CUs: a single batch is a latency chain (T = 300 timesteps x ~1.1 k
+        # cycles per iteration) that leaves three quarters of the chip idle.  Eight batches in flight on eight handles / streams
+        # (DDPSolverPool) is how a caller with more than one batch fills it: the pooled rate and its contract fraction ride along.
+        pool = nmpc_amd.DDPSolverPool(problem, wl.B, n_handles=8, device=device_index)
+        pc = pool.config()
+        pc.print_level, pc.horizon_steps, pc.max_iter = 0, wl.T, iters_per_solve
+        pool.applyConfig()
+        for _ in range(16):
+            pool.submit(d_t0.data_ptr(), d_x0.data_ptr(), d_u0.data_ptr())
+        pool.synchronize()
+        torch.cuda.synchronize()
+        n_pool = max(64, 8 * n_steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(n_pool):
+            pool.submit(d_t0.data_ptr(), d_x0.data_ptr(), d_u0.data_ptr())
+        pool.synchronize()
+        dtp = time.perf_counter() - t0
+        it_p = float(pool.solvers[-1].iters().sum())
+        out["pooled"] = {"value": n_pool * (it_p / wl.B) / dtp, "handles": 8, "batches": n_pool, "ms_per_solve": 1e3 * dtp / n_pool,
+                         "contract_frac": words * elem * it_p * n_pool / dtp / 1e9 / HBM_PEAK_GBS}
+        del pool
     return out
 
 

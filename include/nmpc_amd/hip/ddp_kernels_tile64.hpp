@@ -245,7 +245,28 @@ struct TileSolver64
   static constexpr int kWaveDoubles = wDump + 2;
   static constexpr int kScratchPerWave = 1;
   static constexpr int kLsAt = kWaveAt + kT64MatrixWaves * kScratchPerWave * kWaveDoubles; //!< lsJ[NMPC_HIP_MAX_ALPHA][kT64MaxGroup]: cost of every trial
-  static constexpr int kTraceAt = kLsAt + NMPC_HIP_MAX_ALPHA * kT64MaxGroup; //!< trace row of the running iteration, [field][kT64MaxGroup]
+  // Box-constrained solves with a per-lane factorisation (static m <= 8), round 5: the QPs of a matrix wave's (up to five) slots of a
+  // timestep are solved TOGETHER, lane e = slot e of the wave (backwardSweepMatrix) — one pass of the QP code per wave and timestep
+  // instead of five with all 64 lanes solving the same problem.  What a slot's QP reads (Quu_F, Qu) waits here between the wave's
+  // "prepare" trip over its slots and the batch; the last slot's is still in the wave's exchange scratch.  Per wave: four inputs of
+  // MM * MM + MM elements, five results (free set, return code).  The area starts where lsJ lives: the line search is idle during a sweep.
+  static constexpr bool kBatchQP = kConstrained && !kBig && std::is_same<S, double>::value;
+  // Matrix waves that OWN slots in the backward sweep, and slots per owner: seven owners of up to five slots.  (Measured and not
+  // kept for the batched QP, -DNMPC_AMD_AB_QP_OWNERS=4: four owners of up to nine slots — one QP pass per SIMD and timestep instead of
+  // two — are SLOWER, manipulator box 12.2 -> 15.4 ms, quadrotor box 4.8 -> 5.8: a pass lasts as long as the slowest of its lanes'
+  // QPs, whose iteration counts are heavy-tailed, and nine slots' steps run one after the other.  profiles/r05_constrained_tile64_ab.txt)
+#ifdef NMPC_AMD_AB_QP_OWNERS
+  static constexpr int kOwnerWaves = kBatchQP ? NMPC_AMD_AB_QP_OWNERS : kT64MatrixWaves;
+#else
+  static constexpr int kOwnerWaves = kT64MatrixWaves;
+#endif
+  static constexpr int kPerWave = (kT64MaxGroup + kOwnerWaves - 1) / kOwnerWaves;
+  static constexpr int kQpIn = MM * MM + MM;
+  static constexpr int kQpPerWave = (kPerWave - 1) * kQpIn + 2 * kPerWave;
+  static constexpr int kQpAt = kLsAt;
+  static constexpr int kLsDoubles = NMPC_HIP_MAX_ALPHA * kT64MaxGroup;
+  static constexpr int kLsOrQp = (kBatchQP && kOwnerWaves * kQpPerWave > kLsDoubles) ? kOwnerWaves * kQpPerWave : kLsDoubles;
+  static constexpr int kTraceAt = kLsAt + kLsOrQp; //!< trace row of the running iteration, [field][kT64MaxGroup]
   static constexpr int kProfAt = (kTraceAt + NMPC_HIP_NTRACE * kT64MaxGroup + 1) & ~1; //!< profiling builds: 40 tick counters of workgroup 0
 #ifdef NMPC_AMD_PROFILE_TILE64
   static constexpr int kFixedRaw = kProfAt + kW * 40;
@@ -1733,6 +1754,155 @@ struct TileSolver64
     }
     c.ok = c.ok && ok_now;
   }
+  // ---- batched BoxQP (kBatchQP): prepare / batch / gains from the parked result -------------------------------------------------
+  NMPC_D S * qpIn(int e) const
+  {
+    return lds + kQpAt + (wave - 1) * kQpPerWave + e * kQpIn;
+  }
+  NMPC_D S * qpOut(int e) const
+  {
+    return lds + kQpAt + (wave - 1) * kQpPerWave + (kPerWave - 1) * kQpIn + 2 * e;
+  }
+  /** Slot e of the wave, timestep i: the Q terms and the regularisation as backwardStep computes them, Quu_F and Qu through the
+      exchange scratch into the slot's QP input (the last slot's stay in the scratch: nobody writes it before the batch). */
+  NMPC_D void qpPrepare(const Vec4 & VV, const LaneMap & mp, const LaneAddr & la_sweep, const S * r, S lambda, int e) const
+  {
+    S * W = waveScratch(0);
+    LaneAddr la = la_sweep;
+    asm volatile("" : "+v"(la.ew_equ), "+v"(la.eqx_rq), "+v"(la.rx_tw), "+v"(la.tr_trn));
+    StepCtx c;
+    c.VV = VV;
+    c.ok = true;
+    Vec4 F0, F1, L0, L1, L2;
+    stepQTerms(c, mp, r, F0, F1, L0, L1, L2);
+    if(cfg.reg_type == 2)
+    {
+      stepRegType2(c, lambda, F0, F1, L0, L1, L2);
+    }
+    else if(cfg.reg_type == 1)
+    {
+      stepRegType1(c, lambda);
+    }
+    stepExchangeWrite(c, la);
+    fence();
+    if(e < kPerWave - 1)
+    {
+      S * in = qpIn(e);
+      if(lane < MM * MM)
+      {
+        in[lane] = W[wF + kColLd * (lane / MM) + lane % MM]; // H(a, c) at a + c MM, as stepExchangeRead fills c.fac
+      }
+      else if(lane < kQpIn)
+      {
+        in[lane] = W[wQQ + kColLd * N + (lane - MM * MM)]; // Qu
+      }
+    }
+    fence();
+  }
+  /** The QPs of this wave's slots of timestep i, lane e = slot e (BoxQP.h:141-347 through InstanceSolver::boxQPMasked: the code every
+      lane of the wave used to run for one slot at a time).  x goes to the slot's warm-start row (k_{i+1} of the next timestep's QP
+      and k_i of this timestep's gains), free set and return code to qpOut, and — while the slot's pass has not failed — to HBM. */
+  NMPC_D void qpBatch(const LaneMap & mp, int i, int parity, int dt, int chunk, int n_act, unsigned ok_mask) const
+  {
+    const int mw = wave - 1;
+    const int e = lane;
+    const int a_idx = mw + kOwnerWaves * e;
+    if(mw < kOwnerWaves && e < kPerWave && a_idx < n_act)
+    {
+      const int slot = actSlot(a_idx);
+      const int b = slotI(sB, slot);
+      const S * r = recAt(parity, dt, a_idx, chunk, n_act);
+      const S * W = waveScratch(0);
+      const S * in = qpIn((mw < kOwnerWaves && e < kPerWave - 1) ? e : 0);
+      S H[MM * MM], g[MM], lo[MM], up[MM], k0[MM];
+      S * knext = lds + kKnextAt + slot * 8;
+#pragma unroll
+      for(int cc = 0; cc < MM; cc++)
+      {
+#pragma unroll
+        for(int aa = 0; aa < MM; aa++)
+        {
+          const S parked = in[aa + cc * MM], last = W[wF + kColLd * cc + aa];
+          H[aa + cc * MM] = (e < kPerWave - 1) ? parked : last;
+        }
+      }
+#pragma unroll
+      for(int aa = 0; aa < MM; aa++)
+      {
+        const S parked = in[MM * MM + aa], last = W[wQQ + kColLd * N + aa];
+        g[aa] = (e < kPerWave - 1) ? parked : last;
+        const S ua = r[mp.oU[aa]];
+        k0[aa] = (i != T - 1) ? knext[aa] : 0.0; // warm start from k_{i+1}    :452-467
+        lo[aa] = inputLimitLo(buf, b, i, aa) - ua; // :470-472
+        up[aa] = inputLimitHi(buf, b, i, aa) - ua;
+      }
+      const Lane lane_code(problem, cfg, buf, b);
+      typename Lane::QPOutMasked qp;
+      lane_code.boxQPMasked(H, g, lo, up, k0, qp);
+      S * out = qpOut(e);
+      out[0] = static_cast<S>(qp.free);
+      out[1] = static_cast<S>(qp.retval);
+#pragma unroll
+      for(int aa = 0; aa < MM; aa++)
+      {
+        knext[aa] = qp.x[aa];
+      }
+      if(((ok_mask >> e) & 1u) != 0) // (backwardPass returns at the first failing timestep, :473-480: nothing below it is written)
+      {
+        const size_t tl = tileOf(b), ln = lnOf(b);
+        buf.qp_ret[(tl * T + i) * 64 + ln] = qp.retval;
+        buf.qp_free[(tl * T + i) * 64 + ln] = qp.free;
+      }
+    }
+    fence();
+  }
+  /** Phase 3a of a slot whose QP the batch has solved: the factorisation of the free block is rebuilt from Quu_F and the free set —
+      the statements of boxQPMasked's last refactorisation on the same values, hence the same factor — and lane (., j) solves its
+      column of K on the free rows (:482-496); column n takes k = x. */
+  NMPC_D void stepGainsFromQP(StepCtx & c, int slot, int e) const
+  {
+    const int j = colOf(lane & 15);
+    const S * out = qpOut(e);
+    typename Lane::QPOutMasked qp;
+    qp.free = static_cast<unsigned>(out[0]);
+    qp.retval = static_cast<int>(out[1]);
+    const S * knext = lds + kKnextAt + slot * 8;
+    const unsigned clamped = ~qp.free;
+#pragma unroll
+    for(int a = 0; a < MM; a++)
+    {
+      qp.x[a] = knext[a];
+      qp.inv_d[a] = 0;
+#pragma unroll
+      for(int cc = 0; cc < MM; cc++)
+      {
+        const bool both = (((clamped >> a) | (clamped >> cc)) & 1u) == 0;
+        qp.fac[a + cc * MM] = both ? c.fac[a + cc * MM] : ((a == cc) ? 1.0 : 0.0);
+      }
+    }
+    if(qp.free != 0 && qp.retval >= 0)
+    {
+      (void)Lane::template ldltInPlace<MM>(qp.fac, qp.inv_d, MM); // (succeeded in the batch: the same values)
+    }
+    if(j == N)
+    {
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        c.col[a] = qp.x[a];
+      }
+    }
+    else
+    {
+#pragma unroll
+      for(int a = 0; a < MM; a++)
+      {
+        c.col[a] = c.colQ[a];
+      }
+      Lane::maskedGainColumn(qp, c.col); // clamped rows of K stay zero    :482-496
+    }
+    c.ok = c.ok && !(qp.retval < 0); // :473-480
+  }
   /** Phase 3b: A = [K | k], QQ = [Qux | Qu] in natural layout; the cost-to-go (:522-527) up to the symmetrisation; rows of the new
       value function to the scratch.  Branch-free. */
   NMPC_D void stepValueUpdate(StepCtx & c, S * W, int m, const LaneAddr & la) const
@@ -2024,7 +2194,7 @@ struct TileSolver64
   /** One timestep of one instance.  VV = [Vxx | Vx] in natural layout (in / out), r = the instance's record of this timestep,
       ok = no factorisation of this sweep has failed yet (in / out).  Everything but the lane id is wave-uniform. */
   NMPC_D void backwardStep(Vec4 & VV, bool & ok, const LaneMap & mp, const LaneAddr & la_sweep, const S * r, int slot, int b, int i,
-                           S lambda) const
+                           S lambda, int qp_e = -1) const
   {
     S * W = waveScratch(0);
     LaneAddr la = la_sweep;
@@ -2053,7 +2223,11 @@ struct TileSolver64
       fence();
       stepExchangeRead(c, W, la);
       fence();
-      if constexpr(kConstrained)
+      if constexpr(kBatchQP)
+      {
+        stepGainsFromQP(c, slot, qp_e); // (the QP itself: qpBatch, for all of the wave's slots of this timestep at once)
+      }
+      else if constexpr(kConstrained)
       {
         stepGainsBoxQP(c, mp, r, W, slot, b, i);
       }
@@ -2080,20 +2254,31 @@ struct TileSolver64
       group share nothing but the record buffers. */
   NMPC_D void backwardSweepMatrix() const
   {
-    static_assert(kT64MaxPerWave == 5, "the rotations below are written for five slots per wave");
+    static_assert(kPerWave <= 16, "ok_mask and the QP batch's lane = slot mapping");
     const LaneMap mp = makeLaneMap();
     const LaneAddr la = makeLaneAddr();
     const int q = lane >> 4, j = colOf(lane & 15);
     const int mw = wave - 1;
     const int n_act = uniform(meta(mNAct)), chunk = uniform(meta(mChunk));
-    Vec4 V0, V1, V2, V3, V4;
+    Vec4 V[kPerWave]; // (indexed by compile-time constants only: registers)
+    Vec4 & V0 = V[0];
+    auto rotate = [&]()
+    {
+      const Vec4 t = V[0];
+#pragma unroll
+      for(int k = 0; k + 1 < kPerWave; k++)
+      {
+        V[k] = V[k + 1];
+      }
+      V[kPerWave - 1] = t;
+    };
     unsigned ok_mask = ~0u;
     barrier(); // the terminal records are complete
     auto loadTerminal = [&](int e) -> Vec4
     {
-      const int a = mw + kT64MatrixWaves * e;
+      const int a = mw + kOwnerWaves * e;
       Vec4 v = {0, 0, 0, 0};
-      if(a < n_act)
+      if(mw < kOwnerWaves && a < n_act)
       {
         const int slot = uniform(actSlot(a));
         const S * tr = term(slot);
@@ -2113,11 +2298,11 @@ struct TileSolver64
       }
       return v;
     };
-    V0 = loadTerminal(0);
-    V1 = loadTerminal(1);
-    V2 = loadTerminal(2);
-    V3 = loadTerminal(3);
-    V4 = loadTerminal(4);
+#pragma unroll
+    for(int e = 0; e < kPerWave; e++)
+    {
+      V[e] = loadTerminal(e);
+    }
     barrier(); // the terminal records have been read
     barrier(); // the records of the first chunk are complete
     int parity = 0;
@@ -2127,25 +2312,35 @@ struct TileSolver64
       const int lo = (hi - chunk + 1 > 0) ? hi - chunk + 1 : 0;
       for(int i = hi; i >= lo; i--)
       {
-#pragma nounroll
-        for(int e = 0; e < kT64MaxPerWave; e++)
+        if constexpr(kBatchQP)
         {
-          const int a = mw + kT64MatrixWaves * e;
-          if(a < n_act)
+#pragma nounroll
+          for(int e = 0; e < kPerWave; e++)
+          {
+            const int a = mw + kOwnerWaves * e;
+            if(mw < kOwnerWaves && a < n_act)
+            {
+              const int slot = uniform(actSlot(a));
+              qpPrepare(V0, mp, la, recAt(parity, hi - i, a, chunk, n_act), uniformD(slotF(sLambda, slot)), e);
+            }
+            rotate();
+          }
+          qpBatch(mp, i, parity, hi - i, chunk, n_act, ok_mask);
+        }
+#pragma nounroll
+        for(int e = 0; e < kPerWave; e++)
+        {
+          const int a = mw + kOwnerWaves * e;
+          if(mw < kOwnerWaves && a < n_act)
           {
             const int slot = uniform(actSlot(a));
             bool ok = ((ok_mask >> e) & 1u) != 0;
             backwardStep(V0, ok, mp, la, recAt(parity, hi - i, a, chunk, n_act), slot, uniform(slotI(sB, slot)), i,
-                         uniformD(slotF(sLambda, slot)));
+                         uniformD(slotF(sLambda, slot)), e);
             ok_mask = ok ? ok_mask : (ok_mask & ~(1u << e));
             profAdd(4, 1, 1);
           }
-          const Vec4 t = V0;
-          V0 = V1;
-          V1 = V2;
-          V2 = V3;
-          V3 = V4;
-          V4 = t;
+          rotate();
         }
       }
       const unsigned long long pb = profNow();
@@ -2159,10 +2354,10 @@ struct TileSolver64
     if(lane == kStarLane)
     {
 #pragma unroll
-      for(int e = 0; e < kT64MaxPerWave; e++)
+      for(int e = 0; e < kPerWave; e++)
       {
-        const int a = mw + kT64MatrixWaves * e;
-        if(a < n_act)
+        const int a = mw + kOwnerWaves * e;
+        if(mw < kOwnerWaves && a < n_act)
         {
           slotI(sOk, actSlot(a)) = static_cast<int>((ok_mask >> e) & 1u);
         }

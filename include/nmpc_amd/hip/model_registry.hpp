@@ -74,6 +74,8 @@ struct ModelOpsFor
   static constexpr int kTile64MinBatch = 64;
   //! box-constrained solves: round 3's threshold (the QP dominates their timestep; small batches have not been re-measured)
   static constexpr int kTile64MinBatchBoxQP = 1025;
+  //! ... and for m > 4 (the QP grows with m^3; measured at 8192 instances only: profiles/r05_constrained_tile64_ab.txt)
+  static constexpr int kTile64MinBatchBoxQPWide = 4096;
   static bool useTile64(bool constrained, int batch)
   {
     const LaunchKnobs knobs = launchKnobs();
@@ -101,7 +103,9 @@ struct ModelOpsFor
     // iterations): quadrotor (m = 4) tile 7.2 ms against 11.1 ms on the wave-per-instance kernel, manipulator (m = 7) 23.7
     // against 17.1 — the QP grows with m^3 and the wave-per-instance kernel hides it behind more waves per SIMD.  So the tile
     // kernel takes the constrained solves up to m = 4 (and all of 5 <= n <= 8, where no other matrix-core kernel exists).
-    return !(constrained && kWpiBoxQP && Problem::kInputDimMax > 4);
+    // Round 5: the QPs of a matrix wave's five slots are solved together, lane = slot (TileSolver64::qpBatch) — manipulator box 24.3 ->
+    // 12.2 ms (wave-per-instance kernel 15.1), quadrotor box 7.2 -> 4.8 (11.1): m > 4 goes to the tile kernel on full chips too.
+    return !(constrained && kWpiBoxQP && Problem::kInputDimMax > 4 && batch < kTile64MinBatchBoxQPWide);
   }
   /** Where k_list_ / K_list_ are after a solve: the tile kernel leaves instance-major records in the workspace. */
   static int gainLayoutOf(int batch, int constrained)

@@ -5,14 +5,15 @@ import numpy as np
 import nmpc_amd
 from nmpc_amd import workloads
 
-for model, T in (("quadrotor", 50), ("manipulator", 30)):
+for model, T in (("quadrotor", 50), ("manipulator", 30), ("planar_vtol", 60)):
     res = {}
     for kernel in (None, "wpi", "tile64"):
         os.environ.pop("NMPC_HIP_DDP_KERNEL", None)
         if kernel:
             os.environ["NMPC_HIP_DDP_KERNEL"] = kernel
         wl = (workloads.quadrotor_batch(B=8192, T=T, seed=31, constrained=True) if model == "quadrotor" else
-              workloads.manipulator_batch(B=8192, T=T, seed=32, constrained=True))
+              workloads.manipulator_batch(B=8192, T=T, seed=32, constrained=True) if model == "manipulator" else
+              workloads.planar_vtol_batch(B=8192, T=T, seed=33, constrained=True))
         s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B)
         c = s.config(); c.print_level = 0; c.horizon_steps = wl.T; c.max_iter = 4; c.with_input_constraint = True
         s.setInputLimits(*wl.limits)

@@ -734,7 +734,12 @@ def test_matrix_kernel_dispatch(monkeypatch):
         s = nmpc_amd.DDPSolverBatch(prob, 8192)
         s.config().with_input_constraint = True
         s.setInputLimits(np.full(prob.dims()[1], -1.0), np.full(prob.dims()[1], 1.0))
-        # box-constrained: the tile kernel up to m = 4 (quadrotor: 7.2 against 11.1 ms), the wave-per-instance kernel beyond
+        # box-constrained on a full chip: the tile kernel, which solves the QPs of a matrix wave's slots together, lane = slot (round 5:
+        # quadrotor 4.8 against 11.1 ms, manipulator 12.2 against 15.1); m > 4 below 4096 instances: the wave-per-instance kernel
+        assert s.kernelName() == "ddp_solve_tile64_kernel"
+        s = nmpc_amd.DDPSolverBatch(prob, 2048)
+        s.config().with_input_constraint = True
+        s.setInputLimits(np.full(prob.dims()[1], -1.0), np.full(prob.dims()[1], 1.0))
         assert s.kernelName() == ("ddp_solve_tile64_kernel" if prob.dims()[1] <= 4 else "ddp_solve_wpi_kernel")
         s = nmpc_amd.DDPSolverBatch(prob, 512)
         s.config().with_input_constraint = True

@@ -138,7 +138,12 @@ int main(int argc, char ** argv)
       if(k >= n_handles) // the handle's previous batch: wait for it and compare before it is overwritten
       {
         pool.wait(h);
-        bad += sameResults(pool.solver(h), *refs[k - n_handles], B) ? 0 : 1;
+        const bool same = sameResults(pool.solver(h), *refs[k - n_handles], B);
+        if(!same)
+        {
+          std::printf("  batch %d (handle %d) differs from the lone solver's\n", k - n_handles, h);
+        }
+        bad += same ? 0 : 1;
       }
       pool.submit(batches[k].t, batches[k].x, batches[k].u);
       where[k] = h;
@@ -147,7 +152,12 @@ int main(int argc, char ** argv)
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for(int k = std::max(0, n_batches - n_handles); k < n_batches; k++)
     {
-      bad += sameResults(pool.solver(where[k]), *refs[k], B) ? 0 : 1;
+      const bool same = sameResults(pool.solver(where[k]), *refs[k], B);
+      if(!same)
+      {
+        std::printf("  batch %d (handle %d) differs from the lone solver's\n", k, where[k]);
+      }
+      bad += same ? 0 : 1;
     }
     std::printf("pool of %d handles, ragged_schedule %2d: %d batches in %.1f ms (launches per solve: %d), batches differing from the "
                 "lone solver: %d\n", n_handles, ragged, n_batches, ms, pool.solver(0).lastSolveLaunches(), bad);

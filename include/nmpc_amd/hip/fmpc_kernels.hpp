@@ -2237,13 +2237,12 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
     const double Hr = bcast0(S), Qxl = bcast1(S);
     // Eigen's LDLT solve of the 1 x 1 system (pseudo-inverse of D), then (2.35e)
     const bool pivot = fabs(G) > DBL_MIN;
-    // (one reciprocal — recipFast: v_rcp_f64 + two Newton steps, the IEEE quotient 1 / G on every measured argument — and three
-    // products instead of the quad kernel's three IEEE divides: ~28 of the step's ~160 instructions, all on its dependency chain;
-    // the quotients differ from k_rhs / G by at most one rounding)
-    const double rG = nmpc_amd::recipFast(pivot ? G : 1.0);
-    const double k = -1 * (pivot ? k_rhs * rG : 0.0);
-    const double Kc = -1 * (pivot ? HA * rG : 0.0);
-    const double Kr = -1 * (pivot ? Hr * rG : 0.0);
+    // (Measured and not kept: one recipFast and three products instead of the three IEEE divides — 0 - 1 % on the launch, and the
+    // ill-conditioned golden case fmpc_cartpole_loop_tick2 then deviates 4e-8 instead of 1e-8; with the divides this kernel returns
+    // the quad kernel's bits.)
+    const double k = -1 * (pivot ? k_rhs / G : 0.0);
+    const double Kc = -1 * (pivot ? HA / G : 0.0);
+    const double Kr = -1 * (pivot ? Hr / G : 0.0);
     const double s_new = (-1 * Qxl) - Hr * k; // (2.35a)
     const double Pn = F - (Kr * G) * Kc;
     const double PnT = FT - (Kc * G) * Kr;

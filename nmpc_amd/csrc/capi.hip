@@ -974,6 +974,9 @@ extern "C"
       g_last_error = keep;
       return rc;
     }
+    // devAlloc clears every buffer with hipMemset, which is ordered on the NULL stream; the handle's stream is non-blocking, and a
+    // caller in compiled code launches its first solve microseconds from here: the clears must have landed (once per handle)
+    NMPC_HIP_TRY(hipDeviceSynchronize());
     *out = s;
     return NMPC_HIP_OK;
   }

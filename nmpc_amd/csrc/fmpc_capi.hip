@@ -662,6 +662,12 @@ extern "C"
     h->problems_bytes = m->param_bytes;
     b.problems = h->d_problems;
     b.own_problems = 0;
+    // (the allocations above were cleared with hipMemset, which is ordered on the NULL stream, and the handle's stream is non-blocking:
+    // the clears must have landed before anything on it runs)
+    if(hipDeviceSynchronize() != hipSuccess)
+    {
+      return cleanup(fail(NMPC_HIP_ERR_HIP, "hipDeviceSynchronize failed"));
+    }
     hipLaunchKernelGGL(fmpc_fill_kernel, dim3(blocks(B, 256)), dim3(256), 0, h->stream, b.barrier_eps, B, 1e-4);
     if(hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
     {

@@ -459,3 +459,22 @@ def test_max_iter_zero_returns_uninitialized():
     assert (st == 0).all() and np.array_equal(st, ref.status) and (s.iters() == 0).all() and (ref.iters == 0).all()
     for a, c in zip(s.variable().arrays(), var.arrays()):
         assert np.array_equal(a, c)
+
+
+def test_fused_riccati_kernel_returns_the_quad_kernels_bits(monkeypatch):
+    """fmpc_riccati_fused_kernel computes the coefficient records in its producer waves (fmpc::coefficients, the body of the coefficient
+    kernel with another sink) and runs the quad kernel's recursion on them: the same statements on the same values — every output of a
+    solve is bit-identical to the unfused path's (coefficient kernel + records through HBM + fmpc_riccati_quad_kernel)."""
+    res = {}
+    for riccati in ("quad", "fused"):
+        monkeypatch.setenv("NMPC_HIP_FMPC_RICCATI", riccati)
+        prob = F.FmpcProblemCartPole()
+        var, x0, t0 = make_case("fmpc_cartpole", 200, 61, seed=7)
+        s = F.FmpcSolverBatch(prob, 200, 61)
+        s.config().max_iter = 4
+        s.solve(t0, x0, var)
+        assert ("fmpc_riccati_%s_kernel" % riccati) in s.kernelNames()
+        cl = s.coeffList()
+        res[riccati] = [a.copy() for a in s.variable().arrays()] + [s.traceDataList().copy(), s.iters().copy(), cl["K"].copy(), cl["P"].copy()]
+    for a, b in zip(res["quad"], res["fused"]):
+        assert np.array_equal(a, b, equal_nan=True)

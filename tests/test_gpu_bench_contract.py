@@ -83,6 +83,8 @@ def test_default_line_has_the_contract_keys():
         assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.01 < r["frac"] < 2.0 and r["kernel_ms_avg"] > 0
         assert leg["traffic"] == r["traffic"]
     assert sec["seconds_total"] < 60.0
+    # c3 is 64 workgroups on 256 CUs — a latency chain: eight batches in flight (DDPSolverPool) is how a caller fills the chip
+    assert sec["c3"]["pooled"]["value"] > 1.5 * sec["c3"]["value"] and sec["c3"]["pooled"]["handles"] == 8
 
 
 def test_c4_runs_in_fp32_on_a_tile_kernel():

@@ -1079,12 +1079,22 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
   /** Every wave of the workgroup, after a fan-out pass in which instances accepted the step size of a group g > 0 (the
       master left g in the instance's cost mailbox, 0 otherwise): the trajectory of slot g - 1 of the scratch becomes the
       candidate (rows are shared out over the workgroup's threads: thread = (instance, part)).  The pass boundaries on
-      either side are full barriers (post()): the helper's stores have landed, these land before the next pass reads. */
+      either side are full barriers (post()): the helper's stores have landed, these land before the next pass reads; barrier A
+      inside keeps the mailbox words of this pass from being rewritten before every wave has read them. */
   NMPC_D void adoptFanOut(int sel_lane) const
   {
     const unsigned inst = waveLane() % kGroupLanes;
     const unsigned part = threadIdx.x / kGroupLanes, parts = blockDim.x / kGroupLanes;
     const int g = static_cast<int>(mailCostAt(inst));
+#ifndef NMPC_AMD_AB_REOPEN_FAN_ADOPT_RACE // (A/B builds: the race below open again — scripts/fuzz_diff.py shows it within one run)
+    // Barrier A: every wave has read this pass's command word (followerLoop) and its g.  The pass has no other barrier, and
+    // without this one the master — done with its share of the copy — posts the NEXT pass's command into the same LDS words while
+    // a wave that was slow out of barrier P has yet to read this one's: that wave skips the copy and runs the next pass twice, one
+    // barrier out of step with the workgroup from there on (costs read from the mailbox before they are written).  The copy is
+    // ~2 k cycles long, so it takes a wave that late: never seen in 2000-repetition soaks of the product build, found by the
+    // wave-timing fuzz build (fuzz_sched.hpp) within one solve — profiles/r05_fuzz_fan_adopt_race.txt.
+    wgBarrier();
+#endif
     if(g > 0)
     {
       const FanDest src = fanSlot(static_cast<unsigned>(g));

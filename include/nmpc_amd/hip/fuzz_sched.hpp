@@ -35,15 +35,21 @@ __device__ __forceinline__ void fuzzSched(unsigned site)
   h = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(h)));
   // three wave in four: 0 .. 15 short naps (<= 1 k cycles: shuffles who arrives first); one in four: up to 255 more (~16 k cycles:
   // longer than any phase between two barriers of these kernels, so a wave really is a whole phase behind its neighbours)
-  unsigned n = h & 15u;
-  if(((h >> 4) & 3u) == 0u)
-  {
-    n += (h >> 8) & 255u;
-  }
-  for(unsigned i = 0; i < n; i++)
-  {
-    __builtin_amdgcn_s_sleep(1);
-  }
+  unsigned n = (h & 15u) + (((h >> 8) & 255u) & (0u - static_cast<unsigned>(((h >> 4) & 3u) == 0u)));
+  // The nap loop is ONE inline-assembly statement: a loop written in C++ would split every basic block a barrier sits in, and with
+  // it the compiler's floating-point contraction (an a * b in front of the barrier and the + c behind it fuse in the product build
+  // and would not here) — the fuzz build has to differ from the product build in timing only, not in a rounding.
+  asm volatile("s_cmp_eq_u32 %0, 0\n\t"
+               "s_cbranch_scc1 2f\n"
+               "1:\n\t"
+               "s_sleep 1\n\t"
+               "s_sub_u32 %0, %0, 1\n\t"
+               "s_cmp_lg_u32 %0, 0\n\t"
+               "s_cbranch_scc1 1b\n"
+               "2:"
+               : "+s"(n)
+               :
+               : "scc");
 }
 #else
 __device__ __forceinline__ void fuzzSched(unsigned) {}

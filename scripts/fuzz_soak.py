@@ -32,6 +32,19 @@ CASES = [
     ("quad c2", lambda: W.cartpole_batch(B=4096 if big else 1024, T=100, seed=1234), dict(max_iter=8), None),
     ("quad c2 forced", lambda: W.cartpole_batch(B=4096 if big else 512, T=100, seed=3), dict(max_iter=12, **FORCED), None),
     ("quad c2 box", lambda: W.cartpole_batch(B=4096 if big else 512, T=100, seed=1234, constrained=True), dict(max_iter=6, with_input_constraint=True), None),
+    # the step-size-parallel line search (automatic only for long solves: the cases above never run it) with wide passes, accepted
+    # rollouts adopted from the fan-out scratch, step sizes taken from the cost-only waves; then without the scratch; then the
+    # sequential search of the same kernel family — and the resumable launches of the ragged schedule
+    ("quad c2 fan-out forced", lambda: W.cartpole_batch(B=4096 if big else 512, T=100, seed=3), dict(max_iter=50, line_search_fan_out=1, ragged_schedule=-1, **FORCED), None),
+    ("quad c2 fan-out 25 step sizes", lambda: W.cartpole_batch(B=4096 if big else 512, T=100, seed=3),
+     dict(max_iter=40, line_search_fan_out=1, ragged_schedule=-1, alpha_list=np.power(10.0, np.linspace(0, -3, 25)), **FORCED), None),
+    ("quad c2 fan-out no scratch", lambda: W.cartpole_batch(B=512, T=100, seed=3), dict(max_iter=50, line_search_fan_out=1, ragged_schedule=-1, **FORCED), "env:NMPC_HIP_DDP_FAN_SCRATCH=0"),
+    ("quad c2 sequential forced", lambda: W.cartpole_batch(B=512, T=100, seed=3), dict(max_iter=50, line_search_fan_out=2, ragged_schedule=-1, **FORCED), None),
+    ("quad c2 to convergence", lambda: W.cartpole_batch(B=4096 if big else 1000, T=100, seed=1500), dict(max_iter=500, ragged_schedule=-1), None),
+    ("quad c2 ragged schedule", lambda: W.cartpole_batch(B=4096 if big else 1000, T=100, seed=1500), dict(max_iter=500, ragged_schedule=1), None),
+    ("quad c2 box ragged schedule", lambda: W.cartpole_batch(B=520, T=100, seed=610, constrained=True), dict(max_iter=90, with_input_constraint=True, ragged_schedule=1), None),
+    ("quad bipedal ragged schedule", lambda: W.bipedal_batch(B=260, T=300, seed=5), dict(max_iter=60, ragged_schedule=1), None),
+    ("two-wave ragged schedule", lambda: W.cartpole_batch(B=1500, T=100, seed=77), dict(max_iter=100, ragged_schedule=1), "2w"),
     ("quad bipedal", lambda: W.bipedal_batch(B=1024 if big else 256, T=300, seed=7), dict(max_iter=4), None),
     ("two-wave", lambda: W.cartpole_batch(B=8192 if big else 1024, T=100, seed=99), dict(max_iter=6), "2w"),
     ("two-wave box", lambda: W.cartpole_batch(B=8192 if big else 512, T=100, seed=98, constrained=True), dict(max_iter=5, with_input_constraint=True), "2w"),
@@ -77,7 +90,11 @@ for label, mk, cfg, kernel in CASES:
     if args.only and args.only not in label:
         continue
     os.environ.pop("NMPC_HIP_DDP_KERNEL", None)
-    if kernel:
+    os.environ.pop("NMPC_HIP_DDP_FAN_SCRATCH", None)
+    if kernel and kernel.startswith("env:"):  # (the knobs are read when a handle is created)
+        k, v = kernel[4:].split("=")
+        os.environ[k] = v
+    elif kernel:
         os.environ["NMPC_HIP_DDP_KERNEL"] = kernel
     wl = mk()
     s = make(wl, cfg)
@@ -89,6 +106,7 @@ for label, mk, cfg, kernel in CASES:
     out[label] = {"kernel": s.kernelName(), "digests": digests}
     print(f"{label:28s} {s.kernelName():28s} {len(set(digests))} distinct digest(s) in {args.reps} repetitions", file=sys.stderr, flush=True)
 os.environ.pop("NMPC_HIP_DDP_KERNEL", None)
+os.environ.pop("NMPC_HIP_DDP_FAN_SCRATCH", None)
 
 if not args.only or "fmpc" in args.only:
     from nmpc_amd import fmpc as F

@@ -76,12 +76,22 @@ struct ModelOpsFor
   static constexpr int kTile64MinBatchBoxQP = 1025;
   //! ... and for m > 4 (the QP grows with m^3; measured at 8192 instances only: profiles/r05_constrained_tile64_ab.txt)
   static constexpr int kTile64MinBatchBoxQPWide = 4096;
+  //! Small models: the lane kernels keep a timestep's blocks in registers (n (n + m) <= 48 — planar VTOL: 70 - 80 scratch
+  //! instructions; the quadrotor's 192 make 1500) and hold 64 instances per wavefront, several wavefronts per SIMD, so their
+  //! time barely grows with the batch, while the tile kernel's (<= 35 instances per CU and round) grows linearly.  Measured
+  //! (scripts/lane_vs_tile_ab.py, profiles/r05_lane_vs_tile_ab.txt; planar VTOL, T 60, 6 iterations; tile / lane ms):
+  //! unconstrained 0.94 / 0.98 at 1024, 1.42 / 1.00 at 2048, 2.87 / 1.04 at 8192, 11.0 / 1.62 at 32768; box 3.78 / 4.81 at
+  //! 4096, 6.04 / 4.74 at 8192, 23.2 / 5.75 at 32768.  Above these batches such shapes go back to the lane kernels.
+  static constexpr bool kLaneKeepsUp =
+      !Problem::kDynamicInput && Problem::kStateDim * (Problem::kStateDim + Problem::kInputDimMax) <= 48;
+  static constexpr int kTile64MaxBatchSmall = 1024;
+  static constexpr int kTile64MaxBatchSmallBoxQP = 6143;
   static bool useTile64(bool constrained, int batch)
   {
     const LaunchKnobs knobs = launchKnobs();
     // (without the per-instance workspace — the allocation failed at create — the gain records and the candidate scratch have
     // nowhere to live: the lane kernels, which need none, take the solve)
-    if(!kTile64Shape || knobs.kernelIs("1w") || knobs.kernelIs("wpi") || knobs.have_workspace == 0)
+    if(!kTile64Shape || knobs.kernelIs("1w") || knobs.kernelIs("wpi") || (knobs.kernelIs("2w") && kTwoWaveFits) || knobs.have_workspace == 0)
     {
       return false;
     }
@@ -93,6 +103,10 @@ struct ModelOpsFor
     if(knobs.kernelIs("tile64"))
     {
       return true;
+    }
+    if(kLaneKeepsUp && batch > (constrained ? kTile64MaxBatchSmallBoxQP : kTile64MaxBatchSmall))
+    {
+      return false;
     }
     if(kWpiShape && batch < (constrained ? kTile64MinBatchBoxQP : kTile64MinBatch))
     {

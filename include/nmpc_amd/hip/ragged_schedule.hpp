@@ -79,7 +79,7 @@ __global__ __launch_bounds__(1024) void ragged_compact_kernel(const S * __restri
   {
     carry = 0;
   }
-  __syncthreads();
+  syncThreadsFuzzed(41);
   for(int base = 0; base < n_prev; base += 1024)
   {
     const int p = base + tid;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(1024) void ragged_compact_kernel(const S * __restri
     {
       warp_sums[tid >> 6] = v;
     }
-    __syncthreads();
+    syncThreadsFuzzed(42);
     int before = carry;
     for(int w = 0; w < (tid >> 6); w++)
     {
@@ -113,12 +113,12 @@ __global__ __launch_bounds__(1024) void ragged_compact_kernel(const S * __restri
     {
       rank[p] = before + v - flag; // running positions in [0, p)
     }
-    __syncthreads();
+    syncThreadsFuzzed(43);
     if(tid == 1023)
     {
       carry = before + v;
     }
-    __syncthreads();
+    syncThreadsFuzzed(44);
   }
   const int n_run = carry;
   const int wg_prev = (n_prev + wg_size - 1) / wg_size, wg_dense = (n_run + wg_size - 1) / wg_size;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(1024) void ragged_compact_kernel(const S * __restri
   }
   const int n_next = n_run;
   __threadfence_block();
-  __syncthreads();
+  syncThreadsFuzzed(45);
   const int run_in_prefix = (n_next < n_prev) ? rank[n_next] : n_next; // running positions in [0, n_next)
   for(int p = tid; p < n_prev; p += 1024)
   {
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(1024) void ragged_compact_kernel(const S * __restri
   }
   const int n_sw = n_next - run_in_prefix;
   __threadfence_block();
-  __syncthreads();
+  syncThreadsFuzzed(46);
   for(int k = tid; k < n_sw; k += 1024)
   {
     const int p = pairs[2 * k], q = pairs[2 * k + 1];

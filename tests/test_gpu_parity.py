@@ -1056,6 +1056,40 @@ def test_planar_vtol_box_constrained_on_the_tile_kernel(monkeypatch):
     assert (s.qpFreeMask()[stable] != 3).any(), "the batch never hit the bounds"
 
 
+def test_small_models_leave_the_tile_kernel_at_large_batches(monkeypatch):
+    """ModelOpsFor::kLaneKeepsUp (n (n + m) <= 48: planar VTOL): up to 1024 instances (BoxQP: 6143) the tile kernel, above the lane
+    kernel, whose time does not grow with the batch (profiles/r05_lane_vs_tile_ab.txt) — same decisions, values to TOL, oracle
+    parity on either side of the switch; a handle that pins the tile kernel keeps it; the quadrotor (n (n + m) = 192) never switches."""
+    import nmpc_amd
+    from nmpc_amd import workloads
+    monkeypatch.delenv("NMPC_HIP_DDP_KERNEL", raising=False)
+    prob = nmpc_amd.make_problem("planar_vtol")
+    assert nmpc_amd.DDPSolverBatch(prob, 1024).kernelName() == "ddp_solve_tile64_kernel"
+    assert nmpc_amd.DDPSolverBatch(prob, 1025).kernelName() == "ddp_solve_tpi_kernel"
+    assert nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem("quadrotor"), 32768).kernelName() == "ddp_solve_tile64_kernel"
+    for B, con in ((1500, False), (6200, True)):
+        wl = workloads.planar_vtol_batch(B=B, T=60, seed=B, constrained=con)
+        cfg = dict(max_iter=10, with_input_constraint=con)
+        below = make_solver(workloads.planar_vtol_batch(B=1000, T=60, seed=B, constrained=con), **cfg)
+        assert below.kernelName() == "ddp_solve_tile64_kernel"
+        s = make_solver(wl, **cfg)
+        assert s.kernelName() == "ddp_solve_tpi_kernel"
+        s.solve(wl.t0, wl.x0, wl.u_init)
+        pinned = make_solver(wl, **cfg)
+        pinned.setKernel("tile64")
+        assert pinned.kernelName() == "ddp_solve_tile64_kernel"
+        pinned.solve(wl.t0, wl.x0, wl.u_init)
+        if con:
+            same = (s.status() == pinned.status()) & (s.iters() == pinned.iters())
+            assert same.mean() > 0.97  # BoxQP decisions at rounding-level ties may differ between families (INTEGRATION 2a)
+            assert scaled_err(s.X()[same], pinned.X()[same]) <= 1e-6
+        else:
+            assert np.array_equal(s.status(), pinned.status()) and np.array_equal(s.iters(), pinned.iters())
+            assert scaled_err(s.X(), pinned.X()) <= TOL and scaled_err(s.U(), pinned.U()) <= TOL
+            ref = oracle_batch(wl, **cfg)
+            check_against_oracle(wl, s, ref)
+
+
 @pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
 def test_per_instance_problem_objects(model):
     """nmpc_hip_ddp_set_model_params_batch: every instance solves its own problem object (different masses / lengths /

@@ -1080,9 +1080,13 @@ def test_small_models_leave_the_tile_kernel_at_large_batches(monkeypatch):
         assert pinned.kernelName() == "ddp_solve_tile64_kernel"
         pinned.solve(wl.t0, wl.x0, wl.u_init)
         if con:
-            same = (s.status() == pinned.status()) & (s.iters() == pinned.iters())
-            assert same.mean() > 0.97  # BoxQP decisions at rounding-level ties may differ between families
-            assert scaled_err(s.X()[same], pinned.X()[same]) <= 1e-6
+            # (a BoxQP decision at a rounding-level tie may differ between families and send an instance elsewhere — INTEGRATION 2a;
+            # the oracle-side treatment of those is test_planar_vtol_box_constrained_on_the_tile_kernel's: here, per instance)
+            err = np.abs(s.X() - pinned.X()).reshape(B, -1).max(axis=1) / np.maximum(1.0, np.abs(pinned.X()).reshape(B, -1).max(axis=1))
+            same = (s.status() == pinned.status()) & (s.iters() == pinned.iters()) & (err <= 1e-6)
+            assert same.mean() > 0.97, same.mean()
+            assert np.abs(s.cost()[same] - pinned.cost()[same]).max() <= 1e-6 * np.abs(pinned.cost()[same]).max()
+            assert (s.qpFreeMask() != 3).any(), "the batch never hit the bounds"
         else:
             assert np.array_equal(s.status(), pinned.status()) and np.array_equal(s.iters(), pinned.iters())
             assert scaled_err(s.X(), pinned.X()) <= TOL and scaled_err(s.U(), pinned.U()) <= TOL

@@ -44,7 +44,7 @@ def test_default_line_has_the_contract_keys():
     cfg = d["config"]
     assert cfg["m1_value"] > 0 and cfg["m2_value"] > 0
     # consecutive batches on eight streams under the ragged-convergence schedule: the tails overlap and converged instances free their slots
-    assert cfg["m2_overlapped_value"] > 2.5 * cfg["m2_value"] and cfg["m2_overlapped_value"] > 1.3 * cfg["m2_overlapped"]["whole_solve_launches_value"]
+    assert cfg["m2_overlapped_value"] > 2.5 * cfg["m2_value"] and cfg["m2_overlapped_value"] > 1.15 * cfg["m2_overlapped"]["whole_solve_launches_value"]
     assert cfg["m2_overlapped"]["launches_per_solve"] == 5 and cfg["m2_overlapped"]["handles"] == 8
     assert cfg["m1"]["status_counts"].get("1", 0) == 0 and cfg["m1"]["max_iterations"] <= 50
     assert cfg["m2"]["status_counts"].get("1", 0) >= 0.99 * 4096

@@ -86,20 +86,50 @@ struct T64Scalar<float>
   }
 };
 
-constexpr int kT64Waves = 8; //!< wavefronts per workgroup: two per SIMD, 256 registers each
-constexpr int kT64Threads = kT64Waves * 64;
-constexpr int kT64MatrixWaves = kT64Waves - 1;
-//! Instances per group at most (lanes 0 .. 34 of the model wave; five per matrix wave).  A full chip's round is 256 x 32 = 8192
-//! instances; the three extra slots take batches up to 8960 in ONE round — 8200 instances were two rounds of 17-slot groups,
-//! 1.30 x the time of 8192 (profiles/r04a_tile64_chunk_ab.txt) — where the LDS holds the records (manipulator: 2 x 35 x 205 doubles).
+//! Wavefronts per workgroup: 8 (two per SIMD, 256 registers each) — or 12 (three per SIMD, 168 registers) for the small float
+//! instantiations, whose step is a latency chain (VALU issue share 0.40, s_waitcnt / barrier 0.56 on c4: profiles/r05_pmc_summary_c4.txt)
+//! and whose code fits 168 registers: eleven matrix waves of at most three slots hide more of one another's latencies.  Measured
+//! (profiles/r05_tile64_waves_ab.txt, 8 / 12 / 16 waves): c4 quadrotor fp32 1.94 / 2.18 / 2.14 k it/s; quadrotor fp64 1.74 / 1.75 /
+//! 1.72 k (stays at 8); manipulator 1.43 / 0.94 / 0.38 k and centroidal 396 / 243 / 159 (their steps spill at 168 registers).
+//! -DNMPC_T64_WAVES=n forces one count for every instantiation (A/B builds).
+template<class Problem>
+struct T64Waves
+{
+#ifdef NMPC_T64_WAVES
+  static constexpr int value = NMPC_T64_WAVES;
+#else
+  static constexpr int value =
+      (sizeof(typename Problem::Scalar) == 4 && Problem::kStateDim * (Problem::kStateDim + Problem::kInputDimMax) <= 200) ? 12 : 8;
+#endif
+  static_assert(value == 8 || value == 12 || value == 16, "8, 12 or 16 wavefronts per workgroup");
+};
+//! Instances per group at most (lanes 0 .. 34 of the model wave; five per matrix wave of an eight-wave workgroup).  A full chip's
+//! round is 256 x 32 = 8192 instances; the three extra slots take batches up to 8960 in ONE round — 8200 instances were two rounds
+//! of 17-slot groups, 1.30 x the time of 8192 (profiles/r04a_tile64_chunk_ab.txt) — where the LDS holds the records (manipulator:
+//! 2 x 35 x 205 doubles).
 constexpr int kT64MaxGroup = 35;
-constexpr int kT64MaxPerWave = (kT64MaxGroup + kT64MatrixWaves - 1) / kT64MatrixWaves; //!< 5
 constexpr size_t kT64LdsBytes = 160 * 1024; //!< the whole LDS of a CU: one workgroup per CU
 
 template<class Problem, bool kConstrained = false, bool kOwnProblem = false>
 struct TileSolver64
 {
   using S = typename Problem::Scalar; //!< double: the reference's arithmetic; float: BASELINE.json's config 4 (round 4)
+  static constexpr int kT64Waves = T64Waves<Problem>::value; //!< wave 0: model code; wave w runs on SIMD w % 4
+  static constexpr int kT64Threads = kT64Waves * 64;
+  static constexpr int kT64MatrixWaves = kT64Waves - 1;
+  //! matrix waves that share SIMD 0 with the model wave (4, 8, 12), and the others ("spec" waves: numbered 0 .. kSpecWaves - 1 in
+  //! wave order) — the line search's roles are dealt by these numbers (specIndex, ringOrder)
+  static constexpr int kSharedWaves = (kT64Waves - 1) / 4;
+  static constexpr int kSpecWaves = kT64MatrixWaves - kSharedWaves;
+  NMPC_D static int specIndex(int w)
+  {
+    return (w >= 1 && (w & 3) != 0) ? (w - 1) - (w >> 2) : -1;
+  }
+  //! order in which the matrix waves take rows of the ring prefetch: the spec waves, then the waves on the model wave's SIMD
+  NMPC_D static int ringOrder(int w)
+  {
+    return ((w & 3) == 0) ? kSpecWaves + (w >> 2) - 1 : specIndex(w);
+  }
   using Vec4 = typename T64Scalar<S>::Vec4;
   static constexpr bool kF32 = std::is_same<S, float>::value;
   static_assert(std::is_same<S, double>::value || kF32, "the tile kernel computes in S or in float");
@@ -2724,7 +2754,7 @@ struct TileSolver64
           // (three waves cover the group), or share it among themselves (six waves) and the group's previous search made
           // a quarter of its slots go beyond the first step size: the pass then takes as long as two, and saves a third one
           const int waves_needed = (G + laterPerWave() - 1) / laterPerWave();
-          meta(mWide) = (cfg.n_alpha > 1 && wide_cap != 0 && (waves_needed <= 3 || (waves_needed <= 6 && meta(mRejected) != 0))) ? 1 : 0;
+          meta(mWide) = (cfg.n_alpha > 1 && wide_cap != 0 && (waves_needed <= 3 || (waves_needed <= kSpecWaves && meta(mRejected) != 0))) ? 1 : 0;
         }
       }
       barrier(); // B4
@@ -2761,8 +2791,8 @@ struct TileSolver64
         const int later_per_wave = laterPerWave();
         const int covered = later_per_wave * kT64MatrixWaves;
         const bool wide = !first_trip && uniform(meta(mWide)) != 0;
-        const int spec_index = (wave >= 1 && wave <= 3) ? wave - 1 : ((wave >= 5) ? wave - 2 : -1);
-        const int waves_rolling = (G + later_per_wave - 1) / later_per_wave; // (a wide pass 1: <= 6)
+        const int spec_index = specIndex(wave); // (eight waves: 1 2 3 5 6 7 -> 0 .. 5; wave 4 shares the model wave's SIMD: -1)
+        const int waves_rolling = (G + later_per_wave - 1) / later_per_wave; // (a wide pass 1: <= kSpecWaves)
         // the later step sizes' trajectories go to the workspace, and the one that is taken is copied from there (no pass 3)
         const bool adopt = adopt_cap != 0 && cfg.n_alpha - 1 <= kScratchAlphas;
         // A narrow pass 1 uses the model wave's lanes 0 .. G - 1; with G <= 32 its lanes 32 .. 32 + G - 1 roll out the SECOND step size
@@ -2849,13 +2879,13 @@ struct TileSolver64
           {
             // the rolling wave's SIMD is the rolling wave's: wave 4, which shares it, stays out of the prefetch (its rows were a
             // tenth of the model wave's issue slots)
-            const int order = (wave == 4) ? 6 : spec_index; // 1 2 3 5 6 7 | 4
+            const int order = ringOrder(wave); // 1 2 3 5 6 7 | 4
             p_lane = order * 64 + lane; // (>= p_count for wave 4: no rows)
-            p_count = (kT64MatrixWaves - 1) * 64;
+            p_count = kSpecWaves * 64;
           }
           if(pass == 1 && wide && !model_wave)
           {
-            const int order = (wave == 4) ? 6 : spec_index; // 1 2 3 5 6 7 4
+            const int order = ringOrder(wave); // 1 2 3 5 6 7 4
             p_lane = (order - waves_rolling) * 64 + lane; // (the waves that roll out do not prefetch: compute is set)
             p_count = (kT64MatrixWaves - waves_rolling) * 64;
           }
@@ -3160,7 +3190,7 @@ struct TileSolver64
 
 /** The fp64 tile kernel: persistent workgroups of eight wavefronts, grid = number of CUs (or fewer for small batches). */
 template<class Problem, bool kConstrained, bool kOwnProblem>
-__global__ __launch_bounds__(kT64Threads) void ddp_solve_tile64_kernel(const Problem problem,
+__global__ __launch_bounds__(T64Waves<Problem>::value * 64) void ddp_solve_tile64_kernel(const Problem problem,
                                                                         const nmpc_hip_ddp_config cfg,
                                                                         const DeviceBuffersT<typename Problem::Scalar> buf,
                                                                         const int group_cap)
@@ -3211,7 +3241,7 @@ inline hipError_t launchTile64(const Problem & problem, const nmpc_hip_ddp_confi
     grid = groups < grid ? (groups < 1 ? 1 : groups) : grid;
   }
   grid = buf.B < grid ? buf.B : grid;
-  hipLaunchKernelGGL((ddp_solve_tile64_kernel<Problem, kConstrained, kOwnProblem>), dim3(grid), dim3(kT64Threads), 0, stream, problem,
+  hipLaunchKernelGGL((ddp_solve_tile64_kernel<Problem, kConstrained, kOwnProblem>), dim3(grid), dim3(T64Waves<Problem>::value * 64), 0, stream, problem,
                      cfg, buf, static_cast<int>(static_cast<unsigned>(cap) | (static_cast<unsigned>(chunk_cap) << 16) | (no_wide << 31) | (no_adopt << 30) | (no_pair << 29)));
   // (the kernel's 160 KB of LDS are a static array)
   return hipGetLastError();

@@ -92,7 +92,12 @@ WORKLOADS = {
 
 def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks of the job, one per GPU.  Under torch.distributed.run (WORLD_SIZE set) it must equal the world size; a plain "
+                         "`python bench.py --gpus N` with N > 1 launches the N ranks itself (torch.distributed.run, 127.0.0.1 rendezvous)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="allow more ranks than visible devices (rank r on device r %% n_devices, the final gather over gloo because RCCL "
+                         "wants one device per rank): the one-GPU test box.  Without it a job with fewer devices than ranks is refused")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["fmpc"], default="c2",
@@ -162,7 +167,7 @@ def host_cores():
     return n, quota
 
 
-def cpu_baseline(wl, mode: str, iters_per_solve: int, target_seconds: float, cost_update_thre=None):
+def cpu_baseline(wl, mode: str, iters_per_solve: int, target_seconds: float, cost_update_thre=None, extra_modes=()):
     """Time the CPU oracle (kind "port") on a bounded sample of the same workload: a thread sweep (1, 16, 64, all usable
     cores; threads pinned, instances handed out dynamically), the best rate is the baseline.  The first 256 instances' iteration
     counts / statuses are kept (`check_*`): main() compares the GPU's last solve with them (the checker's usual role)."""
@@ -194,7 +199,21 @@ def cpu_baseline(wl, mode: str, iters_per_solve: int, target_seconds: float, cos
     n_chk = min(256, wl.B)
     chk = oracle.solve_batch(wl.model, cfg, wl.x0[:n_chk], wl.u_init[:n_chk], t0=wl.t0[:n_chk], n_threads=usable, want_gains=False,
                              native=True, native_dir=build_dir)
+    # "same M1 / M2 modes" on the CPU — the whole batch once per mode (twice when the first pass took under a second) on the
+    # thread count that won the sweep, from the very inputs the GPU legs solve
+    modes = {}
+    for m_name, m_iters in extra_modes:
+        m_cfg = oracle.default_config(horizon_steps=wl.T, **mode_config(m_name, m_iters))
+        it_m, sec_m, reps = 0, 0.0, 0
+        while reps < 2 and (reps == 0 or sec_m < 1.0):
+            r = oracle.solve_batch(wl.model, m_cfg, wl.x0, wl.u_init, t0=wl.t0, n_threads=best, want_gains=False, native=True,
+                                   native_dir=build_dir)
+            it_m, sec_m, reps = it_m + r.total_iters, sec_m + r.seconds, reps + 1
+        modes[m_name] = {"cpu_value": it_m / sec_m / wl.B, "cpu_cores": best, "cpu_seconds": sec_m, "cpu_solves": reps * wl.B,
+                         "cpu_mean_iterations": it_m / float(reps * wl.B),
+                         "cpu_status_counts": {str(k): int(v) for k, v in zip(*np.unique(r.status, return_counts=True))}}
     return {
+        "modes": modes,
         "check_iters": [int(v) for v in chk.iters], "check_status": [int(v) for v in chk.status],
         "value": sweep[best]["instance_iterations_per_s"] / wl.B,  # batch-iterations / s
         "unit": "DDP iterations/s (batch=%d)" % wl.B,
@@ -356,8 +375,36 @@ def secondary_legs(device_index: int, seed: int, iters_per_solve: int, min_secon
     return out
 
 
+def launch_ranks(n: int) -> None:
+    """`python bench.py --gpus N` outside a launcher: become the launcher of N ranks of this very command line (one process per GPU,
+    rendezvous on 127.0.0.1, a free port) — the form the driver itself uses for N > 1.  Does not return."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def check_world(args, world: int, n_dev: int) -> None:
+    """--gpus is the number of ranks that must have joined, each on its own device (the flag used to be parsed and never read)."""
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a job of another size"
+                         % (args.gpus, world))
+    if n_dev < world and not args.share_devices:
+        raise SystemExit("bench.py: %d rank(s) but only %d visible device(s); one process per GPU is the contract "
+                         "(--share-devices runs them on the devices there are, gather over gloo: test boxes only)" % (world, n_dev))
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus)
     if args.workload == "fmpc":  # SURVEY.md 8 f-4: the FMPC path has its own script behind the same contract
         import bench_fmpc
         return bench_fmpc.main(args, host_cores)
@@ -371,7 +418,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     n_dev = torch.cuda.device_count()
-    device_index = local_rank % n_dev  # (tests run two ranks on a one-GPU box: both on device 0)
+    check_world(args, world, n_dev)
+    device_index = local_rank % n_dev  # (--share-devices: tests run two ranks on a one-GPU box, both on device 0)
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     if world > 1:
@@ -422,14 +470,18 @@ def main():
         args.cost_update_thre = 1e-3  # the threshold an fp32 cost can resolve is the c4 headline (see --cost-update-thre)
     configure(args.mode, args.iters_per_solve, args.cost_update_thre)
 
-    # The CPU leg runs FIRST (rank 0 of a one-GPU job only): the GPU legs then come last and back to back, where an outside
+    # The CPU leg runs FIRST (on rank 0's host cores): the GPU legs then come last and back to back, where an outside
     # observer sampling the device sees them (the driver's sampler saw an idle GPU behind a 16 s CPU tail).
     cpu_leg = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    want_extra_modes = not args.no_extra_modes and args.mode == "nominal" and args.workload == "c2"
+    if rank == 0 and not args.no_cpu_baseline:  # rank 0 at every world size (the other ranks wait at the barrier below)
         try:
-            cpu_leg = cpu_baseline(wl, args.mode, args.iters_per_solve, args.cpu_seconds, args.cost_update_thre)
+            cpu_leg = cpu_baseline(wl, args.mode, args.iters_per_solve, args.cpu_seconds, args.cost_update_thre,
+                                   extra_modes=(("m1", 50), ("m2", 500)) if want_extra_modes else ())
         except Exception as e:  # the GPU number stands on its own; say why the baseline is missing
             cpu_leg = {"value": None, "unit": "DDP iterations/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+    if world > 1 and not args.no_cpu_baseline:
+        dist.barrier()
 
     d_x0 = torch.from_numpy(wl.x0).to(dev)
     d_u0 = torch.from_numpy(wl.u_init).to(dev)
@@ -715,6 +767,8 @@ def main():
             config["m1"] = dict(extras["m1"], note="SURVEY 8(d) M1: termination tests disabled, max_iter = N = 50; batch-iterations/s")
             config["m2_value"] = extras["m2"]["value"]
             config["m2"] = dict(extras["m2"], note="SURVEY 8(d) M2: default Configuration, solve to convergence (max_iter 500)")
+            for m_name in ("m1", "m2"):  # the CPU oracle in the same mode on the same inputs (cpu_baseline()'s extra modes)
+                config[m_name].update((cpu_leg or {}).get("modes", {}).get(m_name, {}))
             config["m2_overlapped_value"] = extras["m2_overlapped"]["value"]
             config["m2_overlapped"] = dict(extras["m2_overlapped"], note="M2 with 32 consecutive batches on eight handles / streams "
                                            "(nmpc_amd.DDPSolverPool) under the ragged-convergence schedule: sustained rate with the convergence "
@@ -780,6 +834,7 @@ def main():
             # tests/test_gpu_fp32.py in one number — the oracle here is the -march=native build (contracted), one of the perturbed runs
             # the tests accept
             chk_it, chk_st = cpu_leg.pop("check_iters", None), cpu_leg.pop("check_status", None)
+            cpu_leg.pop("modes", None)  # (reported under config.m1 / config.m2)
             if chk_it is not None and headline_iters is not None:
                 k = len(chk_it)
                 agree = (headline_iters[:k] == np.asarray(chk_it)) & (headline_status[:k] == np.asarray(chk_st))

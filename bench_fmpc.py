@@ -218,6 +218,8 @@ def main(args, host_cores):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     n_dev = torch.cuda.device_count()
+    import bench
+    bench.check_world(args, world, n_dev)  # --gpus = ranks that joined, one device each (unless --share-devices)
     device_index = local_rank % n_dev
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)

@@ -10,6 +10,7 @@
 // `problem->param_` between solves behaves as with the reference's shared_ptr.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <fstream>
@@ -258,11 +259,17 @@ public:
 
   /** \brief solve() without waiting for the device: the inputs are validated and staged (the arguments may be reused when the call
       returns), the solve is queued on the handle's stream; wait() blocks until it is done and fetches the results, after which the
-      accessors (controlData(b), traceDataList(b), ...) hold them.  What DDPSolverPool overlaps consecutive batches with. */
+      accessors (controlData(b), traceDataList(b), ...) hold them.  What DDPSolverPool overlaps consecutive batches with.
+      A solve still in flight on this solver is waited for first and its results are fetched: the accessors hold THEM until the
+      new solve is waited for (queueing over an unfetched solve would overwrite its results on the device unread). */
   void solveAsync(const std::vector<double> & current_t,
                   const std::vector<StateDimVector> & current_x,
                   const std::vector<std::vector<InputDimVector>> & initial_u_list)
   {
+    if(in_flight_)
+    {
+      wait();
+    }
     std::vector<double> x0, u0;
     sampleInputLimits(current_t);
     packInputs(current_t, current_x, initial_u_list, x0, u0);
@@ -292,8 +299,6 @@ public:
     return ok;
   }
 
-  /** \brief Kernel launches the last solve was cut into (1: one whole-solve launch; more: the ragged-convergence schedule,
-      Configuration::ragged_schedule). */
   /** \brief Pin the kernel family of this solver: "auto" (the default), "1w", "2w", "quad", "wpi", "tile64", "tile32"
       (nmpc_hip_ddp_set_kernel).  Results are bit-reproducible across batch sizes and shardings within one family. */
   void setKernel(const std::string & name)
@@ -787,7 +792,7 @@ protected:
     A batch that is solved to convergence ends with a tail — a few instances that run for hundreds of iterations (every DDPSolver
     object of the reference runs its own loop to ITS end, DDPSolver.hpp:115-123).  With the next batches already queued on other
     streams their workgroups take the CUs the converged instances have vacated; with the ragged-convergence schedule
-    (Configuration::ragged_schedule, on by default for long solves) a finished instance vacates its slot within sixteen iterations
+    (Configuration::ragged_schedule; automatic = on for the queued solves of a pool) a finished instance vacates its slot within sixteen iterations
     instead of when the slowest of its workgroup is done.  The results of a batch are those of the handle it ran on — bit-identical
     to a lone DDPSolverBatch.
 
@@ -812,10 +817,22 @@ public:
     {
       throw std::invalid_argument("n_handles should be positive");
     }
+    // one hardware queue per handle, or the streams that share one do not overlap (nmpc_hip_ddp_request_hw_queues: effective
+    // only before the first HIP call of the process — construct the pool first, or export GPU_MAX_HW_QUEUES)
+    int took_effect = 0;
+    nmpc_hip_ddp_request_hw_queues(std::min(std::max(n_handles, 4), 64), &took_effect);
+    hw_queues_ok_ = took_effect != 0;
     for(int k = 0; k < n_handles; k++)
     {
       solvers_.emplace_back(new Solver(problem, batch_size, device));
     }
+  }
+
+  /** \brief Whether the HIP runtime has (or will have) one hardware queue per handle; false: it was already initialised with
+      fewer, and fewer batches overlap than the pool has handles. */
+  inline bool hwQueuesOk() const
+  {
+    return hw_queues_ok_;
   }
 
   /** \brief The Configuration of every handle (the first one's object; copied to the others at every submit()). */
@@ -873,6 +890,7 @@ public:
 protected:
   std::vector<std::unique_ptr<Solver>> solvers_;
   int next_ = 0;
+  bool hw_queues_ok_ = false;
 };
 
 } // namespace nmpc_amd

@@ -263,20 +263,24 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
 #endif
 #ifdef NMPC_AMD_PROFILE_2W
   NMPC_D void phaseStart() const {}
-  NMPC_D void phaseFlush(bool) const {}
+  NMPC_D void phaseFlush(bool, bool = true, bool = false) const {}
 #else
   NMPC_D void phaseStart() const
   {
     phase_start = __builtin_readcyclecounter();
   }
-  NMPC_D void phaseFlush(bool valid) const
+  /** took_part / resumed: under resumable launches (the ragged schedule) the ticks of ONE solve are the sum over its launches — the
+      first launch writes, a later one adds, and only for the instances it actually iterated (the rows travel with their instance
+      through the compaction swaps), so that nmpc_hip_ddp_last_solve_phases splits the whole solve and not its last launch. */
+  NMPC_D void phaseFlush(bool valid, bool took_part = true, bool resumed = false) const
   {
-    if(valid && buf.phase_ticks != nullptr)
+    if(valid && buf.phase_ticks != nullptr && (took_part || !resumed))
     {
       unsigned long long * p = buf.phase_ticks + static_cast<size_t>(b) * 4;
-      p[0] = phase_acc[0];
-      p[1] = phase_acc[1];
-      p[2] = __builtin_readcyclecounter() - phase_start;
+      const unsigned long long whole = __builtin_readcyclecounter() - phase_start;
+      p[0] = (resumed ? p[0] : 0ull) + phase_acc[0];
+      p[1] = (resumed ? p[1] : 0ull) + phase_acc[1];
+      p[2] = (resumed ? p[2] : 0ull) + whole;
     }
   }
 #endif
@@ -2107,7 +2111,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     }
     post(kCmdExit);
     profFlush(0);
-    phaseFlush(valid);
+    phaseFlush(valid, kResumable ? took_part : true, resumed);
 
     if(kResumable ? took_part : valid)
     {
@@ -2467,7 +2471,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     }
     post(kCmdExit);
     profFlush(0);
-    phaseFlush(valid);
+    phaseFlush(valid, kResumable ? took_part : true, resumed);
 
     if(kResumable ? took_part : valid)
     {

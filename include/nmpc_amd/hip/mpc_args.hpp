@@ -16,6 +16,7 @@ struct MpcAdvanceArgs
   int clamp_u0; //!< plant pattern: clamp u[0] to the handle's input limits first
   void * t0; //!< [Bp]            solver input: start time of the next solve   } elements of the problem's Scalar
   void * x0; //!< [tile][N][64]   solver input: initial state of the next solve } (double, or float: fp32 problem types)
+  double * t_exact; //!< [Bp] current_t of the next tick in double (owned by the handle; never NULL)
   double * t_log; //!< [B][n_ticks]
   double * x_log; //!< [B][n_ticks][N]    state handed to the solve of this tick
   double * u0_log; //!< [B][n_ticks][MM]  first input of the solution (clamped in the plant pattern)

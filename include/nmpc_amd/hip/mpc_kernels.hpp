@@ -65,11 +65,11 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
   const S * Us = buf.U + ((tile * 2 + sel) * rows_u) * LW + lane; // control_data_.u_list
   S * U0 = buf.U + ((tile * 2 + 0) * rows_u) * LW + lane; // initial_u_list of the next solve
   S * x0 = static_cast<S *>(args.x0) + (tile * N) * LW + lane;
-  // current_t lives in DOUBLE whatever the problem's scalar: an fp32 handle's t0 array holds its rounding, the exact value rides
-  // in the time log from tick to tick (row tick + 1 is written below) — accumulated in float, sim_dt = 0.01 at t ~ 100 s is
-  // 1e-3 relative per step off.  Double handles: the same additions as before, bit for bit.
-  const double t_exact = (args.tick == 0 || args.t_log == nullptr) ? static_cast<double>(static_cast<S *>(args.t0)[b])
-                                                                    : args.t_log[static_cast<size_t>(b) * args.n_ticks + args.tick];
+  // current_t lives in DOUBLE whatever the problem's scalar: an fp32 handle's t0 array holds its rounding, the exact value is carried
+  // from tick to tick in the handle's own per-instance array args.t_exact (written below; until round 5 it rode in the caller's
+  // optional time log) — accumulated in float, sim_dt = 0.01 at t ~ 100 s is 1e-3 relative per step off.  Double
+  // handles: the same additions as before, bit for bit.
+  const double t_exact = (args.tick == 0) ? static_cast<double>(static_cast<S *>(args.t0)[b]) : args.t_exact[b];
   const S t = static_cast<S>(t_exact);
   const int m0 = buf.input_dim[(tile * T + 0) * LW + lane];
   const size_t log_at = static_cast<size_t>(b) * args.n_ticks + args.tick;
@@ -178,10 +178,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
     }
   }
   static_cast<S *>(args.t0)[b] = static_cast<S>(t_next);
-  if(args.t_log && args.tick + 1 < args.n_ticks)
-  {
-    args.t_log[static_cast<size_t>(b) * args.n_ticks + args.tick + 1] = t_next;
-  }
+  args.t_exact[b] = t_next;
 }
 } // namespace hip
 } // namespace nmpc_amd

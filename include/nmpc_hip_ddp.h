@@ -86,8 +86,12 @@ extern "C"
        DDPSolver.hpp:115-123; a batch converges raggedly).  The solve is cut into resumable launches (iterations 1-16, 17-32, 33-48,
        49-64, 65-96, ... of those still running) with a device-side compaction between them, so that a persistent workgroup is not held
        by the one unconverged instance of its sixteen; no host round trip, results bit-identical to a single launch.
-       0: automatic (on for max_iter >= 64 where the kernel family has resumable instantiations: the quad and two-wave kernels
-       with a shared problem object), 1: on wherever supported, -1: off (one launch per solve). */
+       0: automatic — on for solves QUEUED through nmpc_hip_ddp_solve_async with max_iter >= 64 (a caller that overlaps batches: the
+       CUs a converged instance frees go to the batches behind it), off for the synchronous nmpc_hip_ddp_solve, for
+       nmpc_hip_ddp_solve_device and for the ticks of nmpc_hip_ddp_mpc_run (max_iter is only a cap: a warm-started solve that
+       converges within sixteen iterations must not pay the boundaries of the schedule, and a lone stream gains nothing from it);
+       1: on wherever supported (the quad and two-wave kernels with a shared problem object; what a pool of handles over
+       solve_device asks for), -1: off (one launch per solve). */
     int ragged_schedule;
   } nmpc_hip_ddp_config;
 
@@ -310,6 +314,15 @@ extern "C"
       schedule (nmpc_hip_ddp_config::ragged_schedule: resumable launches with a device-side compaction between them).  No reference
       counterpart: diagnostics. */
   int nmpc_hip_ddp_last_solve_launches(nmpc_hip_ddp_handle h, int * launches);
+
+  /** Ask the HIP runtime for at least n hardware queues (GPU_MAX_HW_QUEUES; its default is 4).  Streams of one process are
+      multiplexed onto them, and kernels of streams that share a queue run one after the other: a pool of handles overlaps only as
+      many batches as there are queues.  The runtime reads the variable when it initialises, so this has to come before the first HIP
+      call of the process (by anyone: torch, another library): *took_effect = 1 when the runtime is not up yet (the variable is raised
+      to n if it was unset or smaller) or was started with a value >= n; 0 when it is already running with fewer — the caller can then
+      say so instead of silently overlapping less.  The library never edits the environment on its own (it did, at load, until round 5).
+      No reference counterpart (one solver, one thread there); DDPSolverPool's constructors call it with their handle count. */
+  int nmpc_hip_ddp_request_hw_queues(int n, int * took_effect);
 
   /** Text of the last error raised on this thread (HIP error string or argument description). */
   const char * nmpc_hip_ddp_last_error(void);

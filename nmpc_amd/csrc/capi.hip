@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+
 #include <nmpc_amd/hip/model_ops.hpp>
 #include <nmpc_amd/hip/ragged_schedule.hpp>
 
@@ -22,9 +24,29 @@ namespace
 // Hardware queues.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels
 // of two streams that share a queue run one after the other.  A pool of handles (DDPSolverPool: consecutive batches on their own
 // streams) overlaps only as many batches as there are queues [measured, profiles/r05_m2_overlap.txt: 8 handles, ragged schedule,
-// 2048 batch-iterations/s with 4 queues, 4685 with 16].  The variable is read when the runtime initialises, so the library asks for
-// 16 when it is loaded — unless the caller set it, and without effect if something initialised HIP earlier in the process.
-const int g_hw_queues_requested = setenv("GPU_MAX_HW_QUEUES", "16", 0);
+// 2048 batch-iterations/s with 4 queues, 4685 with 16].  The variable is read when the runtime initialises; the library does not
+// touch its host's environment on its own — a caller that wants more queues says so through nmpc_hip_ddp_request_hw_queues()
+// (the pool mirrors do), which reports whether the request can still take effect.
+
+/** Whether the ROCm runtime of this process is already up: it holds /dev/kfd open from its initialisation on. */
+bool runtimeInitialised()
+{
+  char link[64], target[256];
+  for(int fd = 0; fd < 4096; fd++)
+  {
+    std::snprintf(link, sizeof(link), "/proc/self/fd/%d", fd);
+    const ssize_t len = readlink(link, target, sizeof(target) - 1);
+    if(len > 0)
+    {
+      target[len] = '\0';
+      if(std::strcmp(target, "/dev/kfd") == 0)
+      {
+        return true;
+      }
+    }
+  }
+  return false;
+}
 
 thread_local std::string g_last_error;
 
@@ -92,6 +114,7 @@ struct nmpc_hip_ddp_solver
   float last_total_ms = 0, last_kernel_ms = 0;
   hipStream_t last_stream = nullptr;
   hipEvent_t ev_staged = nullptr; // behind the H2D staging copies of nmpc_hip_ddp_solve_async
+  bool queued_solve = false; // the solve being launched came through nmpc_hip_ddp_solve_async (ragged_schedule 0: see raggedRounds)
 
   int elem = 8; //!< sizeof(Problem::Scalar): element size of every Scalar array below (ModelOps::scalar_bytes)
   // device memory (Scalar arrays are typed double here; an fp32 problem type stores floats in them, see elem)
@@ -133,6 +156,8 @@ struct nmpc_hip_ddp_solver
   int * d_ragged_rank = nullptr; // [Bp] scratch of the compaction kernel
   int * d_ragged_used = nullptr; // [Bp / 2] trace rows in use per pair of the round being swapped
   nmpc_amd::hip::LaunchKnobs knobs; // kernel family / schedule choices of this handle (environment overrides read once at create)
+  bool ragged_ready = false; // all five ragged buffers are allocated and cleared (ensureRagged)
+  bool ragged_unavailable = false; // their allocation failed once: the handle keeps to whole-solve launches
   int ragged_env = 0; // NMPC_HIP_DDP_RAGGED, read once at create: 1 forces the schedule on, -1 off (A/B measurements)
   int last_ragged_rounds = 0; // launches of the last solve (1: an ordinary whole-solve launch)
 };
@@ -478,11 +503,17 @@ namespace
 bool raggedRounds(const nmpc_hip_ddp_solver * s, std::vector<int> * caps)
 {
   const int mode = s->ragged_env != 0 ? s->ragged_env : s->cfg.ragged_schedule;
-  if(mode < 0 || s->elem != 8 || s->ops->resumable_supported == nullptr)
+  if(mode < 0 || s->ragged_unavailable || s->elem != 8 || s->ops->resumable_supported == nullptr)
   {
     return false;
   }
-  if(mode == 0 && s->cfg.max_iter < 64)
+  // Automatic mode.  max_iter is only a cap (500 by default) and says nothing about how long THIS solve runs: a warm-started MPC
+  // tick converges within the first launch and would still pay four more launches, eight compaction and eight replay kernels
+  // (~90 us of launch gaps per boundary), and a lone stream gains nothing from the schedule even on a long solve
+  // [measured 858 -> 842 batch-iterations/s].  What gains is a caller with OTHER batches queued behind this one, so automatic
+  // means: solves queued through nmpc_hip_ddp_solve_async (DDPSolverBatch::solveAsync, the C++ DDPSolverPool); synchronous solve(),
+  // solve_device() and the ticks of mpc_run() take one launch.  Pools over solve_device ask with 1 (nmpc_amd.DDPSolverPool does).
+  if(mode == 0 && (!s->queued_solve || s->cfg.max_iter < 64))
   {
     return false;
   }
@@ -503,9 +534,24 @@ bool raggedRounds(const nmpc_hip_ddp_solver * s, std::vector<int> * caps)
   return caps->size() > 1;
 }
 
+void freeRagged(nmpc_hip_ddp_solver * s)
+{
+  for(void ** p : {reinterpret_cast<void **>(&s->d_resume), reinterpret_cast<void **>(&s->d_ragged_words),
+                   reinterpret_cast<void **>(&s->d_ragged_pairs), reinterpret_cast<void **>(&s->d_ragged_rank),
+                   reinterpret_cast<void **>(&s->d_ragged_used)})
+  {
+    if(*p)
+    {
+      (void)hipFree(*p);
+      *p = nullptr;
+    }
+  }
+  s->ragged_ready = false;
+}
+
 int ensureRagged(nmpc_hip_ddp_solver * s)
 {
-  if(s->d_resume)
+  if(s->ragged_ready)
   {
     return NMPC_HIP_OK;
   }
@@ -527,13 +573,18 @@ int ensureRagged(nmpc_hip_ddp_solver * s)
   {
     rc = devAlloc(&s->d_ragged_used, static_cast<size_t>(s->Bp / 2 + 1));
   }
-  if(rc == NMPC_HIP_OK)
+  if(rc != NMPC_HIP_OK)
   {
-    // devAlloc clears with hipMemset, which is ordered on the NULL stream; the handle's stream is non-blocking and the first
-    // launches of the schedule follow at once: without this wait the clear could land in the middle of them (once per handle)
-    NMPC_HIP_TRY(hipDeviceSynchronize());
+    // all five buffers or none: a later solve must not find d_resume set and the others null
+    freeRagged(s);
+    (void)hipGetLastError(); // the failed hipMalloc is handled here: the caller falls back to one whole-solve launch
+    return rc;
   }
-  return rc;
+  // devAlloc clears with hipMemset, which is ordered on the NULL stream; the handle's stream is non-blocking and the first
+  // launches of the schedule follow at once: without this wait the clear could land in the middle of them (once per handle)
+  NMPC_HIP_TRY(hipDeviceSynchronize());
+  s->ragged_ready = true;
+  return NMPC_HIP_OK;
 }
 
 /** Every per-instance array of the handle (ragged_schedule.hpp: a compaction swap exchanges all of an instance's rows). */
@@ -585,12 +636,15 @@ nmpc_amd::hip::SwapTable swapTable(const nmpc_hip_ddp_solver * s)
 
 /** The ragged-convergence schedule: resumable launches of iterations (caps[r-1], caps[r]] with a compaction between them, then
     the recorded swaps replayed in reverse.  All on stream st, no host round trip. */
-int launchRagged(nmpc_hip_ddp_solver * s, hipStream_t st, DeviceBuffers buf, const std::vector<int> & caps)
+int launchRagged(nmpc_hip_ddp_solver * s, hipStream_t st, DeviceBuffers buf, const std::vector<int> & caps, bool * fell_back)
 {
-  int rc = ensureRagged(s);
-  if(rc != NMPC_HIP_OK)
+  *fell_back = false;
+  if(ensureRagged(s) != NMPC_HIP_OK)
   {
-    return rc;
+    // no memory for the schedule's buffers: this handle runs whole-solve launches from now on (the results are the same bits)
+    s->ragged_unavailable = true;
+    *fell_back = true;
+    return NMPC_HIP_OK;
   }
   constexpr int R = nmpc_hip_ddp_solver::kRaggedMaxRounds;
   const int rounds = static_cast<int>(caps.size());
@@ -601,15 +655,17 @@ int launchRagged(nmpc_hip_ddp_solver * s, hipStream_t st, DeviceBuffers buf, con
   const int wg_size = std::strcmp(s->ops->kernel_name(s->B, s->cfg), "ddp_solve_quad_kernel") == 0 ? 16 : 64;
   buf.resume = s->d_resume;
   hipLaunchKernelGGL(nmpc_amd::hip::ragged_init_kernel, dim3(1), dim3(64), 0, st, n_active, s->B);
+  int swapped_rounds = 0; // rounds whose compaction swaps are queued: they are replayed in reverse whatever happens after them
+  hipError_t le = hipSuccess;
   for(int r = 0; r < rounds; r++)
   {
     buf.n_active = n_active + r;
     buf.iter_begin = (r == 0) ? 1 : caps[r - 1] + 1;
     buf.iter_end = caps[r];
-    const hipError_t le = s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
+    le = s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
     if(le != hipSuccess)
     {
-      return fail(NMPC_HIP_ERR_HIP, std::string("resumable launch: ") + hipGetErrorString(le));
+      break;
     }
     if(r + 1 < rounds)
     {
@@ -617,14 +673,23 @@ int launchRagged(nmpc_hip_ddp_solver * s, hipStream_t st, DeviceBuffers buf, con
       hipLaunchKernelGGL((nmpc_amd::hip::ragged_compact_kernel<double>), dim3(1), dim3(1024), 0, st, s->d_resume, s->d_ragged_rank,
                          pairs, s->d_ragged_used, n_swaps + r, n_active + r, s->d_iters, wg_size);
       hipLaunchKernelGGL(nmpc_amd::hip::ragged_swap_kernel, swap_grid, dim3(256), 0, st, tab, pairs, s->d_ragged_used, n_swaps + r);
+      swapped_rounds = r + 1;
     }
   }
-  for(int r = rounds - 2; r >= 0; r--)
+  // A failed launch in the middle of the schedule still gets the reverse replay of the rounds already swapped: the swaps
+  // moved every per-instance array of the handle — the persistent inputs too (per-instance limits and problem objects, x0, the
+  // warm-start trajectories) — and later solves must find instance b at position b again.
+  for(int r = swapped_rounds - 1; r >= 0; r--)
   {
     const int * pairs = s->d_ragged_pairs + static_cast<size_t>(r) * s->Bp;
     hipLaunchKernelGGL(nmpc_amd::hip::ragged_replay_prepare_kernel, dim3(static_cast<unsigned>((s->Bp / 2 + 255) / 256)), dim3(256), 0, st,
                        pairs, s->d_ragged_used, n_swaps + r, s->d_iters);
     hipLaunchKernelGGL(nmpc_amd::hip::ragged_swap_kernel, swap_grid, dim3(256), 0, st, tab, pairs, s->d_ragged_used, n_swaps + r);
+  }
+  if(le != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return fail(NMPC_HIP_ERR_HIP, std::string("resumable launch: ") + hipGetErrorString(le));
   }
   NMPC_HIP_TRY(hipGetLastError());
   s->last_ragged_rounds = rounds;
@@ -681,15 +746,16 @@ int launchRecorded(nmpc_hip_ddp_solver * s,
   std::vector<int> caps;
   s->last_gain_layout = s->ops->gain_layout_of ? s->ops->gain_layout_of(s->B, s->cfg.with_input_constraint != 0 ? 1 : 0) : s->ops->gain_layout;
   s->last_ragged_rounds = 1;
-  if(raggedRounds(s, &caps))
+  bool whole_solve = !raggedRounds(s, &caps);
+  if(!whole_solve)
   {
-    int rrc = launchRagged(s, st, buf, caps);
+    int rrc = launchRagged(s, st, buf, caps, &whole_solve);
     if(rrc != NMPC_HIP_OK)
     {
       return rrc;
     }
   }
-  else
+  if(whole_solve)
   {
     const hipError_t le = s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
     if(le == hipErrorNotSupported)
@@ -978,6 +1044,35 @@ extern "C"
     // caller in compiled code launches its first solve microseconds from here: the clears must have landed (once per handle)
     NMPC_HIP_TRY(hipDeviceSynchronize());
     *out = s;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_request_hw_queues(int n, int * took_effect)
+  {
+    if(n < 1 || n > 64)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "hardware queues: 1 .. 64");
+    }
+    const char * cur = std::getenv("GPU_MAX_HW_QUEUES");
+    const bool up = runtimeInitialised();
+    int effective = 0;
+    if(up)
+    {
+      // too late to change: what the runtime read is what the variable held then (unset: its default of 4)
+      effective = (cur && std::atoi(cur) >= n) ? 1 : 0;
+    }
+    else
+    {
+      if(!cur || std::atoi(cur) < n)
+      {
+        setenv("GPU_MAX_HW_QUEUES", std::to_string(n).c_str(), 1);
+      }
+      effective = 1;
+    }
+    if(took_effect)
+    {
+      *took_effect = effective;
+    }
     return NMPC_HIP_OK;
   }
 
@@ -1349,7 +1444,7 @@ extern "C"
       return rc;
     }
     rc = ensureStage(&s->d_stage_out, &s->stage_out_bytes,
-                     std::max(log_d * sizeof(double) + log_i * sizeof(int), nx * sizeof(double)));
+                     std::max(log_d * sizeof(double) + log_i * sizeof(int), nx * sizeof(double)) + 8 + static_cast<size_t>(s->Bp) * sizeof(double));
     if(rc != NMPC_HIP_OK)
     {
       return rc;
@@ -1377,6 +1472,9 @@ extern "C"
     args.iter_log = reinterpret_cast<int *>(args.u0_log + B * nt * s->MM);
     args.status_log = args.iter_log + B * nt;
     args.m0_log = args.status_log + B * nt;
+    // current_t per instance in double, carried from tick to tick (behind the logs, 8-byte aligned: the logs are 3 B nt ints)
+    args.t_exact = reinterpret_cast<double *>(static_cast<char *>(s->d_stage_out)
+                                              + ((std::max(log_d * sizeof(double) + log_i * sizeof(int), nx * sizeof(double)) + 7) / 8) * 8);
     const int max_iter_saved = s->cfg.max_iter;
     for(int tick = 0; tick < opt->n_ticks && rc == NMPC_HIP_OK; tick++)
     {
@@ -1440,9 +1538,11 @@ extern "C"
     return NMPC_HIP_OK;
   }
 
+  static int stageAndLaunch(nmpc_hip_ddp_handle s, const double * t0, const double * x0, const double * u_init, bool queued);
+
   int nmpc_hip_ddp_solve(nmpc_hip_ddp_handle s, const double * t0, const double * x0, const double * u_init)
   {
-    int rc = nmpc_hip_ddp_solve_async(s, t0, x0, u_init);
+    int rc = stageAndLaunch(s, t0, x0, u_init, false);
     if(rc != NMPC_HIP_OK)
     {
       return rc;
@@ -1452,6 +1552,11 @@ extern "C"
   }
 
   int nmpc_hip_ddp_solve_async(nmpc_hip_ddp_handle s, const double * t0, const double * x0, const double * u_init)
+  {
+    return stageAndLaunch(s, t0, x0, u_init, true);
+  }
+
+  static int stageAndLaunch(nmpc_hip_ddp_handle s, const double * t0, const double * x0, const double * u_init, bool queued)
   {
     if(!s || !x0 || !u_init)
     {
@@ -1482,7 +1587,9 @@ extern "C"
       NMPC_HIP_TRY(hipEventCreateWithFlags(&s->ev_staged, hipEventDisableTiming));
     }
     NMPC_HIP_TRY(hipEventRecord(s->ev_staged, s->stream));
+    s->queued_solve = queued;
     rc = nmpc_hip_ddp_solve_device(s, t0 ? dt : nullptr, dx, du, nullptr);
+    s->queued_solve = false;
     NMPC_HIP_TRY(hipEventSynchronize(s->ev_staged));
     return rc;
   }

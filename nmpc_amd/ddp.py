@@ -266,6 +266,8 @@ class DDPSolverBatch:
                 _capi.check(self._L.nmpc_hip_ddp_set_model_params_batch(self._h, raw, nb))
             self._problem_batch_dirty = False
         c = self._config.to_c()
+        if getattr(self, "_pooled", False) and c.ragged_schedule == 0:
+            c.ragged_schedule = 1  # a pool's handle has other batches queued behind this one: "automatic" means on (where supported)
         _capi.check(self._L.nmpc_hip_ddp_set_config(self._h, C.byref(c)))
         if self._limits is not None:
             lo, up = self._limits
@@ -405,7 +407,8 @@ class DDPSolverBatch:
         self._cache = {}
 
     def synchronize(self) -> None:
-        _capi.check(self._L.nmpc_hip_ddp_synchronize(self._h))
+        if self._h:  # (a solver that has not solved yet has no handle and nothing in flight: a pool's idle handles)
+            _capi.check(self._L.nmpc_hip_ddp_synchronize(self._h))
 
     # ---- results ----
     def _field(self, field: int, dtype, shape) -> np.ndarray:
@@ -539,6 +542,16 @@ class DDPSolverBatch:
                         f"{t.duration_derivative:g} {t.duration_backward:g} {t.duration_forward:g}\n")
 
 
+def request_hw_queues(n: int = 16) -> bool:
+    """Ask the HIP runtime for at least n hardware queues (nmpc_hip_ddp_request_hw_queues: GPU_MAX_HW_QUEUES, read when the runtime
+    initialises; streams that share a queue do not overlap).  True when the request can still take effect or the runtime already
+    has that many; False when the runtime of this process is up with fewer — call it (or construct the pool) before anything touches
+    the device, or export GPU_MAX_HW_QUEUES yourself.  Importing nmpc_amd does not change the environment."""
+    ok = C.c_int(0)
+    _capi.check(_capi.load().nmpc_hip_ddp_request_hw_queues(int(n), C.byref(ok)))
+    return bool(ok.value)
+
+
 class DDPSolverPool:
     """Several DDPSolverBatch handles of the same problem and batch size, each with its own stream: consecutive batches are
     queued round-robin and overlap on the device.  A batch that is solved to convergence ends with a tail — a few instances
@@ -549,7 +562,18 @@ class DDPSolverPool:
     def __init__(self, problem: _Problem, batch_size: int, n_handles: int = 4, device: int = 0):
         if n_handles < 1:
             raise ValueError("n_handles should be positive")
+        #: whether the runtime has (or will have) one hardware queue per handle; False: fewer batches overlap than there are handles
+        self.hw_queues_ok = request_hw_queues(min(max(n_handles, 4), 64))
+        if not self.hw_queues_ok:
+            import warnings
+            warnings.warn("DDPSolverPool: the HIP runtime is already initialised with GPU_MAX_HW_QUEUES=%s (< %d handles): streams that "
+                          "share a hardware queue do not overlap; call nmpc_amd.request_hw_queues() or export the variable before the first "
+                          "HIP call of the process" % (__import__("os").environ.get("GPU_MAX_HW_QUEUES", "unset (4)"), n_handles))
         self.solvers = [DDPSolverBatch(problem, batch_size, device=device) for _ in range(n_handles)]
+        for s in self.solvers:
+            # Configuration::ragged_schedule 0 (automatic) is off for a lone handle's solve() / solveDevice() — max_iter is only a cap,
+            # and a lone stream gains nothing from the schedule — and on for a pool: the freed CUs go to the batches queued behind
+            s._pooled = True
         self._next = 0
 
     def config(self) -> Configuration:

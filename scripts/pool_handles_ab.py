@@ -1,4 +1,5 @@
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before torch initialises the HIP runtime
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 import nmpc_amd

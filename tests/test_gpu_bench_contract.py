@@ -43,6 +43,10 @@ def test_default_line_has_the_contract_keys():
     # SURVEY 8(d)'s two timing modes ride in the default line
     cfg = d["config"]
     assert cfg["m1_value"] > 0 and cfg["m2_value"] > 0
+    # ... each with the CPU oracle's rate in the same mode on the same 4096 inputs beside it ("same M1/M2 modes")
+    for m_name in ("m1", "m2"):
+        assert 0 < cfg[m_name]["cpu_value"] < cfg[m_name]["value"] and cfg[m_name]["cpu_cores"] == cb["cores"], m_name
+    assert abs(cfg["m2"]["cpu_mean_iterations"] - cfg["m2"]["mean_iterations"]) < 0.05 * cfg["m2"]["mean_iterations"]
     # consecutive batches on eight streams under the ragged-convergence schedule: the tails overlap and converged instances free their slots
     assert cfg["m2_overlapped_value"] > 2.5 * cfg["m2_value"] and cfg["m2_overlapped_value"] > 1.15 * cfg["m2_overlapped"]["whole_solve_launches_value"]
     assert cfg["m2_overlapped"]["launches_per_solve"] == 5 and cfg["m2_overlapped"]["handles"] == 8

@@ -31,9 +31,20 @@ def soak(lib, reps):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def fuzz_seed() -> int:
+    """One of the three prebuilt seeds (nmpc_amd/lib/fuzz{1,2,3}/, __graft_entry__.build()), rotating with the hour of the run so that
+    repeated runs of the suite — the driver's at round end, the builder's during the round — do not all sleep the same waves at the same
+    barriers (only seed 1 ever ran there).  NMPC_FUZZ_SEED pins it to reproduce a failure; the seed is in every message."""
+    import time
+    env = os.environ.get("NMPC_FUZZ_SEED")
+    return int(env) if env else 1 + int(time.time() // 3600) % 3
+
+
 def test_fuzzed_wave_timing_changes_no_bit_in_any_kernel_family():
     from nmpc_amd import build as hip_build
-    fuzz_lib = hip_build.build_fuzz(1)  # (in-tree, nmpc_amd/lib/fuzz1/: shipped with the tree; rebuilt here only if stale)
+    seed = fuzz_seed()
+    print("wave-timing fuzz seed", seed)
+    fuzz_lib = hip_build.build_fuzz(seed)  # (in-tree, nmpc_amd/lib/fuzz<seed>/: shipped with the tree; rebuilt here only if stale)
     want = soak(None, 1)
     got = soak(fuzz_lib, 3)
     assert set(want) == set(got) and len(want) >= 29
@@ -46,8 +57,8 @@ def test_fuzzed_wave_timing_changes_no_bit_in_any_kernel_family():
         assert k in families, (k, families)
     bad = {}
     for case, ref in want.items():
-        assert got[case]["kernel"] == ref["kernel"], case
+        assert got[case]["kernel"] == ref["kernel"], (case, "seed", seed)
         d = set(got[case]["digests"]) | set(ref["digests"])
         if len(d) != 1:
             bad[case] = (ref["digests"], got[case]["digests"])
-    assert not bad, bad
+    assert not bad, ("fuzz seed %d" % seed, bad)

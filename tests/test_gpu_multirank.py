@@ -58,7 +58,7 @@ def test_two_ranks_on_one_gpu_gather_equals_unsharded_hip_solve(tmp_path):
 def test_bench_under_two_ranks():
     """bench.py launched the way the driver launches it for N > 1 (both ranks share device 0 here): one JSON line from rank 0,
     n_gpus = 2, the whole-job value is the sum of both ranks' work, per-rank solve and gather times are reported."""
-    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-devices", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
                    "--no-extra-modes", "--min-seconds", "0.5"], 29643)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -72,11 +72,39 @@ def test_bench_under_two_ranks():
     assert abs(d["value"] - it_per_step / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
 
+def test_plain_python_bench_gpus_2_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (--gpus was parsed and never read — the line said n_gpus = 1):
+    bench.py starts the two ranks itself; rank 0 times the CPU oracle first (the other rank waits at a barrier), so a multi-GPU line has its
+    cpu_baseline too.  --share-devices because this box has one GPU; without it a job with fewer devices than ranks is refused, loudly."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-extra-modes", "--cpu-seconds", "0.5",
+            "--min-seconds", "0.5"]
+    r = subprocess.run(base + ["--share-devices"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and len(d["config"]["per_rank_solve_ms"]) == 2
+    assert d["config"]["gather_backend"] == "gloo"  # two ranks on one device; "nccl" (= RCCL) when every rank has its own
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and d["value"] > cb["value"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(base, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+        assert r.returncode != 0 and "visible device" in (r.stdout + r.stderr) and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # a launcher that started another number of ranks than --gpus says is refused as well
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "4", "--share-devices", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                   "--no-extra-modes", "--min-seconds", "0.2"], 29651)
+    assert r.returncode != 0 and "--gpus 4" in (r.stdout + r.stderr)
+
+
 def test_bench_c5_uneven_strong_split_gathers_the_unsharded_solve():
     """bench.py --workload c5 with ONE batch of 8200 + 1 instances cut over two ranks (4101 / 4100: uneven shards, padded to one
     fixed-size all-gather): the gathered records — X | U | cost | status | iters of every shard — equal the unsharded solve of
     the same batch bit for bit (both sides on the fp64 tile kernel), and the line says so."""
-    r = _torchrun([os.path.join(ROOT, "bench.py"), "--workload", "c5", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--workload", "c5", "--gpus", "2", "--share-devices", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                    "--no-extra-modes", "--min-seconds", "0.2", "--global-batch", "8201", "--verify-gather"], 29645)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -94,7 +122,7 @@ def test_bench_c4_fp32_two_ranks_at_global_batch_8192_equal_the_unsharded_solve(
     """fp32 at the reference's default threshold: 8192 instances run on the fp32 tile kernel, a lone 4096-instance handle would take the
     tile kernel's float instantiation — families that differ in the last bits.  The shards set the whole batch's size as their dispatch
     batch (bench.py --global-batch; nmpc_hip_ddp_set_dispatch_batch) and return the unsharded solve bit for bit."""
-    r = _torchrun([os.path.join(ROOT, "bench.py"), "--workload", "c4", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--workload", "c4", "--gpus", "2", "--share-devices", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                    "--no-extra-modes", "--min-seconds", "0.2", "--global-batch", "8192", "--cost-update-thre", "1e-7", "--verify-gather"], 29649)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
@@ -105,7 +133,7 @@ def test_bench_c4_fp32_two_ranks_at_global_batch_8192_equal_the_unsharded_solve(
 def test_fmpc_bench_under_two_ranks():
     """bench.py --workload fmpc under two ranks (both on device 0): FMPC shards like DDP — independent instances, no collective in
     the data path; the job's value counts both ranks' iterations."""
-    r = _torchrun([os.path.join(ROOT, "bench.py"), "--workload", "fmpc", "--gpus", "2", "--steps", "4", "--warmup", "1",
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--workload", "fmpc", "--gpus", "2", "--share-devices", "--steps", "4", "--warmup", "1",
                    "--no-cpu-baseline", "--batch", "1024"], 29647)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -42,7 +42,9 @@ def test_ragged_solve_returns_the_bits_of_one_launch(B, max_iter, constrained):
     for mode in (0, 1):
         s = make_solver(wl, ragged_schedule=mode, **cfg)
         s.solve(wl.t0, wl.x0, wl.u_init)
-        assert s.lastSolveLaunches() == (1 if (mode == 0 and max_iter < 64) else schedule_launches(max_iter))
+        # automatic (0): a lone handle's synchronous solve() takes one launch whatever the max_iter cap is (a warm-started
+        # solve that converges at once must not pay the schedule's boundaries); queued solves and pools switch it on (tests below)
+        assert s.lastSolveLaunches() == (1 if mode == 0 else schedule_launches(max_iter))
         assert s.kernelName() == "ddp_solve_quad_kernel"
         assert_same_bits(outputs(s), want, f"ragged_schedule {mode}")
         s.solve(wl.t0, wl.x0, wl.u_init)  # the handle again: nothing of the first solve's schedule may linger
@@ -58,7 +60,7 @@ def test_ragged_schedule_on_the_two_wave_kernel_and_on_bipedal(monkeypatch):
     wl = workloads.cartpole_batch(B=1500, T=100, seed=77)
     whole = make_solver(wl, max_iter=100, ragged_schedule=-1)
     whole.solve(wl.t0, wl.x0, wl.u_init)
-    s = make_solver(wl, max_iter=100)
+    s = make_solver(wl, max_iter=100, ragged_schedule=1)
     s.solve(wl.t0, wl.x0, wl.u_init)
     assert s.kernelName() == "ddp_solve_tpi2w_kernel" and s.lastSolveLaunches() == schedule_launches(100) == 5 and whole.lastSolveLaunches() == 1
     assert_same_bits(outputs(s), outputs(whole), "two-wave kernel")
@@ -76,7 +78,7 @@ def test_short_solves_and_unsupported_shapes_stay_one_launch():
     wl = workloads.cartpole_batch(B=256, T=100, seed=3)
     s = make_solver(wl, max_iter=8)
     s.solve(wl.t0, wl.x0, wl.u_init)
-    assert s.lastSolveLaunches() == 1  # automatic: max_iter < 64
+    assert s.lastSolveLaunches() == 1  # automatic: a synchronous solve
     s = make_solver(wl, max_iter=8, ragged_schedule=1)
     s.solve(wl.t0, wl.x0, wl.u_init)
     assert s.lastSolveLaunches() == 1  # eight iterations are one launch of the schedule anyway
@@ -84,6 +86,42 @@ def test_short_solves_and_unsupported_shapes_stay_one_launch():
     s = make_solver(wl, max_iter=40, ragged_schedule=1)  # the tile / wave-per-instance kernels have no resumable instantiation
     s.solve(wl.t0, wl.x0, wl.u_init)
     assert s.lastSolveLaunches() == 1
+
+
+def test_automatic_mode_follows_the_entry_point():
+    """ragged_schedule 0: one launch for solve(), solveDevice() and the ticks of mpcRun() on a lone handle, whatever max_iter says (the
+    reference's default is 500 and only a cap); the schedule for a handle of a pool and for nmpc_hip_ddp_solve_async — same bits."""
+    import ctypes as C
+
+    import torch
+
+    import nmpc_amd
+    from nmpc_amd import _capi
+
+    wl = workloads.cartpole_batch(B=512, T=100, seed=41)
+    s = make_solver(wl, max_iter=500)
+    s.solve(wl.t0, wl.x0, wl.u_init)
+    assert s.lastSolveLaunches() == 1
+    want = outputs(s)
+    d = [torch.from_numpy(a).cuda() for a in (wl.t0, wl.x0, wl.u_init)]
+    s.solveDevice(*[t.data_ptr() for t in d])
+    s.synchronize()
+    assert s.lastSolveLaunches() == 1
+    assert_same_bits(outputs(s), want, "solveDevice")
+    dp = C.POINTER(C.c_double)
+    _capi.check(s._L.nmpc_hip_ddp_solve_async(s._h, wl.t0.ctypes.data_as(dp), wl.x0.ctypes.data_as(dp), wl.u_init.ctypes.data_as(dp)))
+    s.synchronize()
+    s._cache = {}
+    assert s.lastSolveLaunches() == schedule_launches(500)
+    assert_same_bits(outputs(s), want, "solve_async")
+    pool = nmpc_amd.DDPSolverPool(nmpc_amd.make_problem(wl.model), wl.B, n_handles=2)
+    c = pool.config()
+    c.print_level, c.horizon_steps, c.max_iter = 0, wl.T, 500
+    pool.applyConfig()
+    h = pool.submit(*[t.data_ptr() for t in d])
+    pool.synchronize()
+    assert h.lastSolveLaunches() == schedule_launches(500)
+    assert_same_bits(outputs(h), want, "pool handle")
 
 
 def test_solver_pool_with_the_ragged_schedule_overlaps_more():

@@ -269,7 +269,27 @@ struct TileSolver64
   static constexpr int wExchange = wX + 16;
   static constexpr int kTrLd = 17; //!< leading dimension of the transposition scratch: conflict-free both ways
   static constexpr int wT = 0;
-  static constexpr int wZero = (wExchange > 16 * kTrLd ? wExchange : 16 * kTrLd); //!< sixteen zeros, read by lanes outside a block
+  // Natural-layout gains (kBig), round 6: the factorisations of a wave's slots of a timestep run TOGETHER, sixteen lanes per slot and
+  // a column per lane (gainsPrepare / gainsBatch / gainsComplete).  A slot's Quu_F and [Qux_reg | Qu] pass through this staging on
+  // their way from the natural layout (register r of lane (q, c) = entry (4 r + q, c)) into the registers of ONE lane group, and the
+  // solved columns the same way back: column c at kStLd c, row 4 r + q at position 4 q + r of its column (what a natural-layout lane
+  // holds of a column is contiguous).  kStLd = 9 x 16 bytes: the sixteen lanes of a row hit different banks with their 16-byte accesses.
+  // One slot at a time, aliased with the transposition scratch (one wave's LDS traffic is ordered).
+#ifdef NMPC_AMD_AB_NATURAL_GAINS
+  static constexpr bool kBatchGains = false; // A/B builds: every slot factorises over the whole wave (stepGainsNatural), as until round 5
+#else
+  static constexpr bool kBatchGains = kBig && !kConstrained && std::is_same<S, double>::value;
+#endif
+  static constexpr int kStLd = 18;
+  static constexpr int wStA = 0; //!< Quu_F, both triangles
+  static constexpr int wStR = 16 * kStLd; //!< [Qux_reg | Qu], then the solved columns x
+#ifdef NMPC_AMD_AB_FORCE_STAGING_SPACE
+  static constexpr int kStDoubles = 2 * 16 * kStLd; // (A/B: the LDS layout of the batched gains without their code)
+#else
+  static constexpr int kStDoubles = kBatchGains ? 2 * 16 * kStLd : 0;
+#endif
+  static constexpr int wZero0 = (wExchange > 16 * kTrLd ? wExchange : 16 * kTrLd);
+  static constexpr int wZero = (wZero0 > kStDoubles ? wZero0 : kStDoubles); //!< sixteen zeros, read by lanes outside a block
                                                                                    //!< (with the immediate offsets of the lanes inside)
   static constexpr int wDump = wZero + 16; //!< written by lanes outside a block
   static constexpr int kWaveDoubles = wDump + 2;
@@ -290,7 +310,15 @@ struct TileSolver64
 #else
   static constexpr int kOwnerWaves = kT64MatrixWaves;
 #endif
-  static constexpr int kPerWave = (kT64MaxGroup + kOwnerWaves - 1) / kOwnerWaves;
+  //! Instances per group at most for THIS instantiation.  The batched natural-layout gains keep a slot's operands of the value update in
+  //! registers between its two trips (GainStash): with more than three slots per wave the trips spill, and a spilled step costs more
+  //! than the batch saves [measured, profiles/r06_centroidal_gains_ab.txt].  -DNMPC_AMD_AB_BIG_GROUP=n: A/B builds.
+#ifdef NMPC_AMD_AB_BIG_GROUP
+  static constexpr int kGroupMax = kBatchGains ? NMPC_AMD_AB_BIG_GROUP : kT64MaxGroup;
+#else
+  static constexpr int kGroupMax = kBatchGains ? 3 * kT64MatrixWaves : kT64MaxGroup;
+#endif
+  static constexpr int kPerWave = (kGroupMax + kOwnerWaves - 1) / kOwnerWaves;
   static constexpr int kQpIn = MM * MM + MM;
   static constexpr int kQpPerWave = (kPerWave - 1) * kQpIn + 2 * kPerWave;
   static constexpr int kQpAt = kLsAt;
@@ -859,11 +887,21 @@ struct TileSolver64
   }
   /** What a prefetching lane keeps for a whole pass: it serves ONE slot (p_lane % G) and every (p_count / G)-th row of it, so
       everything that depends on the slot is computed once. */
+  //! A pointer into the handle's HBM arrays, said so: the prefetch loads must be global_load (vmcnt), not flat_load.  The compiler
+  //! does not see through the selects and arrays these pointers pass and fell back to flat_load — whose completion a wait for the
+  //! LDS (lgkmcnt) also waits for, and in front of which it may put a wait of its own: round 6 found one build of this file with
+  //! s_waitcnt vmcnt(0) lgkmcnt(0) in front of EVERY load of prefetchIssue, i.e. nineteen sequential round trips to L2 per trip
+  //! (centroidal forward passes 6.5 -> 10.4 ms) — the "register allocation side effect" of round 4 (HISTORY) was this.
+  using GlobalPtr = const S __attribute__((address_space(1))) *;
+  NMPC_D static GlobalPtr asGlobal(const S * p)
+  {
+    return (GlobalPtr)p;
+  }
   struct PrefetchLane
   {
     bool want; //!< the slot takes part in the pass and this lane has rows to fetch
     int row0, row_step, slot;
-    const S *pk, *pK, *pX, *pU; //!< row 0 of timestep 0 of k_list_, K_list_, x_list, u_list of the slot's instance
+    GlobalPtr pk, pK, pX, pU; //!< row 0 of timestep 0 of k_list_, K_list_, x_list, u_list of the slot's instance
   };
   NMPC_D PrefetchLane makePrefetchLane(int group, int p_lane, int p_count) const
   {
@@ -877,10 +915,10 @@ struct TileSolver64
     const int sel = slotI(sSel, pl.slot);
     const size_t tile = pl.want ? tileOf(b) : 0, ln = pl.want ? lnOf(b) : 0;
     const size_t rows_x = static_cast<size_t>(T + 1) * N, rows_u = static_cast<size_t>(T) * MM;
-    pl.pk = buf.wpi_ws + static_cast<size_t>(pl.want ? b : 0) * gainDoubles(T); // gain record of timestep 0
+    pl.pk = asGlobal(buf.wpi_ws + static_cast<size_t>(pl.want ? b : 0) * gainDoubles(T)); // gain record of timestep 0
     pl.pK = pl.pk + MM;
-    pl.pX = buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln;
-    pl.pU = buf.U + ((tile * 2 + sel) * rows_u) * 64 + ln;
+    pl.pX = asGlobal(buf.X + ((tile * 2 + sel) * rows_x) * 64 + ln);
+    pl.pU = asGlobal(buf.U + ((tile * 2 + sel) * rows_u) * 64 + ln);
     return pl;
   }
   /** Prefetch role: this lane's rows of timestep i -> ring(i): element (row, slot) at slot * kRingStride + row. */
@@ -900,7 +938,7 @@ struct TileSolver64
         const bool ok = pl.want && row < kRingRows;
         // row < m: k_i | < m + m n: K_i | < m + m n + n: x_i | else u_i
         const bool is_k = row < MM, is_K = !is_k && row < kGainRows, is_x = !is_k && !is_K && row < kGainRows + N;
-        const S * base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
+        GlobalPtr base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
         const int per_step = (is_k || is_K) ? kGainRows : (is_x ? N * 64 : MM * 64); // gains: records; x, u: tile-major rows
         const int r = is_k ? row : (is_K ? row - MM : (is_x ? (row - kGainRows) * 64 : (row - kGainRows - N) * 64));
         at[k] = ok ? row : -1;
@@ -968,7 +1006,7 @@ struct TileSolver64
   struct PrefetchRegs
   {
     S v[kPipeRows]; //!< the rows in flight
-    const S * src[kPipeRows]; //!< row k of this lane at timestep 0 (a valid address also where the lane has no row k) ...
+    GlobalPtr src[kPipeRows]; //!< row k of this lane at timestep 0 (a valid address also where the lane has no row k) ...
     int step[kPipeRows]; //!< ... and the distance to the same row of the next timestep, in doubles
     int at[kPipeRows]; //!< where it goes in the slot's ring entry (-1: nowhere)
   };
@@ -986,7 +1024,7 @@ struct TileSolver64
       const bool ok = pl.want && row < kRingRows;
       // row < m: k_i | < m + m n: K_i | < m + m n + n: x_i | else u_i
       const bool is_k = row < MM, is_K = !is_k && row < kGainRows, is_x = !is_k && !is_K && row < kGainRows + N;
-      const S * base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
+      GlobalPtr base = is_k ? pl.pk : (is_K ? pl.pK : (is_x ? pl.pX : pl.pU));
       const int per_step = (is_k || is_K) ? kGainRows : (is_x ? N * 64 : MM * 64); // gains: records; x, u: tile-major rows
       const int r = is_k ? row : (is_K ? row - MM : (is_x ? (row - kGainRows) * 64 : (row - kGainRows - N) * 64));
       pr.src[k] = ok ? base + r : pl.pk; // (pk: the slot's — or instance 0's — first gain record: always readable)
@@ -1302,16 +1340,53 @@ struct TileSolver64
   // matrix waves: one backward timestep of one instance    DDPSolver.hpp:381-530
   // ===================================================================================================
   /** What a matrix lane knows for the whole kernel: where its entries of a record are (offsets in doubles). */
+  //! kPackMap (the batched natural-layout gains): the offsets live PACKED two per register (they are below 2^16: a record has a few
+  //! hundred entries) and the symmetrisation weights are derived from the lane id where they are used — twenty registers less across the
+  //! sweep.  The batched gains hold the columns of a whole factorisation (64 registers) and two slots' stashes beside the step's
+  //! own working set; with the plain map the trips spilled a handful of values, and every reload waits (vmcnt(0)) for the gain
+  //! stores of the trip in front of it — a round trip to HBM per slot and timestep.
+  static constexpr bool kPackMap = kBatchGains;
   struct LaneMap
   {
-    int oFx[4], oFu[4], oLxx[4], oLxuT[KM], oLuu[KM], oLx, oLu, oInvU, oU[kConstrained ? MM : 1], oM;
+    int oFx[kPackMap ? 1 : 4], oFu[kPackMap ? 1 : 4], oLxx[kPackMap ? 1 : 4], oLxuT[kPackMap ? 1 : KM], oLuu[kPackMap ? 1 : KM], oLx, oLu, oInvU,
+        oU[kConstrained ? MM : 1], oM;
     S wn, wt; //!< weights of (Vn, Vn^T) in the new [Vxx | Vx]: (1/2, 1/2) inside the n x n block, (1, 0) in column n
+    unsigned pFxFu[kPackMap ? 4 : 1], pLxxLxuT[kPackMap ? 4 : 1], pLuu[kPackMap ? 2 : 1], pLxLu; // (kPackMap: low | high << 16)
+    NMPC_D int fx(int r) const
+    {
+      return kPackMap ? static_cast<int>(pFxFu[kPackMap ? r : 0] & 0xffffu) : oFx[kPackMap ? 0 : r];
+    }
+    NMPC_D int fu(int r) const
+    {
+      return kPackMap ? static_cast<int>(pFxFu[kPackMap ? r : 0] >> 16) : oFu[kPackMap ? 0 : r];
+    }
+    NMPC_D int lxx(int r) const
+    {
+      return kPackMap ? static_cast<int>(pLxxLxuT[kPackMap ? r : 0] & 0xffffu) : oLxx[kPackMap ? 0 : r];
+    }
+    NMPC_D int lxuT(int r) const
+    {
+      return kPackMap ? static_cast<int>(pLxxLxuT[kPackMap ? r : 0] >> 16) : oLxuT[kPackMap ? 0 : r];
+    }
+    NMPC_D int luu(int r) const
+    {
+      return kPackMap ? static_cast<int>((r & 1) ? pLuu[kPackMap ? r >> 1 : 0] >> 16 : pLuu[kPackMap ? r >> 1 : 0] & 0xffffu) : oLuu[kPackMap ? 0 : r];
+    }
+    NMPC_D int lx() const
+    {
+      return kPackMap ? static_cast<int>(pLxLu & 0xffffu) : oLx;
+    }
+    NMPC_D int lu() const
+    {
+      return kPackMap ? static_cast<int>(pLxLu >> 16) : oLu;
+    }
   };
   NMPC_D LaneMap makeLaneMap() const
   {
     const int q = lane >> 4, j = colOf(lane & 15);
     const unsigned short * t = tbl();
     LaneMap mp;
+    int oFx[4], oFu[4], oLxx[4], oLxuT[4] = {0, 0, 0, 0}, oLuu[4] = {0, 0, 0, 0};
 #pragma unroll
     for(int r = 0; r < 4; r++)
     {
@@ -1320,7 +1395,7 @@ struct TileSolver64
       {
         // oFx: the augmented F = [Fx Fu]; oLxx: the augmented L = [[Lxx Lxu],[Lxu^T Luu]]
         const int ju = (j >= N && j < NA) ? j - N : 0, ru = (row >= N && row < NA) ? row - N : 0, jx = j < N ? j : 0, rx = row < N ? row : 0;
-        mp.oFx[r] = (row < N) ? ((j < N) ? t[idFx + jx * N + rx] : ((j < NA) ? t[idFu + ju * N + rx] : 0)) : 0;
+        oFx[r] = (row < N) ? ((j < N) ? t[idFx + jx * N + rx] : ((j < NA) ? t[idFu + ju * N + rx] : 0)) : 0;
         int l = 0;
         if(row < N && j < N)
         {
@@ -1338,26 +1413,58 @@ struct TileSolver64
         {
           l = t[idLuu + ju * MM + ru];
         }
-        mp.oLxx[r] = l;
-        mp.oFu[r] = 0;
+        oLxx[r] = l;
+        oFu[r] = 0;
       }
       else
       {
-        mp.oFx[r] = (row < N && j < N) ? t[idFx + j * N + row] : 0;
-        mp.oFu[r] = (row < N && j < MM) ? t[idFu + j * N + row] : 0;
-        mp.oLxx[r] = (row < N && j < N) ? t[idLxx + j * N + row] : 0;
+        oFx[r] = (row < N && j < N) ? t[idFx + j * N + row] : 0;
+        oFu[r] = (row < N && j < MM) ? t[idFu + j * N + row] : 0;
+        oLxx[r] = (row < N && j < N) ? t[idLxx + j * N + row] : 0;
       }
     }
 #pragma unroll
     for(int r = 0; r < KM; r++)
     {
       const int a = 4 * r + q;
-      mp.oLxuT[r] = (a < MM && j < N) ? t[idLxuT + j * MM + a] : 0;
-      mp.oLuu[r] = (a < MM && j < MM) ? t[idLuu + j * MM + a] : 0;
+      oLxuT[r] = (a < MM && j < N) ? t[idLxuT + j * MM + a] : 0;
+      oLuu[r] = (a < MM && j < MM) ? t[idLuu + j * MM + a] : 0;
     }
-    mp.oLx = (j < N) ? t[idLx + j] : ((kAug && j < NA) ? t[idLu + ((j >= N && j < NA) ? j - N : 0)] : 0); // (augmented: [Lx; Lu])
-    mp.oLu = (j < MM) ? t[idLu + j] : 0;
-    mp.oInvU = t[idInvU];
+    const int oLx_ = (j < N) ? t[idLx + j] : ((kAug && j < NA) ? t[idLu + ((j >= N && j < NA) ? j - N : 0)] : 0); // (augmented: [Lx; Lu])
+    const int oLu_ = (j < MM) ? t[idLu + j] : 0;
+    mp.oLx = oLx_;
+    mp.oLu = oLu_;
+    if constexpr(kPackMap)
+    {
+#pragma unroll
+      for(int r = 0; r < 4; r++)
+      {
+        mp.pFxFu[r] = static_cast<unsigned>(oFx[r]) | (static_cast<unsigned>(oFu[r]) << 16);
+        mp.pLxxLxuT[r] = static_cast<unsigned>(oLxx[r]) | (static_cast<unsigned>(oLxuT[r]) << 16);
+      }
+      mp.pLuu[0] = static_cast<unsigned>(oLuu[0]) | (static_cast<unsigned>(oLuu[1]) << 16);
+      mp.pLuu[1] = static_cast<unsigned>(oLuu[2]) | (static_cast<unsigned>(oLuu[3]) << 16);
+      mp.pLxLu = static_cast<unsigned>(oLx_) | (static_cast<unsigned>(oLu_) << 16);
+      mp.oFx[0] = mp.oFu[0] = mp.oLxx[0] = mp.oLxuT[0] = mp.oLuu[0] = 0;
+    }
+    else
+    {
+#pragma unroll
+      for(int r = 0; r < 4; r++)
+      {
+        mp.oFx[kPackMap ? 0 : r] = oFx[r];
+        mp.oFu[kPackMap ? 0 : r] = oFu[r];
+        mp.oLxx[kPackMap ? 0 : r] = oLxx[r];
+      }
+#pragma unroll
+      for(int r = 0; r < KM; r++)
+      {
+        mp.oLxuT[kPackMap ? 0 : r] = oLxuT[r];
+        mp.oLuu[kPackMap ? 0 : r] = oLuu[r];
+      }
+      mp.pFxFu[0] = mp.pLxxLxuT[0] = mp.pLuu[0] = mp.pLxLu = 0;
+    }
+    mp.oInvU = uniform(t[idInvU]);
     if constexpr(kConstrained)
     {
 #pragma unroll
@@ -1370,7 +1477,7 @@ struct TileSolver64
     {
       mp.oU[0] = 0;
     }
-    mp.oM = kDyn ? t[kDyn ? idM : 0] : 0;
+    mp.oM = kDyn ? uniform(t[kDyn ? idM : 0]) : 0;
     mp.wn = (j < N) ? 0.5 : ((j == N) ? 1.0 : 0.0);
     mp.wt = (j < N) ? 0.5 : 0.0;
     return mp;
@@ -1484,10 +1591,10 @@ struct TileSolver64
 #pragma unroll
       for(int rr = 0; rr < 4; rr++)
       {
-        F[rr] = r[mp.oFx[rr]];
-        L[rr] = r[mp.oLxx[rr]];
+        F[rr] = r[mp.fx(rr)];
+        L[rr] = r[mp.lxx(rr)];
       }
-      const S lv = r[mp.oLx];
+      const S lv = r[mp.lx()];
       c.inv_u = r[mp.oInvU];
       // G = VV^T F: rows < n: Vxx [Fx Fu], row n: Vx^T [Fx Fu];  Q = G^T F + L = [[Qxx Qxu],[Qux Quu]] (row n of G meets the
       // zero row n of F).  Same products in the same order as the block form below: (Fu^T Vxx) Fx etc., left to right.
@@ -1516,17 +1623,17 @@ struct TileSolver64
 #pragma unroll
       for(int rr = 0; rr < 4; rr++)
       {
-        Fx[rr] = r[mp.oFx[rr]];
-        Fu[rr] = r[mp.oFu[rr]];
-        Lxx[rr] = r[mp.oLxx[rr]];
+        Fx[rr] = r[mp.fx(rr)];
+        Fu[rr] = r[mp.fu(rr)];
+        Lxx[rr] = r[mp.lxx(rr)];
       }
 #pragma unroll
       for(int rr = 0; rr < KM; rr++)
       {
-        LxuT[rr] = r[mp.oLxuT[rr]];
-        Luu[rr] = r[mp.oLuu[rr]];
+        LxuT[rr] = r[mp.lxuT(rr)];
+        Luu[rr] = r[mp.luu(rr)];
       }
-      const S lx = r[mp.oLx], lu = r[mp.oLu];
+      const S lx = r[mp.lx()], lu = r[mp.lu()];
       c.inv_u = r[mp.oInvU];
       const Vec4 Pa = mma<KN>(c.VV, Fx);
       const Vec4 Pb = mma<KN>(c.VV, Fu);
@@ -1992,6 +2099,11 @@ struct TileSolver64
       kn += c.col[a] * c.col[a];
     }
     }
+    stepValueTail(c, QQ, kn, m, la, q, j);
+  }
+  /** ... the four products of the value update from A = [K | k], QQ = [Qux | Qu], |k|^2 (kn): what follows the gains, whoever computed them. */
+  NMPC_D void stepValueTail(StepCtx & c, const Vec4 & QQ, S kn, int m, const LaneAddr & la, int q, int j) const
+  {
     const Vec4 Z = mma<KM>(c.Quu, c.A);
     const Vec4 C1 = mma<KM>(Z, c.A);
     const Vec4 T2 = mma<KM>(c.A, QQ);
@@ -2029,6 +2141,13 @@ struct TileSolver64
     // entry (j, 4 r + q) of the scratch where it belongs to the n x n block (the zero words elsewhere): rows < 4 rN from one
     // address with immediate offsets, row 4 rN + q from its own, the rows behind are outside the block
     const S * col_j = &ldsAt(lo16(la.tr_trn));
+    S wn = mp.wn, wt = mp.wt;
+    if constexpr(kPackMap)
+    {
+      const int jj = colOf(fl & 15); // (the weights from the lane id: two registers less across the sweep)
+      wn = (jj < N) ? 0.5 : ((jj == N) ? 1.0 : 0.0);
+      wt = (jj < N) ? 0.5 : 0.0;
+    }
 #pragma unroll
     for(int rr = 0; rr < 4; rr++)
     {
@@ -2041,7 +2160,7 @@ struct TileSolver64
       {
         vt = ldsAt(hi16(la.tr_trn));
       }
-      c.VV[rr] = mp.wn * c.Vn[rr] + mp.wt * vt;
+      c.VV[rr] = wn * c.Vn[rr] + wt * vt;
     }
     const bool star = fl == kStarLane;
     S * dv0 = star ? &slotF(sDV0, slot) : W + wDump;
@@ -2202,6 +2321,227 @@ struct TileSolver64
     c.ok = c.ok && ok_now;
   }
 
+  // ---------------------------------------------------------------------------------------------------
+  // natural-layout gains, the slots of a wave together (kBatchGains): sixteen lanes per slot, a column per lane
+  // ---------------------------------------------------------------------------------------------------
+  // stepGainsNatural spends ~37 of its ~50 instructions per pivot on moving ONE slot's pivot row and pivot across the four lane groups
+  // (v_readlane, two ds_bpermute pairs and their waits) — a latency chain of ~9 k cycles per slot and timestep, run for the wave's
+  // slots one after the other (centroidal, 4096 instances: three slots per wave; profiles/r05_pmc_summary_centroidal.txt: VALU : MFMA
+  // 42 : 1).  Here lane c of lane group g holds COLUMN c of slot g's Quu_F — all sixteen rows, both triangles — and column c of its
+  // right-hand sides [Qux_reg | Qu] in registers: the pivot row entry (j, c) = L_cj d_j is the lane's OWN register j, the pivot d_j
+  // and the column L_ij come from lane j of the lane's 16-lane row by a DPP row broadcast (v_mov_b64_dpp row_newbcast: the one
+  // DPP control the fp64 pipeline takes), and the back substitution is one v_fmac_f64_dpp per (row, column).  No cross-lane-group
+  // move, no LDS, and up to four slots share every instruction.  The arithmetic is stepGainsNatural's, operation for operation:
+  // the rank-one update (L_ij L_cj) d_j on both triangles, y_i -= L_ij y_j, z_j = y_j / d_j, x_i -= L_Ki x_K.
+  /** What a slot keeps in registers between its prepare and its complete trip (next to [Qxx | Qx], which waits in the slot's value
+      function registers: the old [Vxx | Vx] is dead once the Q terms are formed). */
+  struct GainStash
+  {
+    Vec4 Quu, QQ;
+  };
+  /** The value of lane J of this lane's 16-lane row (one instruction; s_nop: a DPP operand written by the VALU instruction in front
+      of it needs two wait states, and the hazard recogniser does not look into inline assembly). */
+  template<int J>
+  NMPC_D static double bcastRow(double v)
+  {
+    double o;
+#ifdef NMPC_AMD_AB_NO_DPP_NOP
+    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "n"(J));
+#else
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "n"(J));
+#endif
+    return o;
+  }
+  /** acc -= (lane K's a) * x   (the back substitution's step; a was written long before: no wait states needed) */
+  template<int K>
+  NMPC_D static void fmsubRow(double & acc, double a, double x)
+  {
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(x), "n"(K));
+  }
+  /** Pivot J of the factorisation and the forward substitution for every lane group at once.  m_lane: the input dimension of the
+      lane's slot (pivots beyond it leave the padded blocks alone: r = 0). */
+  template<int J>
+  NMPC_D static void batchPivot(S (&a)[MM], S (&y)[MM], bool & ok, int c, int m_lane)
+  {
+    const S d = bcastRow<J>(a[J]);
+    const bool act = !kDyn || J < m_lane;
+    ok = ok && !(act && d <= 0.0); // the pivot rule of Eigen's LLT (fails iff a pivot is <= 0, NaN passes)
+    const S r = act ? recipFast(d) : 0.0;
+    const S lc = (c > J) ? a[J] * r : 0.0; // L_cj; columns <= j are finished: they receive - 0
+    const S yj = y[J];
+#pragma unroll
+    for(int i = J + 1; i < MM; i++)
+    {
+      const S li = bcastRow<J>(a[i] * r); // L_ij
+      a[i] -= (li * lc) * d;
+      y[i] -= li * yj;
+    }
+    a[J] = lc; // lane K > j: L_Kj, what the back substitution takes from lane K for row j
+    y[J] = act ? yj * r : yj; // z_j = y_j / d_j
+  }
+  // (No branch per pivot: a run-time input dimension is handled by the lanes' masks alone — a pivot beyond a slot's dimension moves
+  // zeros — and the whole batch is skipped when no slot has an input.  Branches on m here cost more than they save: sixteen
+  // control-flow joins with thirty-two live values each.)
+  template<int J>
+  NMPC_D static void batchForward(S (&a)[MM], S (&y)[MM], bool & ok, int c, int m_lane)
+  {
+    if constexpr(J < MM)
+    {
+      batchPivot<J>(a, y, ok, c, m_lane);
+      batchForward<J + 1>(a, y, ok, c, m_lane);
+    }
+  }
+  template<int K>
+  NMPC_D static void batchBackward(const S (&a)[MM], S (&y)[MM])
+  {
+    if constexpr(K >= 1)
+    {
+      const S xk = y[K];
+#pragma unroll
+      for(int i = K - 1; i >= 0; i--) // (row K - 1 first: it is the next column's x)
+      {
+        fmsubRow<K>(y[i], a[i], xk);
+      }
+      batchBackward<K - 1>(a, y);
+    }
+  }
+  /** a: columns of Quu_F, y: columns of [Qux_reg | Qu] -> y = Quu_F^-1 [Qux_reg | Qu] per lane group; false in the lanes of a group
+      whose factorisation failed. */
+  NMPC_D bool gainsBatch(S (&a)[MM], S (&y)[MM], int m_lane) const
+  {
+    const int c = freshLane() & 15;
+    bool ok = true;
+    asm volatile("s_nop 4"); // (an exec mask written by a VALU compare in front of a DPP instruction: five wait states)
+#ifndef NMPC_AMD_AB_SKIP_BATCH_FORWARD
+    batchForward<0>(a, y, ok, c, m_lane);
+#endif
+#ifndef NMPC_AMD_AB_SKIP_BATCH_BACKWARD
+    batchBackward<MM - 1>(a, y);
+#endif
+    return ok;
+  }
+  /** Prepare trip of the slot whose columns lane group G4 will hold: Q terms and regularisation as backwardStep computes them, the
+      operands of the value update into VV ([Qxx | Qx]) and the stash, Quu_F (lower triangle mirrored: the reference's LLT reads the
+      lower triangle only, :500) and [Qux_reg | Qu] through the staging into a[], y[] of lane group G4. */
+  template<int G4>
+  NMPC_D void gainsPrepare(Vec4 & VV, GainStash & st, S (&a)[MM], S (&y)[MM], int & m_lane, const LaneMap & mp, const S * r, S lambda, int m) const
+  {
+    S * W = waveScratch(0);
+    StepCtx c;
+    c.VV = VV;
+    c.ok = true;
+    Vec4 F0, F1, L0, L1, L2;
+    stepQTerms(c, mp, r, F0, F1, L0, L1, L2);
+    if(cfg.reg_type == 2)
+    {
+      stepRegType2(c, lambda, F0, F1, L0, L1, L2);
+    }
+    else if(cfg.reg_type == 1)
+    {
+      stepRegType1(c, lambda);
+    }
+    const int fl = freshLane(), q = fl >> 4, col = colOf(fl & 15);
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      W[wT + (4 * rr + q) * kTrLd + col] = c.QuuF[rr];
+    }
+    fence();
+    Vec4 Aq = {0, 0, 0, 0}, R = {0, 0, 0, 0}, QQ = {0, 0, 0, 0};
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      const int row = 4 * rr + q;
+      const S mirrored = W[wT + col * kTrLd + row]; // entry (col, row)
+      Aq[rr] = (row >= col) ? c.QuuF[rr] : mirrored;
+      const S qu_c = fromLane(c.qurow, 16 * qN + laneOfCol(row & 15));
+      R[rr] = (col < N) ? c.QuxR[rr] : ((col == N) ? qu_c : 0.0);
+      QQ[rr] = (col < N) ? c.Qux[rr] : ((col == N) ? qu_c : 0.0);
+    }
+#pragma unroll
+    for(int rr = 0; rr < 4; rr++)
+    {
+      const int row = 4 * rr + q;
+      const S qx_c = fromLane(c.qxrow, 16 * qN + laneOfCol(row & 15));
+      VV[rr] = (col < N) ? c.Qxx[rr] : ((col == N && row < N) ? qx_c : 0.0); // [Qxx | Qx]: what the value update starts from
+    }
+    st.Quu = c.Quu;
+    st.QQ = QQ;
+    fence(); // (the mirror has been read: the staging aliases it)
+    S * Wc = W + col * kStLd + 4 * q;
+#pragma unroll
+    for(int rr = 0; rr < 4; rr++)
+    {
+      Wc[wStA + rr] = Aq[rr];
+      Wc[wStR + rr] = R[rr];
+    }
+    fence();
+    if(q == G4)
+    {
+      const S * colp = W + col * kStLd;
+#pragma unroll
+      for(int row = 0; row < MM; row++)
+      {
+        a[row] = colp[wStA + 4 * (row & 3) + (row >> 2)];
+        y[row] = colp[wStR + 4 * (row & 3) + (row >> 2)];
+      }
+      m_lane = m;
+    }
+    fence();
+  }
+  /** Complete trip: the solved columns of lane group G4 back to the natural layout (A = - x where the slot has inputs and the
+      column is one of [K | k]), then the value update, the symmetrisation and the gain record as backwardStep does them. */
+  template<int G4>
+  NMPC_D void gainsComplete(Vec4 & VV, const GainStash & st, const S (&y)[MM], bool ok_now, bool & ok, const LaneMap & mp,
+                            const LaneAddr & la_sweep, const S * r, int slot, int b, int i, int m) const
+  {
+    S * W = waveScratch(0);
+    LaneAddr la = la_sweep;
+    asm volatile("" : "+v"(la.ew_equ), "+v"(la.eqx_rq), "+v"(la.rx_tw), "+v"(la.tr_trn));
+    const int fl = freshLane(), q = fl >> 4, col = colOf(fl & 15);
+    fence();
+    if(q == G4)
+    {
+      S * colp = W + col * kStLd;
+#pragma unroll
+      for(int row = 0; row < MM; row++)
+      {
+        colp[wStR + 4 * (row & 3) + (row >> 2)] = y[row];
+      }
+    }
+    fence();
+    StepCtx c;
+    c.ok = ok && ok_now;
+    c.Quu = st.Quu;
+    c.Qux = st.QQ; // (column n holds Qu: it only reaches row n of Qux^T A, which is not part of the value function)
+    c.Qxx = VV;
+    c.qxcol = VV;
+    c.inv_u = r[mp.oInvU];
+    const S * Wc = W + col * kStLd + 4 * q + wStR;
+    c.A = Vec4{0, 0, 0, 0};
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      c.A[rr] = (4 * rr + q < m && col <= N) ? -1 * Wc[rr] : 0.0;
+    }
+    fence(); // (the scratch is written again below)
+    S kn = 0;
+#pragma unroll
+    for(int rr = 0; rr < KM; rr++)
+    {
+      kn += c.A[rr] * c.A[rr];
+    }
+    kn += fromLane(kn, fl ^ 16);
+    kn += fromLane(kn, fl ^ 32);
+    stepValueTail(c, st.QQ, kn, m, la, q, col);
+    fence();
+    stepFinish(c, mp, W, slot, la);
+    fence();
+    stepStoreGains(c, b, i);
+    VV = c.VV;
+    ok = c.ok;
+  }
+
   /** k_i, K_i -> the instance's gain record (:529-530); not after a failed factorisation: backwardPass() returned before storing (:505-508). */
   NMPC_D void stepStoreGains(const StepCtx & c, int b, int i) const
   {
@@ -2342,6 +2682,106 @@ struct TileSolver64
       const int lo = (hi - chunk + 1 > 0) ? hi - chunk + 1 : 0;
       for(int i = hi; i >= lo; i--)
       {
+        if constexpr(kBatchGains)
+        {
+          // The wave's first four slots: prepare trips, ONE factorisation for all of them (lane group = slot), complete trips.
+          // Straight-line code with compile-time slot indices (the stash lives in registers; no rotation).  A fifth slot (groups
+          // beyond 28 instances) takes the whole-wave factorisation below.
+          constexpr int kB4 = kPerWave < 4 ? kPerWave : 4;
+          // (Measured and not kept: a wave that owns ONE slot of the sweep taking the whole-wave factorisation instead of a batch of
+          // one — 3 % at 256 instances, but with both paths in the loop the batched one lost what it had gained at 4096:
+          // backward 11.6 -> 13.5 ms, profiles/r06_centroidal_gains_ab.txt.)
+          GainStash st[kB4];
+          S ga[MM], gy[MM];
+#pragma unroll
+          for(int k = 0; k < MM; k++)
+          {
+            ga[k] = 0; // (lane groups without a slot: m_lane = 0, nothing but zeros moves through their lanes)
+            gy[k] = 0;
+          }
+          int m_lane = 0, m_hi = 0;
+#pragma unroll
+          for(int e = 0; e < kB4; e++)
+          {
+            const int a = mw + kOwnerWaves * e;
+            if(a < n_act)
+            {
+              const int slot = uniform(actSlot(a));
+              const S * rec = recAt(parity, hi - i, a, chunk, n_act);
+              const int m = kDyn ? uniform(static_cast<int>(rec[mp.oM])) : MM;
+              if(e == 0)
+              {
+                gainsPrepare<0>(V[e], st[e], ga, gy, m_lane, mp, rec, uniformD(slotF(sLambda, slot)), m);
+              }
+              else if(e == 1)
+              {
+                gainsPrepare<1>(V[e], st[e], ga, gy, m_lane, mp, rec, uniformD(slotF(sLambda, slot)), m);
+              }
+              else if(e == 2)
+              {
+                gainsPrepare<2>(V[e], st[e], ga, gy, m_lane, mp, rec, uniformD(slotF(sLambda, slot)), m);
+              }
+              else
+              {
+                gainsPrepare<3>(V[e], st[e], ga, gy, m_lane, mp, rec, uniformD(slotF(sLambda, slot)), m);
+              }
+              m_hi = m > m_hi ? m : m_hi;
+            }
+          }
+          bool ok_lane = true;
+          if(uniform(m_hi) > 0)
+          {
+            ok_lane = gainsBatch(ga, gy, m_lane);
+          }
+          const unsigned long long ok_groups = __ballot(ok_lane);
+#pragma unroll
+          for(int e = 0; e < kB4; e++)
+          {
+            const int a = mw + kOwnerWaves * e;
+            if(a < n_act)
+            {
+              const int slot = uniform(actSlot(a));
+              const S * rec = recAt(parity, hi - i, a, chunk, n_act);
+              const int m = kDyn ? uniform(static_cast<int>(rec[mp.oM])) : MM;
+              bool ok = ((ok_mask >> e) & 1u) != 0;
+              const bool ok_now = ((ok_groups >> (16 * e)) & 1ull) != 0;
+              const int b = uniform(slotI(sB, slot));
+              if(e == 0)
+              {
+                gainsComplete<0>(V[e], st[e], gy, ok_now, ok, mp, la, rec, slot, b, i, m);
+              }
+              else if(e == 1)
+              {
+                gainsComplete<1>(V[e], st[e], gy, ok_now, ok, mp, la, rec, slot, b, i, m);
+              }
+              else if(e == 2)
+              {
+                gainsComplete<2>(V[e], st[e], gy, ok_now, ok, mp, la, rec, slot, b, i, m);
+              }
+              else
+              {
+                gainsComplete<3>(V[e], st[e], gy, ok_now, ok, mp, la, rec, slot, b, i, m);
+              }
+              ok_mask = ok ? ok_mask : (ok_mask & ~(1u << e));
+              profAdd(4, 1, 1);
+            }
+          }
+#pragma unroll
+          for(int e = kB4; e < kPerWave; e++)
+          {
+            const int a = mw + kOwnerWaves * e;
+            if(a < n_act)
+            {
+              const int slot = uniform(actSlot(a));
+              bool ok = ((ok_mask >> e) & 1u) != 0;
+              backwardStep(V[e], ok, mp, la, recAt(parity, hi - i, a, chunk, n_act), slot, uniform(slotI(sB, slot)), i,
+                           uniformD(slotF(sLambda, slot)), e);
+              ok_mask = ok ? ok_mask : (ok_mask & ~(1u << e));
+              profAdd(4, 1, 1);
+            }
+          }
+          continue;
+        }
         if constexpr(kBatchQP)
         {
 #pragma nounroll
@@ -2440,7 +2880,11 @@ struct TileSolver64
         // the last bit.  double: the two copies agree bit for bit (tests, soak) — and with one copy the centroidal
         // problem's rollouts take 10.1 instead of 6.6 ms at 4096 instances (measured A/B on one box, round 4; a side effect
         // of the register allocation that was not tracked down), so double keeps two.
+#ifdef NMPC_AMD_AB_ONE_LIN_COPY
+        if constexpr(true)
+#else
         if constexpr(kF32)
+#endif
         {
           int nc = n_chunk;
           asm volatile("" : "+s"(nc));
@@ -2506,7 +2950,7 @@ struct TileSolver64
       int per_instance = (2 * s > kTerm) ? 2 * s : kTerm;
       per_instance = (per_instance > kRingDepth * kRingStride) ? per_instance : kRingDepth * kRingStride; // (line search: nominal ring)
       int g = room / per_instance;
-      g = g > kT64MaxGroup ? kT64MaxGroup : g;
+      g = g > kGroupMax ? kGroupMax : g;
       // every workgroup gets work, and the same amount: rounds = passes a workgroup makes over its groups with the largest group
       // the LDS holds; the groups are then as small as that number of rounds allows (8200 instances on 256 CUs: two rounds
       // of 17 instead of a round of 32 and one straggler group)

@@ -21,7 +21,14 @@ The CPU baseline leg runs first, the GPU legs last; the number of timed blocks i
 
 After the timed job the default (c2, nominal) run also measures SURVEY.md 8(d)'s two timing modes with the same handle —
 m1 (termination tests disabled, N = 50 iterations forced) and m2 (solve to convergence, max_iter 500) — and reports them as
-config.m1_value / config.m2_value (batch-iterations/s): outside the timed region, a few solves each.
+config.m1_value / config.m2_value (batch-iterations/s): outside the timed region, a few solves each; with the CPU oracle's rate in the
+same mode beside each (config.m1.cpu_value / config.m2.cpu_value), M2 with eight batches in flight on a pool of handles
+(config.m2_overlapped_value) and M2 as a STREAM of 32768 / 262144 instances through the 4096 slots of one handle
+(config.m2_stream_value / config.m2_stream_sustained_value: nmpc_hip_ddp_solve_stream).
+
+Multi-GPU: `python bench.py --gpus N` with N > 1 outside a launcher starts the N ranks itself (torch.distributed.run on 127.0.0.1) and
+refuses a job with fewer visible devices than ranks (--share-devices: test boxes).  BASELINE config 5 (manipulator, 65536 instances
+over 8 GPUs, one RCCL all-gather of the results):   python bench.py --gpus 8 --workload c5 --global-batch 65536
 
 The default line finally carries `secondary`: the other workloads of DESIGN.md 5's table (c3, c4, c4f64, c5, fmpc, centroidal), each
 on its own handle, >= --secondary-seconds of back-to-back solves after the c2 job, with value, ms_per_step, kernel and roofline
@@ -689,6 +696,35 @@ def main():
 
             extras["m2_overlapped"] = pooled_m2(0)
             extras["m2_overlapped"]["whole_solve_launches_value"] = pooled_m2(-1)["value"]
+
+            # M2 as a STREAM: a queue of N >> 4096 instances through the 4096 slots of ONE handle (nmpc_hip_ddp_solve_stream): the slot of
+            # an instance that has converged takes the next one of the queue at the next round boundary (the successor of the pool: no
+            # batch boundaries at all; every instance returns the bits of its lone solve, tests/test_gpu_stream.py).  The rate is
+            # instance-iterations / 4096 / device time (HIP events around the whole schedule, staging copies excluded).  32768 instances:
+            # the queue holds ~36 that never converge, and ONE such instance is a chain of 500 iterations x ~47 us = 23.5 ms that
+            # nothing shortens — 157 batch-iterations of work cannot take less, i.e. <= 6.7 k whatever the schedule; 262144 instances
+            # amortise that tail: the sustained rate.
+            def stream_leg(n_inst, span):
+                wl_s = workloads.cartpole_batch(B=n_inst, T=wl.T, seed=args.seed)
+                st = nmpc_amd.DDPSolverBatch(problem, wl.B, device=device_index)
+                sc = st.config()
+                sc.print_level, sc.horizon_steps, sc.trace_level = 0, wl.T, 0
+                for key, val in mode_config("m2", 500).items():
+                    setattr(sc, key, val)
+                best = None
+                for _ in range(2):
+                    r = st.solveStream(wl_s.t0, wl_s.x0, wl_s.u_init, span=span)
+                    if best is None or r.device_ms < best.device_ms:
+                        best = r
+                it_s = float(best.iters.sum())
+                res = {"value": it_s / wl.B / (best.device_ms * 1e-3), "instances": n_inst, "slots": wl.B, "span": span, "rounds": best.rounds,
+                       "device_ms": best.device_ms, "mean_iterations": it_s / n_inst, "solves_per_s": n_inst / (best.device_ms * 1e-3),
+                       "status_counts": {str(k): int(v) for k, v in zip(*np.unique(best.status, return_counts=True))}}
+                del st
+                return res
+
+            extras["m2_stream"] = stream_leg(32768, 16)
+            extras["m2_stream"]["sustained"] = stream_leg(262144, 8)
         if args.workload == "c3":
             # 1024 bipedal instances are 64 quad workgroups on 256 CUs: the single-batch rate is a latency, not the chip's rate.
             # Four batches in flight on four handles / streams (DDPSolverPool) is how a caller with more than one batch fills it.
@@ -773,6 +809,13 @@ def main():
             config["m2_overlapped"] = dict(extras["m2_overlapped"], note="M2 with 32 consecutive batches on eight handles / streams "
                                            "(nmpc_amd.DDPSolverPool) under the ragged-convergence schedule: sustained rate with the convergence "
                                            "tails overlapped; whole_solve_launches_value: the same pool with one launch per solve")
+        if "m2_stream" in extras:
+            config["m2_stream_value"] = extras["m2_stream"]["value"]
+            config["m2_stream_sustained_value"] = extras["m2_stream"]["sustained"]["value"]
+            config["m2_stream"] = dict(extras["m2_stream"], note="M2 as a stream: 32768 instances to convergence through the 4096 slots of ONE "
+                                       "handle, freed slots refilled at round boundaries (nmpc_hip_ddp_solve_stream); batch-iterations/s-equivalent = "
+                                       "instance-iterations / 4096 / device time.  Bounded by the 23.5 ms chain of an instance that runs to max_iter "
+                                       "500; `sustained`: 262144 instances (the tail amortised)")
         if "pooled" in extras:
             config["pooled_value"] = extras["pooled"]["value"]
             config["pooled"] = dict(extras["pooled"], note="the same workload with four batches in flight on four handles / streams "

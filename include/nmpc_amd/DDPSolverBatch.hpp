@@ -257,6 +257,96 @@ public:
     return ok;
   }
 
+  /** \brief Results of solveStream(): controlData() and the verdict of every instance of the queue. */
+  struct StreamResult
+  {
+    std::vector<ControlData> control_data; //!< per instance (DDPSolver::controlData)
+    std::vector<int> status; //!< 1 converged (solve() would return true), 0 max_iter exhausted, -1 failure due to large lambda
+    std::vector<int> iters; //!< iterations of each instance (traceDataList().back().iter)
+    int rounds = 0;
+    double device_ms = 0;
+  };
+
+  /** \brief A QUEUE of instances through the solver's batch_size slots (nmpc_hip_ddp_solve_stream): any number of problems, each
+      solved to ITS convergence as DDPSolver::solve does (DDPSolver.hpp:26-141, 115-123); the slot of an instance that has finished
+      takes the next one of the queue after at most `span` (0: 16) further iterations.  Every instance returns the bits of its lone
+      solve on the same kernel family.  State dimension <= 4, one input, fp64; shared problem object and constant limits. */
+  StreamResult solveStream(const std::vector<double> & current_t,
+                           const std::vector<StateDimVector> & current_x,
+                           const std::vector<std::vector<InputDimVector>> & initial_u_list,
+                           int span = 0)
+  {
+    const int T = config_.horizon_steps;
+    const size_t N = current_x.size();
+    if(current_t.size() != N || initial_u_list.size() != N || N == 0)
+    {
+      throw std::invalid_argument("current_t / current_x / initial_u_list should have one entry per instance of the queue.");
+    }
+    if(!current_t.empty())
+    {
+      sampleInputLimits(std::vector<double>(static_cast<size_t>(batch_size_), current_t[0]));
+    }
+    ensureHandle();
+    pushState();
+    std::vector<double> x0(N * StateDim), u0(N * T * MM, 0.0);
+    for(size_t b = 0; b < N; b++)
+    {
+      if(static_cast<int>(initial_u_list[b].size()) != T)
+      {
+        throw std::invalid_argument("initial_u_list length should be " + std::to_string(T) + " but " + std::to_string(initial_u_list[b].size()) + ".");
+      }
+      for(int j = 0; j < StateDim; j++)
+      {
+        x0[b * StateDim + j] = current_x[b][j];
+      }
+      for(int i = 0; i < T; i++)
+      {
+        for(int a = 0; a < static_cast<int>(initial_u_list[b][i].size()) && a < MM; a++)
+        {
+          u0[(b * T + i) * MM + a] = initial_u_list[b][i][a];
+        }
+      }
+    }
+    check(nmpc_hip_ddp_solve_stream(handle_, static_cast<int>(N), current_t.data(), x0.data(), u0.data(), span));
+    std::vector<double> X(N * (T + 1) * StateDim), U(N * T * MM), C(N * (T + 1));
+    StreamResult r;
+    r.status.resize(N);
+    r.iters.resize(N);
+    check(nmpc_hip_ddp_stream_get(handle_, NMPC_HIP_FIELD_X, X.data(), X.size() * sizeof(double)));
+    check(nmpc_hip_ddp_stream_get(handle_, NMPC_HIP_FIELD_U, U.data(), U.size() * sizeof(double)));
+    check(nmpc_hip_ddp_stream_get(handle_, NMPC_HIP_FIELD_COST, C.data(), C.size() * sizeof(double)));
+    check(nmpc_hip_ddp_stream_get(handle_, NMPC_HIP_FIELD_STATUS, r.status.data(), N * sizeof(int)));
+    check(nmpc_hip_ddp_stream_get(handle_, NMPC_HIP_FIELD_ITERS, r.iters.data(), N * sizeof(int)));
+    float ms = 0;
+    check(nmpc_hip_ddp_last_stream_stats(handle_, &r.rounds, &ms));
+    r.device_ms = ms;
+    r.control_data.resize(N);
+    for(size_t b = 0; b < N; b++)
+    {
+      ControlData & cd = r.control_data[b];
+      cd.x_list.resize(static_cast<size_t>(T + 1));
+      cd.u_list.resize(static_cast<size_t>(T));
+      cd.cost_list.resize(T + 1);
+      for(int i = 0; i <= T; i++)
+      {
+        for(int j = 0; j < StateDim; j++)
+        {
+          cd.x_list[static_cast<size_t>(i)][j] = X[(b * (T + 1) + i) * StateDim + j];
+        }
+        cd.cost_list[i] = C[b * (T + 1) + i];
+      }
+      for(int i = 0; i < T; i++)
+      {
+        cd.u_list[static_cast<size_t>(i)].resize(MM);
+        for(int a = 0; a < MM; a++)
+        {
+          cd.u_list[static_cast<size_t>(i)][a] = U[(b * T + i) * MM + a];
+        }
+      }
+    }
+    return r;
+  }
+
   /** \brief solve() without waiting for the device: the inputs are validated and staged (the arguments may be reused when the call
       returns), the solve is queued on the handle's stream; wait() blocks until it is done and fetches the results, after which the
       accessors (controlData(b), traceDataList(b), ...) hold them.  What DDPSolverPool overlaps consecutive batches with.

@@ -87,9 +87,17 @@ struct DeviceBuffersT
   const int * n_active = nullptr; //!< device word: instances in the dense prefix of this launch (nullptr: B)
   int iter_begin = 0; //!< first iteration of this launch (1: fresh start with the initial rollout; > 1: resume)
   int iter_end = 0; //!< last iteration of this launch (<= max_iter); 0: not a resumable launch
-  S * resume = nullptr; //!< [tile][kResumeRows][64]: lambda, dlambda, J_cur, running (1 / 0) between launches
+  S * resume = nullptr; //!< [tile][kResumeRows][64]: lambda, dlambda, J_cur, running (1 / 0), iterations done, between launches
+  // ---- streamed solves (nmpc_hip_ddp_solve_stream, stream_schedule.hpp; round 6): the handle's B positions are SLOTS that a
+  // queue of N >> B instances passes through.  Launches number their iterations per instance (row 4 of `resume`), not per launch:
+  //   stream_mode 1  the slots [*first_active, *n_active) have just been filled: initial rollout (DDPSolver.hpp:83-95), state parked
+  //                  (workgroups below *first_active — a multiple of 64 — exit at once: they hold instances in mid-solve);
+  //   stream_mode 2  every slot of [0, *n_active) whose instance still iterates runs at most iter_end further iterations, or up
+  //                  to its max_iter-th.
+  int stream_mode = 0;
+  const int * first_active = nullptr; //!< device word (stream_mode 1), or nullptr: 0
 };
-constexpr int kResumeRows = 4;
+constexpr int kResumeRows = 5;
 /** The reference computes in double (DDPProblem.h:20-35): every kernel but the fp32 tile kernel uses this one. */
 using DeviceBuffers = DeviceBuffersT<double>;
 

@@ -1899,12 +1899,19 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     }
     return running;
   }
-  NMPC_D void parkState(bool still_running) const
+  NMPC_D void parkState(bool still_running, int iterations_done = 0) const
   {
     resumeWord(0) = lambda;
     resumeWord(1) = dlambda;
     resumeWord(2) = J_cur;
     resumeWord(3) = still_running ? 1.0 : 0.0;
+    resumeWord(4) = static_cast<double>(iterations_done); // (streamed solves: the instance's own iteration count so far)
+  }
+  /** Streamed solves (DeviceBuffers::stream_mode): 0 none, 1 initial rollout of freshly filled slots, 2 further iterations. */
+  template<bool kResumable>
+  NMPC_D int streamMode() const
+  {
+    return kResumable ? buf.stream_mode : 0;
   }
 
   /** \param runBackward (need) -> ok: one backward pass for the lanes in `need`, entered by the whole wave */
@@ -1920,7 +1927,14 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     J_cand = 0;
     J_cur = 0;
     phaseStart();
-    const bool resumed = kResumable && buf.iter_begin > 1;
+    const int smode = streamMode<kResumable>();
+    const bool resumed = kResumable && (smode == 2 || (smode == 0 && buf.iter_begin > 1));
+    if(smode == 1)
+    {
+      valid = valid && resumeWord(3) != 0.0; // (the refill marks the slots it has put an instance into)
+    }
+    const int it_base = (smode == 2 && valid) ? static_cast<int>(resumeWord(4)) : 0; // this instance's iterations before this launch
+    int it_done = it_base;
     bool active = valid; // this lane still iterates
     double tr[NMPC_HIP_NTRACE];
 #pragma unroll
@@ -1949,8 +1963,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       }
     }
     const bool took_part = active; // (a resumed launch leaves the results of instances that had finished before it alone)
-    const int iter_first = resumed ? buf.iter_begin : 1;
-    const int iter_last = (kResumable && buf.iter_end > 0 && buf.iter_end < cfg.max_iter) ? buf.iter_end : cfg.max_iter;
+    const int iter_first = (resumed && smode == 0) ? buf.iter_begin : 1;
+    const int iter_last = (smode == 1) ? 0 : ((smode == 2) ? buf.iter_end
+                                              : ((kResumable && buf.iter_end > 0 && buf.iter_end < cfg.max_iter) ? buf.iter_end : cfg.max_iter));
 
     int retval = 0;
     for(int iter = iter_first; iter <= iter_last; iter++)
@@ -1966,7 +1981,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
         {
           tr[f] = 0;
         }
-        tr[NMPC_HIP_TRACE_ITER] = iter;
+        tr[NMPC_HIP_TRACE_ITER] = iter + it_base;
         tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
         retval = 0;
       }
@@ -2102,8 +2117,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       }
       if(active)
       {
-        Base::writeTraceRow(iter, tr);
-        if(retval != 0)
+        Base::writeTraceRow(iter + it_base, tr);
+        it_done = iter + it_base;
+        if(retval != 0 || (smode == 2 && it_done >= cfg.max_iter)) // (streamed: the instance's own max_iter-th iteration, :115-123)
         {
           active = false;
         }
@@ -2127,7 +2143,11 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       Base::elem(buf.dV, 2, 1) = dV1;
       if constexpr(kResumable)
       {
-        if(buf.iter_end > 0)
+        if(smode != 0)
+        {
+          parkState(active, it_done);
+        }
+        else if(buf.iter_end > 0)
         {
           parkState(active && iter_last < cfg.max_iter);
         }
@@ -2149,7 +2169,14 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     k_rel_norm = 0;
     J_cand = 0;
     phaseStart();
-    const bool resumed = kResumable && buf.iter_begin > 1; // (see solveMasterWith)
+    const int smode = streamMode<kResumable>(); // (see solveMasterWith)
+    const bool resumed = kResumable && (smode == 2 || (smode == 0 && buf.iter_begin > 1));
+    if(smode == 1)
+    {
+      valid = valid && resumeWord(3) != 0.0;
+    }
+    const int it_base = (smode == 2 && valid) ? static_cast<int>(resumeWord(4)) : 0;
+    int it_done = it_base;
     bool resumed_running = false;
     if(resumed)
     {
@@ -2196,8 +2223,9 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     int retval = 0;
     bool active = resumed ? resumed_running : valid; // this lane still iterates
     const bool took_part = active; // (a resumed launch leaves the results of instances that had finished before it alone)
-    const int iter_first = resumed ? buf.iter_begin : 1;
-    const int iter_last = (kResumable && buf.iter_end > 0 && buf.iter_end < cfg.max_iter) ? buf.iter_end : cfg.max_iter;
+    const int iter_first = (resumed && smode == 0) ? buf.iter_begin : 1;
+    const int iter_last = (smode == 1) ? 0 : ((smode == 2) ? buf.iter_end
+                                              : ((kResumable && buf.iter_end > 0 && buf.iter_end < cfg.max_iter) ? buf.iter_end : cfg.max_iter));
     // Extra masters: whether the FIRST pass of a line search is a wide one (twelve step sizes: waves 2 and 3 roll out too) is
     // predicted from the workgroup's previous search — wide if an instance went beyond the master's lane groups then.  The
     // nominal regime (first step size accepted) keeps the narrow pass, in which wave 2 only prefetches and the master never
@@ -2442,7 +2470,7 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
         {
           tr[f] = 0;
         }
-        tr[NMPC_HIP_TRACE_ITER] = iter;
+        tr[NMPC_HIP_TRACE_ITER] = iter + it_base;
         tr[NMPC_HIP_TRACE_ALPHA_IDX] = -1;
         tr[NMPC_HIP_TRACE_N_BACKWARD] = n_backward;
         if(bw_ok)
@@ -2461,9 +2489,10 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
           tr[NMPC_HIP_TRACE_LAMBDA] = lambda;
           tr[NMPC_HIP_TRACE_DLAMBDA] = dlambda;
         }
-        Base::writeTraceRow(iter, tr);
-        writeLastRow(tr, iter);
-        if(retval != 0)
+        Base::writeTraceRow(iter + it_base, tr);
+        writeLastRow(tr, iter + it_base);
+        it_done = iter + it_base;
+        if(retval != 0 || (smode == 2 && it_done >= cfg.max_iter))
         {
           active = false;
         }
@@ -2487,7 +2516,11 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
       Base::elem(buf.dV, 2, 1) = dV1;
       if constexpr(kResumable)
       {
-        if(buf.iter_end > 0)
+        if(smode != 0)
+        {
+          parkState(active, it_done);
+        }
+        else if(buf.iter_end > 0)
         {
           parkState(active && iter_last < cfg.max_iter);
         }
@@ -2506,6 +2539,18 @@ __global__ __launch_bounds__(2 * kLanesPerBlock) void ddp_solve_tpi2w_kernel(con
   extern __shared__ __attribute__((aligned(16))) double lds_2w[];
   const int wave = threadIdx.x / kLanesPerBlock;
   const int b = blockIdx.x * kLanesPerBlock + (threadIdx.x % kLanesPerBlock);
+  int first = 0;
+  if constexpr(kResumable)
+  {
+    // streamed solves, the rollout of freshly filled slots: the workgroups below hold instances in mid-solve and stay out of it
+    // (*first_active is a multiple of 64: no workgroup holds both kinds)
+    first = (buf.stream_mode == 1 && buf.first_active) ? *buf.first_active : 0;
+    if(static_cast<int>(blockIdx.x + 1) * kLanesPerBlock <= first
+       || (buf.stream_mode == 1 && buf.n_active && static_cast<int>(blockIdx.x) * kLanesPerBlock >= *buf.n_active)) // (... and the empty slots behind)
+    {
+      return;
+    }
+  }
   // kOwnProblem: every instance has its own problem object (nmpc_hip_ddp_set_model_params_batch).  A separate
   // instantiation: with it the problem's fields live in VGPRs, which costs the shared-object kernel ~1 % if merged in.
   const Problem mine = kOwnProblem ? instanceProblem(problem, buf, b) : problem;
@@ -2515,7 +2560,7 @@ __global__ __launch_bounds__(2 * kLanesPerBlock) void ddp_solve_tpi2w_kernel(con
     if constexpr(kResumable)
     {
       // (positions [0, *n_active) hold the instances that still iterate: the host's compaction between launches, capi.hip)
-      solver.template solveMaster<true>(b < (buf.n_active ? *buf.n_active : buf.B));
+      solver.template solveMaster<true>(b >= first && b < (buf.n_active ? *buf.n_active : buf.B));
     }
     else
     {

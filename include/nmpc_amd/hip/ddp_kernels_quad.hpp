@@ -758,6 +758,17 @@ __global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const P
   using Solver = QuadSolver<Problem, kConstrained, kFanOut>;
   extern __shared__ __attribute__((aligned(16))) double lds_quad[];
   const int wl = threadIdx.x % 64;
+  int first = 0;
+  if constexpr(kResumable)
+  {
+    // streamed solves, the rollout of freshly filled slots (DeviceBuffers::stream_mode 1): see ddp_solve_tpi2w_kernel
+    first = (buf.stream_mode == 1 && buf.first_active) ? *buf.first_active : 0;
+    if(static_cast<int>(blockIdx.x + 1) * kQuadInstances <= first
+       || (buf.stream_mode == 1 && buf.n_active && static_cast<int>(blockIdx.x) * kQuadInstances >= *buf.n_active)) // (... and the empty slots behind)
+    {
+      return;
+    }
+  }
   // in the lane-per-instance roles (master, forward helper) every group of 16 lanes mirrors the workgroup's 16
   // instances: same inputs, same instruction stream, hence the same values and decisions, written to the same places
   const int b = blockIdx.x * kQuadInstances + wl % kQuadInstances;
@@ -771,7 +782,7 @@ __global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const P
   {
     if constexpr(kResumable)
     {
-      solver.template solveMasterQuad<true>(b < (buf.n_active ? *buf.n_active : buf.B));
+      solver.template solveMasterQuad<true>(b >= first && b < (buf.n_active ? *buf.n_active : buf.B));
     }
     else
     {

@@ -315,6 +315,18 @@ extern "C"
       counterpart: diagnostics. */
   int nmpc_hip_ddp_last_solve_launches(nmpc_hip_ddp_handle h, int * launches);
 
+  /** A QUEUE of n_instances problems (host arrays, reference layouts: t0 [N] or NULL, x0 [N][n], u_init [N][T][m]) through the
+      handle's B slots, N >> B: every instance is solved to ITS convergence (or its max_iter-th iteration) — DDPSolver::solve of
+      DDPSolver.hpp:26-141 once per instance, as a caller of the reference runs many problems through a few solver objects — and the
+      slot of an instance that has finished takes the next one of the queue at the next round boundary (`span` iterations, 0: 16;
+      include/nmpc_amd/hip/stream_schedule.hpp).  Every instance returns the bits of its lone solve on this kernel family.
+      Kernel families with resumable launches only (n <= 4, one input, fp64, shared problem object and limits); blocks until the
+      queue has drained.  Results: nmpc_hip_ddp_stream_get (X, U, COST, STATUS, ITERS, TRACE_LAST, DV; arrays of N instances). */
+  int nmpc_hip_ddp_solve_stream(nmpc_hip_ddp_handle h, int n_instances, const double * t0, const double * x0, const double * u_init, int span);
+  int nmpc_hip_ddp_stream_get(nmpc_hip_ddp_handle h, int field, void * out, size_t bytes);
+  /** Rounds of the last streamed solve and its device time (HIP events, input staging excluded) [msec]. */
+  int nmpc_hip_ddp_last_stream_stats(nmpc_hip_ddp_handle h, int * rounds, float * ms);
+
   /** Ask the HIP runtime for at least n hardware queues (GPU_MAX_HW_QUEUES; its default is 4).  Streams of one process are
       multiplexed onto them, and kernels of streams that share a queue run one after the other: a pool of handles overlaps only as
       many batches as there are queues.  The runtime reads the variable when it initialises, so this has to come before the first HIP

@@ -87,7 +87,7 @@ EXPORTS = (
     "nmpc_hip_ddp_destroy", "nmpc_hip_ddp_set_config", "nmpc_hip_ddp_get_config",
     "nmpc_hip_ddp_set_model_params", "nmpc_hip_ddp_set_model_params_batch", "nmpc_hip_ddp_set_input_limits_batch",
     "nmpc_hip_ddp_input_dims", "nmpc_hip_ddp_set_input_limits", "nmpc_hip_ddp_set_input_limits_horizon",
-    "nmpc_hip_ddp_set_input_limits_schedule", "nmpc_hip_ddp_solve", "nmpc_hip_ddp_solve_async", "nmpc_hip_ddp_request_hw_queues",
+    "nmpc_hip_ddp_set_input_limits_schedule", "nmpc_hip_ddp_solve", "nmpc_hip_ddp_solve_async", "nmpc_hip_ddp_request_hw_queues", "nmpc_hip_ddp_solve_stream", "nmpc_hip_ddp_stream_get", "nmpc_hip_ddp_last_stream_stats",
     "nmpc_hip_ddp_solve_device", "nmpc_hip_ddp_synchronize", "nmpc_hip_ddp_get", "nmpc_hip_ddp_get_device",
     "nmpc_hip_ddp_field_bytes", "nmpc_hip_ddp_last_solve_ms", "nmpc_hip_ddp_last_solve_phases", "nmpc_hip_ddp_timing_stats",
     "nmpc_hip_ddp_kernel_name", "nmpc_hip_ddp_kernel_name_for_batch", "nmpc_hip_ddp_set_kernel", "nmpc_hip_ddp_set_dispatch_batch",
@@ -148,6 +148,9 @@ def load():
     L.nmpc_hip_ddp_mpc_run.argtypes = [vp, dp, dp, dp, C.POINTER(MpcOptions), dp, dp, dp, ip, ip, ip, dp, dp]
     L.nmpc_hip_ddp_timing_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), dp, dp]
     L.nmpc_hip_ddp_request_hw_queues.argtypes = [C.c_int, ip]
+    L.nmpc_hip_ddp_solve_stream.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
+    L.nmpc_hip_ddp_stream_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.nmpc_hip_ddp_last_stream_stats.argtypes = [vp, ip, C.POINTER(C.c_float)]
     L.nmpc_hip_ddp_last_error.argtypes = []
     L.nmpc_hip_ddp_last_error.restype = C.c_char_p
     for name in EXPORTS:

@@ -15,6 +15,7 @@
 
 #include <nmpc_amd/hip/model_ops.hpp>
 #include <nmpc_amd/hip/ragged_schedule.hpp>
+#include <nmpc_amd/hip/stream_schedule.hpp>
 
 using nmpc_amd::hip::DeviceBuffers;
 using nmpc_amd::hip::ModelOps;
@@ -156,6 +157,16 @@ struct nmpc_hip_ddp_solver
   int * d_ragged_rank = nullptr; // [Bp] scratch of the compaction kernel
   int * d_ragged_used = nullptr; // [Bp / 2] trace rows in use per pair of the round being swapped
   nmpc_amd::hip::LaunchKnobs knobs; // kernel family / schedule choices of this handle (environment overrides read once at create)
+  // streamed solves (nmpc_hip_ddp_solve_stream): slot -> instance, the schedule's device words, the caller-facing arrays of the last stream
+  int * d_stream_id = nullptr; // [Bp]
+  int * d_stream_words = nullptr; // [kSwCount]
+  void * d_stream_io = nullptr; // inputs and outputs of the last streamed solve, reference layouts (stream_io_bytes allocated)
+  size_t stream_io_bytes = 0;
+  int stream_n = 0; // instances of the last streamed solve (0: none)
+  nmpc_amd::hip::StreamArrays stream_arrays = {};
+  int stream_rounds = 0;
+  long long stream_instance_iterations = 0;
+  float stream_ms = 0;
   bool ragged_ready = false; // all five ragged buffers are allocated and cleared (ensureRagged)
   bool ragged_unavailable = false; // their allocation failed once: the handle keeps to whole-solve launches
   int ragged_env = 0; // NMPC_HIP_DDP_RAGGED, read once at create: 1 forces the schedule on, -1 off (A/B measurements)
@@ -621,6 +632,7 @@ nmpc_amd::hip::SwapTable swapTable(const nmpc_hip_ddp_solver * s)
   tile(s->d_resume, nmpc_amd::hip::kResumeRows, e);
   tile(s->d_status, 1, 4);
   tile(s->d_sel, 1, 4); // (d_iters: exchanged by the compaction / replay-prepare kernels, which take the pairs' trace rows from it)
+  tile(s->d_stream_id, 1, 4); // (streamed solves: which instance of the queue sits in the slot)
   tile(s->d_qp_ret, T, 4);
   tile(s->d_qp_free, T, 4);
   tile(s->d_input_dim, T, 4);
@@ -693,6 +705,102 @@ int launchRagged(nmpc_hip_ddp_solver * s, hipStream_t st, DeviceBuffers buf, con
   }
   NMPC_HIP_TRY(hipGetLastError());
   s->last_ragged_rounds = rounds;
+  return NMPC_HIP_OK;
+}
+
+/** A queue of n_total instances through the handle's B slots (stream_schedule.hpp).  in / out: device arrays in the reference
+    layouts.  span: iterations per round. */
+int launchStream(nmpc_hip_ddp_solver * s, hipStream_t st, const nmpc_amd::hip::StreamArrays & io, int n_total, int span)
+{
+  using namespace nmpc_amd::hip;
+  int rc = ensureRagged(s);
+  if(rc != NMPC_HIP_OK)
+  {
+    return rc;
+  }
+  if(!s->d_stream_id)
+  {
+    rc = devAlloc(&s->d_stream_id, static_cast<size_t>(s->Bp));
+    if(rc == NMPC_HIP_OK)
+    {
+      rc = devAlloc(&s->d_stream_words, static_cast<size_t>(kSwCount));
+    }
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    NMPC_HIP_TRY(hipDeviceSynchronize()); // (devAlloc's clears are ordered on the NULL stream)
+  }
+  nmpc_amd::hip::ScopedKnobs knobs_guard(&s->knobs);
+  int * w = s->d_stream_words;
+  DeviceBuffers buf = makeBuffers(s);
+  buf.resume = s->d_resume;
+  buf.n_active = w + kSwPrefix;
+  buf.first_active = w + kSwFirst;
+  buf.iter_begin = 1;
+  buf.iter_end = span;
+  const SwapTable tab = swapTable(s);
+  const dim3 swap_grid(static_cast<unsigned>((s->Bp / 2 + 63) / 64), 64);
+  const int wg_size = std::strcmp(s->ops->kernel_name(s->B, s->cfg), "ddp_solve_quad_kernel") == 0 ? 16 : 64;
+  const dim3 fill_grid(static_cast<unsigned>(s->B), static_cast<unsigned>((s->T * s->MM + 1023) / 1024));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  NMPC_HIP_TRY(hipEventCreate(&ev0));
+  NMPC_HIP_TRY(hipEventCreate(&ev1));
+  NMPC_HIP_TRY(hipEventRecord(ev0, st));
+  hipLaunchKernelGGL(stream_begin_kernel, dim3(1), dim3(64), 0, st, w, n_total);
+  NMPC_HIP_TRY(hipMemsetAsync(s->d_stream_id, 0xff, static_cast<size_t>(s->Bp) * sizeof(int), st)); // every slot empty (-1)
+  auto refill = [&]() -> hipError_t
+  {
+    hipLaunchKernelGGL(stream_plan_kernel, dim3(1), dim3(64), 0, st, w, s->B);
+    hipLaunchKernelGGL(stream_fill_kernel, fill_grid, dim3(256), 0, st, buf, io, s->d_stream_id, w, s->N, s->MM, s->d_t0, s->d_x0);
+    hipLaunchKernelGGL(stream_fill_done_kernel, dim3(1), dim3(64), 0, st, w);
+    buf.stream_mode = 1; // the initial rollout of the slots filled just now
+    return s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
+  };
+  hipError_t le = refill();
+  int rounds = 0, done = 0;
+  // an instance leaves after at most ceil(max_iter / span) rounds; a slot serves ceil(n_total / B) instances (+ slack for the rounds
+  // in which too little finished for a compaction to pay)
+  const long long max_rounds = 4ll * (static_cast<long long>((n_total + s->B - 1) / s->B) + 1) * ((std::max(s->cfg.max_iter, 1) + span - 1) / span + 1);
+  while(le == hipSuccess && done < n_total && rounds < max_rounds)
+  {
+    for(int k = 0; k < 4 && le == hipSuccess; k++, rounds++)
+    {
+      buf.stream_mode = 2;
+      le = s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
+      if(le != hipSuccess)
+      {
+        break;
+      }
+      hipLaunchKernelGGL(stream_extract_kernel, dim3(static_cast<unsigned>(s->B)), dim3(256), 0, st, buf, io, s->d_stream_id, w, s->N, s->MM);
+      hipLaunchKernelGGL((ragged_compact_kernel<double>), dim3(1), dim3(1024), 0, st, s->d_resume, s->d_ragged_rank, s->d_ragged_pairs,
+                         s->d_ragged_used, s->d_ragged_words, w + kSwPrefix, s->d_iters, wg_size);
+      hipLaunchKernelGGL(ragged_swap_kernel, swap_grid, dim3(256), 0, st, tab, s->d_ragged_pairs, s->d_ragged_used, s->d_ragged_words);
+      le = refill();
+    }
+    if(le != hipSuccess)
+    {
+      break;
+    }
+    NMPC_HIP_TRY(hipMemcpyAsync(&done, w + kSwDone, sizeof(int), hipMemcpyDeviceToHost, st));
+    NMPC_HIP_TRY(hipStreamSynchronize(st));
+  }
+  if(le != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return fail(NMPC_HIP_ERR_HIP, std::string("streamed solve: ") + hipGetErrorString(le));
+  }
+  NMPC_HIP_TRY(hipGetLastError());
+  NMPC_HIP_TRY(hipEventRecord(ev1, st));
+  NMPC_HIP_TRY(hipEventSynchronize(ev1));
+  NMPC_HIP_TRY(hipEventElapsedTime(&s->stream_ms, ev0, ev1));
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  s->stream_rounds = rounds;
+  if(done < n_total)
+  {
+    return fail(NMPC_HIP_ERR_RUNTIME, "streamed solve: the queue did not drain (" + std::to_string(done) + " of " + std::to_string(n_total) + ")");
+  }
   return NMPC_HIP_OK;
 }
 
@@ -1090,7 +1198,8 @@ extern "C"
     void * ptrs[] = {s->d_t0,     s->d_x0,     s->d_X,   s->d_U,      s->d_cost,    s->d_kff,       s->d_Kfb,
                      s->d_trace,  s->d_trace_last, s->d_dV, s->d_status, s->d_iters, s->d_sel,     s->d_qp_ret,
                      s->d_qp_free, s->d_input_dim, s->d_wpi_ws, s->d_params_batch, s->d_lim_batch, s->d_lim_steps, s->d_phase_ticks, s->d_stage_in,
-                     s->d_stage_out, s->d_resume, s->d_ragged_words, s->d_ragged_pairs, s->d_ragged_rank, s->d_ragged_used};
+                     s->d_stage_out, s->d_resume, s->d_ragged_words, s->d_ragged_pairs, s->d_ragged_rank, s->d_ragged_used,
+                     s->d_stream_id, s->d_stream_words, s->d_stream_io};
     for(void * p : ptrs)
     {
       if(p)
@@ -1592,6 +1701,130 @@ extern "C"
     s->queued_solve = false;
     NMPC_HIP_TRY(hipEventSynchronize(s->ev_staged));
     return rc;
+  }
+
+  int nmpc_hip_ddp_solve_stream(nmpc_hip_ddp_handle s, int n_instances, const double * t0, const double * x0, const double * u_init, int span)
+  {
+    if(!s || !x0 || !u_init || n_instances < 1)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle, x0 or u_init, or no instances");
+    }
+    if(s->cfg.with_input_constraint && !s->has_limits)
+    {
+      return fail(NMPC_HIP_ERR_RUNTIME, "with_input_constraint is set but no input limits were given "
+                                        "(setInputLimitsFunc, DDPSolver.h:282-285)");
+    }
+    if(s->elem != 8 || s->ops->resumable_supported == nullptr || !s->ops->resumable_supported(s->B, s->cfg, s->d_params_batch ? 1 : 0))
+    {
+      return fail(NMPC_HIP_ERR_RUNTIME, "a streamed solve needs a kernel family with resumable launches: the quad / two-wave kernels "
+                                        "(n <= 4, one input, fp64) with a shared problem object");
+    }
+    if(s->d_lim_batch != nullptr || s->lim_steps_per_instance != 0 || s->d_lim_steps != nullptr)
+    {
+      return fail(NMPC_HIP_ERR_RUNTIME, "a streamed solve takes input limits shared by all instances and constant along the horizon");
+    }
+    if(span <= 0)
+    {
+      span = 16;
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    NMPC_HIP_TRY(hipStreamSynchronize(s->stream));
+    const size_t N = static_cast<size_t>(n_instances), T = static_cast<size_t>(s->T), n = static_cast<size_t>(s->N), mm = static_cast<size_t>(s->MM);
+    const size_t n_t0 = N, n_x0 = N * n, n_u = N * T * mm, n_X = N * (T + 1) * n, n_c = N * (T + 1), n_tr = N * NMPC_HIP_NTRACE, n_dv = N * 2;
+    const size_t doubles = n_t0 + n_x0 + n_u + n_X + n_u + n_c + n_tr + n_dv;
+    const size_t bytes = doubles * sizeof(double) + 2 * N * sizeof(int);
+    if(bytes > s->stream_io_bytes)
+    {
+      if(s->d_stream_io)
+      {
+        NMPC_HIP_TRY(hipFree(s->d_stream_io));
+        s->d_stream_io = nullptr;
+        s->stream_io_bytes = 0;
+      }
+      NMPC_HIP_TRY(hipMalloc(&s->d_stream_io, bytes));
+      s->stream_io_bytes = bytes;
+    }
+    s->stream_n = 0;
+    double * d = static_cast<double *>(s->d_stream_io);
+    nmpc_amd::hip::StreamArrays io;
+    double * d_t0 = d;
+    double * d_x0 = d_t0 + n_t0;
+    double * d_u = d_x0 + n_x0;
+    io.t0 = t0 ? d_t0 : nullptr;
+    io.x0 = d_x0;
+    io.u_init = d_u;
+    io.X = d_u + n_u;
+    io.U = io.X + n_X;
+    io.cost = io.U + n_u;
+    io.trace_last = io.cost + n_c;
+    io.dV = io.trace_last + n_tr;
+    io.status = reinterpret_cast<int *>(io.dV + n_dv);
+    io.iters = io.status + N;
+    if(t0)
+    {
+      NMPC_HIP_TRY(hipMemcpyAsync(d_t0, t0, n_t0 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    }
+    NMPC_HIP_TRY(hipMemcpyAsync(d_x0, x0, n_x0 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    NMPC_HIP_TRY(hipMemcpyAsync(d_u, u_init, n_u * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    int rc = launchStream(s, s->stream, io, n_instances, span);
+    if(rc != NMPC_HIP_OK)
+    {
+      return rc;
+    }
+    s->stream_arrays = io;
+    s->stream_n = n_instances;
+    s->solved = true;
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_stream_get(nmpc_hip_ddp_handle s, int field, void * out, size_t bytes)
+  {
+    if(!s || !out)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle or output");
+    }
+    if(s->stream_n <= 0)
+    {
+      return fail(NMPC_HIP_ERR_RUNTIME, "no streamed solve on this handle");
+    }
+    const size_t N = static_cast<size_t>(s->stream_n), T = static_cast<size_t>(s->T), n = static_cast<size_t>(s->N), mm = static_cast<size_t>(s->MM);
+    const void * src = nullptr;
+    size_t want = 0;
+    switch(field)
+    {
+      case NMPC_HIP_FIELD_X: src = s->stream_arrays.X; want = N * (T + 1) * n * sizeof(double); break;
+      case NMPC_HIP_FIELD_U: src = s->stream_arrays.U; want = N * T * mm * sizeof(double); break;
+      case NMPC_HIP_FIELD_COST: src = s->stream_arrays.cost; want = N * (T + 1) * sizeof(double); break;
+      case NMPC_HIP_FIELD_TRACE_LAST: src = s->stream_arrays.trace_last; want = N * NMPC_HIP_NTRACE * sizeof(double); break;
+      case NMPC_HIP_FIELD_DV: src = s->stream_arrays.dV; want = N * 2 * sizeof(double); break;
+      case NMPC_HIP_FIELD_STATUS: src = s->stream_arrays.status; want = N * sizeof(int); break;
+      case NMPC_HIP_FIELD_ITERS: src = s->stream_arrays.iters; want = N * sizeof(int); break;
+      default: return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "a streamed solve returns X, U, cost, status, iterations, the last trace row and dV");
+    }
+    if(bytes != want)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "output size: " + std::to_string(want) + " bytes expected");
+    }
+    NMPC_HIP_TRY(hipSetDevice(s->device));
+    NMPC_HIP_TRY(hipMemcpy(out, src, want, hipMemcpyDeviceToHost));
+    return NMPC_HIP_OK;
+  }
+
+  int nmpc_hip_ddp_last_stream_stats(nmpc_hip_ddp_handle s, int * rounds, float * ms)
+  {
+    if(!s)
+    {
+      return fail(NMPC_HIP_ERR_INVALID_ARGUMENT, "NULL handle");
+    }
+    if(rounds)
+    {
+      *rounds = s->stream_rounds;
+    }
+    if(ms)
+    {
+      *ms = s->stream_ms;
+    }
+    return NMPC_HIP_OK;
   }
 
   int nmpc_hip_ddp_field_bytes(nmpc_hip_ddp_handle s, int field, size_t * bytes)

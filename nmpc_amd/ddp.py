@@ -108,6 +108,20 @@ class MpcLog:
 
 
 @dataclass
+class StreamResult:
+    """Results of DDPSolverBatch.solveStream: one row per instance of the queue (controlData() / the last traceDataList() row of each)."""
+    X: np.ndarray  # (N, T+1, n)
+    U: np.ndarray  # (N, T, MM)
+    cost: np.ndarray  # (N, T+1)
+    status: np.ndarray  # (N,)  1 converged, 0 max_iter, -1 failed
+    iters: np.ndarray  # (N,)
+    trace_last: np.ndarray  # (N, 12)
+    dV: np.ndarray  # (N, 2)
+    rounds: int = 0
+    device_ms: float = 0.0
+
+
+@dataclass
 class ComputationDuration:
     """DDPSolver::ComputationDuration (DDPSolver.h:219-247) for the whole batch [msec]: `solve` is the HIP-event
     time of ingest + solve kernel, `opt` the solve kernel alone, `setup` their difference.  `backward` and `forward`
@@ -362,6 +376,39 @@ class DDPSolverBatch:
             if n_fail:
                 print(f"[DDP] Failure due to large lambda in {n_fail} of {B} instances.")
         return status == 1
+
+    # ---- a queue of instances through the handle's slots (nmpc_hip_ddp_solve_stream; round 6) ----
+    def solveStream(self, current_t, current_x, initial_u_list, span: int = 0) -> "StreamResult":
+        """N >> batch_size instances (current_t: scalar or (N,), current_x: (N, n), initial_u_list: (N, T, MM)), each solved to ITS
+        convergence as DDPSolver::solve would (DDPSolver.hpp:26-141): batch_size slots, and the slot of an instance that has finished
+        takes the next one of the queue after at most `span` (0: 16) further iterations of its neighbours
+        (include/nmpc_amd/hip/stream_schedule.hpp).  Every instance returns the bits of its lone solve on the same kernel family.
+        Kernel families with resumable launches only (n <= 4, one input, fp64; shared problem object and limits)."""
+        x0 = np.ascontiguousarray(np.asarray(current_x, dtype=np.float64))
+        if x0.ndim != 2 or x0.shape[1] != self.n:
+            raise ValueError("current_x should be (N, %d)" % self.n)
+        N = x0.shape[0]
+        t0 = np.broadcast_to(np.asarray(current_t, dtype=np.float64), (N,)).copy()
+        self._sample_limits_func(t0[:1])
+        self._push_state()
+        T = int(self._config.horizon_steps)
+        u = np.ascontiguousarray(np.asarray(initial_u_list, dtype=np.float64).reshape(N, T, self.mm))
+        dp = C.POINTER(C.c_double)
+        _capi.check(self._L.nmpc_hip_ddp_solve_stream(self._h, N, t0.ctypes.data_as(dp), x0.ctypes.data_as(dp), u.ctypes.data_as(dp), int(span)))
+        self._cache = {}
+
+        def get(field, dtype, shape):
+            out = np.zeros(shape, dtype=dtype)
+            _capi.check(self._L.nmpc_hip_ddp_stream_get(self._h, field, out.ctypes.data_as(C.c_void_p), out.nbytes))
+            return out
+
+        rounds, ms = C.c_int(), C.c_float()
+        _capi.check(self._L.nmpc_hip_ddp_last_stream_stats(self._h, C.byref(rounds), C.byref(ms)))
+        return StreamResult(X=get(_capi.FIELD_X, np.float64, (N, T + 1, self.n)), U=get(_capi.FIELD_U, np.float64, (N, T, self.mm)),
+                            cost=get(_capi.FIELD_COST, np.float64, (N, T + 1)), status=get(_capi.FIELD_STATUS, np.int32, (N,)),
+                            iters=get(_capi.FIELD_ITERS, np.int32, (N,)),
+                            trace_last=get(_capi.FIELD_TRACE_LAST, np.float64, (N, len(_capi.TRACE_COLUMNS))),
+                            dV=get(_capi.FIELD_DV, np.float64, (N, 2)), rounds=rounds.value, device_ms=ms.value)
 
     # ---- the reference's receding-horizon caller loops, device-resident  (SURVEY.md §8 f-1) ----
     def mpcRun(self, current_t, current_x, initial_u_list, n_ticks: int, shift_warm_start: bool = True,

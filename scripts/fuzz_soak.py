@@ -108,6 +108,28 @@ for label, mk, cfg, kernel in CASES:
 os.environ.pop("NMPC_HIP_DDP_KERNEL", None)
 os.environ.pop("NMPC_HIP_DDP_FAN_SCRATCH", None)
 
+# streamed solves (nmpc_hip_ddp_solve_stream): a queue through the slots of one handle — resumable launches numbered per instance, the
+# rollout-only launches of refilled slots, extraction / compaction / refill kernels between them
+if not args.only or "stream" in args.only:
+    for label, kern, N, S, cfg in (("quad c2 stream", "quad", 3000 if big else 1500, 512, dict(max_iter=120, trace_level=0)),
+                                   ("quad c2 box stream", "quad", 1500, 256, dict(max_iter=60, trace_level=0, with_input_constraint=True)),
+                                   ("two-wave stream", "2w", 1200, 256, dict(max_iter=80, trace_level=0))):
+        wl = W.cartpole_batch(B=N, T=100, seed=31, constrained=bool(cfg.get("with_input_constraint")))
+        digests = []
+        for r in range(args.reps):
+            s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), S)
+            c = s.config()
+            c.print_level, c.horizon_steps = 0, wl.T
+            for k, v in cfg.items():
+                setattr(c, k, v)
+            if wl.limits is not None and cfg.get("with_input_constraint"):
+                s.setInputLimits(*wl.limits)
+            s.setKernel(kern)
+            res = s.solveStream(wl.t0, wl.x0, wl.u_init, span=(8, 16, 5)[r % 3])  # (the round length does not show in the results)
+            digests.append(sha(res.X, res.U, res.cost, res.iters, res.status, res.trace_last))
+        out[label] = {"kernel": s.kernelName(), "digests": digests}
+        print(f"{label:28s} {s.kernelName():28s} {len(set(digests))} distinct digest(s) in {args.reps} repetitions", file=sys.stderr, flush=True)
+
 if not args.only or "fmpc" in args.only:
     from nmpc_amd import fmpc as F
     for label, cls, B, T, it, ric in (("fmpc cartpole fused", F.FmpcProblemCartPole, 1024 if big else 300, 200 if big else 60, 4, "fused"),

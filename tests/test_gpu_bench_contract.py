@@ -50,6 +50,10 @@ def test_default_line_has_the_contract_keys():
     # consecutive batches on eight streams under the ragged-convergence schedule: the tails overlap and converged instances free their slots
     assert cfg["m2_overlapped_value"] > 2.5 * cfg["m2_value"] and cfg["m2_overlapped_value"] > 1.15 * cfg["m2_overlapped"]["whole_solve_launches_value"]
     assert cfg["m2_overlapped"]["launches_per_solve"] == 5 and cfg["m2_overlapped"]["handles"] == 8
+    # M2 as a stream through one handle: slots refilled at round boundaries — no batch boundary, so well above the pool of batches
+    assert cfg["m2_stream_value"] > 0.75 * cfg["m2_overlapped_value"] and cfg["m2_stream_sustained_value"] > 1.5 * cfg["m2_overlapped_value"]
+    assert cfg["m2_stream"]["instances"] == 32768 and cfg["m2_stream"]["sustained"]["instances"] == 262144
+    assert cfg["m2_stream"]["status_counts"].get("1", 0) >= 0.99 * 32768
     assert cfg["m1"]["status_counts"].get("1", 0) == 0 and cfg["m1"]["max_iterations"] <= 50
     assert cfg["m2"]["status_counts"].get("1", 0) >= 0.99 * 4096
     assert cfg["per_rank_solve_ms"] and abs(cfg["per_rank_solve_ms"][0] - d["ms_per_step"]) < 0.5 * d["ms_per_step"]

@@ -723,7 +723,7 @@ def main():
                 del st
                 return res
 
-            extras["m2_stream"] = stream_leg(32768, 16)
+            extras["m2_stream"] = stream_leg(32768, 8)
             extras["m2_stream"]["sustained"] = stream_leg(262144, 8)
         if args.workload == "c3":
             # 1024 bipedal instances are 64 quad workgroups on 256 CUs: the single-batch rate is a latency, not the chip's rate.

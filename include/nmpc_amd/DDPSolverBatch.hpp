@@ -269,7 +269,7 @@ public:
 
   /** \brief A QUEUE of instances through the solver's batch_size slots (nmpc_hip_ddp_solve_stream): any number of problems, each
       solved to ITS convergence as DDPSolver::solve does (DDPSolver.hpp:26-141, 115-123); the slot of an instance that has finished
-      takes the next one of the queue after at most `span` (0: 16) further iterations.  Every instance returns the bits of its lone
+      takes the next one of the queue after at most `span` (0: 8) further iterations.  Every instance returns the bits of its lone
       solve on the same kernel family.  State dimension <= 4, one input, fp64; shared problem object and constant limits. */
   StreamResult solveStream(const std::vector<double> & current_t,
                            const std::vector<StateDimVector> & current_x,

@@ -1907,7 +1907,11 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     resumeWord(3) = still_running ? 1.0 : 0.0;
     resumeWord(4) = static_cast<double>(iterations_done); // (streamed solves: the instance's own iteration count so far)
   }
-  /** Streamed solves (DeviceBuffers::stream_mode): 0 none, 1 initial rollout of freshly filled slots, 2 further iterations. */
+  //! streamed solves, stream_mode 2: this workgroup's slots were filled just now (they lie at or behind *first_active) — it starts
+  //! with the initial rollout instead of resuming (set by the kernel: the fresh region starts on a workgroup boundary)
+  bool stream_fresh_wg = false;
+  /** Streamed solves (DeviceBuffers::stream_mode): 0 none, 1 initial rollout of freshly filled slots only, 2 a round — the
+      rollout for the workgroups filled just now, then at most iter_end iterations for everyone. */
   template<bool kResumable>
   NMPC_D int streamMode() const
   {
@@ -1928,12 +1932,13 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     J_cur = 0;
     phaseStart();
     const int smode = streamMode<kResumable>();
-    const bool resumed = kResumable && (smode == 2 || (smode == 0 && buf.iter_begin > 1));
-    if(smode == 1)
+    const bool fresh = smode == 1 || (smode == 2 && stream_fresh_wg);
+    const bool resumed = kResumable && ((smode == 2 && !fresh) || (smode == 0 && buf.iter_begin > 1));
+    if(fresh)
     {
       valid = valid && resumeWord(3) != 0.0; // (the refill marks the slots it has put an instance into)
     }
-    const int it_base = (smode == 2 && valid) ? static_cast<int>(resumeWord(4)) : 0; // this instance's iterations before this launch
+    const int it_base = (smode == 2 && !fresh && valid) ? static_cast<int>(resumeWord(4)) : 0; // this instance's iterations before this launch
     int it_done = it_base;
     bool active = valid; // this lane still iterates
     double tr[NMPC_HIP_NTRACE];
@@ -2170,12 +2175,13 @@ struct PairSolver : InstanceSolver<Problem, kConstrained>
     J_cand = 0;
     phaseStart();
     const int smode = streamMode<kResumable>(); // (see solveMasterWith)
-    const bool resumed = kResumable && (smode == 2 || (smode == 0 && buf.iter_begin > 1));
-    if(smode == 1)
+    const bool fresh = smode == 1 || (smode == 2 && stream_fresh_wg);
+    const bool resumed = kResumable && ((smode == 2 && !fresh) || (smode == 0 && buf.iter_begin > 1));
+    if(fresh)
     {
       valid = valid && resumeWord(3) != 0.0;
     }
-    const int it_base = (smode == 2 && valid) ? static_cast<int>(resumeWord(4)) : 0;
+    const int it_base = (smode == 2 && !fresh && valid) ? static_cast<int>(resumeWord(4)) : 0;
     int it_done = it_base;
     bool resumed_running = false;
     if(resumed)
@@ -2540,13 +2546,16 @@ __global__ __launch_bounds__(2 * kLanesPerBlock) void ddp_solve_tpi2w_kernel(con
   const int wave = threadIdx.x / kLanesPerBlock;
   const int b = blockIdx.x * kLanesPerBlock + (threadIdx.x % kLanesPerBlock);
   int first = 0;
+  bool solver_fresh = false;
   if constexpr(kResumable)
   {
     // streamed solves, the rollout of freshly filled slots: the workgroups below hold instances in mid-solve and stay out of it
     // (*first_active is a multiple of 64: no workgroup holds both kinds)
-    first = (buf.stream_mode == 1 && buf.first_active) ? *buf.first_active : 0;
+    const int first_fresh = (buf.stream_mode != 0 && buf.first_active) ? *buf.first_active : 0;
+    solver_fresh = buf.stream_mode == 2 && buf.first_active && static_cast<int>(blockIdx.x) * kLanesPerBlock >= first_fresh;
+    first = (buf.stream_mode == 1) ? first_fresh : 0;
     if(static_cast<int>(blockIdx.x + 1) * kLanesPerBlock <= first
-       || (buf.stream_mode == 1 && buf.n_active && static_cast<int>(blockIdx.x) * kLanesPerBlock >= *buf.n_active)) // (... and the empty slots behind)
+       || (buf.stream_mode != 0 && buf.n_active && static_cast<int>(blockIdx.x) * kLanesPerBlock >= *buf.n_active)) // (... and the empty slots behind)
     {
       return;
     }
@@ -2555,6 +2564,7 @@ __global__ __launch_bounds__(2 * kLanesPerBlock) void ddp_solve_tpi2w_kernel(con
   // instantiation: with it the problem's fields live in VGPRs, which costs the shared-object kernel ~1 % if merged in.
   const Problem mine = kOwnProblem ? instanceProblem(problem, buf, b) : problem;
   Solver solver(mine, cfg, buf, b, lds_2w);
+  solver.stream_fresh_wg = solver_fresh;
   if(wave == 0)
   {
     if constexpr(kResumable)

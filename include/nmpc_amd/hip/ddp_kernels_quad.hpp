@@ -759,12 +759,15 @@ __global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const P
   extern __shared__ __attribute__((aligned(16))) double lds_quad[];
   const int wl = threadIdx.x % 64;
   int first = 0;
+  bool solver_fresh = false;
   if constexpr(kResumable)
   {
-    // streamed solves, the rollout of freshly filled slots (DeviceBuffers::stream_mode 1): see ddp_solve_tpi2w_kernel
-    first = (buf.stream_mode == 1 && buf.first_active) ? *buf.first_active : 0;
+    // streamed solves (DeviceBuffers::stream_mode): see ddp_solve_tpi2w_kernel
+    const int first_fresh = (buf.stream_mode != 0 && buf.first_active) ? *buf.first_active : 0;
+    solver_fresh = buf.stream_mode == 2 && buf.first_active && static_cast<int>(blockIdx.x) * kQuadInstances >= first_fresh;
+    first = (buf.stream_mode == 1) ? first_fresh : 0;
     if(static_cast<int>(blockIdx.x + 1) * kQuadInstances <= first
-       || (buf.stream_mode == 1 && buf.n_active && static_cast<int>(blockIdx.x) * kQuadInstances >= *buf.n_active)) // (... and the empty slots behind)
+       || (buf.stream_mode != 0 && buf.n_active && static_cast<int>(blockIdx.x) * kQuadInstances >= *buf.n_active)) // (... and the empty slots behind)
     {
       return;
     }
@@ -778,6 +781,7 @@ __global__ __launch_bounds__(kQuadWaves * 64) void ddp_solve_quad_kernel(const P
   const Problem mine = kOwnProblem ? instanceProblem(problem, buf, b) : problem;
   const Problem mine_lin = kOwnProblem ? instanceProblem(problem, buf, b_lin) : problem;
   Solver solver(mine, kOwnProblem ? mine_lin : mine, cfg, buf, b, lds_quad);
+  solver.stream_fresh_wg = solver_fresh;
   if(threadIdx.x / 64 == 0)
   {
     if constexpr(kResumable)

@@ -319,6 +319,17 @@ struct TileSolver64
   static constexpr int kGroupMax = kBatchGains ? 3 * kT64MatrixWaves : kT64MaxGroup;
 #endif
   static constexpr int kPerWave = (kGroupMax + kOwnerWaves - 1) / kOwnerWaves;
+  //! The slot loop of the sweep as straight-line code — one copy of the step per slot, no rotation of the value functions' registers
+  //! (eight moves per slot and step) — where the step is small: the quadrotor's (n (n + m) = 192) gains 6.5 % in float and 7 % in
+  //! double, the manipulator's (294) loses 23 % (five copies of a 673-instruction step: spills) [measured, round 6, A/B on one box:
+  //! c4 2.10 -> 1.97 ms, c4f64 3.90 -> 3.63, c5 2.67 -> 3.29 — and 3.29 as well with scheduling barriers between the copies: 3 026 instead of
+  //! 3 365 instructions per timestep, but 60 scratch accesses behind 32 s_waitcnt vmcnt(0) in the loop; round 3 had measured no difference
+  //! for the quadrotor].
+#ifdef NMPC_AMD_AB_ROLLED_SLOTS
+  static constexpr bool kUnrollSlots = false;
+#else
+  static constexpr bool kUnrollSlots = !kBig && !kConstrained && N * (N + MM) <= 200;
+#endif
   static constexpr int kQpIn = MM * MM + MM;
   static constexpr int kQpPerWave = (kPerWave - 1) * kQpIn + 2 * kPerWave;
   static constexpr int kQpAt = kLsAt;
@@ -2796,6 +2807,24 @@ struct TileSolver64
             rotate();
           }
           qpBatch(mp, i, parity, hi - i, chunk, n_act, ok_mask);
+        }
+        if constexpr(kUnrollSlots)
+        {
+          // small steps: a copy of the step per slot, the value functions addressed by constants, no rotation moves
+#pragma unroll
+          for(int e = 0; e < kPerWave; e++)
+          {
+            const int a = mw + kOwnerWaves * e;
+            if(a < n_act)
+            {
+              const int slot = uniform(actSlot(a));
+              bool ok = ((ok_mask >> e) & 1u) != 0;
+              backwardStep(V[e], ok, mp, la, recAt(parity, hi - i, a, chunk, n_act), slot, uniform(slotI(sB, slot)), i,
+                           uniformD(slotF(sLambda, slot)), e);
+              ok_mask = ok ? ok_mask : (ok_mask & ~(1u << e));
+            }
+          }
+          continue;
         }
 #pragma nounroll
         for(int e = 0; e < kPerWave; e++)

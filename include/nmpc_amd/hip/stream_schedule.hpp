@@ -10,8 +10,9 @@
 //            row and dV go to the caller-facing output arrays (reference layouts, indexed by instance), the slot is free;
 //   compact  ragged_compact_kernel / ragged_swap_kernel: the instances in mid-solve swapped into a dense prefix [0, n_run);
 //   refill   the slots from the next multiple of 64 on take the next instances of the queue (inputs converted into the slot's
-//            tile-major rows), a launch with stream_mode 1 rolls them out (DDPSolver.hpp:83-95) — its workgroups below that
-//            position exit at once, which is why the fresh region starts on a workgroup boundary of both kernel families.
+//            tile-major rows); the NEXT round's launch starts the workgroups of that region with the initial rollout
+//            (DDPSolver.hpp:83-95) instead of resuming them — which is why the region starts on a workgroup boundary of both
+//            kernel families.
 // Everything is queued on the handle's stream; the kernels read the prefix length, the queue cursor and the count of finished
 // instances from device memory, the host looks at that count every few rounds.  An instance's iterations are the same instructions
 // on the same values whichever slot it sits in and whoever its neighbours are (the property the ragged schedule rests on:
@@ -35,6 +36,7 @@ enum StreamWord
   kSwCursor, //!< instances handed out so far
   kSwDone, //!< instances extracted so far
   kSwTotal, //!< N
+  kSwTaken, //!< instances the last fill took (the next plan moves the cursor past them)
   kSwCount
 };
 
@@ -63,6 +65,7 @@ __global__ void stream_begin_kernel(int * w, int n_total)
     w[kSwCursor] = 0;
     w[kSwDone] = 0;
     w[kSwTotal] = n_total;
+    w[kSwTaken] = 0;
   }
 }
 
@@ -117,11 +120,12 @@ __global__ __launch_bounds__(256) void stream_extract_kernel(const DeviceBuffers
   }
 }
 
-/** After the compaction: where the next instances go.  One thread. */
+/** After the compaction: where the next instances go (and the cursor past the ones the previous fill took).  One thread. */
 __global__ void stream_plan_kernel(int * w, int n_slots)
 {
   if(threadIdx.x == 0 && blockIdx.x == 0)
   {
+    w[kSwCursor] += w[kSwTaken];
     const int run = w[kSwRun];
     const int first = (run + 63) & ~63;
     const int room = n_slots > first ? n_slots - first : 0;
@@ -129,7 +133,7 @@ __global__ void stream_plan_kernel(int * w, int n_slots)
     const int take = left < room ? left : room;
     w[kSwFirst] = first;
     w[kSwPrefix] = take > 0 ? first + take : run;
-    // (the cursor moves in stream_fill_done_kernel: the fill reads the old one)
+    w[kSwTaken] = take;
   }
 }
 
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void stream_fill_kernel(const DeviceBuffers bu
     return; // in mid-solve
   }
   const size_t tile = static_cast<size_t>(p) >> 6, ln = static_cast<size_t>(p) & 63;
-  const bool fill = prefix > run && p >= first && p < prefix;
+  const bool fill = w[kSwTaken] > 0 && p >= first && p < prefix;
   if(!fill)
   {
     if(threadIdx.x == 0 && blockIdx.y == 0)
@@ -183,13 +187,5 @@ __global__ __launch_bounds__(256) void stream_fill_kernel(const DeviceBuffers bu
   }
 }
 
-__global__ void stream_fill_done_kernel(int * w)
-{
-  if(threadIdx.x == 0 && blockIdx.x == 0)
-  {
-    const int taken = w[kSwPrefix] > w[kSwRun] ? w[kSwPrefix] - w[kSwFirst] : 0;
-    w[kSwCursor] += taken;
-  }
-}
 } // namespace hip
 } // namespace nmpc_amd

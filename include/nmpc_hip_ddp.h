@@ -318,7 +318,7 @@ extern "C"
   /** A QUEUE of n_instances problems (host arrays, reference layouts: t0 [N] or NULL, x0 [N][n], u_init [N][T][m]) through the
       handle's B slots, N >> B: every instance is solved to ITS convergence (or its max_iter-th iteration) — DDPSolver::solve of
       DDPSolver.hpp:26-141 once per instance, as a caller of the reference runs many problems through a few solver objects — and the
-      slot of an instance that has finished takes the next one of the queue at the next round boundary (`span` iterations, 0: 16;
+      slot of an instance that has finished takes the next one of the queue at the next round boundary (`span` iterations, 0: 8;
       include/nmpc_amd/hip/stream_schedule.hpp).  Every instance returns the bits of its lone solve on this kernel family.
       Kernel families with resumable launches only (n <= 4, one input, fp64, shared problem object and limits); blocks until the
       queue has drained.  Results: nmpc_hip_ddp_stream_get (X, U, COST, STATUS, ITERS, TRACE_LAST, DV; arrays of N instances). */

@@ -749,24 +749,44 @@ int launchStream(nmpc_hip_ddp_solver * s, hipStream_t st, const nmpc_amd::hip::S
   NMPC_HIP_TRY(hipEventRecord(ev0, st));
   hipLaunchKernelGGL(stream_begin_kernel, dim3(1), dim3(64), 0, st, w, n_total);
   NMPC_HIP_TRY(hipMemsetAsync(s->d_stream_id, 0xff, static_cast<size_t>(s->Bp) * sizeof(int), st)); // every slot empty (-1)
-  auto refill = [&]() -> hipError_t
+  auto refill = [&]()
   {
     hipLaunchKernelGGL(stream_plan_kernel, dim3(1), dim3(64), 0, st, w, s->B);
     hipLaunchKernelGGL(stream_fill_kernel, fill_grid, dim3(256), 0, st, buf, io, s->d_stream_id, w, s->N, s->MM, s->d_t0, s->d_x0);
-    hipLaunchKernelGGL(stream_fill_done_kernel, dim3(1), dim3(64), 0, st, w);
-    buf.stream_mode = 1; // the initial rollout of the slots filled just now
-    return s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
   };
-  hipError_t le = refill();
+  refill();
+  buf.stream_mode = 2; // a round: the workgroups of the region filled last start with the initial rollout, the others resume
+  hipError_t le = hipSuccess;
   int rounds = 0, done = 0;
   // an instance leaves after at most ceil(max_iter / span) rounds; a slot serves ceil(n_total / B) instances (+ slack for the rounds
   // in which too little finished for a compaction to pay)
   const long long max_rounds = 4ll * (static_cast<long long>((n_total + s->B - 1) / s->B) + 1) * ((std::max(s->cfg.max_iter, 1) + span - 1) / span + 1);
+  // The host queues blocks of four rounds and looks at the count of finished instances behind each block — two blocks ahead of the
+  // device, so that the queue never runs dry while the host waits (a round behind an empty queue costs a few empty launches).
+  constexpr int kBlock = 4, kAhead = 2;
+  int * h_done = nullptr;
+  NMPC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_done), kAhead * sizeof(int), hipHostMallocDefault));
+  hipEvent_t ev_blk[kAhead] = {nullptr, nullptr};
+  for(int k = 0; k < kAhead; k++)
+  {
+    h_done[k] = 0;
+    NMPC_HIP_TRY(hipEventCreateWithFlags(&ev_blk[k], hipEventDisableTiming));
+  }
+  long long queued_blocks = 0;
   while(le == hipSuccess && done < n_total && rounds < max_rounds)
   {
-    for(int k = 0; k < 4 && le == hipSuccess; k++, rounds++)
+    const int slot = static_cast<int>(queued_blocks % kAhead);
+    if(queued_blocks >= kAhead)
     {
-      buf.stream_mode = 2;
+      NMPC_HIP_TRY(hipEventSynchronize(ev_blk[slot])); // the block queued kAhead blocks ago
+      done = h_done[slot];
+      if(done >= n_total)
+      {
+        break;
+      }
+    }
+    for(int k = 0; k < kBlock && le == hipSuccess; k++, rounds++)
+    {
       le = s->ops->launch_solve(s->params.data(), s->cfg, buf, st);
       if(le != hipSuccess)
       {
@@ -776,15 +796,29 @@ int launchStream(nmpc_hip_ddp_solver * s, hipStream_t st, const nmpc_amd::hip::S
       hipLaunchKernelGGL((ragged_compact_kernel<double>), dim3(1), dim3(1024), 0, st, s->d_resume, s->d_ragged_rank, s->d_ragged_pairs,
                          s->d_ragged_used, s->d_ragged_words, w + kSwPrefix, s->d_iters, wg_size);
       hipLaunchKernelGGL(ragged_swap_kernel, swap_grid, dim3(256), 0, st, tab, s->d_ragged_pairs, s->d_ragged_used, s->d_ragged_words);
-      le = refill();
+      refill();
     }
     if(le != hipSuccess)
     {
       break;
     }
-    NMPC_HIP_TRY(hipMemcpyAsync(&done, w + kSwDone, sizeof(int), hipMemcpyDeviceToHost, st));
-    NMPC_HIP_TRY(hipStreamSynchronize(st));
+    NMPC_HIP_TRY(hipMemcpyAsync(&h_done[slot], w + kSwDone, sizeof(int), hipMemcpyDeviceToHost, st));
+    NMPC_HIP_TRY(hipEventRecord(ev_blk[slot], st));
+    queued_blocks++;
   }
+  if(le == hipSuccess)
+  {
+    NMPC_HIP_TRY(hipStreamSynchronize(st));
+    for(int k = 0; k < kAhead; k++)
+    {
+      done = h_done[k] > done ? h_done[k] : done;
+    }
+  }
+  for(int k = 0; k < kAhead; k++)
+  {
+    (void)hipEventDestroy(ev_blk[k]);
+  }
+  (void)hipHostFree(h_done);
   if(le != hipSuccess)
   {
     (void)hipGetLastError();
@@ -1725,7 +1759,7 @@ extern "C"
     }
     if(span <= 0)
     {
-      span = 16;
+      span = 8; // [measured, profiles/r06_stream_throughput.txt: 4 / 6 / 8 / 12 / 16 iterations per round: 10.3 / 10.8 / 10.9 / 10.5 / 10.1 k]
     }
     NMPC_HIP_TRY(hipSetDevice(s->device));
     NMPC_HIP_TRY(hipStreamSynchronize(s->stream));

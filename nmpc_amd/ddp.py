@@ -381,7 +381,7 @@ class DDPSolverBatch:
     def solveStream(self, current_t, current_x, initial_u_list, span: int = 0) -> "StreamResult":
         """N >> batch_size instances (current_t: scalar or (N,), current_x: (N, n), initial_u_list: (N, T, MM)), each solved to ITS
         convergence as DDPSolver::solve would (DDPSolver.hpp:26-141): batch_size slots, and the slot of an instance that has finished
-        takes the next one of the queue after at most `span` (0: 16) further iterations of its neighbours
+        takes the next one of the queue after at most `span` (0: 8) further iterations of its neighbours
         (include/nmpc_amd/hip/stream_schedule.hpp).  Every instance returns the bits of its lone solve on the same kernel family.
         Kernel families with resumable launches only (n <= 4, one input, fp64; shared problem object and limits)."""
         x0 = np.ascontiguousarray(np.asarray(current_x, dtype=np.float64))

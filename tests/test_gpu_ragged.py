@@ -183,3 +183,34 @@ def test_cpp_solver_pool_matches_lone_solvers(tmp_path):
                       r.stdout)
     assert len(rows) == 2 and all(int(x[3]) == 0 for x in rows)
     assert int(rows[0][2]) == 1 and int(rows[1][2]) > 2  # whole-solve launches, then the schedule's resumable launches
+
+
+def test_ragged_schedule_moves_the_per_instance_limits_with_their_instances():
+    """Per-instance boxes (setInputLimitsBatch) and per-instance time-varying limit tables (setInputLimitsHorizon with (B, T, MM)) are
+    PERSISTENT inputs of a handle: the compaction swaps them with their instances and the replay puts them back (a schedule that
+    returned early would leave later solves pairing instances with their neighbours' limits).  Same bits as whole-solve launches, and the
+    same again on a second solve of the same handle."""
+    wl = workloads.cartpole_batch(B=520, T=100, seed=77, constrained=True)
+    rng = np.random.default_rng(3)
+    lo = -(8.0 + 12.0 * rng.random((wl.B, 1)))
+    up = 8.0 + 12.0 * rng.random((wl.B, 1))
+    cfg = dict(max_iter=90, with_input_constraint=True)
+    for kind in ("batch", "horizon"):
+        def prepare(s):
+            if kind == "batch":
+                s.setInputLimitsBatch(lo, up)
+            else:
+                ramp = 1.0 + 0.3 * np.linspace(0.0, 1.0, wl.T)[None, :, None]
+                s.setInputLimitsHorizon(lo[:, None, :] * ramp, up[:, None, :] * ramp)
+        whole = make_solver(wl, ragged_schedule=-1, **cfg)
+        prepare(whole)
+        whole.solve(wl.t0, wl.x0, wl.u_init)
+        want = outputs(whole)
+        s = make_solver(wl, ragged_schedule=1, **cfg)
+        prepare(s)
+        s.solve(wl.t0, wl.x0, wl.u_init)
+        assert s.lastSolveLaunches() == schedule_launches(90) and whole.lastSolveLaunches() == 1
+        assert_same_bits(outputs(s), want, f"per-instance limits ({kind})")
+        s.solve(wl.t0, wl.x0, wl.u_init)  # the limits are where the first solve found them
+        assert_same_bits(outputs(s), want, f"per-instance limits ({kind}), second solve")
+        assert want["iters"].max() > 16 and len(set(want["iters"].tolist())) > 3

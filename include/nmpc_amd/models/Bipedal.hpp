@@ -72,9 +72,12 @@ public:
     return (zdd + g) / z;
   }
 
-  NMPC_HD StateStateDimMatrix A(double t) const
+  // A(t), B(t) of the discretised dynamics from omega^2(t).  The two share ONE evaluation of the schedule wherever both are needed
+  // (stateEq, calcStateEqDeriv): omega2() is two polynomials, three range tests and an fp64 division — evaluated per matrix, as A(t)
+  // and B(t) each do, the compiler kept both copies, ~45 of the ~290 instructions of a rollout timestep on the quad kernel's master
+  // wave (round 6, BASELINE config 3).  Element for element the same expressions: the same bits.
+  NMPC_HD StateStateDimMatrix Aof(double w2) const
   {
-    const double w2 = omega2(t);
     StateStateDimMatrix A;
     A(0, 0) = 1 + 0.5 * dt_ * dt_ * w2;
     A(0, 1) = dt_;
@@ -83,19 +86,29 @@ public:
     return A;
   }
 
-  NMPC_HD StateInputDimMatrix B(double t) const
+  NMPC_HD StateInputDimMatrix Bof(double w2) const
   {
-    const double w2 = omega2(t);
     StateInputDimMatrix B;
     B(0, 0) = -0.5 * dt_ * dt_ * w2;
     B(1, 0) = -1 * dt_ * w2;
     return B;
   }
 
+  NMPC_HD StateStateDimMatrix A(double t) const
+  {
+    return Aof(omega2(t));
+  }
+
+  NMPC_HD StateInputDimMatrix B(double t) const
+  {
+    return Bof(omega2(t));
+  }
+
   NMPC_HD StateDimVector stateEq(double t, const StateDimVector & x, const InputDimVector & u) const
   {
-    const StateStateDimMatrix a = A(t);
-    const StateInputDimMatrix b = B(t);
+    const double w2 = omega2(t);
+    const StateStateDimMatrix a = Aof(w2);
+    const StateInputDimMatrix b = Bof(w2);
     StateDimVector x_next;
     x_next[0] = (a(0, 0) * x[0] + a(0, 1) * x[1]) + b(0, 0) * u[0];
     x_next[1] = (a(1, 0) * x[0] + a(1, 1) * x[1]) + b(1, 0) * u[0];
@@ -120,8 +133,9 @@ public:
                                 StateStateDimMatrix & state_eq_deriv_x,
                                 StateInputDimMatrix & state_eq_deriv_u) const
   {
-    state_eq_deriv_x = A(t);
-    state_eq_deriv_u = B(t);
+    const double w2 = omega2(t);
+    state_eq_deriv_x = Aof(w2);
+    state_eq_deriv_u = Bof(w2);
   }
 
   NMPC_HD void calcRunningCostDeriv(double t,

@@ -902,7 +902,7 @@ struct TileSolver64
   //! does not see through the selects and arrays these pointers pass and fell back to flat_load — whose completion a wait for the
   //! LDS (lgkmcnt) also waits for, and in front of which it may put a wait of its own: round 6 found one build of this file with
   //! s_waitcnt vmcnt(0) lgkmcnt(0) in front of EVERY load of prefetchIssue, i.e. nineteen sequential round trips to L2 per trip
-  //! (centroidal forward passes 6.5 -> 10.4 ms) — the "register allocation side effect" of round 4 (HISTORY) was this.
+  //! (centroidal forward passes 6.5 -> 10.4 ms); round 4's unexplained "register allocation side effect" (HISTORY) has the same signature.
   using GlobalPtr = const S __attribute__((address_space(1))) *;
   NMPC_D static GlobalPtr asGlobal(const S * p)
   {
@@ -2356,11 +2356,8 @@ struct TileSolver64
   NMPC_D static double bcastRow(double v)
   {
     double o;
-#ifdef NMPC_AMD_AB_NO_DPP_NOP
-    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "n"(J));
-#else
+    // (without the s_nop the results are WRONG — measured, HISTORY round 6: 980 of 4 096 instances failed)
     asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "n"(J));
-#endif
     return o;
   }
   /** acc -= (lane K's a) * x   (the back substitution's step; a was written long before: no wait states needed) */
@@ -2423,12 +2420,8 @@ struct TileSolver64
     const int c = freshLane() & 15;
     bool ok = true;
     asm volatile("s_nop 4"); // (an exec mask written by a VALU compare in front of a DPP instruction: five wait states)
-#ifndef NMPC_AMD_AB_SKIP_BATCH_FORWARD
     batchForward<0>(a, y, ok, c, m_lane);
-#endif
-#ifndef NMPC_AMD_AB_SKIP_BATCH_BACKWARD
     batchBackward<MM - 1>(a, y);
-#endif
     return ok;
   }
   /** Prepare trip of the slot whose columns lane group G4 will hold: Q terms and regularisation as backwardStep computes them, the

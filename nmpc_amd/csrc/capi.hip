@@ -743,9 +743,24 @@ int launchStream(nmpc_hip_ddp_solver * s, hipStream_t st, const nmpc_amd::hip::S
   const dim3 swap_grid(static_cast<unsigned>((s->Bp / 2 + 63) / 64), 64);
   const int wg_size = std::strcmp(s->ops->kernel_name(s->B, s->cfg), "ddp_solve_quad_kernel") == 0 ? 16 : 64;
   const dim3 fill_grid(static_cast<unsigned>(s->B), static_cast<unsigned>((s->T * s->MM + 1023) / 1024));
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  NMPC_HIP_TRY(hipEventCreate(&ev0));
-  NMPC_HIP_TRY(hipEventCreate(&ev1));
+  struct TimingEvents
+  {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~TimingEvents()
+    {
+      if(a)
+      {
+        (void)hipEventDestroy(a);
+      }
+      if(b)
+      {
+        (void)hipEventDestroy(b);
+      }
+    }
+  } tev;
+  NMPC_HIP_TRY(hipEventCreate(&tev.a));
+  NMPC_HIP_TRY(hipEventCreate(&tev.b));
+  hipEvent_t ev0 = tev.a, ev1 = tev.b;
   NMPC_HIP_TRY(hipEventRecord(ev0, st));
   hipLaunchKernelGGL(stream_begin_kernel, dim3(1), dim3(64), 0, st, w, n_total);
   NMPC_HIP_TRY(hipMemsetAsync(s->d_stream_id, 0xff, static_cast<size_t>(s->Bp) * sizeof(int), st)); // every slot empty (-1)
@@ -764,9 +779,28 @@ int launchStream(nmpc_hip_ddp_solver * s, hipStream_t st, const nmpc_amd::hip::S
   // The host queues blocks of four rounds and looks at the count of finished instances behind each block — two blocks ahead of the
   // device, so that the queue never runs dry while the host waits (a round behind an empty queue costs a few empty launches).
   constexpr int kBlock = 4, kAhead = 2;
-  int * h_done = nullptr;
-  NMPC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_done), kAhead * sizeof(int), hipHostMallocDefault));
-  hipEvent_t ev_blk[kAhead] = {nullptr, nullptr};
+  struct HostSide // (released on every way out of this function)
+  {
+    int * done = nullptr;
+    hipEvent_t ev[kAhead] = {nullptr, nullptr};
+    ~HostSide()
+    {
+      for(hipEvent_t e : ev)
+      {
+        if(e)
+        {
+          (void)hipEventDestroy(e);
+        }
+      }
+      if(done)
+      {
+        (void)hipHostFree(done);
+      }
+    }
+  } host;
+  NMPC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host.done), kAhead * sizeof(int), hipHostMallocDefault));
+  int * h_done = host.done;
+  hipEvent_t * ev_blk = host.ev;
   for(int k = 0; k < kAhead; k++)
   {
     h_done[k] = 0;
@@ -814,11 +848,6 @@ int launchStream(nmpc_hip_ddp_solver * s, hipStream_t st, const nmpc_amd::hip::S
       done = h_done[k] > done ? h_done[k] : done;
     }
   }
-  for(int k = 0; k < kAhead; k++)
-  {
-    (void)hipEventDestroy(ev_blk[k]);
-  }
-  (void)hipHostFree(h_done);
   if(le != hipSuccess)
   {
     (void)hipGetLastError();
@@ -828,8 +857,6 @@ int launchStream(nmpc_hip_ddp_solver * s, hipStream_t st, const nmpc_amd::hip::S
   NMPC_HIP_TRY(hipEventRecord(ev1, st));
   NMPC_HIP_TRY(hipEventSynchronize(ev1));
   NMPC_HIP_TRY(hipEventElapsedTime(&s->stream_ms, ev0, ev1));
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
   s->stream_rounds = rounds;
   if(done < n_total)
   {

@@ -318,7 +318,10 @@ def main(args, host_cores):
                 "solves_per_s": world * args.steps * B / elapsed,
                 "kernels": solver.kernelNames(),
                 "kernel_ms_per_iteration": per_iter_ms,
-                "lane_mapping": "timestep-parallel kernels: one thread per (instance, timestep), arrays [timestep][element][instance]; "
+                "lane_mapping": "an iteration of the fused sequence is three launches: Riccati (coefficient records by producer waves), delta, "
+                                "tail (step length + update + the next iteration's barrier parameter, KKT-error terms and terminal record: a "
+                                "workgroup per 16 instances walks the horizon in slices); "
+                                "timestep-parallel kernels: one thread per (instance, timestep), arrays [timestep][element][instance]; "
                                 "Riccati recursion: sixteen lanes per instance on v_mfma_f64_4x4x4 (16-instance workgroups, operands "
                                 "staged through LDS) up to two workgroups per CU, one lane per instance beyond",
                 "final_gather_ms": 1e3 * gather_s,

@@ -45,6 +45,7 @@ struct FmpcBuffers
   int T = 0; // horizon_steps
   int N = 0, M = 0, G = 0;
   int riccati_force = 0; // host side: which Riccati kernel the handle launches (0 automatic, 1 matrix-core, 2 lane; fmpc_ops.hpp)
+  int fuse_tail = 1; // host side: fmpc_tail_kernel closes an iteration of the fused-Riccati sequence (0: the separate kernels; NMPC_HIP_FMPC_TAIL)
   int coef_stride = 0; // doubles per timestep in `coef`
   int gain_stride = 0; // doubles per timestep in `gain`
   // Variable (FmpcSolver.h:117-158): x [T+1][N][B], u [T][M][B], lambda [T+1][N][B], s [T][G][B], nu [T][G][B]
@@ -122,6 +123,25 @@ __device__ __forceinline__ bool bad(double v)
 {
   return !(fabs(v) <= DBL_MAX); // NaN or Inf (CHECK_NAN, FmpcSolver.hpp:10-18)
 }
+
+/** bad(v_1) || bad(v_2) || ... in one instruction per value: v x 0 is NaN exactly when v is NaN or Inf and (+-)0 otherwise, a sum of
+    such terms is NaN exactly when one of them is.  (Coefficient::containsNaN, FmpcSolver.hpp:136-154, checks ~75 values per
+    timestep; as compare + scalar AND pairs they were a tenth of a producer wave's record in fmpc_riccati_fused_kernel [measured:
+    224 -> 233 us per launch when the producers took the check over].)  Four sums, so that consecutive terms do not wait for each other. */
+struct NanAccumulator
+{
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  int n = 0; // (a compile-time constant wherever the calls sit in straight-line code)
+  __device__ __forceinline__ void add(double v)
+  {
+    acc[n & 3] = __builtin_fma(v, 0.0, acc[n & 3]);
+    n++;
+  }
+  __device__ __forceinline__ bool any() const
+  {
+    return bad((acc[0] + acc[1]) + (acc[2] + acc[3]));
+  }
+};
 
 /** Offsets of the per-timestep coefficient record. */
 template<int N, int M>
@@ -730,6 +750,15 @@ namespace fmpc
     producer wave of fmpc_riccati_fused_kernel (the record, into LDS) are this function with other sinks. */
 /** What coefficients() reads of the variable: requested by loadCoefInputs() — the producer wave of fmpc_riccati_fused_kernel does
     that a chunk before it computes from them, so that the round trip to HBM is off its path. */
+/** a b + c in ONE rounding, written out.  The sums of the KKT-error terms and of (2.25b), (2.25c) start from zero: as `acc += a * b`
+    their first two products are a sum of two products, of which the compiler fuses EITHER into the addition — which one depended on
+    the code around it [measured: the terminal term of coefficients() inlined into fmpc_tail_kernel came out as fma(L0, L0, L1 L1),
+    in fmpc_coeff_kernel as fma(L1, L1, L0 L0): one ulp apart in a quarter of the instances].  With the fusion spelled out every
+    kernel that inlines coefficients() computes the same bits by construction. */
+__device__ __forceinline__ double fused(double a, double b, double c)
+{
+  return __builtin_fma(a, b, c);
+}
 template<class Problem>
 struct CoefInputs
 {
@@ -751,20 +780,34 @@ __device__ __forceinline__ void loadCoefInputs(const FmpcBuffers & buf, int b, i
     loadVec(buf.nu, buf, i, b, in.nu);
   }
 }
-template<class Problem, class Sink>
+/** \tparam kPart 0: whatever timestep i is; 1: i is the terminal timestep (i == buf.T); 2: i is not — a caller that knows which
+    (fmpc_tail_kernel) leaves the other branch out of its code */
+template<class Problem, class Sink, int kPart = 0>
+__device__ __forceinline__ void coefficientsOf(const FmpcBuffers & buf, int b, int i, const CoefInputs<Problem> & in, Sink & sink,
+                                               const Problem & prob, double t0);
+template<class Problem, class Sink, int kPart = 0>
 __device__ __forceinline__ void coefficients(const FmpcBuffers & buf, int b, int i, const CoefInputs<Problem> & in, Sink & sink)
+{
+  const Problem prob = loadProblem<Problem>(buf, b);
+  coefficientsOf<Problem, Sink, kPart>(buf, b, i, in, sink, prob, buf.t0[b]);
+}
+/** coefficients() with the instance's problem object and current_t handed in (fmpc_tail_kernel keeps them at hand: a load from
+    global memory in the middle of its walk waits for everything requested before it). */
+template<class Problem, class Sink, int kPart>
+__device__ __forceinline__ void coefficientsOf(const FmpcBuffers & buf, int b, int i, const CoefInputs<Problem> & in, Sink & sink,
+                                               const Problem & prob, double t0)
 {
   constexpr int N = Problem::kStateDim, M = Problem::kInputDimMax, G = Problem::kIneqDim;
   using CL = CoefLayout<N, M>;
   using GL = GainLayout<N, M>;
-  const Problem prob = loadProblem<Problem>(buf, b);
   const double dt = prob.dt();
-  const double t = buf.t0[b] + i * dt;
+  const double t = t0 + i * dt;
   const typename Problem::StateDimVector & x = in.x, & lambda = in.lambda;
   double kkt = 0;
   bool nan = false;
+  NanAccumulator nan_acc;
 
-  if(i == buf.T)
+  if(kPart != 2 && (kPart == 1 || i == buf.T))
   {
     // terminal coefficient (:429-436), start of the backward recursion (2.34) (:541-548)
     typename Problem::StateDimVector Vx;
@@ -774,7 +817,7 @@ __device__ __forceinline__ void coefficients(const FmpcBuffers & buf, int b, int
     for(int a = 0; a < N; a++)
     {
       const double Lx_bar = Vx[a] - lambda[a]; // (2.25a)
-      kkt += Lx_bar * Lx_bar;
+      kkt = fused(Lx_bar, Lx_bar, kkt);
       const double sT = -1 * Lx_bar;
       nan = nan || bad(Vx[a]) || bad(Lx_bar);
       sink.terminal(GL::S + a, sT);
@@ -816,7 +859,7 @@ __device__ __forceinline__ void coefficients(const FmpcBuffers & buf, int b, int
     for(int a = 0; a < N; a++)
     {
       const double e = buf.x0[static_cast<size_t>(a) * buf.B + b] - x[a];
-      kkt += e * e;
+      kkt = fused(e, e, kkt);
     }
   }
   double x_bar[N], g_bar[G > 0 ? G : 1], Lx_bar[N], Lu_bar[M > 0 ? M : 1];
@@ -825,8 +868,8 @@ __device__ __forceinline__ void coefficients(const FmpcBuffers & buf, int b, int
   for(int a = 0; a < N; a++)
   {
     x_bar[a] = f[a] - next_x[a]; // (2.23c)
-    part += x_bar[a] * x_bar[a];
-    nan = nan || bad(x_bar[a]);
+    part = fused(x_bar[a], x_bar[a], part);
+    nan_acc.add(x_bar[a]);
   }
   kkt += part;
   part = 0;
@@ -834,8 +877,8 @@ __device__ __forceinline__ void coefficients(const FmpcBuffers & buf, int b, int
   for(int a = 0; a < G; a++)
   {
     g_bar[a] = g[a] + s[a]; // (2.23d)
-    part += g_bar[a] * g_bar[a];
-    nan = nan || bad(g_bar[a]);
+    part = fused(g_bar[a], g_bar[a], part);
+    nan_acc.add(g_bar[a]);
   }
   kkt += part;
   part = 0;
@@ -846,16 +889,17 @@ __device__ __forceinline__ void coefficients(const FmpcBuffers & buf, int b, int
     NMPC_UNROLL
     for(int r = 0; r < N; r++)
     {
-      at += A(r, a) * next_lambda[r];
+      at = fused(A(r, a), next_lambda[r], at);
     }
     NMPC_UNROLL
     for(int r = 0; r < G; r++)
     {
-      ct += C(r, a) * nu[r];
+      ct = fused(C(r, a), nu[r], ct);
     }
     Lx_bar[a] = ((-1 * lambda[a] + dt * Lx[a]) + at) + ct;
-    part += Lx_bar[a] * Lx_bar[a];
-    nan = nan || bad(Lx_bar[a]) || bad(Lx[a]);
+    part = fused(Lx_bar[a], Lx_bar[a], part);
+    nan_acc.add(Lx_bar[a]);
+    nan_acc.add(Lx[a]);
   }
   kkt += part;
   part = 0;
@@ -866,16 +910,17 @@ __device__ __forceinline__ void coefficients(const FmpcBuffers & buf, int b, int
     NMPC_UNROLL
     for(int r = 0; r < N; r++)
     {
-      bt += Bm(r, a) * next_lambda[r];
+      bt = fused(Bm(r, a), next_lambda[r], bt);
     }
     NMPC_UNROLL
     for(int r = 0; r < G; r++)
     {
-      dn += D(r, a) * nu[r];
+      dn = fused(D(r, a), nu[r], dn);
     }
     Lu_bar[a] = (dt * Lu[a] + bt) + dn;
-    part += Lu_bar[a] * Lu_bar[a];
-    nan = nan || bad(Lu_bar[a]) || bad(Lu[a]);
+    part = fused(Lu_bar[a], Lu_bar[a], part);
+    nan_acc.add(Lu_bar[a]);
+    nan_acc.add(Lu[a]);
   }
   kkt += part;
   part = 0;
@@ -884,7 +929,7 @@ __device__ __forceinline__ void coefficients(const FmpcBuffers & buf, int b, int
   {
     const double v = s[j] * nu[j];
     const double e = v < 0.0 ? 0.0 : v; // array().max(0): (a < 0) ? 0 : a
-    part += e * e;
+    part = fused(e, e, part);
   }
   kkt += part;
   sink.kkt(kkt);
@@ -893,29 +938,31 @@ __device__ __forceinline__ void coefficients(const FmpcBuffers & buf, int b, int
   NMPC_UNROLL
   for(int e = 0; e < N * N; e++)
   {
-    nan = nan || bad(A.data()[e]) || bad(Lxx.data()[e]);
+    nan_acc.add(A.data()[e]);
+    nan_acc.add(Lxx.data()[e]);
   }
   NMPC_UNROLL
   for(int e = 0; e < N * M; e++)
   {
-    nan = nan || bad(Bm.data()[e]) || bad(Lxu.data()[e]);
+    nan_acc.add(Bm.data()[e]);
+    nan_acc.add(Lxu.data()[e]);
   }
   NMPC_UNROLL
   for(int e = 0; e < G * N; e++)
   {
-    nan = nan || bad(C.data()[e]);
+    nan_acc.add(C.data()[e]);
   }
   NMPC_UNROLL
   for(int e = 0; e < G * M; e++)
   {
-    nan = nan || bad(D.data()[e]);
+    nan_acc.add(D.data()[e]);
   }
   NMPC_UNROLL
   for(int e = 0; e < M * M; e++)
   {
-    nan = nan || bad(Luu.data()[e]);
+    nan_acc.add(Luu.data()[e]);
   }
-  if(nan)
+  if(nan || nan_acc.any())
   {
     sink.nanFlag();
   }
@@ -1061,6 +1108,480 @@ __global__ void __launch_bounds__(256) fmpc_coeff_kernel(FmpcBuffers buf)
   fmpc::CoefInputs<Problem> in;
   fmpc::loadCoefInputs<Problem>(buf, b, i, in);
   fmpc::coefficients<Problem>(buf, b, i, in, sink);
+}
+
+namespace fmpc
+{
+/** Sink of fmpc_tail_kernel: the timestep's KKT-error terms; of the terminal timestep also the terminal record and its NaN verdict.
+    The records of the other timesteps — and THEIR NaN verdict — are the business of fmpc_riccati_fused_kernel's producer waves, so
+    everything of coefficients() behind the KKT terms is dead code here. */
+template<int N, int M, bool kTerminal>
+struct TailSink
+{
+  const FmpcBuffers & buf;
+  int b, i;
+  int * nan_flag;
+  __device__ __forceinline__ void coef(int, double) const {}
+  __device__ __forceinline__ void terminal(int e, double v) const
+  {
+    if constexpr(kTerminal)
+    {
+      buf.gain[at(buf, i, e, GainLayout<N, M>::kStride, b)] = v;
+    }
+  }
+  __device__ __forceinline__ void kkt(double v) const
+  {
+    buf.part[at(buf, i, 0, kPartSlots, b)] = v;
+  }
+  __device__ __forceinline__ void nanFlag() const
+  {
+    if constexpr(kTerminal)
+    {
+      *nan_flag = 1; // (benign race: every writer stores 1)
+    }
+  }
+  __device__ __forceinline__ void midpoint() const {}
+};
+
+/** v + a d, the variable update (FmpcSolver.hpp:803-808): ONE function for the timestep's owner and for the neighbour that needs the
+    updated value before the owner has stored it, so both evaluate the same instruction. */
+__device__ __forceinline__ double stepped(double v, double a, double d)
+{
+  return v + a * d;
+}
+// Horizon slices of a workgroup of fmpc_tail_kernel at most (x 16 instances = its threads).  16: 256 threads, one wave per SIMD with
+// 512 registers — the KKT terms' model code next to a timestep in flight needs ~300 (cart-pole); with 32 / 48 / 64 slices (256 /
+// 168 / 128 registers) it spills, and a reload waits for every request in flight [measured, us per launch: 81 / 87 / 165 / 185].
+#ifndef NMPC_AMD_FMPC_TAIL_SLICES
+#  define NMPC_AMD_FMPC_TAIL_SLICES 16
+#endif
+constexpr int kTailMaxSlices = NMPC_AMD_FMPC_TAIL_SLICES;
+/** Byte offset of element (timestep i, entry e, instance b) in 32 bits, and accesses by it: fmpc_tail_kernel's arrays are below 4 GB
+    (tailFits), and a row offset is then ONE register shared by every array of the same entry count — as 64-bit addresses, one pair
+    per access, the walk's body needed more registers than a 512-thread workgroup has [measured: 256 + 44 spilled]. */
+__device__ __forceinline__ unsigned off32(const FmpcBuffers & buf, int i, int e, int stride, int b)
+{
+  return ((static_cast<unsigned>(i) * stride + e) * static_cast<unsigned>(buf.B) + b) * 8u;
+}
+__device__ __forceinline__ double ld32(const double * base, unsigned off)
+{
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + off);
+}
+__device__ __forceinline__ void st32(double * base, unsigned off, double v)
+{
+  *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + off) = v;
+}
+/** Dynamic LDS of fmpc_tail_kernel for the s . nu terms of a horizon of T steps, 0 when that is more than a workgroup gets. */
+inline unsigned tailDotBytes(int T)
+{
+  const size_t bytes = static_cast<size_t>(T) * 16 * sizeof(double);
+  return bytes <= 48 * 1024 ? static_cast<unsigned>(bytes) : 0u;
+}
+/** Whether every array fmpc_tail_kernel touches is below 4 GB. */
+inline bool tailFits(const FmpcBuffers & buf)
+{
+  int widest = buf.gain_stride;
+  widest = buf.N > widest ? buf.N : widest;
+  widest = buf.G > widest ? buf.G : widest;
+  widest = kPartSlots > widest ? kPartSlots : widest;
+  return static_cast<double>(buf.T + 1) * widest * buf.B * 8.0 < 4.0e9;
+}
+/** Horizon slices of fmpc_tail_kernel for a horizon of T steps (a workgroup has 16 x this many threads). */
+inline int tailSlices(int T)
+{
+  const int per = (T + 1 + kTailMaxSlices - 1) / kTailMaxSlices;
+  int S = (T + 1 + per - 1) / per;
+  S = (S + 3) & ~3; // whole wavefronts
+  return S < kSlices ? kSlices : S;
+}
+} // namespace fmpc
+
+/** Everything of an iteration behind the forward pass, and the head of the next one, in ONE kernel (sequence with
+    fmpc_riccati_fused_kernel, line search off): the fraction-to-boundary reduction (fmpc_step_length_kernel, FmpcSolver.hpp:713-742),
+    the variable update (fmpc_update_kernel, :801-835), and for iteration iter + 1 the barrier parameter (fmpc_barrier_kernel,
+    :370-392), the KKT-error terms and the terminal record (fmpc_coeff_kernel<Problem, false>, :429-436, :493-521) — computed from the
+    updated variables while they are in registers instead of being read back by two more kernels; same arithmetic, same order of the
+    horizon sums, same bits.  A workgroup owns the WHOLE horizon of sixteen instances (one 128-byte line per row): thread = (horizon
+    slice, instance), a slice is a run of consecutive timesteps walked from its last to its first, so that the updated x, lambda of
+    timestep i + 1 — which the KKT terms of timestep i need (2.23c), (2.25b) — are the ones the thread computed a moment ago; only for
+    the last timestep of its run it computes the neighbour's (before anybody stores: the barrier in front of the walk).
+    \param last  iter is the solve's last iteration: nothing of an iteration iter + 1
+    \param dots_in_lds  the launch gave T x 16 doubles of dynamic LDS for the s . nu terms (fmpc::tailDotBytes; else they are read back
+                        from FmpcBuffers::part) */
+template<class Problem>
+__global__ void __launch_bounds__(16 * fmpc::kTailMaxSlices) fmpc_tail_kernel(FmpcBuffers buf, int iter, int last, int dots_in_lds)
+{
+  constexpr int N = Problem::kStateDim, M = Problem::kInputDimMax, G = Problem::kIneqDim;
+  extern __shared__ double sh_dot[]; // [T][16] s . nu of the updated timesteps when dots_in_lds (the launch sized it), else unused
+  __shared__ double sh_a[2][fmpc::kTailMaxSlices][16];
+  __shared__ double sh_sum[fmpc::kSlices][16];
+  __shared__ double sh_alpha[2][16];
+  __shared__ int sh_go[16];
+  __shared__ int sh_nan[16];
+  // the sixteen problem objects: read from LDS inside the walk (a global load there would wait for the requests of the next timestep)
+  static_assert(sizeof(Problem) % sizeof(unsigned) == 0, "[FMPC] a problem object is a whole number of 32-bit words");
+  constexpr int kProbWords = sizeof(Problem) / sizeof(unsigned);
+  __shared__ __attribute__((aligned(16))) unsigned sh_prob[16][(kProbWords + 3) / 4 * 4];
+  const int inst = threadIdx.x & 15;
+  const int q = threadIdx.x >> 4;
+  const int S = blockDim.x >> 4;
+  for(int k = threadIdx.x; k < 16 * kProbWords; k += blockDim.x)
+  {
+    const int pi = k / kProbWords, w = k % kProbWords;
+    const int pb = min(static_cast<int>(blockIdx.x) * 16 + pi, buf.B - 1);
+    sh_prob[pi][w] = reinterpret_cast<const unsigned *>(static_cast<const Problem *>(buf.problems) + (buf.own_problems ? pb : 0))[w];
+  }
+  const int b_raw = blockIdx.x * 16 + inst;
+  const int b = b_raw < buf.B ? b_raw : buf.B - 1; // lanes beyond the batch mirror the last instance and store nothing
+  const int T = buf.T;
+  const bool act = b_raw < buf.B && buf.status[b] == fmpc::kStatusContinued;
+  const int per = (T + 1 + S - 1) / S;
+  const int lo = q * per;
+  const int hi = min(T + 1, lo + per); // this thread's timesteps: [lo, hi), possibly none
+#ifdef NMPC_AMD_FMPC_TAIL_PROFILE
+  const unsigned long long tick_a = wall_clock64();
+#endif
+  /** What the update of one timestep reads. */
+  struct Loaded
+  {
+    double x[N], dx[N], lam[N], dlam[N];
+    double u[M > 0 ? M : 1], du[M > 0 ? M : 1];
+    double s[G > 0 ? G : 1], ds[G > 0 ? G : 1], nu[G > 0 ? G : 1], dnu[G > 0 ? G : 1];
+  };
+  auto request = [&](int i, Loaded & v) {
+    NMPC_UNROLL
+    for(int e = 0; e < N; e++)
+    {
+      const unsigned k = fmpc::off32(buf, i, e, N, b);
+      v.x[e] = fmpc::ld32(buf.x, k);
+      v.dx[e] = fmpc::ld32(buf.dx, k);
+      v.lam[e] = fmpc::ld32(buf.lam, k);
+      v.dlam[e] = fmpc::ld32(buf.dlam, k);
+    }
+    if(i < T)
+    {
+      NMPC_UNROLL
+      for(int e = 0; e < M; e++)
+      {
+        const unsigned k = fmpc::off32(buf, i, e, M, b);
+        v.u[e] = fmpc::ld32(buf.u, k);
+        v.du[e] = fmpc::ld32(buf.du, k);
+      }
+      NMPC_UNROLL
+      for(int e = 0; e < G; e++)
+      {
+        const unsigned k = fmpc::off32(buf, i, e, G, b);
+        v.s[e] = fmpc::ld32(buf.s, k);
+        v.ds[e] = fmpc::ld32(buf.ds, k);
+        v.nu[e] = fmpc::ld32(buf.nu, k);
+        v.dnu[e] = fmpc::ld32(buf.dnu, k);
+      }
+    }
+  };
+  // ---- requested first, used behind the step-length reduction (one round trip for all three): x, dx, lambda, dlambda of the
+  // timestep behind this thread's run — read before anybody stores, the workgroup barriers of the reduction see to that — and the
+  // run's last timestep
+  const int top = hi - 1;
+  const bool has_run = lo < hi;
+  const bool has_behind = has_run && top < T;
+  double bx[N] = {}, bdx[N] = {}, bl[N] = {}, bdl[N] = {};
+  Loaded next;
+  if(act && has_behind)
+  {
+    NMPC_UNROLL
+    for(int e = 0; e < N; e++)
+    {
+      const unsigned k = fmpc::off32(buf, top + 1, e, N, b);
+      bx[e] = fmpc::ld32(buf.x, k);
+      bdx[e] = fmpc::ld32(buf.dx, k);
+      bl[e] = fmpc::ld32(buf.lam, k);
+      bdl[e] = fmpc::ld32(buf.dlam, k);
+    }
+  }
+  if(act && has_run)
+  {
+    request(top, next);
+  }
+  const double t0 = buf.t0[b];
+
+  // ---- step length: minimum of the per-timestep candidates, in timestep order (the first of equal minima wins, as in the
+  // sequential loop of the reference and in fmpc_step_length_kernel)
+  // (loads in batches of eight: the compiler does not move a load of the next trip over the compare of this one, and a trip per
+  // round trip to L2 was a third of the kernel)
+  constexpr int kBatch = 16;
+  double a_s = 1.0, a_nu = 1.0;
+  if(act)
+  {
+    const int i1 = min(hi, T);
+    for(int i0 = lo; i0 < i1; i0 += kBatch)
+    {
+      double cs[kBatch], cn[kBatch];
+      NMPC_UNROLL
+      for(int j = 0; j < kBatch; j++)
+      {
+        const int i = min(i0 + j, i1 - 1);
+        cs[j] = fmpc::ld32(buf.part, fmpc::off32(buf, i, 1, fmpc::kPartSlots, b));
+        cn[j] = fmpc::ld32(buf.part, fmpc::off32(buf, i, 2, fmpc::kPartSlots, b));
+      }
+      NMPC_UNROLL
+      for(int j = 0; j < kBatch; j++)
+      {
+        if(i0 + j < i1)
+        {
+          a_s = (cs[j] < a_s) ? cs[j] : a_s;
+          a_nu = (cn[j] < a_nu) ? cn[j] : a_nu;
+        }
+      }
+    }
+  }
+  sh_a[0][q][inst] = a_s;
+  sh_a[1][q][inst] = a_nu;
+  if(q == 0)
+  {
+    sh_nan[inst] = 0;
+  }
+  // (the values of the timestep behind the run have ARRIVED before the barrier — a use the compiler cannot move: their owner
+  // stores the updated ones two barriers from here)
+  NMPC_UNROLL
+  for(int e = 0; e < N; e++)
+  {
+    asm volatile("" ::"v"(bx[e]), "v"(bdx[e]), "v"(bl[e]), "v"(bdl[e]));
+  }
+  syncThreadsFuzzed(__LINE__);
+  if(q == 0)
+  {
+    bool go = false;
+    if(act)
+    {
+      for(int k = 1; k < S; k++)
+      {
+        a_s = (sh_a[0][k][inst] < a_s) ? sh_a[0][k][inst] : a_s;
+        a_nu = (sh_a[1][k][inst] < a_nu) ? sh_a[1][k][inst] : a_nu;
+      }
+      if(buf.check_nan && (buf.flags[b] & 2))
+      {
+        buf.status[b] = 2; // Status::ErrorInForward
+      }
+      else
+      {
+        double * row = buf.trace + (static_cast<size_t>(b) * buf.max_iter + (iter - 1)) * NMPC_HIP_FMPC_NTRACE;
+        row[NMPC_HIP_FMPC_TRACE_ALPHA_S_MAX] = a_s;
+        row[NMPC_HIP_FMPC_TRACE_ALPHA_NU_MAX] = a_nu;
+        row[NMPC_HIP_FMPC_TRACE_ALPHA_S] = a_s;
+        buf.alpha[0 * buf.B + b] = a_s;
+        buf.alpha[1 * buf.B + b] = a_nu;
+        buf.alpha[2 * buf.B + b] = a_s;
+        if(!(a_s > 0.0 && a_s <= 1.0 && a_nu > 0.0 && a_nu <= 1.0))
+        {
+          buf.status[b] = 4; // Status::ErrorInUpdate
+        }
+        else
+        {
+          go = true;
+        }
+      }
+    }
+    sh_alpha[0][inst] = a_s;
+    sh_alpha[1][inst] = a_nu;
+    sh_go[inst] = go ? 1 : 0;
+  }
+  syncThreadsFuzzed(__LINE__);
+  const bool go = sh_go[inst] != 0; // the instance takes the step
+  const double alpha_s = sh_alpha[0][inst], alpha_nu = sh_alpha[1][inst];
+  const Problem & prob = *reinterpret_cast<const Problem *>(sh_prob[inst]);
+
+  // ---- the updated x, lambda of the timestep behind this thread's run
+  typename Problem::StateDimVector nx, nl;
+  if(go && has_behind)
+  {
+    NMPC_UNROLL
+    for(int e = 0; e < N; e++)
+    {
+      nx[e] = fmpc::stepped(bx[e], alpha_s, bdx[e]);
+      nl[e] = fmpc::stepped(bl[e], alpha_nu, bdl[e]);
+    }
+  }
+#ifdef NMPC_AMD_FMPC_TAIL_PROFILE
+  const unsigned long long tick_b = wall_clock64();
+#endif
+
+  // ---- update, s . nu and the KKT-error terms of the updated timestep, last timestep of the run first.  A timestep's values are
+  // all requested before the previous timestep's are stored (the stores of timestep i and the loads of timestep i - 1 may alias as
+  // far as the compiler knows: written in source order they were ~17 dependent round trips per timestep [measured: 118 us])
+  if(go)
+  {
+    for(int walk = top; walk >= lo; walk--)
+    {
+      // (the timestep behind an empty asm: the ~120 row addresses of the body are then computed from it where they are used — as
+      // induction variables of the walk they were 2 x 120 registers that lived across the whole body [measured: 251 spills])
+      int i = walk;
+      asm volatile("" : "+v"(i));
+      const Loaded v = next;
+      if(walk > lo)
+      {
+        request(i - 1, next);
+      }
+      fmpc::CoefInputs<Problem> in;
+      NMPC_UNROLL
+      for(int e = 0; e < N; e++)
+      {
+        in.x[e] = fmpc::stepped(v.x[e], alpha_s, v.dx[e]);
+        in.lambda[e] = fmpc::stepped(v.lam[e], alpha_nu, v.dlam[e]);
+      }
+      double dot = 0; // s . nu of the updated timestep, for the barrier update below (FmpcSolver.hpp:376-380)
+      if(i < T)
+      {
+        NMPC_UNROLL
+        for(int e = 0; e < M; e++)
+        {
+          in.u[e] = fmpc::stepped(v.u[e], alpha_s, v.du[e]);
+        }
+        // the reference clamps at numeric_limits<double>::lowest() (= -DBL_MAX, FmpcSolver.hpp:812) when an entry went negative:
+        // restated as written (array().max(c) = (a < c) ? c : a)
+        constexpr double min_positive_value = -DBL_MAX;
+        bool s_neg = false, nu_neg = false;
+        NMPC_UNROLL
+        for(int e = 0; e < G; e++)
+        {
+          in.s[e] = fmpc::stepped(v.s[e], alpha_s, v.ds[e]);
+          in.nu[e] = fmpc::stepped(v.nu[e], alpha_nu, v.dnu[e]);
+          s_neg = s_neg || in.s[e] < 0;
+          nu_neg = nu_neg || in.nu[e] < 0;
+        }
+        NMPC_UNROLL
+        for(int e = 0; e < G; e++)
+        {
+          if(s_neg && in.s[e] < min_positive_value)
+          {
+            in.s[e] = min_positive_value;
+          }
+          if(nu_neg && in.nu[e] < min_positive_value)
+          {
+            in.nu[e] = min_positive_value;
+          }
+          dot += in.s[e] * in.nu[e];
+        }
+      }
+      // stores
+      NMPC_UNROLL
+      for(int e = 0; e < N; e++)
+      {
+        const unsigned k = fmpc::off32(buf, i, e, N, b);
+        fmpc::st32(buf.x, k, in.x[e]);
+        fmpc::st32(buf.lam, k, in.lambda[e]);
+      }
+      if(i < T)
+      {
+        NMPC_UNROLL
+        for(int e = 0; e < M; e++)
+        {
+          fmpc::st32(buf.u, fmpc::off32(buf, i, e, M, b), in.u[e]);
+        }
+        NMPC_UNROLL
+        for(int e = 0; e < G; e++)
+        {
+          const unsigned k = fmpc::off32(buf, i, e, G, b);
+          fmpc::st32(buf.s, k, in.s[e]);
+          fmpc::st32(buf.nu, k, in.nu[e]);
+        }
+        fmpc::st32(buf.part, fmpc::off32(buf, i, 3, fmpc::kPartSlots, b), dot);
+        if(dots_in_lds)
+        {
+          sh_dot[i * 16 + inst] = dot;
+        }
+      }
+      if(!last)
+      {
+        if(i == T)
+        {
+          fmpc::TailSink<N, M, true> sink{buf, b, i, &sh_nan[inst]};
+          fmpc::coefficientsOf<Problem, fmpc::TailSink<N, M, true>, 1>(buf, b, i, in, sink, prob, t0);
+        }
+        else
+        {
+          in.next_x = nx;
+          in.next_lambda = nl;
+          fmpc::TailSink<N, M, false> sink{buf, b, i, nullptr};
+          fmpc::coefficientsOf<Problem, fmpc::TailSink<N, M, false>, 2>(buf, b, i, in, sink, prob, t0);
+        }
+      }
+      nx = in.x;
+      nl = in.lambda;
+    }
+  }
+#ifdef NMPC_AMD_FMPC_TAIL_PROFILE
+  const unsigned long long tick_c = wall_clock64();
+  syncThreadsFuzzed(__LINE__);
+  if(q == 0 && b_raw < buf.B && !last) // developer build only: 100 MHz ticks in the merit slots — reductions, this slice's walk, wait for the slowest
+  {
+    buf.merit[0 * buf.B + b] = static_cast<double>(tick_b - tick_a);
+    buf.merit[1 * buf.B + b] = static_cast<double>(tick_c - tick_b);
+    buf.merit[2 * buf.B + b] = static_cast<double>(wall_clock64() - tick_c);
+  }
+#endif
+  if(last)
+  {
+    return; // workgroup-uniform
+  }
+
+  // ---- head of iteration iter + 1: barrier parameter (19.19), the sums in fmpc_barrier_kernel's order; trace row
+  syncThreadsFuzzed(__LINE__); // the s . nu terms of the sixteen instances are in memory (workgroup scope)
+  if(q < fmpc::kSlices)
+  {
+    double acc = 0;
+    if(go && buf.update_barrier_eps)
+    {
+      const int chunk = (T + fmpc::kSlices - 1) / fmpc::kSlices;
+      const int i1 = min(T, (q + 1) * chunk);
+      for(int i = q * chunk; i < (dots_in_lds ? i1 : 0); i++)
+      {
+        acc += sh_dot[i * 16 + inst];
+      }
+      for(int i0 = q * chunk; i0 < (dots_in_lds ? 0 : i1); i0 += kBatch)
+      {
+        double v[kBatch];
+        NMPC_UNROLL
+        for(int j = 0; j < kBatch; j++)
+        {
+          v[j] = fmpc::ld32(buf.part, fmpc::off32(buf, min(i0 + j, i1 - 1), 3, fmpc::kPartSlots, b));
+        }
+        NMPC_UNROLL
+        for(int j = 0; j < kBatch; j++)
+        {
+          if(i0 + j < i1)
+          {
+            acc += v[j];
+          }
+        }
+      }
+    }
+    sh_sum[q][inst] = acc;
+  }
+  syncThreadsFuzzed(__LINE__);
+  if(q == 0 && go)
+  {
+    double eps = buf.barrier_eps[b];
+    if(buf.update_barrier_eps)
+    {
+      double s_nu_ave = 0;
+      for(int k = 0; k < fmpc::kSlices; k++)
+      {
+        s_nu_ave += sh_sum[k][inst];
+      }
+      s_nu_ave /= static_cast<double>(T * buf.G);
+      constexpr double sigma = 0.5;
+      constexpr double barrier_eps_min = 1e-8;
+      constexpr double barrier_eps_max = 1e6;
+      const double v = sigma * s_nu_ave;
+      eps = (v < barrier_eps_min) ? barrier_eps_min : ((barrier_eps_max < v) ? barrier_eps_max : v);
+      buf.barrier_eps[b] = eps;
+    }
+    buf.iters[b] = iter + 1;
+    buf.flags[b] = sh_nan[inst]; // bit 0 of the terminal record; the producer waves of the Riccati kernel speak for the other records
+    double * row = buf.trace + (static_cast<size_t>(b) * buf.max_iter + iter) * NMPC_HIP_FMPC_NTRACE;
+    row[NMPC_HIP_FMPC_TRACE_ITER] = iter + 1;
+    row[NMPC_HIP_FMPC_TRACE_BARRIER_EPS] = eps;
+  }
 }
 
 namespace fmpc
@@ -2012,6 +2533,7 @@ struct StagedCoefSink
   const FmpcBuffers & buf;
   int b, i;
   bool on, to_hbm;
+  int * nan_flag; //!< the instance's word of the workgroup: Coefficient::containsNaN of one of its records
   __device__ __forceinline__ void coef(int e, double v) const
   {
     if(on)
@@ -2030,7 +2552,13 @@ struct StagedCoefSink
   }
   __device__ __forceinline__ void terminal(int, double) const {}
   __device__ __forceinline__ void kkt(double) const {}
-  __device__ __forceinline__ void nanFlag() const {}
+  __device__ __forceinline__ void nanFlag() const
+  {
+    if(on)
+    {
+      *nan_flag = 1; // (every writer stores 1; read behind the backward pass, a workgroup barrier later)
+    }
+  }
 };
 } // namespace fmpc
 
@@ -2054,12 +2582,22 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
   constexpr int kFwdGain = GL::K + M * N; // k, K: elements [0, kFwdGain) of the gain record
   constexpr int kRecF = (kFwdCoef + kFwdGain) | 1;
   constexpr int kSlotDoubles = kS * 16 * (kRecB > kRecF ? kRecB : kRecF);
+  // the forward pass walks the horizon in chunks of kF steps through TWO slots laid over the backward pass's three: a chunk costs one
+  // (partly hidden) round trip to HBM whatever its length
+#ifndef NMPC_AMD_FMPC_FWD_STEPS
+#  define NMPC_AMD_FMPC_FWD_STEPS (2 * NMPC_AMD_FMPC_STAGE_STEPS)
+#endif
+  constexpr int kF = NMPC_AMD_FMPC_FWD_STEPS;
+  constexpr int kFwdSlotDoubles = 3 * kSlotDoubles / 2;
+  static_assert(kF * 16 * kRecF <= kFwdSlotDoubles, "[FMPC] a forward chunk fits half of the staging area");
   constexpr int kRecG = (GL::kStride + 2) | 1; // gain record + two spare slots
   constexpr int kRecX = (N + M + 2) | 1; // dx, du + two spare slots
+  static_assert(kF * kRecX <= kS * kRecG, "[FMPC] dx, du of a forward chunk fit the area the gains of a backward chunk are parked in");
   __shared__ double stage_lds[3 * kSlotDoubles]; // chunk k of the backward pass in slot k % 3 (the forward pass uses two)
   __shared__ double gain_lds[kS * 16 * kRecG]; // what the chunk's steps produce (backward: gains, forward: dx, du), before it goes to HBM
   __shared__ double sh_kkt[16][17];
   __shared__ int sh_live[16];
+  __shared__ int sh_coef_nan[16]; // a record of the instance holds a NaN / Inf (the producer waves' finding)
 
   const int wl = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -2104,6 +2642,10 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
     }
     sh_kkt[t_inst][t_slot] = acc;
   }
+  else if(threadIdx.x < 256 + 16)
+  {
+    sh_coef_nan[threadIdx.x - 256] = 0;
+  }
   syncThreadsFuzzed(__LINE__);
   if(head)
   {
@@ -2146,34 +2688,32 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
   // every 16-lane group reads one whole line), parked in registers while the previous chunk is being consumed, written to LDS
   // as per-(timestep, instance) records and read from there by the lanes that need them.
   /** Elements [0, NR) of timesteps i0, i0 + dir, ..., i0 + (kS - 1) dir of this thread's instance: request into v. */
+  /** ... of the forward pass (dir = +1): every lane loads for every step — a lane without an element of its own the record's last
+      one, a step beyond the horizon the last step — so the requests are straight-line code and the wait in front of a commit can be
+      counted (behind per-lane branches the compiler waited for ALL requests, also the ones for two chunks ahead). */
   auto request = [&](auto nr_tag, const double * src, int stride, int i0, int dir, double * v) {
     constexpr int NR = decltype(nr_tag)::value;
     constexpr int kQ = (NR + 15) / 16;
     NMPC_UNROLL
-    for(int st = 0; st < kS; st++)
+    for(int st = 0; st < kF; st++)
     {
-      const int step = i0 + dir * st; // wavefront-uniform
-      if(step >= 0 && step < T)
+      const int step_raw = i0 + dir * st; // wavefront-uniform
+      const int step = step_raw < 0 ? 0 : (step_raw < T ? step_raw : T - 1);
+      NMPC_UNROLL
+      for(int q = 0; q < kQ; q++)
       {
-        const double * rowp = src + (static_cast<size_t>(step) * stride) * Bz + lane_stage;
-        NMPC_UNROLL
-        for(int q = 0; q < kQ; q++)
-        {
-          if(16 * q + 15 < NR || t_slot < NR - 16 * q)
-          {
-            v[st * kQ + q] = rowp[static_cast<size_t>(16 * q) * Bz];
-          }
-        }
+        const int e = (16 * q + 15 < NR || t_slot < NR - 16 * q) ? 16 * q + t_slot : NR - 1;
+        v[st * kQ + q] = src[(static_cast<size_t>(step) * stride + e) * Bz + b_stage];
       }
     }
   };
-  /** ... and park them in LDS slot `slot` as records of width W, at offset `off` of each record. */
+  /** ... and park them in forward-pass LDS slot `slot` as records of width W, at offset `off` of each record. */
   auto commit = [&](auto nr_tag, int slot, int W, int off, const double * v) {
     constexpr int NR = decltype(nr_tag)::value;
     constexpr int kQ = (NR + 15) / 16;
-    double * base = stage_lds + static_cast<size_t>(slot) * kSlotDoubles + t_inst * W + off + t_slot;
+    double * base = stage_lds + static_cast<size_t>(slot) * kFwdSlotDoubles + t_inst * W + off + t_slot;
     NMPC_UNROLL
-    for(int st = 0; st < kS; st++)
+    for(int st = 0; st < kF; st++)
     {
       NMPC_UNROLL
       for(int q = 0; q < kQ; q++)
@@ -2291,7 +2831,7 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
     fmpc::CoefInputs<Problem> in;
     fmpc::loadCoefInputs<Problem>(buf, b, i > 0 ? i : 0, in);
     fmpc::StagedCoefSink<N, M> sink{stage_lds + static_cast<size_t>(k % 3) * kSlotDoubles + (p_ts * 16 + p_inst) * kRecB, buf, b,
-                                    i > 0 ? i : 0, i >= 0, live};
+                                    i > 0 ? i : 0, i >= 0, live, &sh_coef_nan[p_inst]};
     fmpc::coefficients<Problem>(buf, b, i > 0 ? i : 0, in, sink); // (two workgroup barriers inside: sink.midpoint())
   };
   {
@@ -2371,7 +2911,7 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
     bad_any |= __shfl_xor(bad_any, 2);
     bad_any |= __shfl_xor(bad_any, 16);
     bad_any |= __shfl_xor(bad_any, 32);
-    const bool failed = buf.check_nan && (bad_any != 0 || (buf.flags[b] & 1));
+    const bool failed = buf.check_nan && (bad_any != 0 || (buf.flags[b] & 1) || sh_coef_nan[inst] != 0);
     if(live && failed && head)
     {
       buf.status[b] = 3; // Status::ErrorInBackward
@@ -2418,70 +2958,95 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
     dx_row = rv ? nx : 0.0;
   };
   {
+    // Operands of a chunk are requested TWO chunks ahead (two register sets, used alternately: the chunk loop is unrolled by two):
+    // a chunk of four steps is ~0.5 us of arithmetic and barriers, a request one chunk ahead came back after ~1.6 us — the forward
+    // pass was 50 round trips to HBM in a row [measured, profile build: 79 us of the launch's 233].
     constexpr int kQC = (kFwdCoef + 15) / 16, kQG = (kFwdGain + 15) / 16;
-    double vc[kS * kQC], vg[kS * kQG];
-    if(!producer)
+    double vcA[kF * kQC], vgA[kF * kQG], vcB[kF * kQC], vgB[kF * kQG];
+    // The two kinds of wavefront run SEPARATE loops with the same barriers.  dx, du of a chunk go from LDS to HBM (whole lines) by
+    // the producer waves, idle in this pass: a recursion wave then has loads only in flight, and its wait for the operands
+    // requested two chunks ago can leave the later requests pending — with stores of its own among them a wave has to wait for
+    // everything (loads and stores share a counter and complete out of order with respect to each other), and so it does if the
+    // stores merely sit on another path of the same loop.
+    if(producer)
     {
-      request(TagFc(), buf.coef, CL::kStride, 0, 1, vc);
-      request(TagFg(), buf.gain, GL::kStride, 0, 1, vg);
-      commit(TagFc(), 0, kRecF, 0, vc);
-      commit(TagFg(), 0, kRecF, kFwdCoef, vg);
-    }
-    syncThreadsFuzzed(__LINE__);
-    int slot = 0;
-    for(int i0 = 0; i0 < T; i0 += kS)
-    {
-      if(!producer)
+      const int f_slot = t_slot - 16; // waves 4, 5: element slot 0 ... 7 of instance t_inst
+      syncThreadsFuzzed(__LINE__);
+      for(int i0 = 0; i0 < T; i0 += kF)
       {
-        if(i0 + kS < T)
+        syncThreadsFuzzed(__LINE__); // the chunk's dx, du are in LDS
+        if(sh_live[t_inst] != 0 && f_slot < N + M)
         {
-          request(TagFc(), buf.coef, CL::kStride, i0 + kS, 1, vc);
-          request(TagFg(), buf.gain, GL::kStride, i0 + kS, 1, vg);
+          NMPC_UNROLL
+          for(int st = 0; st < kF; st++)
+          {
+            const int step = i0 + st;
+            if(step < T)
+            {
+              const double v = gain_lds[(st * 16 + t_inst) * kRecX + f_slot];
+              if(f_slot < N)
+              {
+                buf.dx[(static_cast<size_t>(step) * N + f_slot) * Bz + b_stage] = v;
+              }
+              else
+              {
+                buf.du[(static_cast<size_t>(step) * M + (f_slot - N)) * Bz + b_stage] = v;
+              }
+            }
+          }
         }
-        const double * recs = stage_lds + static_cast<size_t>(slot) * kSlotDoubles + inst * kRecF;
+        syncThreadsFuzzed(__LINE__);
+      }
+    }
+    else
+    {
+      request(TagFc(), buf.coef, CL::kStride, 0, 1, vcA);
+      request(TagFg(), buf.gain, GL::kStride, 0, 1, vgA);
+      commit(TagFc(), 0, kRecF, 0, vcA);
+      commit(TagFg(), 0, kRecF, kFwdCoef, vgA);
+      request(TagFc(), buf.coef, CL::kStride, kF, 1, vcB); // (steps beyond the horizon: the last step again, never parked)
+      request(TagFg(), buf.gain, GL::kStride, kF, 1, vgB);
+      request(TagFc(), buf.coef, CL::kStride, 2 * kF, 1, vcA);
+      request(TagFg(), buf.gain, GL::kStride, 2 * kF, 1, vgA);
+      syncThreadsFuzzed(__LINE__);
+      /** Chunk [i0, i0 + kF) from staging slot `slot`; parks chunk i0 + kF (register set `vc`, `vg`, requested two chunks ago) in the
+          other slot and requests chunk i0 + 3 kF into the set at once: at the next chunk's commit the compiler's wait lets at most
+          eleven requests stay pending, i.e. it also waits for the first of the set requested last — which is then a whole chunk
+          old instead of a chunk's arithmetic. */
+      auto forwardChunk = [&](int i0, int slot, double * vc, double * vg) {
+        const double * recs = stage_lds + static_cast<size_t>(slot) * kFwdSlotDoubles + inst * kRecF;
         ForwardOperands o[2];
         loadForward(recs, o[0]);
         NMPC_UNROLL
-        for(int st = 0; st < kS; st++)
+        for(int st = 0; st < kF; st++)
         {
           if(i0 + st < T)
           {
-            if(st + 1 < kS)
+            if(st + 1 < kF)
             {
               loadForward(recs + (st + 1) * 16 * kRecF, o[(st + 1) & 1]);
             }
             forwardStep(st, o[st & 1]);
           }
         }
-      }
-      syncThreadsFuzzed(__LINE__);
-      if(!producer && i0 + kS < T)
-      {
-        commit(TagFc(), slot ^ 1, kRecF, 0, vc);
-        commit(TagFg(), slot ^ 1, kRecF, kFwdCoef, vg);
-      }
-      if(!producer && sh_live[t_inst] != 0 && t_slot < N + M) // dx, du of the chunk: LDS -> HBM in whole lines
-      {
-        NMPC_UNROLL
-        for(int st = 0; st < kS; st++)
+        syncThreadsFuzzed(__LINE__);
+        if(i0 + kF < T)
         {
-          const int step = i0 + st;
-          if(step < T)
-          {
-            const double v = gain_lds[(st * 16 + t_inst) * kRecX + t_slot];
-            if(t_slot < N)
-            {
-              buf.dx[(static_cast<size_t>(step) * N + t_slot) * Bz + b_stage] = v;
-            }
-            else
-            {
-              buf.du[(static_cast<size_t>(step) * M + (t_slot - N)) * Bz + b_stage] = v;
-            }
-          }
+          commit(TagFc(), slot ^ 1, kRecF, 0, vc);
+          commit(TagFg(), slot ^ 1, kRecF, kFwdCoef, vg);
+          request(TagFc(), buf.coef, CL::kStride, i0 + 3 * kF, 1, vc);
+          request(TagFg(), buf.gain, GL::kStride, i0 + 3 * kF, 1, vg);
+        }
+        syncThreadsFuzzed(__LINE__);
+      };
+      for(int i0 = 0; i0 < T; i0 += 2 * kF)
+      {
+        forwardChunk(i0, 0, vcB, vgB);
+        if(i0 + kF < T) // (workgroup-uniform)
+        {
+          forwardChunk(i0 + kF, 1, vcA, vgA);
         }
       }
-      syncThreadsFuzzed(__LINE__);
-      slot ^= 1;
     }
   }
   if(!producer && live && c0 && rv)

@@ -84,6 +84,12 @@ struct FmpcOps
   hipError_t (*launch_coeff)(const FmpcBuffers & buf, hipStream_t stream);
   hipError_t (*launch_riccati)(const FmpcBuffers & buf, int iter, hipStream_t stream);
   hipError_t (*launch_delta)(const FmpcBuffers & buf, hipStream_t stream);
+  //! fmpc_tail_kernel: step length + update of iteration iter and the head of iteration iter + 1 (barrier parameter, KKT-error terms,
+  //! terminal record).  \return hipErrorNotSupported where the sequence does not apply (tail_applies)
+  hipError_t (*launch_tail)(const FmpcBuffers & buf, int iter, int last, hipStream_t stream);
+  //! whether an iteration of this handle ends in fmpc_tail_kernel: the fused Riccati kernel is the one launched (its producer waves
+  //! take over the records' NaN verdict), no line search between step length and update, not switched off (FmpcBuffers::fuse_tail)
+  bool (*tail_applies)(const FmpcBuffers & buf);
   hipError_t (*launch_line_search)(const FmpcBuffers & buf, int iter, hipStream_t stream);
   hipError_t (*launch_plant)(const FmpcBuffers & buf,
                              double * x_plant,
@@ -166,6 +172,24 @@ struct FmpcOpsOf
       hipLaunchKernelGGL(fmpc_delta_kernel<Problem>, dim3(blocks(static_cast<size_t>(buf.B) * (buf.T + 1), 256)), dim3(256), 0,
                          stream, buf);
       return hipGetLastError();
+    };
+    o.tail_applies = [](const FmpcBuffers & buf) {
+      if constexpr(N <= 4 && M == 1)
+      {
+        return buf.fuse_tail != 0 && !buf.enable_line_search && fmpc::tailFits(buf) && fmpcUseQuadRiccati(N, M, buf.B, buf.riccati_force)
+               && fmpcUseFusedRiccati(buf.B, buf.riccati_force);
+      }
+      return false;
+    };
+    o.launch_tail = [](const FmpcBuffers & buf, int iter, int last, hipStream_t stream) {
+      if constexpr(N <= 4 && M == 1)
+      {
+        const unsigned dot_bytes = fmpc::tailDotBytes(buf.T);
+        hipLaunchKernelGGL(fmpc_tail_kernel<Problem>, dim3(blocks(buf.B, 16)), dim3(16 * fmpc::tailSlices(buf.T)), dot_bytes, stream, buf,
+                           iter, last, dot_bytes != 0 ? 1 : 0);
+        return hipGetLastError();
+      }
+      return hipErrorNotSupported;
     };
     o.launch_line_search = [](const FmpcBuffers & buf, int iter, hipStream_t stream) {
       hipLaunchKernelGGL(fmpc_line_search_kernel<Problem>, dim3(blocks(buf.B, 64)), dim3(64), 0, stream, buf, iter);

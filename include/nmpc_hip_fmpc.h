@@ -107,7 +107,10 @@ extern "C"
     NMPC_HIP_FMPC_FIELD_DELTA_LAMBDA = 15,
     NMPC_HIP_FMPC_FIELD_DELTA_S = 16,
     NMPC_HIP_FMPC_FIELD_DELTA_NU = 17,
-    NMPC_HIP_FMPC_FIELD_MERIT = 18 /* [B][3]: merit_func_, merit_deriv_, merit_const_scale_ of the last line search (:417-423) */
+    NMPC_HIP_FMPC_FIELD_MERIT = 18, /* [B][3]: merit_func_, merit_deriv_, merit_const_scale_ of the last line search (:417-423) */
+    NMPC_HIP_FMPC_FIELD_PARTIALS = 19 /* diagnostic, [B][T+1][4]: per-timestep terms of the horizon reductions as the last kernels left
+                                         them — KKT-error terms (calcKktError, :493-521), the two fraction-to-boundary candidates
+                                         (:713-731), s . nu (:376-380) */
   } nmpc_hip_fmpc_field;
 
   typedef struct nmpc_hip_fmpc_solver * nmpc_hip_fmpc_handle;
@@ -179,7 +182,9 @@ extern "C"
     NMPC_HIP_FMPC_KERNEL_DELTA = 3,
     NMPC_HIP_FMPC_KERNEL_STEP_LENGTH = 4,
     NMPC_HIP_FMPC_KERNEL_LINE_SEARCH = 5,
-    NMPC_HIP_FMPC_KERNEL_UPDATE = 6,
+    NMPC_HIP_FMPC_KERNEL_UPDATE = 6, /* fmpc_update_kernel; or fmpc_tail_kernel, which does step length + update of an iteration and the
+                                        barrier parameter + KKT-error terms of the next in one launch (fused-Riccati sequence without
+                                        line search: classes 0, 1 and 4 then count the first iteration's launches only) */
     NMPC_HIP_FMPC_KERNEL_OTHER = 7, /* begin / init / check / finish */
     NMPC_HIP_FMPC_NKERNELS = 8
   } nmpc_hip_fmpc_kernel_class;

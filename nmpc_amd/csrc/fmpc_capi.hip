@@ -266,14 +266,25 @@ int enqueueSolve(nmpc_hip_fmpc_solver * h, hipStream_t stream)
   FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_OTHER,
              hipLaunchKernelGGL(nmpc_amd::hip::fmpc_check_variable_kernel, dim3(blocks(static_cast<size_t>(buf.B) * buf.T, 256)),
                                 dim3(256), 0, stream, buf));
+  // With the fused Riccati kernel and no line search an iteration is three launches: fmpc_tail_kernel closes it (step length, update)
+  // and opens the next one (barrier parameter, KKT-error terms, terminal record); the first iteration is opened by the two kernels below.
+  const bool tail = ops->tail_applies(buf);
   for(int iter = 1; iter <= h->cfg.max_iter; iter++)
   {
-    FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_BARRIER,
-               hipLaunchKernelGGL(nmpc_amd::hip::fmpc_barrier_kernel, dim3(nb), dim3(64 * nmpc_amd::hip::fmpc::kSlices), 0, stream, buf,
-                                  iter));
-    FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_COEFF, FMPC_TRY(ops->launch_coeff(buf, stream)));
+    if(iter == 1 || !tail)
+    {
+      FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_BARRIER,
+                 hipLaunchKernelGGL(nmpc_amd::hip::fmpc_barrier_kernel, dim3(nb), dim3(64 * nmpc_amd::hip::fmpc::kSlices), 0, stream, buf,
+                                    iter));
+      FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_COEFF, FMPC_TRY(ops->launch_coeff(buf, stream)));
+    }
     FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_RICCATI, FMPC_TRY(ops->launch_riccati(buf, iter, stream)));
     FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_DELTA, FMPC_TRY(ops->launch_delta(buf, stream)));
+    if(tail)
+    {
+      FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_UPDATE, FMPC_TRY(ops->launch_tail(buf, iter, iter == h->cfg.max_iter ? 1 : 0, stream)));
+      continue;
+    }
     FMPC_TIMED(h, stream, NMPC_HIP_FMPC_KERNEL_STEP_LENGTH,
                hipLaunchKernelGGL(nmpc_amd::hip::fmpc_step_length_kernel, dim3(nb), dim3(64 * nmpc_amd::hip::fmpc::kSlices), 0, stream,
                                   buf, iter));
@@ -352,6 +363,7 @@ int fieldInfo(nmpc_hip_fmpc_solver * h, int field, FieldInfo * fi)
     case NMPC_HIP_FMPC_FIELD_GAIN_S: *fi = {nullptr, T + 1, N, h->ops->gain_offset_s}; break;
     case NMPC_HIP_FMPC_FIELD_GAIN_P: *fi = {nullptr, T + 1, N * N, h->ops->gain_offset_P}; break;
     case NMPC_HIP_FMPC_FIELD_MERIT: *fi = {b.merit, 1, 3}; break;
+    case NMPC_HIP_FMPC_FIELD_PARTIALS: *fi = {b.part, T + 1, nmpc_amd::hip::fmpc::kPartSlots}; break;
     case NMPC_HIP_FMPC_FIELD_BARRIER_EPS: *fi = {b.barrier_eps, 1, 1}; break;
     case NMPC_HIP_FMPC_FIELD_TRACE: // already [B][..]; rows and stride of the solve that wrote it
       *fi = {h->solved ? h->solved_trace : b.trace, h->solved ? h->solved_max_iter : h->cfg.max_iter, NMPC_HIP_FMPC_NTRACE};
@@ -595,6 +607,10 @@ extern "C"
     b.coef_stride = m->coef_stride;
     b.gain_stride = m->gain_stride;
     b.riccati_force = nmpc_amd::hip::fmpcRiccatiForceFromEnvironment(); // (developer override, read once per handle)
+    {
+      const char * tail_env = getenv("NMPC_HIP_FMPC_TAIL"); // (developer override, read once per handle: 0 = the separate kernels)
+      b.fuse_tail = (tail_env && tail_env[0] == '0') ? 0 : 1;
+    }
     const size_t B = batch, T = horizon_steps, N = b.N, M = b.M, G = b.G;
     int rc = NMPC_HIP_OK;
     auto A = [&](double ** p, size_t count) {
@@ -927,7 +943,7 @@ extern "C"
       FMPC_TRY(hipStreamSynchronize(h->stream));
       return NMPC_HIP_OK;
     }
-    if(field == NMPC_HIP_FMPC_FIELD_TRACE || (fi.steps == 1 && fi.E == 1))
+    if(field == NMPC_HIP_FMPC_FIELD_TRACE || (fi.steps == 1 && fi.E == 1 && fi.gain_offset < 0))
     {
       FMPC_TRY(hipMemcpyAsync(out, fi.dev, bytes, kind, h->stream)); // already instance-major
       FMPC_TRY(hipStreamSynchronize(h->stream));
@@ -1154,8 +1170,11 @@ extern "C"
                       + (nmpc_amd::hip::fmpcUseQuadRiccati(h->buf.N, h->buf.M, h->buf.B, h->buf.riccati_force)
                              ? (nmpc_amd::hip::fmpcUseFusedRiccati(h->buf.B, h->buf.riccati_force) ? "fmpc_riccati_fused_kernel" : "fmpc_riccati_quad_kernel")
                              : "fmpc_riccati_kernel")
-                      + ",fmpc_delta_kernel,fmpc_step_length_kernel," + (h->cfg.enable_line_search ? "fmpc_line_search_kernel," : "")
-                      + "fmpc_update_kernel";
+                      + ",fmpc_delta_kernel,"
+                      + (h->ops->tail_applies(h->buf)
+                             ? std::string("fmpc_tail_kernel")
+                             : std::string("fmpc_step_length_kernel,") + (h->cfg.enable_line_search ? "fmpc_line_search_kernel," : "")
+                                   + "fmpc_update_kernel");
     *names = h->kernel_names.c_str();
     return NMPC_HIP_OK;
   }

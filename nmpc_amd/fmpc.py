@@ -20,7 +20,7 @@ NTRACE = 6
 TRACE_COLUMNS = ("iter", "kkt_error", "barrier_eps", "alpha_s_max", "alpha_nu_max", "alpha_s")
 (FIELD_X, FIELD_U, FIELD_LAMBDA, FIELD_S, FIELD_NU, FIELD_STATUS, FIELD_ITERS, FIELD_TRACE, FIELD_GAIN_K, FIELD_GAIN_k,
  FIELD_GAIN_S, FIELD_GAIN_P, FIELD_BARRIER_EPS, FIELD_DELTA_X, FIELD_DELTA_U, FIELD_DELTA_LAMBDA, FIELD_DELTA_S, FIELD_DELTA_NU,
- FIELD_MERIT) = range(19)
+ FIELD_MERIT, FIELD_PARTIALS) = range(20)
 STATUS_INVALID_VARIABLE = -2
 
 
@@ -378,6 +378,11 @@ class FmpcSolverBatch:
     def meritFunc(self) -> np.ndarray:
         """[B][3]: merit_func_, merit_deriv_, merit_const_scale_ of the last line search (FmpcSolver.h:417-423)."""
         return self._get(FIELD_MERIT, (self.batch, 3))
+
+    def partials(self) -> np.ndarray:
+        """Diagnostic: [B][T+1][4] per-timestep terms of the horizon reductions as the last kernels left them (KKT-error terms,
+        alpha_s / alpha_nu candidates, s . nu)."""
+        return self._get(FIELD_PARTIALS, (self.batch, self._config.horizon_steps + 1, 4))
 
     def traceDataList(self) -> np.ndarray:
         """traceDataList() (FmpcSolver.h:298-301): [B][max_iter][NTRACE] (TRACE_COLUMNS); rows beyond iters() are zero."""

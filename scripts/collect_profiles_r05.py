@@ -106,7 +106,7 @@ if os.path.exists(stats):
         f.write("each counter set collected in its own run; SQ_* cycle counters in quad-cycles summed over the waves of a launch\n\n")
         f.write("%-28s %9s %11s %11s %8s %9s %9s %9s\n" % ("kernel", "avg_us", "fetch_MB", "write_MB", "L2_hit", "GB/s", "VALU_act", "waitcnt"))
         for short in ("fmpc_barrier_kernel", "fmpc_coeff_kernel", "fmpc_riccati_fused_kernel", "fmpc_riccati_quad_kernel", "fmpc_riccati_kernel", "fmpc_delta_kernel",
-                      "fmpc_step_length_kernel", "fmpc_update_kernel", "fmpc_transpose_kernel"):
+                      "fmpc_step_length_kernel", "fmpc_update_kernel", "fmpc_tail_kernel", "fmpc_transpose_kernel"):
             pm, cnt = means("pmc?_fmpc_counter_collection.csv", short)
             if not pm:
                 continue

@@ -35,6 +35,13 @@ print(f"B={B} T={T} max_iter={max_iter} model={model}: solve {np.mean(ms[1:]):.3
 if os.environ.get("NMPC_AMD_EXTRA_HIPCC_FLAGS", "").find("NMPC_AMD_FMPC_PROFILE") >= 0:
     m = s.meritFunc()
     print(f"riccati kernel, 100 MHz ticks: backward {m[:, 0].mean() / 100:.1f} us, forward {m[:, 1].mean() / 100:.1f} us")
+if os.environ.get("FMPC_TAIL_PROFILE"):
+    m = s.meritFunc()
+    print("tail kernel (last but one iteration), us: reductions %.1f, walk of slice 0 %.1f, wait for the slowest slice %.1f"
+          % (m[:, 0].mean() / 100, m[:, 1].mean() / 100, m[:, 2].mean() / 100))
+    tot = m.sum(axis=1) / 100
+    print("  per workgroup (sum of the three): min %.1f  median %.1f  max %.1f;  walk min %.1f max %.1f;  reductions min %.1f max %.1f"
+          % (tot.min(), np.median(tot), tot.max(), m[:, 1].min() / 100, m[:, 1].max() / 100, m[:, 0].min() / 100, m[:, 0].max() / 100))
 if os.environ.get("FMPC_PROFILE2"):
     tr = s.traceDataList()
     m = s.meritFunc()

@@ -345,9 +345,71 @@ def test_full_size_batch_properties():
     s.config().time_kernels = True
     s.solve(0.0, x0, var)
     d = s.computationDuration()
-    assert d.launches["riccati"] == 8 and d.launches["coeff"] == 8 and d.launches["line_search"] == 0
+    # (fused-Riccati sequence: fmpc_tail_kernel closes an iteration and opens the next, barrier + KKT kernels run for the first only)
+    tail = "fmpc_tail_kernel" in s.kernelNames()
+    assert d.launches["riccati"] == 8 and d.launches["coeff"] == (1 if tail else 8) and d.launches["line_search"] == 0
+    assert d.launches["update"] == 8 and d.launches["step_length"] == (0 if tail else 8) and d.launches["barrier"] == (1 if tail else 8)
     assert 0 < d.backward < d.solve and d.coeff > 0 and d.update > 0
     assert abs(sum(d.kernels.values()) - d.solve) < 0.5 * d.solve
+
+
+def _solve_outputs(model, B, T, max_iter, tail, poison, line_search=False):
+    import os
+    os.environ["NMPC_HIP_FMPC_TAIL"] = "1" if tail else "0"  # read when the handle is created
+    try:
+        prob = {"fmpc_cartpole": F.FmpcProblemCartPole, "fmpc_oscillator": F.FmpcProblemOscillator}[model](0.01)
+        rng = np.random.default_rng(B * 1000 + T)
+        n = prob.state_dim
+        x0 = np.zeros((B, n))
+        x0[:, 0] = rng.uniform(-1, 1, B)
+        x0[:, 1] = rng.uniform(-0.3, 0.3, B) + (np.pi if n == 4 and T % 2 else 0.0)
+        if poison:  # the error paths: NaN in the state (ErrorInBackward / Forward), a huge one
+            x0[::7, 0] = np.nan
+            x0[3::11, 1] = 1e200
+        s = F.FmpcSolverBatch(prob, B, T)
+        s.config().max_iter = max_iter
+        s.config().enable_line_search = line_search
+        var = F.Variable.make(prob, T, B)
+        var.reset(0.0, 0.0, 0.0, 1.0, 1.0)
+        try:
+            s.solve(0.0, x0, var)
+        except RuntimeError:
+            pass
+        out = dict(zip(("x", "u", "lambda", "s", "nu"), s.variable().arrays()))
+        out.update(zip(("dx", "du", "dlambda", "ds", "dnu"), s.deltaVariable().arrays()))
+        out.update(status=s.status(), iters=s.iters(), barrier_eps=s.barrierEps(), trace=s.traceDataList(), partials=s.partials())
+        out.update(("gain_" + k, v) for k, v in s.coeffList().items())
+        return out, s.kernelNames()
+    finally:
+        os.environ.pop("NMPC_HIP_FMPC_TAIL", None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,B,T,max_iter", [("fmpc_cartpole", 1024, 200, 6), ("fmpc_cartpole", 1000, 37, 8), ("fmpc_cartpole", 17, 5, 3),
+                                                ("fmpc_cartpole", 100, 1, 2), ("fmpc_cartpole", 256, 130, 1), ("fmpc_cartpole", 512, 200, 40),
+                                                ("fmpc_oscillator", 2048, 100, 10), ("fmpc_oscillator", 333, 64, 4)])
+@pytest.mark.parametrize("poison", [False, True])
+def test_tail_kernel_returns_the_bits_of_the_separate_kernels(model, B, T, max_iter, poison):
+    """fmpc_tail_kernel (step length + update of iteration k, barrier parameter + KKT-error terms + terminal record of iteration k + 1
+    in one launch; FmpcSolver.hpp:370-392, :429-436, :493-521, :713-742, :801-835) against the kernel-per-step sequence
+    (NMPC_HIP_FMPC_TAIL=0): every output of the solve, the trace, the gains and the per-timestep partial sums are bit-equal — also for
+    instances that leave through an error status or converge early, ragged batch sizes, T = 1 and a single iteration."""
+    a, names_a = _solve_outputs(model, B, T, max_iter, False, poison)
+    b, names_b = _solve_outputs(model, B, T, max_iter, True, poison)
+    assert "fmpc_tail_kernel" in names_b and "fmpc_tail_kernel" not in names_a and "fmpc_update_kernel" in names_a
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True) and a[k].tobytes() == b[k].tobytes(), k
+    if poison:
+        assert len(np.unique(b["status"])) >= 2
+    if max_iter == 40 and not poison:
+        assert (b["status"] == 1).sum() > 0.9 * B and b["iters"].max() > b["iters"].min()  # converged, after different numbers of iterations
+
+
+@pytest.mark.gpu
+def test_tail_kernel_is_not_used_with_the_line_search():
+    """The line search sits between step length and update (FmpcSolver.hpp:748-792): those solves keep the kernel-per-step sequence."""
+    _, names = _solve_outputs("fmpc_cartpole", 64, 50, 3, True, False, line_search=True)
+    assert "fmpc_tail_kernel" not in names and "fmpc_line_search_kernel" in names
 
 
 def test_cpp_mirror_runs_the_reference_oscillator_loop(tmp_path):

@@ -36,7 +36,7 @@ constexpr int kQuadWaves = 4;
 /** \tparam kFanOut step-size-parallel line search: the four lane groups of 16 — mirrors of one another otherwise — try four
     step sizes of alpha_list per forward pass, from the first pass on (at most 3 passes instead of 11).  Group 0 stores its
     rollout into the candidate half, groups 1 - 3 into the handle's fan-out scratch, and the rollout of the accepted step
-    size is copied from there by the whole workgroup (PairSolver::adoptFanOut: ~2 k cycles instead of another pass).
+    size is copied from there by the whole workgroup (PairSolver::adoptFanOut instead of another pass).
     Box-constrained solves backtrack often (cart-pole with a +-15 N box: ~3 trials per iteration) and always use it.
     Unconstrained solves have both instantiations; Configuration::line_search_fan_out = 0 picks this one (nominal bench:
     +4 %, the few instances whose first step size fails no longer cost their workgroup a pass each; M1: 2.4 x), 2 the

@@ -2148,10 +2148,26 @@ __global__ void __launch_bounds__(256) fmpc_riccati_quad_kernel(FmpcBuffers buf,
   // ---- KKT-error test (FmpcSolver.hpp:443-449): sixteen partial sums per instance (timesteps t_slot, t_slot + 16, ...; every
   // 16-lane group reads one full line per row), added up by the head lane in slot order
   {
+    // (eight terms requested before the first is added, the additions in the loop's order: one term per trip was a round trip to
+    // L2 per term, thirteen in a row in front of the recursion for T = 200)
     double acc = 0;
-    for(int i = t_slot; i <= T; i += 16)
+    for(int i0 = t_slot; i0 <= T; i0 += 16 * 8)
     {
-      acc += buf.part[fmpc::at(buf, i, 0, fmpc::kPartSlots, b_stage)];
+      double term[8];
+      NMPC_UNROLL
+      for(int k = 0; k < 8; k++)
+      {
+        const int i = i0 + 16 * k;
+        term[k] = buf.part[fmpc::at(buf, i <= T ? i : T, 0, fmpc::kPartSlots, b_stage)];
+      }
+      NMPC_UNROLL
+      for(int k = 0; k < 8; k++)
+      {
+        if(i0 + 16 * k <= T)
+        {
+          acc += term[k];
+        }
+      }
     }
     sh_kkt[t_inst][t_slot] = acc;
   }
@@ -2635,10 +2651,26 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
   // 16-lane group reads one full line per row), added up by the head lane in slot order
   if(!producer)
   {
+    // (eight terms requested before the first is added, the additions in the loop's order: one term per trip was a round trip to
+    // L2 per term, thirteen in a row in front of the recursion for T = 200)
     double acc = 0;
-    for(int i = t_slot; i <= T; i += 16)
+    for(int i0 = t_slot; i0 <= T; i0 += 16 * 8)
     {
-      acc += buf.part[fmpc::at(buf, i, 0, fmpc::kPartSlots, b_stage)];
+      double term[8];
+      NMPC_UNROLL
+      for(int k = 0; k < 8; k++)
+      {
+        const int i = i0 + 16 * k;
+        term[k] = buf.part[fmpc::at(buf, i <= T ? i : T, 0, fmpc::kPartSlots, b_stage)];
+      }
+      NMPC_UNROLL
+      for(int k = 0; k < 8; k++)
+      {
+        if(i0 + 16 * k <= T)
+        {
+          acc += term[k];
+        }
+      }
     }
     sh_kkt[t_inst][t_slot] = acc;
   }

@@ -1,8 +1,8 @@
-"""A/B of library builds on one GPU box for a bench workload: python scripts/ab_workload.py <c4|c4f64|c5|centroidal|c3> <lib|main> ...
+"""A/B of library builds on one GPU box for a bench workload: python scripts/ab_workload.py <c2|c2m2|c4|c4f64|c5|centroidal|c3> <lib|main> ...
 (one process per library and repetition, interleaved; kernel ms by HIP events, backward / forward split)."""
 import os, subprocess, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-W = {"c4": ("quadrotor_batch", dict(fp32=True), 8192, 50, 1e-3), "c4f64": ("quadrotor_batch", {}, 8192, 50, None), "c5": ("manipulator_batch", {}, 8192, 30, None),
+W = {"c2": ("cartpole_batch", {}, 4096, 100, None), "c2m2": ("cartpole_batch", {}, 4096, 100, "m2"), "c4": ("quadrotor_batch", dict(fp32=True), 8192, 50, 1e-3), "c4f64": ("quadrotor_batch", {}, 8192, 50, None), "c5": ("manipulator_batch", {}, 8192, 30, None),
      "centroidal": ("centroidal_batch", {}, 4096, 100, None), "c3": ("bipedal_batch", {}, 1024, 300, None)}
 if sys.argv[1] == "--worker":
     sys.path.insert(0, ROOT)
@@ -12,7 +12,9 @@ if sys.argv[1] == "--worker":
     wl = getattr(workloads, gen)(B=B, T=T, seed=1234, **kw)
     s = nmpc_amd.DDPSolverBatch(nmpc_amd.make_problem(wl.model), wl.B)
     c = s.config(); c.print_level, c.horizon_steps, c.max_iter = 0, wl.T, 8
-    if thre is not None:
+    if thre == "m2":  # the reference's default Configuration: to convergence, max_iter 500
+        c.max_iter = 500
+    elif thre is not None:
         c.cost_update_thre = thre
     ms, bw, fw = [], [], []
     for _ in range(10):

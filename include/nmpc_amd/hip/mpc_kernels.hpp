@@ -41,6 +41,34 @@ struct HasPlantStep<Problem,
 {
 };
 
+/** Rows 0 ... n - 1 of one lane's column (stride kLanesPerBlock) from src to dst, sixteen rows requested before the first is stored —
+    as `dst[r] = src[r]` per trip the copy was a round trip to L2 per row, T of them in a row per tick (the store may alias the next
+    load as far as the compiler knows).  dst may be the column src starts MM rows into (the in-place shift of the warm start): every
+    row is read before a batch that reaches it is stored, ascending. */
+template<class S>
+__device__ __forceinline__ void copyColumn(S * dst, const S * src, size_t n)
+{
+  constexpr size_t LW = kLanesPerBlock;
+  constexpr int kBatch = 16;
+  for(size_t r0 = 0; r0 < n; r0 += kBatch)
+  {
+    S v[kBatch];
+#pragma unroll
+    for(int k = 0; k < kBatch; k++)
+    {
+      v[k] = src[(r0 + k < n ? r0 + k : n - 1) * LW];
+    }
+#pragma unroll
+    for(int k = 0; k < kBatch; k++)
+    {
+      if(r0 + k < n)
+      {
+        dst[(r0 + k) * LW] = v[k];
+      }
+    }
+  }
+}
+
 /** \tparam S element type of the handle's arrays = Problem::Scalar (the logs are double whatever it is: the C-ABI side) */
 template<class Problem, class S = typename Problem::Scalar>
 __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Problem shared_problem,
@@ -135,13 +163,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
     }
     // erase(begin()); push_back(back()) — or a zero vector when the terminal input dimension differs.  When sel == 0
     // source and destination are the same column: row i + 1 is read before row i is written, ascending i.
-    for(int i = 0; i + 1 < T; i++)
-    {
-      for(int a = 0; a < MM; a++)
-      {
-        U0[(static_cast<size_t>(i) * MM + a) * LW] = Us[(static_cast<size_t>(i + 1) * MM + a) * LW];
-      }
-    }
+    copyColumn(U0, Us + static_cast<size_t>(MM) * LW, static_cast<size_t>(T - 1) * MM);
     int last_m = MM, term_m = MM;
     if constexpr(Problem::kDynamicInput)
     {
@@ -171,10 +193,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void mpc_advance_kernel(const Probl
     }
     if(sel != 0)
     {
-      for(size_t r = 0; r < rows_u; r++)
-      {
-        U0[r * LW] = Us[r * LW];
-      }
+      copyColumn(U0, Us, rows_u);
     }
   }
   static_cast<S *>(args.t0)[b] = static_cast<S>(t_next);

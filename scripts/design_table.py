@@ -22,7 +22,7 @@ extra = (f" (M1 {c['m1_value'] / 1e3:.1f} k, CPU {c['m1'].get('cpu_value', 0):.0
 print(row("**c2** cart-pole 4096 × T 100 fp64 (BASELINE metric)", "quad", f"**{d['value'] / 1e3:.1f} k**", d["roofline"], extra))
 names = {"c3": ("c3 bipedal 1024 × T 300", "quad"), "c4": ("c4 quadrotor 8192 × T 50 fp32, thre 1e-3", "tile64<float>, twelve waves"),
          "c4f64": ("c4f64 quadrotor fp64", "tile64"), "c5": ("c5 manipulator 8192 × T 30", "tile64"), "centroidal": ("centroidal 4096 × T 100", "tile64, batched gains"),
-         "fmpc": ("fmpc cart-pole 4096 × T 200 × 5", "fused Riccati (+ 5 small kernels per iteration)")}
+         "fmpc": ("fmpc cart-pole 4096 × T 200 × 5", "fused Riccati, delta, tail (three launches per iteration)")}
 for k, (nm, kern) in names.items():
     v = d["secondary"][k]
     r = dict(v["roofline"])

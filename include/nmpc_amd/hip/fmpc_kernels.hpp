@@ -2608,9 +2608,9 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
   static_assert(kF * 16 * kRecF <= kFwdSlotDoubles, "[FMPC] a forward chunk fits half of the staging area");
   constexpr int kRecG = (GL::kStride + 2) | 1; // gain record + two spare slots
   constexpr int kRecX = (N + M + 2) | 1; // dx, du + two spare slots
-  static_assert(kF * kRecX <= kS * kRecG, "[FMPC] dx, du of a forward chunk fit the area the gains of a backward chunk are parked in");
   __shared__ double stage_lds[3 * kSlotDoubles]; // chunk k of the backward pass in slot k % 3 (the forward pass uses two)
-  __shared__ double gain_lds[kS * 16 * kRecG]; // what the chunk's steps produce (backward: gains, forward: dx, du), before it goes to HBM
+  constexpr int kGainLds = kS * 16 * kRecG > 2 * kF * 16 * kRecX ? kS * 16 * kRecG : 2 * kF * 16 * kRecX;
+  __shared__ double gain_lds[kGainLds]; // what a chunk's steps produce (backward: gains; forward: dx, du, two areas used alternately), before it goes to HBM
   __shared__ double sh_kkt[16][17];
   __shared__ int sh_live[16];
   __shared__ int sh_coef_nan[16]; // a record of the instance holds a NaN / Inf (the producer waves' finding)
@@ -2720,43 +2720,6 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
   // every 16-lane group reads one whole line), parked in registers while the previous chunk is being consumed, written to LDS
   // as per-(timestep, instance) records and read from there by the lanes that need them.
   /** Elements [0, NR) of timesteps i0, i0 + dir, ..., i0 + (kS - 1) dir of this thread's instance: request into v. */
-  /** ... of the forward pass (dir = +1): every lane loads for every step — a lane without an element of its own the record's last
-      one, a step beyond the horizon the last step — so the requests are straight-line code and the wait in front of a commit can be
-      counted (behind per-lane branches the compiler waited for ALL requests, also the ones for two chunks ahead). */
-  auto request = [&](auto nr_tag, const double * src, int stride, int i0, int dir, double * v) {
-    constexpr int NR = decltype(nr_tag)::value;
-    constexpr int kQ = (NR + 15) / 16;
-    NMPC_UNROLL
-    for(int st = 0; st < kF; st++)
-    {
-      const int step_raw = i0 + dir * st; // wavefront-uniform
-      const int step = step_raw < 0 ? 0 : (step_raw < T ? step_raw : T - 1);
-      NMPC_UNROLL
-      for(int q = 0; q < kQ; q++)
-      {
-        const int e = (16 * q + 15 < NR || t_slot < NR - 16 * q) ? 16 * q + t_slot : NR - 1;
-        v[st * kQ + q] = src[(static_cast<size_t>(step) * stride + e) * Bz + b_stage];
-      }
-    }
-  };
-  /** ... and park them in forward-pass LDS slot `slot` as records of width W, at offset `off` of each record. */
-  auto commit = [&](auto nr_tag, int slot, int W, int off, const double * v) {
-    constexpr int NR = decltype(nr_tag)::value;
-    constexpr int kQ = (NR + 15) / 16;
-    double * base = stage_lds + static_cast<size_t>(slot) * kFwdSlotDoubles + t_inst * W + off + t_slot;
-    NMPC_UNROLL
-    for(int st = 0; st < kF; st++)
-    {
-      NMPC_UNROLL
-      for(int q = 0; q < kQ; q++)
-      {
-        if(16 * q + 15 < NR || t_slot < NR - 16 * q)
-        {
-          base[st * 16 * W + 16 * q] = v[st * kQ + q];
-        }
-      }
-    }
-  };
   using TagB = std::integral_constant<int, CL::kStride>;
   using TagFc = std::integral_constant<int, kFwdCoef>;
   using TagFg = std::integral_constant<int, kFwdGain>;
@@ -2981,71 +2944,112 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
     o.Bv = rv ? bv : 0.0;
     o.xb = rv ? xb : 0.0;
   };
-  auto forwardStep = [&](int st, const ForwardOperands & o) {
+  auto forwardStep = [&](int st, const ForwardOperands & o, int park) {
     const double Y = c0 ? dx_row : 0.0;
     const double ax = bcast0(mma(o.AT, Y, 0.0)); // (A dx)[row]
     const double du = bcast0(mma(o.Kx, Y, 0.0)) + o.k; // (2.36), the same in every row
-    fP[st * 16 * kRecX] = role_du ? du : dx_row;
+    fP[park + st * 16 * kRecX] = role_du ? du : dx_row;
     const double nx = (ax + o.Bv * du) + o.xb; // (2.26b)
     dx_row = rv ? nx : 0.0;
   };
   {
-    // Operands of a chunk are requested TWO chunks ahead (two register sets, used alternately: the chunk loop is unrolled by two):
-    // a chunk of four steps is ~0.5 us of arithmetic and barriers, a request one chunk ahead came back after ~1.6 us — the forward
-    // pass was 50 round trips to HBM in a row [measured, profile build: 79 us of the launch's 233].
-    constexpr int kQC = (kFwdCoef + 15) / 16, kQG = (kFwdGain + 15) / 16;
-    double vcA[kF * kQC], vgA[kF * kQG], vcB[kF * kQC], vgB[kF * kQG];
-    // The two kinds of wavefront run SEPARATE loops with the same barriers.  dx, du of a chunk go from LDS to HBM (whole lines) by
-    // the producer waves, idle in this pass: a recursion wave then has loads only in flight, and its wait for the operands
-    // requested two chunks ago can leave the later requests pending — with stores of its own among them a wave has to wait for
-    // everything (loads and stores share a counter and complete out of order with respect to each other), and so it does if the
-    // stores merely sit on another path of the same loop.
+    // The forward pass, one workgroup barrier per chunk of kF steps.  The PRODUCER waves (idle in this pass) stage the operands: a
+    // chunk's A, B, x_bar, k, K go from HBM through registers into one of two LDS slots, requested two chunks before the recursion
+    // waves read them and parked while those compute the chunk in front; the recursion waves do the recursion and send dx, du of the
+    // chunk before — parked in LDS, two areas used alternately — to HBM in whole lines.  How it got here: (1) requests one chunk
+    // ahead, issued and parked by the recursion waves, were a round trip to HBM per chunk of four steps [profile build: 79 us of the
+    // launch's 233]; (2) requesting further ahead only pays if the wait in front of the parking is COUNTED (s_waitcnt vmcnt(N)),
+    // which needs a wave that has loads only in flight — loads and stores share the counter and complete out of order with respect
+    // to each other, one pending store makes every wait vmcnt(0), also when the stores sit on another path of the same loop — no
+    // per-lane branches around the requests (every lane loads for every step; one without an element of its own loads the record's
+    // last), and a set requested right behind the parking of its predecessor (across the loop's back edge the compiler still counts
+    // short and waits for the first request of the newest set: by then it is a chunk old) [62 us]; (3) then the recursion waves were
+    // bound by their ~90 instructions per step, 20 of them the recursion: staging moved to the producers.
+    constexpr int kQC = (kFwdCoef + 7) / 8, kQG = (kFwdGain + 7) / 8; // elements per staging thread (eight element slots x sixteen instances)
+    constexpr int kPark = kF * 16 * kRecX;
+    static_assert(2 * kPark <= kGainLds, "[FMPC] two parking areas for dx, du");
     if(producer)
     {
-      const int f_slot = t_slot - 16; // waves 4, 5: element slot 0 ... 7 of instance t_inst
-      syncThreadsFuzzed(__LINE__);
-      for(int i0 = 0; i0 < T; i0 += kF)
-      {
-        syncThreadsFuzzed(__LINE__); // the chunk's dx, du are in LDS
-        if(sh_live[t_inst] != 0 && f_slot < N + M)
+      // (Measured and not kept: each producer wave staging every OTHER chunk alone, one chunk in flight per wave — what a wave waits
+      // for is then two chunks old, but parking + requesting a whole chunk is ~650 instructions of one wave inside one chunk's time:
+      // 65 us against 53.)
+      const int s_slot = t_slot - 16; // waves 4, 5: element slot 0 ... 7 of instance t_inst
+      /** Elements s_slot, s_slot + 8, ... of steps i0 ... i0 + kF - 1 of this thread's instance: request (straight-line: a step
+          beyond the horizon is the last step again, a lane without an element of its own re-reads the record's last one). */
+      auto request = [&](auto nr_tag, const double * src, int stride, int i0, double * v) {
+        constexpr int NR = decltype(nr_tag)::value;
+        constexpr int kQ = (NR + 7) / 8;
+        NMPC_UNROLL
+        for(int st = 0; st < kF; st++)
+        {
+          const int step = i0 + st < T ? i0 + st : T - 1; // wavefront-uniform
+          NMPC_UNROLL
+          for(int q = 0; q < kQ; q++)
+          {
+            const int e = (8 * q + 7 < NR || s_slot < NR - 8 * q) ? 8 * q + s_slot : NR - 1;
+            v[st * kQ + q] = src[(static_cast<size_t>(step) * stride + e) * Bz + b_stage];
+          }
+        }
+      };
+      /** ... and park them in forward-pass slot `slot` as records of width kRecF, at offset `off` of each record. */
+      auto commit = [&](auto nr_tag, int slot, int off, const double * v) {
+        constexpr int NR = decltype(nr_tag)::value;
+        constexpr int kQ = (NR + 7) / 8;
+        double * base = stage_lds + static_cast<size_t>(slot) * kFwdSlotDoubles + t_inst * kRecF + off + s_slot;
+        NMPC_UNROLL
+        for(int st = 0; st < kF; st++)
         {
           NMPC_UNROLL
-          for(int st = 0; st < kF; st++)
+          for(int q = 0; q < kQ; q++)
           {
-            const int step = i0 + st;
-            if(step < T)
+            if(8 * q + 7 < NR || s_slot < NR - 8 * q)
             {
-              const double v = gain_lds[(st * 16 + t_inst) * kRecX + f_slot];
-              if(f_slot < N)
-              {
-                buf.dx[(static_cast<size_t>(step) * N + f_slot) * Bz + b_stage] = v;
-              }
-              else
-              {
-                buf.du[(static_cast<size_t>(step) * M + (f_slot - N)) * Bz + b_stage] = v;
-              }
+              base[st * 16 * kRecF + 8 * q] = v[st * kQ + q];
             }
           }
         }
+      };
+      double vcA[kF * kQC], vgA[kF * kQG], vcB[kF * kQC], vgB[kF * kQG];
+      request(TagFc(), buf.coef, CL::kStride, 0, vcA);
+      request(TagFg(), buf.gain, GL::kStride, 0, vgA);
+      commit(TagFc(), 0, 0, vcA);
+      commit(TagFg(), 0, kFwdCoef, vgA);
+      request(TagFc(), buf.coef, CL::kStride, kF, vcB);
+      request(TagFg(), buf.gain, GL::kStride, kF, vgB);
+      request(TagFc(), buf.coef, CL::kStride, 2 * kF, vcA);
+      request(TagFg(), buf.gain, GL::kStride, 2 * kF, vgA);
+      syncThreadsFuzzed(__LINE__); // chunk 0 is staged
+      for(int i0 = 0; i0 < T; i0 += 2 * kF)
+      {
+        // while the recursion waves compute chunk i0 from slot 0 (they are done with slot 1 since the barrier before)
+        if(i0 + kF < T)
+        {
+          commit(TagFc(), 1, 0, vcB);
+          commit(TagFg(), 1, kFwdCoef, vgB);
+          request(TagFc(), buf.coef, CL::kStride, i0 + 3 * kF, vcB);
+          request(TagFg(), buf.gain, GL::kStride, i0 + 3 * kF, vgB);
+        }
         syncThreadsFuzzed(__LINE__);
+        if(i0 + kF < T) // (workgroup-uniform) ... chunk i0 + kF from slot 1
+        {
+          if(i0 + 2 * kF < T)
+          {
+            commit(TagFc(), 0, 0, vcA);
+            commit(TagFg(), 0, kFwdCoef, vgA);
+            request(TagFc(), buf.coef, CL::kStride, i0 + 4 * kF, vcA);
+            request(TagFg(), buf.gain, GL::kStride, i0 + 4 * kF, vgA);
+          }
+          syncThreadsFuzzed(__LINE__);
+        }
       }
     }
     else
     {
-      request(TagFc(), buf.coef, CL::kStride, 0, 1, vcA);
-      request(TagFg(), buf.gain, GL::kStride, 0, 1, vgA);
-      commit(TagFc(), 0, kRecF, 0, vcA);
-      commit(TagFg(), 0, kRecF, kFwdCoef, vgA);
-      request(TagFc(), buf.coef, CL::kStride, kF, 1, vcB); // (steps beyond the horizon: the last step again, never parked)
-      request(TagFg(), buf.gain, GL::kStride, kF, 1, vgB);
-      request(TagFc(), buf.coef, CL::kStride, 2 * kF, 1, vcA);
-      request(TagFg(), buf.gain, GL::kStride, 2 * kF, 1, vgA);
-      syncThreadsFuzzed(__LINE__);
-      /** Chunk [i0, i0 + kF) from staging slot `slot`; parks chunk i0 + kF (register set `vc`, `vg`, requested two chunks ago) in the
-          other slot and requests chunk i0 + 3 kF into the set at once: at the next chunk's commit the compiler's wait lets at most
-          eleven requests stay pending, i.e. it also waits for the first of the set requested last — which is then a whole chunk
-          old instead of a chunk's arithmetic. */
-      auto forwardChunk = [&](int i0, int slot, double * vc, double * vg) {
+      syncThreadsFuzzed(__LINE__); // chunk 0 is staged
+      int chunk = 0;
+      for(int i0 = 0; i0 < T; i0 += kF, chunk++)
+      {
+        const int slot = chunk & 1, park = (chunk & 1) * kPark;
         const double * recs = stage_lds + static_cast<size_t>(slot) * kFwdSlotDoubles + inst * kRecF;
         ForwardOperands o[2];
         loadForward(recs, o[0]);
@@ -3058,25 +3062,29 @@ __global__ void __launch_bounds__(384) fmpc_riccati_fused_kernel(FmpcBuffers buf
             {
               loadForward(recs + (st + 1) * 16 * kRecF, o[(st + 1) & 1]);
             }
-            forwardStep(st, o[st & 1]);
+            forwardStep(st, o[st & 1], park);
           }
         }
-        syncThreadsFuzzed(__LINE__);
-        if(i0 + kF < T)
+        syncThreadsFuzzed(__LINE__); // dx, du of the chunk are parked; the next chunk's operands are staged
+        if(sh_live[t_inst] != 0 && t_slot < N + M) // dx, du of the chunk: LDS -> HBM in whole lines (the next chunk parks in the other area)
         {
-          commit(TagFc(), slot ^ 1, kRecF, 0, vc);
-          commit(TagFg(), slot ^ 1, kRecF, kFwdCoef, vg);
-          request(TagFc(), buf.coef, CL::kStride, i0 + 3 * kF, 1, vc);
-          request(TagFg(), buf.gain, GL::kStride, i0 + 3 * kF, 1, vg);
-        }
-        syncThreadsFuzzed(__LINE__);
-      };
-      for(int i0 = 0; i0 < T; i0 += 2 * kF)
-      {
-        forwardChunk(i0, 0, vcB, vgB);
-        if(i0 + kF < T) // (workgroup-uniform)
-        {
-          forwardChunk(i0 + kF, 1, vcA, vgA);
+          NMPC_UNROLL
+          for(int st = 0; st < kF; st++)
+          {
+            const int step = i0 + st;
+            if(step < T)
+            {
+              const double v = gain_lds[park + (st * 16 + t_inst) * kRecX + t_slot];
+              if(t_slot < N)
+              {
+                buf.dx[(static_cast<size_t>(step) * N + t_slot) * Bz + b_stage] = v;
+              }
+              else
+              {
+                buf.du[(static_cast<size_t>(step) * M + (t_slot - N)) * Bz + b_stage] = v;
+              }
+            }
+          }
         }
       }
     }

@@ -29,6 +29,19 @@ def test_library_exports_every_declared_fmpc_symbol():
         assert re.search(rf"\bT {name}\b", nm), name
 
 
+def test_field_and_kernel_class_numbers_match_the_header():
+    """The Python mirror's FIELD_* / KERNEL_CLASSES are the enum values of include/nmpc_hip_fmpc.h, in order."""
+    hdr = open(os.path.join(ROOT, "include", "nmpc_hip_fmpc.h")).read()
+    fields = dict((k, int(v)) for k, v in re.findall(r"NMPC_HIP_FMPC_FIELD_(\w+)\s*=\s*(\d+)", hdr))
+    assert len(fields) == 20 and sorted(fields.values()) == list(range(20))
+    for name, value in fields.items():
+        py = {"LAMBDA": "FIELD_LAMBDA", "GAIN_k": "FIELD_GAIN_k"}.get(name, "FIELD_" + name)
+        assert getattr(F, py) == value, name
+    classes = dict((k.lower(), int(v)) for k, v in re.findall(r"NMPC_HIP_FMPC_KERNEL_(\w+)\s*=\s*(\d+)", hdr))
+    assert [k for k, _ in sorted(classes.items(), key=lambda kv: kv[1])] == list(F.KERNEL_CLASSES)
+    assert int(re.search(r"NMPC_HIP_FMPC_NKERNELS\s*=\s*(\d+)", hdr).group(1)) == len(F.KERNEL_CLASSES)
+
+
 def test_problem_types_match_the_oracle_models():
     assert set(F.model_names()) >= {"fmpc_oscillator", "fmpc_cartpole", "fmpc_pointmass"}
     for model, cls in (("fmpc_oscillator", F.FmpcProblemOscillator), ("fmpc_cartpole", F.FmpcProblemCartPole),

@@ -387,7 +387,8 @@ def _solve_outputs(model, B, T, max_iter, tail, poison, line_search=False):
 @pytest.mark.gpu
 @pytest.mark.parametrize("model,B,T,max_iter", [("fmpc_cartpole", 1024, 200, 6), ("fmpc_cartpole", 1000, 37, 8), ("fmpc_cartpole", 17, 5, 3),
                                                 ("fmpc_cartpole", 100, 1, 2), ("fmpc_cartpole", 256, 130, 1), ("fmpc_cartpole", 512, 200, 40),
-                                                ("fmpc_oscillator", 2048, 100, 10), ("fmpc_oscillator", 333, 64, 4)])
+                                                ("fmpc_oscillator", 2048, 100, 10), ("fmpc_oscillator", 333, 64, 4),
+                                                ("fmpc_cartpole", 48, 400, 4), ("fmpc_oscillator", 40, 777, 3)])  # (T > 384: s . nu terms not in LDS)
 @pytest.mark.parametrize("poison", [False, True])
 def test_tail_kernel_returns_the_bits_of_the_separate_kernels(model, B, T, max_iter, poison):
     """fmpc_tail_kernel (step length + update of iteration k, barrier parameter + KKT-error terms + terminal record of iteration k + 1
